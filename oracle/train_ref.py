@@ -1,0 +1,198 @@
+"""CPU restatement of one G+D training iteration and of the synthetic workload (TEST ORACLE).
+
+Follows (reference paths relative to /root/reference):
+  * train_D                    train.py:398-462   (D.train, G.eval, D(real), G(noise), D(fake),
+                                                   LSGAN  mse(real,1)+mse(fake,0)  :368-370,378)
+  * train_G                    train.py:479-523   (G.train, D stays in train mode, mse(D(G(z)),1) :471-472)
+  * get_gen_noise              train.py:100-141   (Normal(0, sd=0.2) of [B,N,latent])
+  * optimizers                 setup_training.py:1511-1513  (torch.optim.RMSprop defaults)
+  * data layout                train.py:41-67, gen.py:10-17  (eta_rel, phi_rel, pt_rel, mask-0.5)
+
+``train.py`` itself cannot be imported here (needs the ``jetnet`` package), so the step is
+restated from its source text; its pieces (G, D forward) are pinned by the goldens.
+In train_D the reference back-propagates through G as well and throws those gradients
+away at the next ``zero_grad`` (train.py:420,495): the fake batch is detached here, which
+changes no result.
+"""
+
+from __future__ import annotations
+
+import zlib
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import mpgan_ref as M
+from . import gapt_ref as A
+
+Tensor = torch.Tensor
+
+
+# ----------------------------------------------------------------------------- shapes / init
+def mpgan_param_shapes(gen: bool, latent=32, hidden=32, feat=3, fe=(96, 160, 192), fn=(256, 256)):
+    """State-dict manifest of the default MPGenerator / MPDiscriminator."""
+    shapes = {}
+    ins = [latent, hidden] if gen else [feat, hidden]
+    outs = [hidden, feat] if gen else [hidden, hidden]
+    for l in range(2):
+        dims = [2 * ins[l]] + list(fe)
+        for k in range(len(fe)):
+            shapes[f"mp_layers.{l}.fe.net.{k}.weight"] = (dims[k + 1], dims[k])
+            shapes[f"mp_layers.{l}.fe.net.{k}.bias"] = (dims[k + 1],)
+        dims = [fe[-1] + ins[l]] + list(fn) + [outs[l]]
+        for k in range(len(fn) + 1):
+            shapes[f"mp_layers.{l}.fn.net.{k}.weight"] = (dims[k + 1], dims[k])
+            shapes[f"mp_layers.{l}.fn.net.{k}.bias"] = (dims[k + 1],)
+    if not gen:
+        shapes["fnd_layer.net.0.weight"] = (1, hidden)
+        shapes["fnd_layer.net.0.bias"] = (1,)
+    return shapes
+
+
+def _mab_shapes(prefix, E):
+    return {
+        f"{prefix}.attention.in_proj_weight": (3 * E, E),
+        f"{prefix}.attention.in_proj_bias": (3 * E,),
+        f"{prefix}.attention.out_proj.weight": (E, E),
+        f"{prefix}.attention.out_proj.bias": (E,),
+        f"{prefix}.ff.net.0.weight": (E, E),
+        f"{prefix}.ff.net.0.bias": (E,),
+    }
+
+
+def gapt_param_shapes(gen: bool, E=64, feat=3, sab_layers=None):
+    """State-dict manifest of the default GAPT_G / GAPT_D."""
+    shapes = {}
+    if sab_layers is None:
+        sab_layers = 4 if gen else 2
+    if not gen:
+        shapes["input_embedding.net.0.weight"] = (E, feat)
+        shapes["input_embedding.net.0.bias"] = (E,)
+    for s in range(sab_layers):
+        shapes.update(_mab_shapes(f"sabs.{s}.mab", E))
+    if not gen:
+        shapes["pma.S"] = (1, 1, E)
+        shapes.update(_mab_shapes("pma.mab", E))
+    shapes["final_fc.net.0.weight"] = (feat if gen else 1, E)
+    shapes["final_fc.net.0.bias"] = (feat if gen else 1,)
+    return shapes
+
+
+def init_state_dict(shapes: Dict[str, tuple], seed: int = 0, dtype=torch.float32, scale: float = 1.0):
+    """Deterministic, torch-version-independent parameter values (numpy MT19937 keyed on the
+    parameter name): U(-b, b), b = scale/sqrt(fan_in) for matrices (and for their biases),
+    matching the distribution family of nn.Linear's default init.  Used so that goldens need
+    to carry inputs/outputs only -- the generator script loads these values into the
+    reference modules, the tests load them into the oracle and into the HIP modules."""
+    sd = {}
+    fan_in = {}
+    for name, shp in shapes.items():
+        if len(shp) >= 2:
+            fan_in[name.rsplit(".", 1)[0] if name.endswith(".weight") else name] = shp[-1]
+    for name, shp in shapes.items():
+        rs = np.random.RandomState((zlib.crc32(name.encode()) + 7919 * seed) % (2**31))
+        base = name.rsplit(".", 1)[0]
+        if name.endswith("in_proj_bias"):
+            fi = shapes[name.replace("in_proj_bias", "in_proj_weight")][-1]
+        else:
+            fi = fan_in.get(base, shp[-1])
+        b = scale / np.sqrt(fi)
+        sd[name] = torch.from_numpy(rs.uniform(-b, b, size=shp)).to(dtype)
+    return sd
+
+
+# ----------------------------------------------------------------------------- synthetic data
+def synthetic_batch(B: int, N: int, seed: int = 4, dist: str = "gluon", dtype=torch.float32):
+    """Synthetic JetNet-like batch.  data [B,N,4] = (eta_rel, phi_rel,
+    pt_rel, mask-0.5); labels [B,1] = float32(n) * float32(1/N) (multiply by reciprocal so that
+    int(labels*N) round-trips for every n <= 150)."""
+    rs = np.random.RandomState(seed)
+    if dist == "uniform":
+        n = rs.randint(1, N + 1, size=B)
+    else:  # gluon-like: most jets are close to full
+        n = np.clip(np.rint(rs.normal(0.8 * N, 0.15 * N, size=B)), 1, N).astype(np.int64)
+    eta = np.clip(rs.normal(0, 0.15, size=(B, N)), -1, 1)
+    phi = np.clip(rs.normal(0, 0.15, size=(B, N)), -1, 1)
+    pt = rs.uniform(-0.5, 0.5, size=(B, N))
+    real = (np.arange(N)[None, :] < n[:, None])
+    data = np.stack(
+        [np.where(real, eta, 0.0), np.where(real, phi, 0.0), np.where(real, pt, -0.5),
+         np.where(real, 0.5, -0.5)], axis=2)
+    labels = (n.astype(np.float32) * np.float32(1.0 / N)).reshape(B, 1)
+    return torch.from_numpy(data).to(dtype), torch.from_numpy(labels).to(dtype)
+
+
+# ----------------------------------------------------------------------------- optimiser
+def rmsprop_step(params: Dict[str, Tensor], grads: Dict[str, Tensor], state: Dict[str, Tensor],
+                 lr: float, alpha: float = 0.99, eps: float = 1e-8):
+    """torch.optim.RMSprop defaults (momentum 0, not centered, no weight decay):
+    v = alpha v + (1-alpha) g^2 ;  p -= lr * g / (sqrt(v) + eps)."""
+    for k, p in params.items():
+        g = grads[k]
+        v = state.setdefault(k, torch.zeros_like(p))
+        v.mul_(alpha).addcmul_(g, g, value=1 - alpha)
+        p.data.addcdiv_(g, v.sqrt().add_(eps), value=-lr)
+
+
+# ----------------------------------------------------------------------------- one iteration
+def _fwd_G(model, sdG, noise, labels, N, cfg):
+    if model == "mpgan":
+        return M.mpgen_forward(sdG, noise, labels, num_particles=N, **cfg.get("G", {}))
+    return A.gapt_g_forward(sdG, noise, labels, num_particles=N, **cfg.get("G", {}))
+
+
+def _fwd_D(model, sdD, x, labels, p, keeps, cfg):
+    if model == "mpgan":
+        return M.mpdisc_forward(sdD, x, labels, p=p, keeps=keeps,
+                                keep_fnd=None if keeps is None else keeps.get("fnd"),
+                                **cfg.get("D", {}))
+    return A.gapt_d_forward(sdD, x, labels, p=p, keeps=keeps, **cfg.get("D", {}))
+
+
+def train_iteration(
+    model: str,
+    sdD: Dict[str, Tensor],
+    sdG: Dict[str, Tensor],
+    stD: Dict[str, Tensor],
+    stG: Dict[str, Tensor],
+    data: Tensor,
+    labels: Tensor,
+    noise_D: Tensor,
+    noise_G: Tensor,
+    lr_disc: float,
+    lr_gen: float,
+    p_disc: float = 0.0,
+    keeps: Optional[Tuple] = None,
+    cfg: Optional[dict] = None,
+    return_grads: bool = False,
+):
+    """One train_D + train_G (num_critic = num_gen = 1), LSGAN loss, RMSprop.  Parameters in
+    ``sdD``/``sdG`` are updated in place.  ``keeps`` = (keeps for D(real), D(fake) in the
+    D step, D(fake) in the G step) or None; each is a dict as taken by the D forward, or a
+    ``RandKeeps()`` to draw Bernoulli masks.  Returns (D_loss, G_loss[, gradsD, gradsG])."""
+    cfg = cfg or {}
+    N = data.shape[1]
+    kr, kf, kg = keeps if keeps is not None else (None, None, None)
+
+    # ---- train_D (train.py:398-462)
+    pD = {k: v.detach().requires_grad_(True) for k, v in sdD.items()}
+    with torch.no_grad():
+        fake = _fwd_G(model, sdG, noise_D, labels, N, cfg)
+    out_r = _fwd_D(model, pD, data, labels, p_disc, kr, cfg)
+    out_f = _fwd_D(model, pD, fake, labels, p_disc, kf, cfg)
+    D_loss = ((out_r - 1.0) ** 2).mean() + (out_f**2).mean()
+    gD = dict(zip(pD.keys(), torch.autograd.grad(D_loss, list(pD.values()))))
+    rmsprop_step(sdD, gD, stD, lr_disc)
+
+    # ---- train_G (train.py:479-523)
+    pG = {k: v.detach().requires_grad_(True) for k, v in sdG.items()}
+    fake = _fwd_G(model, pG, noise_G, labels, N, cfg)
+    out = _fwd_D(model, sdD, fake, labels, p_disc, kg, cfg)
+    G_loss = ((out - 1.0) ** 2).mean()
+    gG = dict(zip(pG.keys(), torch.autograd.grad(G_loss, list(pG.values()))))
+    rmsprop_step(sdG, gG, stG, lr_gen)
+
+    if return_grads:
+        return float(D_loss.detach()), float(G_loss.detach()), gD, gG
+    return float(D_loss.detach()), float(G_loss.detach())

@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REFERENCE implementation (build container only).
+
+Imports the reference's own ``mpgan`` / ``gapt`` / ``setup_training`` modules from
+/root/reference (read-only; never copied), loads deterministic parameter values from
+``oracle.init_state_dict`` into the reference nn.Modules, runs forward/backward on seeded
+inputs and stores inputs + outputs as small ``.npz`` files under tests/golden/.
+
+Weights are NOT stored: they are a pure function of (parameter name, seed) via numpy's
+MT19937, so the tests rebuild the very same tensors.  Parameter gradients are stored as
+summaries (sum, L2 norm, 64 sampled entries per tensor) to keep the fixtures small; input
+gradients and outputs are stored in full.
+
+Run:  python tests/gen_golden.py          (no-op with a message if /root/reference is absent)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = os.environ.get("MPGAN_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "golden")
+sys.path.insert(0, os.path.dirname(HERE))
+
+from oracle.train_ref import (  # noqa: E402
+    init_state_dict, mpgan_param_shapes, gapt_param_shapes, synthetic_batch)
+
+
+def summarize(name, t):
+    """sum, l2, and 64 sampled entries (indices from a RandomState keyed on the name)."""
+    import zlib
+    flat = t.detach().double().reshape(-1)
+    rs = np.random.RandomState(zlib.crc32(name.encode()) % (2**31))
+    idx = rs.randint(0, flat.numel(), size=64)
+    return np.concatenate([[flat.sum().item(), flat.norm().item()], flat[idx].numpy()])
+
+
+def seeded(shape, seed, scale=1.0):
+    return torch.from_numpy(np.random.RandomState(seed).normal(0, scale, size=shape))
+
+
+def rand_mask(B, N, seed):
+    rs = np.random.RandomState(seed)
+    n = rs.randint(1, N + 1, size=B)
+    m = np.zeros((B, N, 1))
+    for b in range(B):
+        m[b, rs.permutation(N)[: n[b]], 0] = 1.0
+    return torch.from_numpy(m)
+
+
+def main():
+    if not os.path.isdir(REF):
+        print(f"reference not found at {REF}; nothing generated")
+        return 0
+    sys.path.insert(0, REF)
+    import mpgan as rmp  # reference
+    import gapt as rga  # reference
+    import setup_training as st  # reference
+
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+
+    # ------------------------------------------------------------------ 1. MPLayer fwd/bwd
+    fe, fn = [96, 160, 192], [256, 256]
+    cases = [  # name, B, N, F, out, use_mask, sum
+        ("g0", 4, 30, 32, 32, True, True),
+        ("d0", 4, 30, 3, 32, True, True),
+        ("g1", 4, 30, 32, 3, True, True),
+        ("n150", 2, 150, 32, 32, True, True),
+        ("mean", 3, 30, 32, 32, True, False),
+        ("nomask", 3, 30, 32, 32, False, True),
+        ("small", 2, 5, 32, 32, True, True),
+    ]
+    for dt_name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        for ci, (name, B, N, F, out, use_mask, sm) in enumerate(cases):
+            if dt_name == "f32" and name not in ("g0", "d0"):
+                continue
+            layer = rmp.MPLayer(F, fe, fn, out, sum=sm).to(dt)
+            shapes = {k: tuple(v.shape) for k, v in layer.state_dict().items()}
+            sd = init_state_dict(shapes, seed=ci, dtype=dt)
+            layer.load_state_dict(sd)
+            x = seeded((B, N, F), 100 + ci, 0.5).to(dt).requires_grad_(True)
+            mask = rand_mask(B, N, 200 + ci).to(dt) if use_mask else None
+            g = seeded((B, N, out), 300 + ci).to(dt)
+            y = layer(x, use_mask, mask)
+            (y * g).sum().backward()
+            rec = dict(x=x.detach().numpy(), g=g.numpy(), y=y.detach().numpy(),
+                       dx=x.grad.numpy(), seed=ci, sum=int(sm), out=out)
+            if mask is not None:
+                rec["mask"] = mask.numpy()
+            for k, p in layer.named_parameters():
+                rec["grad__" + k] = summarize(k, p.grad)
+            np.savez_compressed(os.path.join(OUT, f"mplayer_{name}_{dt_name}.npz"), **rec)
+            print("mplayer", name, dt_name, float(y.abs().max()))
+
+    # ------------------------------------------------------------------ default args / manifests
+    sys.argv = ["gen_golden"]
+    args = st.process_args(st.parse_args())
+    manifests = {}
+    G = st.setup_mpgan(args, gen=True)
+    D = st.setup_mpgan(args, gen=False)
+    manifests["mpgan_G"] = {k: list(v.shape) for k, v in G.state_dict().items()}
+    manifests["mpgan_D"] = {k: list(v.shape) for k, v in D.state_dict().items()}
+    args.model = "gapt"
+    Gg = st.setup_gapt(args, gen=True)
+    Dg = st.setup_gapt(args, gen=False)
+    manifests["gapt_G"] = {k: list(v.shape) for k, v in Gg.state_dict().items()}
+    manifests["gapt_D"] = {k: list(v.shape) for k, v in Dg.state_dict().items()}
+    args.use_isab = True
+    manifests["gapt_G_isab"] = {k: list(v.shape) for k, v in st.setup_gapt(args, gen=True).state_dict().items()}
+    args.use_isab = False
+    with open(os.path.join(OUT, "manifests.json"), "w") as f:
+        json.dump(manifests, f, indent=1, sort_keys=True)
+    assert manifests["mpgan_G"] == {k: list(v) for k, v in mpgan_param_shapes(True).items()}
+    assert manifests["mpgan_D"] == {k: list(v) for k, v in mpgan_param_shapes(False).items()}
+    assert manifests["gapt_G"] == {k: list(v) for k, v in gapt_param_shapes(True).items()}
+    assert manifests["gapt_D"] == {k: list(v) for k, v in gapt_param_shapes(False).items()}
+
+    # ------------------------------------------------------------------ 2. MPGenerator / MPDiscriminator fwd
+    for dt_name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        B, N = 6, 30
+        G.to(dt).eval()
+        D.to(dt).eval()
+        G.load_state_dict(init_state_dict(mpgan_param_shapes(True), seed=11, dtype=dt))
+        D.load_state_dict(init_state_dict(mpgan_param_shapes(False), seed=12, dtype=dt))
+        data, labels = synthetic_batch(B, N, seed=5, dist="uniform", dtype=dt)
+        noise = seeded((B, N, 32), 17, 0.2).to(dt).requires_grad_(True)
+        gout = G(noise, labels)
+        gg = seeded(gout.shape, 18).to(dt)
+        (gout * gg).sum().backward()
+        dd = data.clone().requires_grad_(True)
+        dout = D(dd, labels)
+        dg = seeded(dout.shape, 19).to(dt)
+        (dout * dg).sum().backward()
+        rec = dict(noise=noise.detach().numpy(), labels=labels.numpy(), data=data.numpy(),
+                   gout=gout.detach().numpy(), gg=gg.numpy(), dnoise=noise.grad.numpy(),
+                   dout=dout.detach().numpy(), dg=dg.numpy(), ddata=dd.grad.numpy())
+        for k, p in G.named_parameters():
+            rec["gradG__" + k] = summarize(k, p.grad)
+        for k, p in D.named_parameters():
+            rec["gradD__" + k] = summarize(k, p.grad)
+        np.savez_compressed(os.path.join(OUT, f"mpgan_nets_{dt_name}.npz"), **rec)
+        G.zero_grad(); D.zero_grad()
+        print("mpgan nets", dt_name, float(dout.mean()))
+
+    # ------------------------------------------------------------------ 3. published weights (outputs only)
+    for jets in ("g", "q", "t"):
+        path = os.path.join(REF, "trained_models", f"mp_{jets}", "G_best_epoch.pt")
+        if not os.path.isfile(path):
+            continue
+        G.to(torch.float32).eval()
+        G.load_state_dict(torch.load(path, map_location="cpu"))
+        _, labels = synthetic_batch(8, 30, seed=21, dist="gluon")
+        noise = seeded((8, 30, 32), 22, 0.2).float()
+        with torch.no_grad():
+            out = G(noise, labels)
+        np.savez_compressed(os.path.join(OUT, f"published_mp_{jets}.npz"), noise=noise.numpy(),
+                            labels=labels.numpy(), out=out.numpy())
+        print("published", jets, float(out.abs().max()))
+
+    # ------------------------------------------------------------------ 4. GAPT blocks
+    E, H = 64, 4
+    sab_args = dict(embed_dim=E, ff_layers=[], final_linear=False, num_heads=H, layer_norm=False,
+                    dropout_p=0.0, linear_args={"leaky_relu_alpha": 0.2, "dropout_p": 0.0})
+    for dt_name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        for ci, (name, B, N, use_mask) in enumerate(
+                [("m30", 4, 30, True), ("u30", 3, 30, False), ("m150", 2, 150, True)]):
+            if dt_name == "f32" and name != "m30":
+                continue
+            mask = rand_mask(B, N, 400 + ci).to(dt) if use_mask else None
+            amask = None if mask is None else rga.model._attn_mask(mask)
+            x0 = seeded((B, N, E), 410 + ci, 0.5).to(dt)
+            rec = dict(x=x0.numpy())
+            if mask is not None:
+                rec["mask"] = mask.numpy()
+            blocks = {
+                "sab": rga.SAB(**sab_args),
+                "pma": rga.PMA(num_seeds=1, **sab_args),
+                "isab": rga.ISAB(10, **sab_args),
+            }
+            for bname, blk in blocks.items():
+                blk.to(dt)
+                shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+                blk.load_state_dict(init_state_dict(shapes, seed=50 + ci, dtype=dt))
+                x = x0.clone().requires_grad_(True)
+                y = blk(x, amask)
+                g = seeded(y.shape, 420 + ci).to(dt)
+                (y * g).sum().backward()
+                rec[f"{bname}_y"] = y.detach().numpy()
+                rec[f"{bname}_g"] = g.numpy()
+                rec[f"{bname}_dx"] = x.grad.numpy()
+                for k, p in blk.named_parameters():
+                    rec[f"{bname}_grad__{k}"] = summarize(k, p.grad)
+            np.savez_compressed(os.path.join(OUT, f"gapt_blocks_{name}_{dt_name}.npz"), **rec)
+            print("gapt blocks", name, dt_name)
+
+        B, N = 6, 30
+        Gg.to(dt).eval(); Dg.to(dt).eval()
+        Gg.load_state_dict(init_state_dict(gapt_param_shapes(True), seed=31, dtype=dt))
+        Dg.load_state_dict(init_state_dict(gapt_param_shapes(False), seed=32, dtype=dt))
+        data, labels = synthetic_batch(B, N, seed=6, dist="uniform", dtype=dt)
+        noise = seeded((B, N, E), 33, 0.2).to(dt)
+        with torch.no_grad():
+            gout = Gg(noise, labels)
+            dout = Dg(data, labels)
+        np.savez_compressed(os.path.join(OUT, f"gapt_nets_{dt_name}.npz"), noise=noise.numpy(),
+                            labels=labels.numpy(), data=data.numpy(), gout=gout.numpy(),
+                            dout=dout.reshape(B, 1).numpy())
+        print("gapt nets", dt_name, float(dout.mean()))
+
+    # ------------------------------------------------------------------ 5. one train_D + train_G step
+    # train.py cannot be imported (needs jetnet): its step (train.py:398-523) is driven here
+    # with the reference's own modules, torch.optim.RMSprop and MSELoss; dropout p = 0.
+    mse = torch.nn.MSELoss()
+    for model in ("mpgan", "gapt"):
+        dt = torch.float64
+        B, N = 8, 30
+        sys.argv = ["gen_golden", "--model", model, "--disc-dropout", "0"]
+        a = st.process_args(st.parse_args())
+        if model == "mpgan":
+            Gm, Dm = st.setup_mpgan(a, gen=True), st.setup_mpgan(a, gen=False)
+            shG, shD, lat = mpgan_param_shapes(True), mpgan_param_shapes(False), 32
+        else:
+            Gm, Dm = st.setup_gapt(a, gen=True), st.setup_gapt(a, gen=False)
+            shG, shD, lat = gapt_param_shapes(True), gapt_param_shapes(False), 64
+        Gm.to(dt); Dm.to(dt)
+        Gm.load_state_dict(init_state_dict(shG, seed=41, dtype=dt))
+        Dm.load_state_dict(init_state_dict(shD, seed=42, dtype=dt))
+        # the reference's default learning rates (setup_training.py:848-872); RMSprop's first
+        # update is +-10*lr per parameter whatever the gradient's size, so larger values
+        # saturate D after one step
+        lr_d, lr_g = (3e-5, 1e-5) if model == "mpgan" else (1.5e-4, 0.5e-4)
+        oD = torch.optim.RMSprop(Dm.parameters(), lr=lr_d)
+        oG = torch.optim.RMSprop(Gm.parameters(), lr=lr_g)
+        data, labels = synthetic_batch(B, N, seed=7, dist="uniform", dtype=dt)
+        nD = seeded((B, N, lat), 43, 0.2).to(dt)
+        nG = seeded((B, N, lat), 44, 0.2).to(dt)
+        rec = dict(data=data.numpy(), labels=labels.numpy(), noise_D=nD.numpy(), noise_G=nG.numpy(),
+                   lr_d=lr_d, lr_g=lr_g)
+        for it in range(2):
+            # train_D
+            Dm.train(); oD.zero_grad(); Gm.eval()
+            out_r = Dm(data.clone(), labels).reshape(B, 1)
+            fake = Gm(nD, labels)
+            out_f = Dm(fake, labels).reshape(B, 1)
+            D_loss = mse(out_r, torch.ones(B, 1, dtype=dt)) + mse(out_f, torch.zeros(B, 1, dtype=dt))
+            D_loss.backward(); oD.step()
+            if it == 0:
+                for k, p in Dm.named_parameters():
+                    rec["gradD__" + k] = summarize(k, p.grad)
+            # train_G
+            Gm.train(); oG.zero_grad()
+            fake = Gm(nG, labels)
+            out = Dm(fake, labels).reshape(B, 1)
+            G_loss = mse(out, torch.ones(B, 1, dtype=dt))
+            G_loss.backward(); oG.step()
+            if it == 0:
+                for k, p in Gm.named_parameters():
+                    rec["gradG__" + k] = summarize(k, p.grad)
+            rec[f"D_loss{it}"] = D_loss.item()
+            rec[f"G_loss{it}"] = G_loss.item()
+        for k, p in Dm.named_parameters():
+            rec["postD__" + k] = summarize(k, p.data)
+        for k, p in Gm.named_parameters():
+            rec["postG__" + k] = summarize(k, p.data)
+        np.savez_compressed(os.path.join(OUT, f"train_step_{model}.npz"), **rec)
+        print("train step", model, rec["D_loss0"], rec["G_loss0"], rec["D_loss1"], rec["G_loss1"])
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
