@@ -1,0 +1,117 @@
+/* mpgan_amd.h -- C ABI of libmpgan_amd.so (MI355X / gfx950 hot path of MPGAN + GAPT).
+ *
+ * Plain pointers and sizes only: every pointer is a DEVICE pointer into caller-owned fp32
+ * (or, where noted, packed-bf16 "image") memory, `stream` is a hipStream_t passed as
+ * void*, and every entry point enqueues work on that stream and returns at once
+ * (0 = success, otherwise a hipError_t value or a negative argument-error code).  Nothing
+ * is allocated, freed or synchronised inside, so every call can be captured in a hipGraph.
+ *
+ * The reference (rkansal47/MPGAN) has no FFI: its hot path is Python calling ATen.  Each
+ * entry point below therefore cites the reference Python lines whose ATen work it replaces
+ * (paths relative to the reference root); INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ */
+#ifndef MPGAN_AMD_H
+#define MPGAN_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- generic fused linear (nn.Linear + LeakyReLU + Dropout and their backward) -----------
+ * Replaces LinearNet.forward's per-layer addmm / leaky_relu / dropout (mpgan/model.py:77-83,
+ * gapt/model.py:78-84) and their autograd backward for the node network fn, the final fnd
+ * layer and GAPT's projections. */
+typedef struct MpgGemm {
+    const float* A;      /* A(m,k) = ak ? A[m*lda+k] : A[k*lda+m]                                   */
+    const float* A2;     /* optional second K-segment: columns k >= K1 come from A2(m, k-K1) (ak=1) */
+    int lda, lda2, K1;
+    const float* B;      /* B(k,n) = bk ? B[n*ldb+k] : B[k*ldb+n]                                   */
+    int ldb;
+    float* C;            /* C[m*ldc+n]; with split-K, slice z is written at C + z*split_stride      */
+    int ldc;
+    int M, N, K;
+    long long split_stride;
+    const float* bias;   /* [N] or NULL                                                             */
+    float out_scale;     /* product is multiplied by this before the bias                           */
+    int act;             /* 1 = LeakyReLU(alpha)                                                    */
+    float alpha;
+    const uint64_t* seed;/* device pointer to the 64-bit dropout seed (NULL = no dropout anywhere)  */
+    uint32_t drop_tag, drop_thr; float drop_scale;   /* forward dropout on C (thr = round(256 p))   */
+    const float* gateH;  /* backward: C *= d(dropout o act)/dz evaluated from the saved output H    */
+    int ldh, gate_act;
+    uint32_t gate_tag, gate_thr; float gate_scale;
+    const float* resid;  /* C += resid[m*ldr+n]                                                     */
+    int ldr;
+    int accumulate;      /* C += result instead of C = result                                       */
+    int f16;             /* 1: split operands as fp16 hi/lo (forward products); 0: bf16 hi/lo (gradients) */
+} MpgGemm;
+
+int mpg_gemm(const MpgGemm* g, int ak, int bk, int splitk, void* stream);
+
+/* out = in * gate(H): backward through Dropout (and LeakyReLU when gate_act) ahead of a GEMM. */
+int mpg_gate(const float* in, int ldi, const float* H, int ldh, float* out, int ldo, int M, int N,
+             int gate_act, float alpha, const uint64_t* seed, uint32_t tag, uint32_t thr, float scale,
+             void* stream);
+
+/* Test helper: the {0,1} keep mask [rows, F] the kernels use for dropout site `tag`. */
+int mpg_dropout_mask(float* out, uint64_t rows, int F, const uint64_t* seed, uint32_t tag, uint32_t thr,
+                     void* stream);
+
+/* ---- fused edge network of MPLayer ------------------------------------------------------------
+ * Widths are the reference defaults fe = [96,160,192] (setup_training.py:471-477).
+ *
+ * mpg_pack_weights: W[rows,cols] (row stride ldw; transpose=1 reads W^T) * scale  ->  bf16 hi/lo
+ * (f16=0) or fp16 hi/lo (f16=1)
+ * fragment image of ceil(rows/32) x ceil(cols/32) x 2 fragments of 1 KiB, hi part then lo part
+ * (2 * MT*QT*2 KiB in all).  Layer images: W2 = fe.net.1.weight (160x96), W3 = fe.net.2.weight
+ * (192x160); the backward also takes their transposes.  When dropout is on, `scale` carries the
+ * 1/(1-p) of the dropout in FRONT of that layer (inverted dropout commutes with LeakyReLU). */
+int mpg_pack_weights(const float* W, int ldw, int rows, int cols, int transpose, float scale, int f16,
+                     void* img, void* stream);
+
+/* mpg_edge_fwd: replaces MPLayer._getA_fully_connected + self.fe(A) + mask multiply + sum/mean
+ * (mpgan/model.py:241, :256-267, :284-317).  Inputs are the layer-1 node terms
+ *   a[b,i,:] = W1[:, :F] x_i + b1   (receiver),   c[b,j,:] = W1[:, F:] x_j   (sender),
+ * so that fe.net.0 applied to [x_i ; x_j] is a_i + c_j exactly.  Output
+ *   agg[b,i,:] = agg_scale * sum_j mask[b,j] * fe([x_i ; x_j])        ([B,N,192], agg_scale = 1 | 1/N)
+ * With SC > 1 the senders are split over SC workgroups and agg has a leading [SC] axis of partial
+ * sums the caller adds up. */
+typedef struct MpgEdgeFwd {
+    const float* a; const float* c;       /* [B*N, 96]                                        */
+    const float* mask;                    /* [B*N] (1 real / 0 padded) or NULL                */
+    const void* W2img; const void* W3img; /* from mpg_pack_weights                            */
+    const float* b2; const float* b3;     /* fe.net.1.bias [160], fe.net.2.bias [192]         */
+    float* agg;                           /* [SC, B*N, 192]                                   */
+    int B, N, SC;
+    float alpha, agg_scale;
+    const uint64_t* seed; uint32_t tag_base, thr; float dscale;  /* dropout: thr=round(256p), dscale=1/(1-p_eff) */
+    int skip_masked;                      /* skip senders with mask == 0 (exact: they add 0)   */
+    int weights_in_lds;                   /* keep W3 (hi,lo) + W2 hi resident in LDS           */
+    int f16;                              /* images and activations are fp16 hi/lo (else bf16)  */
+} MpgEdgeFwd;
+int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream);
+
+/* mpg_edge_bwd: autograd backward of the same span.  Given dagg = dL/dagg it produces
+ *   da [SC, B*N, 96]  (partial over sender chunks),  dc [RB, B*N, 96]  (partial over receiver blocks
+ *   of 32; RB = ceil(N/32)), and -- when the pointers are non-NULL -- the per-edge rows
+ *   E1 [B*N*N,96], E2 [B*N*N,160], dZ2 [B*N*N,160], dZ3 [B*N*N,192] from which
+ *   dW3 = dscale * dZ3^T E2, dW2 = dscale * dZ2^T E1, db3 = colsum dZ3, db2 = colsum dZ2. */
+typedef struct MpgEdgeBwd {
+    const float* a; const float* c; const float* mask;
+    const float* dagg; int ld_dagg;
+    const void* W2img; const void* W3img; const void* W3Timg; const void* W2Timg;
+    const float* b2; const float* b3;
+    float* da; float* dc;
+    float* E1; float* E2; float* dZ2; float* dZ3;
+    int B, N, SC;
+    float alpha, agg_scale;
+    const uint64_t* seed; uint32_t tag_base, thr; float dscale;
+    int f16;  /* W2img/W3img (forward recomputation) are fp16 images; W3Timg/W2Timg are always bf16 */
+} MpgEdgeBwd;
+int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPGAN_AMD_H */

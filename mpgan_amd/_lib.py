@@ -1,0 +1,133 @@
+"""ctypes binding of libmpgan_amd.so (the C ABI declared in include/mpgan_amd.h).
+
+The library is built in-tree (``mpgan_amd/lib/libmpgan_amd.so``) by ``build()`` with
+``hipcc --offload-arch=gfx950``; there is no CPU fallback: importing the ops without the
+library raises, and every entry point's non-zero return raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import glob
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIBDIR = os.path.join(_HERE, "lib")
+LIBPATH = os.path.join(LIBDIR, "libmpgan_amd.so")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+_u64p = C.POINTER(C.c_uint64)
+_fp = C.c_void_p  # device pointers travel as integers
+
+
+class MpgGemm(C.Structure):
+    _fields_ = [
+        ("A", _fp), ("A2", _fp), ("lda", C.c_int), ("lda2", C.c_int), ("K1", C.c_int),
+        ("B", _fp), ("ldb", C.c_int),
+        ("C", _fp), ("ldc", C.c_int),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("split_stride", C.c_longlong),
+        ("bias", _fp), ("out_scale", C.c_float), ("act", C.c_int), ("alpha", C.c_float),
+        ("seed", _fp),
+        ("drop_tag", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float),
+        ("gateH", _fp), ("ldh", C.c_int), ("gate_act", C.c_int),
+        ("gate_tag", C.c_uint32), ("gate_thr", C.c_uint32), ("gate_scale", C.c_float),
+        ("resid", _fp), ("ldr", C.c_int),
+        ("accumulate", C.c_int), ("f16", C.c_int),
+    ]
+
+
+class MpgEdgeFwd(C.Structure):
+    _fields_ = [
+        ("a", _fp), ("c", _fp), ("mask", _fp),
+        ("W2img", _fp), ("W3img", _fp), ("b2", _fp), ("b3", _fp),
+        ("agg", _fp),
+        ("B", C.c_int), ("N", C.c_int), ("SC", C.c_int),
+        ("alpha", C.c_float), ("agg_scale", C.c_float),
+        ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
+        ("skip_masked", C.c_int), ("weights_in_lds", C.c_int), ("f16", C.c_int),
+    ]
+
+
+class MpgEdgeBwd(C.Structure):
+    _fields_ = [
+        ("a", _fp), ("c", _fp), ("mask", _fp),
+        ("dagg", _fp), ("ld_dagg", C.c_int),
+        ("W2img", _fp), ("W3img", _fp), ("W3Timg", _fp), ("W2Timg", _fp),
+        ("b2", _fp), ("b3", _fp),
+        ("da", _fp), ("dc", _fp),
+        ("E1", _fp), ("E2", _fp), ("dZ2", _fp), ("dZ3", _fp),
+        ("B", C.c_int), ("N", C.c_int), ("SC", C.c_int),
+        ("alpha", C.c_float), ("agg_scale", C.c_float),
+        ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
+        ("f16", C.c_int),
+    ]
+
+
+# name -> (restype, argtypes); kept in step with include/mpgan_amd.h (tests check the symbol list)
+SIGNATURES = {
+    "mpg_gemm": (C.c_int, [C.POINTER(MpgGemm), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mpg_gate": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                           _fp, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]),
+    "mpg_dropout_mask": (C.c_int, [_fp, C.c_uint64, C.c_int, _fp, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "mpg_pack_weights": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp, C.c_void_p]),
+    "mpg_edge_fwd": (C.c_int, [C.POINTER(MpgEdgeFwd), C.c_void_p]),
+    "mpg_edge_bwd": (C.c_int, [C.POINTER(MpgEdgeBwd), C.c_void_p]),
+}
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale():
+    if not os.path.isfile(LIBPATH):
+        return True
+    t = os.path.getmtime(LIBPATH)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into mpgan_amd/lib/libmpgan_amd.so (in-tree)."""
+    if not force and not _stale():
+        return LIBPATH
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for src in sources():
+        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", INCLUDE, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIBPATH] + objs
+    subprocess.run(cmd, check=True)
+    return LIBPATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library (built on first use if the toolchain is present).  Raises if absent."""
+    global _lib
+    if _lib is None:
+        if _stale():
+            if os.path.isfile(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) and os.path.isdir(CSRC):
+                build()
+            elif not os.path.isfile(LIBPATH):
+                raise RuntimeError("libmpgan_amd.so is missing and hipcc is not available: run __graft_entry__.build()")
+        _lib = C.CDLL(LIBPATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise RuntimeError(f"{what} failed with code {code}")

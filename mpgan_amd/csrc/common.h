@@ -1,0 +1,103 @@
+// Common device helpers for the MPGAN/GAPT hot-path kernels (gfx950 / CDNA4 only).
+//
+// Arithmetic: every matrix product runs on the 16-bit matrix cores as a 3-term split:
+// x = hi + lo with hi = T(x), lo = T(x - hi);  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi,
+// accumulated in fp32 by v_mfma_f32_32x32x16_{f16,bf16}.
+//   T = _Float16 ("f16x3"): 11+11 significand bits, product error ~2^-21 -- used for every
+//       FORWARD product (and its recomputation in the backward), because those decide on which
+//       side of the LeakyReLU kink a pre-activation falls; operands must be < 65504 in
+//       magnitude (activations / weights of these networks are O(1); fp16 subnormals carry lo).
+//   T = __bf16   ("bf16x3"): 8+8 bits, product error ~2^-17, fp32 exponent range -- used for
+//       the products that carry GRADIENTS (arbitrarily small), where there is no kink.
+// Both sit well inside the 1e-3 parity bar of BASELINE.json (plain bf16 would be ~2e-3).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// 16-byte MFMA operand fragment of either 16-bit type
+template <bool F16> struct FragT { typedef bf16x8 type; typedef __bf16 elem; };
+template <> struct FragT<true> { typedef f16x8 type; typedef _Float16 elem; };
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MPG_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------
+// MFMA 32x32x16 bf16 fragment maps (cdna_hip_programming.md section 3):
+//   A operand: lane l (r = l&31, h = l>>5) holds A[row r][k = 8h + j], j = 0..7
+//   B operand: lane l holds B[k = 8h + j][col r]
+//   C/D      : lane l, reg g*4+t (g,t = 0..3) holds D[row = 8g + 4h + t][col r]
+// "Chain" use of a D tile X as the next product's B operand (Y = A.X, contraction over X's
+// rows): registers 8s..8s+7 form the fragment of k-step s (s = 0,1); element j of lane half
+// h then IS row  rho(s,h,j) = 16s + 8(j>>2) + 4h + (j&3)  of X, so the A operand of that
+// k-step must hold column rho(s,h,j) of the weight in its element j.  pack_weights() builds
+// weight images in exactly that order, for every layer, so all products share one map.
+MPG_DEV int chain_rho(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+MPG_DEV f32x16 mfma3(const bf16x8 ahi, const bf16x8 alo, const bf16x8 bhi, const bf16x8 blo, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc, 0, 0, 0);
+    return acc;
+}
+MPG_DEV f32x16 mfma3(const f16x8 ahi, const f16x8 alo, const f16x8 bhi, const f16x8 blo, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
+    return acc;
+}
+
+// hi/lo split of 8 floats into two 16-bit x8 fragments
+template <typename V> struct ElemOf;
+template <> struct ElemOf<bf16x8> { typedef __bf16 type; };
+template <> struct ElemOf<f16x8> { typedef _Float16 type; };
+
+template <typename V>
+MPG_DEV void split8(const float* v, V& hi, V& lo) {
+    typedef typename ElemOf<V>::type E;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const E hh = (E)v[j];
+        hi[j] = hh;
+        lo[j] = (E)(v[j] - (float)hh);
+    }
+}
+template <typename E>
+MPG_DEV void split1(float x, E& hh, E& ll) { hh = (E)x; ll = (E)(x - (float)hh); }
+
+MPG_DEV float lrelu(float v, float alpha) { return v > 0.f ? v : v * alpha; }
+// derivative as torch's leaky_relu_backward takes it: slope at v <= 0
+MPG_DEV float lrelu_grad(float v, float alpha) { return v > 0.f ? 1.f : alpha; }
+
+// ---------------------------------------------------------------------------------------
+// Counter-based dropout.  One 32-bit hash word per (row, group of 4 consecutive features);
+// byte t of the word decides feature 4*grp + t:  keep  <=>  byte >= thr,  thr = round(256 p).
+// (p = 0.5 -> thr = 128, keep probability exactly 1/2.)  The scale applied to kept values
+// is 256 / (256 - thr).  Forward and backward regenerate the same word from
+// (seed, tag, row, grp); nothing is stored.  `tag` names the dropout site.
+struct DropCfg {
+    uint32_t seed_lo, seed_hi;
+    uint32_t thr;    // 0 => dropout off
+    float scale;     // 256/(256-thr)
+};
+
+MPG_DEV uint32_t drop_word(uint32_t seed_lo, uint32_t seed_hi, uint32_t tag, uint32_t row, uint32_t grp) {
+    uint32_t x = (row + seed_lo) * 0x9E3779B1u;
+    x ^= (grp + tag * 0x10001u) * 0x85EBCA77u + seed_hi;
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+MPG_DEV bool drop_keep(uint32_t word, int t, uint32_t thr) { return ((word >> (8 * t)) & 0xffu) >= thr; }
+
+// dropout sites (tag values); the layer id of the call is mixed in by the host as tag_base
+enum { TAG_E0 = 1, TAG_E1 = 2, TAG_E2 = 3, TAG_N0 = 4, TAG_N1 = 5, TAG_N2 = 6, TAG_GENERIC = 7 };
+
+#define HIP_CHECK_RET(expr)                                        \
+    do {                                                           \
+        hipError_t _e = (expr);                                    \
+        if (_e != hipSuccess) return (int)_e;                      \
+    } while (0)

@@ -1,0 +1,201 @@
+// Generic fp32-in / fp32-out GEMM on the bf16 matrix cores (3-term split), with the fused
+// epilogues the node network (fn), the layer-1 node terms (a, c) and GAPT's projections need.
+//
+//   C[M,N] = epi( sum_k A(m,k) * B(k,n) )
+//   A(m,k) = AK ? A[m*lda + k] : A[k*lda + m]        (k >= K1 reads the optional 2nd segment A2)
+//   B(k,n) = BK ? B[n*ldb + k] : B[k*ldb + n]
+//
+//   (AK,BK) = (1,1): Y = X W^T          (nn.Linear forward,      mpgan/model.py:78)
+//   (AK,BK) = (1,0): dX = dY W          (its input gradient)
+//   (AK,BK) = (0,0): dW = dY^T X        (its weight gradient; split-K over gridDim.z)
+//
+// Tile 64x64x32, 256 threads = 4 waves in a 2x2 grid of 32x32 MFMA tiles.  Operands are
+// split to bf16 hi/lo while being staged into LDS in MFMA-fragment order (16 B per lane,
+// conflict-free ds_read_b128).
+#include "common.h"
+#include "gemm.h"
+
+namespace {
+
+template <bool KC, typename V>  // KC: the contraction index k is the contiguous one in memory
+MPG_DEV void stage_tile(const float* __restrict__ P, int ld, const float* __restrict__ P2, int ld2, int K1,
+                        int row0, int nrows, int kt, int kend, V (*hi)[2][64], V (*lo)[2][64],
+                        int tid, bool vec_ok) {
+    typedef typename ElemOf<V>::type E;
+    if constexpr (KC) {
+        const int row = tid >> 2, kc = tid & 3;
+        const int gr = row0 + row;
+        const int k0 = kt + 8 * kc;
+        float v[8];
+        if (vec_ok && gr < nrows && k0 + 8 <= kend && P2 == nullptr) {
+            const float4 u0 = *reinterpret_cast<const float4*>(P + (size_t)gr * ld + k0);
+            const float4 u1 = *reinterpret_cast<const float4*>(P + (size_t)gr * ld + k0 + 4);
+            v[0] = u0.x; v[1] = u0.y; v[2] = u0.z; v[3] = u0.w;
+            v[4] = u1.x; v[5] = u1.y; v[6] = u1.z; v[7] = u1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + e;
+                float x = 0.f;
+                if (gr < nrows && k < kend) x = (P2 != nullptr && k >= K1) ? P2[(size_t)gr * ld2 + (k - K1)] : P[(size_t)gr * ld + k];
+                v[e] = x;
+            }
+        }
+        V h8, l8;
+        split8(v, h8, l8);
+        const int blk = row >> 5, r = row & 31, s = kc >> 1, h = kc & 1;
+        hi[blk][s][h * 32 + r] = h8;
+        lo[blk][s][h * 32 + r] = l8;
+    } else {
+        // rows (m or n) are contiguous in memory: coalesce along them, scatter 2-byte elements
+        const int kr = tid >> 3, rc = tid & 7;
+        const int k = kt + kr;
+        const int s = kr >> 4, h = (kr >> 3) & 1, j = kr & 7;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int row = 8 * rc + e;
+            const int gr = row0 + row;
+            float x = 0.f;
+            if (gr < nrows && k < kend) x = P[(size_t)k * ld + gr];
+            E hh, ll;
+            split1(x, hh, ll);
+            const int blk = row >> 5, r = row & 31;
+            reinterpret_cast<E*>(&hi[blk][s][h * 32 + r])[j] = hh;
+            reinterpret_cast<E*>(&lo[blk][s][h * 32 + r])[j] = ll;
+        }
+    }
+}
+
+template <bool AK, bool BK, bool F16>
+__global__ __launch_bounds__(256) void gemm_kernel(const MpgGemm g) {
+    typedef typename FragT<F16>::type V;
+    __shared__ V As_hi[2][2][64], As_lo[2][2][64], Bs_hi[2][2][64], Bs_lo[2][2][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    // split-K range of this z-slice (multiples of 32)
+    const int nz = gridDim.z;
+    const int ktiles = (g.K + 31) / 32;
+    const int per = (ktiles + nz - 1) / nz;
+    const int kbeg = blockIdx.z * per * 32;
+    const int kend_z = min(g.K, (int)(blockIdx.z + 1) * per * 32);
+    const bool a_vec = AK && (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+    const bool b_vec = BK && (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    for (int kt = kbeg; kt < kend_z; kt += 32) {
+        stage_tile<AK>(g.A, g.lda, g.A2, g.lda2, g.K1, m0, g.M, kt, kend_z, As_hi, As_lo, tid, a_vec);
+        stage_tile<BK>(g.B, g.ldb, nullptr, 0, 0, n0, g.N, kt, kend_z, Bs_hi, Bs_lo, tid, b_vec);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            acc = mfma3(As_hi[wr][s][lane], As_lo[wr][s][lane], Bs_hi[wc][s][lane], Bs_lo[wc][s][lane], acc);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue (D layout: reg 4g+t -> row 8g+4h+t, lane&31 -> col)
+    const int c = lane & 31, h = lane >> 5;
+    const int n = n0 + 32 * wc + c;
+    if (n >= g.N) return;
+    uint32_t seed_lo = 0, seed_hi = 0;
+    if (g.seed != nullptr) { const uint64_t sd = *g.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+    const float bias = (g.bias != nullptr && blockIdx.z == 0) ? g.bias[n] : 0.f;
+    float* Cz = g.C + (size_t)blockIdx.z * g.split_stride;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 32 * wr + 8 * (r >> 2) + 4 * h + (r & 3);
+        if (m >= g.M) continue;
+        float v = acc[r] * g.out_scale + bias;
+        if (g.act == 1) v = lrelu(v, g.alpha);
+        if (g.drop_thr) {  // forward dropout on the output element (m, n)
+            const uint32_t wd = drop_word(seed_lo, seed_hi, g.drop_tag, (uint32_t)m, (uint32_t)(n >> 2));
+            v = drop_keep(wd, n & 3, g.drop_thr) ? v * g.drop_scale : 0.f;
+        }
+        if (g.gateH != nullptr) {  // backward through (dropout o leaky-relu) of the layer that produced H
+            const float hv = g.gateH[(size_t)m * g.ldh + n];
+            float gt = g.gate_act ? lrelu_grad(hv, g.alpha) : 1.f;
+            if (g.gate_thr) {
+                const uint32_t wd = drop_word(seed_lo, seed_hi, g.gate_tag, (uint32_t)m, (uint32_t)(n >> 2));
+                gt = drop_keep(wd, n & 3, g.gate_thr) ? gt * g.gate_scale : 0.f;
+            }
+            v *= gt;
+        }
+        if (g.resid != nullptr) v += g.resid[(size_t)m * g.ldr + n];
+        float* dst = Cz + (size_t)m * g.ldc + n;
+        if (g.accumulate) v += *dst;
+        *dst = v;
+    }
+}
+
+// out[m,n] = in[m,n] * gate(H[m,n]) : the elementwise "backward through dropout (and leaky
+// relu)" step applied to an upstream gradient before it enters a GEMM.
+__global__ void gate_kernel(const float* __restrict__ in, int ldi, const float* __restrict__ H, int ldh,
+                            float* __restrict__ out, int ldo, int M, int N, int gate_act, float alpha,
+                            const uint64_t* seed, uint32_t tag, uint32_t thr, float scale) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)M * N) return;
+    const int m = idx / N, n = idx % N;
+    uint32_t seed_lo = 0, seed_hi = 0;
+    if (seed != nullptr) { const uint64_t sd = *seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+    float gt = 1.f;
+    if (gate_act && H != nullptr) gt = lrelu_grad(H[(size_t)m * ldh + n], alpha);
+    if (thr) {
+        const uint32_t wd = drop_word(seed_lo, seed_hi, tag, (uint32_t)m, (uint32_t)(n >> 2));
+        gt = drop_keep(wd, n & 3, thr) ? gt * scale : 0.f;
+    }
+    out[(size_t)m * ldo + n] = in[(size_t)m * ldi + n] * gt;
+}
+
+// keep-mask materialiser for tests: mask[row, f] in {0,1} exactly as the kernels decide it
+__global__ void drop_mask_kernel(float* __restrict__ out, size_t rows, int F, const uint64_t* seed, uint32_t tag,
+                                 uint32_t thr) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * (size_t)F) return;
+    const size_t row = idx / F;
+    const int f = idx % F;
+    const uint64_t sd = *seed;
+    const uint32_t wd = drop_word((uint32_t)sd, (uint32_t)(sd >> 32), tag, (uint32_t)row, (uint32_t)(f >> 2));
+    out[idx] = (thr == 0 || drop_keep(wd, f & 3, thr)) ? 1.f : 0.f;
+}
+
+}  // namespace
+
+extern "C" int mpg_gemm(const MpgGemm* g, int ak, int bk, int splitk, void* stream) {
+    if (g->M <= 0 || g->N <= 0) return 0;
+    if (g->K < 0 || splitk < 1) return -1;
+    dim3 grid((g->N + 63) / 64, (g->M + 63) / 64, splitk), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define MPG_LAUNCH(AKV, BKV)                                                                              \
+    do {                                                                                                  \
+        if (g->f16) hipLaunchKernelGGL((gemm_kernel<AKV, BKV, true>), grid, block, 0, st, *g);           \
+        else hipLaunchKernelGGL((gemm_kernel<AKV, BKV, false>), grid, block, 0, st, *g);                 \
+    } while (0)
+    if (ak && bk) MPG_LAUNCH(true, true);
+    else if (ak && !bk) MPG_LAUNCH(true, false);
+    else if (!ak && !bk) MPG_LAUNCH(false, false);
+    else MPG_LAUNCH(false, true);
+#undef MPG_LAUNCH
+    return (int)hipGetLastError();
+}
+
+extern "C" int mpg_gate(const float* in, int ldi, const float* H, int ldh, float* out, int ldo, int M, int N,
+                        int gate_act, float alpha, const uint64_t* seed, uint32_t tag, uint32_t thr, float scale,
+                        void* stream) {
+    const size_t tot = (size_t)M * N;
+    if (tot == 0) return 0;
+    hipLaunchKernelGGL(gate_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, ldi, H, ldh, out,
+                       ldo, M, N, gate_act, alpha, seed, tag, thr, scale);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mpg_dropout_mask(float* out, uint64_t rows, int F, const uint64_t* seed, uint32_t tag, uint32_t thr,
+                                void* stream) {
+    const size_t tot = (size_t)rows * F;
+    if (tot == 0) return 0;
+    hipLaunchKernelGGL(drop_mask_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, (size_t)rows,
+                       F, seed, tag, thr);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,219 @@
+"""MPGAN networks on the fused MI355X hot path -- drop-in for the reference's ``mpgan`` package.
+
+Same class names, constructor keywords, ``forward`` signatures and state-dict key names as
+rkansal47/MPGAN ``mpgan/model.py`` (LinearNet :11-88, MPLayer :91-384, MPNet :387-569,
+MPGenerator :572-757, MPDiscriminator :760-894), so ``setup_training.setup_mpgan`` /
+``train.py`` / ``gen.py`` and published checkpoints work unchanged.  The arithmetic runs in
+libmpgan_amd.so (HIP, gfx950); there is no composite/CPU fallback -- option combinations the
+fused path does not cover raise ``NotImplementedError`` at construction time.
+
+Covered (= the reference's default and every published ``mp_*`` configuration): fully connected
+graph, no edge features, ``clabels=0``, ``mask_fne_np=False``, no batch/spectral norm,
+``fe=[96,160,192]``, two hidden ``fn`` layers, ``mask_c`` masking, ``dea`` pooling.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from .. import ops
+
+
+def _unsupported(**flags):
+    bad = [k for k, v in flags.items() if v]
+    if bad:
+        raise NotImplementedError(
+            "mpgan_amd: option(s) %s are outside the fused MI355X path (see DESIGN.md, scope)" % ", ".join(bad))
+
+
+class LinearNet(nn.Module):
+    """Stack of ``Linear -> LeakyReLU -> Dropout`` (last layer ``Linear -> Dropout`` when
+    ``final_linear``); parameters live in ``self.net`` so keys read ``net.{i}.weight|bias``."""
+
+    def __init__(self, layers: list, input_size: int = 0, output_size: int = 0, final_linear: bool = False,
+                 leaky_relu_alpha: float = 0.2, dropout_p: float = 0, batch_norm: bool = False,
+                 spectral_norm: bool = False):
+        super().__init__()
+        _unsupported(batch_norm=batch_norm, spectral_norm=spectral_norm)
+        widths = ([input_size] if input_size else []) + list(layers) + ([output_size] if output_size else [])
+        self.final_linear = final_linear
+        self.leaky_relu_alpha = leaky_relu_alpha
+        self.dropout_p = float(dropout_p)
+        self.net = nn.ModuleList(nn.Linear(i, o) for i, o in zip(widths[:-1], widths[1:]))
+
+    def forward(self, x: Tensor) -> Tensor:
+        last = len(self.net) - 1
+        for k, lin in enumerate(self.net):
+            act = not (self.final_linear and k == last)
+            x = ops.FusedLinearFn.apply(x, lin.weight, lin.bias, act, self.leaky_relu_alpha, self.dropout_p,
+                                        self.training)
+        return x
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}(net = {self.net})"
+
+
+class MPLayer(nn.Module):
+    """One message-passing iteration, executed by ``ops.FusedMPLayerFn`` (one fused edge kernel +
+    the node network)."""
+
+    def __init__(self, input_node_size: int, fe_layers: list, fn_layers: list, output_node_size: int,
+                 pos_diffs: bool = False, all_ef: bool = True, coords: str = "polarrel", delta_coords: bool = False,
+                 delta_r: bool = True, int_diffs: bool = False, clabels: int = 0, mask_fne_np: bool = False,
+                 fully_connected: bool = True, num_knn: int = 20, self_loops: bool = True, sum: bool = True,
+                 **linear_args):
+        super().__init__()
+        _unsupported(pos_diffs=pos_diffs, int_diffs=int_diffs, clabels=clabels, mask_fne_np=mask_fne_np,
+                     knn_graph=not fully_connected)
+        if list(fe_layers) != [ops.H1, ops.H2, ops.H3] or len(fn_layers) != 2:
+            raise NotImplementedError("mpgan_amd: the fused edge kernel is built for fe_layers=[96,160,192] and two "
+                                      f"hidden fn layers (got fe={list(fe_layers)}, fn={list(fn_layers)})")
+        self.input_node_size, self.output_node_size = input_node_size, output_node_size
+        self.fe_layers, self.fn_layers = list(fe_layers), list(fn_layers)
+        self.sum = sum
+        self.fe = LinearNet(self.fe_layers, input_size=2 * input_node_size, final_linear=False, **linear_args)
+        self.fn = LinearNet(self.fn_layers, input_size=self.fe_layers[-1] + input_node_size,
+                            output_size=output_node_size, final_linear=True, **linear_args)
+
+    def forward(self, x: Tensor, use_mask: bool = False, mask: Tensor = None, labels: Tensor = None,
+                num_jet_particles: Tensor = None) -> Tensor:
+        assert not (use_mask and mask is None), "need ``mask`` tensor if using ``use_mask`` option"
+        fe, fn = self.fe.net, self.fn.net
+        return ops.FusedMPLayerFn.apply(
+            x, mask if use_mask else None,
+            fe[0].weight, fe[0].bias, fe[1].weight, fe[1].bias, fe[2].weight, fe[2].bias,
+            fn[0].weight, fn[0].bias, fn[1].weight, fn[1].bias, fn[2].weight, fn[2].bias,
+            self.sum, self.fe.leaky_relu_alpha, self.fe.dropout_p, self.training)
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}(fe = {self.fe}, \n fn = {self.fn})"
+
+
+class MPNet(nn.Module):
+    """``mp_iters`` MPLayers with generator-/discriminator-specific hooks around them."""
+
+    def __init__(self, num_particles: int, input_node_size: int, mp_iters: int = 2,
+                 fe_layers: list = [96, 160, 192], fn_layers: list = [256, 256], fe1_layers: list = None,
+                 fn1_layers: list = None, hidden_node_size: int = 32, output_node_size: int = 0,
+                 final_activation: str = "", linear_args: dict = {}, mp_args: dict = {},
+                 mp_args_first_layer: dict = {}, mask_args: dict = {}):
+        super().__init__()
+        self.num_particles = num_particles
+        self.input_node_size = input_node_size
+        self.hidden_node_size = hidden_node_size
+        self.output_node_size = output_node_size if output_node_size > 0 else hidden_node_size
+        self.mp_iters = mp_iters
+        self.final_activation = final_activation
+        self.linear_args = linear_args
+        self.mask_args = mask_args
+        first = {**mp_args, **mp_args_first_layer}
+        self._init_mask(**mask_args)
+        sizes = [input_node_size] + [hidden_node_size] * (mp_iters - 1) + [self.output_node_size]
+        self.mp_layers = nn.ModuleList()
+        for k in range(mp_iters):
+            fe_k = (fe1_layers or fe_layers) if k == 0 else fe_layers
+            fn_k = (fn1_layers or fn_layers) if k == 0 else fn_layers
+            self.mp_layers.append(MPLayer(sizes[k], fe_k, fn_k, sizes[k + 1], **(first if k == 0 else mp_args),
+                                          **linear_args))
+
+    def forward(self, x: Tensor, labels: Tensor = None) -> Tensor:
+        x = self._pre_mp(x, labels)
+        x, use_mask, mask, njp = self._get_mask(x, labels, **self.mask_args)
+        for layer in self.mp_layers:
+            x = layer(x, use_mask, mask, labels, njp)
+        x = self._post_mp(x, labels, use_mask, mask, njp)
+        if self.final_activation == "tanh":
+            x = torch.tanh(x)
+        elif self.final_activation == "sigmoid":
+            x = torch.sigmoid(x)
+        return self._final_mask(x, mask, **self.mask_args)
+
+    # hooks
+    def _init_mask(self, **mask_args):
+        pass
+
+    def _pre_mp(self, x, labels):
+        return x
+
+    def _get_mask(self, x, labels, **mask_args):
+        return x, False, None, None
+
+    def _post_mp(self, x, labels, use_mask, mask, num_jet_particles):
+        return x
+
+    def _final_mask(self, x, mask, **mask_args):
+        return x
+
+    def __repr__(self):
+        return f"MPLayers = {self.mp_layers})"
+
+
+def _rank_mask(first_feature: Tensor, labels: Tensor, num_particles: int) -> Tensor:
+    """mask_c: the n = int(label * N) lowest-noise particles are real (reference :689-699)."""
+    n_minus_1 = (labels[:, -1] * num_particles).int() - 1
+    rank = first_feature.argsort(1).argsort(1)
+    return (rank <= n_minus_1.unsqueeze(1)).unsqueeze(2).float()
+
+
+class MPGenerator(MPNet):
+    def __init__(self, lfc: bool = False, lfc_latent_size: int = 128, **mpnet_args):
+        super().__init__(**mpnet_args)
+        self.lfc = lfc
+        if lfc:
+            self.lfc_layer = nn.Linear(lfc_latent_size, self.num_particles * self.input_node_size)
+
+    def _init_mask(self, mask_learn: bool = False, mask_learn_sep: bool = False, fmg: list = [64], **mask_args):
+        _unsupported(mask_learn=mask_learn, mask_learn_sep=mask_learn_sep)
+
+    def _pre_mp(self, x, labels):
+        if self.lfc:
+            x = ops.FusedLinearFn.apply(x, self.lfc_layer.weight, self.lfc_layer.bias, False, 0.2, 0.0, False)
+            x = x.reshape(x.shape[0], self.num_particles, self.input_node_size)
+        return x
+
+    def _get_mask(self, x, labels=None, mask_learn=False, mask_learn_bin=True, mask_learn_sep=False, mask_c=True,
+                  mask_fne_np=False, **mask_args):
+        if not mask_c:
+            return x, False, None, None
+        return x, True, _rank_mask(x[:, :, 0], labels, self.num_particles), None
+
+    def _final_mask(self, x, mask, mask_feat_bin: bool = False, **mask_args):
+        _unsupported(mask_feat_bin=mask_feat_bin)
+        return torch.cat((x, mask - 0.5), dim=2) if mask is not None else x
+
+    def __repr__(self):
+        lfc_str = f"LFC = {self.lfc_layer},\n" if self.lfc else ""
+        return f"{self.__class__.__name__}({lfc_str}MPLayers = {self.mp_layers})"
+
+
+class MPDiscriminator(MPNet):
+    def __init__(self, dea: bool = True, dea_sum: bool = True, fnd: list = [], mask_fnd_np: bool = False,
+                 **mpnet_args):
+        super().__init__(output_node_size=1 if not dea else 0, **mpnet_args)
+        _unsupported(mask_fnd_np=mask_fnd_np)
+        self.dea, self.dea_sum, self.mask_fnd_np = dea, dea_sum, mask_fnd_np
+        if dea:
+            self.fnd_layer = LinearNet(fnd, input_size=self.hidden_node_size, output_size=1, final_linear=True,
+                                       **self.linear_args)
+
+    def _get_mask(self, x, labels, mask_manual=False, mask_learn=False, mask_learn_sep=False, mask_c=True,
+                  mask_fne_np=False, mask_fnd_np=False, **mask_args):
+        if not (mask_manual or mask_learn or mask_c or mask_learn_sep):
+            return x, False, None, None
+        return x[:, :, :-1], True, x[:, :, -1:] + 0.5, None
+
+    def _post_mp(self, x, labels, use_mask, mask, num_jet_particles):
+        mean = not (self.dea and self.dea_sum)
+        if use_mask:
+            x = (x * mask).sum(1)
+            if mean:
+                x = x / (mask.sum(1) + 1e-12)
+        else:
+            x = x.mean(1) if mean else x.sum(1)
+        return self.fnd_layer(x) if self.dea else x
+
+    def __repr__(self):
+        dea_str = f",\nFND = {self.fnd_layer}" if self.dea else ""
+        return f"{self.__class__.__name__}(MPLayers = {self.mp_layers}{dea_str})"

@@ -1,0 +1,340 @@
+"""torch.autograd front-ends over the C ABI (include/mpgan_amd.h).
+
+Everything here hands raw device pointers + sizes to libmpgan_amd.so on torch's current HIP
+stream; torch is used for memory, autograd bookkeeping and a few tiny reductions only.  There is
+no CPU path: tensors must live on a gfx950 device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import itertools
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import MpgGemm, MpgEdgeFwd, MpgEdgeBwd, check
+
+H1, H2, H3 = 96, 160, 192
+TAG_E0, TAG_E1, TAG_E2, TAG_N0, TAG_N1, TAG_N2, TAG_GENERIC = 1, 2, 3, 4, 5, 6, 7
+
+# ------------------------------------------------------------------------------------- state
+_seed = {}
+_tag_counter = itertools.count(1)
+OPTIONS = {
+    "weights_in_lds": True,   # edge forward: W3 (hi,lo) + W2 hi resident in LDS
+    "skip_masked": True,      # edge forward: skip zero-masked senders (they contribute exactly 0)
+    # forward products (they decide LeakyReLU signs) split as fp16 hi/lo (~2^-21 per product);
+    # False = bf16 hi/lo (~2^-17, unlimited range).  Gradient products are always bf16 hi/lo.
+    "fwd_f16": True,
+}
+
+
+def seed_tensor(device) -> torch.Tensor:
+    """Per-device 64-bit dropout seed living in device memory (so that a captured hipGraph sees
+    a new value on every replay).  ``bump_seed`` advances it; call once per training iteration."""
+    key = torch.device(device).index or 0
+    if key not in _seed:
+        _seed[key] = torch.full((1,), 0x243F6A8885A308D3, dtype=torch.int64, device=device)
+    return _seed[key]
+
+
+def set_seed(value: int, device="cuda"):
+    seed_tensor(device).fill_(value & 0x7FFFFFFFFFFFFFFF)
+
+
+def bump_seed(device="cuda"):
+    seed_tensor(device).add_(0x1E3779B97F4A7C15)
+
+
+def next_tag() -> int:
+    """A fresh dropout-site tag base (8 sites per call) for one fused-op invocation."""
+    return (next(_tag_counter) % (1 << 24)) * 8
+
+
+def drop_params(p: float):
+    """thr = round(256 p) (keep <=> byte >= thr); scale = 256/(256-thr)."""
+    thr = int(round(256.0 * p))
+    if thr <= 0:
+        return 0, 1.0
+    if thr >= 256:
+        raise ValueError("dropout p too close to 1")
+    return thr, 256.0 / (256.0 - thr)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor], offset_elems: int = 0):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr() + 4 * offset_elems)
+
+
+def _chk(t: torch.Tensor, name: str):
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise RuntimeError(f"{name}: expected a float32 tensor on the GPU (got {t.dtype} on {t.device}); "
+                           "mpgan_amd has no CPU path")
+
+
+# ------------------------------------------------------------------------------------- GEMM
+def gemm(A, lda, B, ldb, Cout, ldc, M, N, K, *, ak=True, bk=True, a_off=0, b_off=0, c_off=0,
+         A2=None, lda2=0, K1=0, bias=None, out_scale=1.0, act=False, alpha=0.2,
+         drop=None, gate=None, resid=None, ldr=0, accumulate=False, splitk=1, split_stride=0, f16=False):
+    """Thin wrapper of mpg_gemm.  drop = (seed_t, tag, thr, scale) applies forward dropout to C;
+    gate = (H, ldh, gate_act, seed_t, tag, thr, scale) multiplies C by d(dropout o act)/dz."""
+    g = MpgGemm()
+    g.A, g.A2, g.lda, g.lda2, g.K1 = _p(A, a_off), _p(A2), lda, lda2, K1
+    g.B, g.ldb = _p(B, b_off), ldb
+    g.C, g.ldc = _p(Cout, c_off), ldc
+    g.M, g.N, g.K = M, N, K
+    g.split_stride = split_stride
+    g.bias, g.out_scale, g.act, g.alpha = _p(bias), out_scale, int(act), alpha
+    g.seed = None
+    if drop is not None and drop[2]:
+        g.seed = _p(drop[0]); g.drop_tag, g.drop_thr, g.drop_scale = drop[1], drop[2], drop[3]
+    if gate is not None:
+        H, ldh, gact, seed_t, tag, thr, scale = gate
+        g.gateH, g.ldh, g.gate_act = _p(H), ldh, int(gact)
+        if thr:
+            g.seed = _p(seed_t); g.gate_tag, g.gate_thr, g.gate_scale = tag, thr, scale
+    g.resid, g.ldr = _p(resid), ldr
+    g.accumulate = int(accumulate)
+    g.f16 = int(f16)
+    check(_lib.lib().mpg_gemm(C.byref(g), int(ak), int(bk), splitk, _stream()), "mpg_gemm")
+
+
+def linear_fwd(x, W, bias=None, *, act=False, alpha=0.2, drop=None, x2=None, w_col0=0, w_cols=None, resid=None):
+    """y = drop(act([x | x2] @ W[:, w_col0:w_col0+K]^T + bias)) (+ resid).  x [M,K1], W [N,ldw]."""
+    M, K1 = x.shape
+    K2 = 0 if x2 is None else x2.shape[1]
+    K = K1 + K2 if w_cols is None else w_cols
+    N = W.shape[0]
+    y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    gemm(x, x.stride(0), W, W.stride(0), y, N, M, N, K, ak=True, bk=True, b_off=w_col0,
+         A2=x2, lda2=0 if x2 is None else x2.stride(0), K1=K1, bias=bias, act=act, alpha=alpha, drop=drop,
+         resid=resid, ldr=0 if resid is None else resid.stride(0), f16=OPTIONS["fwd_f16"])
+    return y
+
+
+def linear_bwd_data(dy, W, *, w_col0=0, w_cols=None, gate=None, out=None, accumulate=False, alpha=0.2):
+    """dx = (dy @ W[:, w_col0:w_col0+K]) * gate.   dy [M,N], W [N,ldw] -> dx [M,K]."""
+    M, N = dy.shape
+    K = (W.shape[1] - w_col0) if w_cols is None else w_cols
+    if out is None:
+        out = torch.empty((M, K), device=dy.device, dtype=torch.float32)
+    gemm(dy, dy.stride(0), W, W.stride(0), out, out.stride(0), M, K, N, ak=True, bk=False, b_off=w_col0,
+         gate=gate, accumulate=accumulate, alpha=alpha)
+    return out
+
+
+def linear_bwd_weight(dy, x, *, out=None, out_col0=0, out_scale=1.0):
+    """dW[:, out_col0:out_col0+K] = out_scale * dy^T @ x.   dy [M,N], x [M,K] -> dW [N,K] (split-K)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    if out is None:
+        out = torch.empty((N, K), device=dy.device, dtype=torch.float32)
+    ldc = out.stride(0)
+    tiles = ((N + 63) // 64) * ((K + 63) // 64)
+    splitk = max(1, min((M + 255) // 256, (1024 + tiles - 1) // tiles))
+    if splitk == 1:
+        gemm(dy, dy.stride(0), x, x.stride(0), out, ldc, N, K, M, ak=False, bk=False, c_off=out_col0,
+             out_scale=out_scale)
+        return out
+    part = torch.empty((splitk, N, K), device=dy.device, dtype=torch.float32)
+    gemm(dy, dy.stride(0), x, x.stride(0), part, K, N, K, M, ak=False, bk=False, out_scale=out_scale,
+         splitk=splitk, split_stride=N * K)
+    red = part.sum(0)
+    if out_col0 == 0 and out.shape[1] == K:
+        out.copy_(red)
+    else:
+        out[:, out_col0:out_col0 + K] = red
+    return out
+
+
+def gate(g, H, *, gate_act, alpha, seed_t=None, tag=0, thr=0, scale=1.0):
+    M, N = g.shape
+    out = torch.empty((M, N), device=g.device, dtype=torch.float32)
+    check(_lib.lib().mpg_gate(_p(g), g.stride(0), _p(H), 0 if H is None else H.stride(0), _p(out), N, M, N,
+                              int(gate_act), alpha, _p(seed_t), tag, thr, scale, _stream()), "mpg_gate")
+    return out
+
+
+def dropout_mask(rows: int, F: int, tag: int, thr: int, device="cuda"):
+    """The {0,1} keep mask [rows, F] of dropout site ``tag`` under the current seed (tests)."""
+    out = torch.empty((rows, F), device=device, dtype=torch.float32)
+    check(_lib.lib().mpg_dropout_mask(_p(out), rows, F, _p(seed_tensor(device)), tag, thr, _stream()),
+          "mpg_dropout_mask")
+    return out
+
+
+# ------------------------------------------------------------------------------------- edge
+def pack_weights(W, rows, cols, *, col0=0, transpose=False, scale=1.0, f16=False):
+    """bf16 hi/lo fragment image of W[:, col0:col0+cols] (or its transpose)."""
+    r, c = (cols, rows) if transpose else (rows, cols)
+    MT, QT = (r + 31) // 32, (c + 31) // 32
+    img = torch.empty((2 * MT * QT * 2 * 512,), device=W.device, dtype=torch.bfloat16)
+    check(_lib.lib().mpg_pack_weights(_p(W, col0), W.stride(0), r, c, int(transpose), scale, int(f16),
+                                      C.c_void_p(img.data_ptr()), _stream()), "mpg_pack_weights")
+    return img
+
+
+def _sender_chunks(B, N):
+    """Number of sender chunks so that the grid fills the chip (256 CUs) when B*RB is small."""
+    RB = (N + 31) // 32
+    wg = B * RB
+    sc = 1
+    while wg * sc < 512 and (N + sc - 1) // sc > 8:
+        sc *= 2
+    return sc
+
+
+class FusedMPLayerFn(torch.autograd.Function):
+    """MPLayer.forward (mpgan/model.py:206-282), default configuration: fully connected, no edge
+    features, no conditioning labels; fe = 3 layers [96,160,192], fn = 2 hidden layers + linear."""
+
+    @staticmethod
+    def forward(ctx, x, mask, W1, b1, W2, b2, W3, b3, V1, c1, V2, c2, V3, c3, sum_agg, alpha, p_drop, training):
+        _chk(x, "x")
+        B, N, F = x.shape
+        V = B * N
+        dev = x.device
+        thr, dscale = drop_params(p_drop) if training else (0, 1.0)
+        seed_t = seed_tensor(dev)
+        tag = next_tag()
+        x2 = x.reshape(V, F).contiguous()
+        m1 = None if mask is None else mask.reshape(V).contiguous()
+
+        def dr(site):
+            return (seed_t, tag + site, thr, dscale) if thr else None
+
+        a = linear_fwd(x2, W1, b1, w_cols=F)
+        c = linear_fwd(x2, W1, None, w_col0=F, w_cols=F)
+        f16 = OPTIONS["fwd_f16"]
+        W2img = pack_weights(W2, H2, H1, scale=dscale, f16=f16)
+        W3img = pack_weights(W3, H3, H2, scale=dscale, f16=f16)
+        SC = _sender_chunks(B, N)
+        aggp = torch.empty((SC, V, H3), device=dev, dtype=torch.float32)
+        e = MpgEdgeFwd()
+        e.a, e.c, e.mask = _p(a), _p(c), _p(m1)
+        e.W2img, e.W3img = C.c_void_p(W2img.data_ptr()), C.c_void_p(W3img.data_ptr())
+        e.b2, e.b3, e.agg = _p(b2), _p(b3), _p(aggp)
+        e.B, e.N, e.SC = B, N, SC
+        e.alpha, e.agg_scale = alpha, 1.0 if sum_agg else 1.0 / N
+        e.seed, e.tag_base, e.thr, e.dscale = _p(seed_t), tag, thr, dscale
+        e.skip_masked = int(OPTIONS["skip_masked"])
+        e.weights_in_lds = int(OPTIONS["weights_in_lds"])
+        e.f16 = int(f16)
+        check(_lib.lib().mpg_edge_fwd(C.byref(e), _stream()), "mpg_edge_fwd")
+        agg = aggp[0] if SC == 1 else aggp.sum(0)
+
+        h1 = linear_fwd(agg, V1, c1, act=True, alpha=alpha, drop=dr(TAG_N0), x2=x2)
+        h2 = linear_fwd(h1, V2, c2, act=True, alpha=alpha, drop=dr(TAG_N1))
+        y = linear_fwd(h2, V3, c3, act=False, drop=dr(TAG_N2))
+
+        ctx.save_for_backward(x2, m1, a, c, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3)
+        ctx.cfg = (B, N, F, sum_agg, alpha, thr, dscale, tag, SC, f16)
+        return y.reshape(B, N, V3.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, m1, a, c, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3 = ctx.saved_tensors
+        B, N, F, sum_agg, alpha, thr, dscale, tag, SC, f16 = ctx.cfg
+        V = B * N
+        dev = x2.device
+        seed_t = seed_tensor(dev)
+        gy2 = gy.reshape(V, -1).contiguous()
+
+        def gt(H, site, act):
+            return (H, H.stride(0), act, seed_t, tag + site, thr, dscale)
+
+        # ---- node network fn (mpgan/model.py:279) backward
+        dz3 = gate(gy2, None, gate_act=False, alpha=alpha, seed_t=seed_t, tag=tag + TAG_N2, thr=thr, scale=dscale) \
+            if thr else gy2
+        dV3 = linear_bwd_weight(dz3, h2)
+        dc3 = dz3.sum(0)
+        dz2 = linear_bwd_data(dz3, V3, gate=gt(h2, TAG_N1, True), alpha=alpha)
+        dV2 = linear_bwd_weight(dz2, h1)
+        dc2 = dz2.sum(0)
+        dz1 = linear_bwd_data(dz2, V2, gate=gt(h1, TAG_N0, True), alpha=alpha)
+        dV1 = torch.empty_like(V1)
+        linear_bwd_weight(dz1, agg, out=dV1, out_col0=0)
+        linear_bwd_weight(dz1, x2, out=dV1, out_col0=H3)
+        dc1 = dz1.sum(0)
+        dh0 = linear_bwd_data(dz1, V1)  # [V, 192+F] = [dagg | dx(node path)]
+
+        # ---- edge network backward
+        W2img = pack_weights(W2, H2, H1, scale=dscale, f16=f16)
+        W3img = pack_weights(W3, H3, H2, scale=dscale, f16=f16)
+        W3Timg = pack_weights(W3, H3, H2, transpose=True, scale=dscale)
+        W2Timg = pack_weights(W2, H2, H1, transpose=True, scale=dscale)
+        RB = (N + 31) // 32
+        E = V * N
+        dap = torch.empty((SC, V, H1), device=dev, dtype=torch.float32)
+        dcp = torch.empty((RB, V, H1), device=dev, dtype=torch.float32)
+        E1 = torch.empty((E, H1), device=dev, dtype=torch.float32)
+        E2 = torch.empty((E, H2), device=dev, dtype=torch.float32)
+        dZ2 = torch.empty((E, H2), device=dev, dtype=torch.float32)
+        dZ3 = torch.empty((E, H3), device=dev, dtype=torch.float32)
+        e = MpgEdgeBwd()
+        e.a, e.c, e.mask = _p(a), _p(c), _p(m1)
+        e.dagg, e.ld_dagg = _p(dh0), dh0.stride(0)
+        e.W2img, e.W3img = C.c_void_p(W2img.data_ptr()), C.c_void_p(W3img.data_ptr())
+        e.W3Timg, e.W2Timg = C.c_void_p(W3Timg.data_ptr()), C.c_void_p(W2Timg.data_ptr())
+        e.b2, e.b3 = _p(b2), _p(b3)
+        e.da, e.dc = _p(dap), _p(dcp)
+        e.E1, e.E2, e.dZ2, e.dZ3 = _p(E1), _p(E2), _p(dZ2), _p(dZ3)
+        e.B, e.N, e.SC = B, N, SC
+        e.alpha, e.agg_scale = alpha, 1.0 if sum_agg else 1.0 / N
+        e.seed, e.tag_base, e.thr, e.dscale = _p(seed_t), tag, thr, dscale
+        e.f16 = int(f16)
+        check(_lib.lib().mpg_edge_bwd(C.byref(e), _stream()), "mpg_edge_bwd")
+        da = dap[0] if SC == 1 else dap.sum(0)
+        dc = dcp[0] if RB == 1 else dcp.sum(0)
+        dW3 = linear_bwd_weight(dZ3, E2, out_scale=dscale)
+        db3 = dZ3.sum(0)
+        dW2 = linear_bwd_weight(dZ2, E1, out_scale=dscale)
+        db2 = dZ2.sum(0)
+        del E1, E2, dZ2, dZ3
+
+        # ---- layer 1 (fe.net.0): a = W1[:, :F] x + b1, c = W1[:, F:] x
+        dW1 = torch.empty_like(W1)
+        linear_bwd_weight(da, x2, out=dW1, out_col0=0)
+        linear_bwd_weight(dc, x2, out=dW1, out_col0=F)
+        db1 = da.sum(0)
+        dx = dh0[:, H3:].contiguous()
+        linear_bwd_data(da, W1, w_cols=F, out=dx, accumulate=True)
+        linear_bwd_data(dc, W1, w_col0=F, w_cols=F, out=dx, accumulate=True)
+        return (dx.reshape(B, N, F), None, dW1, db1, dW2, db2, dW3, db3, dV1, dc1, dV2, dc2, dV3, dc3,
+                None, None, None, None)
+
+
+class FusedLinearFn(torch.autograd.Function):
+    """Linear -> [LeakyReLU] -> [Dropout] (one LinearNet layer; mpgan/model.py:77-83)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act, alpha, p_drop, training):
+        _chk(x, "x")
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous()
+        thr, dscale = drop_params(p_drop) if training else (0, 1.0)
+        seed_t = seed_tensor(x.device)
+        tag = next_tag()
+        y = linear_fwd(x2, W, b, act=act, alpha=alpha, drop=(seed_t, tag + TAG_GENERIC, thr, dscale) if thr else None)
+        ctx.save_for_backward(x2, W, y)
+        ctx.cfg = (shp, act, alpha, thr, dscale, tag, b is not None)
+        return y.reshape(*shp[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, W, y = ctx.saved_tensors
+        shp, act, alpha, thr, dscale, tag, has_b = ctx.cfg
+        g2 = gy.reshape(-1, W.shape[0]).contiguous()
+        if act or thr:
+            g2 = gate(g2, y, gate_act=act, alpha=alpha, seed_t=seed_tensor(g2.device), tag=tag + TAG_GENERIC,
+                      thr=thr, scale=dscale)
+        dW = linear_bwd_weight(g2, x2)
+        db = g2.sum(0) if has_b else None
+        dx = linear_bwd_data(g2, W)
+        return dx.reshape(shp), dW, db, None, None, None, None

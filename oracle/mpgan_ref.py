@@ -103,6 +103,7 @@ def mplayer_forward(
     n_fe: int = 3,
     n_fn: int = 3,
     exact_concat: bool = False,
+    probe: Optional[list] = None,
 ) -> Tensor:
     """One fully-connected message-passing layer.
 
@@ -124,11 +125,16 @@ def mplayer_forward(
         a = x @ w1[:, :F].t() + b1  # receiver term  [B,N,H1]
         c = x @ w1[:, F:].t()  # sender term    [B,N,H1]
         e = a.unsqueeze(2) + c.unsqueeze(1)  # [B,N(i),N(j),H1]
+    if probe is not None:  # pre-activations, for the tests' distance-from-the-kink check
+        probe.append(e.detach())
     e = _drop(leaky(e, alpha), k.get("e0"), p)
     for l in range(1, n_fe):
         w = sd[f"{prefix}.fe.net.{l}.weight"]
         b = sd[f"{prefix}.fe.net.{l}.bias"]
-        e = _drop(leaky(e @ w.t() + b, alpha), k.get(f"e{l}"), p)
+        e = e @ w.t() + b
+        if probe is not None:
+            probe.append(e.detach())
+        e = _drop(leaky(e, alpha), k.get(f"e{l}"), p)
     if mask is not None:
         e = e * mask.reshape(B, 1, N, 1)
     agg = e.sum(dim=2)
@@ -140,6 +146,8 @@ def mplayer_forward(
         b = sd[f"{prefix}.fn.net.{l}.bias"]
         h = h @ w.t() + b
         if l != n_fn - 1:
+            if probe is not None:
+                probe.append(h.detach())
             h = leaky(h, alpha)
         h = _drop(h, k.get(f"n{l}"), p)
     return h

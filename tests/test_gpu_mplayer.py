@@ -1,0 +1,201 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle, fp32 tolerance 1e-3 relative.
+
+Metric everywhere: max|got - ref| / max|ref| per tensor (conftest.rel_err); the north-star bar is
+1e-3, the bf16x3 kernels are expected (and asserted) to sit near 1e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3       # BASELINE.json north_star: "within 1e-3 rel fp32"
+TIGHT = 1e-4     # what the split-bf16 path actually delivers (margin asserted)
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def test_library_loaded():
+    import mpgan_amd
+    lib = mpgan_amd._lib.lib()
+    assert lib.mpg_gemm and lib.mpg_edge_fwd and lib.mpg_edge_bwd
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (7680, 256, 224), (100, 3, 256), (37, 195, 6), (1, 1, 1),
+                                   (513, 96, 64)])
+def test_gemm_nt(M, N, K):
+    from mpgan_amd import ops
+    rs = np.random.RandomState(M + N + K)
+    x = torch.from_numpy(rs.normal(size=(M, K))).float().to(_dev())
+    w = torch.from_numpy(rs.normal(size=(N, K))).float().to(_dev())
+    b = torch.from_numpy(rs.normal(size=(N,))).float().to(_dev())
+    y = ops.linear_fwd(x, w, b, act=True, alpha=0.2)
+    ref = x.double() @ w.double().t() + b.double()
+    ref = torch.where(ref > 0, ref, 0.2 * ref)
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < TIGHT
+
+
+@pytest.mark.parametrize("M,N,K", [(7680, 256, 224), (100, 3, 256), (37, 195, 6), (230400 // 8, 192, 160)])
+def test_gemm_bwd_forms(M, N, K):
+    from mpgan_amd import ops
+    rs = np.random.RandomState(M + N + K + 1)
+    dy = torch.from_numpy(rs.normal(size=(M, N))).float().to(_dev())
+    w = torch.from_numpy(rs.normal(size=(N, K))).float().to(_dev())
+    x = torch.from_numpy(rs.normal(size=(M, K))).float().to(_dev())
+    dx = ops.linear_bwd_data(dy, w)
+    assert rel_err(dx.cpu().numpy(), (dy.double() @ w.double()).cpu().numpy()) < TIGHT
+    dw = ops.linear_bwd_weight(dy, x)
+    assert rel_err(dw.cpu().numpy(), (dy.double().t() @ x.double()).cpu().numpy()) < TIGHT
+
+
+def test_gemm_two_segments_and_slices():
+    from mpgan_amd import ops
+    rs = np.random.RandomState(3)
+    M, K1, K2, N = 300, 192, 3, 256
+    a = torch.from_numpy(rs.normal(size=(M, K1))).float().to(_dev())
+    x = torch.from_numpy(rs.normal(size=(M, K2))).float().to(_dev())
+    w = torch.from_numpy(rs.normal(size=(N, K1 + K2))).float().to(_dev())
+    y = ops.linear_fwd(a, w, None, x2=x)
+    ref = torch.cat((a, x), 1).double() @ w.double().t()
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < TIGHT
+    # column slice of W as the operand (layer-1 factorisation uses W1[:, :F] and W1[:, F:])
+    y2 = ops.linear_fwd(x, w, None, w_col0=K1, w_cols=K2)
+    assert rel_err(y2.cpu().numpy(), (x.double() @ w[:, K1:].double().t()).cpu().numpy()) < TIGHT
+
+
+def _mplayer_shapes(F, out):
+    from test_oracle_golden import mplayer_shapes
+    return mplayer_shapes(F, out)
+
+
+def _run_case(B, N, F, out, use_mask, sum_agg, seed, lds=True, skip=True, alpha=0.2):
+    """HIP MPLayer vs fp64 oracle on the same inputs.  Returns per-tensor
+    (max-norm error, fraction of elements off by more than 1e-3 of the max) and the oracle's
+    kink margin = min |pre-activation| / max |pre-activation| over all LeakyReLU inputs."""
+    import oracle
+    from oracle import train_ref as T
+    from mpgan_amd import ops
+    from mpgan_amd.mpgan import MPLayer
+    ops.OPTIONS["weights_in_lds"] = lds
+    ops.OPTIONS["skip_masked"] = skip
+    rs = np.random.RandomState(1000 + seed)
+    sd64 = T.init_state_dict(_mplayer_shapes(F, out), seed=seed, dtype=torch.float64)
+    layer = MPLayer(F, [96, 160, 192], [256, 256], out, sum=sum_agg, leaky_relu_alpha=alpha).to(_dev())
+    layer.load_state_dict({k: v.float() for k, v in sd64.items()})
+    x64 = torch.from_numpy(rs.normal(0, 0.5, size=(B, N, F)))
+    g64 = torch.from_numpy(rs.normal(size=(B, N, out)))
+    mask64 = None
+    if use_mask:
+        m = np.zeros((B, N, 1))
+        for b in range(B):
+            m[b, rs.permutation(N)[: rs.randint(1, N + 1)], 0] = 1
+        mask64 = torch.from_numpy(m)
+    sdo = {"L." + k: v.clone().requires_grad_(True) for k, v in sd64.items()}
+    xo = x64.clone().requires_grad_(True)
+    probe = []
+    yo = oracle.mplayer_forward(sdo, "L", xo, mask64, sum_agg=sum_agg, alpha=alpha, probe=probe)
+    (yo * g64).sum().backward()
+    margin = min(float(z.abs().min() / z.abs().max()) for z in probe)
+    x = x64.float().to(_dev()).requires_grad_(True)
+    mask = None if mask64 is None else mask64.float().to(_dev())
+    y = layer(x, use_mask, mask)
+    (y * g64.float().to(_dev())).sum().backward()
+    torch.cuda.synchronize()
+    ops.OPTIONS["weights_in_lds"] = True
+    ops.OPTIONS["skip_masked"] = True
+    pairs = {"y": (y.detach(), yo.detach()), "dx": (x.grad, xo.grad)}
+    for k, p in layer.named_parameters():
+        pairs[k] = (p.grad, sdo["L." + k].grad)
+    errs, frac = {}, {}
+    for k, (a, b) in pairs.items():
+        a = a.double().cpu().numpy()
+        b = b.numpy()
+        errs[k] = rel_err(a, b)
+        frac[k] = float((np.abs(a - b) > 1e-3 * np.abs(b).max()).mean())
+    return errs, frac, margin
+
+
+CASES = [  # B, N, F, out, mask, sum
+    (4, 30, 32, 32, True, True), (4, 30, 3, 32, True, True), (4, 30, 32, 3, True, True),
+    (2, 150, 32, 32, True, True), (3, 30, 32, 32, True, False), (3, 30, 32, 32, False, True),
+    (2, 5, 32, 32, True, True), (1, 1, 32, 32, False, True), (2, 33, 32, 32, True, True),
+    (2, 32, 3, 32, True, True),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_mplayer_slope1_strict(case):
+    """LeakyReLU slope 1 makes the layer smooth: every GEMM orientation, reduction and layout of
+    the forward AND backward path must then agree with the fp64 oracle to bf16x3 accuracy."""
+    errs, _, _ = _run_case(*case, seed=CASES.index(case), alpha=1.0)
+    bad = {k: v for k, v in errs.items() if not v < TIGHT}
+    assert not bad, (bad, errs)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_mplayer_vs_oracle(case):
+    """Default slope 0.2.  Forward: strict.  Gradients: LeakyReLU' jumps at 0, so an element
+    whose pre-activation lies within the forward rounding error of zero (|z| ~ 1e-5 of the
+    scale here, ~1e-7 for the reference's own fp32 arithmetic) may take the other slope; that
+    is a property of the function, not an arithmetic error.  Hence: at most a few % of the
+    elements of any gradient tensor may differ by more than 1e-3 of its max (each flip touches
+    one edge row; here, with a handful of jets, a flipped edge moves the summed gradients by ~1 %,
+    at B = 256 by ~1e-4 -- test_mplayer_full_size)."""
+    errs, frac, margin = _run_case(*case, seed=CASES.index(case))
+    assert errs["y"] < TIGHT, errs
+    # gross-error bound only: a single flipped edge shifts these small sums by ~1 %; exactness of
+    # the gradient path is pinned by the slope-1 and the margin-checked tests around this one
+    bad = {k: (errs[k], frac[k]) for k in errs if errs[k] > 5e-2}
+    assert not bad, (bad, margin)
+
+
+def test_mplayer_small_strict_gradients():
+    """Small graphs whose every pre-activation is verifiably away from the kink
+    (margin asserted from the fp64 oracle): gradients must then match strictly."""
+    found = 0
+    for seed in range(200, 260):
+        for case in ((1, 4, 32, 32, True, True), (1, 5, 3, 32, False, True), (1, 3, 32, 3, True, False)):
+            errs, _, margin = _run_case(*case, seed=seed)
+            if margin < 5e-5:
+                continue
+            found += 1
+            assert max(errs.values()) < TIGHT, (case, seed, margin, errs)
+    assert found >= 5, found
+
+
+def test_mplayer_global_weights_and_noskip():
+    for lds, skip in ((False, True), (True, False), (False, False)):
+        errs, _, _ = _run_case(4, 30, 32, 32, True, True, seed=42, lds=lds, skip=skip, alpha=1.0)
+        assert max(errs.values()) < TIGHT, (lds, skip, errs)
+
+
+@pytest.mark.parametrize("name,F,out,ci", [("g0", 32, 32, 0), ("d0", 3, 32, 1)])
+def test_mplayer_vs_reference_golden(name, F, out, ci):
+    """Directly against outputs captured from the reference implementation (fp32 goldens)."""
+    from oracle import train_ref as T
+    from mpgan_amd.mpgan import MPLayer
+    g = load_golden(f"mplayer_{name}_f32.npz")
+    layer = MPLayer(F, [96, 160, 192], [256, 256], out).to(_dev())
+    layer.load_state_dict(T.init_state_dict(_mplayer_shapes(F, out), seed=ci, dtype=torch.float32))
+    x = torch.from_numpy(g["x"]).to(_dev()).requires_grad_(True)
+    y = layer(x, True, torch.from_numpy(g["mask"]).to(_dev()))
+    (y * torch.from_numpy(g["g"]).to(_dev())).sum().backward()
+    assert rel_err(y.detach().cpu().numpy(), g["y"]) < TIGHT
+    dx, ref = x.grad.cpu().numpy(), g["dx"]
+    assert float((np.abs(dx - ref) > 1e-3 * np.abs(ref).max()).mean()) < 0.05
+
+
+def test_mplayer_full_size():
+    """BASELINE config 2 (B = 256, N = 30, F = 32): forward strict; parameter gradients (sums over
+    230,400 edges) within the 1e-3 bar; input gradient: all but a tiny fraction of elements."""
+    errs, frac, margin = _run_case(256, 30, 32, 32, True, True, seed=7)
+    print("full-size errors", errs, "\nfrac>1e-3", frac, "margin", margin)
+    assert errs["y"] < TIGHT
+    for k, v in errs.items():
+        if k not in ("y", "dx"):
+            assert v < TOL, (k, v)
+    assert frac["dx"] < 0.02
