@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Headline benchmark: jets/sec of one full G+D training iteration, MPGAN gluon-30, B = 256 per GPU.
+
+  python bench.py --gpus N --steps K --warmup W            (N = 1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+One "step" = train_D + train_G (reference train.py:398-523) on one synthetic JetNet-30-like batch
+resident in HBM, fresh generator noise and dropout masks every step, RMSprop updates included.
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline      -- the dominant kernel's algorithmic FLOP rate vs the dense 16-bit MFMA peak, from
+                   HIP-event timings taken in this process on the launch stream
+  cpu_baseline  -- the CPU oracle (own port of the reference step) timed on this box's host cores
+                   on a bounded sample (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_16BIT = 2.5e15  # dense bf16/f16 MFMA, MI355X (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def edge_flops_per_jet(N, F):
+    """Algorithmic FLOPs of fe on one jet, dense reference formulation."""
+    return N * N * 2 * (2 * F * 96 + 96 * 160 + 160 * 192)
+
+
+def node_flops_per_jet(N, F, out):
+    return N * 2 * ((192 + F) * 256 + 256 * 256 + 256 * out)
+
+
+def iteration_flops_per_jet(N):
+    g = edge_flops_per_jet(N, 32) * 2 + node_flops_per_jet(N, 32, 32) + node_flops_per_jet(N, 32, 3)
+    d = edge_flops_per_jet(N, 3) + edge_flops_per_jet(N, 32) + node_flops_per_jet(N, 3, 32) + node_flops_per_jet(N, 32, 32)
+    return 3 * (3 * d + 2 * g)  # forward (3 D + 2 G) + backward counted as 2x forward
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def host_threads():
+    """Threads for the CPU leg: the cores this process may run on, capped at the GPU box's CPU
+    share for one GPU (16) -- os.cpu_count() reports the whole host and oversubscribes."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("MPGAN_BENCH_CPU_THREADS", "16"))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="jets per GPU (weak scaling)")
+    ap.add_argument("--particles", type=int, default=30)
+    ap.add_argument("--dist", default="gluon", choices=["gluon", "uniform"], help="particle-multiplicity law")
+    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        pg = dist.group.WORLD
+
+    from mpgan_amd import train, ops
+    from oracle.train_ref import synthetic_batch
+
+    B, N = args.batch, args.particles
+    torch.manual_seed(4 + rank)  # setup_training.py:184 (+ rank: every rank draws its own noise)
+    G, D = train.default_mpgan(N, disc_dropout=0.5)
+    if world > 1:  # one-time parameter broadcast from rank 0
+        for p in list(G.parameters()) + list(D.parameters()):
+            dist.broadcast(p.data, 0)
+    lr_d, lr_g = train.LR["g"]
+    ts = train.TrainStep(G, D, B, N, lr_disc=lr_d, lr_gen=lr_g, use_graphs=not args.no_graphs,
+                         process_group=pg, world_size=world)
+    data, labels = synthetic_batch(B, N, seed=4 + rank, dist=args.dist)
+    ts.set_batch(data.to(dev), labels.to(dev))
+    ops.set_seed(0x5EED + rank, dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    log(f"rank {rank}/{world}: models built, B={B} N={N}; warm-up ({args.warmup} steps, hipGraph capture)")
+    for _ in range(args.warmup):
+        ts.step()
+    barrier()
+    log("warm-up done; timing")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    jets_per_s = world * B * args.steps / dt
+    log(f"timed {args.steps} steps in {dt:.3f} s -> {jets_per_s:.0f} jets/s")
+    d_loss, g_loss = float(ts.D_loss), float(ts.G_loss)
+
+    out = {
+        "metric": "jets/sec (G+D step) MPGAN gluon N=30 bs=256 @1/2/4/8 MI355X",
+        "value": jets_per_s, "unit": "jets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16x3 (forward) / bf16x3 (gradients) split-16-bit MFMA, fp32 accumulate, fp32 in/out",
+        "data": "synthetic",
+        "config": {"workload": f"MPGAN gluon-like jets, N={N} particles, B={B} per GPU, one train_D+train_G "
+                               "iteration (LSGAN, RMSprop, D dropout 0.5)",
+                   "global_batch": world * B, "particles": N, "multiplicity": args.dist,
+                   "parallelism": f"dp{world}", "hip_graphs": not args.no_graphs},
+        "losses": {"D": d_loss, "G": g_loss},
+        "algorithmic_gflop_per_jet": iteration_flops_per_jet(N) / 1e9,
+        "whole_step_mfma_frac": jets_per_s / world * iteration_flops_per_jet(N) / PEAK_MFMA_16BIT,
+    }
+
+    # ------------------------------------------------------------------ roofline of the dominant kernel
+    if rank == 0 and not args.no_roofline:
+        out["roofline"], out["kernels"] = roofline(torch, ts, B, N, dev)
+        log("roofline leg done", out["kernels"])
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(torch, N)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def roofline(torch, ts, B, N, dev):
+    """Time every launch of the two fused edge kernels with HIP events on the launch stream during
+    a few eager (un-captured) iterations of the same step, and price the slower one."""
+    from mpgan_amd import _lib
+    lib = _lib.lib()
+    rec = {"mpg_edge_fwd": [], "mpg_edge_bwd": []}
+    orig = {k: getattr(lib, k) for k in rec}
+
+    def wrap(name):
+        fn = orig[name]
+
+        def timed(*a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a)
+            e1.record()
+            rec[name].append((e0, e1, a[0]._obj.thr != 0))
+            return r
+        return timed
+
+    class Proxy:
+        def __getattr__(self, k):
+            return wrap(k) if k in rec else getattr(lib, k)
+
+    saved = _lib._lib
+    _lib._lib = Proxy()
+    try:
+        for _ in range(4):
+            ts._eager()
+        torch.cuda.synchronize(dev)
+    finally:
+        _lib._lib = saved
+    kern = {}
+    for name, evs in rec.items():
+        evs = evs[len(evs) // 4:]  # drop the first iteration
+        ms = [a.elapsed_time(b) for a, b, _ in evs]
+        kern[name] = {"launches_per_step": len(rec[name]) // 4, "avg_ms": sum(ms) / len(ms), "max_ms": max(ms)}
+    # algorithmic FLOPs per launch, averaged over the launches of one step (F = 32 and F = 3 layers):
+    # forward launches per step: D layer0 x3 (F=3), D layer1 x3, G layer0 x2, G layer1 x2
+    f3, f32 = B * 2 * N * N * (2 * 3 * 96 + 96 * 160 + 160 * 192), B * 2 * N * N * (2 * 32 * 96 + 96 * 160 + 160 * 192)
+    fwd_avg = (3 * f3 + 7 * f32) / 10
+    # the backward kernel carries the data-gradient half (dX); the dW half runs in the GEMM launches
+    tot_bwd_ms = kern["mpg_edge_bwd"]["avg_ms"] * kern["mpg_edge_bwd"]["launches_per_step"]
+    tot_fwd_ms = kern["mpg_edge_fwd"]["avg_ms"] * kern["mpg_edge_fwd"]["launches_per_step"]
+    if tot_bwd_ms >= tot_fwd_ms:
+        name, flops, ms = "edge_bwd_kernel", fwd_avg, kern["mpg_edge_bwd"]["avg_ms"]
+    else:
+        name, flops, ms = "edge_fwd_kernel", fwd_avg, kern["mpg_edge_fwd"]["avg_ms"]
+    ach = flops / (ms * 1e-3) / 1e12
+    roof = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_MFMA_16BIT / 1e12, "unit": "TFLOP/s",
+            "frac": ach * 1e12 / PEAK_MFMA_16BIT, "traffic": None,
+            "note": "algorithmic FLOPs (dense reference formulation, one MAC = 2 FLOP); the kernels execute 3 "
+                    "MFMA MACs per algorithmic MAC (hi/lo split), so 1/3 is the ceiling of frac"}
+    return roof, kern
+
+
+def cpu_baseline(torch, N):
+    """The oracle's restatement of the same iteration on this box's host cores, bounded sample:
+    BASELINE config 1 (B = 32), 1 warm-up + 3 timed iterations, D dropout 0.5 (Bernoulli masks)."""
+    import oracle
+    from oracle import train_ref as T
+    from oracle.mpgan_ref import RandKeeps
+    cores = host_threads()
+    torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} threads")
+    B = 32
+    sdG = T.init_state_dict(T.mpgan_param_shapes(True), 1)
+    sdD = T.init_state_dict(T.mpgan_param_shapes(False), 2)
+    stD, stG = {}, {}
+    data, labels = T.synthetic_batch(B, N, seed=4)
+    keeps = (RandKeeps(), RandKeeps(), RandKeeps())
+    times = []
+    for it in range(4):
+        nD, nG = torch.randn(B, N, 32) * 0.2, torch.randn(B, N, 32) * 0.2
+        t0 = time.perf_counter()
+        T.train_iteration("mpgan", sdD, sdG, stD, stG, data, labels, nD, nG, 3e-5, 1e-5, p_disc=0.5, keeps=keeps)
+        times.append(time.perf_counter() - t0)
+        log(f"cpu iteration {it}: {times[-1]:.2f} s")
+    dt = sum(times[1:]) / len(times[1:])
+    return {"value": B / dt, "unit": "jets/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"3 timed G+D iterations (after 1 warm-up) at B={B}, N={N} (BASELINE config 1), fp32, "
+                      f"torch {torch.__version__} CPU ops, D dropout 0.5", "ms_per_step": 1e3 * dt}
+
+
+if __name__ == "__main__":
+    main()

@@ -111,6 +111,31 @@ typedef struct MpgEdgeBwd {
 } MpgEdgeBwd;
 int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream);
 
+/* ---- attention core of GAPT's MAB ---------------------------------------------------------------
+ * mpg_attn_fwd / mpg_attn_bwd: per (jet b, head h), d = E / H:
+ *     P = softmax_s( q_h k_h^T / sqrt(d)  with keys s where ignore[b,s] != 0 at -inf ),   o_h = P v_h
+ * i.e. what nn.MultiheadAttention does between its in- and out-projection as called by MAB.forward
+ * (gapt/model.py:127-129).  q [B*L, ldq], k/v [B*S, ldk/ldv], o [B*L, ldo] hold the H heads side by
+ * side (head h = columns h*d .. h*d+d-1); P [B,H,L,S] is written by fwd and read by bwd;
+ * ignore [B*S] floats (1 = padded key) or NULL.  bwd takes d_o = dL/do and writes dq, dk, dv. */
+typedef struct MpgAttn {
+    const float* q; const float* k; const float* v; int ldq, ldk, ldv;
+    const float* ignore;
+    float* o; int ldo;
+    float* P;
+    const float* d_o;
+    float* dq; float* dk; float* dv; int lddq, lddk, lddv;
+    int B, L, S, H, d;
+} MpgAttn;
+int mpg_attn_fwd(const MpgAttn* p, void* stream);
+int mpg_attn_bwd(const MpgAttn* p, void* stream);
+
+/* ---- optimiser --------------------------------------------------------------------------------
+ * mpg_rmsprop: torch.optim.RMSprop.step() with the reference's settings (setup_training.py:1511-1513)
+ * over one flat buffer of n parameters: v = alpha v + (1-alpha)(gscale g)^2; p -= lr gscale g/(sqrt(v)+eps). */
+int mpg_rmsprop(float* p, const float* g, float* v, uint64_t n, float lr, float alpha, float eps, float gscale,
+                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

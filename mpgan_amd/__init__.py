@@ -8,11 +8,12 @@ import sys as _sys
 
 from . import _lib, ops  # noqa: F401
 from . import mpgan  # noqa: F401
+from . import gapt  # noqa: F401
 from .mpgan import LinearNet, MPLayer, MPNet, MPGenerator, MPDiscriminator  # noqa: F401
+from .gapt import MAB, SAB, PMA, ISAB, GAPT_G, GAPT_D  # noqa: F401
 
 
 def install_as_reference_packages():
     """Make ``import mpgan`` / ``import gapt`` resolve to the MI355X implementations."""
-    from . import gapt as _gapt
     _sys.modules["mpgan"] = mpgan
-    _sys.modules["gapt"] = _gapt
+    _sys.modules["gapt"] = gapt

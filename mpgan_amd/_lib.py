@@ -65,6 +65,15 @@ class MpgEdgeBwd(C.Structure):
     ]
 
 
+class MpgAttn(C.Structure):
+    _fields_ = [
+        ("q", _fp), ("k", _fp), ("v", _fp), ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int),
+        ("ignore", _fp), ("o", _fp), ("ldo", C.c_int), ("P", _fp), ("d_o", _fp),
+        ("dq", _fp), ("dk", _fp), ("dv", _fp), ("lddq", C.c_int), ("lddk", C.c_int), ("lddv", C.c_int),
+        ("B", C.c_int), ("L", C.c_int), ("S", C.c_int), ("H", C.c_int), ("d", C.c_int),
+    ]
+
+
 # name -> (restype, argtypes); kept in step with include/mpgan_amd.h (tests check the symbol list)
 SIGNATURES = {
     "mpg_gemm": (C.c_int, [C.POINTER(MpgGemm), C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -74,6 +83,9 @@ SIGNATURES = {
     "mpg_pack_weights": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp, C.c_void_p]),
     "mpg_edge_fwd": (C.c_int, [C.POINTER(MpgEdgeFwd), C.c_void_p]),
     "mpg_edge_bwd": (C.c_int, [C.POINTER(MpgEdgeBwd), C.c_void_p]),
+    "mpg_attn_fwd": (C.c_int, [C.POINTER(MpgAttn), C.c_void_p]),
+    "mpg_attn_bwd": (C.c_int, [C.POINTER(MpgAttn), C.c_void_p]),
+    "mpg_rmsprop": (C.c_int, [_fp, _fp, _fp, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
 }
 
 

@@ -56,16 +56,55 @@ MPG_DEV V frag(const V* __restrict__ glb, const V* lds, int idx) {
 
 MPG_DEV float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// global -> LDS copy with 16 x 16 B loads in flight per thread (a plain copy loop runs one L2 round
+// trip per iteration: ~10 us for the 150 KiB of weight images)
 template <typename V>
 MPG_DEV void copy_to_lds(V* dst, const V* __restrict__ src, int n16, int tid) {
-    for (int i = tid; i < n16; i += 256) dst[i] = src[i];
+    for (int base = 0; base < n16; base += 256 * 16) {
+        V tmp[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = base + u * 256 + tid;
+            if (i < n16) tmp[u] = src[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = base + u * 256 + tid;
+            if (i < n16) dst[i] = tmp[u];
+        }
+    }
+}
+
+// One 32-row output tile of a chained layer: KS = 2*QT k-steps of 3 MFMAs.  Fragments of k-step
+// k+1 are requested before the MFMAs of k-step k are issued, and after every k-step a slice of
+// OTHER work (the epilogue of the previous tile, passed as `side(k)`) is placed, so that a single
+// wave keeps the matrix pipe and the VALU busy together; sched_barrier pins that order.
+template <int KS, typename V, typename LH, typename LL, typename Side>
+MPG_DEV void tile_chain(f32x16& acc, const V (*bhi)[2], const V (*blo)[2], LH load_hi, LL load_lo, Side side) {
+    V ah[2], al[2];
+    ah[0] = load_hi(0);
+    al[0] = load_lo(0);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        if (k + 1 < KS) {
+            ah[(k + 1) & 1] = load_hi(k + 1);
+            al[(k + 1) & 1] = load_lo(k + 1);
+        }
+        acc = mfma3(ah[k & 1], al[k & 1], bhi[k >> 1][k & 1], blo[k >> 1][k & 1], acc);
+        side(k);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // LDS plan of the forward kernel: W3 hi | W3 lo | W2 hi  (W2 lo streams from L2)
 constexpr int NF2 = T2 * T1 * 2;  // 30 fragments of 1 KiB
 constexpr int NF3 = T3 * T2 * 2;  // 60
-constexpr int FWD_LDS_BYTES = (2 * NF3 + NF2) * 1024;  // 153,600
+constexpr int FWD_W_BYTES = (2 * NF3 + NF2) * 1024;    // 153,600 weight images
+constexpr int FWD_BIAS_BYTES = (H2 + H3) * 4;          //   1,408 b2 | b3
+constexpr int FWD_C_SLOTS = 22;                        // sender rows of c staged in LDS (22 * 384 B)
+constexpr int FWD_LDS_BYTES = FWD_W_BYTES + FWD_BIAS_BYTES + FWD_C_SLOTS * H1 * 4;  // 163,456 <= 163,840
 constexpr int RED_BYTES = 4 * T3 * 16 * 64 * 4;        //  98,304
+constexpr int NOLDS_BYTES = RED_BYTES + FWD_BIAS_BYTES + FWD_C_SLOTS * H1 * 4;
 
 template <bool WLDS, bool DROP, bool F16>
 __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
@@ -90,11 +129,20 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
     V* l3hi = reinterpret_cast<V*>(smem);
     V* l3lo = l3hi + NF3 * 64;
     V* l2hi = l3lo + NF3 * 64;
+    // biases and this chunk's sender terms c_j live in LDS too (a global load feeding the very next
+    // instruction costs a full L2 round trip per tile)
+    float* lbias = reinterpret_cast<float*>(smem + (WLDS ? FWD_W_BYTES : RED_BYTES));
+    float* lc = lbias + (H2 + H3);
     if constexpr (WLDS) {
-        copy_to_lds(l3hi, g3hi, 2 * NF3 * 64, tid);  // hi and lo are adjacent in the image
-        copy_to_lds(l2hi, g2hi, NF2 * 64, tid);
-        __syncthreads();
+        if (!(p.skip_masked & 2)) {
+            copy_to_lds(l3hi, g3hi, 2 * NF3 * 64, tid);  // hi and lo are adjacent in the image
+            copy_to_lds(l2hi, g2hi, NF2 * 64, tid);
+        }
     }
+    const V* w2lsrc = (WLDS && (p.skip_masked & 4)) ? l2hi : g2lo;
+    for (int t = tid; t < H2 + H3; t += 256) lbias[t] = t < H2 ? p.b2[t] : p.b3[t - H2];
+    const float* lb2 = lbias;
+    const float* lb3 = lbias + H2;
 
     uint32_t seed_lo = 0, seed_hi = 0;
     if (DROP) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
@@ -122,12 +170,19 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) agg[m][k] = 0.f;
 
-    for (int j = jbeg + w; j < jend; j += 4) {
+    // senders are walked in chunks of FWD_C_SLOTS whose terms c_j are staged in LDS
+    for (int j0 = jbeg; j0 < jend; j0 += FWD_C_SLOTS) {
+    const int j1 = min(jend, j0 + FWD_C_SLOTS);
+    __syncthreads();  // previous chunk fully consumed (first pass: weight/bias fill issued)
+    for (int t = tid; t < (j1 - j0) * (H1 / 4); t += 256)
+        reinterpret_cast<float4*>(lc)[t] = reinterpret_cast<const float4*>(p.c + (size_t)(b * p.N + j0) * H1)[t];
+    __syncthreads();
+    for (int j = j0 + w; j < j1; j += 4) {
         const float mj = p.mask ? p.mask[b * p.N + j] : 1.f;
-        if (p.skip_masked && mj == 0.f) continue;  // wave-uniform
+        if ((p.skip_masked & 1) && mj == 0.f) continue;  // wave-uniform
         const float mjs = mj * p.dscale;
         const uint32_t erow = (uint32_t)((b * p.N + i) * p.N + j);
-        const float* cj = p.c + (size_t)(b * p.N + j) * H1;
+        const float* cj = lc + (j - j0) * H1;
 
         // ---- layer 1: e1 = drop(lrelu(a_i + c_j)), produced directly as B fragments
         V e1hi[T1][2], e1lo[T1][2];
@@ -152,69 +207,88 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
                 split8(v, e1hi[q][s], e1lo[q][s]);
             }
 
-        // ---- layer 2
+        // ---- layer 2.  Tile m's MFMAs run beside the epilogue of tile m-1 (split in 4 slices of one
+        //      register group each); the W2-lo fragments (streamed from L2) are requested a tile ahead.
         V e2hi[T2][2], e2lo[T2][2];
+        {
+            V w2l[2][T1 * 2];
 #pragma unroll
-        for (int m = 0; m < T2; ++m) {
-            __builtin_amdgcn_sched_barrier(0);
-            f32x16 acc;
+            for (int k = 0; k < T1 * 2; ++k) w2l[0][k] = w2lsrc[k * 64 + lane];
+            f32x16 accs[2];
+            float v2[16];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 b4 = ld4(p.b2 + 32 * m + 8 * g + 4 * h);
-                acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
-            }
+            for (int m = 0; m <= T2; ++m) {
+                const int mm = m - 1;
+                auto epi2 = [&](int g) {  // epilogue slice g of tile mm: lrelu, dropout, hi/lo split
+                    uint32_t wd = 0;
+                    if (DROP) wd = drop_word(seed_lo, seed_hi, p.tag_base + TAG_E1, erow, 8 * mm + 2 * g + h);
 #pragma unroll
-            for (int q = 0; q < T1; ++q)
+                    for (int t = 0; t < 4; ++t) {
+                        float x = lrelu(accs[(m + 1) & 1][4 * g + t], p.alpha);
+                        if (DROP && !drop_keep(wd, t, p.thr)) x = 0.f;
+                        v2[4 * g + t] = x;
+                    }
+                    if (g == 1) split8(v2, e2hi[mm][0], e2lo[mm][0]);
+                    if (g == 3) split8(v2 + 8, e2hi[mm][1], e2lo[mm][1]);
+                };
+                if (m < T2) {
+                    if (m + 1 < T2) {
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int idx = ((m * T1 + q) * 2 + s) * 64 + lane;
-                    acc = mfma3(frag<WLDS, V>(g2hi, l2hi, idx), g2lo[idx], e1hi[q][s], e1lo[q][s], acc);
+                        for (int k = 0; k < T1 * 2; ++k) w2l[(m + 1) & 1][k] = w2lsrc[((m + 1) * T1 * 2 + k) * 64 + lane];
+                    }
+                    f32x16& acc = accs[m & 1];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 b4 = ld4(lb2 + 32 * m + 8 * g + 4 * h);
+                        acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
+                    }
+                    tile_chain<T1 * 2, V>(
+                        acc, e1hi, e1lo,
+                        [&](int k) { return frag<WLDS, V>(g2hi, l2hi, (m * T1 * 2 + k) * 64 + lane); },
+                        [&](int k) { return w2l[m & 1][k]; },
+                        [&](int k) { if (m > 0 && k >= 1 && k <= 4) epi2(k - 1); });
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) epi2(g);
                 }
-            float v[16];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint32_t wd = 0;
-                if (DROP) wd = drop_word(seed_lo, seed_hi, p.tag_base + TAG_E1, erow, 8 * m + 2 * g + h);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float x = lrelu(acc[4 * g + t], p.alpha);
-                    if (DROP && !drop_keep(wd, t, p.thr)) x = 0.f;
-                    v[4 * g + t] = x;
-                }
             }
-            split8(v, e2hi[m][0], e2lo[m][0]);
-            split8(v + 8, e2hi[m][1], e2lo[m][1]);
         }
 
-        // ---- layer 3 + masked aggregation over senders
+        // ---- layer 3 + masked aggregation over senders, pipelined the same way
+        {
+            f32x16 accs[2];
 #pragma unroll
-        for (int m = 0; m < T3; ++m) {
-            __builtin_amdgcn_sched_barrier(0);
-            f32x16 acc;
+            for (int m = 0; m <= T3; ++m) {
+                const int mm = m - 1;
+                auto epi3 = [&](int g) {
+                    uint32_t wd = 0;
+                    if (DROP) wd = drop_word(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, 8 * mm + 2 * g + h);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 b4 = ld4(p.b3 + 32 * m + 8 * g + 4 * h);
-                acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
-            }
+                    for (int t = 0; t < 4; ++t) {
+                        float x = lrelu(accs[(m + 1) & 1][4 * g + t], p.alpha);
+                        if (DROP && !drop_keep(wd, t, p.thr)) x = 0.f;
+                        agg[mm][4 * g + t] += mjs * x;
+                    }
+                };
+                if (m < T3) {
+                    f32x16& acc = accs[m & 1];
 #pragma unroll
-            for (int q = 0; q < T2; ++q)
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 b4 = ld4(lb3 + 32 * m + 8 * g + 4 * h);
+                        acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
+                    }
+                    tile_chain<T2 * 2, V>(
+                        acc, e2hi, e2lo,
+                        [&](int k) { return frag<WLDS, V>(g3hi, l3hi, (m * T2 * 2 + k) * 64 + lane); },
+                        [&](int k) { return frag<WLDS, V>(g3lo, l3lo, (m * T2 * 2 + k) * 64 + lane); },
+                        [&](int k) { if (m > 0 && (k & 1) && k < 8) epi3(k >> 1); });
+                } else {
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int idx = ((m * T2 + q) * 2 + s) * 64 + lane;
-                    acc = mfma3(frag<WLDS, V>(g3hi, l3hi, idx), frag<WLDS, V>(g3lo, l3lo, idx), e2hi[q][s], e2lo[q][s], acc);
-                }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint32_t wd = 0;
-                if (DROP) wd = drop_word(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, 8 * m + 2 * g + h);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float x = lrelu(acc[4 * g + t], p.alpha);
-                    if (DROP && !drop_keep(wd, t, p.thr)) x = 0.f;
-                    agg[m][4 * g + t] += mjs * x;
+                    for (int g = 0; g < 4; ++g) epi3(g);
                 }
             }
         }
+    }
     }
 
     // ---- reduce the four waves' partial sums through LDS and write agg[b, i, :]
@@ -538,8 +612,8 @@ extern "C" int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream) {
     if (!attr_set) {
         MPG_FWD_ATTR(true, false, false, FWD_LDS_BYTES); MPG_FWD_ATTR(true, true, false, FWD_LDS_BYTES);
         MPG_FWD_ATTR(true, false, true, FWD_LDS_BYTES);  MPG_FWD_ATTR(true, true, true, FWD_LDS_BYTES);
-        MPG_FWD_ATTR(false, false, false, RED_BYTES);    MPG_FWD_ATTR(false, true, false, RED_BYTES);
-        MPG_FWD_ATTR(false, false, true, RED_BYTES);     MPG_FWD_ATTR(false, true, true, RED_BYTES);
+        MPG_FWD_ATTR(false, false, false, NOLDS_BYTES);  MPG_FWD_ATTR(false, true, false, NOLDS_BYTES);
+        MPG_FWD_ATTR(false, false, true, NOLDS_BYTES);   MPG_FWD_ATTR(false, true, true, NOLDS_BYTES);
         attr_set = true;
     }
 #undef MPG_FWD_ATTR
@@ -552,7 +626,7 @@ extern "C" int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream) {
         else hipLaunchKernelGGL((edge_fwd_kernel<L, false, false>), grid, block, BYTES, st, *p);                \
     } while (0)
     if (p->weights_in_lds) MPG_FWD_GO(true, FWD_LDS_BYTES);
-    else MPG_FWD_GO(false, RED_BYTES);
+    else MPG_FWD_GO(false, NOLDS_BYTES);
 #undef MPG_FWD_GO
     return (int)hipGetLastError();
 }

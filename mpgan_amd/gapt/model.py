@@ -1,0 +1,171 @@
+"""GAPT (set-transformer GAN) on the MI355X path -- drop-in for the reference's ``gapt`` package.
+
+Same class names, constructor keywords, ``forward`` signatures and state-dict key names as
+rkansal47/MPGAN ``gapt/model.py`` (LinearNet :11-89, MAB :93-139, SAB :143-154, PMA :158-174,
+ISAB :178-191, GAPT_G :205-274, GAPT_D :277-344).  ``MAB.attention`` keeps the parameter layout of
+``nn.MultiheadAttention`` (``in_proj_weight [3E,E]``, ``in_proj_bias``, ``out_proj.weight|bias``) so
+reference checkpoints load; the arithmetic runs in libmpgan_amd.so: projections and the feed-forward
+on the split-16-bit MFMA GEMM, softmax(QK^T)V in the attention-core kernel.
+LayerNorm / batch norm / spectral norm variants are outside the fused path (NotImplementedError).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from .. import ops
+from ..mpgan.model import LinearNet, _unsupported, _rank_mask
+
+
+class _MHAParams(nn.Module):
+    """Parameter container with nn.MultiheadAttention's names and default initialisation."""
+
+    def __init__(self, embed_dim: int):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+def _lin(x2, W, b, row0, rows):
+    """x2 @ W[row0:row0+rows].T + b[row0:row0+rows] through the fused linear op."""
+    return ops.FusedLinearFn.apply(x2, W[row0:row0 + rows], None if b is None else b[row0:row0 + rows],
+                                   False, 0.2, 0.0, False)
+
+
+class MAB(nn.Module):
+    def __init__(self, embed_dim: int, num_heads: int, ff_layers: list = [], layer_norm: bool = False,
+                 dropout_p: float = 0.0, final_linear: bool = True, linear_args={}):
+        super().__init__()
+        _unsupported(layer_norm=layer_norm)
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.attention = _MHAParams(embed_dim)
+        self.ff = LinearNet(ff_layers, input_size=embed_dim, output_size=embed_dim, final_linear=final_linear,
+                            **linear_args)
+        self.layer_norm = layer_norm
+        self.dropout_p = float(dropout_p)
+
+    def forward(self, x: Tensor, y: Tensor, y_mask: Tensor = None):
+        """x [B,L,E] queries, y [B,S,E] keys/values; y_mask: bool, True = ignore, of shape [B,L,S]
+        (every query row carries the same key mask -- that is how SAB/PMA/ISAB build it) or [B,S]."""
+        B, L, E = x.shape
+        S = y.shape[1]
+        att = self.attention
+        ignore = None
+        if y_mask is not None:
+            km = y_mask if y_mask.dim() == 2 else y_mask[:, 0, :]
+            ignore = km.reshape(B * S).float().contiguous()
+        x2 = x.reshape(B * L, E)
+        if x is y:
+            qkv = _lin(x2, att.in_proj_weight, att.in_proj_bias, 0, 3 * E)
+            q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
+        else:
+            q = _lin(x2, att.in_proj_weight, att.in_proj_bias, 0, E)
+            kv = _lin(y.reshape(B * S, E), att.in_proj_weight, att.in_proj_bias, E, 2 * E)
+            k, v = kv[:, :E], kv[:, E:]
+        o = ops.FusedAttnFn.apply(q, k, v, ignore, B, L, S, self.num_heads)
+        a = ops.FusedLinearFn.apply(o, att.out_proj.weight, att.out_proj.bias, False, 0.2, 0.0, False)
+        z = ops.FusedDropoutFn.apply(x2 + a, self.dropout_p, self.training)
+        out = ops.FusedDropoutFn.apply(z + self.ff(z), self.dropout_p, self.training)
+        return out.reshape(B, L, E)
+
+
+class SAB(nn.Module):
+    def __init__(self, **mab_args):
+        super().__init__()
+        self.mab = MAB(**mab_args)
+
+    def forward(self, x: Tensor, mask: Tensor = None):
+        return self.mab(x, x, None if mask is None else mask[:, :, 0])  # mask [B,N,1] bool, True = ignore
+
+
+class PMA(nn.Module):
+    def __init__(self, embed_dim: int, num_seeds: int, **mab_args):
+        super().__init__()
+        self.S = nn.Parameter(torch.empty(1, num_seeds, embed_dim))
+        nn.init.xavier_uniform_(self.S)
+        self.mab = MAB(embed_dim, **mab_args)
+
+    def forward(self, x: Tensor, mask: Tensor = None):
+        seeds = self.S.expand(x.size(0), -1, -1).contiguous()
+        return self.mab(seeds, x, None if mask is None else mask[:, :, 0])
+
+
+class ISAB(nn.Module):
+    def __init__(self, num_inds, embed_dim, **mab_args):
+        super().__init__()
+        self.I = nn.Parameter(torch.empty(1, num_inds, embed_dim))
+        self.num_inds = num_inds
+        nn.init.xavier_uniform_(self.I)
+        self.mab0 = MAB(embed_dim=embed_dim, **mab_args)
+        self.mab1 = MAB(embed_dim=embed_dim, **mab_args)
+
+    def forward(self, X, mask: Tensor = None):
+        ind = self.I.expand(X.size(0), -1, -1).contiguous()
+        H = self.mab0(ind, X, None if mask is None else mask[:, :, 0])
+        return self.mab1(X, H)
+
+
+def _attn_mask(mask: Tensor) -> Optional[Tensor]:
+    """JetNet mask (1 real, 0 padded) -> attention convention (True = ignore)."""
+    return None if mask is None else (1 - mask).bool()
+
+
+def _sab_args(embed_dim, sab_fc_layers, num_heads, layer_norm, dropout_p, linear_args):
+    return {"embed_dim": embed_dim, "ff_layers": sab_fc_layers, "final_linear": False, "num_heads": num_heads,
+            "layer_norm": layer_norm, "dropout_p": dropout_p, "linear_args": linear_args}
+
+
+class GAPT_G(nn.Module):
+    def __init__(self, num_particles: int, output_feat_size: int, sab_layers: int = 2, num_heads: int = 4,
+                 embed_dim: int = 32, sab_fc_layers: list = [], layer_norm: bool = False, dropout_p: float = 0.0,
+                 final_fc_layers: list = [], use_mask: bool = True, use_isab: bool = False,
+                 num_isab_nodes: int = 10, linear_args: dict = {}):
+        super().__init__()
+        self.num_particles, self.output_feat_size, self.use_mask = num_particles, output_feat_size, use_mask
+        args = _sab_args(embed_dim, sab_fc_layers, num_heads, layer_norm, dropout_p, linear_args)
+        self.sabs = nn.ModuleList(ISAB(num_isab_nodes, **args) if use_isab else SAB(**args)
+                                  for _ in range(sab_layers))
+        self.final_fc = LinearNet(final_fc_layers, input_size=embed_dim, output_size=output_feat_size,
+                                  final_linear=True, **linear_args)
+
+    def forward(self, x: Tensor, labels: Tensor = None):
+        mask = _rank_mask(x[:, :, 0], labels, self.num_particles) if self.use_mask else None
+        am = _attn_mask(mask)
+        for sab in self.sabs:
+            x = sab(x, am)
+        x = torch.tanh(self.final_fc(x))
+        return torch.cat((x, mask - 0.5), dim=2) if mask is not None else x
+
+
+class GAPT_D(nn.Module):
+    def __init__(self, num_particles: int, input_feat_size: int, sab_layers: int = 2, num_heads: int = 4,
+                 embed_dim: int = 32, sab_fc_layers: list = [], layer_norm: bool = False, dropout_p: float = 0.0,
+                 final_fc_layers: list = [], use_mask: bool = True, use_isab: bool = False,
+                 num_isab_nodes: int = 10, linear_args: dict = {}):
+        super().__init__()
+        self.num_particles, self.input_feat_size, self.use_mask = num_particles, input_feat_size, use_mask
+        args = _sab_args(embed_dim, sab_fc_layers, num_heads, layer_norm, dropout_p, linear_args)
+        self.sabs = nn.ModuleList()  # registered first, as in the reference, so state-dict order matches
+        self.input_embedding = LinearNet([], input_size=input_feat_size, output_size=embed_dim, **linear_args)
+        for _ in range(sab_layers):
+            self.sabs.append(ISAB(num_isab_nodes, **args) if use_isab else SAB(**args))
+        self.pma = PMA(num_seeds=1, **args)
+        self.final_fc = LinearNet(final_fc_layers, input_size=embed_dim, output_size=1, final_linear=True,
+                                  **linear_args)
+
+    def forward(self, x: Tensor, labels: Tensor = None):
+        mask = None
+        if self.use_mask:
+            mask = x[..., -1:] + 0.5
+            x = x[..., :-1]
+        am = _attn_mask(mask)
+        x = self.input_embedding(x.contiguous())
+        for sab in self.sabs:
+            x = sab(x, am)
+        pooled = self.pma(x, am)
+        return torch.sigmoid(self.final_fc(pooled.squeeze()))  # .squeeze() as the reference (:344)

@@ -181,11 +181,12 @@ def pack_weights(W, rows, cols, *, col0=0, transpose=False, scale=1.0, f16=False
 
 
 def _sender_chunks(B, N):
-    """Number of sender chunks so that the grid fills the chip (256 CUs) when B*RB is small."""
+    """Sender chunks per (jet, receiver block): 1 when those alone give every CU a workgroup (each
+    workgroup pays a 150 KiB LDS fill), else enough to cover the 256 CUs about twice."""
     RB = (N + 31) // 32
     wg = B * RB
     sc = 1
-    while wg * sc < 512 and (N + sc - 1) // sc > 8:
+    while wg * sc < 224 and (N + sc - 1) // sc > 8:
         sc *= 2
     return sc
 
@@ -249,20 +250,25 @@ class FusedMPLayerFn(torch.autograd.Function):
         def gt(H, site, act):
             return (H, H.stride(0), act, seed_t, tag + site, thr, dscale)
 
+        need_w = any(ctx.needs_input_grad[2:14])   # False in the G step: D's weights get no update there
+        need_x = ctx.needs_input_grad[0]
+
         # ---- node network fn (mpgan/model.py:279) backward
         dz3 = gate(gy2, None, gate_act=False, alpha=alpha, seed_t=seed_t, tag=tag + TAG_N2, thr=thr, scale=dscale) \
             if thr else gy2
-        dV3 = linear_bwd_weight(dz3, h2)
-        dc3 = dz3.sum(0)
         dz2 = linear_bwd_data(dz3, V3, gate=gt(h2, TAG_N1, True), alpha=alpha)
-        dV2 = linear_bwd_weight(dz2, h1)
-        dc2 = dz2.sum(0)
         dz1 = linear_bwd_data(dz2, V2, gate=gt(h1, TAG_N0, True), alpha=alpha)
-        dV1 = torch.empty_like(V1)
-        linear_bwd_weight(dz1, agg, out=dV1, out_col0=0)
-        linear_bwd_weight(dz1, x2, out=dV1, out_col0=H3)
-        dc1 = dz1.sum(0)
         dh0 = linear_bwd_data(dz1, V1)  # [V, 192+F] = [dagg | dx(node path)]
+        dV1 = dV2 = dV3 = dc1 = dc2 = dc3 = None
+        if need_w:
+            dV3 = linear_bwd_weight(dz3, h2)
+            dc3 = dz3.sum(0)
+            dV2 = linear_bwd_weight(dz2, h1)
+            dc2 = dz2.sum(0)
+            dV1 = torch.empty_like(V1)
+            linear_bwd_weight(dz1, agg, out=dV1, out_col0=0)
+            linear_bwd_weight(dz1, x2, out=dV1, out_col0=H3)
+            dc1 = dz1.sum(0)
 
         # ---- edge network backward
         W2img = pack_weights(W2, H2, H1, scale=dscale, f16=f16)
@@ -273,10 +279,12 @@ class FusedMPLayerFn(torch.autograd.Function):
         E = V * N
         dap = torch.empty((SC, V, H1), device=dev, dtype=torch.float32)
         dcp = torch.empty((RB, V, H1), device=dev, dtype=torch.float32)
-        E1 = torch.empty((E, H1), device=dev, dtype=torch.float32)
-        E2 = torch.empty((E, H2), device=dev, dtype=torch.float32)
-        dZ2 = torch.empty((E, H2), device=dev, dtype=torch.float32)
-        dZ3 = torch.empty((E, H3), device=dev, dtype=torch.float32)
+        E1 = E2 = dZ2 = dZ3 = None
+        if need_w:
+            E1 = torch.empty((E, H1), device=dev, dtype=torch.float32)
+            E2 = torch.empty((E, H2), device=dev, dtype=torch.float32)
+            dZ2 = torch.empty((E, H2), device=dev, dtype=torch.float32)
+            dZ3 = torch.empty((E, H3), device=dev, dtype=torch.float32)
         e = MpgEdgeBwd()
         e.a, e.c, e.mask = _p(a), _p(c), _p(m1)
         e.dagg, e.ld_dagg = _p(dh0), dh0.stride(0)
@@ -292,21 +300,25 @@ class FusedMPLayerFn(torch.autograd.Function):
         check(_lib.lib().mpg_edge_bwd(C.byref(e), _stream()), "mpg_edge_bwd")
         da = dap[0] if SC == 1 else dap.sum(0)
         dc = dcp[0] if RB == 1 else dcp.sum(0)
-        dW3 = linear_bwd_weight(dZ3, E2, out_scale=dscale)
-        db3 = dZ3.sum(0)
-        dW2 = linear_bwd_weight(dZ2, E1, out_scale=dscale)
-        db2 = dZ2.sum(0)
-        del E1, E2, dZ2, dZ3
-
-        # ---- layer 1 (fe.net.0): a = W1[:, :F] x + b1, c = W1[:, F:] x
-        dW1 = torch.empty_like(W1)
-        linear_bwd_weight(da, x2, out=dW1, out_col0=0)
-        linear_bwd_weight(dc, x2, out=dW1, out_col0=F)
-        db1 = da.sum(0)
-        dx = dh0[:, H3:].contiguous()
-        linear_bwd_data(da, W1, w_cols=F, out=dx, accumulate=True)
-        linear_bwd_data(dc, W1, w_col0=F, w_cols=F, out=dx, accumulate=True)
-        return (dx.reshape(B, N, F), None, dW1, db1, dW2, db2, dW3, db3, dV1, dc1, dV2, dc2, dV3, dc3,
+        dW1 = db1 = dW2 = db2 = dW3 = db3 = None
+        if need_w:
+            dW3 = linear_bwd_weight(dZ3, E2, out_scale=dscale)
+            db3 = dZ3.sum(0)
+            dW2 = linear_bwd_weight(dZ2, E1, out_scale=dscale)
+            db2 = dZ2.sum(0)
+            del E1, E2, dZ2, dZ3
+            # layer 1 (fe.net.0): a = W1[:, :F] x + b1, c = W1[:, F:] x
+            dW1 = torch.empty_like(W1)
+            linear_bwd_weight(da, x2, out=dW1, out_col0=0)
+            linear_bwd_weight(dc, x2, out=dW1, out_col0=F)
+            db1 = da.sum(0)
+        dx = None
+        if need_x:
+            dx = dh0[:, H3:].contiguous()
+            linear_bwd_data(da, W1, w_cols=F, out=dx, accumulate=True)
+            linear_bwd_data(dc, W1, w_col0=F, w_cols=F, out=dx, accumulate=True)
+            dx = dx.reshape(B, N, F)
+        return (dx, None, dW1, db1, dW2, db2, dW3, db3, dV1, dc1, dV2, dc2, dV3, dc3,
                 None, None, None, None)
 
 
@@ -334,7 +346,77 @@ class FusedLinearFn(torch.autograd.Function):
         if act or thr:
             g2 = gate(g2, y, gate_act=act, alpha=alpha, seed_t=seed_tensor(g2.device), tag=tag + TAG_GENERIC,
                       thr=thr, scale=dscale)
-        dW = linear_bwd_weight(g2, x2)
-        db = g2.sum(0) if has_b else None
-        dx = linear_bwd_data(g2, W)
-        return dx.reshape(shp), dW, db, None, None, None, None
+        dW = linear_bwd_weight(g2, x2) if ctx.needs_input_grad[1] else None
+        db = g2.sum(0) if (has_b and ctx.needs_input_grad[2]) else None
+        dx = linear_bwd_data(g2, W).reshape(shp) if ctx.needs_input_grad[0] else None
+        return dx, dW, db, None, None, None, None
+
+
+class FusedDropoutFn(torch.autograd.Function):
+    """Stand-alone inverted dropout on the counter-based mask stream (MAB.dropout, gapt/model.py:132,137)."""
+
+    @staticmethod
+    def forward(ctx, x, p_drop, training):
+        thr, scale = drop_params(p_drop) if training else (0, 1.0)
+        if not thr:
+            ctx.cfg = None
+            return x
+        _chk(x, "x")
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        tag = next_tag() + TAG_GENERIC
+        ctx.cfg = (tag, thr, scale, x.shape)
+        return gate(x2, None, gate_act=False, alpha=0.0, seed_t=seed_tensor(x.device), tag=tag, thr=thr,
+                    scale=scale).reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.cfg is None:
+            return g, None, None
+        tag, thr, scale, shp = ctx.cfg
+        g2 = g.reshape(-1, shp[-1]).contiguous()
+        return gate(g2, None, gate_act=False, alpha=0.0, seed_t=seed_tensor(g.device), tag=tag, thr=thr,
+                    scale=scale).reshape(shp), None, None
+
+
+def _attn_struct(q, k, v, ignore, o, P, B, L, S, H, d):
+    a = _lib.MpgAttn()
+    a.q, a.k, a.v = _p(q), _p(k), _p(v)
+    a.ldq, a.ldk, a.ldv = q.stride(0), k.stride(0), v.stride(0)
+    a.ignore = _p(ignore)
+    a.o, a.ldo, a.P = _p(o), o.stride(0), _p(P)
+    a.B, a.L, a.S, a.H, a.d = B, L, S, H, d
+    return a
+
+
+class FusedAttnFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d) + key mask) v per (jet, head): q [B*L, E], k, v [B*S, E] (row-strided
+    views are fine), ignore [B*S] floats (1 = padded key) or None."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, ignore, B, L, S, H):
+        _chk(q, "q")
+        E = q.shape[1]
+        d = E // H
+        o = torch.empty((B * L, E), device=q.device, dtype=torch.float32)
+        P = torch.empty((B, H, L, S), device=q.device, dtype=torch.float32)
+        a = _attn_struct(q, k, v, ignore, o, P, B, L, S, H, d)
+        check(_lib.lib().mpg_attn_fwd(C.byref(a), _stream()), "mpg_attn_fwd")
+        ctx.save_for_backward(q, k, v, P)
+        ctx.ignore = ignore
+        ctx.dims = (B, L, S, H, d)
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v, P = ctx.saved_tensors
+        B, L, S, H, d = ctx.dims
+        go = go.contiguous()
+        dq = torch.empty((B * L, H * d), device=q.device, dtype=torch.float32)
+        dk = torch.empty((B * S, H * d), device=q.device, dtype=torch.float32)
+        dv = torch.empty((B * S, H * d), device=q.device, dtype=torch.float32)
+        a = _attn_struct(q, k, v, ctx.ignore, go, P, B, L, S, H, d)
+        a.d_o = _p(go)
+        a.dq, a.dk, a.dv = _p(dq), _p(dk), _p(dv)
+        a.lddq, a.lddk, a.lddv = H * d, H * d, H * d
+        check(_lib.lib().mpg_attn_bwd(C.byref(a), _stream()), "mpg_attn_bwd")
+        return dq, dk, dv, None, None, None, None, None

