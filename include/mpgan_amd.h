@@ -89,27 +89,49 @@ typedef struct MpgEdgeFwd {
     int skip_masked;                      /* skip senders with mask == 0 (exact: they add 0)   */
     int weights_in_lds;                   /* keep W3 (hi,lo) + W2 hi resident in LDS           */
     int f16;                              /* images and activations are fp16 hi/lo (else bf16)  */
+    unsigned long long* sign3;            /* optional [B*RB*N, 96] lane ballots of (Z3 > 0) for the backward (NULL = off) */
 } MpgEdgeFwd;
 int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream);
 
-/* mpg_edge_bwd: autograd backward of the same span.  Given dagg = dL/dagg it produces
- *   da [SC, B*N, 96]  (partial over sender chunks),  dc [RB, B*N, 96]  (partial over receiver blocks
- *   of 32; RB = ceil(N/32)), and -- when the pointers are non-NULL -- the per-edge rows
- *   E1 [B*N*N,96], E2 [B*N*N,160], dZ2 [B*N*N,160], dZ3 [B*N*N,192] from which
- *   dW3 = dscale * dZ3^T E2, dW2 = dscale * dZ2^T E1, db3 = colsum dZ3, db2 = colsum dZ2. */
+/* mpg_edge_bwd: autograd backward of the same span, data path.  Given dagg = dL/dagg and the
+ * forward's sign ballots it produces
+ *   da [SC, B*N, 96]  (partial over sender chunks),  dc [RB, B*N, 96]  (partial over receiver blocks of 32)
+ * and, when stageE2/stageZ2 are non-NULL (weight gradients wanted), parks E2 = fe.net.1's output and
+ * dZ2 = dL/d(its pre-activation) as 16-bit hi/lo planes [B*RB*N blocks][2][160][32] (fp16 / bf16 resp.
+ * bf16 / bf16 when f16 = 0) for mpg_edge_dw.  W2img is the forward image (mpg_pack_weights, f16 as the
+ * flag says); W3Timg / W2Timg are bf16 images of the transposed weights. */
 typedef struct MpgEdgeBwd {
     const float* a; const float* c; const float* mask;
     const float* dagg; int ld_dagg;
-    const void* W2img; const void* W3img; const void* W3Timg; const void* W2Timg;
-    const float* b2; const float* b3;
+    const unsigned long long* sign3;      /* [B*RB*N, 96] from mpg_edge_fwd                     */
+    const void* W2img; const void* W3Timg; const void* W2Timg;
+    const float* b2;
     float* da; float* dc;
-    float* E1; float* E2; float* dZ2; float* dZ3;
+    void* stageE2; void* stageZ2;
     int B, N, SC;
     float alpha, agg_scale;
     const uint64_t* seed; uint32_t tag_base, thr; float dscale;
-    int f16;  /* W2img/W3img (forward recomputation) are fp16 images; W3Timg/W2Timg are always bf16 */
+    int f16;
 } MpgEdgeBwd;
 int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream);
+
+/* mpg_edge_dw: weight gradients of fe.net.1 / fe.net.2 (and their biases) from the planes parked by
+ * mpg_edge_bwd:  dW3 = dscale * sum_e dZ3 E2^T [192,160], dW2 = dscale * sum_e dZ2 E1^T [160,96],
+ * db3 = sum_e dZ3 [192], db2 = sum_e dZ2 [160]; E1 and dZ3 are rebuilt from a, c, dagg and the ballots.
+ * `part` is scratch of nwg * 46,432 floats (per-workgroup partial sums). */
+typedef struct MpgEdgeDw {
+    const float* a; const float* c; const float* mask;
+    const float* dagg; int ld_dagg;
+    const unsigned long long* sign3;
+    const void* stageE2; const void* stageZ2;
+    float* part; int nwg;
+    float* dW3; float* dW2; float* db3; float* db2;
+    int B, N;
+    float alpha, agg_scale;
+    const uint64_t* seed; uint32_t tag_base, thr; float dscale;
+    int f16;
+} MpgEdgeDw;
+int mpg_edge_dw(const MpgEdgeDw* p, void* stream);
 
 /* ---- attention core of GAPT's MAB ---------------------------------------------------------------
  * mpg_attn_fwd / mpg_attn_bwd: per (jet b, head h), d = E / H:

@@ -47,6 +47,7 @@ class MpgEdgeFwd(C.Structure):
         ("alpha", C.c_float), ("agg_scale", C.c_float),
         ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
         ("skip_masked", C.c_int), ("weights_in_lds", C.c_int), ("f16", C.c_int),
+        ("sign3", _fp),
     ]
 
 
@@ -54,11 +55,26 @@ class MpgEdgeBwd(C.Structure):
     _fields_ = [
         ("a", _fp), ("c", _fp), ("mask", _fp),
         ("dagg", _fp), ("ld_dagg", C.c_int),
-        ("W2img", _fp), ("W3img", _fp), ("W3Timg", _fp), ("W2Timg", _fp),
-        ("b2", _fp), ("b3", _fp),
+        ("sign3", _fp),
+        ("W2img", _fp), ("W3Timg", _fp), ("W2Timg", _fp),
+        ("b2", _fp),
         ("da", _fp), ("dc", _fp),
-        ("E1", _fp), ("E2", _fp), ("dZ2", _fp), ("dZ3", _fp),
+        ("stageE2", _fp), ("stageZ2", _fp),
         ("B", C.c_int), ("N", C.c_int), ("SC", C.c_int),
+        ("alpha", C.c_float), ("agg_scale", C.c_float),
+        ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
+        ("f16", C.c_int),
+    ]
+
+
+class MpgEdgeDw(C.Structure):
+    _fields_ = [
+        ("a", _fp), ("c", _fp), ("mask", _fp),
+        ("dagg", _fp), ("ld_dagg", C.c_int),
+        ("sign3", _fp), ("stageE2", _fp), ("stageZ2", _fp),
+        ("part", _fp), ("nwg", C.c_int),
+        ("dW3", _fp), ("dW2", _fp), ("db3", _fp), ("db2", _fp),
+        ("B", C.c_int), ("N", C.c_int),
         ("alpha", C.c_float), ("agg_scale", C.c_float),
         ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
         ("f16", C.c_int),
@@ -83,6 +99,7 @@ SIGNATURES = {
     "mpg_pack_weights": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp, C.c_void_p]),
     "mpg_edge_fwd": (C.c_int, [C.POINTER(MpgEdgeFwd), C.c_void_p]),
     "mpg_edge_bwd": (C.c_int, [C.POINTER(MpgEdgeBwd), C.c_void_p]),
+    "mpg_edge_dw": (C.c_int, [C.POINTER(MpgEdgeDw), C.c_void_p]),
     "mpg_attn_fwd": (C.c_int, [C.POINTER(MpgAttn), C.c_void_p]),
     "mpg_attn_bwd": (C.c_int, [C.POINTER(MpgAttn), C.c_void_p]),
     "mpg_rmsprop": (C.c_int, [_fp, _fp, _fp, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),

@@ -13,13 +13,9 @@
 // lane movement), weights are the A operand, pre-packed by pack_weights() into per-lane
 // fragment images.  The sum over senders is then a per-lane register accumulation over the
 // j loop, and layer 1 is the exact factorisation  W1 [x_i ; x_j] = a_i + c_j  (SURVEY.md A.3).
-#include "common.h"
-#include "../../include/mpgan_amd.h"
+#include "edge_common.h"
 
 namespace {
-
-constexpr int H1 = 96, H2 = 160, H3 = 192;
-constexpr int T1 = 3, T2 = 5, T3 = 6;  // 32-row tiles per layer width
 
 // ------------------------------------------------------------------------------------------
 // weight image: [part hi|lo][tile m][k-tile q][k-step s][lane][8 x bf16]
@@ -46,65 +42,6 @@ __global__ void pack_kernel(const float* __restrict__ W, int ldw, int rows, int 
     reinterpret_cast<V*>(img)[idx] = hi;
     reinterpret_cast<V*>(img)[(size_t)nfrag * 64 + idx] = lo;
 }
-
-// fragment fetch: from the LDS copy when present, else straight from the (L2-resident) image
-template <bool LDS, typename V>
-MPG_DEV V frag(const V* __restrict__ glb, const V* lds, int idx) {
-    if constexpr (LDS) return lds[idx];
-    else return glb[idx];
-}
-
-MPG_DEV float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
-// global -> LDS copy with 16 x 16 B loads in flight per thread (a plain copy loop runs one L2 round
-// trip per iteration: ~10 us for the 150 KiB of weight images)
-template <typename V>
-MPG_DEV void copy_to_lds(V* dst, const V* __restrict__ src, int n16, int tid) {
-    for (int base = 0; base < n16; base += 256 * 16) {
-        V tmp[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int i = base + u * 256 + tid;
-            if (i < n16) tmp[u] = src[i];
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int i = base + u * 256 + tid;
-            if (i < n16) dst[i] = tmp[u];
-        }
-    }
-}
-
-// One 32-row output tile of a chained layer: KS = 2*QT k-steps of 3 MFMAs.  Fragments of k-step
-// k+1 are requested before the MFMAs of k-step k are issued, and after every k-step a slice of
-// OTHER work (the epilogue of the previous tile, passed as `side(k)`) is placed, so that a single
-// wave keeps the matrix pipe and the VALU busy together; sched_barrier pins that order.
-template <int KS, typename V, typename LH, typename LL, typename Side>
-MPG_DEV void tile_chain(f32x16& acc, const V (*bhi)[2], const V (*blo)[2], LH load_hi, LL load_lo, Side side) {
-    V ah[2], al[2];
-    ah[0] = load_hi(0);
-    al[0] = load_lo(0);
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {
-        if (k + 1 < KS) {
-            ah[(k + 1) & 1] = load_hi(k + 1);
-            al[(k + 1) & 1] = load_lo(k + 1);
-        }
-        acc = mfma3(ah[k & 1], al[k & 1], bhi[k >> 1][k & 1], blo[k >> 1][k & 1], acc);
-        side(k);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// LDS plan of the forward kernel: W3 hi | W3 lo | W2 hi  (W2 lo streams from L2)
-constexpr int NF2 = T2 * T1 * 2;  // 30 fragments of 1 KiB
-constexpr int NF3 = T3 * T2 * 2;  // 60
-constexpr int FWD_W_BYTES = (2 * NF3 + NF2) * 1024;    // 153,600 weight images
-constexpr int FWD_BIAS_BYTES = (H2 + H3) * 4;          //   1,408 b2 | b3
-constexpr int FWD_C_SLOTS = 22;                        // sender rows of c staged in LDS (22 * 384 B)
-constexpr int FWD_LDS_BYTES = FWD_W_BYTES + FWD_BIAS_BYTES + FWD_C_SLOTS * H1 * 4;  // 163,456 <= 163,840
-constexpr int RED_BYTES = 4 * T3 * 16 * 64 * 4;        //  98,304
-constexpr int NOLDS_BYTES = RED_BYTES + FWD_BIAS_BYTES + FWD_C_SLOTS * H1 * 4;
 
 template <bool WLDS, bool DROP, bool F16>
 __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
@@ -257,6 +194,8 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
         // ---- layer 3 + masked aggregation over senders, pipelined the same way
         {
             f32x16 accs[2];
+            unsigned long long balv = 0;
+            unsigned long long* sg = p.sign3 ? p.sign3 + ((size_t)((b * RB + rb) * p.N + j)) * (T3 * 16) : nullptr;
 #pragma unroll
             for (int m = 0; m <= T3; ++m) {
                 const int mm = m - 1;
@@ -265,10 +204,15 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
                     if (DROP) wd = drop_word(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, 8 * mm + 2 * g + h);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
+                        if (p.sign3 != nullptr) {  // lane ballot of (Z3 > 0): lane 4g+t keeps word 4g+t of this tile
+                            const unsigned long long bal = __ballot(accs[(m + 1) & 1][4 * g + t] > 0.f);
+                            if (lane == 4 * g + t) balv = bal;
+                        }
                         float x = lrelu(accs[(m + 1) & 1][4 * g + t], p.alpha);
                         if (DROP && !drop_keep(wd, t, p.thr)) x = 0.f;
                         agg[mm][4 * g + t] += mjs * x;
                     }
+                    if (g == 3 && sg != nullptr && lane < 16) sg[mm * 16 + lane] = balv;  // 16 words of tile mm
                 };
                 if (m < T3) {
                     f32x16& acc = accs[m & 1];
@@ -309,284 +253,8 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Backward (v0).  Recomputes the forward per edge block, runs the data-gradient chain
-//   dZ3 = m_j * dagg_i * phi'(Z3) ; dE2 = W3^T dZ3 ; dZ2 = dE2 * phi'(Z2) ; dE1 = W2^T dZ2 ;
-//   dZ1 = dE1 * phi'(Z1) ; da_i = sum_j dZ1 ; dc_j = sum_i dZ1
-// in the same chain layout, and streams E1, E2, dZ2, dZ3 rows to memory for the weight-gradient
-// GEMMs (dW3 = dZ3^T E2, dW2 = dZ2^T E1) that follow.
-constexpr int NF3T = T2 * T3 * 2;  // W3^T image: 5 row tiles x 6 k-tiles
-constexpr int NF2T = T1 * T2 * 2;  // W2^T image: 3 x 5
-constexpr int RED_DA_BYTES = 4 * T1 * 16 * 64 * 4;
-
-template <bool DROP, bool F16>
-__global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
-    typedef typename FragT<F16>::type V;  // forward-recomputation operands; gradient operands stay bf16
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int RB = (p.N + 31) / 32;
-    int bid = blockIdx.x;
-    const int sc = bid % p.SC; bid /= p.SC;
-    const int rb = bid % RB;
-    const int b = bid / RB;
-    const int i = rb * 32 + r;
-    const bool vi = i < p.N;
-    const int JC = (p.N + p.SC - 1) / p.SC;
-    const int jbeg = sc * JC, jend = min(p.N, jbeg + JC);
-
-    const V* g2hi = reinterpret_cast<const V*>(p.W2img);
-    const V* g2lo = g2hi + NF2 * 64;
-    const V* g3hi = reinterpret_cast<const V*>(p.W3img);
-    const V* g3lo = g3hi + NF3 * 64;
-    const bf16x8* t3hi = reinterpret_cast<const bf16x8*>(p.W3Timg);
-    const bf16x8* t3lo = t3hi + NF3T * 64;
-    const bf16x8* t2hi = reinterpret_cast<const bf16x8*>(p.W2Timg);
-    const bf16x8* t2lo = t2hi + NF2T * 64;
-
-    uint32_t seed_lo = 0, seed_hi = 0;
-    if (DROP) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
-
-    float areg[T1][2][8], dacc[T1][2][8];
-    {
-        const float* ai = p.a + (size_t)(b * p.N + (vi ? i : 0)) * H1;
-#pragma unroll
-        for (int q = 0; q < T1; ++q)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const float4 t4 = ld4(ai + 32 * q + 16 * s + 8 * u + 4 * h);
-                    areg[q][s][4 * u + 0] = vi ? t4.x : 0.f;
-                    areg[q][s][4 * u + 1] = vi ? t4.y : 0.f;
-                    areg[q][s][4 * u + 2] = vi ? t4.z : 0.f;
-                    areg[q][s][4 * u + 3] = vi ? t4.w : 0.f;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) dacc[q][s][4 * u + t] = 0.f;
-                }
-    }
-    // upstream gradient of agg for my receiver, D layout: dg[m][4g+t] = dagg[i][32m+8g+4h+t]
-    f32x16 dg[T3];
-    {
-        const float* di = p.dagg + (size_t)(b * p.N + (vi ? i : 0)) * p.ld_dagg;
-#pragma unroll
-        for (int m = 0; m < T3; ++m)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 t4 = ld4(di + 32 * m + 8 * g + 4 * h);
-                dg[m][4 * g + 0] = vi ? t4.x * p.agg_scale : 0.f;
-                dg[m][4 * g + 1] = vi ? t4.y * p.agg_scale : 0.f;
-                dg[m][4 * g + 2] = vi ? t4.z * p.agg_scale : 0.f;
-                dg[m][4 * g + 3] = vi ? t4.w * p.agg_scale : 0.f;
-            }
-    }
-
-    for (int j = jbeg + w; j < jend; j += 4) {
-        const float mj = p.mask ? p.mask[b * p.N + j] : 1.f;
-        const float mjs = mj * p.dscale;
-        const uint32_t erow = (uint32_t)((b * p.N + i) * p.N + j);
-        const size_t erow_s = (size_t)erow;
-        const float* cj = p.c + (size_t)(b * p.N + j) * H1;
-
-        // ---- recompute layer 1
-        V e1hi[T1][2], e1lo[T1][2];
-#pragma unroll
-        for (int q = 0; q < T1; ++q)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const float4 c4 = ld4(cj + 32 * q + 16 * s + 8 * u + 4 * h);
-                    const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
-                    uint32_t wd = 0;
-                    if (DROP) wd = drop_word(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, 8 * q + 4 * s + 2 * u + h);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        float x = lrelu(areg[q][s][4 * u + t] + cc[t], p.alpha);
-                        if (DROP && !drop_keep(wd, t, p.thr)) x = 0.f;
-                        v[4 * u + t] = x;
-                    }
-                    if (vi && p.E1 != nullptr)
-                        *reinterpret_cast<float4*>(p.E1 + erow_s * H1 + 32 * q + 16 * s + 8 * u + 4 * h) =
-                            make_float4(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
-                }
-                split8(v, e1hi[q][s], e1lo[q][s]);
-            }
-
-        // ---- recompute layer 2 (keep e2hi afterwards: its signs/zeros give phi'(Z2) and the keep mask)
-        V e2hi[T2][2], e2lo[T2][2];
-#pragma unroll
-        for (int m = 0; m < T2; ++m) {
-            __builtin_amdgcn_sched_barrier(0);
-            f32x16 acc;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 b4 = ld4(p.b2 + 32 * m + 8 * g + 4 * h);
-                acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
-            }
-#pragma unroll
-            for (int q = 0; q < T1; ++q)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int idx = ((m * T1 + q) * 2 + s) * 64 + lane;
-                    acc = mfma3(g2hi[idx], g2lo[idx], e1hi[q][s], e1lo[q][s], acc);
-                }
-            float v[16];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint32_t wd = 0;
-                if (DROP) wd = drop_word(seed_lo, seed_hi, p.tag_base + TAG_E1, erow, 8 * m + 2 * g + h);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float x = lrelu(acc[4 * g + t], p.alpha);
-                    if (DROP && !drop_keep(wd, t, p.thr)) x = 0.f;
-                    v[4 * g + t] = x;
-                }
-                if (vi && p.E2 != nullptr)
-                    *reinterpret_cast<float4*>(p.E2 + erow_s * H2 + 32 * m + 8 * g + 4 * h) =
-                        make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
-            }
-            split8(v, e2hi[m][0], e2lo[m][0]);
-            split8(v + 8, e2hi[m][1], e2lo[m][1]);
-        }
-
-        // ---- recompute Z3, form dZ3 = m_j * dagg * keep * phi'(Z3)
-        bf16x8 z3hi[T3][2], z3lo[T3][2];
-#pragma unroll
-        for (int m = 0; m < T3; ++m) {
-            __builtin_amdgcn_sched_barrier(0);
-            f32x16 acc;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 b4 = ld4(p.b3 + 32 * m + 8 * g + 4 * h);
-                acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
-            }
-#pragma unroll
-            for (int q = 0; q < T2; ++q)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int idx = ((m * T2 + q) * 2 + s) * 64 + lane;
-                    acc = mfma3(g3hi[idx], g3lo[idx], e2hi[q][s], e2lo[q][s], acc);
-                }
-            float v[16];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint32_t wd = 0;
-                if (DROP) wd = drop_word(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, 8 * m + 2 * g + h);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float gt = lrelu_grad(acc[4 * g + t], p.alpha);
-                    if (DROP && !drop_keep(wd, t, p.thr)) gt = 0.f;
-                    v[4 * g + t] = mjs * dg[m][4 * g + t] * gt;
-                }
-                if (vi && p.dZ3 != nullptr)
-                    *reinterpret_cast<float4*>(p.dZ3 + erow_s * H3 + 32 * m + 8 * g + 4 * h) =
-                        make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
-            }
-            split8(v, z3hi[m][0], z3lo[m][0]);
-            split8(v + 8, z3hi[m][1], z3lo[m][1]);
-        }
-
-        // ---- dE2 = W3'^T dZ3 ; dZ2 = dE2 * keep * phi'(Z2)
-        bf16x8 z2hi[T2][2], z2lo[T2][2];
-#pragma unroll
-        for (int m = 0; m < T2; ++m) {
-            __builtin_amdgcn_sched_barrier(0);
-            f32x16 acc;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-#pragma unroll
-            for (int q = 0; q < T3; ++q)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int idx = ((m * T3 + q) * 2 + s) * 64 + lane;
-                    acc = mfma3(t3hi[idx], t3lo[idx], z3hi[q][s], z3lo[q][s], acc);
-                }
-            float v[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                // e2 value of register k = element (k&7) of fragment k>>3: >0 -> 1, <0 -> alpha,
-                // ==0 -> dropped (dropout on) or z == 0 (dropout off: slope alpha, as torch)
-                const float e = (float)e2hi[m][k >> 3][k & 7];
-                const float gt = e > 0.f ? 1.f : (e < 0.f ? p.alpha : (DROP ? 0.f : p.alpha));
-                v[k] = acc[k] * gt;
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                if (vi && p.dZ2 != nullptr)
-                    *reinterpret_cast<float4*>(p.dZ2 + erow_s * H2 + 32 * m + 8 * g + 4 * h) =
-                        make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
-            split8(v, z2hi[m][0], z2lo[m][0]);
-            split8(v + 8, z2hi[m][1], z2lo[m][1]);
-        }
-
-        // ---- dE1 = W2'^T dZ2 ; dZ1 = dE1 * keep * phi'(Z1) ; da_i += dZ1 ; dc_j = sum_i dZ1
-        float* dcj = p.dc + ((size_t)rb * p.B * p.N + (size_t)(b * p.N + j)) * H1;
-#pragma unroll
-        for (int m = 0; m < T1; ++m) {
-            __builtin_amdgcn_sched_barrier(0);
-            f32x16 acc;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-#pragma unroll
-            for (int q = 0; q < T2; ++q)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int idx = ((m * T2 + q) * 2 + s) * 64 + lane;
-                    acc = mfma3(t2hi[idx], t2lo[idx], z2hi[q][s], z2lo[q][s], acc);
-                }
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const float4 c4 = ld4(cj + 32 * m + 16 * s + 8 * u + 4 * h);
-                    const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
-                    uint32_t wd = 0;
-                    if (DROP) wd = drop_word(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, 8 * m + 4 * s + 2 * u + h);
-                    float red4[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        float gt = lrelu_grad(areg[m][s][4 * u + t] + cc[t], p.alpha);
-                        if (DROP && !drop_keep(wd, t, p.thr)) gt = 0.f;
-                        // register 8s + 4u + t of the accumulator <-> element 4u+t of k-step s
-                        const float dz = vi ? acc[8 * s + 4 * u + t] * gt : 0.f;
-                        dacc[m][s][4 * u + t] += dz;
-                        float x = dz;
-                        x += __shfl_xor(x, 1, 64);
-                        x += __shfl_xor(x, 2, 64);
-                        x += __shfl_xor(x, 4, 64);
-                        x += __shfl_xor(x, 8, 64);
-                        x += __shfl_xor(x, 16, 64);
-                        red4[t] = x;
-                    }
-                    if (r == 0)
-                        *reinterpret_cast<float4*>(dcj + 32 * m + 16 * s + 8 * u + 4 * h) =
-                            make_float4(red4[0], red4[1], red4[2], red4[3]);
-                }
-        }
-    }
-
-    // ---- da: reduce over the four waves (disjoint sender subsets)
-    float* red = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int q = 0; q < T1; ++q)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) red[((w * T1 + q) * 16 + 8 * s + k) * 64 + lane] = dacc[q][s][k];
-    __syncthreads();
-    float* out = p.da + ((size_t)sc * p.B + b) * p.N * H1;
-    for (int e = tid; e < T1 * 16 * 64; e += 256) {
-        const int ln = e & 63, k = (e >> 6) & 15, q = e >> 10;
-        const float sum = red[e] + red[e + T1 * 1024] + red[e + 2 * T1 * 1024] + red[e + 3 * T1 * 1024];
-        const int ii = rb * 32 + (ln & 31);
-        const int f = 32 * q + 16 * (k >> 3) + 8 * ((k >> 2) & 1) + 4 * (ln >> 5) + (k & 3);
-        if (ii < p.N) out[(size_t)ii * H1 + f] = sum;
-    }
-}
-
 }  // namespace
+
 
 extern "C" int mpg_pack_weights(const float* W, int ldw, int rows, int cols, int transpose, float scale, int f16,
                                 void* img, void* stream) {
@@ -631,14 +299,3 @@ extern "C" int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream) {
     return (int)hipGetLastError();
 }
 
-extern "C" int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream) {
-    if (p->B <= 0 || p->N <= 0 || p->SC <= 0) return -1;
-    const int RB = (p->N + 31) / 32;
-    dim3 grid(p->B * RB * p->SC), block(256);
-    hipStream_t st = (hipStream_t)stream;
-    if (p->thr && p->f16) hipLaunchKernelGGL((edge_bwd_kernel<true, true>), grid, block, RED_DA_BYTES, st, *p);
-    else if (p->thr) hipLaunchKernelGGL((edge_bwd_kernel<true, false>), grid, block, RED_DA_BYTES, st, *p);
-    else if (p->f16) hipLaunchKernelGGL((edge_bwd_kernel<false, true>), grid, block, RED_DA_BYTES, st, *p);
-    else hipLaunchKernelGGL((edge_bwd_kernel<false, false>), grid, block, RED_DA_BYTES, st, *p);
-    return (int)hipGetLastError();
-}

@@ -1,0 +1,71 @@
+// Shared pieces of the fused edge-network kernels (forward: edge.hip, backward: edge_bwd.hip).
+#pragma once
+#include "common.h"
+#include "../../include/mpgan_amd.h"
+
+namespace {
+
+
+constexpr int H1 = 96, H2 = 160, H3 = 192;
+constexpr int T1 = 3, T2 = 5, T3 = 6;  // 32-row tiles per layer width
+
+// fragment fetch: from the LDS copy when present, else straight from the (L2-resident) image
+template <bool LDS, typename V>
+MPG_DEV V frag(const V* __restrict__ glb, const V* lds, int idx) {
+    if constexpr (LDS) return lds[idx];
+    else return glb[idx];
+}
+
+MPG_DEV float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// global -> LDS copy with 16 x 16 B loads in flight per thread (a plain copy loop runs one L2 round
+// trip per iteration: ~10 us for the 150 KiB of weight images)
+template <typename V>
+MPG_DEV void copy_to_lds(V* dst, const V* __restrict__ src, int n16, int tid) {
+    for (int base = 0; base < n16; base += 256 * 16) {
+        V tmp[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = base + u * 256 + tid;
+            if (i < n16) tmp[u] = src[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = base + u * 256 + tid;
+            if (i < n16) dst[i] = tmp[u];
+        }
+    }
+}
+
+// One 32-row output tile of a chained layer: KS = 2*QT k-steps of 3 MFMAs.  Fragments of k-step
+// k+1 are requested before the MFMAs of k-step k are issued, and after every k-step a slice of
+// OTHER work (the epilogue of the previous tile, passed as `side(k)`) is placed, so that a single
+// wave keeps the matrix pipe and the VALU busy together; sched_barrier pins that order.
+template <int KS, typename V, typename LH, typename LL, typename Side>
+MPG_DEV void tile_chain(f32x16& acc, const V (*bhi)[2], const V (*blo)[2], LH load_hi, LL load_lo, Side side) {
+    V ah[2], al[2];
+    ah[0] = load_hi(0);
+    al[0] = load_lo(0);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        if (k + 1 < KS) {
+            ah[(k + 1) & 1] = load_hi(k + 1);
+            al[(k + 1) & 1] = load_lo(k + 1);
+        }
+        acc = mfma3(ah[k & 1], al[k & 1], bhi[k >> 1][k & 1], blo[k >> 1][k & 1], acc);
+        side(k);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// LDS plan of the forward kernel: W3 hi | W3 lo | W2 hi  (W2 lo streams from L2)
+constexpr int NF2 = T2 * T1 * 2;  // 30 fragments of 1 KiB
+constexpr int NF3 = T3 * T2 * 2;  // 60
+constexpr int FWD_W_BYTES = (2 * NF3 + NF2) * 1024;    // 153,600 weight images
+constexpr int FWD_BIAS_BYTES = (H2 + H3) * 4;          //   1,408 b2 | b3
+constexpr int FWD_C_SLOTS = 22;                        // sender rows of c staged in LDS (22 * 384 B)
+constexpr int FWD_LDS_BYTES = FWD_W_BYTES + FWD_BIAS_BYTES + FWD_C_SLOTS * H1 * 4;  // 163,456 <= 163,840
+constexpr int RED_BYTES = 4 * T3 * 16 * 64 * 4;        //  98,304
+constexpr int NOLDS_BYTES = RED_BYTES + FWD_BIAS_BYTES + FWD_C_SLOTS * H1 * 4;
+
+}  // namespace

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import MpgGemm, MpgEdgeFwd, MpgEdgeBwd, check
+from ._lib import MpgGemm, MpgEdgeFwd, MpgEdgeBwd, MpgEdgeDw, check
 
 H1, H2, H3 = 96, 160, 192
 TAG_E0, TAG_E1, TAG_E2, TAG_N0, TAG_N1, TAG_N2, TAG_GENERIC = 1, 2, 3, 4, 5, 6, 7
@@ -227,6 +227,10 @@ class FusedMPLayerFn(torch.autograd.Function):
         e.skip_masked = int(OPTIONS["skip_masked"])
         e.weights_in_lds = int(OPTIONS["weights_in_lds"])
         e.f16 = int(f16)
+        RB = (N + 31) // 32
+        need_grad = any(ctx.needs_input_grad)
+        sign3 = torch.empty((B * RB * N * 96,), device=dev, dtype=torch.int64) if need_grad else None
+        e.sign3 = None if sign3 is None else C.c_void_p(sign3.data_ptr())
         check(_lib.lib().mpg_edge_fwd(C.byref(e), _stream()), "mpg_edge_fwd")
         agg = aggp[0] if SC == 1 else aggp.sum(0)
 
@@ -234,13 +238,13 @@ class FusedMPLayerFn(torch.autograd.Function):
         h2 = linear_fwd(h1, V2, c2, act=True, alpha=alpha, drop=dr(TAG_N1))
         y = linear_fwd(h2, V3, c3, act=False, drop=dr(TAG_N2))
 
-        ctx.save_for_backward(x2, m1, a, c, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3)
+        ctx.save_for_backward(x2, m1, a, c, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3)
         ctx.cfg = (B, N, F, sum_agg, alpha, thr, dscale, tag, SC, f16)
         return y.reshape(B, N, V3.shape[0])
 
     @staticmethod
     def backward(ctx, gy):
-        x2, m1, a, c, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3 = ctx.saved_tensors
+        x2, m1, a, c, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3 = ctx.saved_tensors
         B, N, F, sum_agg, alpha, thr, dscale, tag, SC, f16 = ctx.cfg
         V = B * N
         dev = x2.device
@@ -270,29 +274,28 @@ class FusedMPLayerFn(torch.autograd.Function):
             linear_bwd_weight(dz1, x2, out=dV1, out_col0=H3)
             dc1 = dz1.sum(0)
 
-        # ---- edge network backward
+        # ---- edge network backward: data path, then (if wanted) the weight-gradient pass
         W2img = pack_weights(W2, H2, H1, scale=dscale, f16=f16)
-        W3img = pack_weights(W3, H3, H2, scale=dscale, f16=f16)
         W3Timg = pack_weights(W3, H3, H2, transpose=True, scale=dscale)
         W2Timg = pack_weights(W2, H2, H1, transpose=True, scale=dscale)
         RB = (N + 31) // 32
-        E = V * N
+        nblk = B * RB * N
         dap = torch.empty((SC, V, H1), device=dev, dtype=torch.float32)
         dcp = torch.empty((RB, V, H1), device=dev, dtype=torch.float32)
-        E1 = E2 = dZ2 = dZ3 = None
+        stE2 = stZ2 = None
         if need_w:
-            E1 = torch.empty((E, H1), device=dev, dtype=torch.float32)
-            E2 = torch.empty((E, H2), device=dev, dtype=torch.float32)
-            dZ2 = torch.empty((E, H2), device=dev, dtype=torch.float32)
-            dZ3 = torch.empty((E, H3), device=dev, dtype=torch.float32)
+            stE2 = torch.empty((nblk, 2, H2, 32), device=dev, dtype=torch.int16)
+            stZ2 = torch.empty((nblk, 2, H2, 32), device=dev, dtype=torch.int16)
         e = MpgEdgeBwd()
         e.a, e.c, e.mask = _p(a), _p(c), _p(m1)
         e.dagg, e.ld_dagg = _p(dh0), dh0.stride(0)
-        e.W2img, e.W3img = C.c_void_p(W2img.data_ptr()), C.c_void_p(W3img.data_ptr())
+        e.sign3 = C.c_void_p(sign3.data_ptr())
+        e.W2img = C.c_void_p(W2img.data_ptr())
         e.W3Timg, e.W2Timg = C.c_void_p(W3Timg.data_ptr()), C.c_void_p(W2Timg.data_ptr())
-        e.b2, e.b3 = _p(b2), _p(b3)
+        e.b2 = _p(b2)
         e.da, e.dc = _p(dap), _p(dcp)
-        e.E1, e.E2, e.dZ2, e.dZ3 = _p(E1), _p(E2), _p(dZ2), _p(dZ3)
+        e.stageE2 = None if stE2 is None else C.c_void_p(stE2.data_ptr())
+        e.stageZ2 = None if stZ2 is None else C.c_void_p(stZ2.data_ptr())
         e.B, e.N, e.SC = B, N, SC
         e.alpha, e.agg_scale = alpha, 1.0 if sum_agg else 1.0 / N
         e.seed, e.tag_base, e.thr, e.dscale = _p(seed_t), tag, thr, dscale
@@ -302,11 +305,23 @@ class FusedMPLayerFn(torch.autograd.Function):
         dc = dcp[0] if RB == 1 else dcp.sum(0)
         dW1 = db1 = dW2 = db2 = dW3 = db3 = None
         if need_w:
-            dW3 = linear_bwd_weight(dZ3, E2, out_scale=dscale)
-            db3 = dZ3.sum(0)
-            dW2 = linear_bwd_weight(dZ2, E1, out_scale=dscale)
-            db2 = dZ2.sum(0)
-            del E1, E2, dZ2, dZ3
+            nwg = min(256, nblk)
+            part = torch.empty((nwg, H3 * H2 + H2 * H1 + H3 + H2), device=dev, dtype=torch.float32)
+            dW3, dW2 = torch.empty_like(W3), torch.empty_like(W2)
+            db3, db2 = torch.empty_like(b3), torch.empty_like(b2)
+            d = MpgEdgeDw()
+            d.a, d.c, d.mask = _p(a), _p(c), _p(m1)
+            d.dagg, d.ld_dagg = _p(dh0), dh0.stride(0)
+            d.sign3 = C.c_void_p(sign3.data_ptr())
+            d.stageE2, d.stageZ2 = C.c_void_p(stE2.data_ptr()), C.c_void_p(stZ2.data_ptr())
+            d.part, d.nwg = _p(part), nwg
+            d.dW3, d.dW2, d.db3, d.db2 = _p(dW3), _p(dW2), _p(db3), _p(db2)
+            d.B, d.N = B, N
+            d.alpha, d.agg_scale = alpha, 1.0 if sum_agg else 1.0 / N
+            d.seed, d.tag_base, d.thr, d.dscale = _p(seed_t), tag, thr, dscale
+            d.f16 = int(f16)
+            check(_lib.lib().mpg_edge_dw(C.byref(d), _stream()), "mpg_edge_dw")
+            del stE2, stZ2
             # layer 1 (fe.net.0): a = W1[:, :F] x + b1, c = W1[:, F:] x
             dW1 = torch.empty_like(W1)
             linear_bwd_weight(da, x2, out=dW1, out_col0=0)
