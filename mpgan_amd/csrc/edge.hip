@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
             copy_to_lds(l2hi, g2hi, NF2 * 64, tid);
         }
     }
-    const V* w2lsrc = (WLDS && (p.skip_masked & 4)) ? l2hi : g2lo;
+    const __amdgpu_buffer_rsrc_t r2 = img_rsrc(p.W2img, 2 * NF2);
+    const int lane16 = lane * 16;
     for (int t = tid; t < H2 + H3; t += 256) lbias[t] = t < H2 ? p.b2[t] : p.b3[t - H2];
     const float* lb2 = lbias;
     const float* lb3 = lbias + H2;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
         {
             V w2l[2][T1 * 2];
 #pragma unroll
-            for (int k = 0; k < T1 * 2; ++k) w2l[0][k] = w2lsrc[k * 64 + lane];
+            for (int k = 0; k < T1 * 2; ++k) w2l[0][k] = img_frag<V>(r2, lane16, NF2 + k);
             f32x16 accs[2];
             float v2[16];
 #pragma unroll
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
                 if (m < T2) {
                     if (m + 1 < T2) {
 #pragma unroll
-                        for (int k = 0; k < T1 * 2; ++k) w2l[(m + 1) & 1][k] = w2lsrc[((m + 1) * T1 * 2 + k) * 64 + lane];
+                        for (int k = 0; k < T1 * 2; ++k) w2l[(m + 1) & 1][k] = img_frag<V>(r2, lane16, NF2 + (m + 1) * T1 * 2 + k);
                     }
                     f32x16& acc = accs[m & 1];
 #pragma unroll

@@ -26,6 +26,9 @@ constexpr int BWD_DG_BYTES = T3 * 4 * 64 * 16;
 constexpr int BWD_A_BYTES = T1 * 4 * 64 * 16;
 constexpr int BWD_C_SLOTS = 8;
 constexpr int BWD_LDS_BYTES = BWD_W_BYTES + BWD_DG_BYTES + BWD_A_BYTES + H2 * 4 + BWD_C_SLOTS * H1 * 4;
+#ifndef MPG_PF
+#define MPG_PF 4
+#endif
 constexpr int RED_DA_BYTES = 4 * T1 * 16 * 64 * 4;
 
 // staging: block blk = (b*RB + rb)*N + j ; plane part (0 hi, 1 lo) ; row fi = fragment-order feature
@@ -60,11 +63,10 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     const int JC = (p.N + p.SC - 1) / p.SC;
     const int jbeg = sc * JC, jend = min(p.N, jbeg + JC);
 
-    const V* g2hi = reinterpret_cast<const V*>(p.W2img);
-    const V* g2lo = g2hi + NF2 * 64;
+    const __amdgpu_buffer_rsrc_t r2 = img_rsrc(p.W2img, 2 * NF2);     // W2 hi | lo (forward image)
+    const __amdgpu_buffer_rsrc_t r2t = img_rsrc(p.W2Timg, 2 * NF2T);  // W2^T hi | lo (bf16)
+    const int lane16 = lane * 16;
     const bf16x8* t3g = reinterpret_cast<const bf16x8*>(p.W3Timg);
-    const bf16x8* t2hi = reinterpret_cast<const bf16x8*>(p.W2Timg);
-    const bf16x8* t2lo = t2hi + NF2T * 64;
     bf16x8* l3thi = reinterpret_cast<bf16x8*>(smem);
     bf16x8* l3tlo = l3thi + NF3T * 64;
     float4* ldg = reinterpret_cast<float4*>(smem + BWD_W_BYTES);                 // [(m*4+g)][lane]
@@ -143,10 +145,10 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
         //      stream from L2 through a 5-deep fragment ring that runs across the five tiles
         V e2hi[T2][2], e2lo[T2][2];
         {
-            constexpr int KS = T1 * 2, TOT = T2 * KS, PF = 4;
+            constexpr int KS = T1 * 2, TOT = T2 * KS, PF = MPG_PF;
             V rh[PF + 1], rl[PF + 1];
 #pragma unroll
-            for (int k = 0; k < PF; ++k) { rh[k] = g2hi[k * 64 + lane]; rl[k] = g2lo[k * 64 + lane]; }
+            for (int k = 0; k < PF; ++k) { rh[k] = img_frag<V>(r2, lane16, k); rl[k] = img_frag<V>(r2, lane16, NF2 + k); }
             f32x16 accs[2];
             float v2[16];
             auto epi2 = [&](int mm, int g) {
@@ -171,8 +173,8 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             for (int kk = 0; kk < TOT; ++kk) {
                 const int m = kk / KS, k = kk % KS;
                 if (kk + PF < TOT) {
-                    rh[(kk + PF) % (PF + 1)] = g2hi[(kk + PF) * 64 + lane];
-                    rl[(kk + PF) % (PF + 1)] = g2lo[(kk + PF) * 64 + lane];
+                    rh[(kk + PF) % (PF + 1)] = img_frag<V>(r2, lane16, kk + PF);
+                    rl[(kk + PF) % (PF + 1)] = img_frag<V>(r2, lane16, NF2 + kk + PF);
                 }
                 f32x16& acc = accs[m & 1];
                 if (k == 0) {
@@ -193,7 +195,13 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
         // ---- dZ3 = m_j * dagg * keep3 * phi'(Z3), phi' from the forward's ballots
         bf16x8 z3hi[T3][2], z3lo[T3][2];
         {
+            // the 96 ballot words of this block: two vector loads (lane l holds word l / word 64 + l),
+            // then v_readlane per word -- 96 separate scalar-value loads would sit in ~190 VGPRs
             const unsigned long long* sg = p.sign3 + blk * (T3 * 16);
+            const unsigned long long bwa = sg[lane];
+            const unsigned long long bwb = sg[64 + (lane & 31)];
+            const unsigned int bwa_lo = (unsigned int)bwa, bwa_hi = (unsigned int)(bwa >> 32);
+            const unsigned int bwb_lo = (unsigned int)bwb, bwb_hi = (unsigned int)(bwb >> 32);
 #pragma unroll
             for (int m = 0; m < T3; ++m) {
                 float v[16];
@@ -205,7 +213,10 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                     const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const bool pos = __builtin_amdgcn_inverse_ballot_w64(sg[m * 16 + 4 * g + t]);
+                        const int k = m * 16 + 4 * g + t;
+                        const unsigned int lo = k < 64 ? __builtin_amdgcn_readlane(bwa_lo, k) : __builtin_amdgcn_readlane(bwb_lo, k - 64);
+                        const unsigned int hi = k < 64 ? __builtin_amdgcn_readlane(bwa_hi, k) : __builtin_amdgcn_readlane(bwb_hi, k - 64);
+                        const bool pos = __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)hi << 32) | lo);
                         float gt = pos ? 1.f : p.alpha;
                         if (DROP && !drop_keep(wd, t, p.thr)) gt = 0.f;
                         v[4 * g + t] = mjs * dd[t] * gt;
@@ -263,10 +274,10 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
         //      three tiles) ; dZ1 = dE1 * keep1 * phi'(Z1) ; da_i += dZ1 ; dc_j = sum_i dZ1
         {
             float* dcj = p.dc + ((size_t)rb * p.B * p.N + (size_t)(b * p.N + j)) * H1;
-            constexpr int KS = T2 * 2, TOT = T1 * KS, PF = 4;
+            constexpr int KS = T2 * 2, TOT = T1 * KS, PF = MPG_PF;
             bf16x8 rh[PF + 1], rl[PF + 1];
 #pragma unroll
-            for (int k = 0; k < PF; ++k) { rh[k] = t2hi[k * 64 + lane]; rl[k] = t2lo[k * 64 + lane]; }
+            for (int k = 0; k < PF; ++k) { rh[k] = img_frag<bf16x8>(r2t, lane16, k); rl[k] = img_frag<bf16x8>(r2t, lane16, NF2T + k); }
             f32x16 accs[2];
             auto epi5 = [&](int mm, int su) {  // slice (s,u) of tile mm
                 const int s = su >> 1, u = su & 1;
@@ -299,8 +310,8 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             for (int kk = 0; kk < TOT; ++kk) {
                 const int m = kk / KS, k = kk % KS;
                 if (kk + PF < TOT) {
-                    rh[(kk + PF) % (PF + 1)] = t2hi[(kk + PF) * 64 + lane];
-                    rl[(kk + PF) % (PF + 1)] = t2lo[(kk + PF) * 64 + lane];
+                    rh[(kk + PF) % (PF + 1)] = img_frag<bf16x8>(r2t, lane16, kk + PF);
+                    rl[(kk + PF) % (PF + 1)] = img_frag<bf16x8>(r2t, lane16, NF2T + kk + PF);
                 }
                 f32x16& acc = accs[m & 1];
                 if (k == 0) {
@@ -604,14 +615,23 @@ __global__ __launch_bounds__(256, 1) void edge_dw_kernel(const MpgEdgeDw p) {
     else edge_dw_body<DROP, F16, 35, 45>(p, smem, w);
 }
 
-// out = scale * sum over workgroup partials, feature indices mapped back from fragment order
-__global__ void edge_dw_reduce(const float* __restrict__ part, int nwg, float scale, float* __restrict__ dW3,
-                               float* __restrict__ dW2, float* __restrict__ db3, float* __restrict__ db2) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// out = scale * sum over workgroup partials, feature indices mapped back from fragment order.
+// 32 outputs x 8 partial-slices per block: the 256 partials of an output are read by 8 threads.
+__global__ __launch_bounds__(256) void edge_dw_reduce(const float* __restrict__ part, int nwg, float scale,
+                                                      float* __restrict__ dW3, float* __restrict__ dW2,
+                                                      float* __restrict__ db3, float* __restrict__ db2) {
+    __shared__ float red[8][32];
     constexpr int PER = H3 * H2 + H2 * H1 + H3 + H2;
-    if (idx >= PER) return;
+    const int ix = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + ix;
     float s = 0.f;
-    for (int g = 0; g < nwg; ++g) s += part[(size_t)g * PER + idx];
+    if (idx < PER)
+        for (int g = sl; g < nwg; g += 8) s += part[(size_t)g * PER + idx];
+    red[sl][ix] = s;
+    __syncthreads();
+    if (sl != 0 || idx >= PER) return;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += red[k][ix];
     if (idx < H3 * H2) {
         const int r3 = idx / H2, c2 = idx % H2;
         dW3[feat_of_fi(r3) * H2 + feat_of_fi(c2)] = s * scale;
@@ -624,6 +644,7 @@ __global__ void edge_dw_reduce(const float* __restrict__ part, int nwg, float sc
         db2[feat_of_fi(idx - H3 * H2 - H2 * H1 - H3)] = s;
     }
 }
+
 }  // namespace
 
 extern "C" int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream) {
@@ -673,7 +694,7 @@ extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
     else if (p->f16) hipLaunchKernelGGL((edge_dw_kernel<false, true>), grid, block, DW_LDS_BYTES, st, *p);
     else hipLaunchKernelGGL((edge_dw_kernel<false, false>), grid, block, DW_LDS_BYTES, st, *p);
     constexpr int PER = H3 * H2 + H2 * H1 + H3 + H2;
-    hipLaunchKernelGGL(edge_dw_reduce, dim3((PER + 255) / 256), dim3(256), 0, st, p->part, p->nwg, p->dscale, p->dW3,
+    hipLaunchKernelGGL(edge_dw_reduce, dim3((PER + 31) / 32), dim3(256), 0, st, p->part, p->nwg, p->dscale, p->dW3,
                        p->dW2, p->db3, p->db2);
     return (int)hipGetLastError();
 }

@@ -18,6 +18,19 @@ MPG_DEV V frag(const V* __restrict__ glb, const V* lds, int idx) {
 
 MPG_DEV float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// Streamed weight fragments go through buffer loads: one VGPR (lane * 16) + a scalar fragment
+// offset.  Plain pointer arithmetic makes hipcc keep a 64-bit VGPR address per fragment (hundreds of
+// registers hoisted out of the sender loop, spilled to scratch -- and every scratch reload drains
+// vmcnt, which serialises the whole prefetch pipeline).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+MPG_DEV __amdgpu_buffer_rsrc_t img_rsrc(const void* p, int nfrag) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, nfrag * 1024, 0x00020000);
+}
+template <typename V>
+MPG_DEV V img_frag(__amdgpu_buffer_rsrc_t r, int lane16, int frag) {
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(r, lane16, frag * 1024, 0));
+}
+
 // global -> LDS copy with 16 x 16 B loads in flight per thread (a plain copy loop runs one L2 round
 // trip per iteration: ~10 us for the 150 KiB of weight images)
 template <typename V>

@@ -21,7 +21,7 @@ from typing import Optional
 import torch
 from torch import nn
 
-from . import _lib, ops
+from . import _lib, ops, dist as mdist
 from .mpgan import MPGenerator, MPDiscriminator
 
 LR = {  # setup_training.py:848-872 (lr_disc, lr_gen) per jet type for model = mpgan
@@ -166,8 +166,7 @@ class TrainStep:
         self.fG.rmsprop(self.lr_gen, gscale=1.0 / self.world)
 
     def _allreduce(self, flat: FlatParams):
-        if self.world > 1:
-            torch.distributed.all_reduce(flat.grad, group=self.pg)  # sum; 1/world folded into rmsprop
+        mdist.allreduce_sum_(flat.grad, self.pg, self.world)  # sum; 1/world is folded into rmsprop
 
     def _eager(self):
         self._seg_D(); self._allreduce(self.fD)

@@ -14,6 +14,9 @@ Parity pin: every function here is checked by ``tests/test_oracle_golden.py`` ag
 ``tests/golden/*.npz``, which were produced by ``tests/gen_golden.py`` importing the
 reference's own ``mpgan`` / ``gapt`` packages in the build container (the reference has
 no tests or golden vectors of its own -- SURVEY.md section 4).
+
+The reference is Python only: there is nothing to compile into oracle/_ref/; the imported
+reference itself played that role when the goldens were generated.
 """
 
 from .mpgan_ref import (  # noqa: F401

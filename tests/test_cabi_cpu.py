@@ -1,0 +1,108 @@
+"""CPU: the C-ABI library builds/loads here, exports every symbol include/mpgan_amd.h declares, its
+struct layouts match the ctypes mirrors, and the host-side logic behaves (no compute calls)."""
+import ctypes
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mpgan_amd.h")
+
+
+def _declared():
+    txt = open(HEADER).read()
+    return sorted(set(re.findall(r"^int\s+(mpg_\w+)\s*\(", txt, flags=re.M)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mpgan_amd import _lib
+    lib = _lib.lib()
+    names = _declared()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.SIGNATURES) == names  # ctypes table and header list the same entry points
+
+
+def test_struct_layouts_match_header():
+    """sizeof of every struct as gcc sees the header == ctypes.sizeof of the Python mirror."""
+    from mpgan_amd import _lib
+    structs = ["MpgGemm", "MpgEdgeFwd", "MpgEdgeBwd", "MpgEdgeDw", "MpgAttn"]
+    src = '#include <stdio.h>\n#include "mpgan_amd.h"\nint main(){' + "".join(
+        f'printf("{s} %zu\\n", sizeof({s}));' for s in structs) + "return 0;}"
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-I", os.path.dirname(HEADER), c, "-o", exe], check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    sizes = dict(line.split() for line in out.strip().splitlines())
+    for s in structs:
+        assert int(sizes[s]) == ctypes.sizeof(getattr(_lib, s)), s
+
+
+def test_host_helpers():
+    from mpgan_amd import ops
+    assert ops.drop_params(0.0) == (0, 1.0)
+    assert ops.drop_params(0.5) == (128, 2.0)
+    thr, sc = ops.drop_params(0.3)
+    assert thr == 77 and abs(sc - 256.0 / 179.0) < 1e-12
+    with pytest.raises(ValueError):
+        ops.drop_params(0.9999)
+    assert ops._sender_chunks(256, 30) == 1        # every CU already has a workgroup
+    assert ops._sender_chunks(16, 150) * 16 * 5 >= 224
+    assert ops._sender_chunks(1, 1) == 1
+    a, b = ops.next_tag(), ops.next_tag()
+    assert b - a == 8
+
+
+def test_modules_build_on_cpu_with_reference_state_dict_keys():
+    import json
+    from mpgan_amd import train
+    from oracle import train_ref as T
+    G, D = train.default_mpgan(30, device="cpu")
+    Gg, Dg = train.default_gapt(30, device="cpu")
+    m = json.load(open(os.path.join(ROOT, "tests", "golden", "manifests.json")))
+    assert {k: list(v.shape) for k, v in G.state_dict().items()} == m["mpgan_G"]
+    assert {k: list(v.shape) for k, v in D.state_dict().items()} == m["mpgan_D"]
+    assert {k: list(v.shape) for k, v in Gg.state_dict().items()} == m["gapt_G"]
+    assert {k: list(v.shape) for k, v in Dg.state_dict().items()} == m["gapt_D"]
+    assert list(Dg.state_dict().keys()) == list(m["gapt_D"].keys()) or sorted(Dg.state_dict()) == sorted(m["gapt_D"])
+    # reference-format state dicts load (strict)
+    G.load_state_dict(T.init_state_dict(T.mpgan_param_shapes(True), 0))
+    Dg.load_state_dict(T.init_state_dict(T.gapt_param_shapes(False), 0))
+
+
+def test_product_has_no_cpu_path_and_says_so():
+    from mpgan_amd import train
+    G, _ = train.default_mpgan(30, device="cpu")
+    x = torch.randn(2, 30, 32)
+    labels = torch.full((2, 1), 0.5)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        G(x, labels)
+
+
+def test_unsupported_options_raise():
+    from mpgan_amd.mpgan import MPLayer, LinearNet
+    from mpgan_amd.gapt import MAB
+    with pytest.raises(NotImplementedError):
+        MPLayer(32, [96, 160, 192], [256, 256], 32, fully_connected=False)
+    with pytest.raises(NotImplementedError):
+        MPLayer(32, [64, 64], [256, 256], 32)
+    with pytest.raises(NotImplementedError):
+        LinearNet([8, 8], batch_norm=True)
+    with pytest.raises(NotImplementedError):
+        MAB(64, 4, layer_norm=True)
+
+
+def test_product_does_not_import_the_oracle():
+    import sys
+    import importlib
+    for mod in [m for m in sys.modules if m.startswith("mpgan_amd")]:
+        src = getattr(sys.modules[mod], "__file__", None)
+        if src and src.endswith(".py"):
+            assert "import oracle" not in open(src).read() and "from oracle" not in open(src).read(), mod
