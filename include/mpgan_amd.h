@@ -45,9 +45,14 @@ typedef struct MpgGemm {
     int ldr;
     int accumulate;      /* C += result instead of C = result                                       */
     int f16;             /* 1: split operands as fp16 hi/lo (forward products); 0: bf16 hi/lo (gradients) */
+    int ones_col;        /* 1: column N-1 of B is the constant 1 (N counts it): C[:, N-1] = row sums of A  */
 } MpgGemm;
 
 int mpg_gemm(const MpgGemm* g, int ak, int bk, int splitk, void* stream);
+
+/* Sum S split-K partial slices [S][N][K + has_bias] into out[n*ldo + k] (and bias[n] from the extra column). */
+int mpg_splitk_reduce(const float* part, int S, int N, int K, int has_bias, float* out, int ldo, float* bias,
+                      void* stream);
 
 /* out = in * gate(H): backward through Dropout (and LeakyReLU when gate_act) ahead of a GEMM. */
 int mpg_gate(const float* in, int ldi, const float* H, int ldh, float* out, int ldo, int M, int N,

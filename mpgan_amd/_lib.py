@@ -34,7 +34,7 @@ class MpgGemm(C.Structure):
         ("gateH", _fp), ("ldh", C.c_int), ("gate_act", C.c_int),
         ("gate_tag", C.c_uint32), ("gate_thr", C.c_uint32), ("gate_scale", C.c_float),
         ("resid", _fp), ("ldr", C.c_int),
-        ("accumulate", C.c_int), ("f16", C.c_int),
+        ("accumulate", C.c_int), ("f16", C.c_int), ("ones_col", C.c_int),
     ]
 
 
@@ -93,6 +93,7 @@ class MpgAttn(C.Structure):
 # name -> (restype, argtypes); kept in step with include/mpgan_amd.h (tests check the symbol list)
 SIGNATURES = {
     "mpg_gemm": (C.c_int, [C.POINTER(MpgGemm), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mpg_splitk_reduce": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_void_p]),
     "mpg_gate": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                            _fp, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]),
     "mpg_dropout_mask": (C.c_int, [_fp, C.c_uint64, C.c_int, _fp, C.c_uint32, C.c_uint32, C.c_void_p]),

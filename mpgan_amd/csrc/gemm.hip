@@ -17,17 +17,20 @@
 
 namespace {
 
-template <bool KC, typename V>  // KC: the contraction index k is the contiguous one in memory
-MPG_DEV void stage_tile(const float* __restrict__ P, int ld, const float* __restrict__ P2, int ld2, int K1,
-                        int row0, int nrows, int kt, int kend, V (*hi)[2][64], V (*lo)[2][64],
-                        int tid, bool vec_ok) {
-    typedef typename ElemOf<V>::type E;
+// Staging is split in two so the loop can overlap: tile_load() puts the next k-tile's 8 floats per
+// thread and operand into registers BEFORE the MFMAs of the current tile, tile_store() converts them to
+// 16-bit hi/lo and writes the LDS fragments after the barrier (one workgroup has only a handful of
+// k-tiles and few co-resident workgroups, so an un-pipelined loop pays a full HBM/L2 round trip per tile).
+// `ones_row` (>= 0): that row of the operand is the constant 1 (virtual ones column: C gets the column
+// sums of the other operand, i.e. the bias gradient, for free).
+template <bool KC>
+MPG_DEV void tile_load(float (&v)[8], const float* __restrict__ P, int ld, const float* __restrict__ P2, int ld2,
+                       int K1, int row0, int nrows, int kt, int kend, int tid, bool vec_ok, int ones_row) {
     if constexpr (KC) {
         const int row = tid >> 2, kc = tid & 3;
         const int gr = row0 + row;
         const int k0 = kt + 8 * kc;
-        float v[8];
-        if (vec_ok && gr < nrows && k0 + 8 <= kend && P2 == nullptr) {
+        if (vec_ok && gr < nrows && gr != ones_row && k0 + 8 <= kend && P2 == nullptr) {
             const float4 u0 = *reinterpret_cast<const float4*>(P + (size_t)gr * ld + k0);
             const float4 u1 = *reinterpret_cast<const float4*>(P + (size_t)gr * ld + k0 + 4);
             v[0] = u0.x; v[1] = u0.y; v[2] = u0.z; v[3] = u0.w;
@@ -37,28 +40,45 @@ MPG_DEV void stage_tile(const float* __restrict__ P, int ld, const float* __rest
             for (int e = 0; e < 8; ++e) {
                 const int k = k0 + e;
                 float x = 0.f;
-                if (gr < nrows && k < kend) x = (P2 != nullptr && k >= K1) ? P2[(size_t)gr * ld2 + (k - K1)] : P[(size_t)gr * ld + k];
+                if (gr < nrows && k < kend) {
+                    if (gr == ones_row) x = 1.f;
+                    else x = (P2 != nullptr && k >= K1) ? P2[(size_t)gr * ld2 + (k - K1)] : P[(size_t)gr * ld + k];
+                }
                 v[e] = x;
             }
         }
+    } else {
+        const int kr = tid >> 3, rc = tid & 7;
+        const int k = kt + kr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int gr = row0 + 8 * rc + e;
+            float x = 0.f;
+            if (gr < nrows && k < kend) x = gr == ones_row ? 1.f : P[(size_t)k * ld + gr];
+            v[e] = x;
+        }
+    }
+}
+
+template <bool KC, typename V>
+MPG_DEV void tile_store(const float (&v)[8], V (*hi)[2][64], V (*lo)[2][64], int tid) {
+    typedef typename ElemOf<V>::type E;
+    if constexpr (KC) {
+        const int row = tid >> 2, kc = tid & 3;
         V h8, l8;
         split8(v, h8, l8);
         const int blk = row >> 5, r = row & 31, s = kc >> 1, h = kc & 1;
         hi[blk][s][h * 32 + r] = h8;
         lo[blk][s][h * 32 + r] = l8;
     } else {
-        // rows (m or n) are contiguous in memory: coalesce along them, scatter 2-byte elements
+        // rows (m or n) are contiguous in memory: coalesced along them, 2-byte elements scattered
         const int kr = tid >> 3, rc = tid & 7;
-        const int k = kt + kr;
         const int s = kr >> 4, h = (kr >> 3) & 1, j = kr & 7;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int row = 8 * rc + e;
-            const int gr = row0 + row;
-            float x = 0.f;
-            if (gr < nrows && k < kend) x = P[(size_t)k * ld + gr];
             E hh, ll;
-            split1(x, hh, ll);
+            split1(v[e], hh, ll);
             const int blk = row >> 5, r = row & 31;
             reinterpret_cast<E*>(&hi[blk][s][h * 32 + r])[j] = hh;
             reinterpret_cast<E*>(&lo[blk][s][h * 32 + r])[j] = ll;
@@ -86,10 +106,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const MpgGemm g) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
+    const int b_ones = g.ones_col ? g.N - 1 : -1;  // last "row" of the B operand is the ones column
+    float va[8], vb[8];
+    if (kbeg < kend_z) {
+        tile_load<AK>(va, g.A, g.lda, g.A2, g.lda2, g.K1, m0, g.M, kbeg, kend_z, tid, a_vec, -1);
+        tile_load<BK>(vb, g.B, g.ldb, nullptr, 0, 0, n0, g.N, kbeg, kend_z, tid, b_vec, b_ones);
+    }
     for (int kt = kbeg; kt < kend_z; kt += 32) {
-        stage_tile<AK>(g.A, g.lda, g.A2, g.lda2, g.K1, m0, g.M, kt, kend_z, As_hi, As_lo, tid, a_vec);
-        stage_tile<BK>(g.B, g.ldb, nullptr, 0, 0, n0, g.N, kt, kend_z, Bs_hi, Bs_lo, tid, b_vec);
+        tile_store<AK>(va, As_hi, As_lo, tid);
+        tile_store<BK>(vb, Bs_hi, Bs_lo, tid);
         __syncthreads();
+        if (kt + 32 < kend_z) {  // next tile's global loads fly during the MFMAs
+            tile_load<AK>(va, g.A, g.lda, g.A2, g.lda2, g.K1, m0, g.M, kt + 32, kend_z, tid, a_vec, -1);
+            tile_load<BK>(vb, g.B, g.ldb, nullptr, 0, 0, n0, g.N, kt + 32, kend_z, tid, b_vec, b_ones);
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
             acc = mfma3(As_hi[wr][s][lane], As_lo[wr][s][lane], Bs_hi[wc][s][lane], Bs_lo[wc][s][lane], acc);
@@ -149,6 +179,20 @@ __global__ void gate_kernel(const float* __restrict__ in, int ldi, const float* 
     out[(size_t)m * ldo + n] = in[(size_t)m * ldi + n] * gt;
 }
 
+// out[n, col0 + k] = sum_z part[z][n][k]  (k < K);  bias[n] = sum_z part[z][n][K] when the GEMM carried a
+// ones column (ld of the partials = K + has_bias).  One launch replaces torch's sum + strided copy (+ bias sum).
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int S, int N, int K, int has_bias,
+                                     float* __restrict__ out, int ldo, float* __restrict__ bias) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ldp = K + has_bias;
+    if (idx >= N * ldp) return;
+    const int n = idx / ldp, k = idx % ldp;
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += part[(size_t)z * N * ldp + idx];
+    if (k < K) out[(size_t)n * ldo + k] = s;
+    else if (bias != nullptr) bias[n] = s;
+}
+
 // keep-mask materialiser for tests: mask[row, f] in {0,1} exactly as the kernels decide it
 __global__ void drop_mask_kernel(float* __restrict__ out, size_t rows, int F, const uint64_t* seed, uint32_t tag,
                                  uint32_t thr) {
@@ -178,6 +222,15 @@ extern "C" int mpg_gemm(const MpgGemm* g, int ak, int bk, int splitk, void* stre
     else if (!ak && !bk) MPG_LAUNCH(false, false);
     else MPG_LAUNCH(false, true);
 #undef MPG_LAUNCH
+    return (int)hipGetLastError();
+}
+
+extern "C" int mpg_splitk_reduce(const float* part, int S, int N, int K, int has_bias, float* out, int ldo,
+                                 float* bias, void* stream) {
+    const int tot = N * (K + has_bias);
+    if (tot <= 0) return 0;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, S, N, K,
+                       has_bias, out, ldo, bias);
     return (int)hipGetLastError();
 }
 

@@ -81,7 +81,8 @@ def _chk(t: torch.Tensor, name: str):
 # ------------------------------------------------------------------------------------- GEMM
 def gemm(A, lda, B, ldb, Cout, ldc, M, N, K, *, ak=True, bk=True, a_off=0, b_off=0, c_off=0,
          A2=None, lda2=0, K1=0, bias=None, out_scale=1.0, act=False, alpha=0.2,
-         drop=None, gate=None, resid=None, ldr=0, accumulate=False, splitk=1, split_stride=0, f16=False):
+         drop=None, gate=None, resid=None, ldr=0, accumulate=False, splitk=1, split_stride=0, f16=False,
+         ones_col=False):
     """Thin wrapper of mpg_gemm.  drop = (seed_t, tag, thr, scale) applies forward dropout to C;
     gate = (H, ldh, gate_act, seed_t, tag, thr, scale) multiplies C by d(dropout o act)/dz."""
     g = MpgGemm()
@@ -102,6 +103,7 @@ def gemm(A, lda, B, ldb, Cout, ldc, M, N, K, *, ak=True, bk=True, a_off=0, b_off
     g.resid, g.ldr = _p(resid), ldr
     g.accumulate = int(accumulate)
     g.f16 = int(f16)
+    g.ones_col = int(ones_col)
     check(_lib.lib().mpg_gemm(C.byref(g), int(ak), int(bk), splitk, _stream()), "mpg_gemm")
 
 
@@ -129,27 +131,21 @@ def linear_bwd_data(dy, W, *, w_col0=0, w_cols=None, gate=None, out=None, accumu
     return out
 
 
-def linear_bwd_weight(dy, x, *, out=None, out_col0=0, out_scale=1.0):
-    """dW[:, out_col0:out_col0+K] = out_scale * dy^T @ x.   dy [M,N], x [M,K] -> dW [N,K] (split-K)."""
+def linear_bwd_weight(dy, x, *, out=None, out_col0=0, out_scale=1.0, bias_out=None):
+    """dW[:, out_col0:out_col0+K] = out_scale * dy^T @ x  (dy [M,N], x [M,K]; split-K over M), and, when
+    ``bias_out`` [N] is given, bias_out = column sums of dy (a virtual ones column of x, same launch)."""
     M, N = dy.shape
     K = x.shape[1]
     if out is None:
         out = torch.empty((N, K), device=dy.device, dtype=torch.float32)
-    ldc = out.stride(0)
-    tiles = ((N + 63) // 64) * ((K + 63) // 64)
+    hb = int(bias_out is not None)
+    tiles = ((N + 63) // 64) * ((K + hb + 63) // 64)
     splitk = max(1, min((M + 255) // 256, (1024 + tiles - 1) // tiles))
-    if splitk == 1:
-        gemm(dy, dy.stride(0), x, x.stride(0), out, ldc, N, K, M, ak=False, bk=False, c_off=out_col0,
-             out_scale=out_scale)
-        return out
-    part = torch.empty((splitk, N, K), device=dy.device, dtype=torch.float32)
-    gemm(dy, dy.stride(0), x, x.stride(0), part, K, N, K, M, ak=False, bk=False, out_scale=out_scale,
-         splitk=splitk, split_stride=N * K)
-    red = part.sum(0)
-    if out_col0 == 0 and out.shape[1] == K:
-        out.copy_(red)
-    else:
-        out[:, out_col0:out_col0 + K] = red
+    part = torch.empty((splitk, N, K + hb), device=dy.device, dtype=torch.float32)
+    gemm(dy, dy.stride(0), x, x.stride(0), part, K + hb, N, K + hb, M, ak=False, bk=False, out_scale=out_scale,
+         splitk=splitk, split_stride=N * (K + hb), ones_col=bool(hb))
+    check(_lib.lib().mpg_splitk_reduce(_p(part), splitk, N, K, hb, _p(out, out_col0), out.stride(0), _p(bias_out),
+                                       _stream()), "mpg_splitk_reduce")
     return out
 
 
@@ -265,14 +261,12 @@ class FusedMPLayerFn(torch.autograd.Function):
         dh0 = linear_bwd_data(dz1, V1)  # [V, 192+F] = [dagg | dx(node path)]
         dV1 = dV2 = dV3 = dc1 = dc2 = dc3 = None
         if need_w:
-            dV3 = linear_bwd_weight(dz3, h2)
-            dc3 = dz3.sum(0)
-            dV2 = linear_bwd_weight(dz2, h1)
-            dc2 = dz2.sum(0)
+            dc3, dc2, dc1 = (torch.empty(t.shape[1], device=dev, dtype=torch.float32) for t in (dz3, dz2, dz1))
+            dV3 = linear_bwd_weight(dz3, h2, bias_out=dc3)
+            dV2 = linear_bwd_weight(dz2, h1, bias_out=dc2)
             dV1 = torch.empty_like(V1)
-            linear_bwd_weight(dz1, agg, out=dV1, out_col0=0)
+            linear_bwd_weight(dz1, agg, out=dV1, out_col0=0, bias_out=dc1)
             linear_bwd_weight(dz1, x2, out=dV1, out_col0=H3)
-            dc1 = dz1.sum(0)
 
         # ---- edge network backward: data path, then (if wanted) the weight-gradient pass
         W2img = pack_weights(W2, H2, H1, scale=dscale, f16=f16)
@@ -324,9 +318,9 @@ class FusedMPLayerFn(torch.autograd.Function):
             del stE2, stZ2
             # layer 1 (fe.net.0): a = W1[:, :F] x + b1, c = W1[:, F:] x
             dW1 = torch.empty_like(W1)
-            linear_bwd_weight(da, x2, out=dW1, out_col0=0)
+            db1 = torch.empty(H1, device=dev, dtype=torch.float32)
+            linear_bwd_weight(da, x2, out=dW1, out_col0=0, bias_out=db1)
             linear_bwd_weight(dc, x2, out=dW1, out_col0=F)
-            db1 = da.sum(0)
         dx = None
         if need_x:
             dx = dh0[:, H3:].contiguous()
@@ -361,8 +355,13 @@ class FusedLinearFn(torch.autograd.Function):
         if act or thr:
             g2 = gate(g2, y, gate_act=act, alpha=alpha, seed_t=seed_tensor(g2.device), tag=tag + TAG_GENERIC,
                       thr=thr, scale=dscale)
-        dW = linear_bwd_weight(g2, x2) if ctx.needs_input_grad[1] else None
-        db = g2.sum(0) if (has_b and ctx.needs_input_grad[2]) else None
+        dW = db = None
+        if ctx.needs_input_grad[1]:
+            if has_b and ctx.needs_input_grad[2]:
+                db = torch.empty(W.shape[0], device=g2.device, dtype=torch.float32)
+            dW = linear_bwd_weight(g2, x2, bias_out=db)
+        elif has_b and ctx.needs_input_grad[2]:
+            db = g2.sum(0)
         dx = linear_bwd_data(g2, W).reshape(shp) if ctx.needs_input_grad[0] else None
         return dx, dW, db, None, None, None, None
 
