@@ -93,6 +93,37 @@ MPG_DEV uint32_t drop_word(uint32_t seed_lo, uint32_t seed_hi, uint32_t tag, uin
 }
 MPG_DEV bool drop_keep(uint32_t word, int t, uint32_t thr) { return ((word >> (8 * t)) & 0xffu) >= thr; }
 
+// p = 1/2 (thr == 128, the reference's default disc_dropout) uses one BIT per element instead: the word of
+// (row, 32-feature tile f>>5) is drop_word(.., row, DROP_BIT_GRP + (f>>5)) and feature f keeps iff bit f&31
+// is set -- 8x fewer hashes and a bfe+and per element in the fused kernels.  Every kernel and the test
+// helper go through these two functions, so forward, backward and the mask dump agree by construction.
+constexpr uint32_t DROP_BIT_GRP = 0x8000u;
+MPG_DEV bool drop_keep_f(uint32_t seed_lo, uint32_t seed_hi, uint32_t tag, uint32_t row, int f, uint32_t thr) {
+    if (thr == 128u) return (drop_word(seed_lo, seed_hi, tag, row, DROP_BIT_GRP + (uint32_t)(f >> 5)) >> (f & 31)) & 1u;
+    return drop_keep(drop_word(seed_lo, seed_hi, tag, row, (uint32_t)(f >> 2)), f & 3, thr);
+}
+// fused-kernel form: DM = 1 byte mode, DM = 2 bit mode.  `w` = the word of this lane's tile already shifted
+// right by 4*h (bit mode) or the word of the 4-feature group (byte mode); `k` = compile-time bit index
+// within the lane's view (8g+t in accumulator order, 16s+8u+t in operand order) / byte index t.
+template <int DM>
+MPG_DEV float drop_apply(float x, uint32_t w, int k_bit, int t_byte, uint32_t thr) {
+    if constexpr (DM == 2) {
+        const int m = __builtin_amdgcn_sbfe((int)w, k_bit, 1);  // 0 or -1
+        return __builtin_bit_cast(float, __builtin_bit_cast(int, x) & m);
+    } else if constexpr (DM == 1) {
+        return drop_keep(w, t_byte, thr) ? x : 0.f;
+    } else {
+        return x;
+    }
+}
+// word for accumulator-order group g of tile m (bit mode: one word per tile, CSE'd across g)
+template <int DM>
+MPG_DEV uint32_t drop_tile_word(uint32_t seed_lo, uint32_t seed_hi, uint32_t tag, uint32_t row, int m, int grp_in_tile, int h) {
+    if constexpr (DM == 2) return drop_word(seed_lo, seed_hi, tag, row, DROP_BIT_GRP + (uint32_t)m) >> (4 * h);
+    else if constexpr (DM == 1) return drop_word(seed_lo, seed_hi, tag, row, (uint32_t)(8 * m + grp_in_tile));
+    else return 0u;
+}
+
 // dropout sites (tag values); the layer id of the call is mixed in by the host as tag_base
 enum { TAG_E0 = 1, TAG_E1 = 2, TAG_E2 = 3, TAG_N0 = 4, TAG_N1 = 5, TAG_N2 = 6, TAG_GENERIC = 7 };
 

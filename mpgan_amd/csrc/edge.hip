@@ -43,7 +43,7 @@ __global__ void pack_kernel(const float* __restrict__ W, int ldw, int rows, int 
     reinterpret_cast<V*>(img)[(size_t)nfrag * 64 + idx] = lo;
 }
 
-template <bool WLDS, bool DROP, bool F16>
+template <bool WLDS, int DROP, bool F16>  // DROP: 0 off, 1 byte-threshold dropout, 2 one-bit (p = 1/2) dropout
 __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
     typedef typename FragT<F16>::type V;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -133,13 +133,11 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
                 for (int u = 0; u < 2; ++u) {
                     const float4 c4 = ld4(cj + 32 * q + 16 * s + 8 * u + 4 * h);
                     const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
-                    uint32_t wd = 0;
-                    if (DROP) wd = drop_word(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, 8 * q + 4 * s + 2 * u + h);
+                    const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, q, 4 * s + 2 * u + h, h);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        float x = lrelu(areg[q][s][4 * u + t] + cc[t], p.alpha);
-                        if (DROP && !drop_keep(wd, t, p.thr)) x = 0.f;
-                        v[4 * u + t] = x;
+                        const float x = lrelu(areg[q][s][4 * u + t] + cc[t], p.alpha);
+                        v[4 * u + t] = drop_apply<DROP>(x, wd, 16 * s + 8 * u + t, t, p.thr);
                     }
                 }
                 split8(v, e1hi[q][s], e1lo[q][s]);
@@ -158,13 +156,11 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
             for (int m = 0; m <= T2; ++m) {
                 const int mm = m - 1;
                 auto epi2 = [&](int g) {  // epilogue slice g of tile mm: lrelu, dropout, hi/lo split
-                    uint32_t wd = 0;
-                    if (DROP) wd = drop_word(seed_lo, seed_hi, p.tag_base + TAG_E1, erow, 8 * mm + 2 * g + h);
+                    const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E1, erow, mm, 2 * g + h, h);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        float x = lrelu(accs[(m + 1) & 1][4 * g + t], p.alpha);
-                        if (DROP && !drop_keep(wd, t, p.thr)) x = 0.f;
-                        v2[4 * g + t] = x;
+                        const float x = lrelu(accs[(m + 1) & 1][4 * g + t], p.alpha);
+                        v2[4 * g + t] = drop_apply<DROP>(x, wd, 8 * g + t, t, p.thr);
                     }
                     if (g == 1) split8(v2, e2hi[mm][0], e2lo[mm][0]);
                     if (g == 3) split8(v2 + 8, e2hi[mm][1], e2lo[mm][1]);
@@ -201,16 +197,14 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
             for (int m = 0; m <= T3; ++m) {
                 const int mm = m - 1;
                 auto epi3 = [&](int g) {
-                    uint32_t wd = 0;
-                    if (DROP) wd = drop_word(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, 8 * mm + 2 * g + h);
+                    const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, mm, 2 * g + h, h);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         if (p.sign3 != nullptr) {  // lane ballot of (Z3 > 0): lane 4g+t keeps word 4g+t of this tile
                             const unsigned long long bal = __ballot(accs[(m + 1) & 1][4 * g + t] > 0.f);
                             if (lane == 4 * g + t) balv = bal;
                         }
-                        float x = lrelu(accs[(m + 1) & 1][4 * g + t], p.alpha);
-                        if (DROP && !drop_keep(wd, t, p.thr)) x = 0.f;
+                        const float x = drop_apply<DROP>(lrelu(accs[(m + 1) & 1][4 * g + t], p.alpha), wd, 8 * g + t, t, p.thr);
                         agg[mm][4 * g + t] += mjs * x;
                     }
                     if (g == 3 && sg != nullptr && lane < 16) sg[mm * 16 + lane] = balv;  // 16 words of tile mm
@@ -279,24 +273,27 @@ extern "C" int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream) {
 #define MPG_FWD_ATTR(L, D, H, BYTES) \
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_kernel<L, D, H>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES))
     if (!attr_set) {
-        MPG_FWD_ATTR(true, false, false, FWD_LDS_BYTES); MPG_FWD_ATTR(true, true, false, FWD_LDS_BYTES);
-        MPG_FWD_ATTR(true, false, true, FWD_LDS_BYTES);  MPG_FWD_ATTR(true, true, true, FWD_LDS_BYTES);
-        MPG_FWD_ATTR(false, false, false, NOLDS_BYTES);  MPG_FWD_ATTR(false, true, false, NOLDS_BYTES);
-        MPG_FWD_ATTR(false, false, true, NOLDS_BYTES);   MPG_FWD_ATTR(false, true, true, NOLDS_BYTES);
+        MPG_FWD_ATTR(true, 0, false, FWD_LDS_BYTES); MPG_FWD_ATTR(true, 1, false, FWD_LDS_BYTES); MPG_FWD_ATTR(true, 2, false, FWD_LDS_BYTES);
+        MPG_FWD_ATTR(true, 0, true, FWD_LDS_BYTES);  MPG_FWD_ATTR(true, 1, true, FWD_LDS_BYTES);  MPG_FWD_ATTR(true, 2, true, FWD_LDS_BYTES);
+        MPG_FWD_ATTR(false, 0, false, NOLDS_BYTES);  MPG_FWD_ATTR(false, 1, false, NOLDS_BYTES);  MPG_FWD_ATTR(false, 2, false, NOLDS_BYTES);
+        MPG_FWD_ATTR(false, 0, true, NOLDS_BYTES);   MPG_FWD_ATTR(false, 1, true, NOLDS_BYTES);   MPG_FWD_ATTR(false, 2, true, NOLDS_BYTES);
         attr_set = true;
     }
 #undef MPG_FWD_ATTR
-    const bool drop = p->thr != 0;
-#define MPG_FWD_GO(L, BYTES)                                                                                    \
-    do {                                                                                                        \
-        if (drop && p->f16) hipLaunchKernelGGL((edge_fwd_kernel<L, true, true>), grid, block, BYTES, st, *p);   \
-        else if (drop) hipLaunchKernelGGL((edge_fwd_kernel<L, true, false>), grid, block, BYTES, st, *p);       \
-        else if (p->f16) hipLaunchKernelGGL((edge_fwd_kernel<L, false, true>), grid, block, BYTES, st, *p);     \
-        else hipLaunchKernelGGL((edge_fwd_kernel<L, false, false>), grid, block, BYTES, st, *p);                \
+    const int dm = p->thr == 0 ? 0 : (p->thr == 128 ? 2 : 1);
+#define MPG_FWD_GO2(L, D, BYTES)                                                                              \
+    do {                                                                                                      \
+        if (p->f16) hipLaunchKernelGGL((edge_fwd_kernel<L, D, true>), grid, block, BYTES, st, *p);            \
+        else hipLaunchKernelGGL((edge_fwd_kernel<L, D, false>), grid, block, BYTES, st, *p);                  \
+    } while (0)
+#define MPG_FWD_GO(L, BYTES)                                                                                  \
+    do {                                                                                                      \
+        if (dm == 0) MPG_FWD_GO2(L, 0, BYTES); else if (dm == 1) MPG_FWD_GO2(L, 1, BYTES); else MPG_FWD_GO2(L, 2, BYTES); \
     } while (0)
     if (p->weights_in_lds) MPG_FWD_GO(true, FWD_LDS_BYTES);
     else MPG_FWD_GO(false, NOLDS_BYTES);
 #undef MPG_FWD_GO
+#undef MPG_FWD_GO2
     return (int)hipGetLastError();
 }
 

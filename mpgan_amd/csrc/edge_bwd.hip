@@ -46,7 +46,7 @@ MPG_DEV void stage_frag(void* base, size_t blk, int part, int tile, int s, int h
     }
 }
 
-template <bool DROP, bool F16, bool NEEDW>
+template <int DROP, bool F16, bool NEEDW>  // DROP: 0 off, 1 byte mode, 2 bit mode (see common.h)
 __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     typedef typename FragT<F16>::type V;  // forward-recomputation operands; gradient operands are bf16
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -129,14 +129,10 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                     const float4 c4 = ld4(cj + 32 * q + 16 * s + 8 * u + 4 * h);
                     const float4 a4 = la[((q * 2 + s) * 2 + u) * 64 + lane];
                     const float cc[4] = {c4.x + a4.x, c4.y + a4.y, c4.z + a4.z, c4.w + a4.w};
-                    uint32_t wd = 0;
-                    if (DROP) wd = drop_word(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, 8 * q + 4 * s + 2 * u + h);
+                    const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, q, 4 * s + 2 * u + h, h);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        float x = lrelu(cc[t], p.alpha);
-                        if (DROP && !drop_keep(wd, t, p.thr)) x = 0.f;
-                        v[4 * u + t] = x;
-                    }
+                    for (int t = 0; t < 4; ++t)
+                        v[4 * u + t] = drop_apply<DROP>(lrelu(cc[t], p.alpha), wd, 16 * s + 8 * u + t, t, p.thr);
                 }
                 split8(v, e1hi[q][s], e1lo[q][s]);
             }
@@ -152,14 +148,10 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             f32x16 accs[2];
             float v2[16];
             auto epi2 = [&](int mm, int g) {
-                uint32_t wd = 0;
-                if (DROP) wd = drop_word(seed_lo, seed_hi, p.tag_base + TAG_E1, erow, 8 * mm + 2 * g + h);
+                const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E1, erow, mm, 2 * g + h, h);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float x = lrelu(accs[mm & 1][4 * g + t], p.alpha);
-                    if (DROP && !drop_keep(wd, t, p.thr)) x = 0.f;
-                    v2[4 * g + t] = x;
-                }
+                for (int t = 0; t < 4; ++t)
+                    v2[4 * g + t] = drop_apply<DROP>(lrelu(accs[mm & 1][4 * g + t], p.alpha), wd, 8 * g + t, t, p.thr);
                 if (g == 1 || g == 3) {
                     const int s = g >> 1;
                     split8(v2 + 8 * s, e2hi[mm][s], e2lo[mm][s]);
@@ -207,8 +199,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                 float v[16];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    uint32_t wd = 0;
-                    if (DROP) wd = drop_word(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, 8 * m + 2 * g + h);
+                    const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, m, 2 * g + h, h);
                     const float4 d4 = ldg[(m * 4 + g) * 64 + lane];
                     const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
@@ -217,8 +208,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                         const unsigned int lo = k < 64 ? __builtin_amdgcn_readlane(bwa_lo, k) : __builtin_amdgcn_readlane(bwb_lo, k - 64);
                         const unsigned int hi = k < 64 ? __builtin_amdgcn_readlane(bwa_hi, k) : __builtin_amdgcn_readlane(bwb_hi, k - 64);
                         const bool pos = __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)hi << 32) | lo);
-                        float gt = pos ? 1.f : p.alpha;
-                        if (DROP && !drop_keep(wd, t, p.thr)) gt = 0.f;
+                        const float gt = drop_apply<DROP>(pos ? 1.f : p.alpha, wd, 8 * g + t, t, p.thr);
                         v[4 * g + t] = mjs * dd[t] * gt;
                     }
                 }
@@ -284,13 +274,11 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                 const float4 c4 = ld4(cj + 32 * mm + 16 * s + 8 * u + 4 * h);
                 const float4 a4 = la[((mm * 2 + s) * 2 + u) * 64 + lane];
                 const float cc[4] = {c4.x + a4.x, c4.y + a4.y, c4.z + a4.z, c4.w + a4.w};
-                uint32_t wd = 0;
-                if (DROP) wd = drop_word(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, 8 * mm + 4 * s + 2 * u + h);
+                const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, mm, 4 * s + 2 * u + h, h);
                 float red4[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    float gt = lrelu_grad(cc[t], p.alpha);
-                    if (DROP && !drop_keep(wd, t, p.thr)) gt = 0.f;
+                    const float gt = drop_apply<DROP>(lrelu_grad(cc[t], p.alpha), wd, 16 * s + 8 * u + t, t, p.thr);
                     // accumulator register 8s + 4u + t  <->  element 4u+t of k-step s
                     const float dz = vi ? accs[mm & 1][8 * s + 4 * u + t] * gt : 0.f;
                     dacc[mm][s][4 * u + t] += dz;
@@ -358,7 +346,8 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
 constexpr int DW_LD = 40;  // tile row stride in 16-bit elements (80 B: conflict-free ds_read_b128)
 constexpr int DW_ROWS = H3 + H2 + H2 + H1;  // Z3 | E2 | Z2 | E1
 constexpr int DW_TILE_BYTES = DW_ROWS * 2 * DW_LD * 2;  // 97,280
-constexpr int DW_LDS_BYTES = DW_TILE_BYTES + H3 * 32 * 4 + H1 * 32 * 4 + H1 * 4 + T3 * 16 * 8;  // + dagg^T + a^T + c_j + ballots
+constexpr int DW_TLD = 36;  // row stride (floats) of the dagg^T / a^T tiles: 32 would put every row on the same banks
+constexpr int DW_LDS_BYTES = DW_TILE_BYTES + H3 * DW_TLD * 4 + H1 * DW_TLD * 4 + H1 * 4 + T3 * 16 * 8;  // + dagg^T + a^T + c_j + ballots
 
 struct DwTile { int prod, m, n; };  // prod 0: dW3 (A = Z3 tile m, B = E2 tile n); 1: dW2 (A = Z2, B = E1)
 __device__ constexpr DwTile DW_TILES[45] = {
@@ -426,7 +415,7 @@ MPG_DEV void dw_store(const f32x16* acc, float* part3, float* part2, int lane) {
 // (one workgroup per CU: nothing else would hide the HBM latency) and written to LDS afterwards.
 constexpr int DW_PIECES = H2 * 4;  // (row, piece) units of one 160-row plane
 
-template <bool DROP, bool F16, int BEGIN, int END>
+template <int DROP, bool F16, int BEGIN, int END>
 MPG_DEV void edge_dw_body(const MpgEdgeDw& p, char* smem, const int w) {
     typedef typename FragT<F16>::type E2V;
     __bf16* tiles = reinterpret_cast<__bf16*>(smem);
@@ -439,8 +428,8 @@ MPG_DEV void edge_dw_body(const MpgEdgeDw& p, char* smem, const int w) {
     __bf16* E1h = Z2l + H2 * DW_LD;
     __bf16* E1l = E1h + H1 * DW_LD;
     float* dgT = reinterpret_cast<float*>(smem + DW_TILE_BYTES);  // [feature][32]
-    float* aT = dgT + H3 * 32;                                    // [feature][32]
-    float* cj = aT + H1 * 32;                                     // [feature]
+    float* aT = dgT + H3 * DW_TLD;                                // [feature][32 (+4 pad)]
+    float* cj = aT + H1 * DW_TLD;                                 // [feature]
     unsigned long long* lbal = reinterpret_cast<unsigned long long*>(cj + H1);  // [96] ballots of the block
     const int tid = threadIdx.x, lane = tid & 63;
     const int RB = (p.N + 31) / 32;
@@ -482,11 +471,11 @@ MPG_DEV void edge_dw_body(const MpgEdgeDw& p, char* smem, const int w) {
             cur_brb = brb;
             for (int t = tid; t < H3 * 32; t += 256) {
                 const int f = t >> 5, ii = rb * 32 + (t & 31);
-                dgT[t] = ii < p.N ? p.dagg[(size_t)(b * p.N + ii) * p.ld_dagg + f] * p.agg_scale : 0.f;
+                dgT[f * DW_TLD + (t & 31)] = ii < p.N ? p.dagg[(size_t)(b * p.N + ii) * p.ld_dagg + f] * p.agg_scale : 0.f;
             }
             for (int t = tid; t < H1 * 32; t += 256) {
                 const int f = t >> 5, ii = rb * 32 + (t & 31);
-                aT[t] = ii < p.N ? p.a[(size_t)(b * p.N + ii) * H1 + f] : 0.f;
+                aT[f * DW_TLD + (t & 31)] = ii < p.N ? p.a[(size_t)(b * p.N + ii) * H1 + f] : 0.f;
             }
         }
         if (tid < H1) cj[tid] = p.c[(size_t)(b * p.N + j) * H1 + tid];
@@ -525,16 +514,18 @@ MPG_DEV void edge_dw_body(const MpgEdgeDw& p, char* smem, const int w) {
             const unsigned int bits = (unsigned int)(lbal[m * 16 + reg] >> (32 * hb + 8 * pc)) & 0xffu;
             float v[8];
             float s = 0.f;
+            const float4 d0 = *reinterpret_cast<const float4*>(dgT + f * DW_TLD + 8 * pc);
+            const float4 d1 = *reinterpret_cast<const float4*>(dgT + f * DW_TLD + 8 * pc + 4);
+            const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int rcv = 8 * pc + k, ii = rb * 32 + rcv;
                 float gt = ((bits >> k) & 1u) ? 1.f : p.alpha;
                 if (DROP) {
                     const uint32_t erow = (uint32_t)((b * p.N + ii) * p.N + j);
-                    const uint32_t wd = drop_word(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, 8 * m + 2 * (fl >> 3) + hb);
-                    if (!drop_keep(wd, fl & 3, p.thr)) gt = 0.f;
+                    if (!drop_keep_f(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, f, p.thr)) gt = 0.f;
                 }
-                const float x = ii < p.N ? mjs * dgT[f * 32 + rcv] * gt : 0.f;
+                const float x = ii < p.N ? mjs * dd[k] * gt : 0.f;
                 v[k] = x;
                 s += x;
             }
@@ -552,14 +543,16 @@ MPG_DEV void edge_dw_body(const MpgEdgeDw& p, char* smem, const int w) {
                 const int fi = id >> 2, pc = id & 3;
                 const int f = feat_of_fi(fi);
                 float v[8];
+                const float4 a0 = *reinterpret_cast<const float4*>(aT + f * DW_TLD + 8 * pc);
+                const float4 a1 = *reinterpret_cast<const float4*>(aT + f * DW_TLD + 8 * pc + 4);
+                const float aa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int rcv = 8 * pc + k, ii = rb * 32 + rcv;
-                    float x = lrelu(aT[f * 32 + rcv] + cj[f], p.alpha);
+                    float x = lrelu(aa[k] + cj[f], p.alpha);
                     if (DROP) {
                         const uint32_t erow = (uint32_t)((b * p.N + ii) * p.N + j);
-                        const uint32_t wd = drop_word(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, f >> 2);
-                        if (!drop_keep(wd, f & 3, p.thr)) x = 0.f;
+                        if (!drop_keep_f(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, f, p.thr)) x = 0.f;
                     }
                     v[k] = x;
                 }
@@ -605,7 +598,7 @@ MPG_DEV void edge_dw_body(const MpgEdgeDw& p, char* smem, const int w) {
     }
 }
 
-template <bool DROP, bool F16>
+template <int DROP, bool F16>
 __global__ __launch_bounds__(256, 1) void edge_dw_kernel(const MpgEdgeDw p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -654,45 +647,50 @@ extern "C" int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream) {
     dim3 grid(p->B * RB * p->SC), block(256);
     hipStream_t st = (hipStream_t)stream;
     const bool needw = p->stageE2 != nullptr && p->stageZ2 != nullptr;
-    static bool attr_set = false;
-#define MPG_BWD_ATTR(D, H, W) \
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd_kernel<D, H, W>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS_BYTES))
-    if (!attr_set) {
-        MPG_BWD_ATTR(false, false, false); MPG_BWD_ATTR(false, false, true); MPG_BWD_ATTR(false, true, false);
-        MPG_BWD_ATTR(false, true, true);   MPG_BWD_ATTR(true, false, false); MPG_BWD_ATTR(true, false, true);
-        MPG_BWD_ATTR(true, true, false);   MPG_BWD_ATTR(true, true, true);
-        attr_set = true;
-    }
-#undef MPG_BWD_ATTR
-#define MPG_BWD_GO(D, H)                                                                                          \
+    const int dm = p->thr == 0 ? 0 : (p->thr == 128 ? 2 : 1);
+#define MPG_BWD_ONE(D, H, W)                                                                                      \
     do {                                                                                                          \
-        if (needw) hipLaunchKernelGGL((edge_bwd_kernel<D, H, true>), grid, block, BWD_LDS_BYTES, st, *p);        \
-        else hipLaunchKernelGGL((edge_bwd_kernel<D, H, false>), grid, block, BWD_LDS_BYTES, st, *p);             \
+        static bool done = false;                                                                                 \
+        if (!done) {                                                                                              \
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd_kernel<D, H, W>,                              \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS_BYTES));        \
+            done = true;                                                                                          \
+        }                                                                                                         \
+        hipLaunchKernelGGL((edge_bwd_kernel<D, H, W>), grid, block, BWD_LDS_BYTES, st, *p);                       \
     } while (0)
-    if (p->thr && p->f16) MPG_BWD_GO(true, true);
-    else if (p->thr) MPG_BWD_GO(true, false);
-    else if (p->f16) MPG_BWD_GO(false, true);
-    else MPG_BWD_GO(false, false);
-#undef MPG_BWD_GO
+#define MPG_BWD_W(D, H)                                                                                           \
+    do { if (needw) MPG_BWD_ONE(D, H, true); else MPG_BWD_ONE(D, H, false); } while (0)
+#define MPG_BWD_H(D)                                                                                              \
+    do { if (p->f16) MPG_BWD_W(D, true); else MPG_BWD_W(D, false); } while (0)
+    if (dm == 0) MPG_BWD_H(0);
+    else if (dm == 1) MPG_BWD_H(1);
+    else MPG_BWD_H(2);
+#undef MPG_BWD_H
+#undef MPG_BWD_W
+#undef MPG_BWD_ONE
     return (int)hipGetLastError();
 }
 
 extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
     if (p->B <= 0 || p->N <= 0 || p->nwg <= 0) return -1;
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_dw_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES));
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_dw_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES));
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_dw_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES));
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_dw_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES));
-        attr_set = true;
-    }
     dim3 grid(p->nwg), block(256);
-    if (p->thr && p->f16) hipLaunchKernelGGL((edge_dw_kernel<true, true>), grid, block, DW_LDS_BYTES, st, *p);
-    else if (p->thr) hipLaunchKernelGGL((edge_dw_kernel<true, false>), grid, block, DW_LDS_BYTES, st, *p);
-    else if (p->f16) hipLaunchKernelGGL((edge_dw_kernel<false, true>), grid, block, DW_LDS_BYTES, st, *p);
-    else hipLaunchKernelGGL((edge_dw_kernel<false, false>), grid, block, DW_LDS_BYTES, st, *p);
+    const int dm = p->thr == 0 ? 0 : 1;  // per-element decisions: drop_keep_f picks the bit form itself
+#define MPG_DW_ONE(D, H)                                                                                          \
+    do {                                                                                                          \
+        static bool done = false;                                                                                 \
+        if (!done) {                                                                                              \
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_dw_kernel<D, H>,                                  \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES));         \
+            done = true;                                                                                          \
+        }                                                                                                         \
+        hipLaunchKernelGGL((edge_dw_kernel<D, H>), grid, block, DW_LDS_BYTES, st, *p);                            \
+    } while (0)
+    if (dm && p->f16) MPG_DW_ONE(1, true);
+    else if (dm) MPG_DW_ONE(1, false);
+    else if (p->f16) MPG_DW_ONE(0, true);
+    else MPG_DW_ONE(0, false);
+#undef MPG_DW_ONE
     constexpr int PER = H3 * H2 + H2 * H1 + H3 + H2;
     hipLaunchKernelGGL(edge_dw_reduce, dim3((PER + 31) / 32), dim3(256), 0, st, p->part, p->nwg, p->dscale, p->dW3,
                        p->dW2, p->db3, p->db2);

@@ -48,11 +48,13 @@ MPG_DEV void tile_load(float (&v)[8], const float* __restrict__ P, int ld, const
             }
         }
     } else {
-        const int kr = tid >> 3, rc = tid & 7;
-        const int k = kt + kr;
+        // rows (m or n) contiguous in memory: lane = row (a wave reads 256 contiguous bytes per k), each
+        // thread takes 8 consecutive k of its row = exactly one fragment's elements
+        const int row = tid & 63, kg = tid >> 6;
+        const int gr = row0 + row;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int gr = row0 + 8 * rc + e;
+            const int k = kt + 8 * kg + e;
             float x = 0.f;
             if (gr < nrows && k < kend) x = gr == ones_row ? 1.f : P[(size_t)k * ld + gr];
             v[e] = x;
@@ -71,18 +73,12 @@ MPG_DEV void tile_store(const float (&v)[8], V (*hi)[2][64], V (*lo)[2][64], int
         hi[blk][s][h * 32 + r] = h8;
         lo[blk][s][h * 32 + r] = l8;
     } else {
-        // rows (m or n) are contiguous in memory: coalesced along them, 2-byte elements scattered
-        const int kr = tid >> 3, rc = tid & 7;
-        const int s = kr >> 4, h = (kr >> 3) & 1, j = kr & 7;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int row = 8 * rc + e;
-            E hh, ll;
-            split1(v[e], hh, ll);
-            const int blk = row >> 5, r = row & 31;
-            reinterpret_cast<E*>(&hi[blk][s][h * 32 + r])[j] = hh;
-            reinterpret_cast<E*>(&lo[blk][s][h * 32 + r])[j] = ll;
-        }
+        const int row = tid & 63, kg = tid >> 6;
+        V h8, l8;
+        split8(v, h8, l8);
+        const int blk = row >> 5, r = row & 31, s = kg >> 1, h = kg & 1;
+        hi[blk][s][h * 32 + r] = h8;
+        lo[blk][s][h * 32 + r] = l8;
     }
 }
 
@@ -141,15 +137,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const MpgGemm g) {
         float v = acc[r] * g.out_scale + bias;
         if (g.act == 1) v = lrelu(v, g.alpha);
         if (g.drop_thr) {  // forward dropout on the output element (m, n)
-            const uint32_t wd = drop_word(seed_lo, seed_hi, g.drop_tag, (uint32_t)m, (uint32_t)(n >> 2));
-            v = drop_keep(wd, n & 3, g.drop_thr) ? v * g.drop_scale : 0.f;
+            v = drop_keep_f(seed_lo, seed_hi, g.drop_tag, (uint32_t)m, n, g.drop_thr) ? v * g.drop_scale : 0.f;
         }
         if (g.gateH != nullptr) {  // backward through (dropout o leaky-relu) of the layer that produced H
             const float hv = g.gateH[(size_t)m * g.ldh + n];
             float gt = g.gate_act ? lrelu_grad(hv, g.alpha) : 1.f;
             if (g.gate_thr) {
-                const uint32_t wd = drop_word(seed_lo, seed_hi, g.gate_tag, (uint32_t)m, (uint32_t)(n >> 2));
-                gt = drop_keep(wd, n & 3, g.gate_thr) ? gt * g.gate_scale : 0.f;
+                gt = drop_keep_f(seed_lo, seed_hi, g.gate_tag, (uint32_t)m, n, g.gate_thr) ? gt * g.gate_scale : 0.f;
             }
             v *= gt;
         }
@@ -173,8 +167,7 @@ __global__ void gate_kernel(const float* __restrict__ in, int ldi, const float* 
     float gt = 1.f;
     if (gate_act && H != nullptr) gt = lrelu_grad(H[(size_t)m * ldh + n], alpha);
     if (thr) {
-        const uint32_t wd = drop_word(seed_lo, seed_hi, tag, (uint32_t)m, (uint32_t)(n >> 2));
-        gt = drop_keep(wd, n & 3, thr) ? gt * scale : 0.f;
+        gt = drop_keep_f(seed_lo, seed_hi, tag, (uint32_t)m, n, thr) ? gt * scale : 0.f;
     }
     out[(size_t)m * ldo + n] = in[(size_t)m * ldi + n] * gt;
 }
@@ -201,8 +194,7 @@ __global__ void drop_mask_kernel(float* __restrict__ out, size_t rows, int F, co
     const size_t row = idx / F;
     const int f = idx % F;
     const uint64_t sd = *seed;
-    const uint32_t wd = drop_word((uint32_t)sd, (uint32_t)(sd >> 32), tag, (uint32_t)row, (uint32_t)(f >> 2));
-    out[idx] = (thr == 0 || drop_keep(wd, f & 3, thr)) ? 1.f : 0.f;
+    out[idx] = (thr == 0 || drop_keep_f((uint32_t)sd, (uint32_t)(sd >> 32), tag, (uint32_t)row, f, thr)) ? 1.f : 0.f;
 }
 
 }  // namespace

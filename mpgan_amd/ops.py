@@ -47,9 +47,14 @@ def bump_seed(device="cuda"):
     seed_tensor(device).add_(0x1E3779B97F4A7C15)
 
 
+LAST_TAG = 0
+
+
 def next_tag() -> int:
     """A fresh dropout-site tag base (8 sites per call) for one fused-op invocation."""
-    return (next(_tag_counter) % (1 << 24)) * 8
+    global LAST_TAG
+    LAST_TAG = (next(_tag_counter) % (1 << 24)) * 8
+    return LAST_TAG
 
 
 def drop_params(p: float):

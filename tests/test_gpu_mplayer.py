@@ -199,3 +199,48 @@ def test_mplayer_full_size():
         if k not in ("y", "dx"):
             assert v < TOL, (k, v)
     assert frac["dx"] < 0.02
+
+
+@pytest.mark.parametrize("p_drop", [0.5, 0.3])
+def test_mplayer_dropout_exact(p_drop):
+    """Dropout on (training mode): the kernels' counter-based keep masks are dumped with
+    mpg_dropout_mask and fed to the oracle, so forward AND backward can be compared exactly
+    (p = 0.5 takes the one-bit fast path, p = 0.3 the byte-threshold path; slope 1 keeps it smooth)."""
+    import oracle
+    from oracle import train_ref as T
+    from mpgan_amd import ops
+    from mpgan_amd.mpgan import MPLayer
+    B, N, F, out = 3, 30, 32, 32
+    V = B * N
+    sd64 = T.init_state_dict(_mplayer_shapes(F, out), seed=77, dtype=torch.float64)
+    layer = MPLayer(F, [96, 160, 192], [256, 256], out, leaky_relu_alpha=1.0, dropout_p=p_drop).to(_dev())
+    layer.load_state_dict({k: v.float() for k, v in sd64.items()})
+    layer.train()
+    rs = np.random.RandomState(5)
+    x64 = torch.from_numpy(rs.normal(0, 0.5, size=(B, N, F)))
+    g64 = torch.from_numpy(rs.normal(size=(B, N, out)))
+    mask64 = torch.from_numpy((rs.uniform(size=(B, N, 1)) < 0.8).astype(np.float64))
+    mask64[:, 0] = 1
+    ops.set_seed(4242)
+    x = x64.float().to(_dev()).requires_grad_(True)
+    y = layer(x, True, mask64.float().to(_dev()))
+    tag = ops.LAST_TAG
+    (y * g64.float().to(_dev())).sum().backward()
+    thr, scale = ops.drop_params(p_drop)
+    widths = {"e0": 96, "e1": 160, "e2": 192, "n0": 256, "n1": 256, "n2": out}
+    sites = {"e0": ops.TAG_E0, "e1": ops.TAG_E1, "e2": ops.TAG_E2, "n0": ops.TAG_N0, "n1": ops.TAG_N1, "n2": ops.TAG_N2}
+    keeps = {}
+    for k, wdt in widths.items():
+        rows = V * N if k.startswith("e") else V
+        m = ops.dropout_mask(rows, wdt, tag + sites[k], thr).cpu().double()
+        keeps[k] = m.reshape(B, N, N, wdt) if k.startswith("e") else m.reshape(B, N, wdt)
+        frac = float(m.mean())
+        assert abs(frac - (1 - thr / 256.0)) < 0.02, (k, frac)
+    sdo = {"L." + k: v.clone().requires_grad_(True) for k, v in sd64.items()}
+    xo = x64.clone().requires_grad_(True)
+    yo = oracle.mplayer_forward(sdo, "L", xo, mask64, alpha=1.0, p=thr / 256.0, keeps=keeps)
+    (yo * g64).sum().backward()
+    assert rel_err(y.detach().cpu().numpy(), yo.detach().numpy()) < TIGHT
+    assert rel_err(x.grad.cpu().numpy(), xo.grad.numpy()) < TIGHT
+    for k, p in layer.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), sdo["L." + k].grad.numpy()) < TIGHT, k
