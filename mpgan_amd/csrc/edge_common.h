@@ -3,6 +3,10 @@
 #include "common.h"
 #include "../../include/mpgan_amd.h"
 
+#ifndef MPG_CHAIN_PF
+#define MPG_CHAIN_PF 1
+#endif
+
 namespace {
 
 
@@ -56,16 +60,20 @@ MPG_DEV void copy_to_lds(V* dst, const V* __restrict__ src, int n16, int tid) {
 // wave keeps the matrix pipe and the VALU busy together; sched_barrier pins that order.
 template <int KS, typename V, typename LH, typename LL, typename Side>
 MPG_DEV void tile_chain(f32x16& acc, const V (*bhi)[2], const V (*blo)[2], LH load_hi, LL load_lo, Side side) {
-    V ah[2], al[2];
-    ah[0] = load_hi(0);
-    al[0] = load_lo(0);
+    constexpr int PF = MPG_CHAIN_PF;  // k-steps of fragment prefetch (ring of PF + 1 slots)
+    V ah[PF + 1], al[PF + 1];
+#pragma unroll
+    for (int k = 0; k < PF && k < KS; ++k) {
+        ah[k] = load_hi(k);
+        al[k] = load_lo(k);
+    }
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
-        if (k + 1 < KS) {
-            ah[(k + 1) & 1] = load_hi(k + 1);
-            al[(k + 1) & 1] = load_lo(k + 1);
+        if (k + PF < KS) {
+            ah[(k + PF) % (PF + 1)] = load_hi(k + PF);
+            al[(k + PF) % (PF + 1)] = load_lo(k + PF);
         }
-        acc = mfma3(ah[k & 1], al[k & 1], bhi[k >> 1][k & 1], blo[k >> 1][k & 1], acc);
+        acc = mfma3(ah[k % (PF + 1)], al[k % (PF + 1)], bhi[k >> 1][k & 1], blo[k >> 1][k & 1], acc);
         side(k);
         __builtin_amdgcn_sched_barrier(0);
     }
