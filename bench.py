@@ -58,7 +58,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="jets per GPU (weak scaling)")
+    ap.add_argument("--model", default="mpgan", choices=["mpgan", "gapt"],
+                    help="mpgan = the headline config; gapt = BASELINE config 4 (not the bench line)")
+    ap.add_argument("--batch", type=int, default=0, help="jets per GPU (weak scaling); default 256 (mpgan) / 512 (gapt)")
     ap.add_argument("--particles", type=int, default=30)
     ap.add_argument("--dist", default="gluon", choices=["gluon", "uniform"], help="particle-multiplicity law")
     ap.add_argument("--no-graphs", action="store_true")
@@ -85,14 +87,18 @@ def main():
     from mpgan_amd import train, ops
     from oracle.train_ref import synthetic_batch
 
-    B, N = args.batch, args.particles
+    B, N = args.batch or (256 if args.model == "mpgan" else 512), args.particles
     torch.manual_seed(4 + rank)  # setup_training.py:184 (+ rank: every rank draws its own noise)
-    G, D = train.default_mpgan(N, disc_dropout=0.5)
+    if args.model == "mpgan":
+        G, D = train.default_mpgan(N, disc_dropout=0.5)
+        latent, (lr_d, lr_g) = 32, train.LR["g"]
+    else:
+        G, D = train.default_gapt(N, disc_dropout=0.5)
+        latent, (lr_d, lr_g) = 64, train.LR_GAPT
     if world > 1:  # one-time parameter broadcast from rank 0
         for p in list(G.parameters()) + list(D.parameters()):
             dist.broadcast(p.data, 0)
-    lr_d, lr_g = train.LR["g"]
-    ts = train.TrainStep(G, D, B, N, lr_disc=lr_d, lr_gen=lr_g, use_graphs=not args.no_graphs,
+    ts = train.TrainStep(G, D, B, N, latent=latent, lr_disc=lr_d, lr_gen=lr_g, use_graphs=not args.no_graphs,
                          process_group=pg, world_size=world)
     data, labels = synthetic_batch(B, N, seed=4 + rank, dist=args.dist)
     ts.set_batch(data.to(dev), labels.to(dev))
@@ -122,27 +128,28 @@ def main():
     d_loss, g_loss = float(ts.D_loss), float(ts.G_loss)
 
     out = {
-        "metric": "jets/sec (G+D step) MPGAN gluon N=30 bs=256 @1/2/4/8 MI355X",
+        "metric": "jets/sec (G+D step) MPGAN gluon N=30 bs=256 @1/2/4/8 MI355X" if (args.model == "mpgan" and N == 30) else f"jets/sec (G+D step) {args.model} N={N} bs={B}",
         "value": jets_per_s, "unit": "jets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16x3 (forward) / bf16x3 (gradients) split-16-bit MFMA, fp32 accumulate, fp32 in/out",
         "data": "synthetic",
-        "config": {"workload": f"MPGAN gluon-like jets, N={N} particles, B={B} per GPU, one train_D+train_G "
-                               "iteration (LSGAN, RMSprop, D dropout 0.5)",
+        "config": {"workload": f"{args.model.upper()} gluon-like jets, N={N} particles, B={B} per GPU, one "
+                               "train_D+train_G iteration (LSGAN, RMSprop, D dropout 0.5)",
                    "global_batch": world * B, "particles": N, "multiplicity": args.dist,
                    "parallelism": f"dp{world}", "hip_graphs": not args.no_graphs},
         "losses": {"D": d_loss, "G": g_loss},
-        "algorithmic_gflop_per_jet": iteration_flops_per_jet(N) / 1e9,
-        "whole_step_mfma_frac": jets_per_s / world * iteration_flops_per_jet(N) / PEAK_MFMA_16BIT,
     }
+    if args.model == "mpgan":
+        out["algorithmic_gflop_per_jet"] = iteration_flops_per_jet(N) / 1e9
+        out["whole_step_mfma_frac"] = jets_per_s / world * iteration_flops_per_jet(N) / PEAK_MFMA_16BIT
 
     # ------------------------------------------------------------------ roofline of the dominant kernel
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and args.model == "mpgan":
         out["roofline"], out["kernels"] = roofline(torch, ts, B, N, dev)
         log("roofline leg done", out["kernels"])
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "mpgan":
         out["cpu_baseline"] = cpu_baseline(torch, N)
 
     if rank == 0:
