@@ -92,14 +92,13 @@ typedef struct MpgEdgeFwd {
     float alpha, agg_scale;
     const uint64_t* seed; uint32_t tag_base, thr; float dscale;  /* dropout: thr=round(256p), dscale=1/(1-p_eff) */
     int skip_masked;                      /* skip senders with mask == 0 (exact: they add 0)   */
-    int weights_in_lds;                   /* keep W3 (hi,lo) + W2 hi resident in LDS           */
     int f16;                              /* images and activations are fp16 hi/lo (else bf16)  */
-    unsigned long long* sign3;            /* optional [B*RB*N, 96] lane ballots of (Z3 > 0) for the backward (NULL = off) */
+    unsigned int* sign3;                  /* optional [B*RB*N][3][64] per-lane sign words of Z3 for the backward (NULL = off) */
 } MpgEdgeFwd;
 int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream);
 
 /* mpg_edge_bwd: autograd backward of the same span, data path.  Given dagg = dL/dagg and the
- * forward's sign ballots it produces
+ * forward's sign words it produces
  *   da [SC, B*N, 96]  (partial over sender chunks),  dc [RB, B*N, 96]  (partial over receiver blocks of 32)
  * and, when stageE2/stageZ2 are non-NULL (weight gradients wanted), parks E2 = fe.net.1's output and
  * dZ2 = dL/d(its pre-activation) as 16-bit hi/lo planes [B*RB*N blocks][2][160][32] (fp16 / bf16 resp.
@@ -108,7 +107,7 @@ int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream);
 typedef struct MpgEdgeBwd {
     const float* a; const float* c; const float* mask;
     const float* dagg; int ld_dagg;
-    const unsigned long long* sign3;      /* [B*RB*N, 96] from mpg_edge_fwd                     */
+    const unsigned int* sign3;            /* [B*RB*N][3][64] from mpg_edge_fwd                   */
     const void* W2img; const void* W3Timg; const void* W2Timg;
     const float* b2;
     float* da; float* dc;
@@ -122,12 +121,12 @@ int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream);
 
 /* mpg_edge_dw: weight gradients of fe.net.1 / fe.net.2 (and their biases) from the planes parked by
  * mpg_edge_bwd:  dW3 = dscale * sum_e dZ3 E2^T [192,160], dW2 = dscale * sum_e dZ2 E1^T [160,96],
- * db3 = sum_e dZ3 [192], db2 = sum_e dZ2 [160]; E1 and dZ3 are rebuilt from a, c, dagg and the ballots.
+ * db3 = sum_e dZ3 [192], db2 = sum_e dZ2 [160]; E1 and dZ3 are rebuilt from a, c, dagg and the sign words.
  * `part` is scratch of nwg * 46,432 floats (per-workgroup partial sums). */
 typedef struct MpgEdgeDw {
     const float* a; const float* c; const float* mask;
     const float* dagg; int ld_dagg;
-    const unsigned long long* sign3;
+    const unsigned int* sign3;
     const void* stageE2; const void* stageZ2;
     float* part; int nwg;
     float* dW3; float* dW2; float* db3; float* db2;

@@ -46,7 +46,7 @@ class MpgEdgeFwd(C.Structure):
         ("B", C.c_int), ("N", C.c_int), ("SC", C.c_int),
         ("alpha", C.c_float), ("agg_scale", C.c_float),
         ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
-        ("skip_masked", C.c_int), ("weights_in_lds", C.c_int), ("f16", C.c_int),
+        ("skip_masked", C.c_int), ("f16", C.c_int),
         ("sign3", _fp),
     ]
 

@@ -64,10 +64,33 @@ MPG_DEV void split8(const float* v, V& hi, V& lo) {
         lo[j] = (E)(v[j] - (float)hh);
     }
 }
+// fp16 form: per pair one v_cvt_pk_f16_f32 (RTNE) for hi, two v_fma_mix_f32 (x - f32(hi) straight from the
+// packed halves, exact) and one v_cvt_pk_f16_f32 for lo -- 2 VALU ops per element instead of 3.5.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <>
+MPG_DEV void split8<f16x8>(const float* v, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const f16x2 hp = {(_Float16)v[j], (_Float16)v[j + 1]};
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hp), "v"(v[j]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hp), "v"(v[j + 1]));
+        hi[j] = hp[0]; hi[j + 1] = hp[1];
+        lo[j] = (_Float16)r0; lo[j + 1] = (_Float16)r1;
+    }
+}
 template <typename E>
 MPG_DEV void split1(float x, E& hh, E& ll) { hh = (E)x; ll = (E)(x - (float)hh); }
 
-MPG_DEV float lrelu(float v, float alpha) { return v > 0.f ? v : v * alpha; }
+// LeakyReLU as max(v, alpha v): two VALU ops instead of compare + multiply + select.  Valid for
+// 0 <= alpha <= 1 (the launchers reject anything else).
+// (inline asm: fmaxf() would add a canonicalising v_max v,v,v per MFMA result)
+MPG_DEV float lrelu(float v, float alpha) {
+    float r;
+    const float va = v * alpha;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(va));
+    return r;
+}
 // derivative as torch's leaky_relu_backward takes it: slope at v <= 0
 MPG_DEV float lrelu_grad(float v, float alpha) { return v > 0.f ? 1.f : alpha; }
 

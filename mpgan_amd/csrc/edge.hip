@@ -43,8 +43,11 @@ __global__ void pack_kernel(const float* __restrict__ W, int ldw, int rows, int 
     reinterpret_cast<V*>(img)[(size_t)nfrag * 64 + idx] = lo;
 }
 
-template <bool WLDS, int DROP, bool F16>  // DROP: 0 off, 1 byte-threshold dropout, 2 one-bit (p = 1/2) dropout
+// DROP: 0 off, 1 byte-threshold dropout, 2 one-bit (p = 1/2) dropout.  SIGN: also write the per-lane sign words
+// of Z3 the backward needs (a run-time test here would put a branch after every accumulator register).
+template <int DROP, bool F16, bool SIGN>
 __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
+    constexpr bool WLDS = true;  // W3 hi+lo and W2 hi live in LDS (the only variant kept: streaming all of them spilled)
     typedef typename FragT<F16>::type V;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -191,8 +194,9 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
         // ---- layer 3 + masked aggregation over senders, pipelined the same way
         {
             f32x16 accs[2];
-            unsigned long long balv = 0;
-            unsigned long long* sg = p.sign3 ? p.sign3 + ((size_t)((b * RB + rb) * p.N + j)) * (T3 * 16) : nullptr;
+            // sign words: lane (receiver r, half h) shifts in the sign bit of each of its 96 Z3 registers in
+            // (tile, register) order -> word tile>>1, bit 31 - (16 (tile & 1) + register); one v_alignbit each
+            uint32_t sgn[T3 / 2] = {0u, 0u, 0u};
 #pragma unroll
             for (int m = 0; m <= T3; ++m) {
                 const int mm = m - 1;
@@ -200,14 +204,18 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
                     const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, mm, 2 * g + h, h);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        if (p.sign3 != nullptr) {  // lane ballot of (Z3 > 0): lane 4g+t keeps word 4g+t of this tile
-                            const unsigned long long bal = __ballot(accs[(m + 1) & 1][4 * g + t] > 0.f);
-                            if (lane == 4 * g + t) balv = bal;
-                        }
-                        const float x = drop_apply<DROP>(lrelu(accs[(m + 1) & 1][4 * g + t], p.alpha), wd, 8 * g + t, t, p.thr);
+                        const float z = accs[(m + 1) & 1][4 * g + t];
+                        if constexpr (SIGN) sgn[mm >> 1] = __builtin_amdgcn_alignbit(sgn[mm >> 1], __builtin_bit_cast(uint32_t, z), 31);
+                        const float x = drop_apply<DROP>(lrelu(z, p.alpha), wd, 8 * g + t, t, p.thr);
                         agg[mm][4 * g + t] += mjs * x;
                     }
-                    if (g == 3 && sg != nullptr && lane < 16) sg[mm * 16 + lane] = balv;  // 16 words of tile mm
+                    if constexpr (SIGN) {
+                        if (g == 3 && mm == T3 - 1) {
+                            uint32_t* sg = p.sign3 + ((size_t)((b * RB + rb) * p.N + j)) * (T3 * 32) + lane;
+#pragma unroll
+                            for (int q = 0; q < T3 / 2; ++q) sg[q * 64] = sgn[q];
+                        }
+                    }
                 };
                 if (m < T3) {
                     f32x16& acc = accs[m & 1];
@@ -266,34 +274,30 @@ extern "C" int mpg_pack_weights(const float* W, int ldw, int rows, int cols, int
 
 extern "C" int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream) {
     if (p->B <= 0 || p->N <= 0 || p->SC <= 0) return -1;
+    if (!(p->alpha >= 0.f && p->alpha <= 1.f)) return -4;  // lrelu() is max(v, alpha v)
     const int RB = (p->N + 31) / 32;
     dim3 grid(p->B * RB * p->SC), block(256);
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-#define MPG_FWD_ATTR(L, D, H, BYTES) \
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_kernel<L, D, H>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES))
-    if (!attr_set) {
-        MPG_FWD_ATTR(true, 0, false, FWD_LDS_BYTES); MPG_FWD_ATTR(true, 1, false, FWD_LDS_BYTES); MPG_FWD_ATTR(true, 2, false, FWD_LDS_BYTES);
-        MPG_FWD_ATTR(true, 0, true, FWD_LDS_BYTES);  MPG_FWD_ATTR(true, 1, true, FWD_LDS_BYTES);  MPG_FWD_ATTR(true, 2, true, FWD_LDS_BYTES);
-        MPG_FWD_ATTR(false, 0, false, NOLDS_BYTES);  MPG_FWD_ATTR(false, 1, false, NOLDS_BYTES);  MPG_FWD_ATTR(false, 2, false, NOLDS_BYTES);
-        MPG_FWD_ATTR(false, 0, true, NOLDS_BYTES);   MPG_FWD_ATTR(false, 1, true, NOLDS_BYTES);   MPG_FWD_ATTR(false, 2, true, NOLDS_BYTES);
-        attr_set = true;
-    }
-#undef MPG_FWD_ATTR
     const int dm = p->thr == 0 ? 0 : (p->thr == 128 ? 2 : 1);
-#define MPG_FWD_GO2(L, D, BYTES)                                                                              \
-    do {                                                                                                      \
-        if (p->f16) hipLaunchKernelGGL((edge_fwd_kernel<L, D, true>), grid, block, BYTES, st, *p);            \
-        else hipLaunchKernelGGL((edge_fwd_kernel<L, D, false>), grid, block, BYTES, st, *p);                  \
+#define MPG_FWD_ONE(D, H, S)                                                                                      \
+    do {                                                                                                          \
+        static bool done = false;                                                                                 \
+        if (!done) {                                                                                              \
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_kernel<D, H, S>,                              \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS_BYTES));        \
+            done = true;                                                                                          \
+        }                                                                                                         \
+        hipLaunchKernelGGL((edge_fwd_kernel<D, H, S>), grid, block, FWD_LDS_BYTES, st, *p);                       \
     } while (0)
-#define MPG_FWD_GO(L, BYTES)                                                                                  \
-    do {                                                                                                      \
-        if (dm == 0) MPG_FWD_GO2(L, 0, BYTES); else if (dm == 1) MPG_FWD_GO2(L, 1, BYTES); else MPG_FWD_GO2(L, 2, BYTES); \
-    } while (0)
-    if (p->weights_in_lds) MPG_FWD_GO(true, FWD_LDS_BYTES);
-    else MPG_FWD_GO(false, NOLDS_BYTES);
-#undef MPG_FWD_GO
-#undef MPG_FWD_GO2
+#define MPG_FWD_S(D, H)                                                                                           \
+    do { if (p->sign3 != nullptr) MPG_FWD_ONE(D, H, true); else MPG_FWD_ONE(D, H, false); } while (0)
+#define MPG_FWD_H(D)                                                                                              \
+    do { if (p->f16) MPG_FWD_S(D, true); else MPG_FWD_S(D, false); } while (0)
+    if (dm == 0) MPG_FWD_H(0);
+    else if (dm == 1) MPG_FWD_H(1);
+    else MPG_FWD_H(2);
+#undef MPG_FWD_H
+#undef MPG_FWD_S
+#undef MPG_FWD_ONE
     return (int)hipGetLastError();
 }
-

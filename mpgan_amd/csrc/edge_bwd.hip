@@ -1,6 +1,6 @@
 // Backward of the fused edge network (see edge.hip for the forward and the chain layout).
 //
-//   dZ3 = m_j * dagg_i * keep3 * phi'(Z3)      phi'(Z3) from the forward's saved lane ballots
+//   dZ3 = m_j * dagg_i * keep3 * phi'(Z3)      phi'(Z3) from the forward's saved sign words
 //   dE2 = W3'^T dZ3 ;  dZ2 = dE2 * keep2 * phi'(Z2)     (Z2/E2 recomputed: one 90-MFMA layer)
 //   dE1 = W2'^T dZ2 ;  dZ1 = dE1 * keep1 * phi'(Z1) ;  da_i = sum_j dZ1 ;  dc_j = sum_i dZ1
 //   dW3 = s * sum_e dZ3 E2^T ;  dW2 = s * sum_e dZ2 E1^T ;  db3 = sum_e dZ3 ;  db2 = sum_e dZ2
@@ -10,7 +10,7 @@
 // streamed from L2) and, when weight gradients are wanted, parks E2 and dZ2 in memory as 16-bit
 // hi/lo planes laid out [block of 32 receivers][feature][receiver], i.e. already transposed for the
 // weight-gradient contraction over edges.  edge_dw_kernel then streams those planes, rebuilds the
-// cheap operands (E1 from a_i + c_j, dZ3 from dagg and the ballots) and accumulates dW3/dW2/db3/db2
+// cheap operands (E1 from a_i + c_j, dZ3 from dagg and the sign words) and accumulates dW3/dW2/db3/db2
 // in registers over its share of the edges; the per-workgroup partials are summed by a last small
 // kernel that also undoes the fragment-order permutation of the feature indices.
 #include "edge_common.h"
@@ -116,6 +116,9 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
         const uint32_t erow = (uint32_t)((b * p.N + i) * p.N + j);
         const size_t blk = (size_t)(b * RB + rb) * p.N + j;
         const float* cj = lc + (j - j0) * H1;
+        uint32_t sw[T3 / 2];  // this lane's 96 sign bits of Z3 (requested now, used after layer 2)
+#pragma unroll
+        for (int q = 0; q < T3 / 2; ++q) sw[q] = p.sign3[blk * (T3 * 32) + q * 64 + lane];
 
         // ---- recompute layer 1
         V e1hi[T1][2], e1lo[T1][2];
@@ -184,16 +187,9 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             for (int g = 0; g < 4; ++g) epi2(T2 - 1, g);
         }
 
-        // ---- dZ3 = m_j * dagg * keep3 * phi'(Z3), phi' from the forward's ballots
+        // ---- dZ3 = m_j * dagg * keep3 * phi'(Z3), phi' from the forward's sign words
         bf16x8 z3hi[T3][2], z3lo[T3][2];
         {
-            // the 96 ballot words of this block: two vector loads (lane l holds word l / word 64 + l),
-            // then v_readlane per word -- 96 separate scalar-value loads would sit in ~190 VGPRs
-            const unsigned long long* sg = p.sign3 + blk * (T3 * 16);
-            const unsigned long long bwa = sg[lane];
-            const unsigned long long bwb = sg[64 + (lane & 31)];
-            const unsigned int bwa_lo = (unsigned int)bwa, bwa_hi = (unsigned int)(bwa >> 32);
-            const unsigned int bwb_lo = (unsigned int)bwb, bwb_hi = (unsigned int)(bwb >> 32);
 #pragma unroll
             for (int m = 0; m < T3; ++m) {
                 float v[16];
@@ -204,12 +200,11 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                     const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const int k = m * 16 + 4 * g + t;
-                        const unsigned int lo = k < 64 ? __builtin_amdgcn_readlane(bwa_lo, k) : __builtin_amdgcn_readlane(bwb_lo, k - 64);
-                        const unsigned int hi = k < 64 ? __builtin_amdgcn_readlane(bwa_hi, k) : __builtin_amdgcn_readlane(bwb_hi, k - 64);
-                        const bool pos = __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)hi << 32) | lo);
-                        const float gt = drop_apply<DROP>(pos ? 1.f : p.alpha, wd, 8 * g + t, t, p.thr);
-                        v[4 * g + t] = mjs * dd[t] * gt;
+                        // sign bit of this lane's Z3 register (tile m, 4g+t): see the forward's epi3
+                        const int neg = __builtin_amdgcn_sbfe((int)sw[m >> 1], 31 - (16 * (m & 1) + 4 * g + t), 1);
+                        const float d = mjs * dd[t], da = d * p.alpha;
+                        const float sel = __builtin_bit_cast(float, (neg & __builtin_bit_cast(int, da)) | (~neg & __builtin_bit_cast(int, d)));
+                        v[4 * g + t] = drop_apply<DROP>(sel, wd, 8 * g + t, t, p.thr);
                     }
                 }
                 split8(v, z3hi[m][0], z3lo[m][0]);
@@ -347,7 +342,7 @@ constexpr int DW_LD = 40;  // tile row stride in 16-bit elements (80 B: conflict
 constexpr int DW_ROWS = H3 + H2 + H2 + H1;  // Z3 | E2 | Z2 | E1
 constexpr int DW_TILE_BYTES = DW_ROWS * 2 * DW_LD * 2;  // 97,280
 constexpr int DW_TLD = 36;  // row stride (floats) of the dagg^T / a^T tiles: 32 would put every row on the same banks
-constexpr int DW_LDS_BYTES = DW_TILE_BYTES + H3 * DW_TLD * 4 + H1 * DW_TLD * 4 + H1 * 4 + T3 * 16 * 8;  // + dagg^T + a^T + c_j + ballots
+constexpr int DW_LDS_BYTES = DW_TILE_BYTES + H3 * DW_TLD * 4 + H1 * DW_TLD * 4 + H1 * 4 + T3 * 16 * 8;  // + dagg^T + a^T + c_j + sign words
 
 struct DwTile { int prod, m, n; };  // prod 0: dW3 (A = Z3 tile m, B = E2 tile n); 1: dW2 (A = Z2, B = E1)
 __device__ constexpr DwTile DW_TILES[45] = {
@@ -430,7 +425,7 @@ MPG_DEV void edge_dw_body(const MpgEdgeDw& p, char* smem, const int w) {
     float* dgT = reinterpret_cast<float*>(smem + DW_TILE_BYTES);  // [feature][32]
     float* aT = dgT + H3 * DW_TLD;                                // [feature][32 (+4 pad)]
     float* cj = aT + H1 * DW_TLD;                                 // [feature]
-    unsigned long long* lbal = reinterpret_cast<unsigned long long*>(cj + H1);  // [96] ballots of the block
+    uint32_t* lsg = reinterpret_cast<uint32_t*>(cj + H1);  // [3][64] sign words of the block
     const int tid = threadIdx.x, lane = tid & 63;
     const int RB = (p.N + 31) / 32;
     const int nblk = p.B * RB * p.N;
@@ -479,7 +474,7 @@ MPG_DEV void edge_dw_body(const MpgEdgeDw& p, char* smem, const int w) {
             }
         }
         if (tid < H1) cj[tid] = p.c[(size_t)(b * p.N + j) * H1 + tid];
-        if (tid >= 128 && tid < 128 + T3 * 16) lbal[tid - 128] = p.sign3[(size_t)blk * (T3 * 16) + tid - 128];
+        if (tid >= 64) lsg[tid - 64] = p.sign3[(size_t)blk * (T3 * 32) + tid - 64];
         // staged dZ2 pieces -> tile (bf16 planes as they are); bias sums
 #pragma unroll
         for (int n = 0; n < 5; ++n) {
@@ -500,7 +495,7 @@ MPG_DEV void edge_dw_body(const MpgEdgeDw& p, char* smem, const int w) {
                 *reinterpret_cast<bf16x8*>(E2l + (id >> 2) * DW_LD + 8 * (id & 3)) = ll;
             }
         }
-        __syncthreads();  // dgT / aT / cj / lbal visible
+        __syncthreads();  // dgT / aT / cj / lsg visible
         const float mj = p.mask ? p.mask[b * p.N + j] : 1.f;
         const float mjs = mj * p.dscale;
         // db2 from the dZ2 tile rows just written by this thread's own pieces is done below via LDS
@@ -511,7 +506,11 @@ MPG_DEV void edge_dw_body(const MpgEdgeDw& p, char* smem, const int w) {
             const int f = feat_of_fi(fi);
             const int m = f >> 5, fl = f & 31;
             const int reg = 4 * (fl >> 3) + (fl & 3), hb = (fl >> 2) & 1;
-            const unsigned int bits = (unsigned int)(lbal[m * 16 + reg] >> (32 * hb + 8 * pc)) & 0xffu;
+            // the 8 receivers of this piece are lanes 32 hb + 8 pc + k; each holds the bit at the same position
+            const int sh = 31 - (16 * (m & 1) + reg);
+            const uint4 w0 = *reinterpret_cast<const uint4*>(lsg + (m >> 1) * 64 + 32 * hb + 8 * pc);
+            const uint4 w1 = *reinterpret_cast<const uint4*>(lsg + (m >> 1) * 64 + 32 * hb + 8 * pc + 4);
+            const uint32_t ws[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
             float v[8];
             float s = 0.f;
             const float4 d0 = *reinterpret_cast<const float4*>(dgT + f * DW_TLD + 8 * pc);
@@ -520,7 +519,7 @@ MPG_DEV void edge_dw_body(const MpgEdgeDw& p, char* smem, const int w) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int rcv = 8 * pc + k, ii = rb * 32 + rcv;
-                float gt = ((bits >> k) & 1u) ? 1.f : p.alpha;
+                float gt = ((ws[k] >> sh) & 1u) ? p.alpha : 1.f;
                 if (DROP) {
                     const uint32_t erow = (uint32_t)((b * p.N + ii) * p.N + j);
                     if (!drop_keep_f(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, f, p.thr)) gt = 0.f;
@@ -643,6 +642,7 @@ __global__ __launch_bounds__(256) void edge_dw_reduce(const float* __restrict__ 
 extern "C" int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream) {
     if (p->B <= 0 || p->N <= 0 || p->SC <= 0) return -1;
     if (p->sign3 == nullptr) return -3;
+    if (!(p->alpha >= 0.f && p->alpha <= 1.f)) return -4;
     const int RB = (p->N + 31) / 32;
     dim3 grid(p->B * RB * p->SC), block(256);
     hipStream_t st = (hipStream_t)stream;

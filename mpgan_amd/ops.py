@@ -22,7 +22,6 @@ TAG_E0, TAG_E1, TAG_E2, TAG_N0, TAG_N1, TAG_N2, TAG_GENERIC = 1, 2, 3, 4, 5, 6, 
 _seed = {}
 _tag_counter = itertools.count(1)
 OPTIONS = {
-    "weights_in_lds": True,   # edge forward: W3 (hi,lo) + W2 hi resident in LDS
     "skip_masked": True,      # edge forward: skip zero-masked senders (they contribute exactly 0)
     # forward products (they decide LeakyReLU signs) split as fp16 hi/lo (~2^-21 per product);
     # False = bf16 hi/lo (~2^-17, unlimited range).  Gradient products are always bf16 hi/lo.
@@ -226,11 +225,10 @@ class FusedMPLayerFn(torch.autograd.Function):
         e.alpha, e.agg_scale = alpha, 1.0 if sum_agg else 1.0 / N
         e.seed, e.tag_base, e.thr, e.dscale = _p(seed_t), tag, thr, dscale
         e.skip_masked = int(OPTIONS["skip_masked"])
-        e.weights_in_lds = int(OPTIONS["weights_in_lds"])
         e.f16 = int(f16)
         RB = (N + 31) // 32
         need_grad = any(ctx.needs_input_grad)
-        sign3 = torch.empty((B * RB * N * 96,), device=dev, dtype=torch.int64) if need_grad else None
+        sign3 = torch.empty((B * RB * N * 192,), device=dev, dtype=torch.int32) if need_grad else None
         e.sign3 = None if sign3 is None else C.c_void_p(sign3.data_ptr())
         check(_lib.lib().mpg_edge_fwd(C.byref(e), _stream()), "mpg_edge_fwd")
         agg = aggp[0] if SC == 1 else aggp.sum(0)

@@ -36,12 +36,9 @@ for F, out, p in ((32, 32, 0.0), (32, 32, 0.5), (3, 32, 0.5)):
     n = torch.clamp((torch.randn(B, device=dev) * 0.15 + 0.8) * N, 1, N).round()
     mask = (torch.arange(N, device=dev)[None, :] < n[:, None]).float().unsqueeze(2)
     g = torch.randn(B, N, out, device=dev)
-    for lds in (True, False):
-        ops.OPTIONS["weights_in_lds"] = lds
-        with torch.no_grad():
-            t = timeit(lambda: layer(x, True, mask))
-        print(f"F={F} p={p} lds={lds}: MPLayer fwd (all kernels) {t:8.1f} us")
-    ops.OPTIONS["weights_in_lds"] = True
+    with torch.no_grad():
+        t = timeit(lambda: layer(x, True, mask))
+    print(f"F={F} p={p}: MPLayer fwd (all kernels) {t:8.1f} us")
 
     def fb():
         y = layer(x, True, mask)
