@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -23,6 +24,18 @@ template <> struct FragT<true> { typedef f16x8 type; typedef _Float16 elem; };
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MPG_DEV __device__ __forceinline__
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E-1.  The fused kernels index register
+// arrays with these constants; `#pragma unroll` over run-time ints gives up on their deeply nested bodies
+// (and then indexes registers dynamically through scratch).
+template <int B, int E, typename F>
+MPG_DEV void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+#define MPG_CI(name, c) constexpr int name = decltype(c)::value
 
 // ---------------------------------------------------------------------------------------
 // MFMA 32x32x16 bf16 fragment maps (cdna_hip_programming.md section 3):
@@ -79,6 +92,33 @@ MPG_DEV void split8<f16x8>(const float* v, f16x8& hi, f16x8& lo) {
         lo[j] = (_Float16)r0; lo[j + 1] = (_Float16)r1;
     }
 }
+// The same split for one PAIR of values, cut in two halves (2 VALU ops each in the fp16 form) so that the
+// fused kernels can put them into different issue slots between MFMAs.
+template <typename V> struct PairSplit {
+    typedef typename ElemOf<V>::type E;
+    E h0, h1;
+    float r0;
+    MPG_DEV void first(float v0, float v1) { h0 = (E)v0; h1 = (E)v1; r0 = v0 - (float)h0; }
+    MPG_DEV void second(float v1, V& hi, V& lo, int jj) {
+        const float r1 = v1 - (float)h1;
+        hi[jj] = h0; hi[jj + 1] = h1;
+        lo[jj] = (E)r0; lo[jj + 1] = (E)r1;
+    }
+};
+template <> struct PairSplit<f16x8> {
+    f16x2 hp;
+    float r0;
+    MPG_DEV void first(float v0, float v1) {
+        hp = f16x2{(_Float16)v0, (_Float16)v1};
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hp), "v"(v0));
+    }
+    MPG_DEV void second(float v1, f16x8& hi, f16x8& lo, int jj) {
+        float r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hp), "v"(v1));
+        hi[jj] = hp[0]; hi[jj + 1] = hp[1];
+        lo[jj] = (_Float16)r0; lo[jj + 1] = (_Float16)r1;
+    }
+};
 template <typename E>
 MPG_DEV void split1(float x, E& hh, E& ll) { hh = (E)x; ll = (E)(x - (float)hh); }
 

@@ -15,6 +15,10 @@
 // j loop, and layer 1 is the exact factorisation  W1 [x_i ; x_j] = a_i + c_j  (SURVEY.md A.3).
 #include "edge_common.h"
 
+#ifndef MPG_EXP
+#define MPG_EXP 0  // experiment bits (tools/ubench): 1 no epilogue work, 4 no bias loads, 8 no LDS fragment loads
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -81,6 +85,8 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
     }
     const __amdgpu_buffer_rsrc_t r2 = img_rsrc(p.W2img, 2 * NF2);
     const int lane16 = lane * 16;
+    const uint32_t lb3hi = lds_base(smem, lane16), lb3lo = lds_base(smem, NF3 * 1024 + lane16),
+                   lb2hi = lds_base(smem, 2 * NF3 * 1024 + lane16);
     for (int t = tid; t < H2 + H3; t += 256) lbias[t] = t < H2 ? p.b2[t] : p.b3[t - H2];
     const float* lb2 = lbias;
     const float* lb3 = lbias + H2;
@@ -146,93 +152,128 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
                 split8(v, e1hi[q][s], e1lo[q][s]);
             }
 
-        // ---- layer 2.  Tile m's MFMAs run beside the epilogue of tile m-1 (split in 4 slices of one
-        //      register group each); the W2-lo fragments (streamed from L2) are requested a tile ahead.
+        // ---- layers 2 and 3 as one sequence of 11 output tiles (5 of layer 2, 6 of layer 3).  A single wave has
+        //      to keep the matrix pipe and the VALU busy by itself, and the hardware issues in order: an MFMA
+        //      (32 clk) hides ~6 independent VALU/LDS instructions issued right behind it, no more.  So every
+        //      MFMA is followed by one "slot" of at most a few instructions of OTHER work -- the epilogue of the
+        //      PREVIOUS tile cut into units (one element: read / LeakyReLU / dropout [/ sum / sign bit]; half a
+        //      pair split) and, in the last k-step, the bias load of the NEXT tile -- and sched_barrier pins it.
         V e2hi[T2][2], e2lo[T2][2];
+        if (MPG_EXP & 1) {
+#pragma unroll
+            for (int mm = 0; mm < T2; ++mm) { e2hi[mm][0] = e1hi[0][0]; e2hi[mm][1] = e1hi[0][1]; e2lo[mm][0] = e1lo[0][0]; e2lo[mm][1] = e1lo[0][1]; }
+        }
         {
+            constexpr int NT = T2 + T3;
             V w2l[2][T1 * 2];
 #pragma unroll
             for (int k = 0; k < T1 * 2; ++k) w2l[0][k] = img_frag<V>(r2, lane16, NF2 + k);
             f32x16 accs[2];
             float v2[16];
-#pragma unroll
-            for (int m = 0; m <= T2; ++m) {
-                const int mm = m - 1;
-                auto epi2 = [&](int g) {  // epilogue slice g of tile mm: lrelu, dropout, hi/lo split
-                    const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E1, erow, mm, 2 * g + h, h);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const float x = lrelu(accs[(m + 1) & 1][4 * g + t], p.alpha);
-                        v2[4 * g + t] = drop_apply<DROP>(x, wd, 8 * g + t, t, p.thr);
-                    }
-                    if (g == 1) split8(v2, e2hi[mm][0], e2lo[mm][0]);
-                    if (g == 3) split8(v2 + 8, e2hi[mm][1], e2lo[mm][1]);
-                };
-                if (m < T2) {
-                    if (m + 1 < T2) {
-#pragma unroll
-                        for (int k = 0; k < T1 * 2; ++k) w2l[(m + 1) & 1][k] = img_frag<V>(r2, lane16, NF2 + (m + 1) * T1 * 2 + k);
-                    }
-                    f32x16& acc = accs[m & 1];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 b4 = ld4(lb2 + 32 * m + 8 * g + 4 * h);
-                        acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
-                    }
-                    tile_chain<T1 * 2, V>(
-                        acc, e1hi, e1lo,
-                        [&](int k) { return frag<WLDS, V>(g2hi, l2hi, (m * T1 * 2 + k) * 64 + lane); },
-                        [&](int k) { return w2l[m & 1][k]; },
-                        [&](int k) { if (m > 0 && k >= 1 && k <= 4) epi2(k - 1); });
-                } else {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) epi2(g);
-                }
-            }
-        }
-
-        // ---- layer 3 + masked aggregation over senders, pipelined the same way
-        {
-            f32x16 accs[2];
-            // sign words: lane (receiver r, half h) shifts in the sign bit of each of its 96 Z3 registers in
-            // (tile, register) order -> word tile>>1, bit 31 - (16 (tile & 1) + register); one v_alignbit each
+            PairSplit<V> ps[8];
             uint32_t sgn[T3 / 2] = {0u, 0u, 0u};
+            auto bias_init = [&](auto Tc) {  // accumulator of tile T starts as its bias column
+                MPG_CI(T, Tc);
+                const float* bb = T < T2 ? lb2 + 32 * T : lb3 + 32 * (T - T2);
+                f32x16& acc = accs[T & 1];
 #pragma unroll
-            for (int m = 0; m <= T3; ++m) {
-                const int mm = m - 1;
-                auto epi3 = [&](int g) {
-                    const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, mm, 2 * g + h, h);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const float z = accs[(m + 1) & 1][4 * g + t];
-                        if constexpr (SIGN) sgn[mm >> 1] = __builtin_amdgcn_alignbit(sgn[mm >> 1], __builtin_bit_cast(uint32_t, z), 31);
-                        const float x = drop_apply<DROP>(lrelu(z, p.alpha), wd, 8 * g + t, t, p.thr);
-                        agg[mm][4 * g + t] += mjs * x;
-                    }
-                    if constexpr (SIGN) {
-                        if (g == 3 && mm == T3 - 1) {
-                            uint32_t* sg = p.sign3 + ((size_t)((b * RB + rb) * p.N + j)) * (T3 * 32) + lane;
-#pragma unroll
-                            for (int q = 0; q < T3 / 2; ++q) sg[q * 64] = sgn[q];
-                        }
-                    }
-                };
-                if (m < T3) {
-                    f32x16& acc = accs[m & 1];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 b4 = ld4(lb3 + 32 * m + 8 * g + 4 * h);
-                        acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
-                    }
-                    tile_chain<T2 * 2, V>(
-                        acc, e2hi, e2lo,
-                        [&](int k) { return frag<WLDS, V>(g3hi, l3hi, (m * T2 * 2 + k) * 64 + lane); },
-                        [&](int k) { return frag<WLDS, V>(g3lo, l3lo, (m * T2 * 2 + k) * 64 + lane); },
-                        [&](int k) { if (m > 0 && (k & 1) && k < 8) epi3(k >> 1); });
-                } else {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) epi3(g);
+                for (int g = 0; g < 4; ++g) {
+                    const float4 b4 = ld4(bb + 8 * g + 4 * h);
+                    acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
                 }
+            };
+            // epilogue units of a layer-2 tile mm: q = 4 pair + {element 0, element 1, split half 1, split half 2}
+            auto epi2_unit = [&](auto mc, auto qc) {
+                MPG_CI(mm, mc); MPG_CI(q, qc);
+                constexpr int pr = q >> 2, u = q & 3;
+                if constexpr (u < 2) {
+                    constexpr int e = 2 * pr + u, g = e >> 2, t = e & 3;
+                    const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E1, erow, mm, 2 * g + h, h);
+                    v2[e] = drop_apply<DROP>(lrelu(accs[mm & 1][e], p.alpha), wd, 8 * g + t, t, p.thr);
+                } else if constexpr (u == 2) {
+                    ps[pr].first(v2[2 * pr], v2[2 * pr + 1]);
+                } else {
+                    ps[pr].second(v2[2 * pr + 1], e2hi[mm][pr >> 2], e2lo[mm][pr >> 2], 2 * (pr & 3));
+                }
+            };
+            // epilogue units of a layer-3 tile mm: q = element
+            auto epi3_unit = [&](auto mc, auto ec) {
+                MPG_CI(mm, mc); MPG_CI(e, ec);
+                constexpr int g = e >> 2, t = e & 3;
+                const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, mm, 2 * g + h, h);
+                const float z = accs[(T2 + mm) & 1][e];
+                // sign words: this lane shifts in the sign bit of each of its 96 Z3 registers in (tile, register)
+                // order -> word tile>>1, bit 31 - (16 (tile & 1) + register); one v_alignbit each
+                if constexpr (SIGN) sgn[mm >> 1] = __builtin_amdgcn_alignbit(sgn[mm >> 1], __builtin_bit_cast(uint32_t, z), 31);
+                const float x = drop_apply<DROP>(lrelu(z, p.alpha), wd, 8 * g + t, t, p.thr);
+                agg[mm][e] += mjs * x;
+            };
+            // slot SL of NS slots takes the units u of the previous tile with floor(u * NS / NU) == SL
+            auto side = [&](auto Tc, auto slc, auto nsc) {
+                MPG_CI(T, Tc); MPG_CI(SL, slc); MPG_CI(NS, nsc);
+                if constexpr (T > 0 && !(MPG_EXP & 1)) {
+                    constexpr int P = T - 1;
+                    constexpr int NU = P < T2 ? 32 : 16;
+                    constexpr int q0 = (SL * NU + NS - 1) / NS, q1 = SL + 1 >= NS ? NU : ((SL + 1) * NU + NS - 1) / NS;
+                    static_for<q0, q1>([&](auto qc) {
+                        if constexpr (P < T2) epi2_unit(std::integral_constant<int, P>{}, qc);
+                        else epi3_unit(std::integral_constant<int, P - T2>{}, qc);
+                    });
+                }
+            };
+            bias_init(std::integral_constant<int, 0>{});
+            static_for<0, NT>([&](auto Tc) {
+                MPG_CI(T, Tc);
+                constexpr bool l2 = T < T2;
+                constexpr int m = l2 ? T : T - T2;
+                constexpr int KS = l2 ? T1 * 2 : T2 * 2;
+                constexpr int NS = 3 * KS - 3;  // the last k-step's slots are left to the next tile's bias load
+                if constexpr (l2 && m + 1 < T2) {
+#pragma unroll
+                    for (int k = 0; k < T1 * 2; ++k) w2l[(m + 1) & 1][k] = img_frag<V>(r2, lane16, NF2 + (m + 1) * T1 * 2 + k);
+                }
+                auto load_hi = [&](int k) { return l2 ? lds_frag<V>(lb2hi, (m * T1 * 2 + k) * 1024) : lds_frag<V>(lb3hi, (m * T2 * 2 + k) * 1024); };
+                auto load_lo = [&](int k) { return l2 ? w2l[m & 1][k < T1 * 2 ? k : 0] : lds_frag<V>(lb3lo, (m * T2 * 2 + k) * 1024); };
+                V ah[2], al[2];
+                ah[0] = load_hi(0);
+                al[0] = load_lo(0);
+                if (MPG_EXP & 8) { ah[1] = ah[0]; al[1] = al[0]; }
+                f32x16& acc = accs[T & 1];
+                static_for<0, KS>([&](auto kc) {
+                    MPG_CI(k, kc);
+                    if constexpr (k + 1 < KS && !(MPG_EXP & 8)) {
+                        ah[(k + 1) & 1] = load_hi(k + 1);
+                        al[(k + 1) & 1] = load_lo(k + 1);
+                    }
+                    V bh, bl;
+                    if constexpr (l2) { bh = e1hi[k >> 1][k & 1]; bl = e1lo[k >> 1][k & 1]; }
+                    else { bh = e2hi[k >> 1][k & 1]; bl = e2lo[k >> 1][k & 1]; }
+                    using NSc = std::integral_constant<int, NS>;
+                    if constexpr (F16) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[k & 1], bh, acc, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[k & 1], bh, acc, 0, 0, 0);
+                    side(Tc, std::integral_constant<int, 3 * k + 0>{}, NSc{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (F16) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[k & 1], bl, acc, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[k & 1], bl, acc, 0, 0, 0);
+                    side(Tc, std::integral_constant<int, 3 * k + 1>{}, NSc{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (F16) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[k & 1], bh, acc, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[k & 1], bh, acc, 0, 0, 0);
+                    side(Tc, std::integral_constant<int, 3 * k + 2>{}, NSc{});
+                    if constexpr (k == KS - 1 && T + 1 < NT && !(MPG_EXP & 4)) bias_init(std::integral_constant<int, T + 1>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+            // drain: epilogue of the last tile
+            if (!(MPG_EXP & 1)) static_for<0, 16>([&](auto qc) { epi3_unit(std::integral_constant<int, T3 - 1>{}, qc); });
+            else {  // experiment: keep the accumulators alive without the epilogues
+#pragma unroll
+                for (int q = 0; q < 16; ++q) agg[0][q] += accs[0][q] + accs[1][q];
+            }
+            if constexpr (SIGN) {
+                uint32_t* sg = p.sign3 + ((size_t)((b * RB + rb) * p.N + j)) * (T3 * 32) + lane;
+#pragma unroll
+                for (int q = 0; q < T3 / 2; ++q) sg[q * 64] = sgn[q];
             }
         }
     }
@@ -293,9 +334,13 @@ extern "C" int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream) {
     do { if (p->sign3 != nullptr) MPG_FWD_ONE(D, H, true); else MPG_FWD_ONE(D, H, false); } while (0)
 #define MPG_FWD_H(D)                                                                                              \
     do { if (p->f16) MPG_FWD_S(D, true); else MPG_FWD_S(D, false); } while (0)
+#ifdef MPG_SINGLE_VARIANT  // tools/ubench/fwd_bench.hip: one instantiation, seconds to compile
+    MPG_FWD_ONE(MPG_SINGLE_VARIANT, true, true);
+#else
     if (dm == 0) MPG_FWD_H(0);
     else if (dm == 1) MPG_FWD_H(1);
     else MPG_FWD_H(2);
+#endif
 #undef MPG_FWD_H
 #undef MPG_FWD_S
 #undef MPG_FWD_ONE

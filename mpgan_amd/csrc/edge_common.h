@@ -20,6 +20,19 @@ MPG_DEV V frag(const V* __restrict__ glb, const V* lds, int idx) {
     else return glb[idx];
 }
 
+// LDS fragment reads as  ds_read_b128 v, base offset:imm  -- `base` is a per-lane byte address made opaque to the
+// optimiser (otherwise it materialises one address register per fragment and parks them in AGPRs: an extra
+// v_accvgpr_read in front of every read), `off` a compile-time byte offset below 64 KiB.
+MPG_DEV uint32_t lds_base(const void* smem_ptr, int byte_off) {
+    uint32_t b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)smem_ptr + (uint32_t)byte_off;
+    asm volatile("" : "+v"(b));
+    return b;
+}
+template <typename V>
+MPG_DEV V lds_frag(uint32_t base, int off) {
+    return *reinterpret_cast<__attribute__((address_space(3))) const V*>(base + (uint32_t)off);
+}
+
 MPG_DEV float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // Streamed weight fragments go through buffer loads: one VGPR (lane * 16) + a scalar fragment

@@ -1,0 +1,7 @@
+#!/bin/bash
+# Per-kernel times of MPLayer fwd+bwd (tools/kbwd.py) under rocprofv3; run on the GPU box from the repo root.
+cd /tmp && export TMPDIR=/tmp
+out=$GRAFT_REPO_ROOT/gpurun_out/kprof
+rm -rf $out
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o k -- python3 $GRAFT_REPO_ROOT/tools/kbwd.py > $out.log 2>&1
+python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $out ${1:-14}
