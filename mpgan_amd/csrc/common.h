@@ -187,6 +187,19 @@ MPG_DEV uint32_t drop_tile_word(uint32_t seed_lo, uint32_t seed_hi, uint32_t tag
     else return 0u;
 }
 
+// x + (x of another lane) with the other lane picked by a DPP control (quad_perm / row_ror): no LDS traffic,
+// unlike __shfl_xor (ds_bpermute).  CTRL: 0xB1 = lane^1, 0x4E = lane^2, 0x124 / 0x128 = rotate the 16-lane row by 4 / 8.
+template <int CTRL>
+MPG_DEV float dpp_add(float keep, float send) {
+    return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), CTRL, 0xf, 0xf, true));
+}
+// One halving step of a many-value lane reduction: the two lanes of a pair both hold partial sums of values
+// A and B; the lane with `bit` clear ends up with A's sum over the pair, the other with B's.
+template <int CTRL>
+MPG_DEV float halve_add(bool bit, float a, float b) {
+    return dpp_add<CTRL>(bit ? b : a, bit ? a : b);
+}
+
 // dropout sites (tag values); the layer id of the call is mixed in by the host as tag_base
 enum { TAG_E0 = 1, TAG_E1 = 2, TAG_E2 = 3, TAG_N0 = 4, TAG_N1 = 5, TAG_N2 = 6, TAG_GENERIC = 7 };
 

@@ -264,30 +264,36 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
 #pragma unroll
             for (int k = 0; k < PF; ++k) { rh[k] = img_frag<bf16x8>(r2t, lane16, k); rl[k] = img_frag<bf16x8>(r2t, lane16, NF2T + k); }
             f32x16 accs[2];
+            // dc_j = sum over the 32 receivers (lanes of one half) of dZ1: 16 values per tile and lane.  Halving
+            // reduction: at each step a lane keeps half of its values and hands the other half to its partner
+            // (DPP), so 16 values cost 15 exchanges instead of 80 and lane l ends with the total of value l & 15
+            // (= accumulator register 8s + 4u + t  <->  feature 32 mm + 16 s + 8 u + 4 h + t).
+            const bool lb0 = lane & 1, lb1 = lane & 2, lb2 = lane & 4, lb3 = lane & 8;
+            float ured[4];
             auto epi5 = [&](int mm, int su) {  // slice (s,u) of tile mm
                 const int s = su >> 1, u = su & 1;
                 const float4 c4 = ld4(cj + 32 * mm + 16 * s + 8 * u + 4 * h);
                 const float4 a4 = la[((mm * 2 + s) * 2 + u) * 64 + lane];
                 const float cc[4] = {c4.x + a4.x, c4.y + a4.y, c4.z + a4.z, c4.w + a4.w};
                 const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, mm, 4 * s + 2 * u + h, h);
-                float red4[4];
+                float dz[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const float gt = drop_apply<DROP>(lrelu_grad(cc[t], p.alpha), wd, 16 * s + 8 * u + t, t, p.thr);
-                    // accumulator register 8s + 4u + t  <->  element 4u+t of k-step s
-                    const float dz = vi ? accs[mm & 1][8 * s + 4 * u + t] * gt : 0.f;
-                    dacc[mm][s][4 * u + t] += dz;
-                    float x = dz;
-                    x += __shfl_xor(x, 1, 64);
-                    x += __shfl_xor(x, 2, 64);
-                    x += __shfl_xor(x, 4, 64);
-                    x += __shfl_xor(x, 8, 64);
-                    x += __shfl_xor(x, 16, 64);
-                    red4[t] = x;
+                    // accumulator register 8s + 4u + t  <->  element 4u+t of k-step s.  Padding lanes (i >= N) carry
+                    // exact zeros all the way down: their dagg and a tiles are zero-filled.
+                    dz[t] = accs[mm & 1][8 * s + 4 * u + t] * gt;
+                    dacc[mm][s][4 * u + t] += dz[t];
                 }
-                if (r == 0)
-                    *reinterpret_cast<float4*>(dcj + 32 * mm + 16 * s + 8 * u + 4 * h) =
-                        make_float4(red4[0], red4[1], red4[2], red4[3]);
+                const float w0 = halve_add<0xB1>(lb0, dz[0], dz[1]), w1 = halve_add<0xB1>(lb0, dz[2], dz[3]);
+                ured[su] = halve_add<0x4E>(lb1, w0, w1);
+                if (su == 3) {
+                    const float x0 = halve_add<0x124>(lb2, ured[0], ured[1]), x1 = halve_add<0x124>(lb2, ured[2], ured[3]);
+                    float y = halve_add<0x128>(lb3, x0, x1);
+                    y += __shfl_xor(y, 16, 64);
+                    const int e = lane & 15;
+                    if (!(lane & 16)) dcj[32 * mm + 16 * (e >> 3) + 8 * ((e >> 2) & 1) + 4 * h + (e & 3)] = y;
+                }
             };
 #pragma unroll
             for (int kk = 0; kk < TOT; ++kk) {
