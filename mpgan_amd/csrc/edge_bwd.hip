@@ -31,19 +31,13 @@ constexpr int BWD_LDS_BYTES = BWD_W_BYTES + BWD_DG_BYTES + BWD_A_BYTES + H2 * 4 
 #endif
 constexpr int RED_DA_BYTES = 4 * T1 * 16 * 64 * 4;
 
-// staging: block blk = (b*RB + rb)*N + j ; plane part (0 hi, 1 lo) ; row fi = fragment-order feature
-// index ((tile*2 + s)*16 + h*8 + jj) ; column = receiver lane & 31.   16-bit elements.
-MPG_DEV size_t stage_off(size_t blk, int part, int fi) { return ((blk * 2 + part) * (size_t)H2 + fi) * 32; }
-
+// staging: block blk = (b*RB + rb)*N + j ; plane part (0 hi, 1 lo) ; the 10 B-operand fragments (tile, k-step) of
+// the 160-feature tensor exactly as the lanes hold them: one coalesced 16-byte store per lane and fragment.
+// In "fragment order" a lane's 8 elements are features fi = 16 frag + 8 h + jj of receiver r = lane & 31.
+constexpr int NFR2 = T2 * 2;
 template <typename V>
-MPG_DEV void stage_frag(void* base, size_t blk, int part, int tile, int s, int h, int r, const V f) {
-    uint16_t* out = reinterpret_cast<uint16_t*>(base) + stage_off(blk, part, (tile * 2 + s) * 16 + h * 8) + r;
-    typedef typename ElemOf<V>::type E;
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-        const E x = f[jj];
-        out[jj * 32] = *reinterpret_cast<const uint16_t*>(&x);
-    }
+MPG_DEV void stage_frag(void* base, size_t blk, int part, int frag, int lane, const V f) {
+    reinterpret_cast<V*>(base)[((blk * 2 + part) * NFR2 + frag) * 64 + lane] = f;
 }
 
 template <int DROP, bool F16, bool NEEDW>  // DROP: 0 off, 1 byte mode, 2 bit mode (see common.h)
@@ -112,6 +106,11 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     __syncthreads();
     for (int j = j0 + w; j < j1; j += 4) {
         const float mj = p.mask ? p.mask[b * p.N + j] : 1.f;
+        if (mj == 0.f) {  // masked sender: every gradient through these edges is exactly zero (mpg_edge_dw skips the block too)
+            if (lane < H1 / 4)
+                reinterpret_cast<float4*>(p.dc + ((size_t)rb * p.B * p.N + (size_t)(b * p.N + j)) * H1)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
         const float mjs = mj * p.dscale;
         const uint32_t erow = (uint32_t)((b * p.N + i) * p.N + j);
         const size_t blk = (size_t)(b * RB + rb) * p.N + j;
@@ -159,8 +158,8 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                     const int s = g >> 1;
                     split8(v2 + 8 * s, e2hi[mm][s], e2lo[mm][s]);
                     if (NEEDW) {
-                        stage_frag(p.stageE2, blk, 0, mm, s, h, r, e2hi[mm][s]);
-                        stage_frag(p.stageE2, blk, 1, mm, s, h, r, e2lo[mm][s]);
+                        stage_frag(p.stageE2, blk, 0, mm * 2 + s, lane, e2hi[mm][s]);
+                        stage_frag(p.stageE2, blk, 1, mm * 2 + s, lane, e2lo[mm][s]);
                     }
                 }
             };
@@ -234,8 +233,8 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                         const int s = g >> 1;
                         split8(v2 + 8 * s, z2hi[mm][s], z2lo[mm][s]);
                         if (NEEDW) {
-                            stage_frag(p.stageZ2, blk, 0, mm, s, h, r, z2hi[mm][s]);
-                            stage_frag(p.stageZ2, blk, 1, mm, s, h, r, z2lo[mm][s]);
+                            stage_frag(p.stageZ2, blk, 0, mm * 2 + s, lane, z2hi[mm][s]);
+                            stage_frag(p.stageZ2, blk, 1, mm * 2 + s, lane, z2lo[mm][s]);
                         }
                     }
                 };
@@ -339,56 +338,95 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
 
 
 // ------------------------------------------------------------------------------------------------
-// Weight gradients of fe.net.1 / fe.net.2.  One workgroup walks a contiguous range of 32-receiver
-// blocks; per block it builds, in LDS, the four operand tiles [feature (fragment order)][receiver]
-// as bf16 hi/lo planes -- dZ2 copied and E2 converted from the staged planes, dZ3 and E1 rebuilt --
-// and its four waves accumulate their share of the 30 (dW3) + 15 (dW2) output tiles with
-// A = dZ rows, B = E rows, contraction over the 32 receivers (2 k-steps).
-constexpr int DW_LD = 40;  // tile row stride in 16-bit elements (80 B: conflict-free ds_read_b128)
-constexpr int DW_ROWS = H3 + H2 + H2 + H1;  // Z3 | E2 | Z2 | E1
-constexpr int DW_TILE_BYTES = DW_ROWS * 2 * DW_LD * 2;  // 97,280
-constexpr int DW_TLD = 36;  // row stride (floats) of the dagg^T / a^T tiles: 32 would put every row on the same banks
-constexpr int DW_LDS_BYTES = DW_TILE_BYTES + H3 * DW_TLD * 4 + H1 * DW_TLD * 4 + H1 * 4 + T3 * 16 * 8;  // + dagg^T + a^T + c_j + sign words
+// Weight gradients of fe.net.1 / fe.net.2:  dW3 = sum_e dZ3 E2^T,  dW2 = sum_e dZ2 E1^T  (+ bias sums).
+// The contraction runs over edges = (receiver, sender): per block (32 receivers of one jet, one sender) the
+// four operand tensors are needed as [feature][receiver], but the backward (and any rebuild) naturally
+// produces [receiver][8 features] pieces.  So the block's operands are laid down in LDS as plain
+// [receiver][feature] bf16 images and the MFMA fragments are fetched with gfx950's transposing LDS read
+// (ds_read_b64_tr_b16: a 16-lane group reads 4 receivers x 16 features and each lane receives one feature's
+// 4 receivers).  Row strides are odd multiples of 64 B, which makes those reads bank-conflict free.
+//
+// A workgroup is 8 waves on 4 SIMDs: waves 0-3 are CONSUMERS (each owns 10-12 of the 45 output tiles in
+// registers and only issues LDS reads + MFMAs), waves 4-7 are BUILDERS (VALU only: copy the staged dZ2, convert
+// the staged E2 from fp16 to bf16 hi/lo, rebuild dZ3 from dagg and the sign words and E1 from a_i + c_j, sum
+// the biases).  The images are double buffered (2 x 80 KiB = all of the LDS): builders fill block n+1 while
+// consumers multiply block n, one barrier per block.  Every builder thread owns fixed (receiver, feature
+// chunk) pieces, keeps what it needs of dagg / a in registers and reloads each staged piece for the block
+// after next right after using it, so no builder ever waits on another.
+constexpr int DW_RS3 = 448, DW_RS2 = 320, DW_RS1 = 192;  // image row strides (bytes)
+constexpr int DW_Z3H = 0, DW_Z3L = DW_Z3H + 32 * DW_RS3, DW_E2H = DW_Z3L + 32 * DW_RS3, DW_E2L = DW_E2H + 32 * DW_RS2,
+              DW_Z2H = DW_E2L + 32 * DW_RS2, DW_Z2L = DW_Z2H + 32 * DW_RS2, DW_E1H = DW_Z2L + 32 * DW_RS2,
+              DW_E1L = DW_E1H + 32 * DW_RS1, DW_BUF = DW_E1L + 32 * DW_RS1;
+constexpr int DW_LDS_BYTES = 2 * DW_BUF;  // 163,840
+static_assert(DW_LDS_BYTES <= 163840, "dW images must fit the LDS twice");
 
 struct DwTile { int prod, m, n; };  // prod 0: dW3 (A = Z3 tile m, B = E2 tile n); 1: dW2 (A = Z2, B = E1)
+// consumer wave w owns tiles [0,12) [12,23) [23,34) [34,45)
 __device__ constexpr DwTile DW_TILES[45] = {
     {0,0,0},{0,0,1},{0,0,2},{0,0,3},{0,0,4},{0,1,0},{0,1,1},{0,1,2},{0,1,3},{0,1,4},{1,0,0},{1,0,1},
-    {0,2,0},{0,2,1},{0,2,2},{0,2,3},{0,2,4},{0,3,0},{0,3,1},{0,3,2},{0,3,3},{0,3,4},{1,0,2},{1,1,0},
-    {0,4,0},{0,4,1},{0,4,2},{0,4,3},{0,4,4},{1,1,1},{1,1,2},{1,2,0},{1,2,1},{1,2,2},{1,3,0},
-    {0,5,0},{0,5,1},{0,5,2},{0,5,3},{0,5,4},{1,3,1},{1,3,2},{1,4,0},{1,4,1},{1,4,2}};
+    {0,2,0},{0,2,1},{0,2,2},{0,2,3},{0,2,4},{0,3,0},{0,3,1},{0,3,2},{0,3,3},{0,3,4},{1,0,2},
+    {0,4,0},{0,4,1},{0,4,2},{0,4,3},{0,4,4},{0,5,0},{0,5,1},{0,5,2},{0,5,3},{0,5,4},{1,1,0},
+    {1,1,1},{1,1,2},{1,2,0},{1,2,1},{1,2,2},{1,3,0},{1,3,1},{1,3,2},{1,4,0},{1,4,1},{1,4,2}};
+
+constexpr bool dw_same_rows(int t, int u) { return DW_TILES[t].prod == DW_TILES[u].prod && DW_TILES[t].m == DW_TILES[u].m; }
+constexpr bool dw_leader(int t, int begin) { return t == begin || !dw_same_rows(t, t - 1); }
+constexpr int dw_group_end(int t, int end) {
+    int e = t + 1;
+    while (e < end && dw_same_rows(t, e)) ++e;
+    return e;
+}
 
 MPG_DEV int feat_of_fi(int fi) {  // fragment-order index -> feature
     const int ms = fi >> 4, hh = (fi >> 3) & 1, jj = fi & 7;
     return 32 * (ms >> 1) + 16 * (ms & 1) + 8 * (jj >> 2) + 4 * hh + (jj & 3);
 }
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+// fragment (32 features starting at byte column `col`, receivers 16s .. 16s+15) of an image: two transposed reads
+MPG_DEV bf16x8 dw_frag(uint32_t lane_addr, int off, int rs) {
+    typedef __attribute__((address_space(3))) s16x4* P;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((P)(lane_addr + (uint32_t)off));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((P)(lane_addr + (uint32_t)(off + 4 * rs)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 template <int BEGIN, int END>
-MPG_DEV void dw_mfma(f32x16* acc, const __bf16* tiles, int lane) {
-    const int rr = lane & 31, hh = lane >> 5;
-    const __bf16* Z3h = tiles;                          // plane order: hi rows then lo rows per tensor
-    const __bf16* Z3l = Z3h + H3 * DW_LD;
-    const __bf16* E2h = Z3l + H3 * DW_LD;
-    const __bf16* E2l = E2h + H2 * DW_LD;
-    const __bf16* Z2h = E2l + H2 * DW_LD;
-    const __bf16* Z2l = Z2h + H2 * DW_LD;
-    const __bf16* E1h = Z2l + H2 * DW_LD;
-    const __bf16* E1l = E1h + H1 * DW_LD;
+MPG_DEV void dw_consume(f32x16* acc, uint32_t buf, int lane) {
+    // lane 4q+p of 16-lane group g supplies row (8 (g>>1) + q), feature columns 16 (g&1) + 4p .. +3 of the block
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int row = 8 * (g >> 1) + q, col = (16 * (g & 1) + 4 * pp) * 2;
+    // one opaque base per image family, everything else is an immediate offset
+    uint32_t bz3 = buf + DW_Z3H + row * DW_RS3 + col, be2 = buf + DW_E2H + row * DW_RS2 + col;
+    uint32_t bz2 = buf + DW_Z2H + row * DW_RS2 + col, be1 = buf + DW_E1H + row * DW_RS1 + col;
+    asm volatile("" : "+v"(bz3), "+v"(be2), "+v"(bz2), "+v"(be1));
+    // tiles sharing their A rows (same product and m) form a group: per k-step the A fragments are read once
+    // and only the B fragments change -- 8 + 8 fragment registers live beside the 160-192 accumulators
+    static_for<BEGIN, END>([&](auto tc) {
+        MPG_CI(t, tc);
+        if constexpr (dw_leader(t, BEGIN)) {
+            constexpr DwTile d = DW_TILES[t];
+            constexpr int ge = dw_group_end(t, END);
+            constexpr int rsa = d.prod == 0 ? DW_RS3 : DW_RS2, rsb = d.prod == 0 ? DW_RS2 : DW_RS1;
+            constexpr int alo = d.prod == 0 ? DW_Z3L - DW_Z3H : DW_Z2L - DW_Z2H, blo = d.prod == 0 ? DW_E2L - DW_E2H : DW_E1L - DW_E1H;
+            uint32_t ba = d.prod == 0 ? bz3 : bz2, bb = d.prod == 0 ? be2 : be1;
+            // a fresh (opaque) base per group: otherwise the B fragments of a whole product (80 registers) are kept
+            // for the next group and the accumulators spill
+            asm volatile("" : "+v"(ba), "+v"(bb));
 #pragma unroll
-    for (int t = BEGIN; t < END; ++t) {
-        const DwTile d = DW_TILES[t];
-        const __bf16* Ah = d.prod == 0 ? Z3h : Z2h;
-        const __bf16* Al = d.prod == 0 ? Z3l : Z2l;
-        const __bf16* Bh = d.prod == 0 ? E2h : E1h;
-        const __bf16* Bl = d.prod == 0 ? E2l : E1l;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int ao = (32 * d.m + rr) * DW_LD + 16 * s + 8 * hh;
-            const int bo = (32 * d.n + rr) * DW_LD + 16 * s + 8 * hh;
-            acc[t - BEGIN] = mfma3(*reinterpret_cast<const bf16x8*>(Ah + ao), *reinterpret_cast<const bf16x8*>(Al + ao),
-                                   *reinterpret_cast<const bf16x8*>(Bh + bo), *reinterpret_cast<const bf16x8*>(Bl + bo),
-                                   acc[t - BEGIN]);
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 ah = dw_frag(ba, 16 * s * rsa + 64 * d.m, rsa), al = dw_frag(ba, alo + 16 * s * rsa + 64 * d.m, rsa);
+                static_for<t, ge>([&](auto uc) {
+                    MPG_CI(u, uc);
+                    constexpr int n = DW_TILES[u].n;
+                    const bf16x8 bh = dw_frag(bb, 16 * s * rsb + 64 * n, rsb), bl = dw_frag(bb, blo + 16 * s * rsb + 64 * n, rsb);
+                    acc[u - BEGIN] = mfma3(ah, al, bh, bl, acc[u - BEGIN]);
+                });
+            }
         }
-    }
+    });
 }
 
 template <int BEGIN, int END>
@@ -407,210 +445,285 @@ MPG_DEV void dw_store(const f32x16* acc, float* part3, float* part2, int lane) {
     }
 }
 
-// The whole per-workgroup loop is instantiated once per wave role (BEGIN..END = that wave's output
-// tiles): a run-time branch per block around the MFMA section would make the accumulators merge at
-// every join (hundreds of register moves and scratch spills).
-//
-// Build phase: work units are (tile row, piece of 8 receivers) = one 16-byte LDS write.  The staged
-// dZ2 / E2 planes of block n+1 are requested into registers before the MFMAs of block n are issued
-// (one workgroup per CU: nothing else would hide the HBM latency) and written to LDS afterwards.
-constexpr int DW_PIECES = H2 * 4;  // (row, piece) units of one 160-row plane
+// A workgroup walks at most 64 blocks (the launcher sizes the grid for that); their valid-sender bits are one
+// ballot taken at kernel start, so stepping to the next unmasked block is pure scalar arithmetic -- no memory
+// access and no loop inside the pipelined loops (either would make the compiler drain vmcnt there).
+MPG_DEV unsigned long long dw_valid_bits(const MpgEdgeDw& p, int blk0, int blk1) {
+    const int RB = (p.N + 31) / 32, x = blk0 + (int)(threadIdx.x & 63);
+    bool ok = x < blk1;
+    if (ok && p.mask != nullptr) ok = p.mask[((x / p.N) / RB) * p.N + x % p.N] != 0.f;
+    return __ballot(ok);
+}
+MPG_DEV int dw_next_valid(unsigned long long bits, int blk0, int blk, int blk1) {
+    const int d = blk - blk0;
+    const unsigned long long rem = d < 64 ? bits >> d : 0ull;
+    return rem ? blk + __builtin_ctzll(rem) : blk1;
+}
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL load
+// (vmcnt(0)), which would expose the latency of the staged pieces requested a block ahead.
+MPG_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int DROP, bool F16, int BEGIN, int END>
-MPG_DEV void edge_dw_body(const MpgEdgeDw& p, char* smem, const int w) {
-    typedef typename FragT<F16>::type E2V;
-    __bf16* tiles = reinterpret_cast<__bf16*>(smem);
-    __bf16* Z3h = tiles;
-    __bf16* Z3l = Z3h + H3 * DW_LD;
-    __bf16* E2h = Z3l + H3 * DW_LD;
-    __bf16* E2l = E2h + H2 * DW_LD;
-    __bf16* Z2h = E2l + H2 * DW_LD;
-    __bf16* Z2l = Z2h + H2 * DW_LD;
-    __bf16* E1h = Z2l + H2 * DW_LD;
-    __bf16* E1l = E1h + H1 * DW_LD;
-    float* dgT = reinterpret_cast<float*>(smem + DW_TILE_BYTES);  // [feature][32]
-    float* aT = dgT + H3 * DW_TLD;                                // [feature][32 (+4 pad)]
-    float* cj = aT + H1 * DW_TLD;                                 // [feature]
-    uint32_t* lsg = reinterpret_cast<uint32_t*>(cj + H1);  // [3][64] sign words of the block
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int RB = (p.N + 31) / 32;
-    const int nblk = p.B * RB * p.N;
-    const int per = (nblk + gridDim.x - 1) / gridDim.x;
-    const int blk0 = blockIdx.x * per, blk1 = min(nblk, blk0 + per);
-
-    uint32_t seed_lo = 0, seed_hi = 0;
-    if (DROP) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
-
+// The per-workgroup loop of one consumer wave (its output tiles BEGIN..END of DW_TILES).  Instantiated per
+// role: a run-time branch around the MFMA section would make the accumulators merge at every join.
+template <int BEGIN, int END>
+MPG_DEV void dw_consumer(const MpgEdgeDw& p, int blk0, int blk1, unsigned long long vbits) {
+    const int lane = threadIdx.x & 63;
     f32x16 acc[END - BEGIN];
 #pragma unroll
     for (int t = 0; t < END - BEGIN; ++t)
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
-    float db3[3] = {0.f, 0.f, 0.f}, db2[3] = {0.f, 0.f, 0.f};  // unit n of this thread: row (tid>>2) + 64 n
-
-    // staged planes of one block, as this thread's 16-byte pieces
-    bf16x8 pz[5];      // dZ2: piece id = tid + 256 n over [part][row][pc]
-    E2V peh[3], pel[3];  // E2: (row, pc) id = tid + 256 n, hi and lo planes
-    auto prefetch = [&](int blk) {
-        const bf16x8* sZ = reinterpret_cast<const bf16x8*>(p.stageZ2) + (size_t)blk * 2 * DW_PIECES;
-        const E2V* sE = reinterpret_cast<const E2V*>(p.stageE2) + (size_t)blk * 2 * DW_PIECES;
-#pragma unroll
-        for (int n = 0; n < 5; ++n) pz[n] = sZ[tid + 256 * n];
-#pragma unroll
-        for (int n = 0; n < 3; ++n) {
-            const int id = tid + 256 * n;
-            if (id < DW_PIECES) { peh[n] = sE[id]; pel[n] = sE[DW_PIECES + id]; }
-        }
-    };
-    if (blk0 < blk1) prefetch(blk0);
-
-    int cur_brb = -1;
-    for (int blk = blk0; blk < blk1; ++blk) {
-        const int j = blk % p.N, brb = blk / p.N, rb = brb % RB, b = brb / RB;
-        __syncthreads();  // previous block's MFMAs are done with the tiles
-        if (brb != cur_brb) {  // new (jet, receiver block): refresh dagg^T and a^T
-            cur_brb = brb;
-            for (int t = tid; t < H3 * 32; t += 256) {
-                const int f = t >> 5, ii = rb * 32 + (t & 31);
-                dgT[f * DW_TLD + (t & 31)] = ii < p.N ? p.dagg[(size_t)(b * p.N + ii) * p.ld_dagg + f] * p.agg_scale : 0.f;
-            }
-            for (int t = tid; t < H1 * 32; t += 256) {
-                const int f = t >> 5, ii = rb * 32 + (t & 31);
-                aT[f * DW_TLD + (t & 31)] = ii < p.N ? p.a[(size_t)(b * p.N + ii) * H1 + f] : 0.f;
-            }
-        }
-        if (tid < H1) cj[tid] = p.c[(size_t)(b * p.N + j) * H1 + tid];
-        if (tid >= 64) lsg[tid - 64] = p.sign3[(size_t)blk * (T3 * 32) + tid - 64];
-        // staged dZ2 pieces -> tile (bf16 planes as they are); bias sums
-#pragma unroll
-        for (int n = 0; n < 5; ++n) {
-            const int id = tid + 256 * n, part = id / DW_PIECES, row = (id % DW_PIECES) >> 2, pc = id & 3;
-            *reinterpret_cast<bf16x8*>((part ? Z2l : Z2h) + row * DW_LD + 8 * pc) = pz[n];
-        }
-        // staged E2 pieces (fp16 or bf16 hi/lo) -> bf16 hi/lo
-#pragma unroll
-        for (int n = 0; n < 3; ++n) {
-            const int id = tid + 256 * n;
-            if (id < DW_PIECES) {
-                float v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = (float)peh[n][k] + (float)pel[n][k];
-                bf16x8 hh, ll;
-                split8(v, hh, ll);
-                *reinterpret_cast<bf16x8*>(E2h + (id >> 2) * DW_LD + 8 * (id & 3)) = hh;
-                *reinterpret_cast<bf16x8*>(E2l + (id >> 2) * DW_LD + 8 * (id & 3)) = ll;
-            }
-        }
-        __syncthreads();  // dgT / aT / cj / lsg visible
-        const float mj = p.mask ? p.mask[b * p.N + j] : 1.f;
-        const float mjs = mj * p.dscale;
-        // db2 from the dZ2 tile rows just written by this thread's own pieces is done below via LDS
-        // dZ3 units: 192 rows x 4 pieces = 768 -> 3 per thread
-#pragma unroll
-        for (int n = 0; n < 3; ++n) {
-            const int id = tid + 256 * n, fi = id >> 2, pc = id & 3;
-            const int f = feat_of_fi(fi);
-            const int m = f >> 5, fl = f & 31;
-            const int reg = 4 * (fl >> 3) + (fl & 3), hb = (fl >> 2) & 1;
-            // the 8 receivers of this piece are lanes 32 hb + 8 pc + k; each holds the bit at the same position
-            const int sh = 31 - (16 * (m & 1) + reg);
-            const uint4 w0 = *reinterpret_cast<const uint4*>(lsg + (m >> 1) * 64 + 32 * hb + 8 * pc);
-            const uint4 w1 = *reinterpret_cast<const uint4*>(lsg + (m >> 1) * 64 + 32 * hb + 8 * pc + 4);
-            const uint32_t ws[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-            float v[8];
-            float s = 0.f;
-            const float4 d0 = *reinterpret_cast<const float4*>(dgT + f * DW_TLD + 8 * pc);
-            const float4 d1 = *reinterpret_cast<const float4*>(dgT + f * DW_TLD + 8 * pc + 4);
-            const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int rcv = 8 * pc + k, ii = rb * 32 + rcv;
-                float gt = ((ws[k] >> sh) & 1u) ? p.alpha : 1.f;
-                if (DROP) {
-                    const uint32_t erow = (uint32_t)((b * p.N + ii) * p.N + j);
-                    if (!drop_keep_f(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, f, p.thr)) gt = 0.f;
-                }
-                const float x = ii < p.N ? mjs * dd[k] * gt : 0.f;
-                v[k] = x;
-                s += x;
-            }
-            db3[n] += s;
-            bf16x8 hh, ll;
-            split8(v, hh, ll);
-            *reinterpret_cast<bf16x8*>(Z3h + fi * DW_LD + 8 * pc) = hh;
-            *reinterpret_cast<bf16x8*>(Z3l + fi * DW_LD + 8 * pc) = ll;
-        }
-        // E1 units: 96 rows x 4 pieces = 384
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int id = tid + 256 * n;
-            if (id < H1 * 4) {
-                const int fi = id >> 2, pc = id & 3;
-                const int f = feat_of_fi(fi);
-                float v[8];
-                const float4 a0 = *reinterpret_cast<const float4*>(aT + f * DW_TLD + 8 * pc);
-                const float4 a1 = *reinterpret_cast<const float4*>(aT + f * DW_TLD + 8 * pc + 4);
-                const float aa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int rcv = 8 * pc + k, ii = rb * 32 + rcv;
-                    float x = lrelu(aa[k] + cj[f], p.alpha);
-                    if (DROP) {
-                        const uint32_t erow = (uint32_t)((b * p.N + ii) * p.N + j);
-                        if (!drop_keep_f(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, f, p.thr)) x = 0.f;
-                    }
-                    v[k] = x;
-                }
-                bf16x8 hh, ll;
-                split8(v, hh, ll);
-                *reinterpret_cast<bf16x8*>(E1h + fi * DW_LD + 8 * pc) = hh;
-                *reinterpret_cast<bf16x8*>(E1l + fi * DW_LD + 8 * pc) = ll;
-            }
-        }
-        // db2: this thread's dZ2 pieces (hi + lo planes hold the same rows at n and n + 2.5 -> sum both)
-#pragma unroll
-        for (int n = 0; n < 3; ++n) {
-            const int id = tid + 256 * n;
-            if (id < DW_PIECES) {
-                const bf16x8 zh = *reinterpret_cast<const bf16x8*>(Z2h + (id >> 2) * DW_LD + 8 * (id & 3));
-                const bf16x8 zl = *reinterpret_cast<const bf16x8*>(Z2l + (id >> 2) * DW_LD + 8 * (id & 3));
-                float s = 0.f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) s += (float)zh[k] + (float)zl[k];
-                db2[n] += s;
-            }
-        }
-        __syncthreads();
-        if (blk + 1 < blk1) prefetch(blk + 1);
-        dw_mfma<BEGIN, END>(acc, tiles, lane);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    int cur = dw_next_valid(vbits, blk0, blk0, blk1), it = 0;
+    lds_barrier();  // block `cur` is in buffer 0
+    while (cur < blk1) {
+        dw_consume<BEGIN, END>(acc, lds0 + (it & 1) * DW_BUF, lane);
+        lds_barrier();
+        cur = dw_next_valid(vbits, blk0, cur + 1, blk1);
+        ++it;
     }
-
-    // ---- per-workgroup partials (fragment-order indices; edge_dw_reduce undoes the permutation)
     float* part = p.part + (size_t)blockIdx.x * (H3 * H2 + H2 * H1 + H3 + H2);
-    float* part3 = part, *part2 = part + H3 * H2, *pb3 = part2 + H2 * H1, *pb2 = pb3 + H3;
-    dw_store<BEGIN, END>(acc, part3, part2, lane);
-    // bias sums: add the 4 pieces of a row (4 adjacent threads)
+    dw_store<BEGIN, END>(acc, part, part + H3 * H2, lane);
+}
+
+// keep bits (bit k = element k) of one 8-feature chunk: features 32 tile + f0 + {0..3, 8..11} of edge row `erow`
+template <int DM>
+MPG_DEV uint32_t dw_chunk_keep(uint32_t seed_lo, uint32_t seed_hi, uint32_t tag, uint32_t erow, int tile, int f0, uint32_t thr) {
+    if constexpr (DM == 2) {
+        const uint32_t w = drop_word(seed_lo, seed_hi, tag, erow, DROP_BIT_GRP + (uint32_t)tile) >> f0;
+        return (w & 0xfu) | ((w >> 4) & 0xf0u);  // bits f0..f0+3 and f0+8..f0+11
+    } else if constexpr (DM == 1) {
+        uint32_t m = 0;
 #pragma unroll
-    for (int n = 0; n < 3; ++n) {
-        float x = db3[n], y = db2[n];
-        x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64);
-        y += __shfl_xor(y, 1, 64); y += __shfl_xor(y, 2, 64);
-        const int row = (tid >> 2) + 64 * n;
-        if ((tid & 3) == 0) {
-            pb3[row] = x;
-            if (row < H2) pb2[row] = y;
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t w = drop_word(seed_lo, seed_hi, tag, erow, (uint32_t)(8 * tile + (f0 >> 2) + 2 * u));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) m |= (drop_keep(w, t, thr) ? 1u : 0u) << (4 * u + t);
         }
+        return m;
+    } else {
+        return 0xffu;
     }
 }
 
 template <int DROP, bool F16>
-__global__ __launch_bounds__(256, 1) void edge_dw_kernel(const MpgEdgeDw p) {
+MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsigned long long vbits) {
+    typedef typename FragT<F16>::type E2V;
+    const int bt = threadIdx.x - 256;     // builder thread 0..255
+    const int r = bt & 31, cg = bt >> 5;  // receiver row of the images, chunk group: chunks cg, cg + 8, cg + 16
+    const int RB = (p.N + 31) / 32;
+    // chunk c = 2 frag + h holds fragment-order features 8c .. 8c+7 = registers 8s .. 8s+7 of tile (c >> 2) of
+    // lane (r, h):  s = (c >> 1) & 1 and h = c & 1 are the same for all chunks of this thread
+    const int cs = (cg >> 1) & 1, ch = cg & 1;
+    const int f0 = 16 * cs + 4 * ch;  // features of chunk c: 32 (c >> 2) + f0 + {0..3, 8..11}
+
+    uint32_t seed_lo = 0, seed_hi = 0;
+    if (DROP) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+
+    float dreg[3][8], areg[2][8];   // dagg (x agg_scale x dscale) / a of this thread's Z3 / E1 chunks, current jet
+    float db3[3][8], db2[3][8];
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { db3[n][k] = 0.f; db2[n][k] = 0.f; }
+    uint32_t sw[3];                 // sign words of the Z3 chunks' lanes
+    float4 cv[2][2];                // c_j of the E1 chunks
+    E2V eh[3], el[3];               // staged E2 pieces (hi, lo)
+    bf16x8 zh[3], zl[3];            // staged dZ2 pieces
+
+    const bool third = cg < 4;  // chunk groups 0..3 own a third 160-feature piece and a second E1 chunk
+    auto e1tile = [&](int n) { return n == 0 || third ? 2 * n + (cg >> 2) : (cg >> 2); };  // 0..2
+    // Threads of chunk groups 4..7 have no third piece of the 160-feature tensors (and no second E1 chunk): they
+    // redo their previous piece instead (same data to the same place), which keeps the whole build free of
+    // branches -- inside a branch the compiler waits for ALL outstanding loads, i.e. for the prefetches too.
+    auto chunk160 = [&](int n) { return n < 2 || third ? cg + 8 * n : cg + 8; };
+
+    // Every global read is a raw buffer load: resource in SGPRs, block-dependent part as scalar offset, one
+    // thread-constant VGPR offset per stream (plain pointers cost two VGPRs of address per load in flight).
+    const int nblk = p.B * RB * p.N;
+    const __amdgpu_buffer_rsrc_t rE = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.stageE2), 0, nblk * (2 * NFR2 * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.stageZ2), 0, nblk * (2 * NFR2 * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int*>(p.sign3), 0, nblk * (T3 * 32 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.c), 0, p.B * p.N * H1 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.B * p.N * H1 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dagg), 0, p.B * p.N * p.ld_dagg * 4, 0x00020000);
+    int vo160[3];  // byte offset of this thread's piece n inside a 10 KiB plane
+#pragma unroll
+    for (int n = 0; n < 3; ++n) vo160[n] = (chunk160(n) * 32 + r) * 16;
+    const int voS = (32 * ch + r) * 4;
+    int voE1[2];   // byte offset of E1 chunk n's first feature inside a 96-float row of a / c
+#pragma unroll
+    for (int n = 0; n < 2; ++n) voE1[n] = (32 * e1tile(n) + f0) * 4;
+    auto ldb4 = [&](__amdgpu_buffer_rsrc_t rs, int vo, int so) {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
+    };
+
+    auto load_jet = [&](int blk) {
+        const int brb = blk / p.N, rb = brb % RB, b = brb / RB, ii = rb * 32 + r;
+        const bool ok = ii < p.N;
+        const float sc = p.agg_scale * p.dscale;
+        const int rowD = (ok ? ii : 0) * p.ld_dagg * 4 + (32 * (cg >> 2) + f0) * 4, soD = b * p.N * p.ld_dagg * 4;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const float4 u = ldb4(rD, rowD + 256 * n, soD), v = ldb4(rD, rowD + 256 * n + 32, soD);
+            const float t8[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dreg[n][k] = ok ? t8[k] * sc : 0.f;
+        }
+        const int rowA = (ok ? ii : 0) * H1 * 4, soA = b * p.N * H1 * 4;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const float4 u = ldb4(rA, rowA + voE1[n], soA), v = ldb4(rA, rowA + voE1[n] + 32, soA);
+            const float t8[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) areg[n][k] = ok ? t8[k] : 0.f;
+        }
+    };
+    auto load_sw = [&](int blk) {  // word (tile >> 1) = n of lane (r, h)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) sw[n] = __builtin_amdgcn_raw_buffer_load_b32(rS, voS, blk * (T3 * 32 * 4) + n * 256, 0);
+    };
+    auto load_c = [&](int blk) {
+        const int j = blk % p.N, b = (blk / p.N) / RB, so = (b * p.N + j) * H1 * 4;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) { cv[n][0] = ldb4(rC, voE1[n], so); cv[n][1] = ldb4(rC, voE1[n] + 32, so); }
+    };
+    // staged pieces: chunk c of receiver r is element c * 32 + r of a plane of 640 16-byte pieces
+    auto load_e2 = [&](int blk, int n) {
+        eh[n] = __builtin_bit_cast(E2V, __builtin_amdgcn_raw_buffer_load_b128(rE, vo160[n], blk * (2 * NFR2 * 1024), 0));
+        el[n] = __builtin_bit_cast(E2V, __builtin_amdgcn_raw_buffer_load_b128(rE, vo160[n], blk * (2 * NFR2 * 1024) + NFR2 * 1024, 0));
+    };
+    auto load_z2 = [&](int blk, int n) {
+        zh[n] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rZ, vo160[n], blk * (2 * NFR2 * 1024), 0));
+        zl[n] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rZ, vo160[n], blk * (2 * NFR2 * 1024) + NFR2 * 1024, 0));
+    };
+
+    // build block `blk` into buffer `buf`; right after a staged piece is used, request the one of `pre`
+    auto build = [&](int blk, char* buf, int pre) {
+        const int j = blk % p.N, brb = blk / p.N, rb = brb % RB, b = brb / RB, ii = rb * 32 + r;
+        const uint32_t erow = (uint32_t)((b * p.N + ii) * p.N + j);
+        // dZ2: copy, bias sums
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const int c = chunk160(n);
+            *reinterpret_cast<bf16x8*>(buf + DW_Z2H + r * DW_RS2 + c * 16) = zh[n];
+            *reinterpret_cast<bf16x8*>(buf + DW_Z2L + r * DW_RS2 + c * 16) = zl[n];
+            const float take = n < 2 || third ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) db2[n][k] += take * ((float)zh[n][k] + (float)zl[n][k]);
+            load_z2(pre, n);
+        }
+        // E2: staged fp16 (or bf16) hi/lo -> bf16 hi/lo
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const int c = chunk160(n);
+            bf16x8 hh, ll;
+            if constexpr (F16) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (float)eh[n][k] + (float)el[n][k];
+                split8(v, hh, ll);
+            } else {
+                hh = eh[n]; ll = el[n];
+            }
+            *reinterpret_cast<bf16x8*>(buf + DW_E2H + r * DW_RS2 + c * 16) = hh;
+            *reinterpret_cast<bf16x8*>(buf + DW_E2L + r * DW_RS2 + c * 16) = ll;
+            load_e2(pre, n);
+        }
+        // dZ3 = dagg * slope(sign bit) * keep3
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const int m = 2 * n + (cg >> 2), c = cg + 8 * n;
+            float v[8];
+            const uint32_t keep = dw_chunk_keep<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, m, f0, p.thr);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t neg = (sw[n] >> (31 - (16 * (m & 1) + 8 * cs + k))) & 1u;
+                float x = neg ? dreg[n][k] * p.alpha : dreg[n][k];
+                if (DROP && !((keep >> k) & 1u)) x = 0.f;
+                v[k] = x;
+                db3[n][k] += x;
+            }
+            bf16x8 hh, ll;
+            split8(v, hh, ll);
+            *reinterpret_cast<bf16x8*>(buf + DW_Z3H + r * DW_RS3 + c * 16) = hh;
+            *reinterpret_cast<bf16x8*>(buf + DW_Z3L + r * DW_RS3 + c * 16) = ll;
+        }
+        load_sw(pre);
+        // E1 = keep1 * lrelu(a_i + c_j)   (chunk groups 4..7: the second chunk repeats the first)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int q = e1tile(n), c = 4 * q + (cg & 3);
+            const float cc[8] = {cv[n][0].x, cv[n][0].y, cv[n][0].z, cv[n][0].w, cv[n][1].x, cv[n][1].y, cv[n][1].z, cv[n][1].w};
+            float v[8];
+            const uint32_t keep = dw_chunk_keep<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, q, f0, p.thr);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float x = lrelu(areg[n][k] + cc[k], p.alpha);
+                if (DROP && !((keep >> k) & 1u)) x = 0.f;
+                v[k] = x;
+            }
+            bf16x8 hh, ll;
+            split8(v, hh, ll);
+            *reinterpret_cast<bf16x8*>(buf + DW_E1H + r * DW_RS1 + c * 16) = hh;
+            *reinterpret_cast<bf16x8*>(buf + DW_E1L + r * DW_RS1 + c * 16) = ll;
+        }
+        load_c(pre);
+        load_jet(pre);
+    };
+
+    int cur = dw_next_valid(vbits, blk0, blk0, blk1), it = 0;
+    int nxt = dw_next_valid(vbits, blk0, cur + 1, blk1);
+    // `pre` is clamped to the last block of the range: past the end the prefetches fetch that block again, unused
+    if (cur < blk1) {
+        load_jet(cur); load_sw(cur); load_c(cur);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) { load_e2(cur, n); load_z2(cur, n); }
+        build(cur, smem, min(nxt, blk1 - 1));
+    }
+    lds_barrier();
+    while (cur < blk1) {
+        const int nxt2 = dw_next_valid(vbits, blk0, nxt + 1, blk1);
+        if (nxt < blk1) build(nxt, smem + ((it + 1) & 1) * DW_BUF, min(nxt2, blk1 - 1));
+        lds_barrier();
+        cur = nxt;
+        nxt = nxt2;
+        ++it;
+    }
+
+    // bias sums: add the 32 receivers (one half-wave per chunk group), fragment-order index fi = 8 c + k
+    float* part = p.part + (size_t)blockIdx.x * (H3 * H2 + H2 * H1 + H3 + H2);
+    float* pb3 = part + H3 * H2 + H2 * H1, *pb2 = pb3 + H3;
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float x = db3[n][k], y = db2[n][k];
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) { x += __shfl_xor(x, o, 64); y += __shfl_xor(y, o, 64); }
+            const int c = cg + 8 * n;
+            if (r == 0) {
+                pb3[8 * c + k] = x;
+                if (c < 2 * NFR2) pb2[8 * c + k] = y;  // (the repeated third piece added zeros)
+            }
+        }
+}
+
+template <int DROP, bool F16>
+__global__ __launch_bounds__(512, 1) void edge_dw_kernel(const MpgEdgeDw p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (w == 0) edge_dw_body<DROP, F16, 0, 12>(p, smem, w);
-    else if (w == 1) edge_dw_body<DROP, F16, 12, 24>(p, smem, w);
-    else if (w == 2) edge_dw_body<DROP, F16, 24, 35>(p, smem, w);
-    else edge_dw_body<DROP, F16, 35, 45>(p, smem, w);
+    const int RB = (p.N + 31) / 32;
+    const int nblk = p.B * RB * p.N;
+    const int per = (nblk + gridDim.x - 1) / gridDim.x;
+    const int blk0 = blockIdx.x * per, blk1 = min(nblk, blk0 + per);
+    const unsigned long long vbits = dw_valid_bits(p, blk0, blk1);
+    if (w == 0) dw_consumer<0, 12>(p, blk0, blk1, vbits);
+    else if (w == 1) dw_consumer<12, 23>(p, blk0, blk1, vbits);
+    else if (w == 2) dw_consumer<23, 34>(p, blk0, blk1, vbits);
+    else if (w == 3) dw_consumer<34, 45>(p, blk0, blk1, vbits);
+    else dw_builder<DROP, F16>(p, smem, blk0, blk1, vbits);
 }
 
 // out = scale * sum over workgroup partials, feature indices mapped back from fragment order.
@@ -679,9 +792,13 @@ extern "C" int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream) {
 
 extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
     if (p->B <= 0 || p->N <= 0 || p->nwg <= 0) return -1;
+    {
+        const int nblk = p->B * ((p->N + 31) / 32) * p->N;
+        if ((nblk + p->nwg - 1) / p->nwg > 64) return -5;  // a workgroup walks at most 64 blocks (one ballot of valid bits)
+    }
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(p->nwg), block(256);
-    const int dm = p->thr == 0 ? 0 : 1;  // per-element decisions: drop_keep_f picks the bit form itself
+    dim3 grid(p->nwg), block(512);
+    const int dm = p->thr == 0 ? 0 : (p->thr == 128 ? 2 : 1);
 #define MPG_DW_ONE(D, H)                                                                                          \
     do {                                                                                                          \
         static bool done = false;                                                                                 \
@@ -692,10 +809,11 @@ extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
         }                                                                                                         \
         hipLaunchKernelGGL((edge_dw_kernel<D, H>), grid, block, DW_LDS_BYTES, st, *p);                            \
     } while (0)
-    if (dm && p->f16) MPG_DW_ONE(1, true);
-    else if (dm) MPG_DW_ONE(1, false);
-    else if (p->f16) MPG_DW_ONE(0, true);
-    else MPG_DW_ONE(0, false);
+#define MPG_DW_H(D) do { if (p->f16) MPG_DW_ONE(D, true); else MPG_DW_ONE(D, false); } while (0)
+    if (dm == 0) MPG_DW_H(0);
+    else if (dm == 1) MPG_DW_H(1);
+    else MPG_DW_H(2);
+#undef MPG_DW_H
 #undef MPG_DW_ONE
     constexpr int PER = H3 * H2 + H2 * H1 + H3 + H2;
     hipLaunchKernelGGL(edge_dw_reduce, dim3((PER + 31) / 32), dim3(256), 0, st, p->part, p->nwg, p->dscale, p->dW3,

@@ -302,7 +302,7 @@ class FusedMPLayerFn(torch.autograd.Function):
         dc = dcp[0] if RB == 1 else dcp.sum(0)
         dW1 = db1 = dW2 = db2 = dW3 = db3 = None
         if need_w:
-            nwg = min(256, nblk)
+            nwg = min(nblk, max(256, -(-nblk // 64)))  # one workgroup per CU; at most 64 blocks each
             part = torch.empty((nwg, H3 * H2 + H2 * H1 + H3 + H2), device=dev, dtype=torch.float32)
             dW3, dW2 = torch.empty_like(W3), torch.empty_like(W2)
             db3, db2 = torch.empty_like(b3), torch.empty_like(b2)
