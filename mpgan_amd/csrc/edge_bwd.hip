@@ -15,6 +15,10 @@
 // kernel that also undoes the fragment-order permutation of the feature indices.
 #include "edge_common.h"
 
+#ifndef MPG_DW_EXP
+#define MPG_DW_EXP 0  // experiment bits (tools/ubench/dw_bench.hip): 1 consumers idle, 2 builders idle, 4 no staged loads, 8 no LDS writes
+#endif
+
 namespace {
 
 constexpr int NF3T = T2 * T3 * 2;  // W3^T image: 5 row tiles x 6 k-tiles x 2 = 60 fragments
@@ -478,7 +482,7 @@ MPG_DEV void dw_consumer(const MpgEdgeDw& p, int blk0, int blk1, unsigned long l
     int cur = dw_next_valid(vbits, blk0, blk0, blk1), it = 0;
     lds_barrier();  // block `cur` is in buffer 0
     while (cur < blk1) {
-        dw_consume<BEGIN, END>(acc, lds0 + (it & 1) * DW_BUF, lane);
+        if (!(MPG_DW_EXP & 1)) dw_consume<BEGIN, END>(acc, lds0 + (it & 1) * DW_BUF, lane);
         lds_barrier();
         cur = dw_next_valid(vbits, blk0, cur + 1, blk1);
         ++it;
@@ -521,7 +525,7 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsi
     uint32_t seed_lo = 0, seed_hi = 0;
     if (DROP) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
 
-    float dreg[3][8], areg[2][8];   // dagg (x agg_scale x dscale) / a of this thread's Z3 / E1 chunks, current jet
+    float dreg[3][8], areg[2][8];   // dagg / a of this thread's Z3 / E1 chunks, current jet (raw)
     float db3[3][8], db2[3][8];
 #pragma unroll
     for (int n = 0; n < 3; ++n)
@@ -559,25 +563,27 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsi
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
     };
 
+    // dagg / a of the (jet, receiver block) of block `blk`, RAW: nothing may be computed from a prefetched value
+    // before the block that needs it (a use right behind the load would make every iteration wait for its
+    // youngest load, i.e. drain the whole prefetch queue).  Padding receivers read row 0 and get scale 0.
+    float dscl = 0.f;  // agg_scale * dscale, or 0 for a padding receiver -- belongs to the jet in dreg
     auto load_jet = [&](int blk) {
         const int brb = blk / p.N, rb = brb % RB, b = brb / RB, ii = rb * 32 + r;
         const bool ok = ii < p.N;
-        const float sc = p.agg_scale * p.dscale;
+        dscl = ok ? p.agg_scale * p.dscale : 0.f;
         const int rowD = (ok ? ii : 0) * p.ld_dagg * 4 + (32 * (cg >> 2) + f0) * 4, soD = b * p.N * p.ld_dagg * 4;
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
             const float4 u = ldb4(rD, rowD + 256 * n, soD), v = ldb4(rD, rowD + 256 * n + 32, soD);
-            const float t8[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 8; ++k) dreg[n][k] = ok ? t8[k] * sc : 0.f;
+            dreg[n][0] = u.x; dreg[n][1] = u.y; dreg[n][2] = u.z; dreg[n][3] = u.w;
+            dreg[n][4] = v.x; dreg[n][5] = v.y; dreg[n][6] = v.z; dreg[n][7] = v.w;
         }
         const int rowA = (ok ? ii : 0) * H1 * 4, soA = b * p.N * H1 * 4;
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const float4 u = ldb4(rA, rowA + voE1[n], soA), v = ldb4(rA, rowA + voE1[n] + 32, soA);
-            const float t8[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 8; ++k) areg[n][k] = ok ? t8[k] : 0.f;
+            areg[n][0] = u.x; areg[n][1] = u.y; areg[n][2] = u.z; areg[n][3] = u.w;
+            areg[n][4] = v.x; areg[n][5] = v.y; areg[n][6] = v.z; areg[n][7] = v.w;
         }
     };
     auto load_sw = [&](int blk) {  // word (tile >> 1) = n of lane (r, h)
@@ -600,19 +606,23 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsi
     };
 
     // build block `blk` into buffer `buf`; right after a staged piece is used, request the one of `pre`
-    auto build = [&](int blk, char* buf, int pre) {
+    auto build = [&](int blk, char* buf, int pre_) {
+        const bool exp_noload = (MPG_DW_EXP & 4) && p.N != 12345, exp_nowrite = (MPG_DW_EXP & 8) && p.N != 12345;
+        const int pre = (MPG_DW_EXP & 16) ? blk0 : pre_;
         const int j = blk % p.N, brb = blk / p.N, rb = brb % RB, b = brb / RB, ii = rb * 32 + r;
         const uint32_t erow = (uint32_t)((b * p.N + ii) * p.N + j);
         // dZ2: copy, bias sums
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
             const int c = chunk160(n);
-            *reinterpret_cast<bf16x8*>(buf + DW_Z2H + r * DW_RS2 + c * 16) = zh[n];
-            *reinterpret_cast<bf16x8*>(buf + DW_Z2L + r * DW_RS2 + c * 16) = zl[n];
+            if (!exp_nowrite) {
+                *reinterpret_cast<bf16x8*>(buf + DW_Z2H + r * DW_RS2 + c * 16) = zh[n];
+                *reinterpret_cast<bf16x8*>(buf + DW_Z2L + r * DW_RS2 + c * 16) = zl[n];
+            }
             const float take = n < 2 || third ? 1.f : 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) db2[n][k] += take * ((float)zh[n][k] + (float)zl[n][k]);
-            load_z2(pre, n);
+            if (!exp_noload) load_z2(pre, n);
         }
         // E2: staged fp16 (or bf16) hi/lo -> bf16 hi/lo
 #pragma unroll
@@ -627,11 +637,14 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsi
             } else {
                 hh = eh[n]; ll = el[n];
             }
-            *reinterpret_cast<bf16x8*>(buf + DW_E2H + r * DW_RS2 + c * 16) = hh;
-            *reinterpret_cast<bf16x8*>(buf + DW_E2L + r * DW_RS2 + c * 16) = ll;
-            load_e2(pre, n);
+            if (!exp_nowrite) {
+                *reinterpret_cast<bf16x8*>(buf + DW_E2H + r * DW_RS2 + c * 16) = hh;
+                *reinterpret_cast<bf16x8*>(buf + DW_E2L + r * DW_RS2 + c * 16) = ll;
+            } else if (hh[0] == (__bf16)123.f) db2[0][0] += (float)ll[1];
+            if (!exp_noload) load_e2(pre, n);
         }
         // dZ3 = dagg * slope(sign bit) * keep3
+        const float dscl_1 = dscl, dscl_a = dscl * p.alpha;
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
             const int m = 2 * n + (cg >> 2), c = cg + 8 * n;
@@ -640,17 +653,19 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsi
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const uint32_t neg = (sw[n] >> (31 - (16 * (m & 1) + 8 * cs + k))) & 1u;
-                float x = neg ? dreg[n][k] * p.alpha : dreg[n][k];
+                float x = dreg[n][k] * (neg ? dscl_a : dscl_1);
                 if (DROP && !((keep >> k) & 1u)) x = 0.f;
                 v[k] = x;
                 db3[n][k] += x;
             }
             bf16x8 hh, ll;
             split8(v, hh, ll);
-            *reinterpret_cast<bf16x8*>(buf + DW_Z3H + r * DW_RS3 + c * 16) = hh;
-            *reinterpret_cast<bf16x8*>(buf + DW_Z3L + r * DW_RS3 + c * 16) = ll;
+            if (!exp_nowrite) {
+                *reinterpret_cast<bf16x8*>(buf + DW_Z3H + r * DW_RS3 + c * 16) = hh;
+                *reinterpret_cast<bf16x8*>(buf + DW_Z3L + r * DW_RS3 + c * 16) = ll;
+            } else if (hh[0] == (__bf16)123.f) db2[0][0] += (float)ll[1];
         }
-        load_sw(pre);
+        if (!exp_noload) load_sw(pre);
         // E1 = keep1 * lrelu(a_i + c_j)   (chunk groups 4..7: the second chunk repeats the first)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
@@ -666,11 +681,12 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsi
             }
             bf16x8 hh, ll;
             split8(v, hh, ll);
-            *reinterpret_cast<bf16x8*>(buf + DW_E1H + r * DW_RS1 + c * 16) = hh;
-            *reinterpret_cast<bf16x8*>(buf + DW_E1L + r * DW_RS1 + c * 16) = ll;
+            if (!exp_nowrite) {
+                *reinterpret_cast<bf16x8*>(buf + DW_E1H + r * DW_RS1 + c * 16) = hh;
+                *reinterpret_cast<bf16x8*>(buf + DW_E1L + r * DW_RS1 + c * 16) = ll;
+            } else if (hh[0] == (__bf16)123.f) db2[0][0] += (float)ll[1];
         }
-        load_c(pre);
-        load_jet(pre);
+        if (!exp_noload) { load_c(pre); load_jet(pre); }
     };
 
     int cur = dw_next_valid(vbits, blk0, blk0, blk1), it = 0;
@@ -685,7 +701,7 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsi
     lds_barrier();
     while (cur < blk1) {
         const int nxt2 = dw_next_valid(vbits, blk0, nxt + 1, blk1);
-        if (nxt < blk1) build(nxt, smem + ((it + 1) & 1) * DW_BUF, min(nxt2, blk1 - 1));
+        if (nxt < blk1 && !(MPG_DW_EXP & 2)) build(nxt, smem + ((it + 1) & 1) * DW_BUF, min(nxt2, blk1 - 1));
         lds_barrier();
         cur = nxt;
         nxt = nxt2;
@@ -781,9 +797,13 @@ extern "C" int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream) {
     do { if (needw) MPG_BWD_ONE(D, H, true); else MPG_BWD_ONE(D, H, false); } while (0)
 #define MPG_BWD_H(D)                                                                                              \
     do { if (p->f16) MPG_BWD_W(D, true); else MPG_BWD_W(D, false); } while (0)
+#ifdef MPG_SINGLE_VARIANT
+    MPG_BWD_W(MPG_SINGLE_VARIANT, true);
+#else
     if (dm == 0) MPG_BWD_H(0);
     else if (dm == 1) MPG_BWD_H(1);
     else MPG_BWD_H(2);
+#endif
 #undef MPG_BWD_H
 #undef MPG_BWD_W
 #undef MPG_BWD_ONE
@@ -810,9 +830,13 @@ extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
         hipLaunchKernelGGL((edge_dw_kernel<D, H>), grid, block, DW_LDS_BYTES, st, *p);                            \
     } while (0)
 #define MPG_DW_H(D) do { if (p->f16) MPG_DW_ONE(D, true); else MPG_DW_ONE(D, false); } while (0)
+#ifdef MPG_SINGLE_VARIANT  // tools/ubench/dw_bench.hip: one instantiation
+    MPG_DW_ONE(MPG_SINGLE_VARIANT, true);
+#else
     if (dm == 0) MPG_DW_H(0);
     else if (dm == 1) MPG_DW_H(1);
     else MPG_DW_H(2);
+#endif
 #undef MPG_DW_H
 #undef MPG_DW_ONE
     constexpr int PER = H3 * H2 + H2 * H1 + H3 + H2;
