@@ -75,6 +75,48 @@ int mpg_dropout_mask(float* out, uint64_t rows, int F, const uint64_t* seed, uin
 int mpg_pack_weights(const float* W, int ldw, int rows, int cols, int transpose, float scale, int f16,
                      void* img, void* stream);
 
+/* mpg_pack_many: up to MPG_PACK_MAX_JOBS images in one launch (all images of a layer after an optimizer step).
+ * rows/cols are those of the PACKED matrix, which is W (transpose = 0) or W^T (transpose = 1).  row_split > 0
+ * reads a stacked view of W: logical row n of the un-transposed matrix is W[n % row_split, (n / row_split) *
+ * split_cols + col] -- fe.net.0.weight [96, 2F] seen as [a-half ; c-half] = [192, F]. */
+#define MPG_PACK_MAX_JOBS 12
+typedef struct MpgPackJob {
+    const float* W; int ldw, rows, cols, transpose; float scale; int f16; void* img;
+    int row_split, split_cols;
+} MpgPackJob;
+int mpg_pack_many(const MpgPackJob* jobs, int njobs, void* stream);
+
+/* mpg_chain: up to three Linear(+LeakyReLU)(+Dropout) layers -- or their input-gradient chain -- on row blocks
+ * of 32 without the intermediates returning to memory as operands.  Replaces LinearNet.forward
+ * (mpgan/model.py:70-85) for MPLayer.fn (:268-279) and, in its backward, the three dX = dY W products.
+ *   layer l:  z = Wimg_l x + bias ;  y = z                      (act = 0)
+ *                                    y = LeakyReLU(z)            (act = 1)
+ *             y = dropout(y)  (drop_thr != 0: keep * drop_scale) ; y *= gate(H)  (gateH != NULL: derivative of
+ *             Dropout o LeakyReLU [gate_act] of the forward layer whose OUTPUT is H, as mpg_gemm's gate)
+ *   input  :  rows of A (sum of a_slabs slabs, K1 columns) followed by rows of A2 (K - K1 columns); in_thr != 0
+ *             multiplies it by a dropout keep mask first (backward of a trailing dropout) and in_out, if given,
+ *             receives that gated input.
+ * Wimg_l is the mpg_pack_weights image of the [N, K] matrix applied (the transposed weight in the backward),
+ * fp16 hi/lo when f16 else bf16 hi/lo.  K, N <= 256 for every layer but the last (N unbounded there). */
+typedef struct MpgChainLayer {
+    const void* Wimg; const float* bias; int nbias;      /* bias[n] for n < nbias, 0 beyond (nbias = 0: all N) */
+    int K, N, act;
+    uint32_t drop_tag, drop_thr; float drop_scale;
+    const float* gateH; int ldh, gate_act;
+    uint32_t gate_tag, gate_thr; float gate_scale;
+    float* out; int ldo;
+} MpgChainLayer;
+typedef struct MpgChain {
+    const float* A; int lda, K1;
+    const float* A2; int lda2;
+    int a_slabs; uint64_t a_slab_stride;
+    uint32_t in_tag, in_thr; float in_scale;
+    float* in_out; int ld_in_out;
+    int M, nlayers; float alpha; const uint64_t* seed; int f16;
+    MpgChainLayer L[3];
+} MpgChain;
+int mpg_chain(const MpgChain* p, void* stream);
+
 /* mpg_edge_fwd: replaces MPLayer._getA_fully_connected + self.fe(A) + mask multiply + sum/mean
  * (mpgan/model.py:241, :256-267, :284-317).  Inputs are the layer-1 node terms
  *   a[b,i,:] = W1[:, :F] x_i + b1   (receiver),   c[b,j,:] = W1[:, F:] x_j   (sender),
@@ -83,7 +125,8 @@ int mpg_pack_weights(const float* W, int ldw, int rows, int cols, int transpose,
  * With SC > 1 the senders are split over SC workgroups and agg has a leading [SC] axis of partial
  * sums the caller adds up. */
 typedef struct MpgEdgeFwd {
-    const float* a; const float* c;       /* [B*N, 96]                                        */
+    const float* a; const float* c;       /* [B*N, 96], row stride ld_ac (0 = 96)             */
+    int ld_ac;
     const float* mask;                    /* [B*N] (1 real / 0 padded) or NULL                */
     const void* W2img; const void* W3img; /* from mpg_pack_weights                            */
     const float* b2; const float* b3;     /* fe.net.1.bias [160], fe.net.2.bias [192]         */
@@ -101,11 +144,11 @@ int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream);
  * forward's sign words it produces
  *   da [SC, B*N, 96]  (partial over sender chunks),  dc [RB, B*N, 96]  (partial over receiver blocks of 32)
  * and, when stageE2/stageZ2 are non-NULL (weight gradients wanted), parks E2 = fe.net.1's output and
- * dZ2 = dL/d(its pre-activation) as 16-bit hi/lo planes [B*RB*N blocks][2][160][32] (fp16 / bf16 resp.
+ * dZ2 = dL/d(its pre-activation) as 16-bit hi/lo fragments [B*RB*N blocks][2][10][64 lanes][8] (fp16 / bf16 resp.
  * bf16 / bf16 when f16 = 0) for mpg_edge_dw.  W2img is the forward image (mpg_pack_weights, f16 as the
  * flag says); W3Timg / W2Timg are bf16 images of the transposed weights. */
 typedef struct MpgEdgeBwd {
-    const float* a; const float* c; const float* mask;
+    const float* a; const float* c; int ld_ac; const float* mask;
     const float* dagg; int ld_dagg;
     const unsigned int* sign3;            /* [B*RB*N][3][64] from mpg_edge_fwd                   */
     const void* W2img; const void* W3Timg; const void* W2Timg;
@@ -125,7 +168,7 @@ int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream);
  * `part` is scratch of nwg * 46,432 floats (per-workgroup partial sums); nwg workgroups share the B*RB*N blocks
  * evenly and each may take at most 64 of them (error -5 otherwise). */
 typedef struct MpgEdgeDw {
-    const float* a; const float* c; const float* mask;
+    const float* a; const float* c; int ld_ac; const float* mask;
     const float* dagg; int ld_dagg;
     const unsigned int* sign3;
     const void* stageE2; const void* stageZ2;

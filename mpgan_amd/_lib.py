@@ -40,7 +40,7 @@ class MpgGemm(C.Structure):
 
 class MpgEdgeFwd(C.Structure):
     _fields_ = [
-        ("a", _fp), ("c", _fp), ("mask", _fp),
+        ("a", _fp), ("c", _fp), ("ld_ac", C.c_int), ("mask", _fp),
         ("W2img", _fp), ("W3img", _fp), ("b2", _fp), ("b3", _fp),
         ("agg", _fp),
         ("B", C.c_int), ("N", C.c_int), ("SC", C.c_int),
@@ -53,7 +53,7 @@ class MpgEdgeFwd(C.Structure):
 
 class MpgEdgeBwd(C.Structure):
     _fields_ = [
-        ("a", _fp), ("c", _fp), ("mask", _fp),
+        ("a", _fp), ("c", _fp), ("ld_ac", C.c_int), ("mask", _fp),
         ("dagg", _fp), ("ld_dagg", C.c_int),
         ("sign3", _fp),
         ("W2img", _fp), ("W3Timg", _fp), ("W2Timg", _fp),
@@ -69,7 +69,7 @@ class MpgEdgeBwd(C.Structure):
 
 class MpgEdgeDw(C.Structure):
     _fields_ = [
-        ("a", _fp), ("c", _fp), ("mask", _fp),
+        ("a", _fp), ("c", _fp), ("ld_ac", C.c_int), ("mask", _fp),
         ("dagg", _fp), ("ld_dagg", C.c_int),
         ("sign3", _fp), ("stageE2", _fp), ("stageZ2", _fp),
         ("part", _fp), ("nwg", C.c_int),
@@ -78,6 +78,36 @@ class MpgEdgeDw(C.Structure):
         ("alpha", C.c_float), ("agg_scale", C.c_float),
         ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
         ("f16", C.c_int),
+    ]
+
+
+class MpgPackJob(C.Structure):
+    _fields_ = [
+        ("W", _fp), ("ldw", C.c_int), ("rows", C.c_int), ("cols", C.c_int), ("transpose", C.c_int),
+        ("scale", C.c_float), ("f16", C.c_int), ("img", _fp), ("row_split", C.c_int), ("split_cols", C.c_int),
+    ]
+
+
+class MpgChainLayer(C.Structure):
+    _fields_ = [
+        ("Wimg", _fp), ("bias", _fp), ("nbias", C.c_int),
+        ("K", C.c_int), ("N", C.c_int), ("act", C.c_int),
+        ("drop_tag", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float),
+        ("gateH", _fp), ("ldh", C.c_int), ("gate_act", C.c_int),
+        ("gate_tag", C.c_uint32), ("gate_thr", C.c_uint32), ("gate_scale", C.c_float),
+        ("out", _fp), ("ldo", C.c_int),
+    ]
+
+
+class MpgChain(C.Structure):
+    _fields_ = [
+        ("A", _fp), ("lda", C.c_int), ("K1", C.c_int),
+        ("A2", _fp), ("lda2", C.c_int),
+        ("a_slabs", C.c_int), ("a_slab_stride", C.c_uint64),
+        ("in_tag", C.c_uint32), ("in_thr", C.c_uint32), ("in_scale", C.c_float),
+        ("in_out", _fp), ("ld_in_out", C.c_int),
+        ("M", C.c_int), ("nlayers", C.c_int), ("alpha", C.c_float), ("seed", _fp), ("f16", C.c_int),
+        ("L", MpgChainLayer * 3),
     ]
 
 
@@ -98,6 +128,8 @@ SIGNATURES = {
                            _fp, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]),
     "mpg_dropout_mask": (C.c_int, [_fp, C.c_uint64, C.c_int, _fp, C.c_uint32, C.c_uint32, C.c_void_p]),
     "mpg_pack_weights": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp, C.c_void_p]),
+    "mpg_pack_many": (C.c_int, [C.POINTER(MpgPackJob), C.c_int, C.c_void_p]),
+    "mpg_chain": (C.c_int, [C.POINTER(MpgChain), C.c_void_p]),
     "mpg_edge_fwd": (C.c_int, [C.POINTER(MpgEdgeFwd), C.c_void_p]),
     "mpg_edge_bwd": (C.c_int, [C.POINTER(MpgEdgeBwd), C.c_void_p]),
     "mpg_edge_dw": (C.c_int, [C.POINTER(MpgEdgeDw), C.c_void_p]),

@@ -1,0 +1,270 @@
+// Chained per-node MLP: up to three Linear(+LeakyReLU)(+Dropout) layers -- or their input-gradient
+// chain -- applied to a block of 32 rows without the intermediate activations leaving the CU as operands.
+//
+// Replaces, per MPLayer call, the node network  fn = LinearNet([256, 256] -> out)  (mpgan/model.py:268-279 ->
+// LinearNet.forward :70-85) and, in the backward, the three input-gradient products of the same layers; with
+// one layer it is the  a | c = x W1'^T  projection in front of the edge network.
+//
+// Layout ("chain" layout of common.h / edge.hip): the 32 rows (nodes) of a workgroup sit on the MFMA column,
+// features in accumulator registers.  The weights are the A operand (pre-packed fragment images, streamed
+// from L2), the activations the B operand: a layer's output tile, converted to 16-bit hi/lo, IS a pair of
+// B fragments of the next layer, so between layers the activations only pass through LDS as ready-made
+// fragments (64 KiB for two layers of up to 256 features).  The eight waves of the workgroup split a layer's
+// 32-feature output tiles; two waves per SIMD overlap one wave's epilogue with the other's MFMAs.
+#include "common.h"
+#include "../../include/mpgan_amd.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int CH_MAXKS = 16;                       // k-steps of 16 features: K <= 256
+constexpr int CH_FB_BYTES = CH_MAXKS * 2 * 1024;   // one fragment buffer: [k-step][hi|lo][lane] 16 B
+constexpr int CH_LDS_BYTES = 2 * CH_FB_BYTES;      // 65,536
+
+MPG_DEV float4 chld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <bool F16>
+__global__ __launch_bounds__(512, 1) void chain_kernel(const MpgChain p) {
+    typedef typename FragT<F16>::type V;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * 32;
+    uint32_t seed_lo = 0, seed_hi = 0;
+    if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+
+    // ---- stage the input rows as B fragments: unit = (k-step, lane) = 8 features of one row
+    {
+        const int K = p.L[0].K, KS = 2 * ((K + 31) / 32);
+        V* fb = reinterpret_cast<V*>(smem);
+        const bool vec1 = (p.lda % 4 == 0) && (p.K1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0) &&
+                          (p.a_slab_stride % 4 == 0);
+        for (int u = tid; u < KS * 64; u += 512) {
+            const int ks = u >> 6, ln = u & 63, rr = ln & 31, hh = ln >> 5;
+            const int m = m0 + rr;
+            float v[8];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int f = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * half + 4 * hh;  // features f .. f+3
+                float x4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (m < p.M) {
+                    if (vec1 && f + 4 <= p.K1) {
+                        for (int sl = 0; sl < p.a_slabs; ++sl) {
+                            const float4 t = chld4(p.A + sl * p.a_slab_stride + (size_t)m * p.lda + f);
+                            x4[0] += t.x; x4[1] += t.y; x4[2] += t.z; x4[3] += t.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = f + e;
+                            if (k < p.K1) {
+                                for (int sl = 0; sl < p.a_slabs; ++sl) x4[e] += p.A[sl * p.a_slab_stride + (size_t)m * p.lda + k];
+                            } else if (k < K) {
+                                x4[e] = p.A2[(size_t)m * p.lda2 + (k - p.K1)];
+                            }
+                        }
+                    }
+                    if (p.in_thr) {  // backward of a trailing dropout: gate the incoming gradient
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            x4[e] = (f + e < K && drop_keep_f(seed_lo, seed_hi, p.in_tag, (uint32_t)m, f + e, p.in_thr)) ? x4[e] * p.in_scale : 0.f;
+                    }
+                    if (p.in_out != nullptr) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (f + e < K) p.in_out[(size_t)m * p.ld_in_out + f + e] = x4[e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * half + e] = x4[e];
+            }
+            V hi, lo;
+            split8(v, hi, lo);
+            fb[(ks * 2 + 0) * 64 + ln] = hi;
+            fb[(ks * 2 + 1) * 64 + ln] = lo;
+        }
+    }
+    __syncthreads();
+
+    const int lane16 = lane * 16;
+    for (int l = 0; l < p.nlayers; ++l) {
+        const MpgChainLayer& L = p.L[l];
+        const V* fin = reinterpret_cast<const V*>(smem + (l & 1) * CH_FB_BYTES);
+        V* fout = reinterpret_cast<V*>(smem + ((l + 1) & 1) * CH_FB_BYTES);
+        const int QT = (L.K + 31) / 32, KS = 2 * QT, MT = (L.N + 31) / 32;
+        const int nfrag = MT * QT * 2;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(L.Wimg), 0, 2 * nfrag * 1024, 0x00020000);
+        const bool last = l + 1 == p.nlayers;
+        for (int tile = w; tile < MT; tile += 8) {
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = 32 * tile + 8 * g + 4 * h;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[4 * g + t] = (L.bias != nullptr && n + t < (L.nbias ? L.nbias : L.N)) ? L.bias[n + t] : 0.f;
+            }
+            // weight fragments: ring of 4 k-steps (hi, lo) ahead of the MFMAs; past the end the loads are clamped
+            const int f0 = tile * KS;
+            V wh[4], wl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ks = min(u, KS - 1);
+                wh[u] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, (f0 + ks) * 1024, 0));
+                wl[u] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, (nfrag + f0 + ks) * 1024, 0));
+            }
+            for (int k0 = 0; k0 < KS; k0 += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ks = k0 + u;
+                    if (ks < KS) {
+                        const V bh = fin[(ks * 2 + 0) * 64 + lane], bl = fin[(ks * 2 + 1) * 64 + lane];
+                        acc = mfma3(wh[u], wl[u], bh, bl, acc);
+                        const int kn = min(ks + 4, KS - 1);
+                        wh[u] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, (f0 + kn) * 1024, 0));
+                        wl[u] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, (nfrag + f0 + kn) * 1024, 0));
+                    }
+                }
+            }
+            // ---- epilogue: register 4g+t  <->  feature 32 tile + 8g + 4h + t of row m0 + r
+            const int m = m0 + r;
+            float v[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = 32 * tile + 8 * g + 4 * h;
+                float x4[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float x = acc[4 * g + t];
+                    if (L.act) x = lrelu(x, p.alpha);
+                    x4[t] = x;
+                }
+                if (L.drop_thr) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        x4[t] = drop_keep_f(seed_lo, seed_hi, L.drop_tag, (uint32_t)m, n + t, L.drop_thr) ? x4[t] * L.drop_scale : 0.f;
+                }
+                if (L.gateH != nullptr) {  // backward through (dropout o LeakyReLU) of the layer that produced H
+                    float hv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (m < p.M) {
+                        if (n + 4 <= L.N && (L.ldh % 4 == 0)) {
+                            const float4 t4 = chld4(L.gateH + (size_t)m * L.ldh + n);
+                            hv[0] = t4.x; hv[1] = t4.y; hv[2] = t4.z; hv[3] = t4.w;
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) if (n + t < L.N) hv[t] = L.gateH[(size_t)m * L.ldh + n + t];
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float gt = L.gate_act ? lrelu_grad(hv[t], p.alpha) : 1.f;
+                        if (L.gate_thr) gt = drop_keep_f(seed_lo, seed_hi, L.gate_tag, (uint32_t)m, n + t, L.gate_thr) ? gt * L.gate_scale : 0.f;
+                        x4[t] *= gt;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (n + t >= L.N || m >= p.M) x4[t] = 0.f;  // padding stays exactly zero
+                if (L.out != nullptr && m < p.M) {
+                    float* dst = L.out + (size_t)m * L.ldo + n;
+                    if (n + 4 <= L.N && (L.ldo % 4 == 0)) *reinterpret_cast<float4*>(dst) = make_float4(x4[0], x4[1], x4[2], x4[3]);
+                    else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) if (n + t < L.N) dst[t] = x4[t];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[4 * g + t] = x4[t];
+            }
+            if (!last) {  // registers 8s .. 8s+7 are the B fragment of k-step (2 tile + s) of the next layer
+                V hi, lo;
+                split8(v, hi, lo);
+                fout[((2 * tile + 0) * 2 + 0) * 64 + lane] = hi;
+                fout[((2 * tile + 0) * 2 + 1) * 64 + lane] = lo;
+                split8(v + 8, hi, lo);
+                fout[((2 * tile + 1) * 2 + 0) * 64 + lane] = hi;
+                fout[((2 * tile + 1) * 2 + 1) * 64 + lane] = lo;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+struct PackJobs { MpgPackJob j[MPG_PACK_MAX_JOBS]; int n; int frag0[MPG_PACK_MAX_JOBS + 1]; };
+
+// all weight images of one network layer set in one launch (the per-image kernel is ~5 us of launch each)
+__global__ void pack_many_kernel(const PackJobs jobs) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int frag = idx >> 6, lane = idx & 63;
+    if (frag >= jobs.frag0[jobs.n]) return;
+    int q = 0;
+    while (frag >= jobs.frag0[q + 1]) ++q;
+    const MpgPackJob& J = jobs.j[q];
+    const int rows = J.rows, cols = J.cols;  // of the packed matrix (= W^T when J.transpose)
+    const int MT = (rows + 31) / 32, QT = (cols + 31) / 32, nfrag = MT * QT * 2;
+    const int fr = frag - jobs.frag0[q];
+    const int m = fr / (QT * 2), qq = (fr >> 1) % QT, s = fr & 1;
+    const int r = lane & 31, h = lane >> 5;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = 32 * m + r, col = 32 * qq + chain_rho(s, h, j);
+        float x = 0.f;
+        if (row < rows && col < cols) {
+            int wr = J.transpose ? col : row, wc = J.transpose ? row : col;  // element of W
+            if (J.row_split > 0) {  // stacked view: logical row n -> W[n % split, (n / split) * split_cols + col]
+                wc += (wr / J.row_split) * J.split_cols;
+                wr %= J.row_split;
+            }
+            x = J.W[(size_t)wr * J.ldw + wc] * J.scale;
+        }
+        v[j] = x;
+    }
+    if (J.f16) {
+        f16x8 hi, lo;
+        split8(v, hi, lo);
+        reinterpret_cast<f16x8*>(J.img)[fr * 64 + lane] = hi;
+        reinterpret_cast<f16x8*>(J.img)[(size_t)nfrag * 64 + fr * 64 + lane] = lo;
+    } else {
+        bf16x8 hi, lo;
+        split8(v, hi, lo);
+        reinterpret_cast<bf16x8*>(J.img)[fr * 64 + lane] = hi;
+        reinterpret_cast<bf16x8*>(J.img)[(size_t)nfrag * 64 + fr * 64 + lane] = lo;
+    }
+}
+
+}  // namespace
+
+extern "C" int mpg_chain(const MpgChain* p, void* stream) {
+    if (p->M <= 0 || p->nlayers < 1 || p->nlayers > 3) return -1;
+    if (!(p->alpha >= 0.f && p->alpha <= 1.f)) return -4;
+    for (int l = 0; l < p->nlayers; ++l) {
+        if (p->L[l].K <= 0 || p->L[l].K > 16 * CH_MAXKS || p->L[l].N <= 0) return -2;
+        if (l + 1 < p->nlayers && (p->L[l].N > 16 * CH_MAXKS || p->L[l + 1].K != p->L[l].N)) return -2;
+    }
+    if (p->a_slabs < 1 || p->K1 > p->L[0].K || (p->K1 < p->L[0].K && p->A2 == nullptr)) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((p->M + 31) / 32), block(512);
+    static bool done[2] = {false, false};
+    if (p->f16) {
+        if (!done[1]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES)); done[1] = true; }
+        hipLaunchKernelGGL((chain_kernel<true>), grid, block, CH_LDS_BYTES, st, *p);
+    } else {
+        if (!done[0]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES)); done[0] = true; }
+        hipLaunchKernelGGL((chain_kernel<false>), grid, block, CH_LDS_BYTES, st, *p);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int mpg_pack_many(const MpgPackJob* jobs, int njobs, void* stream) {
+    if (njobs < 1 || njobs > MPG_PACK_MAX_JOBS) return -1;
+    PackJobs pj;
+    pj.n = njobs;
+    pj.frag0[0] = 0;
+    for (int q = 0; q < njobs; ++q) {
+        pj.j[q] = jobs[q];
+        pj.frag0[q + 1] = pj.frag0[q] + ((jobs[q].rows + 31) / 32) * ((jobs[q].cols + 31) / 32) * 2;
+    }
+    const int n = pj.frag0[njobs] * 64;
+    hipLaunchKernelGGL(pack_many_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pj);
+    return (int)hipGetLastError();
+}

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
     // receiver term a_i in B-operand order: areg[q][s][4u+t] = a[i][32q+16s+8u+4h+t]
     float areg[T1][2][8];
     {
-        const float* ai = p.a + (size_t)(b * p.N + (vi ? i : 0)) * H1;
+        const float* ai = p.a + (size_t)(b * p.N + (vi ? i : 0)) * (p.ld_ac ? p.ld_ac : H1);
 #pragma unroll
         for (int q = 0; q < T1; ++q)
 #pragma unroll
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
     const int j1 = min(jend, j0 + FWD_C_SLOTS);
     __syncthreads();  // previous chunk fully consumed (first pass: weight/bias fill issued)
     for (int t = tid; t < (j1 - j0) * (H1 / 4); t += 256)
-        reinterpret_cast<float4*>(lc)[t] = reinterpret_cast<const float4*>(p.c + (size_t)(b * p.N + j0) * H1)[t];
+        reinterpret_cast<float4*>(lc)[t] = ld4(p.c + (size_t)(b * p.N + j0 + t / (H1 / 4)) * (p.ld_ac ? p.ld_ac : H1) + 4 * (t % (H1 / 4)));
     __syncthreads();
     for (int j = j0 + w; j < j1; j += 4) {
         const float mj = p.mask ? p.mask[b * p.N + j] : 1.f;

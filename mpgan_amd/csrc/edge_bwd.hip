@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     for (int t = tid; t < T1 * 4 * 64; t += 256) {
         const int ln = t & 63, qsu = t >> 6, rr = ln & 31, hh = ln >> 5, ii = rb * 32 + rr;
         float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ii < p.N) v4 = ld4(p.a + (size_t)(b * p.N + ii) * H1 + 8 * qsu + 4 * hh);
+        if (ii < p.N) v4 = ld4(p.a + (size_t)(b * p.N + ii) * (p.ld_ac ? p.ld_ac : H1) + 8 * qsu + 4 * hh);
         la[t] = v4;
     }
 
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     const int j1 = min(jend, j0 + BWD_C_SLOTS);
     __syncthreads();
     for (int t = tid; t < (j1 - j0) * (H1 / 4); t += 256)
-        reinterpret_cast<float4*>(lc)[t] = reinterpret_cast<const float4*>(p.c + (size_t)(b * p.N + j0) * H1)[t];
+        reinterpret_cast<float4*>(lc)[t] = ld4(p.c + (size_t)(b * p.N + j0 + t / (H1 / 4)) * (p.ld_ac ? p.ld_ac : H1) + 4 * (t % (H1 / 4)));
     __syncthreads();
     for (int j = j0 + w; j < j1; j += 4) {
         const float mj = p.mask ? p.mask[b * p.N + j] : 1.f;
@@ -549,8 +549,9 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsi
     const __amdgpu_buffer_rsrc_t rE = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.stageE2), 0, nblk * (2 * NFR2 * 1024), 0x00020000);
     const __amdgpu_buffer_rsrc_t rZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.stageZ2), 0, nblk * (2 * NFR2 * 1024), 0x00020000);
     const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int*>(p.sign3), 0, nblk * (T3 * 32 * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.c), 0, p.B * p.N * H1 * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.B * p.N * H1 * 4, 0x00020000);
+    const int ldac = p.ld_ac ? p.ld_ac : H1;
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.c), 0, p.B * p.N * ldac * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.B * p.N * ldac * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dagg), 0, p.B * p.N * p.ld_dagg * 4, 0x00020000);
     int vo160[3];  // byte offset of this thread's piece n inside a 10 KiB plane
 #pragma unroll
@@ -578,7 +579,7 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsi
             dreg[n][0] = u.x; dreg[n][1] = u.y; dreg[n][2] = u.z; dreg[n][3] = u.w;
             dreg[n][4] = v.x; dreg[n][5] = v.y; dreg[n][6] = v.z; dreg[n][7] = v.w;
         }
-        const int rowA = (ok ? ii : 0) * H1 * 4, soA = b * p.N * H1 * 4;
+        const int rowA = (ok ? ii : 0) * ldac * 4, soA = b * p.N * ldac * 4;
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const float4 u = ldb4(rA, rowA + voE1[n], soA), v = ldb4(rA, rowA + voE1[n] + 32, soA);
@@ -591,7 +592,7 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsi
         for (int n = 0; n < 3; ++n) sw[n] = __builtin_amdgcn_raw_buffer_load_b32(rS, voS, blk * (T3 * 32 * 4) + n * 256, 0);
     };
     auto load_c = [&](int blk) {
-        const int j = blk % p.N, b = (blk / p.N) / RB, so = (b * p.N + j) * H1 * 4;
+        const int j = blk % p.N, b = (blk / p.N) / RB, so = (b * p.N + j) * ldac * 4;
 #pragma unroll
         for (int n = 0; n < 2; ++n) { cv[n][0] = ldb4(rC, voE1[n], so); cv[n][1] = ldb4(rC, voE1[n] + 32, so); }
     };

@@ -85,7 +85,24 @@ class MPLayer(nn.Module):
             x, mask if use_mask else None,
             fe[0].weight, fe[0].bias, fe[1].weight, fe[1].bias, fe[2].weight, fe[2].bias,
             fn[0].weight, fn[0].bias, fn[1].weight, fn[1].bias, fn[2].weight, fn[2].bias,
-            self.sum, self.fe.leaky_relu_alpha, self.fe.dropout_p, self.training)
+            self.sum, self.fe.leaky_relu_alpha, self.fe.dropout_p, self.training, self._packed())
+
+    def _packed(self) -> "ops.PackedMPLayer":
+        """Persistent weight images of this layer for the current mode (dropout scale) -- rebuilt when a
+        parameter changes (``PackedMPLayer.ensure``) or on ``refresh_packed()``."""
+        dscale = ops.drop_params(self.fe.dropout_p)[1] if self.training else 1.0
+        key = (dscale, ops.OPTIONS["fwd_f16"])
+        cache = self.__dict__.setdefault("_pack_cache", {})
+        params = tuple(l.weight for l in (*self.fe.net, *self.fn.net))
+        pk = cache.get(key)
+        if pk is None or any(a is not b for a, b in zip(pk.params, params)):
+            pk = cache[key] = ops.PackedMPLayer(params, self.input_node_size, self.output_node_size, *key)
+        return pk
+
+    def refresh_packed(self):
+        """Re-pack after an update torch cannot see (a kernel writing the parameters' storage directly)."""
+        for pk in self.__dict__.get("_pack_cache", {}).values():
+            pk.refresh()
 
     def __repr__(self):
         return f"{self.__class__.__name__}(fe = {self.fe}, \n fn = {self.fn})"

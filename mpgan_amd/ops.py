@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import MpgGemm, MpgEdgeFwd, MpgEdgeBwd, MpgEdgeDw, check
+from ._lib import MpgGemm, MpgEdgeFwd, MpgEdgeBwd, MpgEdgeDw, MpgPackJob, MpgChain, check
 
 H1, H2, H3 = 96, 160, 192
 TAG_E0, TAG_E1, TAG_E2, TAG_N0, TAG_N1, TAG_N2, TAG_GENERIC = 1, 2, 3, 4, 5, 6, 7
@@ -180,6 +180,89 @@ def pack_weights(W, rows, cols, *, col0=0, transpose=False, scale=1.0, f16=False
     return img
 
 
+def _img_elems(rows, cols):
+    return 2 * ((rows + 31) // 32) * ((cols + 31) // 32) * 2 * 512   # 16-bit elements of a hi|lo image
+
+
+class PackedMPLayer:
+    """All weight images one MPLayer call needs (edge network, node network, their transposes and the stacked
+    a|c view of fe.net.0), in persistent buffers, rebuilt by ONE ``mpg_pack_many`` launch.
+
+    ``ensure()`` rebuilds when a parameter's storage or autograd version changed (``optimizer.step()``,
+    ``load_state_dict``).  Updates made behind torch's back -- ``train.TrainStep`` runs RMSprop on a flat buffer
+    through ``mpg_rmsprop`` -- must call ``refresh()`` themselves (TrainStep does, inside its graph segments).
+    """
+
+    def __init__(self, params, F, out, dscale, f16):
+        W1, W2, W3, V1, V2, V3 = params
+        self.params, self.F, self.out, self.dscale, self.f16 = params, F, out, float(dscale), bool(f16)
+        dev = W1.device
+        KN = H3 + F
+        # name: (W, packed rows, packed cols, transpose, scale, f16, row_split, split_cols)
+        spec = {
+            "W2": (W2, H2, H1, 0, dscale, f16, 0, 0), "W3": (W3, H3, H2, 0, dscale, f16, 0, 0),
+            "W3T": (W3, H2, H3, 1, dscale, False, 0, 0), "W2T": (W2, H1, H2, 1, dscale, False, 0, 0),
+            "V1": (V1, V1.shape[0], KN, 0, 1.0, f16, 0, 0), "V2": (V2, V2.shape[0], V2.shape[1], 0, 1.0, f16, 0, 0),
+            "V3": (V3, out, V3.shape[1], 0, 1.0, f16, 0, 0),
+            "V3T": (V3, V3.shape[1], out, 1, 1.0, False, 0, 0), "V2T": (V2, V2.shape[1], V2.shape[0], 1, 1.0, False, 0, 0),
+            "V1T": (V1, KN, V1.shape[0], 1, 1.0, False, 0, 0),
+            "W1S": (W1, 2 * H1, F, 0, 1.0, f16, H1, F),          # [a-half ; c-half] of fe.net.0.weight
+            "W1ST": (W1, F, 2 * H1, 1, 1.0, False, H1, F),
+        }
+        self.img = {k: torch.empty((_img_elems(v[1], v[2]),), device=dev, dtype=torch.bfloat16) for k, v in spec.items()}
+        self._spec = spec
+        self._key = None
+
+    def _current_key(self):
+        return tuple((q.data_ptr(), q._version) for q in self.params)
+
+    def refresh(self):
+        jobs = (MpgPackJob * len(self._spec))()
+        for i, (k, (W, rows, cols, tr, scale, f16, rs, sc)) in enumerate(self._spec.items()):
+            j = jobs[i]
+            j.W, j.ldw, j.rows, j.cols, j.transpose = _p(W), W.stride(0), rows, cols, tr
+            j.scale, j.f16, j.img, j.row_split, j.split_cols = scale, int(f16), C.c_void_p(self.img[k].data_ptr()), rs, sc
+        check(_lib.lib().mpg_pack_many(jobs, len(self._spec), _stream()), "mpg_pack_many")
+        self._key = self._current_key()
+
+    def ensure(self):
+        if self._key != self._current_key():
+            self.refresh()
+        return self
+
+    def ptr(self, name):
+        return C.c_void_p(self.img[name].data_ptr())
+
+
+def chain(M, layers, *, A, lda, K1, A2=None, lda2=0, a_slabs=1, a_slab_stride=0, in_gate=None, in_out=None,
+          alpha=0.2, seed_t=None, f16=False):
+    """mpg_chain front-end.  ``layers``: dicts with img, K, N and optionally bias, nbias, act, drop=(tag,thr,scale),
+    gate=(H, act, tag, thr, scale), out (tensor [M, >=N])."""
+    c = MpgChain()
+    c.A, c.lda, c.K1 = _p(A), lda, K1
+    c.A2, c.lda2 = _p(A2), lda2
+    c.a_slabs, c.a_slab_stride = a_slabs, a_slab_stride
+    if in_gate is not None and in_gate[1]:
+        c.in_tag, c.in_thr, c.in_scale = in_gate
+    if in_out is not None:
+        c.in_out, c.ld_in_out = _p(in_out), in_out.stride(0)
+    c.M, c.nlayers, c.alpha, c.seed, c.f16 = M, len(layers), alpha, _p(seed_t), int(f16)
+    for i, d in enumerate(layers):
+        L = c.L[i]
+        L.Wimg, L.K, L.N = d["img"], d["K"], d["N"]
+        L.bias, L.nbias, L.act = _p(d.get("bias")), d.get("nbias", 0), int(d.get("act", False))
+        if d.get("drop") is not None and d["drop"][1]:
+            L.drop_tag, L.drop_thr, L.drop_scale = d["drop"]
+        if d.get("gate") is not None:
+            H, gact, tag, thr, scale = d["gate"]
+            L.gateH, L.ldh, L.gate_act = _p(H), H.stride(0), int(gact)
+            if thr:
+                L.gate_tag, L.gate_thr, L.gate_scale = tag, thr, scale
+        if d.get("out") is not None:
+            L.out, L.ldo = _p(d["out"]), d["out"].stride(0)
+    check(_lib.lib().mpg_chain(C.byref(c), _stream()), "mpg_chain")
+
+
 def _sender_chunks(B, N):
     """Sender chunks per (jet, receiver block): 1 when those alone give every CU a workgroup (each
     workgroup pays a 150 KiB LDS fill), else enough to cover the 256 CUs about twice."""
@@ -196,7 +279,8 @@ class FusedMPLayerFn(torch.autograd.Function):
     features, no conditioning labels; fe = 3 layers [96,160,192], fn = 2 hidden layers + linear."""
 
     @staticmethod
-    def forward(ctx, x, mask, W1, b1, W2, b2, W3, b3, V1, c1, V2, c2, V3, c3, sum_agg, alpha, p_drop, training):
+    def forward(ctx, x, mask, W1, b1, W2, b2, W3, b3, V1, c1, V2, c2, V3, c3, sum_agg, alpha, p_drop, training,
+                packed=None):
         _chk(x, "x")
         B, N, F = x.shape
         V = B * N
@@ -206,20 +290,24 @@ class FusedMPLayerFn(torch.autograd.Function):
         tag = next_tag()
         x2 = x.reshape(V, F).contiguous()
         m1 = None if mask is None else mask.reshape(V).contiguous()
+        f16 = OPTIONS["fwd_f16"]
+        out_f = V3.shape[0]
+        if packed is None or packed.dscale != dscale or packed.f16 != f16:  # direct callers: pack for this call
+            packed = PackedMPLayer((W1, W2, W3, V1, V2, V3), F, out_f, dscale, f16)
+        pk = packed.ensure()
 
         def dr(site):
-            return (seed_t, tag + site, thr, dscale) if thr else None
+            return (tag + site, thr, dscale)
 
-        a = linear_fwd(x2, W1, b1, w_cols=F)
-        c = linear_fwd(x2, W1, None, w_col0=F, w_cols=F)
-        f16 = OPTIONS["fwd_f16"]
-        W2img = pack_weights(W2, H2, H1, scale=dscale, f16=f16)
-        W3img = pack_weights(W3, H3, H2, scale=dscale, f16=f16)
+        # layer-1 node terms a | c = x [W1a ; W1c]^T (+ b1 on the a half), one launch
+        ac = torch.empty((V, 2 * H1), device=dev, dtype=torch.float32)
+        chain(V, [dict(img=pk.ptr("W1S"), K=F, N=2 * H1, bias=b1, nbias=H1, out=ac)], A=x2, lda=F, K1=F,
+              alpha=alpha, f16=f16)
         SC = _sender_chunks(B, N)
         aggp = torch.empty((SC, V, H3), device=dev, dtype=torch.float32)
         e = MpgEdgeFwd()
-        e.a, e.c, e.mask = _p(a), _p(c), _p(m1)
-        e.W2img, e.W3img = C.c_void_p(W2img.data_ptr()), C.c_void_p(W3img.data_ptr())
+        e.a, e.c, e.ld_ac, e.mask = _p(ac), _p(ac, H1), 2 * H1, _p(m1)
+        e.W2img, e.W3img = pk.ptr("W2"), pk.ptr("W3")
         e.b2, e.b3, e.agg = _p(b2), _p(b3), _p(aggp)
         e.B, e.N, e.SC = B, N, SC
         e.alpha, e.agg_scale = alpha, 1.0 if sum_agg else 1.0 / N
@@ -233,17 +321,25 @@ class FusedMPLayerFn(torch.autograd.Function):
         check(_lib.lib().mpg_edge_fwd(C.byref(e), _stream()), "mpg_edge_fwd")
         agg = aggp[0] if SC == 1 else aggp.sum(0)
 
-        h1 = linear_fwd(agg, V1, c1, act=True, alpha=alpha, drop=dr(TAG_N0), x2=x2)
-        h2 = linear_fwd(h1, V2, c2, act=True, alpha=alpha, drop=dr(TAG_N1))
-        y = linear_fwd(h2, V3, c3, act=False, drop=dr(TAG_N2))
+        # node network fn: three chained layers, one launch
+        n1, n2 = V1.shape[0], V2.shape[0]
+        h1 = torch.empty((V, n1), device=dev, dtype=torch.float32)
+        h2 = torch.empty((V, n2), device=dev, dtype=torch.float32)
+        y = torch.empty((V, out_f), device=dev, dtype=torch.float32)
+        chain(V, [dict(img=pk.ptr("V1"), K=H3 + F, N=n1, bias=c1, act=True, drop=dr(TAG_N0), out=h1),
+                  dict(img=pk.ptr("V2"), K=n1, N=n2, bias=c2, act=True, drop=dr(TAG_N1), out=h2),
+                  dict(img=pk.ptr("V3"), K=n2, N=out_f, bias=c3, act=False, drop=dr(TAG_N2), out=y)],
+              A=agg, lda=H3, K1=H3, A2=x2, lda2=F, alpha=alpha, seed_t=seed_t, f16=f16)
+        ctx.packed = pk
 
-        ctx.save_for_backward(x2, m1, a, c, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3)
+        ctx.save_for_backward(x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3)
         ctx.cfg = (B, N, F, sum_agg, alpha, thr, dscale, tag, SC, f16)
         return y.reshape(B, N, V3.shape[0])
 
     @staticmethod
     def backward(ctx, gy):
-        x2, m1, a, c, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3 = ctx.saved_tensors
+        x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3 = ctx.saved_tensors
+        pk = ctx.packed
         B, N, F, sum_agg, alpha, thr, dscale, tag, SC, f16 = ctx.cfg
         V = B * N
         dev = x2.device
@@ -257,11 +353,16 @@ class FusedMPLayerFn(torch.autograd.Function):
         need_x = ctx.needs_input_grad[0]
 
         # ---- node network fn (mpgan/model.py:279) backward
-        dz3 = gate(gy2, None, gate_act=False, alpha=alpha, seed_t=seed_t, tag=tag + TAG_N2, thr=thr, scale=dscale) \
-            if thr else gy2
-        dz2 = linear_bwd_data(dz3, V3, gate=gt(h2, TAG_N1, True), alpha=alpha)
-        dz1 = linear_bwd_data(dz2, V2, gate=gt(h1, TAG_N0, True), alpha=alpha)
-        dh0 = linear_bwd_data(dz1, V1)  # [V, 192+F] = [dagg | dx(node path)]
+        n1, n2, out_f = V1.shape[0], V2.shape[0], V3.shape[0]
+        dz3 = torch.empty_like(gy2) if thr else gy2
+        dz2 = torch.empty((V, n2), device=dev, dtype=torch.float32)
+        dz1 = torch.empty((V, n1), device=dev, dtype=torch.float32)
+        dh0 = torch.empty((V, H3 + F), device=dev, dtype=torch.float32)  # [dagg | dx(node path)]
+        chain(V, [dict(img=pk.ptr("V3T"), K=out_f, N=n2, gate=(h2, True, tag + TAG_N1, thr, dscale), out=dz2),
+                  dict(img=pk.ptr("V2T"), K=n2, N=n1, gate=(h1, True, tag + TAG_N0, thr, dscale), out=dz1),
+                  dict(img=pk.ptr("V1T"), K=n1, N=H3 + F, out=dh0)],
+              A=gy2, lda=gy2.stride(0), K1=out_f, in_gate=(tag + TAG_N2, thr, dscale), in_out=dz3 if thr else None,
+              alpha=alpha, seed_t=seed_t, f16=False)
         dV1 = dV2 = dV3 = dc1 = dc2 = dc3 = None
         if need_w:
             dc3, dc2, dc1 = (torch.empty(t.shape[1], device=dev, dtype=torch.float32) for t in (dz3, dz2, dz1))
@@ -272,9 +373,6 @@ class FusedMPLayerFn(torch.autograd.Function):
             linear_bwd_weight(dz1, x2, out=dV1, out_col0=H3)
 
         # ---- edge network backward: data path, then (if wanted) the weight-gradient pass
-        W2img = pack_weights(W2, H2, H1, scale=dscale, f16=f16)
-        W3Timg = pack_weights(W3, H3, H2, transpose=True, scale=dscale)
-        W2Timg = pack_weights(W2, H2, H1, transpose=True, scale=dscale)
         RB = (N + 31) // 32
         nblk = B * RB * N
         dap = torch.empty((SC, V, H1), device=dev, dtype=torch.float32)
@@ -284,11 +382,11 @@ class FusedMPLayerFn(torch.autograd.Function):
             stE2 = torch.empty((nblk, 2, H2, 32), device=dev, dtype=torch.int16)
             stZ2 = torch.empty((nblk, 2, H2, 32), device=dev, dtype=torch.int16)
         e = MpgEdgeBwd()
-        e.a, e.c, e.mask = _p(a), _p(c), _p(m1)
+        e.a, e.c, e.ld_ac, e.mask = _p(ac), _p(ac, H1), 2 * H1, _p(m1)
         e.dagg, e.ld_dagg = _p(dh0), dh0.stride(0)
         e.sign3 = C.c_void_p(sign3.data_ptr())
-        e.W2img = C.c_void_p(W2img.data_ptr())
-        e.W3Timg, e.W2Timg = C.c_void_p(W3Timg.data_ptr()), C.c_void_p(W2Timg.data_ptr())
+        e.W2img = pk.ptr("W2")
+        e.W3Timg, e.W2Timg = pk.ptr("W3T"), pk.ptr("W2T")
         e.b2 = _p(b2)
         e.da, e.dc = _p(dap), _p(dcp)
         e.stageE2 = None if stE2 is None else C.c_void_p(stE2.data_ptr())
@@ -307,7 +405,7 @@ class FusedMPLayerFn(torch.autograd.Function):
             dW3, dW2 = torch.empty_like(W3), torch.empty_like(W2)
             db3, db2 = torch.empty_like(b3), torch.empty_like(b2)
             d = MpgEdgeDw()
-            d.a, d.c, d.mask = _p(a), _p(c), _p(m1)
+            d.a, d.c, d.ld_ac, d.mask = _p(ac), _p(ac, H1), 2 * H1, _p(m1)
             d.dagg, d.ld_dagg = _p(dh0), dh0.stride(0)
             d.sign3 = C.c_void_p(sign3.data_ptr())
             d.stageE2, d.stageZ2 = C.c_void_p(stE2.data_ptr()), C.c_void_p(stZ2.data_ptr())
@@ -331,7 +429,7 @@ class FusedMPLayerFn(torch.autograd.Function):
             linear_bwd_data(dc, W1, w_col0=F, w_cols=F, out=dx, accumulate=True)
             dx = dx.reshape(B, N, F)
         return (dx, None, dW1, db1, dW2, db2, dW3, db3, dV1, dc1, dV2, dc2, dV3, dc3,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 class FusedLinearFn(torch.autograd.Function):

@@ -150,8 +150,16 @@ class TrainStep:
         loss.backward()
         self.D_loss.copy_(loss.detach())
 
+    @staticmethod
+    def _refresh_packed(module: nn.Module):
+        # mpg_rmsprop wrote the parameters behind autograd's back: rebuild the layers' cached weight images
+        for m in module.modules():
+            if hasattr(m, "refresh_packed"):
+                m.refresh_packed()
+
     def _seg_G(self):  # D_optimizer.step() (train.py:461) + train_G up to backward (:494-520)
         self.fD.rmsprop(self.lr_disc, gscale=1.0 / self.world)
+        self._refresh_packed(self.D)
         self.G.train()
         self.fG.zero_grad()
         _set_requires_grad(self.D, False)
@@ -164,6 +172,7 @@ class TrainStep:
 
     def _seg_end(self):  # G_optimizer.step() (train.py:521)
         self.fG.rmsprop(self.lr_gen, gscale=1.0 / self.world)
+        self._refresh_packed(self.G)
 
     def _allreduce(self, flat: FlatParams):
         mdist.allreduce_sum_(flat.grad, self.pg, self.world)  # sum; 1/world is folded into rmsprop
