@@ -92,7 +92,8 @@ int mpg_pack_many(const MpgPackJob* jobs, int njobs, void* stream);
  *   layer l:  z = Wimg_l x + bias ;  y = z                      (act = 0)
  *                                    y = LeakyReLU(z)            (act = 1)
  *             y = dropout(y)  (drop_thr != 0: keep * drop_scale) ; y *= gate(H)  (gateH != NULL: derivative of
- *             Dropout o LeakyReLU [gate_act] of the forward layer whose OUTPUT is H, as mpg_gemm's gate)
+ *             Dropout o LeakyReLU [gate_act] of the forward layer whose OUTPUT is H, as mpg_gemm's gate) ;
+ *             y += resid (resid != NULL)
  *   input  :  rows of A (sum of a_slabs slabs, K1 columns) followed by rows of A2 (K - K1 columns); in_thr != 0
  *             multiplies it by a dropout keep mask first (backward of a trailing dropout) and in_out, if given,
  *             receives that gated input.
@@ -104,6 +105,7 @@ typedef struct MpgChainLayer {
     uint32_t drop_tag, drop_thr; float drop_scale;
     const float* gateH; int ldh, gate_act;
     uint32_t gate_tag, gate_thr; float gate_scale;
+    const float* resid; int ldr;                         /* y += resid[m, n] (after everything else), or NULL */
     float* out; int ldo;
 } MpgChainLayer;
 typedef struct MpgChain {

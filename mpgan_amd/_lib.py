@@ -95,6 +95,7 @@ class MpgChainLayer(C.Structure):
         ("drop_tag", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float),
         ("gateH", _fp), ("ldh", C.c_int), ("gate_act", C.c_int),
         ("gate_tag", C.c_uint32), ("gate_thr", C.c_uint32), ("gate_scale", C.c_float),
+        ("resid", _fp), ("ldr", C.c_int),
         ("out", _fp), ("ldo", C.c_int),
     ]
 

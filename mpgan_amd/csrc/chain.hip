@@ -34,12 +34,40 @@ __global__ __launch_bounds__(512, 1) void chain_kernel(const MpgChain p) {
     uint32_t seed_lo = 0, seed_hi = 0;
     if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
 
+    const int lane16 = lane * 16;
+    // Weight fragments come from L2 (~700 ns away): a wave keeps the first 8 k-steps of its NEXT tile in flight
+    // while it works on the current one -- the preload of layer l+1's tile is issued before layer l's MFMAs (the
+    // weights do not depend on the data), layer 0's before the input staging -- and refills each slot with
+    // k-step + 8 of the same tile right after using it.
+    V wbuf[2][8][2];
+    auto layer_geom = [&](int l, int& KS, int& MT, int& nfrag) {
+        const int QT = (p.L[l].K + 31) / 32;
+        KS = 2 * QT; MT = (p.L[l].N + 31) / 32; nfrag = MT * QT * 2;
+    };
+    auto wfrag = [&](int l, int tile, int ks, int part) {
+        int KS, MT, nfrag;
+        layer_geom(l, KS, MT, nfrag);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.L[l].Wimg), 0, 2 * nfrag * 1024, 0x00020000);
+        return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, (part * nfrag + tile * KS + min(ks, KS - 1)) * 1024, 0));
+    };
+    auto preload = [&](auto lc, int tile) {
+        MPG_CI(l, lc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { wbuf[l & 1][u][0] = wfrag(l, tile, u, 0); wbuf[l & 1][u][1] = wfrag(l, tile, u, 1); }
+    };
+    {
+        int KS, MT, nfrag;
+        layer_geom(0, KS, MT, nfrag);
+        if (w < MT) preload(std::integral_constant<int, 0>{}, w);
+    }
+
     // ---- stage the input rows as B fragments: unit = (k-step, lane) = 8 features of one row
     {
         const int K = p.L[0].K, KS = 2 * ((K + 31) / 32);
         V* fb = reinterpret_cast<V*>(smem);
         const bool vec1 = (p.lda % 4 == 0) && (p.K1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0) &&
                           (p.a_slab_stride % 4 == 0);
+        const bool vec2 = p.A2 != nullptr && (p.lda2 % 4 == 0) && (p.K1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.A2) & 15) == 0);
         for (int u = tid; u < KS * 64; u += 512) {
             const int ks = u >> 6, ln = u & 63, rr = ln & 31, hh = ln >> 5;
             const int m = m0 + rr;
@@ -54,6 +82,9 @@ __global__ __launch_bounds__(512, 1) void chain_kernel(const MpgChain p) {
                             const float4 t = chld4(p.A + sl * p.a_slab_stride + (size_t)m * p.lda + f);
                             x4[0] += t.x; x4[1] += t.y; x4[2] += t.z; x4[3] += t.w;
                         }
+                    } else if (vec2 && f >= p.K1 && f + 4 <= K) {
+                        const float4 t = chld4(p.A2 + (size_t)m * p.lda2 + (f - p.K1));
+                        x4[0] = t.x; x4[1] = t.y; x4[2] = t.z; x4[3] = t.w;
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -85,108 +116,122 @@ __global__ __launch_bounds__(512, 1) void chain_kernel(const MpgChain p) {
             fb[(ks * 2 + 1) * 64 + ln] = lo;
         }
     }
-    __syncthreads();
 
-    const int lane16 = lane * 16;
-    for (int l = 0; l < p.nlayers; ++l) {
-        const MpgChainLayer& L = p.L[l];
-        const V* fin = reinterpret_cast<const V*>(smem + (l & 1) * CH_FB_BYTES);
-        V* fout = reinterpret_cast<V*>(smem + ((l + 1) & 1) * CH_FB_BYTES);
-        const int QT = (L.K + 31) / 32, KS = 2 * QT, MT = (L.N + 31) / 32;
-        const int nfrag = MT * QT * 2;
-        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(L.Wimg), 0, 2 * nfrag * 1024, 0x00020000);
-        const bool last = l + 1 == p.nlayers;
-        for (int tile = w; tile < MT; tile += 8) {
-            f32x16 acc;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = 32 * tile + 8 * g + 4 * h;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[4 * g + t] = (L.bias != nullptr && n + t < (L.nbias ? L.nbias : L.N)) ? L.bias[n + t] : 0.f;
-            }
-            // weight fragments: ring of 4 k-steps (hi, lo) ahead of the MFMAs; past the end the loads are clamped
-            const int f0 = tile * KS;
-            V wh[4], wl[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ks = min(u, KS - 1);
-                wh[u] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, (f0 + ks) * 1024, 0));
-                wl[u] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, (nfrag + f0 + ks) * 1024, 0));
-            }
-            for (int k0 = 0; k0 < KS; k0 += 4) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int ks = k0 + u;
-                    if (ks < KS) {
-                        const V bh = fin[(ks * 2 + 0) * 64 + lane], bl = fin[(ks * 2 + 1) * 64 + lane];
-                        acc = mfma3(wh[u], wl[u], bh, bl, acc);
-                        const int kn = min(ks + 4, KS - 1);
-                        wh[u] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, (f0 + kn) * 1024, 0));
-                        wl[u] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, (nfrag + f0 + kn) * 1024, 0));
-                    }
+    __syncthreads();  // input fragments staged
+
+    static_for<0, 3>([&](auto lc) {
+        MPG_CI(l, lc);
+        if (l < p.nlayers) {
+            const MpgChainLayer& L = p.L[l];
+            const V* fin = reinterpret_cast<const V*>(smem + (l & 1) * CH_FB_BYTES);
+            V* fout = reinterpret_cast<V*>(smem + ((l + 1) & 1) * CH_FB_BYTES);
+            int KS, MT, nfrag;
+            layer_geom(l, KS, MT, nfrag);
+            const bool last = l + 1 == p.nlayers;
+            if constexpr (l + 1 < 3) {
+                if (!last) {
+                    int KSn, MTn, nfn;
+                    layer_geom(l + 1, KSn, MTn, nfn);
+                    if (w < MTn) preload(std::integral_constant<int, l + 1>{}, w);
                 }
             }
-            // ---- epilogue: register 4g+t  <->  feature 32 tile + 8g + 4h + t of row m0 + r
-            const int m = m0 + r;
-            float v[16];
+            for (int tile = w; tile < MT; tile += 8) {
+                if (tile != w) preload(lc, tile);  // more than 8 tiles in a layer: later tiles load late
+                f32x16 acc;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = 32 * tile + 8 * g + 4 * h;
-                float x4[4];
+                for (int g = 0; g < 4; ++g) {
+                    const int n = 32 * tile + 8 * g + 4 * h;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float x = acc[4 * g + t];
-                    if (L.act) x = lrelu(x, p.alpha);
-                    x4[t] = x;
+                    for (int t = 0; t < 4; ++t) acc[4 * g + t] = (L.bias != nullptr && n + t < (L.nbias ? L.nbias : L.N)) ? L.bias[n + t] : 0.f;
                 }
-                if (L.drop_thr) {
+                // the gate operand (an activation saved by the forward, in HBM) is requested before the MFMAs
+                float hv[16];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        x4[t] = drop_keep_f(seed_lo, seed_hi, L.drop_tag, (uint32_t)m, n + t, L.drop_thr) ? x4[t] * L.drop_scale : 0.f;
-                }
-                if (L.gateH != nullptr) {  // backward through (dropout o LeakyReLU) of the layer that produced H
-                    float hv[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (m < p.M) {
+                for (int k = 0; k < 16; ++k) hv[k] = 0.f;
+                if (L.gateH != nullptr && m0 + r < p.M) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = 32 * tile + 8 * g + 4 * h;
                         if (n + 4 <= L.N && (L.ldh % 4 == 0)) {
-                            const float4 t4 = chld4(L.gateH + (size_t)m * L.ldh + n);
-                            hv[0] = t4.x; hv[1] = t4.y; hv[2] = t4.z; hv[3] = t4.w;
+                            const float4 t4 = chld4(L.gateH + (size_t)(m0 + r) * L.ldh + n);
+                            hv[4 * g + 0] = t4.x; hv[4 * g + 1] = t4.y; hv[4 * g + 2] = t4.z; hv[4 * g + 3] = t4.w;
                         } else {
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) if (n + t < L.N) hv[t] = L.gateH[(size_t)m * L.ldh + n + t];
+                            for (int t = 0; t < 4; ++t) if (n + t < L.N) hv[4 * g + t] = L.gateH[(size_t)(m0 + r) * L.ldh + n + t];
+                        }
+                    }
+                }
+                // B fragments (activations, LDS) are read one k-step ahead of their MFMAs
+                V bh = fin[0 * 64 + lane], bl = fin[1 * 64 + lane];
+                for (int k0 = 0; k0 < KS; k0 += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int ks = k0 + u;
+                        if (ks < KS) {
+                            const int kn = min(ks + 1, KS - 1);
+                            const V nh = fin[(kn * 2 + 0) * 64 + lane], nl = fin[(kn * 2 + 1) * 64 + lane];
+                            acc = mfma3(wbuf[l & 1][u][0], wbuf[l & 1][u][1], bh, bl, acc);
+                            bh = nh; bl = nl;
+                            if (ks + 8 < KS) { wbuf[l & 1][u][0] = wfrag(l, tile, ks + 8, 0); wbuf[l & 1][u][1] = wfrag(l, tile, ks + 8, 1); }
+                        }
+                    }
+                }
+                // ---- epilogue: register 4g+t  <->  feature 32 tile + 8g + 4h + t of row m0 + r
+                const int m = m0 + r;
+                float v[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = 32 * tile + 8 * g + 4 * h;
+                    float x4[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float x = acc[4 * g + t];
+                        if (L.act) x = lrelu(x, p.alpha);
+                        x4[t] = x;
+                    }
+                    if (L.drop_thr) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            x4[t] = drop_keep_f(seed_lo, seed_hi, L.drop_tag, (uint32_t)m, n + t, L.drop_thr) ? x4[t] * L.drop_scale : 0.f;
+                    }
+                    if (L.gateH != nullptr) {  // backward through (dropout o LeakyReLU) of the layer that produced H
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            float gt = L.gate_act ? lrelu_grad(hv[4 * g + t], p.alpha) : 1.f;
+                            if (L.gate_thr) gt = drop_keep_f(seed_lo, seed_hi, L.gate_tag, (uint32_t)m, n + t, L.gate_thr) ? gt * L.gate_scale : 0.f;
+                            x4[t] *= gt;
+                        }
+                    }
+                    if (L.resid != nullptr && m < p.M) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) if (n + t < L.N) x4[t] += L.resid[(size_t)m * L.ldr + n + t];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (n + t >= L.N || m >= p.M) x4[t] = 0.f;  // padding stays exactly zero
+                    if (L.out != nullptr && m < p.M) {
+                        float* dst = L.out + (size_t)m * L.ldo + n;
+                        if (n + 4 <= L.N && (L.ldo % 4 == 0)) *reinterpret_cast<float4*>(dst) = make_float4(x4[0], x4[1], x4[2], x4[3]);
+                        else {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) if (n + t < L.N) dst[t] = x4[t];
                         }
                     }
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        float gt = L.gate_act ? lrelu_grad(hv[t], p.alpha) : 1.f;
-                        if (L.gate_thr) gt = drop_keep_f(seed_lo, seed_hi, L.gate_tag, (uint32_t)m, n + t, L.gate_thr) ? gt * L.gate_scale : 0.f;
-                        x4[t] *= gt;
-                    }
+                    for (int t = 0; t < 4; ++t) v[4 * g + t] = x4[t];
                 }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) if (n + t >= L.N || m >= p.M) x4[t] = 0.f;  // padding stays exactly zero
-                if (L.out != nullptr && m < p.M) {
-                    float* dst = L.out + (size_t)m * L.ldo + n;
-                    if (n + 4 <= L.N && (L.ldo % 4 == 0)) *reinterpret_cast<float4*>(dst) = make_float4(x4[0], x4[1], x4[2], x4[3]);
-                    else {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) if (n + t < L.N) dst[t] = x4[t];
-                    }
+                if (!last) {  // registers 8s .. 8s+7 are the B fragment of k-step (2 tile + s) of the next layer
+                    V hi, lo;
+                    split8(v, hi, lo);
+                    fout[((2 * tile + 0) * 2 + 0) * 64 + lane] = hi;
+                    fout[((2 * tile + 0) * 2 + 1) * 64 + lane] = lo;
+                    split8(v + 8, hi, lo);
+                    fout[((2 * tile + 1) * 2 + 0) * 64 + lane] = hi;
+                    fout[((2 * tile + 1) * 2 + 1) * 64 + lane] = lo;
                 }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) v[4 * g + t] = x4[t];
             }
-            if (!last) {  // registers 8s .. 8s+7 are the B fragment of k-step (2 tile + s) of the next layer
-                V hi, lo;
-                split8(v, hi, lo);
-                fout[((2 * tile + 0) * 2 + 0) * 64 + lane] = hi;
-                fout[((2 * tile + 0) * 2 + 1) * 64 + lane] = lo;
-                split8(v + 8, hi, lo);
-                fout[((2 * tile + 1) * 2 + 0) * 64 + lane] = hi;
-                fout[((2 * tile + 1) * 2 + 1) * 64 + lane] = lo;
-            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
+    });
 }
 
 struct PackJobs { MpgPackJob j[MPG_PACK_MAX_JOBS]; int n; int frag0[MPG_PACK_MAX_JOBS + 1]; };

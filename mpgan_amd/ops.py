@@ -258,6 +258,8 @@ def chain(M, layers, *, A, lda, K1, A2=None, lda2=0, a_slabs=1, a_slab_stride=0,
             L.gateH, L.ldh, L.gate_act = _p(H), H.stride(0), int(gact)
             if thr:
                 L.gate_tag, L.gate_thr, L.gate_scale = tag, thr, scale
+        if d.get("resid") is not None:
+            L.resid, L.ldr = _p(d["resid"]), d["resid"].stride(0)
         if d.get("out") is not None:
             L.out, L.ldo = _p(d["out"]), d["out"].stride(0)
     check(_lib.lib().mpg_chain(C.byref(c), _stream()), "mpg_chain")
@@ -424,9 +426,10 @@ class FusedMPLayerFn(torch.autograd.Function):
             linear_bwd_weight(dc, x2, out=dW1, out_col0=F)
         dx = None
         if need_x:
-            dx = dh0[:, H3:].contiguous()
-            linear_bwd_data(da, W1, w_cols=F, out=dx, accumulate=True)
-            linear_bwd_data(dc, W1, w_col0=F, w_cols=F, out=dx, accumulate=True)
+            # dx = dx(node path) + [da | dc] [W1a ; W1c]: one chained layer over the stacked transposed view
+            dx = torch.empty((V, F), device=dev, dtype=torch.float32)
+            chain(V, [dict(img=pk.ptr("W1ST"), K=2 * H1, N=F, resid=dh0[:, H3:], out=dx)],
+                  A=dap, lda=H1, K1=H1, a_slabs=SC, a_slab_stride=V * H1, A2=dc, lda2=dc.stride(0), alpha=alpha, f16=False)
             dx = dx.reshape(B, N, F)
         return (dx, None, dW1, db1, dW2, db2, dW3, db3, dV1, dc1, dV2, dc2, dV3, dc3,
                 None, None, None, None, None)
