@@ -54,6 +54,15 @@ int mpg_gemm(const MpgGemm* g, int ak, int bk, int splitk, void* stream);
 int mpg_splitk_reduce(const float* part, int S, int N, int K, int has_bias, float* out, int ldo, float* bias,
                       void* stream);
 
+/* Several weight-gradient GEMMs (dW = dY^T X: AK = BK = 0, split-K partials) / their split-K reductions in ONE
+ * launch each: the six weight gradients of an MPLayer are each too small to fill the chip on their own. */
+#define MPG_GROUP_MAX 8
+typedef struct MpgReduceJob {
+    const float* part; int S, N, K, has_bias; float* out; int ldo; float* bias;
+} MpgReduceJob;
+int mpg_gemm_wgrad_group(const MpgGemm* g, const int* splitk, int n, void* stream);
+int mpg_splitk_reduce_group(const MpgReduceJob* jobs, int n, void* stream);
+
 /* out = in * gate(H): backward through Dropout (and LeakyReLU when gate_act) ahead of a GEMM. */
 int mpg_gate(const float* in, int ldi, const float* H, int ldh, float* out, int ldo, int M, int N,
              int gate_act, float alpha, const uint64_t* seed, uint32_t tag, uint32_t thr, float scale,

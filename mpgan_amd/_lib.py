@@ -81,6 +81,13 @@ class MpgEdgeDw(C.Structure):
     ]
 
 
+class MpgReduceJob(C.Structure):
+    _fields_ = [
+        ("part", _fp), ("S", C.c_int), ("N", C.c_int), ("K", C.c_int), ("has_bias", C.c_int),
+        ("out", _fp), ("ldo", C.c_int), ("bias", _fp),
+    ]
+
+
 class MpgPackJob(C.Structure):
     _fields_ = [
         ("W", _fp), ("ldw", C.c_int), ("rows", C.c_int), ("cols", C.c_int), ("transpose", C.c_int),
@@ -125,6 +132,8 @@ class MpgAttn(C.Structure):
 SIGNATURES = {
     "mpg_gemm": (C.c_int, [C.POINTER(MpgGemm), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mpg_splitk_reduce": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_void_p]),
+    "mpg_gemm_wgrad_group": (C.c_int, [C.POINTER(MpgGemm), C.POINTER(C.c_int), C.c_int, C.c_void_p]),
+    "mpg_splitk_reduce_group": (C.c_int, [C.POINTER(MpgReduceJob), C.c_int, C.c_void_p]),
     "mpg_gate": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                            _fp, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]),
     "mpg_dropout_mask": (C.c_int, [_fp, C.c_uint64, C.c_int, _fp, C.c_uint32, C.c_uint32, C.c_void_p]),

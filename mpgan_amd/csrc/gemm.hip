@@ -83,18 +83,17 @@ MPG_DEV void tile_store(const float (&v)[8], V (*hi)[2][64], V (*lo)[2][64], int
 }
 
 template <bool AK, bool BK, bool F16>
-__global__ __launch_bounds__(256) void gemm_kernel(const MpgGemm g) {
+MPG_DEV void gemm_body(const MpgGemm& g, const int bx, const int by, const int bz, const int nz) {
     typedef typename FragT<F16>::type V;
     __shared__ V As_hi[2][2][64], As_lo[2][2][64], Bs_hi[2][2][64], Bs_lo[2][2][64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = by * 64, n0 = bx * 64;
     // split-K range of this z-slice (multiples of 32)
-    const int nz = gridDim.z;
     const int ktiles = (g.K + 31) / 32;
     const int per = (ktiles + nz - 1) / nz;
-    const int kbeg = blockIdx.z * per * 32;
-    const int kend_z = min(g.K, (int)(blockIdx.z + 1) * per * 32);
+    const int kbeg = bz * per * 32;
+    const int kend_z = min(g.K, (bz + 1) * per * 32);
     const bool a_vec = AK && (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
     const bool b_vec = BK && (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
 
@@ -128,8 +127,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const MpgGemm g) {
     if (n >= g.N) return;
     uint32_t seed_lo = 0, seed_hi = 0;
     if (g.seed != nullptr) { const uint64_t sd = *g.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
-    const float bias = (g.bias != nullptr && blockIdx.z == 0) ? g.bias[n] : 0.f;
-    float* Cz = g.C + (size_t)blockIdx.z * g.split_stride;
+    const float bias = (g.bias != nullptr && bz == 0) ? g.bias[n] : 0.f;
+    float* Cz = g.C + (size_t)bz * g.split_stride;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + 32 * wr + 8 * (r >> 2) + 4 * h + (r & 3);
@@ -152,6 +151,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(const MpgGemm g) {
         if (g.accumulate) v += *dst;
         *dst = v;
     }
+}
+
+template <bool AK, bool BK, bool F16>
+__global__ __launch_bounds__(256) void gemm_kernel(const MpgGemm g) {
+    gemm_body<AK, BK, F16>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z);
+}
+
+// Several independent weight-gradient GEMMs (dW = dY^T X, split-K) in ONE launch: each of these is a few hundred
+// short workgroups that cannot fill the chip or hide their own latencies; side by side they do.
+struct GemmGroup { MpgGemm g[MPG_GROUP_MAX]; int splitk[MPG_GROUP_MAX]; int wg0[MPG_GROUP_MAX + 1]; int n; };
+template <bool F16>
+__global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup G) {
+    int q = 0;
+    while ((int)blockIdx.x >= G.wg0[q + 1]) ++q;
+    const MpgGemm& g = G.g[q];
+    const int local = blockIdx.x - G.wg0[q];
+    const int tx = (g.N + 63) / 64, ty = (g.M + 63) / 64;
+    gemm_body<false, false, F16>(g, local % tx, (local / tx) % ty, local / (tx * ty), G.splitk[q]);
+}
+
+struct ReduceGroup { MpgReduceJob j[MPG_GROUP_MAX]; int blk0[MPG_GROUP_MAX + 1]; int n; };
+__global__ void splitk_reduce_group_kernel(const ReduceGroup R) {
+    int q = 0;
+    while ((int)blockIdx.x >= R.blk0[q + 1]) ++q;
+    const MpgReduceJob& J = R.j[q];
+    const int idx = (blockIdx.x - R.blk0[q]) * blockDim.x + threadIdx.x;
+    const int ldp = J.K + J.has_bias;
+    if (idx >= J.N * ldp) return;
+    const int n = idx / ldp, k = idx % ldp;
+    float s = 0.f;
+    for (int z = 0; z < J.S; ++z) s += J.part[(size_t)z * J.N * ldp + idx];
+    if (k < J.K) J.out[(size_t)n * J.ldo + k] = s;
+    else if (J.bias != nullptr) J.bias[n] = s;
 }
 
 // out[m,n] = in[m,n] * gate(H[m,n]) : the elementwise "backward through dropout (and leaky
@@ -214,6 +246,37 @@ extern "C" int mpg_gemm(const MpgGemm* g, int ak, int bk, int splitk, void* stre
     else if (!ak && !bk) MPG_LAUNCH(false, false);
     else MPG_LAUNCH(false, true);
 #undef MPG_LAUNCH
+    return (int)hipGetLastError();
+}
+
+extern "C" int mpg_gemm_wgrad_group(const MpgGemm* g, const int* splitk, int n, void* stream) {
+    if (n < 1 || n > MPG_GROUP_MAX) return -1;
+    GemmGroup G;
+    G.n = n;
+    G.wg0[0] = 0;
+    for (int q = 0; q < n; ++q) {
+        if (g[q].M <= 0 || g[q].N <= 0 || g[q].K < 0 || splitk[q] < 1 || g[q].f16 != g[0].f16) return -1;
+        G.g[q] = g[q];
+        G.splitk[q] = splitk[q];
+        G.wg0[q + 1] = G.wg0[q] + ((g[q].N + 63) / 64) * ((g[q].M + 63) / 64) * splitk[q];
+    }
+    if (g[0].f16) hipLaunchKernelGGL((gemm_group_kernel<true>), dim3(G.wg0[n]), dim3(256), 0, (hipStream_t)stream, G);
+    else hipLaunchKernelGGL((gemm_group_kernel<false>), dim3(G.wg0[n]), dim3(256), 0, (hipStream_t)stream, G);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mpg_splitk_reduce_group(const MpgReduceJob* jobs, int n, void* stream) {
+    if (n < 1 || n > MPG_GROUP_MAX) return -1;
+    ReduceGroup R;
+    R.n = n;
+    R.blk0[0] = 0;
+    for (int q = 0; q < n; ++q) {
+        R.j[q] = jobs[q];
+        const int tot = jobs[q].N * (jobs[q].K + jobs[q].has_bias);
+        R.blk0[q + 1] = R.blk0[q] + (tot + 255) / 256;
+    }
+    if (R.blk0[n] == 0) return 0;
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(R.blk0[n]), dim3(256), 0, (hipStream_t)stream, R);
     return (int)hipGetLastError();
 }
 

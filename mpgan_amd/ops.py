@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import MpgGemm, MpgEdgeFwd, MpgEdgeBwd, MpgEdgeDw, MpgPackJob, MpgChain, check
+from ._lib import MpgGemm, MpgEdgeFwd, MpgEdgeBwd, MpgEdgeDw, MpgPackJob, MpgChain, MpgReduceJob, check
 
 H1, H2, H3 = 96, 160, 192
 TAG_E0, TAG_E1, TAG_E2, TAG_N0, TAG_N1, TAG_N2, TAG_GENERIC = 1, 2, 3, 4, 5, 6, 7
@@ -151,6 +151,45 @@ def linear_bwd_weight(dy, x, *, out=None, out_col0=0, out_scale=1.0, bias_out=No
     check(_lib.lib().mpg_splitk_reduce(_p(part), splitk, N, K, hb, _p(out, out_col0), out.stride(0), _p(bias_out),
                                        _stream()), "mpg_splitk_reduce")
     return out
+
+
+class WgradBatch:
+    """Weight gradients dW[:, col0:col0+K] = scale * dy^T @ x (+ bias = column sums of dy) collected and issued as
+    ONE grouped split-K GEMM launch plus ONE grouped reduction (``linear_bwd_weight`` does one at a time)."""
+
+    def __init__(self):
+        self.jobs = []
+
+    def add(self, dy, x, *, out, out_col0=0, out_scale=1.0, bias_out=None):
+        M, N = dy.shape
+        K = x.shape[1]
+        hb = int(bias_out is not None)
+        tiles = ((N + 63) // 64) * ((K + hb + 63) // 64)
+        splitk = max(1, min((M + 255) // 256, (1024 + tiles - 1) // tiles))
+        part = torch.empty((splitk, N, K + hb), device=dy.device, dtype=torch.float32)
+        self.jobs.append((dy, x, out, out_col0, out_scale, bias_out, splitk, part))
+
+    def flush(self):
+        for i0 in range(0, len(self.jobs), 8):
+            jobs = self.jobs[i0:i0 + 8]
+            n = len(jobs)
+            gs, sk, rj = (MpgGemm * n)(), (C.c_int * n)(), (MpgReduceJob * n)()
+            for i, (dy, x, out, col0, scale, bias_out, splitk, part) in enumerate(jobs):
+                M, N = dy.shape
+                K = x.shape[1]
+                hb = int(bias_out is not None)
+                g = gs[i]
+                g.A, g.lda, g.B, g.ldb = _p(dy), dy.stride(0), _p(x), x.stride(0)
+                g.C, g.ldc = _p(part), K + hb
+                g.M, g.N, g.K = N, K + hb, M
+                g.split_stride, g.out_scale, g.alpha, g.ones_col = N * (K + hb), scale, 0.2, hb
+                sk[i] = splitk
+                r = rj[i]
+                r.part, r.S, r.N, r.K, r.has_bias = _p(part), splitk, N, K, hb
+                r.out, r.ldo, r.bias = _p(out, col0), out.stride(0), _p(bias_out)
+            check(_lib.lib().mpg_gemm_wgrad_group(gs, sk, n, _stream()), "mpg_gemm_wgrad_group")
+            check(_lib.lib().mpg_splitk_reduce_group(rj, n, _stream()), "mpg_splitk_reduce_group")
+        self.jobs = []
 
 
 def gate(g, H, *, gate_act, alpha, seed_t=None, tag=0, thr=0, scale=1.0):
@@ -366,13 +405,14 @@ class FusedMPLayerFn(torch.autograd.Function):
               A=gy2, lda=gy2.stride(0), K1=out_f, in_gate=(tag + TAG_N2, thr, dscale), in_out=dz3 if thr else None,
               alpha=alpha, seed_t=seed_t, f16=False)
         dV1 = dV2 = dV3 = dc1 = dc2 = dc3 = None
+        wb = WgradBatch()  # all six weight gradients of the layer go out as one grouped launch (below)
         if need_w:
             dc3, dc2, dc1 = (torch.empty(t.shape[1], device=dev, dtype=torch.float32) for t in (dz3, dz2, dz1))
-            dV3 = linear_bwd_weight(dz3, h2, bias_out=dc3)
-            dV2 = linear_bwd_weight(dz2, h1, bias_out=dc2)
-            dV1 = torch.empty_like(V1)
-            linear_bwd_weight(dz1, agg, out=dV1, out_col0=0, bias_out=dc1)
-            linear_bwd_weight(dz1, x2, out=dV1, out_col0=H3)
+            dV3, dV2, dV1 = torch.empty_like(V3), torch.empty_like(V2), torch.empty_like(V1)
+            wb.add(dz3, h2, out=dV3, bias_out=dc3)
+            wb.add(dz2, h1, out=dV2, bias_out=dc2)
+            wb.add(dz1, agg, out=dV1, out_col0=0, bias_out=dc1)
+            wb.add(dz1, x2, out=dV1, out_col0=H3)
 
         # ---- edge network backward: data path, then (if wanted) the weight-gradient pass
         RB = (N + 31) // 32
@@ -422,8 +462,9 @@ class FusedMPLayerFn(torch.autograd.Function):
             # layer 1 (fe.net.0): a = W1[:, :F] x + b1, c = W1[:, F:] x
             dW1 = torch.empty_like(W1)
             db1 = torch.empty(H1, device=dev, dtype=torch.float32)
-            linear_bwd_weight(da, x2, out=dW1, out_col0=0, bias_out=db1)
-            linear_bwd_weight(dc, x2, out=dW1, out_col0=F)
+            wb.add(da, x2, out=dW1, out_col0=0, bias_out=db1)
+            wb.add(dc, x2, out=dW1, out_col0=F)
+            wb.flush()
         dx = None
         if need_x:
             # dx = dx(node path) + [da | dc] [W1a ; W1c]: one chained layer over the stacked transposed view
