@@ -59,6 +59,7 @@ int mpg_splitk_reduce(const float* part, int S, int N, int K, int has_bias, floa
 #define MPG_GROUP_MAX 8
 typedef struct MpgReduceJob {
     const float* part; int S, N, K, has_bias; float* out; int ldo; float* bias;
+    int accumulate;      /* add to out / bias instead of overwriting (gradient accumulation into .grad) */
 } MpgReduceJob;
 int mpg_gemm_wgrad_group(const MpgGemm* g, const int* splitk, int n, void* stream);
 int mpg_splitk_reduce_group(const MpgReduceJob* jobs, int n, void* stream);
@@ -185,6 +186,7 @@ typedef struct MpgEdgeDw {
     const void* stageE2; const void* stageZ2;
     float* part; int nwg;
     float* dW3; float* dW2; float* db3; float* db2;
+    int accumulate;                       /* add to dW3 / dW2 / db3 / db2 instead of overwriting */
     int B, N;
     float alpha, agg_scale;
     const uint64_t* seed; uint32_t tag_base, thr; float dscale;

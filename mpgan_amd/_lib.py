@@ -73,7 +73,7 @@ class MpgEdgeDw(C.Structure):
         ("dagg", _fp), ("ld_dagg", C.c_int),
         ("sign3", _fp), ("stageE2", _fp), ("stageZ2", _fp),
         ("part", _fp), ("nwg", C.c_int),
-        ("dW3", _fp), ("dW2", _fp), ("db3", _fp), ("db2", _fp),
+        ("dW3", _fp), ("dW2", _fp), ("db3", _fp), ("db2", _fp), ("accumulate", C.c_int),
         ("B", C.c_int), ("N", C.c_int),
         ("alpha", C.c_float), ("agg_scale", C.c_float),
         ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
@@ -84,7 +84,7 @@ class MpgEdgeDw(C.Structure):
 class MpgReduceJob(C.Structure):
     _fields_ = [
         ("part", _fp), ("S", C.c_int), ("N", C.c_int), ("K", C.c_int), ("has_bias", C.c_int),
-        ("out", _fp), ("ldo", C.c_int), ("bias", _fp),
+        ("out", _fp), ("ldo", C.c_int), ("bias", _fp), ("accumulate", C.c_int),
     ]
 
 

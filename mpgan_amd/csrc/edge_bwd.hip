@@ -745,7 +745,7 @@ __global__ __launch_bounds__(512, 1) void edge_dw_kernel(const MpgEdgeDw p) {
 
 // out = scale * sum over workgroup partials, feature indices mapped back from fragment order.
 // 32 outputs x 8 partial-slices per block: the 256 partials of an output are read by 8 threads.
-__global__ __launch_bounds__(256) void edge_dw_reduce(const float* __restrict__ part, int nwg, float scale,
+__global__ __launch_bounds__(256) void edge_dw_reduce(const float* __restrict__ part, int nwg, float scale, int accumulate,
                                                       float* __restrict__ dW3, float* __restrict__ dW2,
                                                       float* __restrict__ db3, float* __restrict__ db2) {
     __shared__ float red[8][32];
@@ -762,14 +762,18 @@ __global__ __launch_bounds__(256) void edge_dw_reduce(const float* __restrict__ 
     for (int k = 1; k < 8; ++k) s += red[k][ix];
     if (idx < H3 * H2) {
         const int r3 = idx / H2, c2 = idx % H2;
-        dW3[feat_of_fi(r3) * H2 + feat_of_fi(c2)] = s * scale;
+        float* d = dW3 + feat_of_fi(r3) * H2 + feat_of_fi(c2);
+        *d = s * scale + (accumulate ? *d : 0.f);
     } else if (idx < H3 * H2 + H2 * H1) {
         const int k = idx - H3 * H2, r2 = k / H1, c1 = k % H1;
-        dW2[feat_of_fi(r2) * H1 + feat_of_fi(c1)] = s * scale;
+        float* d = dW2 + feat_of_fi(r2) * H1 + feat_of_fi(c1);
+        *d = s * scale + (accumulate ? *d : 0.f);
     } else if (idx < H3 * H2 + H2 * H1 + H3) {
-        db3[feat_of_fi(idx - H3 * H2 - H2 * H1)] = s;
+        float* d = db3 + feat_of_fi(idx - H3 * H2 - H2 * H1);
+        *d = s + (accumulate ? *d : 0.f);
     } else {
-        db2[feat_of_fi(idx - H3 * H2 - H2 * H1 - H3)] = s;
+        float* d = db2 + feat_of_fi(idx - H3 * H2 - H2 * H1 - H3);
+        *d = s + (accumulate ? *d : 0.f);
     }
 }
 
@@ -841,7 +845,7 @@ extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
 #undef MPG_DW_H
 #undef MPG_DW_ONE
     constexpr int PER = H3 * H2 + H2 * H1 + H3 + H2;
-    hipLaunchKernelGGL(edge_dw_reduce, dim3((PER + 31) / 32), dim3(256), 0, st, p->part, p->nwg, p->dscale, p->dW3,
+    hipLaunchKernelGGL(edge_dw_reduce, dim3((PER + 31) / 32), dim3(256), 0, st, p->part, p->nwg, p->dscale, p->accumulate, p->dW3,
                        p->dW2, p->db3, p->db2);
     return (int)hipGetLastError();
 }

@@ -182,8 +182,8 @@ __global__ void splitk_reduce_group_kernel(const ReduceGroup R) {
     const int n = idx / ldp, k = idx % ldp;
     float s = 0.f;
     for (int z = 0; z < J.S; ++z) s += J.part[(size_t)z * J.N * ldp + idx];
-    if (k < J.K) J.out[(size_t)n * J.ldo + k] = s;
-    else if (J.bias != nullptr) J.bias[n] = s;
+    if (k < J.K) { float* d = J.out + (size_t)n * J.ldo + k; *d = s + (J.accumulate ? *d : 0.f); }
+    else if (J.bias != nullptr) J.bias[n] = s + (J.accumulate ? J.bias[n] : 0.f);
 }
 
 // out[m,n] = in[m,n] * gate(H[m,n]) : the elementwise "backward through dropout (and leaky

@@ -96,7 +96,8 @@ class MPLayer(nn.Module):
         params = tuple(l.weight for l in (*self.fe.net, *self.fn.net))
         pk = cache.get(key)
         if pk is None or any(a is not b for a, b in zip(pk.params, params)):
-            pk = cache[key] = ops.PackedMPLayer(params, self.input_node_size, self.output_node_size, *key)
+            plist = tuple(q for l in (*self.fe.net, *self.fn.net) for q in (l.weight, l.bias))
+            pk = cache[key] = ops.PackedMPLayer(params, self.input_node_size, self.output_node_size, *key, plist=plist)
         return pk
 
     def refresh_packed(self):

@@ -26,6 +26,11 @@ OPTIONS = {
     # forward products (they decide LeakyReLU signs) split as fp16 hi/lo (~2^-21 per product);
     # False = bf16 hi/lo (~2^-17, unlimited range).  Gradient products are always bf16 hi/lo.
     "fwd_f16": True,
+    # FusedMPLayerFn.backward adds the parameter gradients straight into ``param.grad`` (when that exists) and
+    # returns None for them, instead of handing twelve tensors to autograd's AccumulateGrad (one small add kernel
+    # per parameter and backward).  ``train.TrainStep`` switches it on; leave it off when ``torch.autograd.grad``,
+    # gradient hooks or anything else needs the gradients as autograd values.
+    "grad_into_param": False,
 }
 
 
@@ -160,21 +165,21 @@ class WgradBatch:
     def __init__(self):
         self.jobs = []
 
-    def add(self, dy, x, *, out, out_col0=0, out_scale=1.0, bias_out=None):
+    def add(self, dy, x, *, out, out_col0=0, out_scale=1.0, bias_out=None, accumulate=False):
         M, N = dy.shape
         K = x.shape[1]
         hb = int(bias_out is not None)
         tiles = ((N + 63) // 64) * ((K + hb + 63) // 64)
         splitk = max(1, min((M + 255) // 256, (1024 + tiles - 1) // tiles))
         part = torch.empty((splitk, N, K + hb), device=dy.device, dtype=torch.float32)
-        self.jobs.append((dy, x, out, out_col0, out_scale, bias_out, splitk, part))
+        self.jobs.append((dy, x, out, out_col0, out_scale, bias_out, splitk, part, accumulate))
 
     def flush(self):
         for i0 in range(0, len(self.jobs), 8):
             jobs = self.jobs[i0:i0 + 8]
             n = len(jobs)
             gs, sk, rj = (MpgGemm * n)(), (C.c_int * n)(), (MpgReduceJob * n)()
-            for i, (dy, x, out, col0, scale, bias_out, splitk, part) in enumerate(jobs):
+            for i, (dy, x, out, col0, scale, bias_out, splitk, part, acc) in enumerate(jobs):
                 M, N = dy.shape
                 K = x.shape[1]
                 hb = int(bias_out is not None)
@@ -186,7 +191,7 @@ class WgradBatch:
                 sk[i] = splitk
                 r = rj[i]
                 r.part, r.S, r.N, r.K, r.has_bias = _p(part), splitk, N, K, hb
-                r.out, r.ldo, r.bias = _p(out, col0), out.stride(0), _p(bias_out)
+                r.out, r.ldo, r.bias, r.accumulate = _p(out, col0), out.stride(0), _p(bias_out), int(acc)
             check(_lib.lib().mpg_gemm_wgrad_group(gs, sk, n, _stream()), "mpg_gemm_wgrad_group")
             check(_lib.lib().mpg_splitk_reduce_group(rj, n, _stream()), "mpg_splitk_reduce_group")
         self.jobs = []
@@ -232,8 +237,9 @@ class PackedMPLayer:
     through ``mpg_rmsprop`` -- must call ``refresh()`` themselves (TrainStep does, inside its graph segments).
     """
 
-    def __init__(self, params, F, out, dscale, f16):
+    def __init__(self, params, F, out, dscale, f16, plist=None):
         W1, W2, W3, V1, V2, V3 = params
+        self.plist = plist  # the twelve Parameters (W1, b1, ..., V3, c3) when built by MPLayer: .grad targets
         self.params, self.F, self.out, self.dscale, self.f16 = params, F, out, float(dscale), bool(f16)
         dev = W1.device
         KN = H3 + F
@@ -406,13 +412,19 @@ class FusedMPLayerFn(torch.autograd.Function):
               alpha=alpha, seed_t=seed_t, f16=False)
         dV1 = dV2 = dV3 = dc1 = dc2 = dc3 = None
         wb = WgradBatch()  # all six weight gradients of the layer go out as one grouped launch (below)
+        # OPTIONS["grad_into_param"]: add into the parameters' .grad buffers directly and return None for them
+        direct = (need_w and OPTIONS["grad_into_param"] and pk.plist is not None
+                  and all(q.grad is not None and q.grad.is_contiguous() for q in pk.plist))
         if need_w:
-            dc3, dc2, dc1 = (torch.empty(t.shape[1], device=dev, dtype=torch.float32) for t in (dz3, dz2, dz1))
-            dV3, dV2, dV1 = torch.empty_like(V3), torch.empty_like(V2), torch.empty_like(V1)
-            wb.add(dz3, h2, out=dV3, bias_out=dc3)
-            wb.add(dz2, h1, out=dV2, bias_out=dc2)
-            wb.add(dz1, agg, out=dV1, out_col0=0, bias_out=dc1)
-            wb.add(dz1, x2, out=dV1, out_col0=H3)
+            if direct:
+                gW1, gb1, gW2, gb2, gW3, gb3, dV1, dc1, dV2, dc2, dV3, dc3 = (q.grad for q in pk.plist)
+            else:
+                dc3, dc2, dc1 = (torch.empty(t.shape[1], device=dev, dtype=torch.float32) for t in (dz3, dz2, dz1))
+                dV3, dV2, dV1 = torch.empty_like(V3), torch.empty_like(V2), torch.empty_like(V1)
+            wb.add(dz3, h2, out=dV3, bias_out=dc3, accumulate=direct)
+            wb.add(dz2, h1, out=dV2, bias_out=dc2, accumulate=direct)
+            wb.add(dz1, agg, out=dV1, out_col0=0, bias_out=dc1, accumulate=direct)
+            wb.add(dz1, x2, out=dV1, out_col0=H3, accumulate=direct)
 
         # ---- edge network backward: data path, then (if wanted) the weight-gradient pass
         RB = (N + 31) // 32
@@ -444,15 +456,18 @@ class FusedMPLayerFn(torch.autograd.Function):
         if need_w:
             nwg = min(nblk, max(256, -(-nblk // 64)))  # one workgroup per CU; at most 64 blocks each
             part = torch.empty((nwg, H3 * H2 + H2 * H1 + H3 + H2), device=dev, dtype=torch.float32)
-            dW3, dW2 = torch.empty_like(W3), torch.empty_like(W2)
-            db3, db2 = torch.empty_like(b3), torch.empty_like(b2)
+            if direct:
+                dW3, dW2, db3, db2 = gW3, gW2, gb3, gb2
+            else:
+                dW3, dW2 = torch.empty_like(W3), torch.empty_like(W2)
+                db3, db2 = torch.empty_like(b3), torch.empty_like(b2)
             d = MpgEdgeDw()
             d.a, d.c, d.ld_ac, d.mask = _p(ac), _p(ac, H1), 2 * H1, _p(m1)
             d.dagg, d.ld_dagg = _p(dh0), dh0.stride(0)
             d.sign3 = C.c_void_p(sign3.data_ptr())
             d.stageE2, d.stageZ2 = C.c_void_p(stE2.data_ptr()), C.c_void_p(stZ2.data_ptr())
             d.part, d.nwg = _p(part), nwg
-            d.dW3, d.dW2, d.db3, d.db2 = _p(dW3), _p(dW2), _p(db3), _p(db2)
+            d.dW3, d.dW2, d.db3, d.db2, d.accumulate = _p(dW3), _p(dW2), _p(db3), _p(db2), int(direct)
             d.B, d.N = B, N
             d.alpha, d.agg_scale = alpha, 1.0 if sum_agg else 1.0 / N
             d.seed, d.tag_base, d.thr, d.dscale = _p(seed_t), tag, thr, dscale
@@ -460,11 +475,16 @@ class FusedMPLayerFn(torch.autograd.Function):
             check(_lib.lib().mpg_edge_dw(C.byref(d), _stream()), "mpg_edge_dw")
             del stE2, stZ2
             # layer 1 (fe.net.0): a = W1[:, :F] x + b1, c = W1[:, F:] x
-            dW1 = torch.empty_like(W1)
-            db1 = torch.empty(H1, device=dev, dtype=torch.float32)
-            wb.add(da, x2, out=dW1, out_col0=0, bias_out=db1)
-            wb.add(dc, x2, out=dW1, out_col0=F)
+            if direct:
+                dW1, db1 = gW1, gb1
+            else:
+                dW1 = torch.empty_like(W1)
+                db1 = torch.empty(H1, device=dev, dtype=torch.float32)
+            wb.add(da, x2, out=dW1, out_col0=0, bias_out=db1, accumulate=direct)
+            wb.add(dc, x2, out=dW1, out_col0=F, accumulate=direct)
             wb.flush()
+            if direct:  # already in .grad: autograd gets nothing to accumulate
+                dW1 = db1 = dW2 = db2 = dW3 = db3 = dV1 = dc1 = dV2 = dc2 = dV3 = dc3 = None
         dx = None
         if need_x:
             # dx = dx(node path) + [da | dc] [W1a ; W1c]: one chained layer over the stacked transposed view

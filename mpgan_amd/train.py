@@ -138,6 +138,8 @@ class TrainStep:
         return torch.randn(self.B, self.N, self.latent, device=self.dev) * self.noise_std
 
     def _seg_D(self):  # train_D up to and including backward (train.py:419-460)
+        # parameter gradients are added straight into the flat buffers (no AccumulateGrad kernel per parameter)
+        ops.OPTIONS["grad_into_param"] = True
         ops.bump_seed(self.dev)
         self.D.train(); self.G.eval()
         self.fD.zero_grad()
@@ -173,6 +175,7 @@ class TrainStep:
     def _seg_end(self):  # G_optimizer.step() (train.py:521)
         self.fG.rmsprop(self.lr_gen, gscale=1.0 / self.world)
         self._refresh_packed(self.G)
+        ops.OPTIONS["grad_into_param"] = False
 
     def _allreduce(self, flat: FlatParams):
         mdist.allreduce_sum_(flat.grad, self.pg, self.world)  # sum; 1/world is folded into rmsprop
