@@ -115,8 +115,13 @@ class TrainStep:
 
     def __init__(self, G: nn.Module, D: nn.Module, batch_size: int, num_particles: int, latent: int = 32,
                  lr_disc: float = 3e-5, lr_gen: float = 1e-5, noise_std: float = 0.2, use_graphs: bool = True,
-                 process_group=None, world_size: int = 1):
+                 process_group=None, world_size: int = 1, batch_real_fake: bool = True):
         self.G, self.D = G, D
+        # train_D evaluates D on the real and on the generated batch (train.py:432-447).  D has no cross-sample
+        # coupling (no batch norm), so one pass over the concatenated 2B jets gives the same outputs and the same
+        # summed gradients as the reference's two passes -- with half the launches and twice the workgroups per
+        # launch (jets have different multiplicities; more workgroups than CUs evens that out).
+        self.batch_real_fake = batch_real_fake
         self.B, self.N, self.latent = batch_size, num_particles, latent
         self.lr_disc, self.lr_gen, self.noise_std = lr_disc, lr_gen, noise_std
         self.pg, self.world = process_group, world_size
@@ -144,10 +149,14 @@ class TrainStep:
         self.D.train(); self.G.eval()
         self.fD.zero_grad()
         _set_requires_grad(self.D, True)
-        out_r = self.D(self.data.clone(), self.labels)
         with torch.no_grad():
             fake = self.G(self._noise(0), self.labels)
-        out_f = self.D(fake, self.labels)
+        if self.batch_real_fake:
+            out = self.D(torch.cat([self.data, fake], 0), torch.cat([self.labels, self.labels], 0))
+            out_r, out_f = out[: self.B], out[self.B:]
+        else:
+            out_r = self.D(self.data.clone(), self.labels)
+            out_f = self.D(fake, self.labels)
         loss = ((out_r - 1.0) ** 2).mean() + (out_f ** 2).mean()
         loss.backward()
         self.D_loss.copy_(loss.detach())

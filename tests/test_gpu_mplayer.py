@@ -231,8 +231,10 @@ def test_mplayer_dropout_exact(p_drop):
         rows = V * N if k.startswith("e") else V
         m = ops.dropout_mask(rows, wdt, tag + sites[k], thr).cpu().double()
         keeps[k] = m.reshape(B, N, N, wdt) if k.startswith("e") else m.reshape(B, N, wdt)
-        frac = float(m.mean())
-        assert abs(frac - (1 - thr / 256.0)) < 0.02, (k, frac)
+        frac, q = float(m.mean()), 1 - thr / 256.0
+        # statistical sanity of the counter hash: within 5 sigma of the keep probability (the site tags, hence the
+        # realisations, depend on how many fused ops ran before this test)
+        assert abs(frac - q) < max(0.01, 5 * (q * (1 - q) / m.numel()) ** 0.5), (k, frac)
     sdo = {"L." + k: v.clone().requires_grad_(True) for k, v in sd64.items()}
     xo = x64.clone().requires_grad_(True)
     yo = oracle.mplayer_forward(sdo, "L", xo, mask64, alpha=1.0, p=thr / 256.0, keeps=keeps)
