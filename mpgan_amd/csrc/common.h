@@ -77,6 +77,29 @@ MPG_DEV void split8(const float* v, V& hi, V& lo) {
         lo[j] = (E)(v[j] - (float)hh);
     }
 }
+// bf16 form: v_cvt_pk_bf16_f32 per PAIR (left to itself the compiler converts one element per instruction);
+// the residual is exact: f32(hi) is the packed half moved to the upper 16 bits.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+MPG_DEV uint32_t cvt_pk_bf16(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <>
+MPG_DEV void split8<bf16x8>(const float* v, bf16x8& hi, bf16x8& lo) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t h4, l4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t hp = cvt_pk_bf16(v[2 * j], v[2 * j + 1]);
+        const float r0 = v[2 * j] - __builtin_bit_cast(float, hp << 16);
+        const float r1 = v[2 * j + 1] - __builtin_bit_cast(float, hp & 0xffff0000u);
+        h4[j] = hp;
+        l4[j] = cvt_pk_bf16(r0, r1);
+    }
+    hi = __builtin_bit_cast(bf16x8, h4);
+    lo = __builtin_bit_cast(bf16x8, l4);
+}
 // fp16 form: per pair one v_cvt_pk_f16_f32 (RTNE) for hi, two v_fma_mix_f32 (x - f32(hi) straight from the
 // packed halves, exact) and one v_cvt_pk_f16_f32 for lo -- 2 VALU ops per element instead of 3.5.
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));

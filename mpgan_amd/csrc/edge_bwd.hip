@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
         // ---- dZ3 = m_j * dagg * keep3 * phi'(Z3), phi' from the forward's sign words
         bf16x8 z3hi[T3][2], z3lo[T3][2];
         {
+            const int slope_pos = __builtin_bit_cast(int, mjs), slope_neg = __builtin_bit_cast(int, mjs * p.alpha);
 #pragma unroll
             for (int m = 0; m < T3; ++m) {
                 float v[16];
@@ -203,10 +204,10 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                     const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        // sign bit of this lane's Z3 register (tile m, 4g+t): see the forward's epi3
+                        // sign bit of this lane's Z3 register (tile m, 4g+t): see the forward's epi3.  The slope
+                        // (alpha | 1) times m_j * dscale is one select between two wave-uniform constants.
                         const int neg = __builtin_amdgcn_sbfe((int)sw[m >> 1], 31 - (16 * (m & 1) + 4 * g + t), 1);
-                        const float d = mjs * dd[t], da = d * p.alpha;
-                        const float sel = __builtin_bit_cast(float, (neg & __builtin_bit_cast(int, da)) | (~neg & __builtin_bit_cast(int, d)));
+                        const float sel = dd[t] * __builtin_bit_cast(float, (neg & slope_neg) | (~neg & slope_pos));
                         v[4 * g + t] = drop_apply<DROP>(sel, wd, 8 * g + t, t, p.thr);
                     }
                 }
@@ -227,10 +228,13 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int k = 4 * g + t;
-                        // e2 of register k = element (k&7) of fragment k>>3: >0 -> 1, <0 -> alpha,
-                        // ==0 -> dropped (dropout on) or z == 0 (dropout off: slope alpha, as torch)
-                        const float e = (float)e2hi[mm][k >> 3][k & 7];
-                        const float gt = e > 0.f ? 1.f : (e < 0.f ? p.alpha : (DROP ? 0.f : p.alpha));
+                        // e2 of register k = element (k&7) of fragment k>>3, read off the packed 16-bit hi part:
+                        // sign clear -> slope 1, set -> alpha; all-zero magnitude = dropped (dropout on) -> 0
+                        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+                        const unsigned int wd2 = __builtin_bit_cast(u32x4_t, e2hi[mm][k >> 3])[(k & 7) >> 1];
+                        const int neg = __builtin_amdgcn_sbfe((int)wd2, 16 * (k & 1) + 15, 1);
+                        float gt = __builtin_bit_cast(float, (neg & __builtin_bit_cast(int, p.alpha)) | (~neg & 0x3f800000));
+                        if (DROP && __builtin_amdgcn_ubfe(wd2, 16 * (k & 1), 15) == 0u) gt = 0.f;
                         v2[k] = accs[(m + 1) & 1][k] * gt;
                     }
                     if (g == 1 || g == 3) {
