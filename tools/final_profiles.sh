@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round-end evidence: rocprofv3 kernel stats of the default bench, HBM traffic counters of the edge kernels,
+# and the MFMA issue/power micro-benchmarks.  Run on the GPU box from the repo root; results in gpurun_out/final.
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/final
+cd /tmp && export TMPDIR=/tmp
+out=$R/gpurun_out/final/bench_stats
+rm -rf $out
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o b -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/final/bench_under_rocprof.log 2>&1 || exit 1
+python3 $R/tools/prof_summary.py $out 30 > $R/gpurun_out/final/bench_stats_summary.txt
+echo "stats done"
+for c in FETCH_SIZE WRITE_SIZE; do
+  o=$R/gpurun_out/final/pmc_$c
+  rm -rf $o
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $o -o p -- python3 $R/tools/kbwd.py > $o.log 2>&1 || exit 1
+  for k in "edge_fwd_kernel<0" "edge_fwd_kernel<2" "edge_bwd_kernel<0, true, true" "edge_bwd_kernel<0, true, false" "edge_bwd_kernel<2, true, true" "edge_bwd_kernel<2, true, false" "edge_dw_kernel<0" "edge_dw_kernel<2" chain_kernel gemm_group_kernel; do
+    echo "== $c $k"; python3 $R/tools/pmc_summary.py $o "$k"
+  done
+done > $R/gpurun_out/final/pmc_summary.txt 2>&1
+echo "pmc done"
+cd $R
+(timeout -k 10 120 tools/ubench/mfma_model; timeout -k 10 120 tools/ubench/mfma_model2; timeout -k 10 120 tools/ubench/mfma_power) > gpurun_out/final/ubench.txt 2>&1
+echo "ubench done"

@@ -44,7 +44,7 @@ template <int RANDOM> void run(int grid, int iters) {
     long long c; (void)hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
     double n = (double)iters * 64;
     printf("%s operands, grid %4d, %6d MFMA/wave: %8.3f ms  %6.2f ns/MFMA  %6.2f clk/MFMA  -> %.0f TFLOP/s dense f16\n", RANDOM ? "random  " : "constant", grid,
-           iters * 64, ms, ms * 1e6 / n, c / n, grid * 4 * n * 32768 * 2 / (ms * 1e-3) / 1e12);
+           iters * 64, ms, ms * 1e6 / n, c / n, grid * 4 * n * 32768 / (ms * 1e-3) / 1e12);
     (void)hipFree(out); (void)hipFree(cyc);
 }
 int main() {
