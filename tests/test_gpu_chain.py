@@ -1,0 +1,155 @@
+"""GPU parity of the node-path entry points on their own: mpg_chain, mpg_pack_many, the grouped weight-gradient
+GEMM / reduction -- against plain fp64 torch restatements of LinearNet.forward (mpgan/model.py:70-85) and of
+autograd's dX = dY W, dW = dY^T X.  Tolerance: 1e-3 relative (north star), asserted at 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TIGHT = 1e-4
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _t(rs, *shape, scale=1.0):
+    return torch.from_numpy(rs.normal(size=shape) * scale).float().to(_dev())
+
+
+def _lrelu(v, a):
+    return torch.where(v > 0, v, a * v)
+
+
+def _holder(rs, F, out, n1=256, n2=256, dscale=1.0, f16=True):
+    from mpgan_amd import ops
+    W = dict(W1=_t(rs, 96, 2 * F, scale=0.2), W2=_t(rs, 160, 96, scale=0.1), W3=_t(rs, 192, 160, scale=0.1),
+             V1=_t(rs, n1, 192 + F, scale=0.1), V2=_t(rs, n2, n1, scale=0.1), V3=_t(rs, out, n2, scale=0.1))
+    pk = ops.PackedMPLayer(tuple(W.values()), F, out, dscale, f16).ensure()
+    return W, pk
+
+
+@pytest.mark.parametrize("M,F,out,slabs", [(7680, 32, 32, 1), (100, 3, 32, 2), (37, 32, 5, 1), (1, 3, 3, 3)])
+def test_chain_forward_three_layers(M, F, out, slabs):
+    """fn = LinearNet([256,256] -> out) on [sum of agg slabs | x], ragged row counts, odd widths."""
+    from mpgan_amd import ops
+    rs = np.random.RandomState(M + F + out)
+    W, pk = _holder(rs, F, out)
+    aggp, x = _t(rs, slabs, M, 192), _t(rs, M, F)
+    c1, c2, c3 = _t(rs, 256), _t(rs, 256), _t(rs, out)
+    h1, h2, y = (torch.empty(M, n, device=_dev()) for n in (256, 256, out))
+    ops.chain(M, [dict(img=pk.ptr("V1"), K=192 + F, N=256, bias=c1, act=True, out=h1),
+                  dict(img=pk.ptr("V2"), K=256, N=256, bias=c2, act=True, out=h2),
+                  dict(img=pk.ptr("V3"), K=256, N=out, bias=c3, out=y)],
+              A=aggp, lda=192, K1=192, A2=x, lda2=F, a_slabs=slabs, a_slab_stride=M * 192, alpha=0.2, f16=True)
+    inp = torch.cat([aggp.double().sum(0), x.double()], 1)
+    r1 = _lrelu(inp @ W["V1"].double().t() + c1.double(), 0.2)
+    r2 = _lrelu(r1 @ W["V2"].double().t() + c2.double(), 0.2)
+    r3 = r2 @ W["V3"].double().t() + c3.double()
+    for got, ref in ((h1, r1), (h2, r2), (y, r3)):
+        assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < TIGHT
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.5, 0.3])
+def test_chain_gradient_chain_with_gates(p_drop):
+    """dz3 = gy * keep3 ; dz2 = (dz3 V3) * phi'(h2) keep2 ; dz1 = (dz2 V2) * phi'(h1) keep1 ; dh0 = dz1 V1 -- the keep
+    masks are the kernel's own (mpg_dropout_mask), fed to the fp64 restatement."""
+    from mpgan_amd import ops
+    rs = np.random.RandomState(11)
+    M, F, out = 333, 32, 32
+    W, pk = _holder(rs, F, out)
+    thr, scale = ops.drop_params(p_drop)
+    ops.set_seed(99)
+    seed = ops.seed_tensor(_dev())
+    gy, h1, h2 = _t(rs, M, out), _t(rs, M, 256), _t(rs, M, 256)
+    keep = {s: (ops.dropout_mask(M, n, 40 + s, thr).double() if thr else torch.ones(M, n, device=_dev()).double())
+            for s, n in ((0, 256), (1, 256), (2, out))}
+    if thr:  # dropped activations are exactly zero in the saved tensors
+        h1, h2 = h1 * keep[0].float(), h2 * keep[1].float()
+    dz3, dz2, dz1, dh0 = (torch.empty(M, n, device=_dev()) for n in (out, 256, 256, 192 + F))
+    ops.chain(M, [dict(img=pk.ptr("V3T"), K=out, N=256, gate=(h2, True, 41, thr, scale), out=dz2),
+                  dict(img=pk.ptr("V2T"), K=256, N=256, gate=(h1, True, 40, thr, scale), out=dz1),
+                  dict(img=pk.ptr("V1T"), K=256, N=192 + F, out=dh0)],
+              A=gy, lda=out, K1=out, in_gate=(42, thr, scale), in_out=dz3 if thr else None, alpha=0.2, seed_t=seed, f16=False)
+    sc = scale if thr else 1.0
+    r3 = gy.double() * keep[2] * sc
+    slope = lambda h: torch.where(h.double() > 0, torch.ones_like(h.double()), 0.2 * torch.ones_like(h.double()))
+    r2 = (r3 @ W["V3"].double()) * slope(h2) * keep[1] * sc
+    r1 = (r2 @ W["V2"].double()) * slope(h1) * keep[0] * sc
+    r0 = r1 @ W["V1"].double()
+    pairs = [(dz2, r2), (dz1, r1), (dh0, r0)] + ([(dz3, r3)] if thr else [])
+    for got, ref in pairs:
+        assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < TIGHT
+
+
+@pytest.mark.parametrize("F", [32, 3])
+def test_stacked_layer1_views(F):
+    """fe.net.0 on [x_i ; x_j] split as a_i + c_j: the stacked image gives a | c in one launch, its
+    transpose gives dx = [da | dc] [W1a ; W1c] + resid."""
+    from mpgan_amd import ops
+    rs = np.random.RandomState(5 + F)
+    M = 450
+    W, pk = _holder(rs, F, 32)
+    x, b1 = _t(rs, M, F), _t(rs, 96)
+    ac = torch.empty(M, 192, device=_dev())
+    ops.chain(M, [dict(img=pk.ptr("W1S"), K=F, N=192, bias=b1, nbias=96, out=ac)], A=x, lda=F, K1=F, f16=True)
+    W1 = W["W1"].double()
+    ref = torch.cat([x.double() @ W1[:, :F].t() + b1.double(), x.double() @ W1[:, F:].t()], 1)
+    assert rel_err(ac.cpu().numpy(), ref.cpu().numpy()) < TIGHT
+    da, dc, resid = _t(rs, 2, M, 96), _t(rs, M, 96), _t(rs, M, 40)[:, 8:8 + F]
+    dx = torch.empty(M, F, device=_dev())
+    ops.chain(M, [dict(img=pk.ptr("W1ST"), K=192, N=F, resid=resid, out=dx)], A=da, lda=96, K1=96, a_slabs=2,
+              a_slab_stride=M * 96, A2=dc, lda2=96, f16=False)
+    refx = da.double().sum(0) @ W1[:, :F] + dc.double() @ W1[:, F:] + resid.double()
+    assert rel_err(dx.cpu().numpy(), refx.cpu().numpy()) < TIGHT
+
+
+def test_pack_many_equals_pack_weights():
+    """Every image mpg_pack_many builds is bit-identical to mpg_pack_weights' (same fragment order, same split)."""
+    from mpgan_amd import ops
+    rs = np.random.RandomState(8)
+    W, pk = _holder(rs, 32, 32, dscale=2.0)
+    singles = {
+        "W2": ops.pack_weights(W["W2"], 160, 96, scale=2.0, f16=True), "W3": ops.pack_weights(W["W3"], 192, 160, scale=2.0, f16=True),
+        "W3T": ops.pack_weights(W["W3"], 192, 160, transpose=True, scale=2.0), "W2T": ops.pack_weights(W["W2"], 160, 96, transpose=True, scale=2.0),
+        "V2": ops.pack_weights(W["V2"], 256, 256, f16=True), "V1T": ops.pack_weights(W["V1"], 256, 224, transpose=True),
+    }
+    for k, img in singles.items():
+        assert torch.equal(img.view(torch.int16), pk.img[k].view(torch.int16)), k
+
+
+def test_wgrad_group_and_accumulate():
+    """Six dW = dY^T X (+ bias sums) as one grouped launch; a second flush with accumulate doubles the result."""
+    from mpgan_amd import ops
+    rs = np.random.RandomState(21)
+    M = 7680
+    shapes = [(32, 256), (256, 256), (256, 192), (256, 32), (96, 32), (96, 3)]
+    dys = [_t(rs, M, n) for n, _ in shapes]
+    xs = [_t(rs, M, k) for _, k in shapes]
+    outs = [torch.zeros(n, k + 5, device=_dev()) for n, k in shapes]
+    biases = [torch.zeros(n, device=_dev()) if i % 2 == 0 else None for i, (n, _) in enumerate(shapes)]
+    for rep in range(2):
+        wb = ops.WgradBatch()
+        for dy, x, o, b in zip(dys, xs, outs, biases):
+            wb.add(dy, x, out=o, out_col0=5, bias_out=b, accumulate=rep == 1)
+        wb.flush()
+    for dy, x, o, b in zip(dys, xs, outs, biases):
+        ref = 2 * (dy.double().t() @ x.double())
+        assert rel_err(o[:, 5:].cpu().numpy(), ref.cpu().numpy()) < TIGHT
+        assert float(o[:, :5].abs().max()) == 0.0
+        if b is not None:
+            assert rel_err(b.cpu().numpy(), (2 * dy.double().sum(0)).cpu().numpy()) < TIGHT
+
+
+def test_chain_rejects_bad_arguments():
+    from mpgan_amd import ops
+    rs = np.random.RandomState(1)
+    W, pk = _holder(rs, 32, 32)
+    x = _t(rs, 64, 32)
+    y = torch.empty(64, 192, device=_dev())
+    with pytest.raises(RuntimeError):  # LeakyReLU slope outside [0, 1]
+        ops.chain(64, [dict(img=pk.ptr("W1S"), K=32, N=192, out=y)], A=x, lda=32, K1=32, alpha=1.5, f16=True)
+    with pytest.raises(RuntimeError):  # K beyond the 256 features a fragment buffer holds
+        ops.chain(64, [dict(img=pk.ptr("W1S"), K=300, N=192, out=y)], A=x, lda=32, K1=300, f16=True)
