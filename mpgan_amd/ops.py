@@ -158,6 +158,11 @@ def linear_bwd_weight(dy, x, *, out=None, out_col0=0, out_scale=1.0, bias_out=No
     return out
 
 
+# Set by train.TrainStep around a backward: FusedLinearFn queues its weight gradients here instead of launching
+# one small split-K GEMM + reduction per layer; TrainStep flushes the queue (grouped launches) before the optimizer.
+DEFERRED_WGRAD = None
+
+
 class WgradBatch:
     """Weight gradients dW[:, col0:col0+K] = scale * dy^T @ x (+ bias = column sums of dy) collected and issued as
     ONE grouped split-K GEMM launch plus ONE grouped reduction (``linear_bwd_weight`` does one at a time)."""
@@ -509,6 +514,7 @@ class FusedLinearFn(torch.autograd.Function):
         tag = next_tag()
         y = linear_fwd(x2, W, b, act=act, alpha=alpha, drop=(seed_t, tag + TAG_GENERIC, thr, dscale) if thr else None)
         ctx.save_for_backward(x2, W, y)
+        ctx.wparam, ctx.bias = W, b  # (only their .grad buffers are touched, by the deferred weight-gradient path)
         ctx.cfg = (shp, act, alpha, thr, dscale, tag, b is not None)
         return y.reshape(*shp[:-1], W.shape[0])
 
@@ -521,11 +527,17 @@ class FusedLinearFn(torch.autograd.Function):
             g2 = gate(g2, y, gate_act=act, alpha=alpha, seed_t=seed_tensor(g2.device), tag=tag + TAG_GENERIC,
                       thr=thr, scale=dscale)
         dW = db = None
-        if ctx.needs_input_grad[1]:
-            if has_b and ctx.needs_input_grad[2]:
+        Wp, b = ctx.wparam, ctx.bias
+        want_b = has_b and ctx.needs_input_grad[2]
+        if (ctx.needs_input_grad[1] and OPTIONS["grad_into_param"] and DEFERRED_WGRAD is not None
+                and Wp.grad is not None and Wp.grad.is_contiguous() and (not want_b or b.grad is not None)):
+            # TrainStep: queue dW (+ db) for the grouped launch at the end of the backward; it adds into .grad
+            DEFERRED_WGRAD.add(g2, x2, out=Wp.grad, bias_out=b.grad if want_b else None, accumulate=True)
+        elif ctx.needs_input_grad[1]:
+            if want_b:
                 db = torch.empty(W.shape[0], device=g2.device, dtype=torch.float32)
             dW = linear_bwd_weight(g2, x2, bias_out=db)
-        elif has_b and ctx.needs_input_grad[2]:
+        elif want_b:
             db = g2.sum(0)
         dx = linear_bwd_data(g2, W).reshape(shp) if ctx.needs_input_grad[0] else None
         return dx, dW, db, None, None, None, None

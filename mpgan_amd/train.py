@@ -158,8 +158,19 @@ class TrainStep:
             out_r = self.D(self.data.clone(), self.labels)
             out_f = self.D(fake, self.labels)
         loss = ((out_r - 1.0) ** 2).mean() + (out_f ** 2).mean()
-        loss.backward()
+        self._backward(loss)
         self.D_loss.copy_(loss.detach())
+
+    @staticmethod
+    def _backward(loss):
+        """loss.backward() with the stand-alone Linear layers' weight gradients collected and issued as grouped
+        launches that add straight into the flat gradient buffers."""
+        ops.DEFERRED_WGRAD = ops.WgradBatch()
+        try:
+            loss.backward()
+            ops.DEFERRED_WGRAD.flush()
+        finally:
+            ops.DEFERRED_WGRAD = None
 
     @staticmethod
     def _refresh_packed(module: nn.Module):
@@ -177,7 +188,7 @@ class TrainStep:
         fake = self.G(self._noise(1), self.labels)
         out = self.D(fake, self.labels)
         loss = ((out - 1.0) ** 2).mean()
-        loss.backward()
+        self._backward(loss)
         _set_requires_grad(self.D, True)
         self.G_loss.copy_(loss.detach())
 
