@@ -501,6 +501,20 @@ class FusedMPLayerFn(torch.autograd.Function):
                 None, None, None, None, None)
 
 
+def _grad_target(t):
+    """The .grad buffer a parameter gradient may be added into directly: the leaf's own, or -- for a contiguous
+    view of a leaf (a row slice of nn.MultiheadAttention's in_proj_weight / in_proj_bias) -- the matching view of
+    the leaf's .grad.  None when there is no such buffer."""
+    if t is None:
+        return None
+    if t.is_leaf:
+        return t.grad if (t.grad is not None and t.grad.is_contiguous()) else None
+    base = t._base
+    if base is None or not base.is_leaf or base.grad is None or not t.is_contiguous() or not base.grad.is_contiguous():
+        return None
+    return base.grad.as_strided(t.size(), t.stride(), t.storage_offset() - base.storage_offset() + base.grad.storage_offset())
+
+
 class FusedLinearFn(torch.autograd.Function):
     """Linear -> [LeakyReLU] -> [Dropout] (one LinearNet layer; mpgan/model.py:77-83)."""
 
@@ -527,12 +541,13 @@ class FusedLinearFn(torch.autograd.Function):
             g2 = gate(g2, y, gate_act=act, alpha=alpha, seed_t=seed_tensor(g2.device), tag=tag + TAG_GENERIC,
                       thr=thr, scale=dscale)
         dW = db = None
-        Wp, b = ctx.wparam, ctx.bias
         want_b = has_b and ctx.needs_input_grad[2]
-        if (ctx.needs_input_grad[1] and OPTIONS["grad_into_param"] and DEFERRED_WGRAD is not None
-                and Wp.grad is not None and Wp.grad.is_contiguous() and (not want_b or b.grad is not None)):
+        gW = gb = None
+        if ctx.needs_input_grad[1] and OPTIONS["grad_into_param"] and DEFERRED_WGRAD is not None:
+            gW, gb = _grad_target(ctx.wparam), _grad_target(ctx.bias) if want_b else None
+        if gW is not None and (not want_b or gb is not None):
             # TrainStep: queue dW (+ db) for the grouped launch at the end of the backward; it adds into .grad
-            DEFERRED_WGRAD.add(g2, x2, out=Wp.grad, bias_out=b.grad if want_b else None, accumulate=True)
+            DEFERRED_WGRAD.add(g2, x2, out=gW, bias_out=gb, accumulate=True)
         elif ctx.needs_input_grad[1]:
             if want_b:
                 db = torch.empty(W.shape[0], device=g2.device, dtype=torch.float32)
