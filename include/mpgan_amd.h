@@ -199,7 +199,7 @@ int mpg_edge_dw(const MpgEdgeDw* p, void* stream);
  *     P = softmax_s( q_h k_h^T / sqrt(d)  with keys s where ignore[b,s] != 0 at -inf ),   o_h = P v_h
  * i.e. what nn.MultiheadAttention does between its in- and out-projection as called by MAB.forward
  * (gapt/model.py:127-129).  q [B*L, ldq], k/v [B*S, ldk/ldv], o [B*L, ldo] hold the H heads side by
- * side (head h = columns h*d .. h*d+d-1); P [B,H,L,S] is written by fwd and read by bwd;
+ * side (head h = columns h*d .. h*d+d-1); P (B*H*L*S floats, layout private to the pair of kernels) is written by fwd and read by bwd;
  * ignore [B*S] floats (1 = padded key) or NULL.  bwd takes d_o = dL/do and writes dq, dk, dv. */
 typedef struct MpgAttn {
     const float* q; const float* k; const float* v; int ldq, ldk, ldv;

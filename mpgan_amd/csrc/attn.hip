@@ -3,14 +3,190 @@
 // Replaces the scaled-dot-product part of nn.MultiheadAttention as MAB uses it (gapt/model.py:107,
 // :129: batch_first, key-ignore mask expanded over heads :127, need_weights=False) and its
 // backward.  The projections around it (in_proj, out_proj, ff) run on mpg_gemm.  Sets here are
-// tiny (L, S <= 150 particles or 10 inducing points, d = 16): the work is latency/launch bound,
-// so one workgroup owns one (jet, head), keeps K and V in LDS and does the arithmetic in fp32 VALU.
+// tiny (L, S <= 150 particles or 10 inducing points, d = 16): the work is latency/launch bound, fp32 VALU.
+//
+// Fast path (S <= 32 keys, L <= 64 queries, d in {8, 16, 32}: every GAPT block at N = 30): ONE WAVE per (jet, head),
+// four per workgroup; lane = query.  K and V sit in LDS and are read as broadcasts, the 32 scores of a query
+// live in registers (fully unrolled), P is written once, transposed ([S][L]: lanes contiguous).  The backward
+// keeps dS and P in LDS between its query-major half (dQ) and its key-major half (dK, dV).
+// Anything larger takes the generic kernels below (one workgroup per (jet, head), scores through memory).
 #include "common.h"
 #include "../../include/mpgan_amd.h"
 
 namespace {
 constexpr int DMAX = 32;
+constexpr int AT_S = 32, AT_L = 64;  // fast-path limits
 
+template <int D>
+MPG_DEV void lds_row(const float* base, int row, float (&out)[D]) {  // broadcast read of one [D] row
+#pragma unroll
+    for (int c = 0; c < D; c += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(base + row * D + c);
+        out[c] = t.x; out[c + 1] = t.y; out[c + 2] = t.z; out[c + 3] = t.w;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_fast(const MpgAttn p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * 4 + w;           // (jet, head)
+    if (pair >= p.B * p.H) return;                 // whole wave; no block-wide barrier below
+    const int b = pair / p.H, hd = pair % p.H;
+    float* ks = sm + w * (2 * AT_S * D);           // [S][D]
+    float* vs = ks + AT_S * D;
+    for (int t = lane; t < p.S * (D / 4); t += 64) {
+        const int s = t / (D / 4), c = 4 * (t % (D / 4));
+        *reinterpret_cast<float4*>(ks + s * D + c) = *reinterpret_cast<const float4*>(p.k + (size_t)(b * p.S + s) * p.ldk + hd * D + c);
+        *reinterpret_cast<float4*>(vs + s * D + c) = *reinterpret_cast<const float4*>(p.v + (size_t)(b * p.S + s) * p.ldv + hd * D + c);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int l = lane;
+    if (l >= p.L) return;
+    const float scale = rsqrtf((float)D);
+    float q[D];
+    {
+        const float* qp = p.q + (size_t)(b * p.L + l) * p.ldq + hd * D;
+#pragma unroll
+        for (int c = 0; c < D; c += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(qp + c);
+            q[c] = t.x * scale; q[c + 1] = t.y * scale; q[c + 2] = t.z * scale; q[c + 3] = t.w * scale;
+        }
+    }
+    float sc[AT_S];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < AT_S; ++s) {
+        float x = -INFINITY;
+        if (s < p.S) {  // wave-uniform
+            float kr[D];
+            lds_row<D>(ks, s, kr);
+            x = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) x += q[c] * kr[c];
+            if (p.ignore != nullptr && p.ignore[b * p.S + s] != 0.f) x = -INFINITY;
+        }
+        sc[s] = x;
+        mx = fmaxf(mx, x);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int s = 0; s < AT_S; ++s) { sc[s] = __expf(sc[s] - mx); den += sc[s]; }
+    const float inv = 1.f / den;
+    float o[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) o[c] = 0.f;
+    float* Pt = p.P + (size_t)pair * p.S * p.L;    // [S][L]
+#pragma unroll
+    for (int s = 0; s < AT_S; ++s) {
+        if (s < p.S) {
+            const float pr = sc[s] * inv;
+            Pt[s * p.L + l] = pr;
+            float vr[D];
+            lds_row<D>(vs, s, vr);
+#pragma unroll
+            for (int c = 0; c < D; ++c) o[c] += pr * vr[c];
+        }
+    }
+    float* op = p.o + (size_t)(b * p.L + l) * p.ldo + hd * D;
+#pragma unroll
+    for (int c = 0; c < D; c += 4) *reinterpret_cast<float4*>(op + c) = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
+}
+
+// backward: dV = P^T dO ; dP = dO V^T ; dS = P * (dP - rowsum(dP * P)) ; dQ = dS K / sqrt(d) ; dK = dS^T Q / sqrt(d)
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_fast(const MpgAttn p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * 4 + w;
+    if (pair >= p.B * p.H) return;
+    const int b = pair / p.H, hd = pair % p.H;
+    constexpr int PER = 2 * AT_S * D + 2 * AT_L * D + 2 * AT_S * AT_L;
+    float* ks = sm + w * PER;            // [S][D]
+    float* vs = ks + AT_S * D;           // [S][D]
+    float* qs = vs + AT_S * D;           // [L][D]
+    float* gs = qs + AT_L * D;           // [L][D]  dO
+    float* dsl = gs + AT_L * D;          // [S][AT_L]  dS (key-major: lane-contiguous writes)
+    float* pl = dsl + AT_S * AT_L;       // [S][AT_L]  P
+    for (int t = lane; t < p.S * (D / 4); t += 64) {
+        const int s = t / (D / 4), c = 4 * (t % (D / 4));
+        *reinterpret_cast<float4*>(ks + s * D + c) = *reinterpret_cast<const float4*>(p.k + (size_t)(b * p.S + s) * p.ldk + hd * D + c);
+        *reinterpret_cast<float4*>(vs + s * D + c) = *reinterpret_cast<const float4*>(p.v + (size_t)(b * p.S + s) * p.ldv + hd * D + c);
+    }
+    for (int t = lane; t < p.L * (D / 4); t += 64) {
+        const int l = t / (D / 4), c = 4 * (t % (D / 4));
+        *reinterpret_cast<float4*>(qs + l * D + c) = *reinterpret_cast<const float4*>(p.q + (size_t)(b * p.L + l) * p.ldq + hd * D + c);
+        *reinterpret_cast<float4*>(gs + l * D + c) = *reinterpret_cast<const float4*>(p.d_o + (size_t)(b * p.L + l) * p.ldo + hd * D + c);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const float scale = rsqrtf((float)D);
+    const float* Pt = p.P + (size_t)pair * p.S * p.L;  // [S][L]
+    if (lane < p.L) {  // ---- query-major half
+        const int l = lane;
+        float g[D];
+        lds_row<D>(gs, l, g);
+        float dp[AT_S], pr[AT_S];
+        float dot = 0.f;
+#pragma unroll
+        for (int s = 0; s < AT_S; ++s) {
+            dp[s] = 0.f; pr[s] = 0.f;
+            if (s < p.S) {
+                pr[s] = Pt[s * p.L + l];
+                float vr[D];
+                lds_row<D>(vs, s, vr);
+#pragma unroll
+                for (int c = 0; c < D; ++c) dp[s] += g[c] * vr[c];
+                dot += dp[s] * pr[s];
+            }
+        }
+        float dq[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) dq[c] = 0.f;
+#pragma unroll
+        for (int s = 0; s < AT_S; ++s) {
+            if (s < p.S) {
+                const float x = pr[s] * (dp[s] - dot);
+                dsl[s * AT_L + l] = x;
+                pl[s * AT_L + l] = pr[s];
+                float kr[D];
+                lds_row<D>(ks, s, kr);
+#pragma unroll
+                for (int c = 0; c < D; ++c) dq[c] += x * kr[c];
+            }
+        }
+        float* qo = p.dq + (size_t)(b * p.L + l) * p.lddq + hd * D;
+#pragma unroll
+        for (int c = 0; c < D; c += 4)
+            *reinterpret_cast<float4*>(qo + c) = make_float4(dq[c] * scale, dq[c + 1] * scale, dq[c + 2] * scale, dq[c + 3] * scale);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < p.S) {  // ---- key-major half
+        const int s = lane;
+        float dk[D], dv[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+        for (int l = 0; l < p.L; ++l) {
+            const float x = dsl[s * AT_L + l], pr = pl[s * AT_L + l];
+            float qr[D], gr[D];
+            lds_row<D>(qs, l, qr);
+            lds_row<D>(gs, l, gr);
+#pragma unroll
+            for (int c = 0; c < D; ++c) { dk[c] += x * qr[c]; dv[c] += pr * gr[c]; }
+        }
+        float* ko = p.dk + (size_t)(b * p.S + s) * p.lddk + hd * D;
+        float* vo = p.dv + (size_t)(b * p.S + s) * p.lddv + hd * D;
+#pragma unroll
+        for (int c = 0; c < D; c += 4) {
+            *reinterpret_cast<float4*>(ko + c) = make_float4(dk[c] * scale, dk[c + 1] * scale, dk[c + 2] * scale, dk[c + 3] * scale);
+            *reinterpret_cast<float4*>(vo + c) = make_float4(dv[c], dv[c + 1], dv[c + 2], dv[c + 3]);
+        }
+    }
+}
+
+// ---- generic kernels: one workgroup per (jet, head), scores through memory (P is [L][S] here)
 __global__ __launch_bounds__(64) void attn_fwd_kernel(const MpgAttn p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x / p.H, hd = blockIdx.x % p.H;
@@ -113,10 +289,32 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const MpgAttn p) {
         for (int c = 0; c < d; ++c) { ko[c] = dk[c] * scale; vo[c] = dv[c]; }
     }
 }
+// The fast path is chosen by shape alone (forward and backward must agree on the layout of P); its float4 row
+// accesses then REQUIRE 16-byte aligned bases and strides -- anything else is an error, not a silent fallback.
+static bool attn_fast_shape(const MpgAttn* p) {
+    return p->S <= AT_S && p->L <= AT_L && (p->d == 8 || p->d == 16 || p->d == 32);
+}
+static bool attn_aligned(const MpgAttn* p, bool bwd) {
+    auto al = [](const void* q, int ld) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0; };
+    bool ok = al(p->q, p->ldq) && al(p->k, p->ldk) && al(p->v, p->ldv);
+    if (!bwd) ok = ok && al(p->o, p->ldo);
+    else ok = ok && al(p->d_o, p->ldo) && al(p->dq, p->lddq) && al(p->dk, p->lddk) && al(p->dv, p->lddv);
+    return ok;
+}
 }  // namespace
 
 extern "C" int mpg_attn_fwd(const MpgAttn* p, void* stream) {
     if (p->d > DMAX || p->B <= 0) return -1;
+    if (attn_fast_shape(p)) {
+        if (!attn_aligned(p, false)) return -3;
+        const dim3 grid((p->B * p->H + 3) / 4), block(256);
+        const size_t lds = (size_t)4 * 2 * AT_S * p->d * 4;
+        hipStream_t st = (hipStream_t)stream;
+        if (p->d == 8) hipLaunchKernelGGL(attn_fwd_fast<8>, grid, block, lds, st, *p);
+        else if (p->d == 16) hipLaunchKernelGGL(attn_fwd_fast<16>, grid, block, lds, st, *p);
+        else hipLaunchKernelGGL(attn_fwd_fast<32>, grid, block, lds, st, *p);
+        return (int)hipGetLastError();
+    }
     const size_t lds = (size_t)2 * p->S * p->d * 4;
     if (lds > 160 * 1024) return -2;
     if (lds > 64 * 1024) HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -126,6 +324,26 @@ extern "C" int mpg_attn_fwd(const MpgAttn* p, void* stream) {
 
 extern "C" int mpg_attn_bwd(const MpgAttn* p, void* stream) {
     if (p->d > DMAX || p->B <= 0) return -1;
+    if (attn_fast_shape(p)) {
+        if (!attn_aligned(p, true)) return -3;
+        const dim3 grid((p->B * p->H + 3) / 4), block(256);
+        const size_t lds = (size_t)4 * (2 * AT_S * p->d + 2 * AT_L * p->d + 2 * AT_S * AT_L) * 4;
+        hipStream_t st = (hipStream_t)stream;
+#define MPG_ATTN_BWD(DV)                                                                                                  \
+    do {                                                                                                                  \
+        static bool done = false;                                                                                         \
+        if (!done && lds > 64 * 1024) {                                                                                   \
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_fast<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            done = true;                                                                                                  \
+        }                                                                                                                 \
+        hipLaunchKernelGGL(attn_bwd_fast<DV>, grid, block, lds, st, *p);                                                  \
+    } while (0)
+        if (p->d == 8) MPG_ATTN_BWD(8);
+        else if (p->d == 16) MPG_ATTN_BWD(16);
+        else MPG_ATTN_BWD(32);
+#undef MPG_ATTN_BWD
+        return (int)hipGetLastError();
+    }
     const size_t lds = ((size_t)2 * p->S * p->d + 2 * p->L * p->d + (size_t)p->L * p->S) * 4;
     if (lds > 160 * 1024) return -2;
     static size_t attr = 0;
