@@ -169,9 +169,15 @@ class MPNet(nn.Module):
 
 
 def _rank_mask(first_feature: Tensor, labels: Tensor, num_particles: int) -> Tensor:
-    """mask_c: the n = int(label * N) lowest-noise particles are real (reference :689-699)."""
+    """mask_c: the n = int(label * N) lowest-noise particles are real (reference :689-699: rank by
+    ``argsort().argsort()``).  The rank of particle i is the number of particles that sort before it -- counted
+    directly (one comparison + one sum over an [B, N, N] boolean) instead of two device sorts; equal values are
+    ordered by index."""
     n_minus_1 = (labels[:, -1] * num_particles).int() - 1
-    rank = first_feature.argsort(1).argsort(1)
+    xi, xj = first_feature.unsqueeze(2), first_feature.unsqueeze(1)
+    idx = torch.arange(first_feature.shape[1], device=first_feature.device)
+    before = (xj < xi) | ((xj == xi) & (idx.unsqueeze(0) < idx.unsqueeze(1)).unsqueeze(0))
+    rank = before.sum(2)
     return (rank <= n_minus_1.unsqueeze(1)).unsqueeze(2).float()
 
 

@@ -130,6 +130,7 @@ class TrainStep:
         self.fG, self.fD = FlatParams(G), FlatParams(D)
         self.data = torch.zeros(batch_size, num_particles, 4, device=dev)
         self.labels = torch.zeros(batch_size, 1, device=dev)
+        self._target = torch.cat([torch.ones(batch_size, device=dev), torch.zeros(batch_size, device=dev)])
         self.D_loss = torch.zeros((), device=dev)
         self.G_loss = torch.zeros((), device=dev)
         self.use_graphs = use_graphs
@@ -153,11 +154,12 @@ class TrainStep:
             fake = self.G(self._noise(0), self.labels)
         if self.batch_real_fake:
             out = self.D(torch.cat([self.data, fake], 0), torch.cat([self.labels, self.labels], 0))
-            out_r, out_f = out[: self.B], out[self.B:]
+            # mean over the real half of (out - 1)^2 + mean over the generated half of out^2, without slicing
+            loss = ((out - self._target.reshape(out.shape)) ** 2).sum() / self.B
         else:
             out_r = self.D(self.data.clone(), self.labels)
             out_f = self.D(fake, self.labels)
-        loss = ((out_r - 1.0) ** 2).mean() + (out_f ** 2).mean()
+            loss = ((out_r - 1.0) ** 2).mean() + (out_f ** 2).mean()
         self._backward(loss)
         self.D_loss.copy_(loss.detach())
 

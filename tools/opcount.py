@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Count the device kernels one eager G+D iteration launches, by aten op (which PyTorch glue is left)."""
+import sys, os, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from mpgan_amd import train
+from oracle import train_ref as T
+dev = torch.device("cuda:0")
+G, D = train.default_mpgan(30, device=dev)
+ts = train.TrainStep(G, D, 256, 30, use_graphs=False)
+data, labels = T.synthetic_batch(256, 30, seed=1, dist="gluon")
+ts.set_batch(data.to(dev), labels.to(dev))
+for _ in range(3): ts.step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    ts.step()
+    torch.cuda.synchronize()
+rows = [(e.key, e.count, e.device_time_total) for e in prof.key_averages() if e.device_time_total > 0]
+rows.sort(key=lambda r: -r[2])
+for k, c, t in rows[:45]:
+    print(f"{k[:70]:70s} n={c:4d} dev_us={t:9.1f}")
