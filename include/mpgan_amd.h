@@ -174,7 +174,7 @@ typedef struct MpgEdgeBwd {
 } MpgEdgeBwd;
 int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream);
 
-/* mpg_edge_dw: weight gradients of fe.net.1 / fe.net.2 (and their biases) from the planes parked by
+/* mpg_edge_dw: weight gradients of fe.net.1 / fe.net.2 (and their biases) from the fragments parked by
  * mpg_edge_bwd:  dW3 = dscale * sum_e dZ3 E2^T [192,160], dW2 = dscale * sum_e dZ2 E1^T [160,96],
  * db3 = sum_e dZ3 [192], db2 = sum_e dZ2 [160]; E1 and dZ3 are rebuilt from a, c, dagg and the sign words.
  * `part` is scratch of nwg * 46,432 floats (per-workgroup partial sums); nwg workgroups share the B*RB*N blocks

@@ -6,13 +6,13 @@
 //   dW3 = s * sum_e dZ3 E2^T ;  dW2 = s * sum_e dZ2 E1^T ;  db3 = sum_e dZ3 ;  db2 = sum_e dZ2
 //
 // Two kernels.  edge_bwd_kernel walks the data-gradient chain exactly like the forward kernel (a wave
-// per (jet, 32 receivers), senders in a loop, W3^T hi+lo and W2 hi resident in LDS, the rest
-// streamed from L2) and, when weight gradients are wanted, parks E2 and dZ2 in memory as 16-bit
-// hi/lo planes laid out [block of 32 receivers][feature][receiver], i.e. already transposed for the
-// weight-gradient contraction over edges.  edge_dw_kernel then streams those planes, rebuilds the
-// cheap operands (E1 from a_i + c_j, dZ3 from dagg and the sign words) and accumulates dW3/dW2/db3/db2
-// in registers over its share of the edges; the per-workgroup partials are summed by a last small
-// kernel that also undoes the fragment-order permutation of the feature indices.
+// per (jet, 32 receivers), senders in a loop, W3^T hi+lo resident in LDS, the rest streamed from L2) and, when
+// weight gradients are wanted, parks E2 and dZ2 in memory as the 16-bit hi/lo B fragments the lanes hold (one
+// coalesced 16-byte store per lane and fragment).  edge_dw_kernel then streams those fragments into
+// [receiver][feature] LDS images, rebuilds the cheap operands (E1 from a_i + c_j, dZ3 from dagg and the sign
+// words), fetches MFMA operands with transposing LDS reads and accumulates dW3/dW2/db3/db2 in registers over
+// its share of the edges; the per-workgroup partials are summed by a last small kernel that also undoes the
+// fragment-order permutation of the feature indices.
 #include "edge_common.h"
 
 #ifndef MPG_DW_EXP
