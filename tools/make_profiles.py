@@ -54,6 +54,19 @@ txt = ("# HBM traffic of the fused kernels: rocprofv3 --kernel-trace --pmc FETCH
        "#   kernel                                             2 x FETCH + WRITE = MB per launch\n")
 for k, what in rows:
     txt += f"#   {k:34s} {what:32s} 2 x {kb('FETCH_SIZE', k) / 1024:7.1f} + {kb('WRITE_SIZE', k) / 1024:7.1f} = {tot(k) / 2**20:7.1f}\n"
+# achieved HBM rate = bytes per launch / rocprof average duration of the B=256 launches in the bench trace
+dur = {}
+for l in open(os.path.join(P, f"{tag}_bench_kernel_stats.csv")).read().splitlines()[1:]:
+    m = re.match(r'"(.*)",(\d+),(\d+),([\d.]+),', l)
+    if m:
+        dur[m.group(1)] = float(m.group(4)) * 1e-9
+def rate(sub, key):
+    d = [v for k, v in dur.items() if sub in k]
+    return tot(key) / d[0] / 1e12 if d else float("nan")
+txt += ("#\n# Achieved HBM rate at B=256 (bytes above / rocprof average duration in " + f"{tag}_bench_kernel_stats.csv" + "; HBM3E peak 8 TB/s):\n"
+        f"#   edge_fwd_kernel<0, true, true>   {rate('edge_fwd_kernel<0, true, true>', 'edge_fwd_kernel<0'):5.2f} TB/s  (compute bound: see the SQ counters)\n"
+        f"#   edge_bwd_kernel<0, true, true>   {rate('edge_bwd_kernel<0, true, true>', 'edge_bwd_kernel<0, true, true'):5.2f} TB/s\n"
+        f"#   edge_dw_kernel<0, true>          {rate('edge_dw_kernel<0, true>', 'edge_dw_kernel<0'):5.2f} TB/s\n")
 txt += ("#\n# forward: a|c in, agg + sign words out (algorithmic 17.7 MB).  backward + staging: 2 x 20 KiB of E2 / dZ2 fragments per\n"
         "# unmasked (jet, sender) block for mpg_edge_dw, which reads them back and writes 256 per-workgroup partial sums.\n#\n" + pm)
 open(os.path.join(P, f"{tag}_pmc_hbm_traffic.txt"), "w").write(txt)
