@@ -153,3 +153,27 @@ def test_chain_rejects_bad_arguments():
         ops.chain(64, [dict(img=pk.ptr("W1S"), K=32, N=192, out=y)], A=x, lda=32, K1=32, alpha=1.5, f16=True)
     with pytest.raises(RuntimeError):  # K beyond the 256 features a fragment buffer holds
         ops.chain(64, [dict(img=pk.ptr("W1S"), K=300, N=192, out=y)], A=x, lda=32, K1=300, f16=True)
+
+
+def test_packed_images_follow_parameter_updates():
+    """MPLayer caches its weight images; an optimizer step (in-place update seen by autograd's version counter) or a
+    load_state_dict must be picked up by the next forward, refresh_packed() covers writes torch cannot see."""
+    from mpgan_amd.mpgan import MPLayer
+    torch.manual_seed(0)
+    layer = MPLayer(32, [96, 160, 192], [256, 256], 32).to(_dev())
+    x = torch.randn(2, 30, 32, device=_dev())
+    y0 = layer(x).detach().clone()
+    opt = torch.optim.SGD(layer.parameters(), lr=0.05)
+    layer(x).pow(2).mean().backward()
+    opt.step()
+    y1 = layer(x).detach().clone()
+    assert torch.isfinite(y1).all() and (y1 - y0).abs().max() > 1e-5   # the update is visible ...
+    fresh = MPLayer(32, [96, 160, 192], [256, 256], 32).to(_dev())
+    fresh.load_state_dict(layer.state_dict())      # ... and equals a freshly packed layer with the same weights
+    assert torch.equal(fresh(x), y1)
+    with torch.no_grad():
+        for q in layer.parameters():
+            q.data.mul_(0.5)                       # a write behind autograd's back (as mpg_rmsprop does) ...
+    layer.refresh_packed()                         # ... needs the explicit refresh
+    fresh.load_state_dict(layer.state_dict())
+    assert torch.equal(fresh(x), layer(x))
