@@ -4,7 +4,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mpgan_amd import ops
-V, F, out = 7680, 32, 32
+V, F, out = int(os.environ.get("KCHAIN_V", "7680")), 32, 32
 dev = "cuda"
 torch.manual_seed(0)
 W1 = torch.randn(96, 2 * F, device=dev) * 0.1; W2 = torch.randn(160, 96, device=dev) * 0.1; W3 = torch.randn(192, 160, device=dev) * 0.1
