@@ -16,6 +16,7 @@ captured into hipGraphs (three segments, split at the two gradient all-reduces) 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -218,10 +219,14 @@ class TrainStep:
         torch.cuda.synchronize(self.dev)
         graphs = []
         pool = None
-        for seg in (self._seg_D, self._seg_G, self._seg_end):
+        # one graph per segment between collectives; without a process group the whole iteration is one graph
+        groups = [(self._seg_D,), (self._seg_G,), (self._seg_end,)] if (self.world > 1 or os.environ.get("MPG_SPLIT_GRAPHS")) else \
+                 [(self._seg_D, self._seg_G, self._seg_end)]
+        for segs in groups:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool):
-                seg()
+                for seg in segs:
+                    seg()
             pool = g.pool()
             graphs.append(g)
         self._graphs = graphs
@@ -235,6 +240,9 @@ class TrainStep:
             self.capture()
         if not self.use_graphs:
             self._eager()
+            return
+        if len(self._graphs) == 1:
+            self._graphs[0].replay()
             return
         gD, gG, gE = self._graphs
         gD.replay(); self._allreduce(self.fD)
