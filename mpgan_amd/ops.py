@@ -340,7 +340,9 @@ class FusedMPLayerFn(torch.autograd.Function):
         thr, dscale = drop_params(p_drop) if training else (0, 1.0)
         seed_t = seed_tensor(dev)
         tag = next_tag()
-        x2 = x.reshape(V, F).contiguous()
+        x2 = x.reshape(V, F)          # a view when x is a feature slice of a contiguous tensor (D's x[..., :-1]) ...
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()      # ... every consumer below takes the row stride, only unit column stride matters
         m1 = None if mask is None else mask.reshape(V).contiguous()
         f16 = OPTIONS["fwd_f16"]
         out_f = V3.shape[0]
@@ -353,7 +355,7 @@ class FusedMPLayerFn(torch.autograd.Function):
 
         # layer-1 node terms a | c = x [W1a ; W1c]^T (+ b1 on the a half), one launch
         ac = torch.empty((V, 2 * H1), device=dev, dtype=torch.float32)
-        chain(V, [dict(img=pk.ptr("W1S"), K=F, N=2 * H1, bias=b1, nbias=H1, out=ac)], A=x2, lda=F, K1=F,
+        chain(V, [dict(img=pk.ptr("W1S"), K=F, N=2 * H1, bias=b1, nbias=H1, out=ac)], A=x2, lda=x2.stride(0), K1=F,
               alpha=alpha, f16=f16)
         SC = _sender_chunks(B, N)
         aggp = torch.empty((SC, V, H3), device=dev, dtype=torch.float32)
@@ -381,7 +383,7 @@ class FusedMPLayerFn(torch.autograd.Function):
         chain(V, [dict(img=pk.ptr("V1"), K=H3 + F, N=n1, bias=c1, act=True, drop=dr(TAG_N0), out=h1),
                   dict(img=pk.ptr("V2"), K=n1, N=n2, bias=c2, act=True, drop=dr(TAG_N1), out=h2),
                   dict(img=pk.ptr("V3"), K=n2, N=out_f, bias=c3, act=False, drop=dr(TAG_N2), out=y)],
-              A=agg, lda=H3, K1=H3, A2=x2, lda2=F, alpha=alpha, seed_t=seed_t, f16=f16)
+              A=agg, lda=H3, K1=H3, A2=x2, lda2=x2.stride(0), alpha=alpha, seed_t=seed_t, f16=f16)
         ctx.packed = pk
 
         ctx.save_for_backward(x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3)

@@ -142,7 +142,7 @@ class TrainStep:
     def _noise(self, which: int = 0):
         if self.fixed_noise is not None:
             return self.fixed_noise[which]
-        return torch.randn(self.B, self.N, self.latent, device=self.dev) * self.noise_std
+        return torch.empty(self.B, self.N, self.latent, device=self.dev).normal_(0.0, self.noise_std)
 
     def _seg_D(self):  # train_D up to and including backward (train.py:419-460)
         # parameter gradients are added straight into the flat buffers (no AccumulateGrad kernel per parameter)
