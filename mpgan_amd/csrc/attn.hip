@@ -26,16 +26,20 @@ MPG_DEV void lds_row(const float* base, int row, float (&out)[D]) {  // broadcas
     }
 }
 
-template <int D>
+template <int D, bool TWO>
 __global__ __launch_bounds__(256) void attn_fwd_fast(const MpgAttn p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int pair = blockIdx.x * 4 + w;           // (jet, head)
-    if (pair >= p.B * p.H) return;                 // whole wave; no block-wide barrier below
+    // TWO (L <= 32): each 32-lane half of a wave owns its own (jet, head) pair (8 pairs per workgroup), else the wave one
+    const int w = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
+    constexpr bool two = TWO;
+    const int half = two ? lane64 >> 5 : 0, lane = two ? lane64 & 31 : lane64, nl = two ? 32 : 64;
+    int pair = two ? (blockIdx.x * 4 + w) * 2 + half : blockIdx.x * 4 + w;   // (jet, head)
+    const bool live = pair < p.B * p.H;
+    if (!live) pair = p.B * p.H - 1;               // idle half: recompute the last pair, store nothing
     const int b = pair / p.H, hd = pair % p.H;
-    float* ks = sm + w * (2 * AT_S * D);           // [S][D]
+    float* ks = sm + (two ? w * 2 + half : w) * (2 * AT_S * D);   // [S][D]
     float* vs = ks + AT_S * D;
-    for (int t = lane; t < p.S * (D / 4); t += 64) {
+    for (int t = lane; t < p.S * (D / 4); t += nl) {
         const int s = t / (D / 4), c = 4 * (t % (D / 4));
         *reinterpret_cast<float4*>(ks + s * D + c) = *reinterpret_cast<const float4*>(p.k + (size_t)(b * p.S + s) * p.ldk + hd * D + c);
         *reinterpret_cast<float4*>(vs + s * D + c) = *reinterpret_cast<const float4*>(p.v + (size_t)(b * p.S + s) * p.ldv + hd * D + c);
@@ -43,7 +47,7 @@ __global__ __launch_bounds__(256) void attn_fwd_fast(const MpgAttn p) {
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int l = lane;
-    if (l >= p.L) return;
+    if (l >= p.L || !live) return;
     const float scale = rsqrtf((float)D);
     float q[D];
     {
@@ -95,26 +99,33 @@ __global__ __launch_bounds__(256) void attn_fwd_fast(const MpgAttn p) {
 }
 
 // backward: dV = P^T dO ; dP = dO V^T ; dS = P * (dP - rowsum(dP * P)) ; dQ = dS K / sqrt(d) ; dK = dS^T Q / sqrt(d)
-template <int D>
+template <int D, bool TWO>
 __global__ __launch_bounds__(256) void attn_bwd_fast(const MpgAttn p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int pair = blockIdx.x * 4 + w;
-    if (pair >= p.B * p.H) return;
+    const int w = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
+    constexpr bool two = TWO;            // (L <= 32, S <= 32): a 32-lane half per (jet, head) pair
+    const int half = two ? lane64 >> 5 : 0, lane = two ? lane64 & 31 : lane64, nl = two ? 32 : 64;
+    int pair = two ? (blockIdx.x * 4 + w) * 2 + half : blockIdx.x * 4 + w;
+    const bool live = pair < p.B * p.H;
+    if (!live) pair = p.B * p.H - 1;     // idle half: recompute the last pair, store nothing
     const int b = pair / p.H, hd = pair % p.H;
-    constexpr int PER = 2 * AT_S * D + 2 * AT_L * D + 2 * AT_S * AT_L;
-    float* ks = sm + w * PER;            // [S][D]
+    const int capl = two ? 32 : AT_L;    // query capacity of this pair's LDS slice
+    // row stride of dS / P: odd, so that the key-major reads (one row per lane) spread over the banks -- except where
+    // four wave-sized slices with d = 32 would no longer fit the LDS
+    const int ldl = (!two && D == 32) ? capl : capl + 1;
+    const int PER = 2 * AT_S * D + 2 * capl * D + 2 * AT_S * ldl;
+    float* ks = sm + (two ? w * 2 + half : w) * PER;   // [S][D]
     float* vs = ks + AT_S * D;           // [S][D]
     float* qs = vs + AT_S * D;           // [L][D]
-    float* gs = qs + AT_L * D;           // [L][D]  dO
-    float* dsl = gs + AT_L * D;          // [S][AT_L]  dS (key-major: lane-contiguous writes)
-    float* pl = dsl + AT_S * AT_L;       // [S][AT_L]  P
-    for (int t = lane; t < p.S * (D / 4); t += 64) {
+    float* gs = qs + capl * D;           // [L][D]  dO
+    float* dsl = gs + capl * D;          // [S][ldl]  dS (written query-major: lanes contiguous)
+    float* pl = dsl + AT_S * ldl;        // [S][ldl]  P
+    for (int t = lane; t < p.S * (D / 4); t += nl) {
         const int s = t / (D / 4), c = 4 * (t % (D / 4));
         *reinterpret_cast<float4*>(ks + s * D + c) = *reinterpret_cast<const float4*>(p.k + (size_t)(b * p.S + s) * p.ldk + hd * D + c);
         *reinterpret_cast<float4*>(vs + s * D + c) = *reinterpret_cast<const float4*>(p.v + (size_t)(b * p.S + s) * p.ldv + hd * D + c);
     }
-    for (int t = lane; t < p.L * (D / 4); t += 64) {
+    for (int t = lane; t < p.L * (D / 4); t += nl) {
         const int l = t / (D / 4), c = 4 * (t % (D / 4));
         *reinterpret_cast<float4*>(qs + l * D + c) = *reinterpret_cast<const float4*>(p.q + (size_t)(b * p.L + l) * p.ldq + hd * D + c);
         *reinterpret_cast<float4*>(gs + l * D + c) = *reinterpret_cast<const float4*>(p.d_o + (size_t)(b * p.L + l) * p.ldo + hd * D + c);
@@ -123,7 +134,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fast(const MpgAttn p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const float scale = rsqrtf((float)D);
     const float* Pt = p.P + (size_t)pair * p.S * p.L;  // [S][L]
-    if (lane < p.L) {  // ---- query-major half
+    if (lane < p.L && live) {  // ---- query-major half
         const int l = lane;
         float g[D];
         lds_row<D>(gs, l, g);
@@ -148,8 +159,8 @@ __global__ __launch_bounds__(256) void attn_bwd_fast(const MpgAttn p) {
         for (int s = 0; s < AT_S; ++s) {
             if (s < p.S) {
                 const float x = pr[s] * (dp[s] - dot);
-                dsl[s * AT_L + l] = x;
-                pl[s * AT_L + l] = pr[s];
+                dsl[s * ldl + l] = x;
+                pl[s * ldl + l] = pr[s];
                 float kr[D];
                 lds_row<D>(ks, s, kr);
 #pragma unroll
@@ -163,13 +174,13 @@ __global__ __launch_bounds__(256) void attn_bwd_fast(const MpgAttn p) {
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane < p.S) {  // ---- key-major half
+    if (lane < p.S && live) {  // ---- key-major half
         const int s = lane;
         float dk[D], dv[D];
 #pragma unroll
         for (int c = 0; c < D; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
         for (int l = 0; l < p.L; ++l) {
-            const float x = dsl[s * AT_L + l], pr = pl[s * AT_L + l];
+            const float x = dsl[s * ldl + l], pr = pl[s * ldl + l];
             float qr[D], gr[D];
             lds_row<D>(qs, l, qr);
             lds_row<D>(gs, l, gr);
@@ -307,12 +318,20 @@ extern "C" int mpg_attn_fwd(const MpgAttn* p, void* stream) {
     if (p->d > DMAX || p->B <= 0) return -1;
     if (attn_fast_shape(p)) {
         if (!attn_aligned(p, false)) return -3;
-        const dim3 grid((p->B * p->H + 3) / 4), block(256);
-        const size_t lds = (size_t)4 * 2 * AT_S * p->d * 4;
+        const bool two = p->L <= 32;
+        const int ppw = two ? 8 : 4;  // (jet, head) pairs per workgroup
+        const dim3 grid((p->B * p->H + ppw - 1) / ppw), block(256);
+        const size_t lds = (size_t)ppw * 2 * AT_S * p->d * 4;
         hipStream_t st = (hipStream_t)stream;
-        if (p->d == 8) hipLaunchKernelGGL(attn_fwd_fast<8>, grid, block, lds, st, *p);
-        else if (p->d == 16) hipLaunchKernelGGL(attn_fwd_fast<16>, grid, block, lds, st, *p);
-        else hipLaunchKernelGGL(attn_fwd_fast<32>, grid, block, lds, st, *p);
+#define MPG_ATTN_FWD(DV)                                                                          \
+    do {                                                                                          \
+        if (two) hipLaunchKernelGGL((attn_fwd_fast<DV, true>), grid, block, lds, st, *p);         \
+        else hipLaunchKernelGGL((attn_fwd_fast<DV, false>), grid, block, lds, st, *p);            \
+    } while (0)
+        if (p->d == 8) MPG_ATTN_FWD(8);
+        else if (p->d == 16) MPG_ATTN_FWD(16);
+        else MPG_ATTN_FWD(32);
+#undef MPG_ATTN_FWD
         return (int)hipGetLastError();
     }
     const size_t lds = (size_t)2 * p->S * p->d * 4;
@@ -326,21 +345,29 @@ extern "C" int mpg_attn_bwd(const MpgAttn* p, void* stream) {
     if (p->d > DMAX || p->B <= 0) return -1;
     if (attn_fast_shape(p)) {
         if (!attn_aligned(p, true)) return -3;
-        const dim3 grid((p->B * p->H + 3) / 4), block(256);
-        const size_t lds = (size_t)4 * (2 * AT_S * p->d + 2 * AT_L * p->d + 2 * AT_S * AT_L) * 4;
+        auto need = [&](bool two) {
+            const int capl = two ? 32 : AT_L, ldl = (!two && p->d == 32) ? capl : capl + 1;  // as in the kernel
+            return (size_t)(two ? 8 : 4) * (2 * AT_S * p->d + 2 * capl * p->d + 2 * AT_S * ldl) * 4;
+        };
+        const bool two = p->L <= 32 && need(true) <= 160 * 1024;  // d = 32 does not fit eight pairs
+        const int ppw = two ? 8 : 4;
+        const dim3 grid((p->B * p->H + ppw - 1) / ppw), block(256);
+        const size_t lds = need(two);
         hipStream_t st = (hipStream_t)stream;
-#define MPG_ATTN_BWD(DV)                                                                                                  \
+#define MPG_ATTN_BWD(DV, TW)                                                                                              \
     do {                                                                                                                  \
-        static bool done = false;                                                                                         \
-        if (!done && lds > 64 * 1024) {                                                                                   \
-            HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_fast<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            done = true;                                                                                                  \
+        static size_t attr = 0;                                                                                           \
+        if (lds > 64 * 1024 && lds > attr) {                                                                              \
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_fast<DV, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr = lds;                                                                                                   \
         }                                                                                                                 \
-        hipLaunchKernelGGL(attn_bwd_fast<DV>, grid, block, lds, st, *p);                                                  \
+        hipLaunchKernelGGL((attn_bwd_fast<DV, TW>), grid, block, lds, st, *p);                                            \
     } while (0)
-        if (p->d == 8) MPG_ATTN_BWD(8);
-        else if (p->d == 16) MPG_ATTN_BWD(16);
-        else MPG_ATTN_BWD(32);
+#define MPG_ATTN_BWD2(DV) do { if (two) MPG_ATTN_BWD(DV, true); else MPG_ATTN_BWD(DV, false); } while (0)
+        if (p->d == 8) MPG_ATTN_BWD2(8);
+        else if (p->d == 16) MPG_ATTN_BWD2(16);
+        else MPG_ATTN_BWD2(32);
+#undef MPG_ATTN_BWD2
 #undef MPG_ATTN_BWD
         return (int)hipGetLastError();
     }
