@@ -60,14 +60,13 @@ class MAB(nn.Module):
             km = y_mask if y_mask.dim() == 2 else y_mask[:, 0, :]
             ignore = km.reshape(B * S).float().contiguous()
         x2 = x.reshape(B * L, E)
-        if x is y:
+        if x is y:   # the packed projections go to the attention core as they are (no q/k/v slices in autograd)
             qkv = _lin(x2, att.in_proj_weight, att.in_proj_bias, 0, 3 * E)
-            q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
+            o = ops.FusedPackedAttnFn.apply(qkv, None, ignore, B, L, S, self.num_heads)
         else:
             q = _lin(x2, att.in_proj_weight, att.in_proj_bias, 0, E)
             kv = _lin(y.reshape(B * S, E), att.in_proj_weight, att.in_proj_bias, E, 2 * E)
-            k, v = kv[:, :E], kv[:, E:]
-        o = ops.FusedAttnFn.apply(q, k, v, ignore, B, L, S, self.num_heads)
+            o = ops.FusedPackedAttnFn.apply(q, kv, ignore, B, L, S, self.num_heads)
         a = ops.FusedLinearFn.apply(o, att.out_proj.weight, att.out_proj.bias, False, 0.2, 0.0, False)
         z = ops.FusedDropoutFn.apply(x2 + a, self.dropout_p, self.training)
         out = ops.FusedDropoutFn.apply(z + self.ff(z), self.dropout_p, self.training)

@@ -596,6 +596,47 @@ def _attn_struct(q, k, v, ignore, o, P, B, L, S, H, d):
     return a
 
 
+class FusedPackedAttnFn(torch.autograd.Function):
+    """FusedAttnFn on PACKED projections, as MAB produces them: self-attention takes qkv [B*L, 3E] (kv = None),
+    cross-attention q [B*L, E] and kv [B*S, 2E].  The backward writes dq / dk / dv straight into one gradient
+    tensor per packed input -- slicing q, k, v out in autograd instead costs a zero-fill, a copy and an add per slice."""
+
+    @staticmethod
+    def forward(ctx, qx, kv, ignore, B, L, S, H):
+        _chk(qx, "qkv")
+        self_attn = kv is None
+        E = qx.shape[1] // 3 if self_attn else qx.shape[1]
+        d = E // H
+        q = qx[:, :E]
+        k, v = (qx[:, E:2 * E], qx[:, 2 * E:]) if self_attn else (kv[:, :E], kv[:, E:])
+        o = torch.empty((B * L, E), device=qx.device, dtype=torch.float32)
+        P = torch.empty((B, H, L, S), device=qx.device, dtype=torch.float32)
+        a = _attn_struct(q, k, v, ignore, o, P, B, L, S, H, d)
+        check(_lib.lib().mpg_attn_fwd(C.byref(a), _stream()), "mpg_attn_fwd")
+        ctx.save_for_backward(qx, kv, P)
+        ctx.ignore = ignore
+        ctx.dims = (B, L, S, H, d, E, self_attn)
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        qx, kv, P = ctx.saved_tensors
+        B, L, S, H, d, E, self_attn = ctx.dims
+        go = go.contiguous()
+        dqx = torch.empty_like(qx)
+        dkv = None if self_attn else torch.empty_like(kv)
+        q = qx[:, :E]
+        k, v = (qx[:, E:2 * E], qx[:, 2 * E:]) if self_attn else (kv[:, :E], kv[:, E:])
+        dq = dqx[:, :E]
+        dk, dv = (dqx[:, E:2 * E], dqx[:, 2 * E:]) if self_attn else (dkv[:, :E], dkv[:, E:])
+        a = _attn_struct(q, k, v, ctx.ignore, go, P, B, L, S, H, d)
+        a.d_o = _p(go)
+        a.dq, a.dk, a.dv = C.c_void_p(dq.data_ptr()), C.c_void_p(dk.data_ptr()), C.c_void_p(dv.data_ptr())
+        a.lddq, a.lddk, a.lddv = dq.stride(0), dk.stride(0), dv.stride(0)
+        check(_lib.lib().mpg_attn_bwd(C.byref(a), _stream()), "mpg_attn_bwd")
+        return dqx, dkv, None, None, None, None, None
+
+
 class FusedAttnFn(torch.autograd.Function):
     """softmax(q k^T / sqrt(d) + key mask) v per (jet, head): q [B*L, E], k, v [B*S, E] (row-strided
     views are fine), ignore [B*S] floats (1 = padded key) or None."""
