@@ -67,9 +67,10 @@ class MAB(nn.Module):
             q = _lin(x2, att.in_proj_weight, att.in_proj_bias, 0, E)
             kv = _lin(y.reshape(B * S, E), att.in_proj_weight, att.in_proj_bias, E, 2 * E)
             o = ops.FusedPackedAttnFn.apply(q, kv, ignore, B, L, S, self.num_heads)
-        a = ops.FusedLinearFn.apply(o, att.out_proj.weight, att.out_proj.bias, False, 0.2, 0.0, False)
-        z = ops.FusedDropoutFn.apply(x2 + a, self.dropout_p, self.training)
-        out = ops.FusedDropoutFn.apply(z + self.ff(z), self.dropout_p, self.training)
+        # x + out_proj(attention): the residual is added in the projection's own launch
+        za = ops.FusedLinearFn.apply(o, att.out_proj.weight, att.out_proj.bias, False, 0.2, 0.0, False, x2)
+        z = ops.FusedDropoutFn.apply(za, self.dropout_p, self.training)
+        out = ops.FusedDropoutFn.apply(self.ff(z, resid=z), self.dropout_p, self.training)
         return out.reshape(B, L, E)
 
 

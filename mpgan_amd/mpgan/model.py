@@ -43,12 +43,17 @@ class LinearNet(nn.Module):
         self.dropout_p = float(dropout_p)
         self.net = nn.ModuleList(nn.Linear(i, o) for i, o in zip(widths[:-1], widths[1:]))
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, resid: Tensor = None) -> Tensor:
+        """``resid`` (not in the reference signature): added to the output, inside the last layer's launch when that
+        layer has no activation -- MAB's ``x + ff(x)``."""
         last = len(self.net) - 1
         for k, lin in enumerate(self.net):
             act = not (self.final_linear and k == last)
+            fuse = resid if (k == last and not act) else None
             x = ops.FusedLinearFn.apply(x, lin.weight, lin.bias, act, self.leaky_relu_alpha, self.dropout_p,
-                                        self.training)
+                                        self.training, fuse)
+            if k == last and resid is not None and fuse is None:
+                x = x + resid
         return x
 
     def __repr__(self):

@@ -518,17 +518,23 @@ def _grad_target(t):
 
 
 class FusedLinearFn(torch.autograd.Function):
-    """Linear -> [LeakyReLU] -> [Dropout] (one LinearNet layer; mpgan/model.py:77-83)."""
+    """Linear -> [LeakyReLU] -> [Dropout] (one LinearNet layer; mpgan/model.py:77-83), optionally ``+ resid`` in the
+    same launch (MAB's residual connections, gapt/model.py:131-137; only for a layer without activation)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, act, alpha, p_drop, training):
+    def forward(ctx, x, W, b, act, alpha, p_drop, training, resid=None):
         _chk(x, "x")
         shp = x.shape
         x2 = x.reshape(-1, shp[-1]).contiguous()
         thr, dscale = drop_params(p_drop) if training else (0, 1.0)
         seed_t = seed_tensor(x.device)
         tag = next_tag()
-        y = linear_fwd(x2, W, b, act=act, alpha=alpha, drop=(seed_t, tag + TAG_GENERIC, thr, dscale) if thr else None)
+        if resid is not None and act:  # (the backward reads the activation's sign off the saved output)
+            raise NotImplementedError("FusedLinearFn: a fused residual needs a layer without activation")
+        r2 = None if resid is None else resid.reshape(-1, W.shape[0]).contiguous()
+        y = linear_fwd(x2, W, b, act=act, alpha=alpha, drop=(seed_t, tag + TAG_GENERIC, thr, dscale) if thr else None,
+                       resid=r2)
+        ctx.has_resid = resid is not None
         ctx.save_for_backward(x2, W, y)
         ctx.wparam, ctx.bias = W, b  # (only their .grad buffers are touched, by the deferred weight-gradient path)
         ctx.cfg = (shp, act, alpha, thr, dscale, tag, b is not None)
@@ -557,7 +563,7 @@ class FusedLinearFn(torch.autograd.Function):
         elif want_b:
             db = g2.sum(0)
         dx = linear_bwd_data(g2, W).reshape(shp) if ctx.needs_input_grad[0] else None
-        return dx, dW, db, None, None, None, None
+        return dx, dW, db, None, None, None, None, (gy if ctx.has_resid else None)
 
 
 class FusedDropoutFn(torch.autograd.Function):
