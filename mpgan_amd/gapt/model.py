@@ -57,8 +57,10 @@ class MAB(nn.Module):
         att = self.attention
         ignore = None
         if y_mask is not None:
-            km = y_mask if y_mask.dim() == 2 else y_mask[:, 0, :]
-            ignore = km.reshape(B * S).float().contiguous()
+            ignore = getattr(y_mask, "_mpg_ignore", None)  # float key mask prepared once per network forward
+            if ignore is None or ignore.numel() != B * S:
+                km = y_mask if y_mask.dim() == 2 else y_mask[:, 0, :]
+                ignore = km.reshape(B * S).float().contiguous()
         x2 = x.reshape(B * L, E)
         if x is y:   # the packed projections go to the attention core as they are (no q/k/v slices in autograd)
             qkv = _lin(x2, att.in_proj_weight, att.in_proj_bias, 0, 3 * E)
@@ -80,7 +82,7 @@ class SAB(nn.Module):
         self.mab = MAB(**mab_args)
 
     def forward(self, x: Tensor, mask: Tensor = None):
-        return self.mab(x, x, None if mask is None else mask[:, :, 0])  # mask [B,N,1] bool, True = ignore
+        return self.mab(x, x, _key_mask(mask))  # mask [B,N,1] bool, True = ignore
 
 
 class PMA(nn.Module):
@@ -92,7 +94,7 @@ class PMA(nn.Module):
 
     def forward(self, x: Tensor, mask: Tensor = None):
         seeds = self.S.expand(x.size(0), -1, -1).contiguous()
-        return self.mab(seeds, x, None if mask is None else mask[:, :, 0])
+        return self.mab(seeds, x, _key_mask(mask))
 
 
 class ISAB(nn.Module):
@@ -106,13 +108,30 @@ class ISAB(nn.Module):
 
     def forward(self, X, mask: Tensor = None):
         ind = self.I.expand(X.size(0), -1, -1).contiguous()
-        H = self.mab0(ind, X, None if mask is None else mask[:, :, 0])
+        H = self.mab0(ind, X, _key_mask(mask))
         return self.mab1(X, H)
 
 
 def _attn_mask(mask: Tensor) -> Optional[Tensor]:
-    """JetNet mask (1 real, 0 padded) -> attention convention (True = ignore)."""
-    return None if mask is None else (1 - mask).bool()
+    """JetNet mask (1 real, 0 padded) -> attention convention (True = ignore).  The float form the attention kernels
+    take ([B*N], 1 = ignore) rides along as an attribute, so that the blocks of a network do not each convert it."""
+    if mask is None:
+        return None
+    inv = 1 - mask
+    am = inv.bool()
+    am._mpg_ignore = inv.reshape(-1).contiguous()
+    return am
+
+
+def _key_mask(mask: Optional[Tensor]) -> Optional[Tensor]:
+    """[B,N,1] attention mask -> the [B,N] key mask a MAB takes (keeping the prepared float form attached)."""
+    if mask is None:
+        return None
+    km = mask[:, :, 0]
+    ig = getattr(mask, "_mpg_ignore", None)
+    if ig is not None:
+        km._mpg_ignore = ig
+    return km
 
 
 def _sab_args(embed_dim, sab_fc_layers, num_heads, layer_norm, dropout_p, linear_args):

@@ -7,9 +7,10 @@ from torch.profiler import profile, ProfilerActivity
 from mpgan_amd import train
 from oracle import train_ref as T
 dev = torch.device("cuda:0")
-G, D = train.default_mpgan(30, device=dev)
-ts = train.TrainStep(G, D, 256, 30, use_graphs=False)
-data, labels = T.synthetic_batch(256, 30, seed=1, dist="gluon")
+G, D = (train.default_gapt if os.environ.get("OPC_GAPT") else train.default_mpgan)(30, device=dev)
+BATCH = 512 if os.environ.get("OPC_GAPT") else 256
+ts = train.TrainStep(G, D, BATCH, 30, latent=64 if os.environ.get("OPC_GAPT") else 32, use_graphs=False)
+data, labels = T.synthetic_batch(BATCH, 30, seed=1, dist="gluon")
 ts.set_batch(data.to(dev), labels.to(dev))
 for _ in range(3): ts.step()
 torch.cuda.synchronize()
