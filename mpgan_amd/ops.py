@@ -161,6 +161,8 @@ def linear_bwd_weight(dy, x, *, out=None, out_col0=0, out_scale=1.0, bias_out=No
 # Set by train.TrainStep around a backward: FusedLinearFn queues its weight gradients here instead of launching
 # one small split-K GEMM + reduction per layer; TrainStep flushes the queue (grouped launches) before the optimizer.
 DEFERRED_WGRAD = None
+# workgroups a single weight-gradient GEMM of a group aims for when choosing its split-K factor
+WGRAD_TARGET_WGS = int(__import__("os").environ.get("MPG_WGRAD_TARGET", "512"))
 
 
 class WgradBatch:
@@ -175,7 +177,7 @@ class WgradBatch:
         K = x.shape[1]
         hb = int(bias_out is not None)
         tiles = ((N + 63) // 64) * ((K + hb + 63) // 64)
-        splitk = max(1, min((M + 255) // 256, (1024 + tiles - 1) // tiles))
+        splitk = max(1, min((M + 255) // 256, (WGRAD_TARGET_WGS + tiles - 1) // tiles))
         part = torch.empty((splitk, N, K + hb), device=dy.device, dtype=torch.float32)
         self.jobs.append((dy, x, out, out_col0, out_scale, bias_out, splitk, part, accumulate))
 
