@@ -172,14 +172,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIBPATH
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
+    jobs = []
     for src in sources():
         obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + EXTRA_FLAGS + ["-I", INCLUDE, "-c", src, "-o", obj]
+        jobs.append((obj, [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + EXTRA_FLAGS + ["-I", INCLUDE, "-c", src, "-o", obj]))
+    # the translation units are independent (one takes over a minute): compile them side by side
+    from concurrent.futures import ThreadPoolExecutor
+
+    def run(job):
         if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
-        objs.append(obj)
+            print(" ".join(job[1]))
+        subprocess.run(job[1], check=True)
+        return job[0]
+    with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        objs = list(ex.map(run, jobs))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIBPATH] + objs
     subprocess.run(cmd, check=True)
     return LIBPATH
