@@ -1,20 +1,27 @@
 #!/usr/bin/env python3
 """Headline benchmark: jets/sec of one full G+D training iteration, MPGAN gluon-30, B = 256 per GPU.
 
-  python bench.py --gpus N --steps K --warmup W            (N = 1)
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+  python bench.py --gpus N --steps K --warmup W
+
+N = 1 runs in this process.  N > 1 without torchrun's environment starts N ranks itself (one per GPU, RCCL,
+127.0.0.1 rendezvous) BEFORE anything here touches a GPU and waits for them; under
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` it is one of the ranks.
 
 One "step" = train_D + train_G (reference train.py:398-523) on one synthetic JetNet-30-like batch
-resident in HBM, fresh generator noise and dropout masks every step, RMSprop updates included.
+resident in HBM, fresh generator noise and dropout masks every step, optimizer updates included.
 Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline      -- the dominant kernel's algorithmic FLOP rate vs the dense 16-bit MFMA peak, from
-                   HIP-event timings taken in this process on the launch stream
+  roofline      -- the dominant kernel's algorithmic FLOP (or byte) rate vs the MI355X peak, from HIP-event timings
+                   taken in this process on the launch stream
   cpu_baseline  -- the CPU oracle (own port of the reference step) timed on this box's host cores
                    on a bounded sample (rank 0, N = 1 only)
+Other workloads (``--model gapt`` = BASELINE config 4, ``--particles 150 --batch 16`` = config 5's per-GPU shard)
+print the same line under their own metric name.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,13 +29,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_MFMA_16BIT = 2.5e15  # dense bf16/f16 MFMA, MI355X (MI355X_MICROARCH.md, chip-level parameters)
-
+PEAK_HBM = 8.0e12         # HBM3E bytes/s, same guide
 
 H1, H2, H3 = 96, 160, 192
+SPLIT = 3                 # MFMA MACs issued per algorithmic MAC (hi/lo operand split, csrc/common.h)
 
 
+# --------------------------------------------------------------------------- work models
 def edge_flops_per_jet(N, F):
-    """Algorithmic FLOPs of fe on one jet, dense reference formulation (SURVEY.md section 8d)."""
+    """Algorithmic FLOPs of fe on one jet, dense reference formulation."""
     return N * N * 2 * (2 * F * 96 + 96 * 160 + 160 * 192)
 
 
@@ -40,6 +49,35 @@ def iteration_flops_per_jet(N):
     g = edge_flops_per_jet(N, 32) * 2 + node_flops_per_jet(N, 32, 32) + node_flops_per_jet(N, 32, 3)
     d = edge_flops_per_jet(N, 3) + edge_flops_per_jet(N, 32) + node_flops_per_jet(N, 3, 32) + node_flops_per_jet(N, 32, 32)
     return 3 * (3 * d + 2 * g)  # forward (3 D + 2 G) + backward counted as 2x forward
+
+
+def executed_flops_per_jet(N, valid_frac):
+    """MFMA FLOPs the fused path actually ISSUES per jet and G+D iteration: the logical MACs of every launch in the
+    step (x2) times the 3 MFMAs of the hi/lo split.  Differences to the algorithmic figure: layer 1 of fe is the
+    factorised a_i + c_j (two node-level products instead of one per edge); masked senders are skipped (``valid_frac``
+    = mean multiplicity / N of the batch); the backward recomputes fe layer 2; train_D does not back-propagate
+    into G and train_G forms no weight gradients of D (both results-neutral, train.py:420, :495).  Tile padding
+    (30 receivers on 32 lanes, K rounded up to 32) is not counted."""
+    E = N * N * valid_frac                      # edges that are computed per jet-layer
+
+    def layer(F, out, fwd, bwd_x, bwd_w, first):
+        f = 0.0
+        node_fwd = 2 * ((H3 + F) * 256 + 256 * 256 + 256 * out) * N
+        ac = 2 * F * 2 * H1 * N
+        f += fwd * (ac + E * 2 * (H1 * H2 + H2 * H3) + node_fwd)
+        if bwd_x or bwd_w:
+            f += node_fwd                                                       # fn input-gradient chain
+            f += E * 2 * (H1 * H2 + H2 * H3 + H2 * H1)                          # recompute L2, dE2, dE1
+            if bwd_w:
+                f += E * 2 * (H3 * H2 + H2 * H1) + node_fwd + ac                # dW3, dW2; fn dW; dW1
+            if not first:
+                f += ac                                                         # dx through [W1a ; W1c]
+        return f
+    G = lambda fwd, bx, bw: layer(32, 32, fwd, bx, bw, True) + layer(32, 3, fwd, bx, bw, False)
+    D = lambda fwd, bx, bw: layer(3, 32, fwd, bx, bw, True) + layer(32, 32, fwd, bx, bw, False)
+    step_D = G(1, 0, 0) + 2 * D(1, 1, 1)        # G forward only; D forward + full backward on real + generated
+    step_G = G(1, 1, 1) + D(1, 1, 0)            # D: data gradient only
+    return SPLIT * (step_D + step_G)
 
 
 def log(*a):
@@ -56,7 +94,7 @@ def host_threads():
     return max(1, min(n, int(os.environ.get("MPGAN_BENCH_CPU_THREADS", "16"))))
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -69,43 +107,63 @@ def main():
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N > 1 outside torchrun: become the launcher.  Nothing in this process has touched a GPU yet (torch is
+    not even imported), so starting children is safe; the library is built first because ranks must not compile."""
+    from mpgan_amd import _lib
+    _lib.build()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("launching", " ".join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     import torch
     import torch.distributed as dist
+    from mpgan_amd import train, ops, dist as mdist
+    from mpgan_amd.data import synthetic_jets
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would misreport n_gpus")
+    if torch.cuda.device_count() < (local_rank + 1):
+        raise SystemExit(f"rank with LOCAL_RANK={local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    pg = None
+    rank, world, pg = mdist.init_from_env("nccl", dev)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-        pg = dist.group.WORLD
-
-    from mpgan_amd import train, ops
-    from oracle.train_ref import synthetic_batch
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     B, N = args.batch or (256 if args.model == "mpgan" else 512), args.particles
     torch.manual_seed(4 + rank)  # setup_training.py:184 (+ rank: every rank draws its own noise)
     if args.model == "mpgan":
-        G, D = train.default_mpgan(N, disc_dropout=0.5)
+        G, D = train.default_mpgan(N, disc_dropout=0.5, device=dev)
         latent, (lr_d, lr_g) = 32, train.LR["g"]
     else:
-        G, D = train.default_gapt(N, disc_dropout=0.5)
+        G, D = train.default_gapt(N, disc_dropout=0.5, device=dev)
         latent, (lr_d, lr_g) = 64, train.LR_GAPT
     if world > 1:  # one-time parameter broadcast from rank 0
-        for p in list(G.parameters()) + list(D.parameters()):
-            dist.broadcast(p.data, 0)
+        mdist.broadcast_module(G, 0, pg)
+        mdist.broadcast_module(D, 0, pg)
     ts = train.TrainStep(G, D, B, N, latent=latent, lr_disc=lr_d, lr_gen=lr_g, use_graphs=not args.no_graphs,
                          process_group=pg, world_size=world)
-    data, labels = synthetic_batch(B, N, seed=4 + rank, dist=args.dist)
+    data, labels = synthetic_jets(B, N, seed=4 + rank, dist=args.dist)
     ts.set_batch(data.to(dev), labels.to(dev))
-    ops.set_seed(0x5EED + rank, dev)
+    ops.set_seed(mdist.rank_seed(0x5EED, rank), dev)
+    valid_frac = float((data[..., 3] > 0).float().mean())
 
     def barrier():
         if world > 1:
@@ -130,8 +188,10 @@ def main():
     log(f"timed {args.steps} steps in {dt:.3f} s -> {jets_per_s:.0f} jets/s")
     d_loss, g_loss = float(ts.D_loss), float(ts.G_loss)
 
+    headline = args.model == "mpgan" and N == 30 and B == 256
     out = {
-        "metric": "jets/sec (G+D step) MPGAN gluon N=30 bs=256 @1/2/4/8 MI355X" if (args.model == "mpgan" and N == 30 and B == 256) else f"jets/sec (G+D step) {args.model} N={N} bs={B}",
+        "metric": "jets/sec (G+D step) MPGAN gluon N=30 bs=256 @1/2/4/8 MI355X" if headline
+                  else f"jets/sec (G+D step) {args.model} N={N} bs={B}",
         "value": jets_per_s, "unit": "jets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16x3 (forward) / bf16x3 (gradients) split-16-bit MFMA, fp32 accumulate, fp32 in/out",
@@ -139,114 +199,175 @@ def main():
         "config": {"workload": f"{args.model.upper()} gluon-like jets, N={N} particles, B={B} per GPU, one "
                                "train_D+train_G iteration (LSGAN, RMSprop, D dropout 0.5)",
                    "global_batch": world * B, "particles": N, "multiplicity": args.dist,
-                   "parallelism": f"dp{world}", "hip_graphs": not args.no_graphs},
+                   "mean_multiplicity": valid_frac * N, "parallelism": f"dp{world}", "hip_graphs": not args.no_graphs},
         "losses": {"D": d_loss, "G": g_loss},
     }
     if args.model == "mpgan":
         out["algorithmic_gflop_per_jet"] = iteration_flops_per_jet(N) / 1e9
+        out["executed_gflop_per_jet"] = executed_flops_per_jet(N, valid_frac) / 1e9
         out["whole_step_mfma_frac"] = jets_per_s / world * iteration_flops_per_jet(N) / PEAK_MFMA_16BIT
+        out["whole_step_executed_mfma_frac"] = jets_per_s / world * executed_flops_per_jet(N, valid_frac) / PEAK_MFMA_16BIT
 
     # ------------------------------------------------------------------ roofline of the dominant kernel
-    if rank == 0 and not args.no_roofline and args.model == "mpgan":
-        out["roofline"], out["kernels"] = roofline(torch, ts, B, N, dev)
-        log("roofline leg done", out["kernels"])
+    # rank 0 only, after the timed region, with the collectives switched off (the other ranks are not taking part)
+    if rank == 0 and not args.no_roofline:
+        ts.world, ts.pg = 1, None
+        out["roofline"], out["kernels"] = roofline(torch, ts, args.model, dev)
+        log("roofline leg done", out["roofline"]["kernel"], out["roofline"]["frac"])
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "mpgan":
-        out["cpu_baseline"] = cpu_baseline(torch, N)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(torch, args.model, N, B)
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()  # rank 0 arrives after its extra legs; nobody tears the group down under it
         dist.destroy_process_group()
 
 
-def roofline(torch, ts, B, N, dev):
-    """Time every launch of the two fused edge kernels with HIP events on the launch stream during
-    a few eager (un-captured) iterations of the same step, and price the slower one."""
+# --------------------------------------------------------------------------- roofline leg
+def _work(name, a):
+    """(algorithmic FLOPs, algorithmic HBM bytes) of one launch of entry point ``name`` with arguments ``a``."""
+    o = a[0]._obj if hasattr(a[0], "_obj") else None
+    if name in ("mpg_edge_fwd", "mpg_edge_bwd", "mpg_edge_dw"):
+        edges = o.B * o.N * o.N
+        # the two dense layers the kernel fuses per edge: forward e2 = W2 e1, e3 = W3 e2; backward dE2 = W3^T dZ3,
+        # dE1 = W2^T dZ2; weight gradients dW3 = dZ3 E2^T, dW2 = dZ2 E1^T -- (96*160 + 160*192) MAC = 92,160 FLOP per
+        # edge each.  The backward's recomputation of layer 2 and the 3x of the hi/lo split are execution cost.
+        io = {"mpg_edge_fwd": 2 * H1 + H3, "mpg_edge_bwd": 2 * H1 + H3 + 2 * H1, "mpg_edge_dw": 2 * H1 + H3}[name]
+        return edges * 2 * (H1 * H2 + H2 * H3), o.B * o.N * io * 4
+    if name in ("mpg_attn_fwd", "mpg_attn_bwd"):
+        E = o.H * o.d
+        fl = 4 * o.B * o.H * o.L * o.S * o.d
+        by = 4 * (o.B * (o.L + 2 * o.S) * E + o.B * o.L * E + o.B * o.H * o.L * o.S)
+        return (fl, by) if name == "mpg_attn_fwd" else (2 * fl, 2 * by)
+    if name == "mpg_gemm":
+        return 2 * o.M * o.N * o.K, 4 * (o.M * o.K + o.N * o.K + o.M * o.N * (2 if o.resid else 1))
+    if name == "mpg_chain":
+        fl = by = 0
+        for l in range(o.nlayers):
+            L = o.L[l]
+            fl += 2 * o.M * L.K * L.N
+            by += 4 * o.M * L.N * (1 if L.out else 0) + 4 * L.K * L.N
+        return fl, by + 4 * o.M * o.L[0].K
+    return 0, 0
+
+
+def roofline(torch, ts, model, dev):
+    """Time every launch of every C-ABI entry point with HIP events on the launch stream during a few eager
+    (un-captured) iterations of the same step, and price the one that takes the most time."""
     from mpgan_amd import _lib
     lib = _lib.lib()
-    rec = {"mpg_edge_fwd": [], "mpg_edge_bwd": []}
-    orig = {k: getattr(lib, k) for k in rec}
-
-    def wrap(name):
-        fn = orig[name]
-
-        def timed(*a):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = fn(*a)
-            e1.record()
-            rec[name].append((e0, e1, a[0]._obj.B * a[0]._obj.N * a[0]._obj.N))
-            return r
-        return timed
+    rec = {}
+    ITER = 4
 
     class Proxy:
         def __getattr__(self, k):
-            return wrap(k) if k in rec else getattr(lib, k)
+            fn = getattr(lib, k)
+            if not k.startswith("mpg_"):
+                return fn
+
+            def timed(*a):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = fn(*a)
+                e1.record()
+                rec.setdefault(k, []).append((e0, e1) + _work(k, a))
+                return r
+            return timed
 
     saved = _lib._lib
     _lib._lib = Proxy()
     try:
-        for _ in range(4):
+        for _ in range(ITER):
             ts._eager()
         torch.cuda.synchronize(dev)
     finally:
         _lib._lib = saved
-    # Algorithmic work of one launch of either kernel: the two dense layers it fuses per edge -- forward
-    # e2 = W2 e1, e3 = W3 e2; backward dE2 = W3^T dZ3, dE1 = W2^T dZ2 -- (96*160 + 160*192) MAC = 92,160 FLOP per
-    # edge, B*N*N edges (the discriminator step runs real + generated jets as one 2B launch).  The backward's
-    # recomputation of layer 2 and the 3x of the hi/lo split are execution cost, not algorithmic work.
-    FLOP_PER_EDGE = 2 * (H1 * H2 + H2 * H3)
     kern, tot = {}, {}
     for name, evs in rec.items():
-        evs = evs[len(evs) // 4:]  # drop the first iteration
-        ms = [a.elapsed_time(b) for a, b, _ in evs]
-        kern[name] = {"launches_per_step": len(rec[name]) // 4, "avg_ms": sum(ms) / len(ms), "max_ms": max(ms),
-                      "avg_edges": sum(e for _, _, e in evs) / len(evs)}
-        tot[name] = (sum(ms), sum(e for _, _, e in evs) * FLOP_PER_EDGE)
+        per = len(evs) // ITER
+        evs = evs[per:]  # drop the first iteration
+        ms = [a.elapsed_time(b) for a, b, _, _ in evs]
+        kern[name] = {"launches_per_step": per, "avg_ms": sum(ms) / len(ms), "max_ms": max(ms),
+                      "ms_per_step": sum(ms) / (ITER - 1)}
+        tot[name] = (sum(ms), sum(e[2] for e in evs), sum(e[3] for e in evs), len(evs))
     name = max(tot, key=lambda k: tot[k][0])
-    ms_sum, flop_sum = tot[name]
-    ach = flop_sum / (ms_sum * 1e-3) / 1e12
+    ms_sum, flop_sum, byte_sum, nl = tot[name]
+    kname = name.replace("mpg_", "") + "_kernel"
     traffic = None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.isfile(tpath):  # PMC measurement of this kernel (tools/pmc.sh, FETCH_SIZE x2 + WRITE_SIZE), bytes per launch
-        traffic = json.load(open(tpath)).get(name.replace("mpg_", "") + "_kernel", {}).get("bytes_per_launch")
-    roof = {"bound": "mfma", "kernel": name.replace("mpg_", "") + "_kernel", "achieved": ach, "peak": PEAK_MFMA_16BIT / 1e12,
-            "unit": "TFLOP/s", "frac": ach * 1e12 / PEAK_MFMA_16BIT, "traffic": traffic,
-            "note": "algorithmic FLOPs of the two fused dense layers (one MAC = 2 FLOP) over the HIP-event time of all "
-                    "launches of the kernel in a step; the kernel executes 3 MFMA MACs per algorithmic MAC (hi/lo split), "
-                    "so 1/3 is the ceiling of frac, and tools/ubench/mfma_power.hip measures 1.45 PFLOP/s (not 2.5) as "
-                    "the dense f16 MFMA rate this chip sustains on random operands (power-limited clock)"}
+        traffic = json.load(open(tpath)).get(kname, {}).get("bytes_per_launch")
+    # MPGAN's fused edge kernels are MFMA-bound by >100x (SURVEY 8d); GAPT's launches are HBM / latency bound
+    mfma = name.startswith("mpg_edge") or (flop_sum / max(byte_sum, 1) > PEAK_MFMA_16BIT / PEAK_HBM)
+    if mfma:
+        ach = flop_sum / (ms_sum * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": PEAK_MFMA_16BIT / 1e12, "unit": "TFLOP/s",
+                "frac": ach * 1e12 / PEAK_MFMA_16BIT, "traffic": traffic,
+                "flop_per_launch": flop_sum / nl, "avg_launch_ms": ms_sum / nl,
+                "note": "algorithmic FLOPs of the two fused dense layers (one MAC = 2 FLOP, all B*N*N edges) over the "
+                        "HIP-event time of all launches of the kernel in a step; the kernel issues 3 MFMA MACs per "
+                        "algorithmic MAC (hi/lo split), so 1/3 is the ceiling of frac, and tools/ubench/mfma_power.hip "
+                        "measures 1.45 PFLOP/s (not 2.5) as the dense f16 MFMA rate this chip sustains on random operands"}
+    else:
+        ach = byte_sum / (ms_sum * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                "frac": ach * 1e9 / PEAK_HBM, "traffic": traffic,
+                "bytes_per_launch": byte_sum / nl, "avg_launch_ms": ms_sum / nl,
+                "launches_per_step_all_kernels": sum(v["launches_per_step"] for v in kern.values()),
+                "note": "algorithmic bytes (operands read once + results written once, fp32) over the HIP-event time of "
+                        "all launches of the kernel in a step; at this size every launch is latency-bound (a few us of "
+                        "work), so the launch count per step is the figure to lower"}
     return roof, kern
 
 
-def cpu_baseline(torch, N):
-    """The oracle's restatement of the same iteration on this box's host cores, bounded sample:
-    BASELINE config 1 (B = 32), 1 warm-up + 3 timed iterations, D dropout 0.5 (Bernoulli masks)."""
-    import oracle
+# --------------------------------------------------------------------------- CPU leg
+def cpu_baseline(torch, model, N, B_gpu):
+    """The oracle's restatement of the same iteration on this box's host cores, bounded samples: BASELINE config 1
+    (B = 32; >= 10 timed iterations after a warm-up) and the GPU leg's own batch size (as many as fit ~15 s), fp32,
+    D dropout 0.5 (Bernoulli masks)."""
     from oracle import train_ref as T
     from oracle.mpgan_ref import RandKeeps
     cores = host_threads()
     torch.set_num_threads(cores)
     log(f"cpu baseline on {cores} threads")
-    B = 32
-    sdG = T.init_state_dict(T.mpgan_param_shapes(True), 1)
-    sdD = T.init_state_dict(T.mpgan_param_shapes(False), 2)
-    stD, stG = {}, {}
-    data, labels = T.synthetic_batch(B, N, seed=4)
-    keeps = (RandKeeps(), RandKeeps(), RandKeeps())
-    times = []
-    for it in range(4):
-        nD, nG = torch.randn(B, N, 32) * 0.2, torch.randn(B, N, 32) * 0.2
-        t0 = time.perf_counter()
-        T.train_iteration("mpgan", sdD, sdG, stD, stG, data, labels, nD, nG, 3e-5, 1e-5, p_disc=0.5, keeps=keeps)
-        times.append(time.perf_counter() - t0)
-        log(f"cpu iteration {it}: {times[-1]:.2f} s")
-    dt = sum(times[1:]) / len(times[1:])
-    return {"value": B / dt, "unit": "jets/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"3 timed G+D iterations (after 1 warm-up) at B={B}, N={N} (BASELINE config 1), fp32, "
-                      f"torch {torch.__version__} CPU ops, D dropout 0.5", "ms_per_step": 1e3 * dt}
+    if model == "mpgan":
+        shapes, lat, lrs = (T.mpgan_param_shapes(True), T.mpgan_param_shapes(False)), 32, (3e-5, 1e-5)
+    else:
+        shapes, lat, lrs = (T.gapt_param_shapes(True), T.gapt_param_shapes(False)), 64, (1.5e-4, 0.5e-4)
+
+    def sample(B, min_iters, budget_s):
+        sdG, sdD = T.init_state_dict(shapes[0], 1), T.init_state_dict(shapes[1], 2)
+        stD, stG = {}, {}
+        data, labels = T.synthetic_batch(B, N, seed=4)
+        keeps = (RandKeeps(), RandKeeps(), RandKeeps())
+        times = []
+        t_start = time.perf_counter()
+        while len(times) < 1 + min_iters or (time.perf_counter() - t_start < budget_s and len(times) < 1 + 30):
+            nD, nG = torch.randn(B, N, lat) * 0.2, torch.randn(B, N, lat) * 0.2
+            t0 = time.perf_counter()
+            T.train_iteration(model, sdD, sdG, stD, stG, data, labels, nD, nG, *lrs, p_disc=0.5, keeps=keeps)
+            times.append(time.perf_counter() - t0)
+            if len(times) > 1 and time.perf_counter() - t_start > 4 * budget_s:
+                break
+        timed = times[1:]
+        dt = sum(timed) / len(timed)
+        log(f"cpu B={B}: {len(timed)} timed iterations, {dt:.3f} s each")
+        return {"value": B / dt, "ms_per_step": 1e3 * dt, "iterations": len(timed), "batch": B}
+
+    small = sample(32, 10, 8.0)
+    res = {"value": small["value"], "unit": "jets/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{small['iterations']} timed G+D iterations (after 1 warm-up) at B=32, N={N} (BASELINE config 1 "
+                     f"batch), {model}, fp32, torch {torch.__version__} CPU ops, D dropout 0.5; the port skips the "
+                     "reference's results-neutral wasted work (G backward in train_D, D weight gradients in train_G)",
+           "ms_per_step": small["ms_per_step"], "iterations": small["iterations"]}
+    if B_gpu != 32:
+        big = sample(B_gpu, 3, 15.0)
+        res["at_gpu_batch"] = {"value": big["value"], "unit": "jets/s", "batch": B_gpu, "ms_per_step": big["ms_per_step"],
+                               "iterations": big["iterations"]}
+    return res
 
 
 if __name__ == "__main__":

@@ -213,11 +213,19 @@ typedef struct MpgAttn {
 int mpg_attn_fwd(const MpgAttn* p, void* stream);
 int mpg_attn_bwd(const MpgAttn* p, void* stream);
 
-/* ---- optimiser --------------------------------------------------------------------------------
- * mpg_rmsprop: torch.optim.RMSprop.step() with the reference's settings (setup_training.py:1511-1513)
- * over one flat buffer of n parameters: v = alpha v + (1-alpha)(gscale g)^2; p -= lr gscale g/(sqrt(v)+eps). */
+/* ---- optimisers --------------------------------------------------------------------------------
+ * One launch over one flat buffer of n parameters; `gscale` multiplies the gradient first (1/world after a
+ * summing all-reduce).  They replace torch.optim.*.step() as the reference builds them (setup_training.py:1511-1523):
+ * mpg_rmsprop  (--optimizer rmsprop, the default): v = alpha v + (1-alpha) g^2; p -= lr g / (sqrt(v) + eps)
+ * mpg_adam     (--optimizer adam; weight_decay 5e-4 there): torch.optim.Adam with L2 weight decay; `step` is a
+ *              device float holding the number of steps taken so far (advanced by the call)
+ * mpg_adadelta (--optimizer adadelta): torch.optim.Adadelta (rho 0.9, eps 1e-6 by default). */
 int mpg_rmsprop(float* p, const float* g, float* v, uint64_t n, float lr, float alpha, float eps, float gscale,
                 void* stream);
+int mpg_adam(float* p, const float* g, float* m, float* v, float* step, uint64_t n, float lr, float beta1,
+             float beta2, float eps, float weight_decay, float gscale, void* stream);
+int mpg_adadelta(float* p, const float* g, float* v, float* u, uint64_t n, float lr, float rho, float eps,
+                 float gscale, void* stream);
 
 #ifdef __cplusplus
 }

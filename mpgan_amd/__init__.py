@@ -7,6 +7,7 @@ under those names so ``setup_training.py`` / ``train.py`` / ``gen.py`` pick them
 import sys as _sys
 
 from . import _lib, ops  # noqa: F401
+from . import data, checkpoint, gen  # noqa: F401
 from . import mpgan  # noqa: F401
 from . import gapt  # noqa: F401
 from .mpgan import LinearNet, MPLayer, MPNet, MPGenerator, MPDiscriminator  # noqa: F401

@@ -146,6 +146,9 @@ SIGNATURES = {
     "mpg_attn_fwd": (C.c_int, [C.POINTER(MpgAttn), C.c_void_p]),
     "mpg_attn_bwd": (C.c_int, [C.POINTER(MpgAttn), C.c_void_p]),
     "mpg_rmsprop": (C.c_int, [_fp, _fp, _fp, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "mpg_adam": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                           C.c_float, C.c_void_p]),
+    "mpg_adadelta": (C.c_int, [_fp, _fp, _fp, _fp, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
 }
 
 
@@ -166,28 +169,60 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _compiler_env():
+    """Environment for the hipcc children: without a profiler's preload.  ``rocprofv3`` injects a library that
+    initialises the GPU in every process it is loaded into; hipcc then execs clang -- a GPU-initialised exec, which
+    this pool forbids (it takes the machine down)."""
+    env = dict(os.environ)
+    for k in list(env):
+        if k == "LD_PRELOAD" or k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTRACER")):
+            env.pop(k)
+    return env
+
+
+def _under_profiler() -> bool:
+    return bool(os.environ.get("LD_PRELOAD")) or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into mpgan_amd/lib/libmpgan_amd.so (in-tree)."""
+    """Compile every HIP source for gfx950 into mpgan_amd/lib/libmpgan_amd.so (in-tree).
+
+    Safe against concurrent callers (ranks of one torchrun job, parallel test workers): an exclusive file lock is
+    held for the whole build, objects and the library are written under temporary names and moved into place."""
     if not force and not _stale():
         return LIBPATH
+    import fcntl
+    import tempfile
     os.makedirs(LIBDIR, exist_ok=True)
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    jobs = []
-    for src in sources():
-        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
-        jobs.append((obj, [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + EXTRA_FLAGS + ["-I", INCLUDE, "-c", src, "-o", obj]))
-    # the translation units are independent (one takes over a minute): compile them side by side
-    from concurrent.futures import ThreadPoolExecutor
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():  # another process built it while this one waited
+            return LIBPATH
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        env = _compiler_env()
+        tmpdir = tempfile.mkdtemp(prefix=".build.", dir=LIBDIR)
+        try:
+            jobs = []
+            for src in sources():
+                obj = os.path.join(tmpdir, os.path.basename(src)[:-4] + ".o")
+                jobs.append((obj, [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + EXTRA_FLAGS
+                             + ["-I", INCLUDE, "-c", src, "-o", obj]))
+            # the translation units are independent (one takes over a minute): compile them side by side
+            from concurrent.futures import ThreadPoolExecutor
 
-    def run(job):
-        if verbose:
-            print(" ".join(job[1]))
-        subprocess.run(job[1], check=True)
-        return job[0]
-    with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
-        objs = list(ex.map(run, jobs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIBPATH] + objs
-    subprocess.run(cmd, check=True)
+            def run(job):
+                if verbose:
+                    print(" ".join(job[1]))
+                subprocess.run(job[1], check=True, env=env)
+                return job[0]
+            with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+                objs = list(ex.map(run, jobs))
+            tmplib = os.path.join(tmpdir, "libmpgan_amd.so")
+            subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmplib] + objs, check=True, env=env)
+            os.replace(tmplib, LIBPATH)
+        finally:
+            import shutil
+            shutil.rmtree(tmpdir, ignore_errors=True)
     return LIBPATH
 
 
@@ -195,14 +230,23 @@ _lib = None
 
 
 def lib():
-    """The loaded library (built on first use if the toolchain is present).  Raises if absent."""
+    """The loaded library.  Raises if it is absent.  A stale or missing library is rebuilt on first use ONLY in a
+    plain single process: under a multi-rank launch (WORLD_SIZE > 1) or a profiler preload nothing is compiled
+    here -- run ``python __graft_entry__.py`` (build only) first."""
     global _lib
     if _lib is None:
         if _stale():
-            if os.path.isfile(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) and os.path.isdir(CSRC):
+            can_build = os.path.isfile(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) and os.path.isdir(CSRC)
+            guarded = int(os.environ.get("WORLD_SIZE", "1")) > 1 or _under_profiler()
+            if can_build and not guarded:
                 build()
             elif not os.path.isfile(LIBPATH):
-                raise RuntimeError("libmpgan_amd.so is missing and hipcc is not available: run __graft_entry__.build()")
+                raise RuntimeError("libmpgan_amd.so is missing%s: run `python __graft_entry__.py` (build) first"
+                                   % (" and this process must not compile (multi-rank launch or profiler preload)"
+                                      if can_build else " and hipcc is not available"))
+            elif can_build:
+                raise RuntimeError("libmpgan_amd.so is older than its sources and this process must not compile "
+                                   "(multi-rank launch or profiler preload): run `python __graft_entry__.py` first")
         _lib = C.CDLL(LIBPATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(_lib, name)

@@ -336,7 +336,7 @@ extern "C" int mpg_attn_fwd(const MpgAttn* p, void* stream) {
     }
     const size_t lds = (size_t)2 * p->S * p->d * 4;
     if (lds > 160 * 1024) return -2;
-    if (lds > 64 * 1024) HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MPG_ENSURE_LDS(attn_fwd_kernel, lds);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(p->B * p->H), dim3(64), lds, (hipStream_t)stream, *p);
     return (int)hipGetLastError();
 }
@@ -356,11 +356,7 @@ extern "C" int mpg_attn_bwd(const MpgAttn* p, void* stream) {
         hipStream_t st = (hipStream_t)stream;
 #define MPG_ATTN_BWD(DV, TW)                                                                                              \
     do {                                                                                                                  \
-        static size_t attr = 0;                                                                                           \
-        if (lds > 64 * 1024 && lds > attr) {                                                                              \
-            HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_fast<DV, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            attr = lds;                                                                                                   \
-        }                                                                                                                 \
+        MPG_ENSURE_LDS((attn_bwd_fast<DV, TW>), lds);                                                                     \
         hipLaunchKernelGGL((attn_bwd_fast<DV, TW>), grid, block, lds, st, *p);                                            \
     } while (0)
 #define MPG_ATTN_BWD2(DV) do { if (two) MPG_ATTN_BWD(DV, true); else MPG_ATTN_BWD(DV, false); } while (0)
@@ -373,11 +369,7 @@ extern "C" int mpg_attn_bwd(const MpgAttn* p, void* stream) {
     }
     const size_t lds = ((size_t)2 * p->S * p->d + 2 * p->L * p->d + (size_t)p->L * p->S) * 4;
     if (lds > 160 * 1024) return -2;
-    static size_t attr = 0;
-    if (lds > 64 * 1024 && lds > attr) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = lds;
-    }
+    MPG_ENSURE_LDS(attn_bwd_kernel, lds);
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(p->B * p->H), dim3(64), lds, (hipStream_t)stream, *p);
     return (int)hipGetLastError();
 }

@@ -289,12 +289,11 @@ extern "C" int mpg_chain(const MpgChain* p, void* stream) {
     if (p->a_slabs < 1 || p->K1 > p->L[0].K || (p->K1 < p->L[0].K && p->A2 == nullptr)) return -2;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((p->M + 31) / 32), block(512);
-    static bool done[2] = {false, false};
     if (p->f16) {
-        if (!done[1]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES)); done[1] = true; }
+        MPG_ENSURE_LDS((chain_kernel<true>), CH_LDS_BYTES);
         hipLaunchKernelGGL((chain_kernel<true>), grid, block, CH_LDS_BYTES, st, *p);
     } else {
-        if (!done[0]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES)); done[0] = true; }
+        MPG_ENSURE_LDS((chain_kernel<false>), CH_LDS_BYTES);
         hipLaunchKernelGGL((chain_kernel<false>), grid, block, CH_LDS_BYTES, st, *p);
     }
     return (int)hipGetLastError();

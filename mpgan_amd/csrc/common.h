@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -225,6 +226,24 @@ MPG_DEV float halve_add(bool bit, float a, float b) {
 
 // dropout sites (tag values); the layer id of the call is mixed in by the host as tag_base
 enum { TAG_E0 = 1, TAG_E1 = 2, TAG_E2 = 3, TAG_N0 = 4, TAG_N1 = 5, TAG_N2 = 6, TAG_GENERIC = 7 };
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: remember per (call site =
+// kernel instantiation, device) the size already granted.  A process-wide flag would leave every device but the
+// first at the 64 KiB default (the reference's nn.DataParallel drives several devices from one process), and the
+// launchers may be entered from several autograd worker threads at once -- hence the atomics.
+#define MPG_MAX_DEVICES 64
+#define MPG_ENSURE_LDS(kernel, bytes)                                                                              \
+    do {                                                                                                           \
+        static std::atomic<int> _granted[MPG_MAX_DEVICES];                                                         \
+        int _dev = 0;                                                                                              \
+        HIP_CHECK_RET(hipGetDevice(&_dev));                                                                        \
+        _dev &= MPG_MAX_DEVICES - 1;                                                                               \
+        if ((int)(bytes) > 64 * 1024 && _granted[_dev].load(std::memory_order_relaxed) < (int)(bytes)) {           \
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                              (int)(bytes)));                                                      \
+            _granted[_dev].store((int)(bytes), std::memory_order_relaxed);                                         \
+        }                                                                                                          \
+    } while (0)
 
 #define HIP_CHECK_RET(expr)                                        \
     do {                                                           \

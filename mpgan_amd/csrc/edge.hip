@@ -322,12 +322,7 @@ extern "C" int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream) {
     const int dm = p->thr == 0 ? 0 : (p->thr == 128 ? 2 : 1);
 #define MPG_FWD_ONE(D, H, S)                                                                                      \
     do {                                                                                                          \
-        static bool done = false;                                                                                 \
-        if (!done) {                                                                                              \
-            HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_kernel<D, H, S>,                              \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS_BYTES));        \
-            done = true;                                                                                          \
-        }                                                                                                         \
+        MPG_ENSURE_LDS((edge_fwd_kernel<D, H, S>), FWD_LDS_BYTES);                                                \
         hipLaunchKernelGGL((edge_fwd_kernel<D, H, S>), grid, block, FWD_LDS_BYTES, st, *p);                       \
     } while (0)
 #define MPG_FWD_S(D, H)                                                                                           \

@@ -794,12 +794,7 @@ extern "C" int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream) {
     const int dm = p->thr == 0 ? 0 : (p->thr == 128 ? 2 : 1);
 #define MPG_BWD_ONE(D, H, W)                                                                                      \
     do {                                                                                                          \
-        static bool done = false;                                                                                 \
-        if (!done) {                                                                                              \
-            HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd_kernel<D, H, W>,                              \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS_BYTES));        \
-            done = true;                                                                                          \
-        }                                                                                                         \
+        MPG_ENSURE_LDS((edge_bwd_kernel<D, H, W>), BWD_LDS_BYTES);                                                \
         hipLaunchKernelGGL((edge_bwd_kernel<D, H, W>), grid, block, BWD_LDS_BYTES, st, *p);                       \
     } while (0)
 #define MPG_BWD_W(D, H)                                                                                           \
@@ -830,12 +825,7 @@ extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
     const int dm = p->thr == 0 ? 0 : (p->thr == 128 ? 2 : 1);
 #define MPG_DW_ONE(D, H)                                                                                          \
     do {                                                                                                          \
-        static bool done = false;                                                                                 \
-        if (!done) {                                                                                              \
-            HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_dw_kernel<D, H>,                                  \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES));         \
-            done = true;                                                                                          \
-        }                                                                                                         \
+        MPG_ENSURE_LDS((edge_dw_kernel<D, H>), DW_LDS_BYTES);                                                     \
         hipLaunchKernelGGL((edge_dw_kernel<D, H>), grid, block, DW_LDS_BYTES, st, *p);                            \
     } while (0)
 #define MPG_DW_H(D) do { if (p->f16) MPG_DW_ONE(D, true); else MPG_DW_ONE(D, false); } while (0)

@@ -36,7 +36,7 @@ def broadcast_module(module: torch.nn.Module, src: int = 0, group=None):
 def allreduce_sum_(flat_grad: torch.Tensor, group=None, world: int = 1) -> float:
     """In-place SUM all-reduce of a flat gradient buffer; returns the scale (1/world) the optimiser
     must apply to turn the sum into the global-batch mean gradient."""
-    if world > 1:
+    if world > 1 or group is not None:  # a group of one still goes through the collective (and its stream ordering)
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / world
 

@@ -146,6 +146,7 @@ class GAPT_G(nn.Module):
                  num_isab_nodes: int = 10, linear_args: dict = {}):
         super().__init__()
         self.num_particles, self.output_feat_size, self.use_mask = num_particles, output_feat_size, use_mask
+        self.embed_dim = embed_dim
         args = _sab_args(embed_dim, sab_fc_layers, num_heads, layer_norm, dropout_p, linear_args)
         self.sabs = nn.ModuleList(ISAB(num_isab_nodes, **args) if use_isab else SAB(**args)
                                   for _ in range(sab_layers))
@@ -168,6 +169,7 @@ class GAPT_D(nn.Module):
                  num_isab_nodes: int = 10, linear_args: dict = {}):
         super().__init__()
         self.num_particles, self.input_feat_size, self.use_mask = num_particles, input_feat_size, use_mask
+        self.embed_dim = embed_dim
         args = _sab_args(embed_dim, sab_fc_layers, num_heads, layer_norm, dropout_p, linear_args)
         self.sabs = nn.ModuleList()  # registered first, as in the reference, so state-dict order matches
         self.input_embedding = LinearNet([], input_size=input_feat_size, output_size=embed_dim, **linear_args)

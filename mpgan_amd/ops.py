@@ -8,9 +8,11 @@ from __future__ import annotations
 
 import ctypes as C
 import itertools
+import threading
 from typing import Optional
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 from ._lib import MpgGemm, MpgEdgeFwd, MpgEdgeBwd, MpgEdgeDw, MpgPackJob, MpgChain, MpgReduceJob, check
@@ -19,28 +21,78 @@ H1, H2, H3 = 96, 160, 192
 TAG_E0, TAG_E1, TAG_E2, TAG_N0, TAG_N1, TAG_N2, TAG_GENERIC = 1, 2, 3, 4, 5, 6, 7
 
 # ------------------------------------------------------------------------------------- state
-_seed = {}
-_tag_counter = itertools.count(1)
+# Read-only configuration of the arithmetic (set before building models; not step state).
 OPTIONS = {
     "skip_masked": True,      # edge forward: skip zero-masked senders (they contribute exactly 0)
     # forward products (they decide LeakyReLU signs) split as fp16 hi/lo (~2^-21 per product);
     # False = bf16 hi/lo (~2^-17, unlimited range).  Gradient products are always bf16 hi/lo.
     "fwd_f16": True,
-    # FusedMPLayerFn.backward adds the parameter gradients straight into ``param.grad`` (when that exists) and
-    # returns None for them, instead of handing twelve tensors to autograd's AccumulateGrad (one small add kernel
-    # per parameter and backward).  ``train.TrainStep`` switches it on; leave it off when ``torch.autograd.grad``,
-    # gradient hooks or anything else needs the gradients as autograd values.
-    "grad_into_param": False,
 }
 
 
+class DeviceState:
+    """Everything mutable the fused ops keep between calls, ONE INSTANCE PER DEVICE (SURVEY.md section 8b:
+    the reference's ``nn.DataParallel`` drives each device from its own thread, and autograd runs a device's
+    backward nodes on that device's worker thread -- so the key is the device, not the calling thread).
+
+    seed            64-bit dropout seed in device memory (a captured hipGraph sees a new value on every replay)
+    tags / last_tag dropout-site tag counter of fused-op invocations on this device
+    grad_into_param ``FusedMPLayerFn.backward`` adds parameter gradients straight into ``param.grad`` and returns
+                    None for them (``train.TrainStep`` switches it on around its backward; leave it off when
+                    ``torch.autograd.grad``, hooks or anything else needs the gradients as autograd values)
+    deferred_wgrad  a ``WgradBatch`` that collects the stand-alone Linear layers' weight gradients of the
+                    backward in flight (``TrainStep`` flushes it as grouped launches), or None
+    """
+
+    def __init__(self, index: int):
+        self.index = index
+        self._seed = None
+        self.tags = itertools.count(1)
+        self.last_tag = 0
+        self.grad_into_param = False
+        self.deferred_wgrad = None
+
+
+    @property
+    def seed(self) -> torch.Tensor:
+        if self._seed is None:  # created on first use: the host-side state exists without touching the device
+            dev = torch.device("cuda", self.index) if self.index >= 0 else torch.device("cpu")
+            self._seed = torch.full((1,), 0x243F6A8885A308D3, dtype=torch.int64, device=dev)
+        return self._seed
+
+
+_states = {}
+_states_lock = threading.Lock()
+
+
+def _dev_index(device) -> int:
+    """Device ordinal of ``device`` (a torch.device, a string or an int); a bare "cuda" means the CURRENT device,
+    not device 0.  CPU (host-logic tests of ``train.TrainStep`` with toy modules) maps to -1."""
+    if isinstance(device, int):
+        return device
+    d = torch.device(device)
+    if d.type == "cpu":
+        return -1
+    if d.index is not None:
+        return d.index
+    return torch.cuda.current_device() if torch.cuda.is_available() else 0
+
+
+def dev_state(device) -> DeviceState:
+    idx = _dev_index(device)
+    st = _states.get(idx)
+    if st is None:
+        with _states_lock:
+            st = _states.get(idx)
+            if st is None:
+                st = _states[idx] = DeviceState(idx)
+    return st
+
+
 def seed_tensor(device) -> torch.Tensor:
-    """Per-device 64-bit dropout seed living in device memory (so that a captured hipGraph sees
-    a new value on every replay).  ``bump_seed`` advances it; call once per training iteration."""
-    key = torch.device(device).index or 0
-    if key not in _seed:
-        _seed[key] = torch.full((1,), 0x243F6A8885A308D3, dtype=torch.int64, device=device)
-    return _seed[key]
+    """Per-device 64-bit dropout seed living in device memory.  ``bump_seed`` advances it; call once per
+    training iteration."""
+    return dev_state(device).seed
 
 
 def set_seed(value: int, device="cuda"):
@@ -51,14 +103,16 @@ def bump_seed(device="cuda"):
     seed_tensor(device).add_(0x1E3779B97F4A7C15)
 
 
-LAST_TAG = 0
+def next_tag(device="cuda") -> int:
+    """A fresh dropout-site tag base (8 sites per call) for one fused-op invocation on ``device``."""
+    st = dev_state(device)
+    st.last_tag = (next(st.tags) % (1 << 24)) * 8
+    return st.last_tag
 
 
-def next_tag() -> int:
-    """A fresh dropout-site tag base (8 sites per call) for one fused-op invocation."""
-    global LAST_TAG
-    LAST_TAG = (next(_tag_counter) % (1 << 24)) * 8
-    return LAST_TAG
+def last_tag(device="cuda") -> int:
+    """Tag base of the most recent fused-op invocation on ``device`` (tests: dump that call's dropout masks)."""
+    return dev_state(device).last_tag
 
 
 def drop_params(p: float):
@@ -158,9 +212,9 @@ def linear_bwd_weight(dy, x, *, out=None, out_col0=0, out_scale=1.0, bias_out=No
     return out
 
 
-# Set by train.TrainStep around a backward: FusedLinearFn queues its weight gradients here instead of launching
-# one small split-K GEMM + reduction per layer; TrainStep flushes the queue (grouped launches) before the optimizer.
-DEFERRED_WGRAD = None
+# (train.TrainStep sets DeviceState.deferred_wgrad around a backward: FusedLinearFn then queues its weight gradients
+# there instead of launching one small split-K GEMM + reduction per layer; TrainStep flushes the queue -- grouped
+# launches -- before the optimizer.)
 # workgroups a single weight-gradient GEMM of a group aims for when choosing its split-K factor
 WGRAD_TARGET_WGS = int(__import__("os").environ.get("MPG_WGRAD_TARGET", "512"))
 
@@ -341,7 +395,7 @@ class FusedMPLayerFn(torch.autograd.Function):
         dev = x.device
         thr, dscale = drop_params(p_drop) if training else (0, 1.0)
         seed_t = seed_tensor(dev)
-        tag = next_tag()
+        tag = next_tag(dev)
         x2 = x.reshape(V, F)          # a view when x is a feature slice of a contiguous tensor (D's x[..., :-1]) ...
         if x2.stride(1) != 1:
             x2 = x2.contiguous()      # ... every consumer below takes the row stride, only unit column stride matters
@@ -393,6 +447,7 @@ class FusedMPLayerFn(torch.autograd.Function):
         return y.reshape(B, N, V3.shape[0])
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3 = ctx.saved_tensors
         pk = ctx.packed
@@ -421,8 +476,8 @@ class FusedMPLayerFn(torch.autograd.Function):
               alpha=alpha, seed_t=seed_t, f16=False)
         dV1 = dV2 = dV3 = dc1 = dc2 = dc3 = None
         wb = WgradBatch()  # all six weight gradients of the layer go out as one grouped launch (below)
-        # OPTIONS["grad_into_param"]: add into the parameters' .grad buffers directly and return None for them
-        direct = (need_w and OPTIONS["grad_into_param"] and pk.plist is not None
+        # DeviceState.grad_into_param: add into the parameters' .grad buffers directly and return None for them
+        direct = (need_w and dev_state(dev).grad_into_param and pk.plist is not None
                   and all(q.grad is not None and q.grad.is_contiguous() for q in pk.plist))
         if need_w:
             if direct:
@@ -530,7 +585,7 @@ class FusedLinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, shp[-1]).contiguous()
         thr, dscale = drop_params(p_drop) if training else (0, 1.0)
         seed_t = seed_tensor(x.device)
-        tag = next_tag()
+        tag = next_tag(x.device)
         if resid is not None and act:  # (the backward reads the activation's sign off the saved output)
             raise NotImplementedError("FusedLinearFn: a fused residual needs a layer without activation")
         r2 = None if resid is None else resid.reshape(-1, W.shape[0]).contiguous()
@@ -543,6 +598,7 @@ class FusedLinearFn(torch.autograd.Function):
         return y.reshape(*shp[:-1], W.shape[0])
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         x2, W, y = ctx.saved_tensors
         shp, act, alpha, thr, dscale, tag, has_b = ctx.cfg
@@ -553,11 +609,12 @@ class FusedLinearFn(torch.autograd.Function):
         dW = db = None
         want_b = has_b and ctx.needs_input_grad[2]
         gW = gb = None
-        if ctx.needs_input_grad[1] and OPTIONS["grad_into_param"] and DEFERRED_WGRAD is not None:
+        st = dev_state(g2.device)
+        if ctx.needs_input_grad[1] and st.grad_into_param and st.deferred_wgrad is not None:
             gW, gb = _grad_target(ctx.wparam), _grad_target(ctx.bias) if want_b else None
         if gW is not None and (not want_b or gb is not None):
             # TrainStep: queue dW (+ db) for the grouped launch at the end of the backward; it adds into .grad
-            DEFERRED_WGRAD.add(g2, x2, out=gW, bias_out=gb, accumulate=True)
+            st.deferred_wgrad.add(g2, x2, out=gW, bias_out=gb, accumulate=True)
         elif ctx.needs_input_grad[1]:
             if want_b:
                 db = torch.empty(W.shape[0], device=g2.device, dtype=torch.float32)
@@ -579,12 +636,13 @@ class FusedDropoutFn(torch.autograd.Function):
             return x
         _chk(x, "x")
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
-        tag = next_tag() + TAG_GENERIC
+        tag = next_tag(x.device) + TAG_GENERIC
         ctx.cfg = (tag, thr, scale, x.shape)
         return gate(x2, None, gate_act=False, alpha=0.0, seed_t=seed_tensor(x.device), tag=tag, thr=thr,
                     scale=scale).reshape(x.shape)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         if ctx.cfg is None:
             return g, None, None
@@ -627,6 +685,7 @@ class FusedPackedAttnFn(torch.autograd.Function):
         return o
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, go):
         qx, kv, P = ctx.saved_tensors
         B, L, S, H, d, E, self_attn = ctx.dims
@@ -664,6 +723,7 @@ class FusedAttnFn(torch.autograd.Function):
         return o
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, go):
         q, k, v, P = ctx.saved_tensors
         B, L, S, H, d = ctx.dims

@@ -1,9 +1,12 @@
 """One G+D training iteration on the fused path, host side.
 
-Mirrors the reference's ``train_D`` / ``train_G`` (train.py:398-523) for the default recipe:
-LSGAN loss (``--loss ls``, train.py:368-370, :471-472), RMSprop (setup_training.py:1511-1513),
+Mirrors the reference's ``train_D`` / ``train_G`` (train.py:398-523): losses ``ls`` (default, train.py:368-370,
+:471-472), ``og``, ``w``, ``hinge`` (``calc_D_loss`` :331-395, ``calc_G_loss`` :465-476), optimizers RMSprop
+(default), Adam, Adadelta as ``setup_training.optimizers`` builds them (setup_training.py:1511-1523),
 ``num_critic = num_gen = 1``, generator noise ~ N(0, sd=0.2) sampled on the device every step
 (train.py:100-141), D in train mode (dropout on) in both sub-steps, G in eval mode in the D step.
+The gradient penalty (train.py:286-324) needs a second derivative through D; the fused ops are first-order only
+(``once_differentiable``), so ``gp_lambda != 0`` is refused at construction.
 
 Two pieces of work the reference does and throws away are not done (results-neutral, SURVEY.md
 section 3.1): the D step does not back-propagate into G (its gradients are zeroed before use,
@@ -30,9 +33,11 @@ LR = {  # setup_training.py:848-872 (lr_disc, lr_gen) per jet type for model = m
 }
 
 
-def default_mpgan(num_particles: int = 30, disc_dropout: float = 0.5, gen_dropout: float = 0.0, device="cuda"):
+def default_mpgan(num_particles: int = 30, disc_dropout: float = 0.5, gen_dropout: float = 0.0, device="cuda",
+                  loss: str = "ls"):
     """MPGenerator / MPDiscriminator exactly as ``setup_training.setup_mpgan`` builds them from the
-    reference's default arguments (setup_training.py:1195-1293, defaults :415-548)."""
+    reference's default arguments (setup_training.py:1195-1293, defaults :415-548); ``loss`` picks D's final
+    activation as :1250 does (none for ``w`` / ``hinge``, sigmoid otherwise)."""
     def lin(p):
         return {"leaky_relu_alpha": 0.2, "dropout_p": p, "batch_norm": False, "spectral_norm": False}
     mp_args = {"pos_diffs": False, "all_ef": False, "coords": "polarrel", "delta_coords": False, "delta_r": False,
@@ -47,7 +52,8 @@ def default_mpgan(num_particles: int = 30, disc_dropout: float = 0.5, gen_dropou
     G = MPGenerator(mp_iters=2, fe1_layers=None, final_activation="tanh", output_node_size=3, input_node_size=32,
                     lfc=False, lfc_latent_size=128, **common, mp_args=dict(mp_args),
                     mp_args_first_layer={"clabels": 0}, linear_args=lin(gen_dropout), mask_args=dict(mask_args))
-    D = MPDiscriminator(mp_iters=2, fe1_layers=None, final_activation="sigmoid", input_node_size=3, dea=True,
+    D = MPDiscriminator(mp_iters=2, fe1_layers=None, final_activation="" if loss in ("w", "hinge") else "sigmoid",
+                        input_node_size=3, dea=True,
                         dea_sum=True, fnd=[], mask_fnd_np=False, **common, mp_args=dict(mp_args),
                         mp_args_first_layer={"clabels": 0, "all_ef": False}, linear_args=lin(disc_dropout),
                         mask_args=dict(mask_args))
@@ -74,40 +80,176 @@ def default_gapt(num_particles: int = 30, disc_dropout: float = 0.5, gen_dropout
 LR_GAPT = (1.5e-4, 0.5e-4)  # setup_training.py:856-857, :869-870
 
 
+OPTIMIZERS = ("rmsprop", "adam", "adadelta")
+
+
 class FlatParams:
     """All parameters of a module re-pointed into one flat fp32 buffer, with a flat gradient buffer
-    whose views are pre-installed as ``p.grad`` (autograd accumulates into them in place) and a
-    flat RMSprop state.  state_dict() keys/shapes of the module are untouched."""
+    whose views are pre-installed as ``p.grad`` (autograd accumulates into them in place) and the flat
+    optimiser state.  state_dict() keys/shapes of the module are untouched.
 
-    def __init__(self, module: nn.Module):
+    ``optimizer``: "rmsprop" (torch.optim.RMSprop defaults), "adam" (weight_decay 5e-4, betas as given) or
+    "adadelta" -- the three choices of ``setup_training.optimizers`` (setup_training.py:1511-1523), each ONE fused
+    launch over the flat buffer.  ``state_dict()`` / ``load_state_dict()`` speak the matching ``torch.optim``
+    class's own format, so the reference's ``*_optim_<epoch>.pt`` files (train.py:534-535, reloaded at
+    setup_training.py:1525-1535) are read and written as they are."""
+
+    def __init__(self, module: nn.Module, optimizer: str = "rmsprop", betas=(0.9, 0.999), weight_decay: float = 5e-4):
+        if optimizer not in OPTIMIZERS:
+            raise ValueError(f"optimizer must be one of {OPTIMIZERS}, got {optimizer!r}")
         ps = [p for p in module.parameters()]
         self.module = module
+        self.optimizer, self.betas, self.weight_decay = optimizer, tuple(betas), float(weight_decay)
         n = sum(p.numel() for p in ps)
         dev = ps[0].device
         self.flat = torch.empty(n, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.sq = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.sq = torch.zeros(n, device=dev, dtype=torch.float32)       # square_avg / exp_avg_sq
+        self.aux = torch.zeros(n, device=dev, dtype=torch.float32) if optimizer != "rmsprop" else None  # exp_avg / acc_delta
+        # optimiser steps taken.  Adam needs the count in its arithmetic, so it lives in device memory (a replayed
+        # hipGraph must see it advance); the others only report it in state_dict(): host counter.
+        self.step_count = torch.zeros((), device=dev, dtype=torch.float32)
+        self._host_steps = 0
+        self._spans = []
         off = 0
         for p in ps:
             k = p.numel()
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view_as(p)
             p.grad = self.grad[off:off + k].view_as(p)
+            self._spans.append((off, k, tuple(p.shape)))
             off += k
         self.n = n
+        self.lr = None  # last learning rate used (for state_dict's param_groups)
 
     def zero_grad(self):
         self.grad.zero_()
 
+    # -- the fused step -----------------------------------------------------------------------------
+    def step(self, lr: float, gscale: float = 1.0):
+        """One optimiser step over the flat buffer; ``gscale`` multiplies the gradient first."""
+        self.lr = lr
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L = _lib.lib()
+        if self.optimizer == "rmsprop":
+            _lib.check(L.mpg_rmsprop(vp(self.flat), vp(self.grad), vp(self.sq), self.n, lr, 0.99, 1e-8, gscale, st),
+                       "mpg_rmsprop")
+        elif self.optimizer == "adam":
+            _lib.check(L.mpg_adam(vp(self.flat), vp(self.grad), vp(self.aux), vp(self.sq), vp(self.step_count), self.n,
+                                  lr, self.betas[0], self.betas[1], 1e-8, self.weight_decay, gscale, st), "mpg_adam")
+        else:
+            _lib.check(L.mpg_adadelta(vp(self.flat), vp(self.grad), vp(self.sq), vp(self.aux), self.n, lr, 0.9, 1e-6,
+                                      gscale, st), "mpg_adadelta")
+        if not (self.flat.is_cuda and torch.cuda.is_current_stream_capturing()):  # a capture records the launch, it does not run it
+            self._host_steps += 1
+
+    def note_step(self):
+        """Count one step that ran inside a replayed hipGraph (``TrainStep.step`` calls this)."""
+        self._host_steps += 1
+
+    @property
+    def steps(self) -> float:
+        return float(self.step_count) if self.optimizer == "adam" else float(self._host_steps)
+
     def rmsprop(self, lr: float, alpha: float = 0.99, eps: float = 1e-8, gscale: float = 1.0):
-        _lib.check(_lib.lib().mpg_rmsprop(C.c_void_p(self.flat.data_ptr()), C.c_void_p(self.grad.data_ptr()),
-                                          C.c_void_p(self.sq.data_ptr()), self.n, lr, alpha, eps, gscale,
-                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mpg_rmsprop")
+        assert self.optimizer == "rmsprop" and alpha == 0.99 and eps == 1e-8
+        self.step(lr, gscale)
+
+    # -- torch.optim-compatible state ---------------------------------------------------------------
+    _STATE_KEYS = {"rmsprop": ("square_avg", None), "adam": ("exp_avg_sq", "exp_avg"), "adadelta": ("square_avg", "acc_delta")}
+
+    def _torch_optimizer(self, lr):
+        """A torch.optim instance over detached CPU stand-ins of the parameters: the source of truth for the
+        ``param_groups`` defaults of this torch version."""
+        stand_ins = [torch.zeros(shape) for _, _, shape in self._spans]
+        if self.optimizer == "rmsprop":
+            return torch.optim.RMSprop(stand_ins, lr=lr)
+        if self.optimizer == "adam":
+            return torch.optim.Adam(stand_ins, lr=lr, weight_decay=self.weight_decay, betas=self.betas)
+        return torch.optim.Adadelta(stand_ins, lr=lr)
+
+    def state_dict(self, lr: float = None) -> dict:
+        """What ``torch.optim.<Optimizer>(module.parameters(), ...).state_dict()`` would hold after the same steps."""
+        lr = self.lr if lr is None else lr
+        sd = self._torch_optimizer(1e-2 if lr is None else lr).state_dict()
+        k_sq, k_aux = self._STATE_KEYS[self.optimizer]
+        steps = torch.tensor(self.steps, dtype=torch.float32)
+        if float(steps) > 0:
+            for i, (off, k, shape) in enumerate(self._spans):
+                ent = {"step": steps.clone(), k_sq: self.sq[off:off + k].view(shape).clone()}
+                if k_aux is not None:
+                    ent[k_aux] = self.aux[off:off + k].view(shape).clone()
+                sd["state"][i] = ent
+        return sd
+
+    def load_state_dict(self, sd: dict):
+        """Take over the per-parameter state of a ``torch.optim`` state dict of the matching optimizer class
+        (parameters in ``module.parameters()`` order).  Returns the learning rate recorded in it."""
+        k_sq, k_aux = self._STATE_KEYS[self.optimizer]
+        state = sd["state"]
+        if state and len(state) != len(self._spans):
+            raise ValueError(f"optimizer state holds {len(state)} parameters, the module has {len(self._spans)}")
+        self.sq.zero_()
+        if self.aux is not None:
+            self.aux.zero_()
+        steps = 0.0
+        for i, (off, k, shape) in enumerate(self._spans):
+            ent = state.get(i, state.get(str(i)))
+            if ent is None:
+                continue
+            if k_sq not in ent:
+                raise ValueError(f"state of parameter {i} has no {k_sq!r}: not a torch.optim {self.optimizer} state dict")
+            if tuple(ent[k_sq].shape) != shape:
+                raise ValueError(f"state of parameter {i} has shape {tuple(ent[k_sq].shape)}, expected {shape}")
+            self.sq[off:off + k].copy_(ent[k_sq].reshape(-1))
+            if k_aux is not None:
+                self.aux[off:off + k].copy_(ent[k_aux].reshape(-1))
+            steps = max(steps, float(ent.get("step", 0.0)))
+        self.step_count.fill_(steps)
+        self._host_steps = int(steps)
+        groups = sd.get("param_groups") or [{}]
+        self.lr = groups[0].get("lr", self.lr)
+        return self.lr
 
 
 def _set_requires_grad(module: nn.Module, flag: bool):
     for p in module.parameters():
         p.requires_grad_(flag)
+
+
+LOSSES = ("ls", "og", "w", "hinge")
+
+
+def d_loss(loss: str, out: torch.Tensor, B: int, real: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``calc_D_loss`` (train.py:331-395, without label smoothing / noise) on D's outputs for the CONCATENATED
+    batch ``out[:B]`` = real, ``out[B:]`` = generated: D_real_loss + D_fake_loss, each a mean over its B jets.
+    Written on the whole vector with a 0/1 target (no slicing: a slice costs a zero-fill and a copy in autograd)."""
+    out = out.reshape(-1)
+    if real is None:
+        real = (torch.arange(2 * B, device=out.device) < B).to(out.dtype)   # 1 for the real half
+    if loss == "ls":
+        return ((out - real) ** 2).sum() / B
+    if loss == "og":  # nn.BCELoss (clamps its logarithms at -100)
+        return torch.nn.functional.binary_cross_entropy(out, real, reduction="sum") / B
+    sign = 1.0 - 2.0 * real                                             # -1 real, +1 generated
+    if loss == "w":
+        return (sign * out).sum() / B
+    if loss == "hinge":
+        return torch.relu(1.0 + sign * out).sum() / B
+    raise ValueError(f"loss must be one of {LOSSES}, got {loss!r}")
+
+
+def g_loss(loss: str, out: torch.Tensor) -> torch.Tensor:
+    """``calc_G_loss`` (train.py:465-476) on D's outputs for generated jets."""
+    out = out.reshape(-1)
+    if loss == "ls":
+        return ((out - 1.0) ** 2).mean()
+    if loss == "og":
+        return -torch.log(out).clamp(min=-100.0).mean()
+    if loss in ("w", "hinge"):
+        return -out.mean()
+    raise ValueError(f"loss must be one of {LOSSES}, got {loss!r}")
 
 
 class TrainStep:
@@ -116,8 +258,19 @@ class TrainStep:
 
     def __init__(self, G: nn.Module, D: nn.Module, batch_size: int, num_particles: int, latent: int = 32,
                  lr_disc: float = 3e-5, lr_gen: float = 1e-5, noise_std: float = 0.2, use_graphs: bool = True,
-                 process_group=None, world_size: int = 1, batch_real_fake: bool = True):
+                 process_group=None, world_size: int = 1, batch_real_fake: bool = True, loss: str = "ls",
+                 optimizer: str = "rmsprop", betas=(0.9, 0.999), gp_lambda: float = 0.0):
+        if loss not in LOSSES:
+            raise ValueError(f"loss must be one of {LOSSES}, got {loss!r}")
+        if gp_lambda:
+            # train.py:286-324: torch.autograd.grad(D(interpolated), interpolated, create_graph=True) and a backward
+            # through that gradient.  The fused MPLayer / attention backward kernels are not themselves
+            # differentiable (ops: once_differentiable) -- declined here, loudly, rather than training on a
+            # penalty whose second-order terms are silently missing.
+            raise RuntimeError("mpgan_amd: the gradient penalty (--gp) needs double backward through the discriminator, "
+                               "which the fused MI355X ops do not provide; use gp_lambda = 0")
         self.G, self.D = G, D
+        self.loss = loss
         # train_D evaluates D on the real and on the generated batch (train.py:432-447).  D has no cross-sample
         # coupling (no batch norm), so one pass over the concatenated 2B jets gives the same outputs and the same
         # summed gradients as the reference's two passes -- with half the launches and twice the workgroups per
@@ -128,13 +281,15 @@ class TrainStep:
         self.pg, self.world = process_group, world_size
         dev = next(G.parameters()).device
         self.dev = dev
-        self.fG, self.fD = FlatParams(G), FlatParams(D)
+        self.state = ops.dev_state(dev)
+        self.fG = FlatParams(G, optimizer, betas)
+        self.fD = FlatParams(D, optimizer, betas)
         self.data = torch.zeros(batch_size, num_particles, 4, device=dev)
         self.labels = torch.zeros(batch_size, 1, device=dev)
-        self._target = torch.cat([torch.ones(batch_size, device=dev), torch.zeros(batch_size, device=dev)])
+        self._real = torch.cat([torch.ones(batch_size, device=dev), torch.zeros(batch_size, device=dev)])
         self.D_loss = torch.zeros((), device=dev)
         self.G_loss = torch.zeros((), device=dev)
-        self.use_graphs = use_graphs
+        self.use_graphs = use_graphs and dev.type == "cuda"
         self._graphs = None
         self.fixed_noise = None  # tests: (noise_D, noise_G) used instead of fresh samples
 
@@ -146,7 +301,7 @@ class TrainStep:
 
     def _seg_D(self):  # train_D up to and including backward (train.py:419-460)
         # parameter gradients are added straight into the flat buffers (no AccumulateGrad kernel per parameter)
-        ops.OPTIONS["grad_into_param"] = True
+        self.state.grad_into_param = True
         ops.bump_seed(self.dev)
         self.D.train(); self.G.eval()
         self.fD.zero_grad()
@@ -155,53 +310,49 @@ class TrainStep:
             fake = self.G(self._noise(0), self.labels)
         if self.batch_real_fake:
             out = self.D(torch.cat([self.data, fake], 0), torch.cat([self.labels, self.labels], 0))
-            # mean over the real half of (out - 1)^2 + mean over the generated half of out^2, without slicing
-            loss = ((out - self._target.reshape(out.shape)) ** 2).sum() / self.B
         else:
-            out_r = self.D(self.data.clone(), self.labels)
-            out_f = self.D(fake, self.labels)
-            loss = ((out_r - 1.0) ** 2).mean() + (out_f ** 2).mean()
+            out = torch.cat([self.D(self.data.clone(), self.labels).reshape(-1), self.D(fake, self.labels).reshape(-1)])
+        loss = d_loss(self.loss, out, self.B, self._real)
         self._backward(loss)
         self.D_loss.copy_(loss.detach())
 
-    @staticmethod
-    def _backward(loss):
+    def _backward(self, loss):
         """loss.backward() with the stand-alone Linear layers' weight gradients collected and issued as grouped
         launches that add straight into the flat gradient buffers."""
-        ops.DEFERRED_WGRAD = ops.WgradBatch()
+        self.state.deferred_wgrad = ops.WgradBatch()
         try:
             loss.backward()
-            ops.DEFERRED_WGRAD.flush()
+            self.state.deferred_wgrad.flush()
         finally:
-            ops.DEFERRED_WGRAD = None
+            self.state.deferred_wgrad = None
 
     @staticmethod
     def _refresh_packed(module: nn.Module):
-        # mpg_rmsprop wrote the parameters behind autograd's back: rebuild the layers' cached weight images
+        # the fused optimiser wrote the parameters behind autograd's back: rebuild the layers' cached weight images
         for m in module.modules():
             if hasattr(m, "refresh_packed"):
                 m.refresh_packed()
 
     def _seg_G(self):  # D_optimizer.step() (train.py:461) + train_G up to backward (:494-520)
-        self.fD.rmsprop(self.lr_disc, gscale=1.0 / self.world)
+        self.fD.step(self.lr_disc, gscale=1.0 / self.world)
         self._refresh_packed(self.D)
         self.G.train()
         self.fG.zero_grad()
         _set_requires_grad(self.D, False)
         fake = self.G(self._noise(1), self.labels)
         out = self.D(fake, self.labels)
-        loss = ((out - 1.0) ** 2).mean()
+        loss = g_loss(self.loss, out)
         self._backward(loss)
         _set_requires_grad(self.D, True)
         self.G_loss.copy_(loss.detach())
 
     def _seg_end(self):  # G_optimizer.step() (train.py:521)
-        self.fG.rmsprop(self.lr_gen, gscale=1.0 / self.world)
+        self.fG.step(self.lr_gen, gscale=1.0 / self.world)
         self._refresh_packed(self.G)
-        ops.OPTIONS["grad_into_param"] = False
+        self.state.grad_into_param = False
 
     def _allreduce(self, flat: FlatParams):
-        mdist.allreduce_sum_(flat.grad, self.pg, self.world)  # sum; 1/world is folded into rmsprop
+        mdist.allreduce_sum_(flat.grad, self.pg, self.world)  # sum; 1/world is folded into the optimiser step
 
     def _eager(self):
         self._seg_D(); self._allreduce(self.fD)
@@ -220,8 +371,8 @@ class TrainStep:
         graphs = []
         pool = None
         # one graph per segment between collectives; without a process group the whole iteration is one graph
-        groups = [(self._seg_D,), (self._seg_G,), (self._seg_end,)] if (self.world > 1 or os.environ.get("MPG_SPLIT_GRAPHS")) else \
-                 [(self._seg_D, self._seg_G, self._seg_end)]
+        split = self.world > 1 or self.pg is not None or os.environ.get("MPG_SPLIT_GRAPHS")
+        groups = [(self._seg_D,), (self._seg_G,), (self._seg_end,)] if split else [(self._seg_D, self._seg_G, self._seg_end)]
         for segs in groups:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool):
@@ -243,8 +394,18 @@ class TrainStep:
             return
         if len(self._graphs) == 1:
             self._graphs[0].replay()
-            return
-        gD, gG, gE = self._graphs
-        gD.replay(); self._allreduce(self.fD)
-        gG.replay(); self._allreduce(self.fG)
-        gE.replay()
+        else:
+            gD, gG, gE = self._graphs
+            gD.replay(); self._allreduce(self.fD)
+            gG.replay(); self._allreduce(self.fG)
+            gE.replay()
+        self.fD.note_step(); self.fG.note_step()
+
+    # -- optimiser state in the reference's checkpoint format (train.py:534-535, setup_training.py:1525-1535) -----
+    def optimizer_state_dicts(self):
+        """(D_optimizer.state_dict(), G_optimizer.state_dict()) as the reference's ``save_models`` stores them."""
+        return self.fD.state_dict(self.lr_disc), self.fG.state_dict(self.lr_gen)
+
+    def load_optimizer_state_dicts(self, sd_D: dict, sd_G: dict):
+        self.fD.load_state_dict(sd_D)
+        self.fG.load_state_dict(sd_G)

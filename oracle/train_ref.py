@@ -150,6 +150,31 @@ def _fwd_D(model, sdD, x, labels, p, keeps, cfg):
     return A.gapt_d_forward(sdD, x, labels, p=p, keeps=keeps, **cfg.get("D", {}))
 
 
+def d_loss_ref(loss: str, out_r: Tensor, out_f: Tensor) -> Tensor:
+    """calc_D_loss (train.py:352-379), no label smoothing / noise / gradient penalty."""
+    if loss == "ls":
+        return ((out_r - 1.0) ** 2).mean() + (out_f**2).mean()
+    if loss == "og":  # nn.BCELoss against ones / zeros
+        bce = torch.nn.BCELoss()
+        return bce(out_r, torch.ones_like(out_r)) + bce(out_f, torch.zeros_like(out_f))
+    if loss == "w":
+        return -out_r.mean() + out_f.mean()
+    if loss == "hinge":
+        return torch.relu(1.0 - out_r).mean() + torch.relu(1.0 + out_f).mean()
+    raise ValueError(loss)
+
+
+def g_loss_ref(loss: str, out: Tensor) -> Tensor:
+    """calc_G_loss (train.py:465-476)."""
+    if loss == "ls":
+        return ((out - 1.0) ** 2).mean()
+    if loss == "og":
+        return torch.nn.BCELoss()(out, torch.ones_like(out))
+    if loss in ("w", "hinge"):
+        return -out.mean()
+    raise ValueError(loss)
+
+
 def train_iteration(
     model: str,
     sdD: Dict[str, Tensor],
@@ -166,8 +191,11 @@ def train_iteration(
     keeps: Optional[Tuple] = None,
     cfg: Optional[dict] = None,
     return_grads: bool = False,
+    loss: str = "ls",
 ):
-    """One train_D + train_G (num_critic = num_gen = 1), LSGAN loss, RMSprop.  Parameters in
+    """One train_D + train_G (num_critic = num_gen = 1), RMSprop; ``loss`` = ls (default) / og / w / hinge as
+    ``calc_D_loss`` (train.py:331-395) and ``calc_G_loss`` (:465-476) define them (for w / hinge the caller passes
+    ``cfg={"D": {"sigmoid": False}}``, setup_training.py:1250).  Parameters in
     ``sdD``/``sdG`` are updated in place.  ``keeps`` = (keeps for D(real), D(fake) in the
     D step, D(fake) in the G step) or None; each is a dict as taken by the D forward, or a
     ``RandKeeps()`` to draw Bernoulli masks.  Returns (D_loss, G_loss[, gradsD, gradsG])."""
@@ -181,7 +209,7 @@ def train_iteration(
         fake = _fwd_G(model, sdG, noise_D, labels, N, cfg)
     out_r = _fwd_D(model, pD, data, labels, p_disc, kr, cfg)
     out_f = _fwd_D(model, pD, fake, labels, p_disc, kf, cfg)
-    D_loss = ((out_r - 1.0) ** 2).mean() + (out_f**2).mean()
+    D_loss = d_loss_ref(loss, out_r, out_f)
     gD = dict(zip(pD.keys(), torch.autograd.grad(D_loss, list(pD.values()))))
     rmsprop_step(sdD, gD, stD, lr_disc)
 
@@ -189,7 +217,7 @@ def train_iteration(
     pG = {k: v.detach().requires_grad_(True) for k, v in sdG.items()}
     fake = _fwd_G(model, pG, noise_G, labels, N, cfg)
     out = _fwd_D(model, sdD, fake, labels, p_disc, kg, cfg)
-    G_loss = ((out - 1.0) ** 2).mean()
+    G_loss = g_loss_ref(loss, out)
     gG = dict(zip(pG.keys(), torch.autograd.grad(G_loss, list(pG.values()))))
     rmsprop_step(sdG, gG, stG, lr_gen)
 

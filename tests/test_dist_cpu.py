@@ -1,58 +1,130 @@
-"""CPU, world_size 2 over gloo: the data-parallel protocol (flat gradient bucket, SUM all-reduce with
-1/world folded into the update, per-rank seeds, parameter broadcast) reproduces the single-process
-global-batch gradient."""
+"""CPU, world_size 2 over gloo: the data-parallel protocol of the product's ``TrainStep`` -- parameter broadcast,
+local-batch losses, ONE flat-bucket SUM all-reduce per network between the graph segments, 1/world folded into the
+optimiser step, per-rank noise / dropout seeds -- reproduces the single-process global-batch iteration.
+
+``TrainStep`` itself runs here (its host logic is device-agnostic) on toy CPU networks; the one thing replaced is
+the fused optimiser launch (``FlatParams.step`` -> the same RMSprop arithmetic in torch), because libmpgan_amd has
+no CPU path.  The fused kernels under the same protocol are covered on the GPU box (tests/test_gpu_dist.py).
+"""
 import os
 import sys
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+N, LAT = 6, 5
+
+
+class ToyG(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.lin = torch.nn.Linear(LAT, 3)
+
+    def forward(self, noise, labels):
+        x = torch.tanh(self.lin(noise))
+        return torch.cat([x, torch.full_like(x[..., :1], 0.5)], 2)
+
+
+class ToyD(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.net = torch.nn.Sequential(torch.nn.Linear(4 * N, 7), torch.nn.LeakyReLU(0.2), torch.nn.Linear(7, 1))
+
+    def forward(self, x, labels):
+        return torch.sigmoid(self.net(x.reshape(x.shape[0], -1)) + labels)
+
+
+def _torch_rmsprop(self, lr, gscale=1.0):
+    """FlatParams.step for CPU tensors: mpg_rmsprop's arithmetic (csrc/optim.hip) in torch."""
+    g = self.grad * gscale
+    self.sq.mul_(0.99).addcmul_(g, g, value=0.01)
+    self.flat.addcdiv_(g, self.sq.sqrt() + 1e-8, value=-lr)
+    self._host_steps += 1
+    self.lr = lr
+
+
+def _inputs(B):
+    g = torch.Generator().manual_seed(7)
+    data = torch.randn(B, N, 4, generator=g)
+    labels = torch.rand(B, 1, generator=g)
+    nD = torch.randn(B, N, LAT, generator=g) * 0.2
+    nG = torch.randn(B, N, LAT, generator=g) * 0.2
+    return data, labels, nD, nG
+
+
+def _run(world, rank, pg, steps=3, loss="ls"):
+    from mpgan_amd import dist as mdist, train
+    train.FlatParams.step = _torch_rmsprop
+    torch.manual_seed(100 + rank)       # ranks start from different weights ...
+    G, D = ToyG(), ToyD()
+    if world > 1:
+        mdist.broadcast_module(G, 0, pg)  # ... and are brought to rank 0's
+        mdist.broadcast_module(D, 0, pg)
+    Bg = 8
+    B = Bg // world
+    data, labels, nD, nG = _inputs(Bg)
+    sl = slice(rank * B, (rank + 1) * B)
+    ts = train.TrainStep(G, D, B, N, latent=LAT, lr_disc=1e-2, lr_gen=2e-2, use_graphs=False, process_group=pg,
+                         world_size=world, loss=loss)
+    ts.set_batch(data[sl], labels[sl])
+    ts.fixed_noise = (nD[sl], nG[sl])
+    for _ in range(steps):
+        ts.step()
+    return ts.fD.flat.clone(), ts.fG.flat.clone(), ts.fD.grad.clone(), float(ts.D_loss), ts
+
 
 def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from mpgan_amd import dist as mdist
-    from mpgan_amd.train import FlatParams
     r, w, pg = mdist.init_from_env("gloo")
     assert (r, w) == (rank, world)
-    torch.manual_seed(100 + rank)  # ranks start from different weights ...
-    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.LeakyReLU(0.2), torch.nn.Linear(5, 1))
-    mdist.broadcast_module(net, 0, pg)  # ... and are brought to rank 0's
-    flat = FlatParams(net)
-    g = torch.Generator().manual_seed(7)
-    X = torch.randn(8, 6, generator=g)
-    Y = torch.randn(8, 1, generator=g)
-    xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
-    flat.zero_grad()
-    ((net(xs) - ys) ** 2).mean().backward()  # local-batch mean loss, as every rank computes it
-    scale = mdist.allreduce_sum_(flat.grad, pg, w)
-    out[rank] = (flat.flat.clone(), flat.grad.clone() * scale)
+    fD, fG, gD, dl, ts = _run(world, rank, pg)
+    assert ts.fD.steps == 3 and ts.fG.steps == 3
+    out[rank] = (fD, fG, gD, dl)
     assert mdist.rank_seed(4, 0) != mdist.rank_seed(4, 1)
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_equals_global_batch():
+def test_two_rank_trainstep_equals_global_batch():
     world = 2
     mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, 29517, out), nprocs=world, join=True)
-    p0, g0 = out[0]
-    p1, g1 = out[1]
-    assert torch.equal(p0, p1)            # broadcast worked
-    assert torch.allclose(g0, g1)         # every rank holds the same averaged gradient
-    # single-process reference on the global batch
+    (d0, g0, gr0, l0), (d1, g1, gr1, l1) = out[0], out[1]
+    assert torch.equal(d0, d1) and torch.equal(g0, g1)   # broadcast + identical averaged updates on every rank
+    assert torch.equal(gr0, gr1)                         # the all-reduced (summed) gradient buffer
     sys.path.insert(0, ROOT)
-    from mpgan_amd.train import FlatParams
-    torch.manual_seed(100)
-    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.LeakyReLU(0.2), torch.nn.Linear(5, 1))
-    flat = FlatParams(net)
-    g = torch.Generator().manual_seed(7)
-    X = torch.randn(8, 6, generator=g)
-    Y = torch.randn(8, 1, generator=g)
-    ((net(X) - Y) ** 2).mean().backward()
-    assert torch.allclose(flat.flat, p0)
-    assert torch.allclose(flat.grad, g0, atol=1e-6)
+    sD, sG, sgr, sl, _ = _run(1, 0, None)
+    assert torch.allclose(sD, d0, rtol=1e-4, atol=1e-6), float((sD - d0).abs().max())
+    assert torch.allclose(sG, g0, rtol=1e-4, atol=1e-6), float((sG - g0).abs().max())
+    # summed local-mean gradients / world = global-batch mean gradient (last iteration's D gradient)
+    assert torch.allclose(sgr, gr0 / world, rtol=1e-3, atol=1e-6)
+    assert abs(0.5 * (l0 + l1) - sl) < 1e-5              # local losses average to the global loss
+
+
+def test_losses_match_oracle_definitions():
+    """d_loss / g_loss (slice-free forms) == the restated calc_D_loss / calc_G_loss for every loss choice."""
+    sys.path.insert(0, ROOT)
+    from mpgan_amd import train
+    from oracle import train_ref as T
+    g = torch.Generator().manual_seed(3)
+    B = 16
+    for loss in train.LOSSES:
+        raw = torch.randn(2 * B, 1, generator=g, dtype=torch.float64)
+        out = torch.sigmoid(raw) if loss in ("ls", "og") else raw
+        a = train.d_loss(loss, out, B)
+        b = T.d_loss_ref(loss, out[:B], out[B:])
+        assert abs(float(a) - float(b)) < 1e-12, loss
+        assert abs(float(train.g_loss(loss, out[B:])) - float(T.g_loss_ref(loss, out[B:]))) < 1e-12, loss
+
+
+def test_gradient_penalty_is_declined():
+    sys.path.insert(0, ROOT)
+    import pytest
+    from mpgan_amd import train
+    with pytest.raises(RuntimeError, match="double backward"):
+        train.TrainStep(ToyG(), ToyD(), 4, N, latent=LAT, use_graphs=False, gp_lambda=10.0)

@@ -89,11 +89,11 @@ def test_train_step_vs_reference_golden():
         ts._seg_D()
         if it == 0:
             for k, p in D.named_parameters():
-                assert rel_err(summarize(k, p.grad), g["gradD__" + k]) < 2e-3, k
+                assert rel_err(summarize(k, p.grad), g["gradD__" + k]) < 1e-3, k
         ts._seg_G()
         if it == 0:
             for k, p in G.named_parameters():
-                assert rel_err(summarize(k, p.grad), g["gradG__" + k]) < 2e-3, k
+                assert rel_err(summarize(k, p.grad), g["gradG__" + k]) < 1e-3, k
         ts._seg_end()
         assert abs(float(ts.D_loss) - float(g[f"D_loss{it}"])) < 1e-4 * abs(float(g[f"D_loss{it}"]))
         assert abs(float(ts.G_loss) - float(g[f"G_loss{it}"])) < 1e-4 * abs(float(g[f"G_loss{it}"]))
@@ -116,3 +116,14 @@ def test_gapt_graph_step_with_dropout():
         losses.append((float(ts.D_loss), float(ts.G_loss)))
     assert all(np.isfinite(a) and np.isfinite(b) for a, b in losses)
     assert len(set(losses)) == 4
+
+
+def test_gapt_full_size_graph_equals_eager():
+    """BASELINE config 4 as named (GAPT, N = 30, B = 512): hipGraph replay == eager bit for bit with dropout off,
+    finite losses and moving parameters with the default D dropout."""
+    from test_gpu_train import _three_steps
+    a = _three_steps(512, 30, use_graphs=False, model="gapt")
+    b = _three_steps(512, 30, use_graphs=True, model="gapt")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2:] == b[2:]
+    c = _three_steps(512, 30, use_graphs=True, model="gapt", disc_dropout=0.5)
+    assert all(np.isfinite(v) for v in c[2:]) and not torch.equal(c[0], a[0])

@@ -72,10 +72,12 @@ def _mplayer_shapes(F, out):
     return mplayer_shapes(F, out)
 
 
-def _run_case(B, N, F, out, use_mask, sum_agg, seed, skip=True, alpha=0.2):
+def _run_case(B, N, F, out, use_mask, sum_agg, seed, skip=True, alpha=0.2, control=None):
     """HIP MPLayer vs fp64 oracle on the same inputs.  Returns per-tensor
     (max-norm error, fraction of elements off by more than 1e-3 of the max) and the oracle's
-    kink margin = min |pre-activation| / max |pre-activation| over all LeakyReLU inputs."""
+    kink margin = min |pre-activation| / max |pre-activation| over all LeakyReLU inputs.
+    ``control`` (a dict): also run the oracle in plain fp32 -- the reference's own arithmetic -- on the same inputs
+    and store ITS errors / off-fractions against the fp64 run there: the yardstick for kink flips."""
     import oracle
     from oracle import train_ref as T
     from mpgan_amd import ops
@@ -99,6 +101,17 @@ def _run_case(B, N, F, out, use_mask, sum_agg, seed, skip=True, alpha=0.2):
     yo = oracle.mplayer_forward(sdo, "L", xo, mask64, sum_agg=sum_agg, alpha=alpha, probe=probe)
     (yo * g64).sum().backward()
     margin = min(float(z.abs().min() / z.abs().max()) for z in probe)
+    if control is not None:
+        sd32 = {"L." + k: v.float().requires_grad_(True) for k, v in sd64.items()}
+        x32 = x64.float().requires_grad_(True)
+        y32 = oracle.mplayer_forward(sd32, "L", x32, None if mask64 is None else mask64.float(), sum_agg=sum_agg,
+                                     alpha=alpha)
+        (y32 * g64.float()).sum().backward()
+        cpairs = {"y": (y32.detach(), yo.detach()), "dx": (x32.grad, xo.grad)}
+        cpairs.update({k[2:]: (sd32[k].grad, sdo[k].grad) for k in sd32})
+        for k, (a, b) in cpairs.items():
+            a, b = a.double().numpy(), b.numpy()
+            control[k] = (rel_err(a, b), float((np.abs(a - b) > 1e-3 * np.abs(b).max()).mean()))
     x = x64.float().to(_dev()).requires_grad_(True)
     mask = None if mask64 is None else mask64.float().to(_dev())
     y = layer(x, use_mask, mask)
@@ -115,6 +128,26 @@ def _run_case(B, N, F, out, use_mask, sum_agg, seed, skip=True, alpha=0.2):
         errs[k] = rel_err(a, b)
         frac[k] = float((np.abs(a - b) > 1e-3 * np.abs(b).max()).mean())
     return errs, frac, margin
+
+
+def _assert_gradients_up_to_kink_flips(errs, frac, control, margin):
+    """Gradient bar for the default (kinked) activation.  LeakyReLU' jumps at 0, so an element whose pre-activation
+    lies within the forward rounding error of zero may take the other slope -- in the reference's own fp32
+    arithmetic just as here (``control`` = fp32 oracle vs fp64 oracle on the same input: (error, off-fraction) per
+    tensor).  A tensor passes when it meets the 1e-3 bar outright, or three times fp32's own error on this input;
+    failing that, only as an isolated flip: error below 2e-2 AND no more elements off than 3x fp32's or 1 %."""
+    print("errs", errs, "\nfrac", frac, "\ncontrol", control, "margin", margin)
+    bad = {}
+    for k in errs:
+        if k == "y":
+            continue
+        ce, cf = control[k]
+        if errs[k] < max(TOL, 3 * ce):
+            continue
+        if errs[k] < 2e-2 and frac[k] <= max(3 * cf, 1e-2):
+            continue
+        bad[k] = (errs[k], frac[k], ce, cf)
+    assert not bad, (bad, margin)
 
 
 CASES = [  # B, N, F, out, mask, sum
@@ -143,12 +176,33 @@ def test_mplayer_vs_oracle(case):
     elements of any gradient tensor may differ by more than 1e-3 of its max (each flip touches
     one edge row; here, with a handful of jets, a flipped edge moves the summed gradients by ~1 %,
     at B = 256 by ~1e-4 -- test_mplayer_full_size)."""
-    errs, frac, margin = _run_case(*case, seed=CASES.index(case))
+    control = {}
+    errs, frac, margin = _run_case(*case, seed=CASES.index(case), control=control)
     assert errs["y"] < TIGHT, errs
-    # gross-error bound only: a single flipped edge shifts these small sums by ~1 %; exactness of
-    # the gradient path is pinned by the slope-1 and the margin-checked tests around this one
-    bad = {k: (errs[k], frac[k]) for k in errs if errs[k] > 5e-2}
-    assert not bad, (bad, margin)
+    _assert_gradients_up_to_kink_flips(errs, frac, control, margin)
+
+
+@pytest.mark.parametrize("case", [(4, 30, 32, 32, True, True), (3, 30, 3, 32, True, False), (2, 33, 32, 32, False, True)])
+def test_mplayer_plain_relu(case):
+    """alpha = 0 (plain ReLU): the slope of the negative side is exactly 0, which the kernels get from sign bits
+    (v_max(v, -0.0) must keep the sign of a negative pre-activation for the dZ2 gate, edge_bwd.hip).  Forward
+    strict; gradients within the bar up to the kink flips fp32 shows on the same input."""
+    control = {}
+    errs, frac, margin = _run_case(*case, seed=77 + case[0], alpha=0.0, control=control)
+    assert errs["y"] < TIGHT, errs
+    _assert_gradients_up_to_kink_flips(errs, frac, control, margin)
+
+
+def test_mplayer_plain_relu_strict_when_away_from_the_kink():
+    found = 0
+    for seed in range(300, 360):
+        for case in ((1, 4, 32, 32, True, True), (1, 5, 3, 32, False, True)):
+            errs, _, margin = _run_case(*case, seed=seed, alpha=0.0)
+            if margin < 5e-5:
+                continue
+            found += 1
+            assert max(errs.values()) < TIGHT, (case, seed, margin, errs)
+    assert found >= 5, found
 
 
 def test_mplayer_small_strict_gradients():
@@ -182,20 +236,35 @@ def test_mplayer_vs_reference_golden(name, F, out, ci):
     y = layer(x, True, torch.from_numpy(g["mask"]).to(_dev()))
     (y * torch.from_numpy(g["g"]).to(_dev())).sum().backward()
     assert rel_err(y.detach().cpu().numpy(), g["y"]) < TIGHT
-    dx, ref = x.grad.cpu().numpy(), g["dx"]
-    assert float((np.abs(dx - ref) > 1e-3 * np.abs(ref).max()).mean()) < 0.05
+    # yardstick: the reference's fp32 run against its own fp64 run on these inputs (both are goldens)
+    g64 = load_golden(f"mplayer_{name}_f64.npz")
+    off = lambda a, b: float((np.abs(a - b) > 1e-3 * np.abs(b).max()).mean())
+    ctrl = off(g["dx"].astype(np.float64), g64["dx"])
+    ours = off(x.grad.cpu().numpy().astype(np.float64), g64["dx"])
+    print(f"dx off-fraction vs fp64 golden: fp32 reference {ctrl:.2e}, HIP {ours:.2e}")
+    assert ours <= max(3 * ctrl, 2.0 / (x.shape[0] * x.shape[1])), (ours, ctrl)
+    for k, p in layer.named_parameters():   # parameter gradients: summaries (sum, l2, 64 samples) of the fp64 golden
+        from conftest import summarize
+        e = rel_err(summarize(k, p.grad), g64["grad__" + k])
+        c = rel_err(g["grad__" + k], g64["grad__" + k])
+        assert e < max(TOL, 3 * c), (k, e, c)
 
 
 def test_mplayer_full_size():
     """BASELINE config 2 (B = 256, N = 30, F = 32): forward strict; parameter gradients (sums over
     230,400 edges) within the 1e-3 bar; input gradient: all but a tiny fraction of elements."""
-    errs, frac, margin = _run_case(256, 30, 32, 32, True, True, seed=7)
-    print("full-size errors", errs, "\nfrac>1e-3", frac, "margin", margin)
+    control = {}
+    errs, frac, margin = _run_case(256, 30, 32, 32, True, True, seed=7, control=control)
+    print("full-size errors", errs, "\nfrac>1e-3", frac, "margin", margin, "\nfp32 control (err, frac)", control)
     assert errs["y"] < TIGHT
     for k, v in errs.items():
         if k not in ("y", "dx"):
             assert v < TOL, (k, v)
-    assert frac["dx"] < 0.02
+    # input gradient: a kink flip moves one row of dx by O(1) of that row -- rare isolated elements, also in the
+    # reference's own fp32 arithmetic (control).  The HIP path must stay within 3x of fp32's off-fraction.
+    assert errs["dx"] < 5e-3, errs["dx"]
+    assert frac["dx"] < 1e-3, frac["dx"]
+    assert frac["dx"] <= max(3 * control["dx"][1], 5e-5), (frac["dx"], control["dx"])
 
 
 @pytest.mark.parametrize("p_drop", [0.5, 0.3])
@@ -221,7 +290,7 @@ def test_mplayer_dropout_exact(p_drop):
     ops.set_seed(4242)
     x = x64.float().to(_dev()).requires_grad_(True)
     y = layer(x, True, mask64.float().to(_dev()))
-    tag = ops.LAST_TAG
+    tag = ops.last_tag(_dev())
     (y * g64.float().to(_dev())).sum().backward()
     thr, scale = ops.drop_params(p_drop)
     widths = {"e0": 96, "e1": 160, "e2": 192, "n0": 256, "n1": 256, "n2": out}
