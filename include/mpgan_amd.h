@@ -108,7 +108,9 @@ int mpg_pack_many(const MpgPackJob* jobs, int njobs, void* stream);
  *             multiplies it by a dropout keep mask first (backward of a trailing dropout) and in_out, if given,
  *             receives that gated input.
  * Wimg_l is the mpg_pack_weights image of the [N, K] matrix applied (the transposed weight in the backward),
- * fp16 hi/lo when f16 else bf16 hi/lo.  K, N <= 256 for every layer but the last (N unbounded there). */
+ * fp16 hi/lo when f16 else bf16 hi/lo.  K, N <= 256 for every layer but the last (N unbounded there).
+ * wscale / ascale: exact power-of-two operand scales that keep the lo halves of fp16 pairs out of the subnormal
+ * range (an fp16 hi/lo pair has its 22 bits only for |x| >= 2^-3); results are unscaled before the epilogue. */
 typedef struct MpgChainLayer {
     const void* Wimg; const float* bias; int nbias;      /* bias[n] for n < nbias, 0 beyond (nbias = 0: all N) */
     int K, N, act;
@@ -117,6 +119,7 @@ typedef struct MpgChainLayer {
     uint32_t gate_tag, gate_thr; float gate_scale;
     const float* resid; int ldr;                         /* y += resid[m, n] (after everything else), or NULL */
     float* out; int ldo;
+    float wscale;                                        /* the image holds wscale * W (a power of two; 0 = 1): z is divided by it */
 } MpgChainLayer;
 typedef struct MpgChain {
     const float* A; int lda, K1;
@@ -125,6 +128,7 @@ typedef struct MpgChain {
     uint32_t in_tag, in_thr; float in_scale;
     float* in_out; int ld_in_out;
     int M, nlayers; float alpha; const uint64_t* seed; int f16;
+    float ascale;                                        /* activations are split as ascale * x (a power of two; 0 = 1) */
     MpgChainLayer L[3];
 } MpgChain;
 int mpg_chain(const MpgChain* p, void* stream);
@@ -158,7 +162,8 @@ int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream);
  * and, when stageE2/stageZ2 are non-NULL (weight gradients wanted), parks E2 = fe.net.1's output and
  * dZ2 = dL/d(its pre-activation) as 16-bit hi/lo fragments [B*RB*N blocks][2][10][64 lanes][8] (fp16 / bf16 resp.
  * bf16 / bf16 when f16 = 0) for mpg_edge_dw.  W2img is the forward image (mpg_pack_weights, f16 as the
- * flag says); W3Timg / W2Timg are bf16 images of the transposed weights. */
+ * flag says); W3Timg / W2Timg are bf16 images of the transposed weights.  A sender chunk (ceil(N / SC) senders)
+ * may hold at most 188 senders (error -6: raise SC), and the staging buffers must stay below 2 GiB (error -7). */
 typedef struct MpgEdgeBwd {
     const float* a; const float* c; int ld_ac; const float* mask;
     const float* dagg; int ld_dagg;
@@ -212,6 +217,49 @@ typedef struct MpgAttn {
 } MpgAttn;
 int mpg_attn_fwd(const MpgAttn* p, void* stream);
 int mpg_attn_bwd(const MpgAttn* p, void* stream);
+
+/* ---- the per-jet pieces around the message-passing layers ----------------------------------------
+ * mpg_rank_mask: MPGenerator._get_mask, mask_c branch (mpgan/model.py:689-699; GAPT_G :255-258): with
+ * n_b = int(labels[b] * N), mask[b, i] = 1 for the n_b particles of jet b with the smallest first feature
+ * x[b*ld_jet + i*ld_part] (rank = argsort(argsort(.)); ties by index), else 0.  mask is [B, N] contiguous. */
+int mpg_rank_mask(const float* x, int ld_jet, int ld_part, const float* labels, int ld_lab, int B, int N,
+                  float* mask, void* stream);
+
+/* mpg_gen_tail_fwd / _bwd: MPNet._final_activation (:533-538) + MPGenerator._final_mask (:741-757) on V = B*N rows:
+ * out[v, 0:F] = act(y[v, 0:F]) (act 0 none, 1 tanh, 2 sigmoid), out[v, F] = mask[v] - 0.5 when mask != NULL;
+ * backward dy = dout[:, 0:F] * act'(out).  Row strides ldy / ldo / ldd let the output land inside a larger batch. */
+int mpg_gen_tail_fwd(const float* y, int ldy, const float* mask, float* out, int ldo, int V, int F, int act, void* stream);
+int mpg_gen_tail_bwd(const float* dout, int ldd, const float* out, int ldo, float* dy, int ldy, int V, int F, int act,
+                     void* stream);
+
+/* mpg_disc_head_fwd / _bwd: MPDiscriminator._post_mp (masked sum or mean over the particles, :812-829), fnd_layer =
+ * one Linear(F -> 1) followed by Dropout (LinearNet, :77-83) and the final sigmoid (:537); also GAPT_D's
+ * final_fc + sigmoid (gapt/model.py:344) with N = 1.
+ *   fwd:  out[b] = act( keep_b * ( pool_b( sum_i mask[b,i] y[b,i,:] ) . w + bias ) )
+ *   bwd:  dy[b,i,f], and dw / db of the Linear (added to when accumulate), from
+ *         loss < 0 : gout[b] = dL/dout[b] handed in by autograd
+ *         loss >= 0: the loss named (0 ls, 1 og, 2 w, 3 hinge: calc_D_loss / calc_G_loss, train.py:331-395, :465-476),
+ *                    jets [0, n_real) scored as real and the rest as generated (gen_step: all as real, generator
+ *                    form), each term times inv_count; loss_out receives the sum of the terms.
+ * aux [2B] and pooled [B,F] are scratch written by fwd and read by bwd. */
+typedef struct MpgDiscHead {
+    const float* y; int ldy;              /* [B, N, F], row (particle) stride ldy                  */
+    const float* mask;                    /* [B, N] or NULL                                        */
+    const float* w; const float* bias;    /* Linear(F -> 1): weight [F], bias [1] or NULL          */
+    int B, N, F;
+    int mean;                             /* pooling: 0 sum, 1 mean (mask sum + 1e-12, or N)       */
+    int sigmoid;
+    const uint64_t* seed; uint32_t tag, thr; float dscale;   /* dropout on the Linear's output     */
+    float* out;                           /* [B]                                                   */
+    float* pooled; float* aux;
+    int loss, gen_step, n_real; float inv_count;
+    const float* gout;
+    float* terms; float* loss_out;        /* [B] scratch; scalar                                   */
+    float* dy; int ld_dy;                 /* [B, N, F] or NULL                                     */
+    float* dw; float* db; int accumulate;
+} MpgDiscHead;
+int mpg_disc_head_fwd(const MpgDiscHead* p, void* stream);
+int mpg_disc_head_bwd(const MpgDiscHead* p, void* stream);
 
 /* ---- optimisers --------------------------------------------------------------------------------
  * One launch over one flat buffer of n parameters; `gscale` multiplies the gradient first (1/world after a

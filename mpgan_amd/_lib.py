@@ -104,6 +104,7 @@ class MpgChainLayer(C.Structure):
         ("gate_tag", C.c_uint32), ("gate_thr", C.c_uint32), ("gate_scale", C.c_float),
         ("resid", _fp), ("ldr", C.c_int),
         ("out", _fp), ("ldo", C.c_int),
+        ("wscale", C.c_float),
     ]
 
 
@@ -115,6 +116,7 @@ class MpgChain(C.Structure):
         ("in_tag", C.c_uint32), ("in_thr", C.c_uint32), ("in_scale", C.c_float),
         ("in_out", _fp), ("ld_in_out", C.c_int),
         ("M", C.c_int), ("nlayers", C.c_int), ("alpha", C.c_float), ("seed", _fp), ("f16", C.c_int),
+        ("ascale", C.c_float),
         ("L", MpgChainLayer * 3),
     ]
 
@@ -125,6 +127,18 @@ class MpgAttn(C.Structure):
         ("ignore", _fp), ("o", _fp), ("ldo", C.c_int), ("P", _fp), ("d_o", _fp),
         ("dq", _fp), ("dk", _fp), ("dv", _fp), ("lddq", C.c_int), ("lddk", C.c_int), ("lddv", C.c_int),
         ("B", C.c_int), ("L", C.c_int), ("S", C.c_int), ("H", C.c_int), ("d", C.c_int),
+    ]
+
+
+class MpgDiscHead(C.Structure):
+    _fields_ = [
+        ("y", _fp), ("ldy", C.c_int), ("mask", _fp), ("w", _fp), ("bias", _fp),
+        ("B", C.c_int), ("N", C.c_int), ("F", C.c_int), ("mean", C.c_int), ("sigmoid", C.c_int),
+        ("seed", _fp), ("tag", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
+        ("out", _fp), ("pooled", _fp), ("aux", _fp),
+        ("loss", C.c_int), ("gen_step", C.c_int), ("n_real", C.c_int), ("inv_count", C.c_float),
+        ("gout", _fp), ("terms", _fp), ("loss_out", _fp),
+        ("dy", _fp), ("ld_dy", C.c_int), ("dw", _fp), ("db", _fp), ("accumulate", C.c_int),
     ]
 
 
@@ -145,6 +159,11 @@ SIGNATURES = {
     "mpg_edge_dw": (C.c_int, [C.POINTER(MpgEdgeDw), C.c_void_p]),
     "mpg_attn_fwd": (C.c_int, [C.POINTER(MpgAttn), C.c_void_p]),
     "mpg_attn_bwd": (C.c_int, [C.POINTER(MpgAttn), C.c_void_p]),
+    "mpg_rank_mask": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, C.c_void_p]),
+    "mpg_gen_tail_fwd": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mpg_gen_tail_bwd": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mpg_disc_head_fwd": (C.c_int, [C.POINTER(MpgDiscHead), C.c_void_p]),
+    "mpg_disc_head_bwd": (C.c_int, [C.POINTER(MpgDiscHead), C.c_void_p]),
     "mpg_rmsprop": (C.c_int, [_fp, _fp, _fp, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "mpg_adam": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                            C.c_float, C.c_void_p]),
@@ -181,7 +200,8 @@ def _compiler_env():
 
 
 def _under_profiler() -> bool:
-    return bool(os.environ.get("LD_PRELOAD")) or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    pre = os.environ.get("LD_PRELOAD", "").lower()
+    return any(t in pre for t in ("rocprof", "roctracer", "rocp_")) or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -34,6 +34,10 @@ __global__ __launch_bounds__(512, 1) void chain_kernel(const MpgChain p) {
     uint32_t seed_lo = 0, seed_hi = 0;
     if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
 
+    // power-of-two operand scales (fp16 hi/lo carries its 22 bits only for |x| >= 2^-3, see edge_common.h): the
+    // activations of every layer are multiplied by ascale before they are split, layer l's image was packed from
+    // wscale_l * W, so its accumulators hold wscale_l * ascale * z
+    const float ascale = p.ascale > 0.f ? p.ascale : 1.f;
     const int lane16 = lane * 16;
     // Weight fragments come from L2 (~700 ns away): a wave keeps the first 8 k-steps of its NEXT tile in flight
     // while it works on the current one -- the preload of layer l+1's tile is issued before layer l's MFMAs (the
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(512, 1) void chain_kernel(const MpgChain p) {
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * half + e] = x4[e];
+                for (int e = 0; e < 4; ++e) v[4 * half + e] = x4[e] * ascale;
             }
             V hi, lo;
             split8(v, hi, lo);
@@ -138,11 +142,12 @@ __global__ __launch_bounds__(512, 1) void chain_kernel(const MpgChain p) {
             for (int tile = w; tile < MT; tile += 8) {
                 if (tile != w) preload(lc, tile);  // more than 8 tiles in a layer: later tiles load late
                 f32x16 acc;
+                const float zscale = (L.wscale > 0.f ? L.wscale : 1.f) * ascale, inv_zscale = 1.f / zscale;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int n = 32 * tile + 8 * g + 4 * h;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[4 * g + t] = (L.bias != nullptr && n + t < (L.nbias ? L.nbias : L.N)) ? L.bias[n + t] : 0.f;
+                    for (int t = 0; t < 4; ++t) acc[4 * g + t] = (L.bias != nullptr && n + t < (L.nbias ? L.nbias : L.N)) ? L.bias[n + t] * zscale : 0.f;
                 }
                 // the gate operand (an activation saved by the forward, in HBM) is requested before the MFMAs
                 float hv[16];
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(512, 1) void chain_kernel(const MpgChain p) {
                     float x4[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        float x = acc[4 * g + t];
+                        float x = acc[4 * g + t] * inv_zscale;
                         if (L.act) x = lrelu(x, p.alpha);
                         x4[t] = x;
                     }
@@ -220,6 +225,8 @@ __global__ __launch_bounds__(512, 1) void chain_kernel(const MpgChain p) {
                     for (int t = 0; t < 4; ++t) v[4 * g + t] = x4[t];
                 }
                 if (!last) {  // registers 8s .. 8s+7 are the B fragment of k-step (2 tile + s) of the next layer
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v[k] *= ascale;
                     V hi, lo;
                     split8(v, hi, lo);
                     fout[((2 * tile + 0) * 2 + 0) * 64 + lane] = hi;

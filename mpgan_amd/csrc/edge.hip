@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
     const int lane16 = lane * 16;
     const uint32_t lb3hi = lds_base(smem, lane16), lb3lo = lds_base(smem, NF3 * 1024 + lane16),
                    lb2hi = lds_base(smem, 2 * NF3 * 1024 + lane16);
-    for (int t = tid; t < H2 + H3; t += 256) lbias[t] = t < H2 ? p.b2[t] : p.b3[t - H2];
+    for (int t = tid; t < H2 + H3; t += 256) lbias[t] = t < H2 ? p.b2[t] * SC_E2 : p.b3[t - H2] * SC_E3;  // (biases in the accumulators' scale)
     const float* lb2 = lbias;
     const float* lb3 = lbias + H2;
 
@@ -105,10 +105,10 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const float4 t4 = ld4(ai + 32 * q + 16 * s + 8 * u + 4 * h);
-                    areg[q][s][4 * u + 0] = vi ? t4.x : 0.f;
-                    areg[q][s][4 * u + 1] = vi ? t4.y : 0.f;
-                    areg[q][s][4 * u + 2] = vi ? t4.z : 0.f;
-                    areg[q][s][4 * u + 3] = vi ? t4.w : 0.f;
+                    areg[q][s][4 * u + 0] = vi ? t4.x * SC_A : 0.f;
+                    areg[q][s][4 * u + 1] = vi ? t4.y * SC_A : 0.f;
+                    areg[q][s][4 * u + 2] = vi ? t4.z * SC_A : 0.f;
+                    areg[q][s][4 * u + 3] = vi ? t4.w * SC_A : 0.f;
                 }
     }
     f32x16 agg[T3];
@@ -121,13 +121,15 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
     for (int j0 = jbeg; j0 < jend; j0 += FWD_C_SLOTS) {
     const int j1 = min(jend, j0 + FWD_C_SLOTS);
     __syncthreads();  // previous chunk fully consumed (first pass: weight/bias fill issued)
-    for (int t = tid; t < (j1 - j0) * (H1 / 4); t += 256)
-        reinterpret_cast<float4*>(lc)[t] = ld4(p.c + (size_t)(b * p.N + j0 + t / (H1 / 4)) * (p.ld_ac ? p.ld_ac : H1) + 4 * (t % (H1 / 4)));
+    for (int t = tid; t < (j1 - j0) * (H1 / 4); t += 256) {
+        const float4 c4 = ld4(p.c + (size_t)(b * p.N + j0 + t / (H1 / 4)) * (p.ld_ac ? p.ld_ac : H1) + 4 * (t % (H1 / 4)));
+        reinterpret_cast<float4*>(lc)[t] = make_float4(c4.x * SC_A, c4.y * SC_A, c4.z * SC_A, c4.w * SC_A);
+    }
     __syncthreads();
     for (int j = j0 + w; j < j1; j += 4) {
         const float mj = p.mask ? p.mask[b * p.N + j] : 1.f;
         if ((p.skip_masked & 1) && mj == 0.f) continue;  // wave-uniform
-        const float mjs = mj * p.dscale;
+        const float mjs = mj * p.dscale * (1.f / SC_E3);  // (the layer-3 output carries SC_E3)
         const uint32_t erow = (uint32_t)((b * p.N + i) * p.N + j);
         const float* cj = lc + (j - j0) * H1;
 

@@ -15,14 +15,16 @@
 // fragment-order permutation of the feature indices.
 #include "edge_common.h"
 
+#ifndef MPG_BEXP
+#define MPG_BEXP 0  // experiment bits (tools/ubench/bwd_bench.hip): 1 streamed fragments all from index 0 (L1 hits), 2 no staging stores,
+                    // 4 no dZ3 build, 8 no dZ2 epilogue, 16 no dZ1 epilogue, 32 no E2 epilogue
+#endif
 #ifndef MPG_DW_EXP
 #define MPG_DW_EXP 0  // experiment bits (tools/ubench/dw_bench.hip): 1 consumers idle, 2 builders idle, 4 no staged loads, 8 no LDS writes
 #endif
 
 namespace {
 
-constexpr int NF3T = T2 * T3 * 2;  // W3^T image: 5 row tiles x 6 k-tiles x 2 = 60 fragments
-constexpr int NF2T = T1 * T2 * 2;  // W2^T image: 3 x 5 x 2 = 30
 // LDS plan: W3^T hi|lo (bf16, 122,880) | dagg tile of the 32 receivers (24,576) | a tile (12,288) |
 // b2 (640) | c_j of the current sender chunk (8 x 384 = 3,072)   = 163,456 B.  W2 and W2^T stream from L2.
 constexpr int BWD_W_BYTES = 2 * NF3T * 1024;
@@ -38,14 +40,13 @@ constexpr int RED_DA_BYTES = 4 * T1 * 16 * 64 * 4;
 // staging: block blk = (b*RB + rb)*N + j ; plane part (0 hi, 1 lo) ; the 10 B-operand fragments (tile, k-step) of
 // the 160-feature tensor exactly as the lanes hold them: one coalesced 16-byte store per lane and fragment.
 // In "fragment order" a lane's 8 elements are features fi = 16 frag + 8 h + jj of receiver r = lane & 31.
-constexpr int NFR2 = T2 * 2;
 template <typename V>
 MPG_DEV void stage_frag(void* base, size_t blk, int part, int frag, int lane, const V f) {
     reinterpret_cast<V*>(base)[((blk * 2 + part) * NFR2 + frag) * 64 + lane] = f;
 }
 
 template <int DROP, bool F16, bool NEEDW>  // DROP: 0 off, 1 byte mode, 2 bit mode (see common.h)
-__global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
+__global__ __launch_bounds__(256, 1) void edge_bwd_v1_kernel(const MpgEdgeBwd p) {
     typedef typename FragT<F16>::type V;  // forward-recomputation operands; gradient operands are bf16
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     float* lb2 = reinterpret_cast<float*>(smem + BWD_W_BYTES + BWD_DG_BYTES + BWD_A_BYTES);
     float* lc = lb2 + H2;
     copy_to_lds(l3thi, t3g, 2 * NF3T * 64, tid);
-    for (int t = tid; t < H2; t += 256) lb2[t] = p.b2[t];
+    for (int t = tid; t < H2; t += 256) lb2[t] = p.b2[t] * SC_E2;
     // per-receiver tiles shared by the four waves: upstream gradient dagg (scaled) and the layer-1
     // receiver term a, both in the register order the chain layout wants (zeros for padding lanes)
     for (int t = tid; t < T3 * 4 * 64; t += 256) {
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
         const int ln = t & 63, qsu = t >> 6, rr = ln & 31, hh = ln >> 5, ii = rb * 32 + rr;
         float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ii < p.N) v4 = ld4(p.a + (size_t)(b * p.N + ii) * (p.ld_ac ? p.ld_ac : H1) + 8 * qsu + 4 * hh);
-        la[t] = v4;
+        la[t] = make_float4(v4.x * SC_A, v4.y * SC_A, v4.z * SC_A, v4.w * SC_A);
     }
 
     uint32_t seed_lo = 0, seed_hi = 0;
@@ -105,8 +106,10 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     for (int j0 = jbeg; j0 < jend; j0 += BWD_C_SLOTS) {
     const int j1 = min(jend, j0 + BWD_C_SLOTS);
     __syncthreads();
-    for (int t = tid; t < (j1 - j0) * (H1 / 4); t += 256)
-        reinterpret_cast<float4*>(lc)[t] = ld4(p.c + (size_t)(b * p.N + j0 + t / (H1 / 4)) * (p.ld_ac ? p.ld_ac : H1) + 4 * (t % (H1 / 4)));
+    for (int t = tid; t < (j1 - j0) * (H1 / 4); t += 256) {
+        const float4 c4 = ld4(p.c + (size_t)(b * p.N + j0 + t / (H1 / 4)) * (p.ld_ac ? p.ld_ac : H1) + 4 * (t % (H1 / 4)));
+        reinterpret_cast<float4*>(lc)[t] = make_float4(c4.x * SC_A, c4.y * SC_A, c4.z * SC_A, c4.w * SC_A);
+    }
     __syncthreads();
     for (int j = j0 + w; j < j1; j += 4) {
         const float mj = p.mask ? p.mask[b * p.N + j] : 1.f;
@@ -150,10 +153,11 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             constexpr int KS = T1 * 2, TOT = T2 * KS, PF = MPG_PF;
             V rh[PF + 1], rl[PF + 1];
 #pragma unroll
-            for (int k = 0; k < PF; ++k) { rh[k] = img_frag<V>(r2, lane16, k); rl[k] = img_frag<V>(r2, lane16, NF2 + k); }
+            for (int k = 0; k < PF; ++k) { rh[k] = img_frag<V>(r2, lane16, (MPG_BEXP & 1) ? 0 : k); rl[k] = img_frag<V>(r2, lane16, NF2 + ((MPG_BEXP & 1) ? 0 : k)); }
             f32x16 accs[2];
             float v2[16];
             auto epi2 = [&](int mm, int g) {
+                if (MPG_BEXP & 32) { if (g == 1 || g == 3) { e2hi[mm][g >> 1] = e1hi[mm % T1][g >> 1]; e2lo[mm][g >> 1] = e1lo[mm % T1][g >> 1]; } return; }
                 const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E1, erow, mm, 2 * g + h, h);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                 if (g == 1 || g == 3) {
                     const int s = g >> 1;
                     split8(v2 + 8 * s, e2hi[mm][s], e2lo[mm][s]);
-                    if (NEEDW) {
+                    if (NEEDW && !(MPG_BEXP & 2)) {
                         stage_frag(p.stageE2, blk, 0, mm * 2 + s, lane, e2hi[mm][s]);
                         stage_frag(p.stageE2, blk, 1, mm * 2 + s, lane, e2lo[mm][s]);
                     }
@@ -171,8 +175,8 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             for (int kk = 0; kk < TOT; ++kk) {
                 const int m = kk / KS, k = kk % KS;
                 if (kk + PF < TOT) {
-                    rh[(kk + PF) % (PF + 1)] = img_frag<V>(r2, lane16, kk + PF);
-                    rl[(kk + PF) % (PF + 1)] = img_frag<V>(r2, lane16, NF2 + kk + PF);
+                    rh[(kk + PF) % (PF + 1)] = img_frag<V>(r2, lane16, (MPG_BEXP & 1) ? 0 : kk + PF);
+                    rl[(kk + PF) % (PF + 1)] = img_frag<V>(r2, lane16, NF2 + ((MPG_BEXP & 1) ? 0 : kk + PF));
                 }
                 f32x16& acc = accs[m & 1];
                 if (k == 0) {
@@ -192,7 +196,12 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
 
         // ---- dZ3 = m_j * dagg * keep3 * phi'(Z3), phi' from the forward's sign words
         bf16x8 z3hi[T3][2], z3lo[T3][2];
-        {
+        if (MPG_BEXP & 4) {
+#pragma unroll
+            for (int m = 0; m < T3; ++m)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) { z3hi[m][s] = __builtin_bit_cast(bf16x8, e2hi[m % T2][s]); z3lo[m][s] = __builtin_bit_cast(bf16x8, e2lo[m % T2][s]); }
+        } else {
             const int slope_pos = __builtin_bit_cast(int, mjs), slope_neg = __builtin_bit_cast(int, mjs * p.alpha);
 #pragma unroll
             for (int m = 0; m < T3; ++m) {
@@ -225,6 +234,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             for (int m = 0; m <= T2; ++m) {
                 const int mm = m - 1;
                 auto epi4 = [&](int g) {
+                    if (MPG_BEXP & 8) { if (g == 1 || g == 3) { z2hi[mm][g >> 1] = z3hi[mm][g >> 1]; z2lo[mm][g >> 1] = z3lo[mm][g >> 1]; } return; }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int k = 4 * g + t;
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                     if (g == 1 || g == 3) {
                         const int s = g >> 1;
                         split8(v2 + 8 * s, z2hi[mm][s], z2lo[mm][s]);
-                        if (NEEDW) {
+                        if (NEEDW && !(MPG_BEXP & 2)) {
                             stage_frag(p.stageZ2, blk, 0, mm * 2 + s, lane, z2hi[mm][s]);
                             stage_frag(p.stageZ2, blk, 1, mm * 2 + s, lane, z2lo[mm][s]);
                         }
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             constexpr int KS = T2 * 2, TOT = T1 * KS, PF = MPG_PF;
             bf16x8 rh[PF + 1], rl[PF + 1];
 #pragma unroll
-            for (int k = 0; k < PF; ++k) { rh[k] = img_frag<bf16x8>(r2t, lane16, k); rl[k] = img_frag<bf16x8>(r2t, lane16, NF2T + k); }
+            for (int k = 0; k < PF; ++k) { rh[k] = img_frag<bf16x8>(r2t, lane16, (MPG_BEXP & 1) ? 0 : k); rl[k] = img_frag<bf16x8>(r2t, lane16, NF2T + ((MPG_BEXP & 1) ? 0 : k)); }
             f32x16 accs[2];
             // dc_j = sum over the 32 receivers (lanes of one half) of dZ1: 16 values per tile and lane.  Halving
             // reduction: at each step a lane keeps half of its values and hands the other half to its partner
@@ -279,6 +289,11 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             float ured[4];
             auto epi5 = [&](int mm, int su) {  // slice (s,u) of tile mm
                 const int s = su >> 1, u = su & 1;
+                if (MPG_BEXP & 16) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dacc[mm][s][4 * u + t] += accs[mm & 1][8 * s + 4 * u + t];
+                    return;
+                }
                 const float4 c4 = ld4(cj + 32 * mm + 16 * s + 8 * u + 4 * h);
                 const float4 a4 = la[((mm * 2 + s) * 2 + u) * 64 + lane];
                 const float cc[4] = {c4.x + a4.x, c4.y + a4.y, c4.z + a4.z, c4.w + a4.w};
@@ -306,8 +321,8 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             for (int kk = 0; kk < TOT; ++kk) {
                 const int m = kk / KS, k = kk % KS;
                 if (kk + PF < TOT) {
-                    rh[(kk + PF) % (PF + 1)] = img_frag<bf16x8>(r2t, lane16, kk + PF);
-                    rl[(kk + PF) % (PF + 1)] = img_frag<bf16x8>(r2t, lane16, NF2T + kk + PF);
+                    rh[(kk + PF) % (PF + 1)] = img_frag<bf16x8>(r2t, lane16, (MPG_BEXP & 1) ? 0 : kk + PF);
+                    rl[(kk + PF) % (PF + 1)] = img_frag<bf16x8>(r2t, lane16, NF2T + ((MPG_BEXP & 1) ? 0 : kk + PF));
                 }
                 f32x16& acc = accs[m & 1];
                 if (k == 0) {
@@ -749,7 +764,7 @@ __global__ __launch_bounds__(512, 1) void edge_dw_kernel(const MpgEdgeDw p) {
 
 // out = scale * sum over workgroup partials, feature indices mapped back from fragment order.
 // 32 outputs x 8 partial-slices per block: the 256 partials of an output are read by 8 threads.
-__global__ __launch_bounds__(256) void edge_dw_reduce(const float* __restrict__ part, int nwg, float scale, int accumulate,
+__global__ __launch_bounds__(256) void edge_dw_reduce(const float* __restrict__ part, int nwg, float scale3, float scale, int accumulate,
                                                       float* __restrict__ dW3, float* __restrict__ dW2,
                                                       float* __restrict__ db3, float* __restrict__ db2) {
     __shared__ float red[8][32];
@@ -767,7 +782,7 @@ __global__ __launch_bounds__(256) void edge_dw_reduce(const float* __restrict__ 
     if (idx < H3 * H2) {
         const int r3 = idx / H2, c2 = idx % H2;
         float* d = dW3 + feat_of_fi(r3) * H2 + feat_of_fi(c2);
-        *d = s * scale + (accumulate ? *d : 0.f);
+        *d = s * scale3 + (accumulate ? *d : 0.f);
     } else if (idx < H3 * H2 + H2 * H1) {
         const int k = idx - H3 * H2, r2 = k / H1, c1 = k % H1;
         float* d = dW2 + feat_of_fi(r2) * H1 + feat_of_fi(c1);
@@ -783,7 +798,8 @@ __global__ __launch_bounds__(256) void edge_dw_reduce(const float* __restrict__ 
 
 }  // namespace
 
-extern "C" int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream) {
+// first-generation data-gradient kernel (one sender per wave and pass): kept for A/B timing in tools/ubench only
+extern "C" int mpg_edge_bwd_v1(const MpgEdgeBwd* p, void* stream) {
     if (p->B <= 0 || p->N <= 0 || p->SC <= 0) return -1;
     if (p->sign3 == nullptr) return -3;
     if (!(p->alpha >= 0.f && p->alpha <= 1.f)) return -4;
@@ -794,8 +810,8 @@ extern "C" int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream) {
     const int dm = p->thr == 0 ? 0 : (p->thr == 128 ? 2 : 1);
 #define MPG_BWD_ONE(D, H, W)                                                                                      \
     do {                                                                                                          \
-        MPG_ENSURE_LDS((edge_bwd_kernel<D, H, W>), BWD_LDS_BYTES);                                                \
-        hipLaunchKernelGGL((edge_bwd_kernel<D, H, W>), grid, block, BWD_LDS_BYTES, st, *p);                       \
+        MPG_ENSURE_LDS((edge_bwd_v1_kernel<D, H, W>), BWD_LDS_BYTES);                                                \
+        hipLaunchKernelGGL((edge_bwd_v1_kernel<D, H, W>), grid, block, BWD_LDS_BYTES, st, *p);                       \
     } while (0)
 #define MPG_BWD_W(D, H)                                                                                           \
     do { if (needw) MPG_BWD_ONE(D, H, true); else MPG_BWD_ONE(D, H, false); } while (0)
@@ -839,7 +855,8 @@ extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
 #undef MPG_DW_H
 #undef MPG_DW_ONE
     constexpr int PER = H3 * H2 + H2 * H1 + H3 + H2;
-    hipLaunchKernelGGL(edge_dw_reduce, dim3((PER + 31) / 32), dim3(256), 0, st, p->part, p->nwg, p->dscale, p->accumulate, p->dW3,
+    // (the staged E2 carries the forward's operand scale SC_E2)
+    hipLaunchKernelGGL(edge_dw_reduce, dim3((PER + 31) / 32), dim3(256), 0, st, p->part, p->nwg, p->dscale / SC_E2, p->dscale, p->accumulate, p->dW3,
                        p->dW2, p->db3, p->db2);
     return (int)hipGetLastError();
 }

@@ -92,6 +92,19 @@ MPG_DEV void tile_chain(f32x16& acc, const V (*bhi)[2], const V (*blo)[2], LH lo
     }
 }
 
+// Power-of-two operand scales of the FORWARD products (and their recomputation in the backward).  An fp16 hi/lo pair
+// carries 22 significand bits only while lo = x - hi stays a normal fp16 number, i.e. for |x| >= 2^-3; below that lo
+// is subnormal and the pair's absolute error is stuck at 2^-25 -- for weights of ~0.05 that is 10x the error of
+// fp32, enough to flip the sign of near-zero pre-activations (LeakyReLU kinks) measurably more often than fp32
+// does.  Scaling by a power of two is exact, so: layer-1 terms a, c carry SC_A, the W2 image SC_W2, the W3 image
+// SC_W3; LeakyReLU is positively homogeneous, so e1 carries SC_A, e2 SC_A*SC_W2 (= SC_E2) and the layer-3 output
+// SC_E2*SC_W3 (= SC_E3), which the aggregation folds into m_j * dscale.  (fp16 range: e1 < 16k, e2 < 1k, weights < 1k.)
+constexpr float SC_A = 4.f, SC_W2 = 16.f, SC_W3 = 64.f, SC_E2 = SC_A * SC_W2, SC_E3 = SC_E2 * SC_W3;
+
+constexpr int NF3T = T2 * T3 * 2;  // W3^T image: 5 row tiles x 6 k-tiles x 2 = 60 fragments
+constexpr int NF2T = T1 * T2 * 2;  // W2^T image: 3 x 5 x 2 = 30
+constexpr int NFR2 = T2 * 2;       // B-operand fragments of a 160-feature tensor
+
 // LDS plan of the forward kernel: W3 hi | W3 lo | W2 hi  (W2 lo streams from L2)
 constexpr int NF2 = T2 * T1 * 2;  // 30 fragments of 1 KiB
 constexpr int NF3 = T3 * T2 * 2;  // 60

@@ -1,0 +1,218 @@
+// The small per-jet pieces around the message-passing layers, one launch each instead of a dozen elementwise ATen
+// kernels (the "glue" of an iteration):
+//   mpg_rank_mask        MPGenerator._get_mask, mask_c branch (mpgan/model.py:689-699): the n = int(label * N)
+//                        lowest-noise particles of a jet are real
+//   mpg_gen_tail_fwd/bwd MPNet._final_activation (tanh, :533-538) + MPGenerator._final_mask (:741-757): the
+//                        generator's output rows (tanh(y) | mask - 0.5), written wherever the caller wants them
+//                        (e.g. straight into the second half of the discriminator's real+generated batch)
+//   mpg_disc_head_fwd/bwd MPDiscriminator._post_mp (masked sum / mean pooling, :812-829) + fnd_layer (one Linear
+//                        + Dropout) + the final sigmoid -- and, when a loss is named, the per-jet loss terms of
+//                        calc_D_loss / calc_G_loss (train.py:331-395, :465-476) with their gradient, so that the
+//                        backward starts from the last MPLayer's output without any autograd node in between
+#include "common.h"
+#include "../../include/mpgan_amd.h"
+
+namespace {
+
+// rank of particle i among its jet's first features (ties by index) by counting; one workgroup per jet
+__global__ __launch_bounds__(256) void rank_mask_kernel(const float* __restrict__ x, int ld_jet, int ld_part,
+                                                        const float* __restrict__ labels, int ld_lab, int N,
+                                                        float* __restrict__ mask) {
+    extern __shared__ float xs[];
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) xs[i] = x[(size_t)b * ld_jet + (size_t)i * ld_part];
+    __syncthreads();
+    const int n_minus_1 = (int)(labels[(size_t)b * ld_lab] * (float)N) - 1;  // (labels * N).int() - 1
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const float xi = xs[i];
+        int rank = 0;
+        for (int j = 0; j < N; ++j) {
+            const float xj = xs[j];
+            rank += (xj < xi) || (xj == xi && j < i);
+        }
+        mask[(size_t)b * N + i] = rank <= n_minus_1 ? 1.f : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void gen_tail_fwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ mask,
+                                                           float* __restrict__ out, int ldo, int V, int F, int act) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    for (int f = 0; f < F; ++f) {
+        const float t = y[(size_t)v * ldy + f];
+        out[(size_t)v * ldo + f] = act == 1 ? tanhf(t) : (act == 2 ? 1.f / (1.f + expf(-t)) : t);
+    }
+    if (mask != nullptr) out[(size_t)v * ldo + F] = mask[v] - 0.5f;
+}
+
+__global__ __launch_bounds__(256) void gen_tail_bwd_kernel(const float* __restrict__ dout, int ldd, const float* __restrict__ out, int ldo,
+                                                           float* __restrict__ dy, int ldy, int V, int F, int act) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    for (int f = 0; f < F; ++f) {
+        const float o = out[(size_t)v * ldo + f], g = dout[(size_t)v * ldd + f];
+        dy[(size_t)v * ldy + f] = act == 1 ? g * (1.f - o * o) : (act == 2 ? g * o * (1.f - o) : g);
+    }
+}
+
+// one wave per jet; lane = (particle parity, feature) for F <= 32, features looped beyond
+MPG_DEV float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+__global__ __launch_bounds__(256) void disc_head_fwd_kernel(const MpgDiscHead p) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= p.B) return;
+    const float* yb = p.y + (size_t)b * p.N * p.ldy;
+    float z = 0.f, msum = 0.f;
+    for (int f0 = 0; f0 < p.F; f0 += 32) {
+        const int f = f0 + (lane & 31);
+        float acc = 0.f;
+        if (f < p.F)
+            for (int i = lane >> 5; i < p.N; i += 2) acc += (p.mask ? p.mask[(size_t)b * p.N + i] : 1.f) * yb[(size_t)i * p.ldy + f];
+        acc += __shfl_xor(acc, 32, 64);              // both particle parities
+        if (p.pooled != nullptr && lane < 32 && f < p.F) p.pooled[(size_t)b * p.F + f] = acc;   // (un-normalised sum)
+        z += (lane < 32 && f < p.F) ? acc * p.w[f] : 0.f;
+    }
+    if (p.mean) {
+        for (int i = lane; i < p.N; i += 64) msum += p.mask ? p.mask[(size_t)b * p.N + i] : 1.f;
+        msum = wave_sum(msum);
+    }
+    z = wave_sum(z);
+    const float pool_scale = p.mean ? 1.f / (p.mask ? msum + 1e-12f : (float)p.N) : 1.f;
+    z = z * pool_scale + (p.bias ? p.bias[0] : 0.f);
+    float keep = 1.f;
+    if (p.thr) {
+        const uint64_t sd = *p.seed;
+        keep = drop_keep_f((uint32_t)sd, (uint32_t)(sd >> 32), p.tag, (uint32_t)b, 0, p.thr) ? p.dscale : 0.f;
+    }
+    z *= keep;
+    const float out = p.sigmoid ? 1.f / (1.f + expf(-z)) : z;
+    if (lane == 0) {
+        p.out[b] = out;
+        if (p.aux != nullptr) { p.aux[2 * b] = keep * pool_scale; p.aux[2 * b + 1] = 0.f; }
+    }
+}
+
+// dL/dout of jet b for the named loss (and its loss term); t = 1 for a jet scored against the "real" target
+MPG_DEV float loss_grad(int loss, float out, float t, float& term) {
+    switch (loss) {
+    case 0: term = (out - t) * (out - t); return 2.f * (out - t);                       // ls: mse
+    case 1: {                                                                           // og: nn.BCELoss
+        const float l1 = fmaxf(logf(out), -100.f), l0 = fmaxf(logf(1.f - out), -100.f);
+        term = -(t * l1 + (1.f - t) * l0);
+        return (out - t) / fmaxf((1.f - out) * out, 1e-12f);                            // (torch's backward formula)
+    }
+    case 2: term = t > 0.5f ? -out : out; return t > 0.5f ? -1.f : 1.f;                 // w
+    default: {                                                                          // hinge (D); G uses the w form
+        const float s = t > 0.5f ? -1.f : 1.f, m = 1.f + s * out;
+        term = fmaxf(m, 0.f);
+        return m > 0.f ? s : 0.f;
+    }
+    }
+}
+
+__global__ __launch_bounds__(256) void disc_head_bwd_kernel(const MpgDiscHead p) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= p.B) return;
+    const float out = p.out[b];
+    float g;  // dL/dout
+    if (p.loss >= 0) {
+        // D step: jets [0, n_real) are scored against 1, the rest against 0 (hinge: margins); G step (n_real = B with
+        // loss_g): every jet against 1, hinge in its generator form (= w)
+        const float t = b < p.n_real ? 1.f : 0.f;
+        float term;
+        g = loss_grad((p.gen_step && p.loss == 3) ? 2 : p.loss, out, t, term) * p.inv_count;
+        if (lane == 0) p.terms[b] = term * p.inv_count;
+    } else {
+        g = p.gout[b];
+    }
+    const float gz = g * (p.sigmoid ? out * (1.f - out) : 1.f);        // through the sigmoid
+    const float gp = gz * p.aux[2 * b];                                // through dropout and the pooling normalisation
+    if (lane == 0) p.aux[2 * b + 1] = gz * (p.aux[2 * b] != 0.f ? (p.thr ? p.dscale : 1.f) : 0.f);  // d/d(pre-dropout z): for db, dw
+    if (p.dy == nullptr) return;
+    float* db_ = p.dy + (size_t)b * p.N * p.ld_dy;
+    for (int f0 = 0; f0 < p.F; f0 += 32) {
+        const int f = f0 + (lane & 31);
+        if (f >= p.F) continue;
+        const float wf = p.w[f] * gp;
+        for (int i = lane >> 5; i < p.N; i += 2) db_[(size_t)i * p.ld_dy + f] = (p.mask ? p.mask[(size_t)b * p.N + i] : 1.f) * wf;
+    }
+}
+
+// one workgroup: the loss value (sum of the per-jet terms, fixed order) and the head's own parameter gradients
+__global__ __launch_bounds__(256) void disc_head_reduce_kernel(const MpgDiscHead p) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    if (p.loss >= 0 && p.loss_out != nullptr) {
+        float s = 0.f;
+        for (int b = tid; b < p.B; b += 256) s += p.terms[b];
+        red[tid] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+        if (tid == 0) *p.loss_out = red[0];
+        __syncthreads();
+    }
+    if (p.dw == nullptr) return;
+    // dw_f = sum_b gzpre_b * pool_scale_b * pooled[b, f] ;  db = sum_b gzpre_b
+    for (int f = tid >> 3; f <= p.F; f += 32) {   // 8 threads per output (f == F: the bias)
+        float s = 0.f;
+        for (int b = tid & 7; b < p.B; b += 8) {
+            const float gzp = p.aux[2 * b + 1];
+            if (f < p.F) {
+                const float ps = p.aux[2 * b] != 0.f ? p.aux[2 * b] / (p.thr ? p.dscale : 1.f) : 0.f;   // pooling normalisation alone
+                s += gzp * ps * p.pooled[(size_t)b * p.F + f];
+            } else {
+                s += gzp;
+            }
+        }
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        if ((tid & 7) == 0) {
+            if (f < p.F) p.dw[f] = s + (p.accumulate ? p.dw[f] : 0.f);
+            else if (p.db != nullptr) p.db[0] = s + (p.accumulate ? p.db[0] : 0.f);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mpg_rank_mask(const float* x, int ld_jet, int ld_part, const float* labels, int ld_lab, int B, int N,
+                             float* mask, void* stream) {
+    if (B <= 0 || N <= 0 || N > 8192) return -1;
+    hipLaunchKernelGGL(rank_mask_kernel, dim3(B), dim3(N <= 64 ? 64 : 256), N * sizeof(float), (hipStream_t)stream, x, ld_jet, ld_part,
+                       labels, ld_lab, N, mask);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mpg_gen_tail_fwd(const float* y, int ldy, const float* mask, float* out, int ldo, int V, int F, int act,
+                                void* stream) {
+    if (V <= 0 || F <= 0) return -1;
+    hipLaunchKernelGGL(gen_tail_fwd_kernel, dim3((V + 255) / 256), dim3(256), 0, (hipStream_t)stream, y, ldy, mask, out, ldo, V, F, act);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mpg_gen_tail_bwd(const float* dout, int ldd, const float* out, int ldo, float* dy, int ldy, int V, int F,
+                                int act, void* stream) {
+    if (V <= 0 || F <= 0) return -1;
+    hipLaunchKernelGGL(gen_tail_bwd_kernel, dim3((V + 255) / 256), dim3(256), 0, (hipStream_t)stream, dout, ldd, out, ldo, dy, ldy, V, F, act);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mpg_disc_head_fwd(const MpgDiscHead* p, void* stream) {
+    if (p->B <= 0 || p->N <= 0 || p->F <= 0 || p->out == nullptr || p->aux == nullptr) return -1;
+    hipLaunchKernelGGL(disc_head_fwd_kernel, dim3((p->B + 3) / 4), dim3(256), 0, (hipStream_t)stream, *p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mpg_disc_head_bwd(const MpgDiscHead* p, void* stream) {
+    if (p->B <= 0 || p->N <= 0 || p->F <= 0 || p->out == nullptr || p->aux == nullptr) return -1;
+    if (p->loss >= 0 ? p->terms == nullptr : p->gout == nullptr) return -2;
+    if (p->dw != nullptr && p->pooled == nullptr) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(disc_head_bwd_kernel, dim3((p->B + 3) / 4), dim3(256), 0, st, *p);
+    if ((p->loss >= 0 && p->loss_out != nullptr) || p->dw != nullptr)
+        hipLaunchKernelGGL(disc_head_reduce_kernel, dim3(1), dim3(256), 0, st, *p);
+    return (int)hipGetLastError();
+}

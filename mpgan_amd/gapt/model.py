@@ -153,13 +153,32 @@ class GAPT_G(nn.Module):
         self.final_fc = LinearNet(final_fc_layers, input_size=embed_dim, output_size=output_feat_size,
                                   final_linear=True, **linear_args)
 
+    def _mask(self, x, labels):
+        if not self.use_mask:
+            return None
+        if x.is_cuda:
+            return ops.rank_mask(x[:, :, 0], labels, self.num_particles).unsqueeze(2)
+        return _rank_mask(x[:, :, 0], labels, self.num_particles)
+
     def forward(self, x: Tensor, labels: Tensor = None):
-        mask = _rank_mask(x[:, :, 0], labels, self.num_particles) if self.use_mask else None
+        mask = self._mask(x, labels)
         am = _attn_mask(mask)
         for sab in self.sabs:
             x = sab(x, am)
-        x = torch.tanh(self.final_fc(x))
+        x = self.final_fc(x)
+        if x.is_cuda:  # tanh + the (mask - 0.5) column in one launch each way
+            return ops.GenTailFn.apply(x, mask, ops.ACT_CODES["tanh"])
+        x = torch.tanh(x)
         return torch.cat((x, mask - 0.5), dim=2) if mask is not None else x
+
+    def generate_into(self, x: Tensor, labels: Tensor, out: Tensor) -> Tensor:
+        """``forward`` into caller-owned output rows, no gradient (``train.TrainStep``'s D step)."""
+        assert not torch.is_grad_enabled() and x.is_cuda
+        mask = self._mask(x, labels)
+        am = _attn_mask(mask)
+        for sab in self.sabs:
+            x = sab(x, am)
+        return ops.gen_tail_into(self.final_fc(x), mask, ops.ACT_CODES["tanh"], out)
 
 
 class GAPT_D(nn.Module):
@@ -179,7 +198,16 @@ class GAPT_D(nn.Module):
         self.final_fc = LinearNet(final_fc_layers, input_size=embed_dim, output_size=1, final_linear=True,
                                   **linear_args)
 
-    def forward(self, x: Tensor, labels: Tensor = None):
+    def fused_head(self):
+        """(weight [1, E], bias, mean?, sigmoid?, dropout p) of ``final_fc`` + sigmoid as ``ops.DiscHeadFn`` (with
+        N = 1 "particles": the pooled seed), when ``final_fc`` is a single Linear; else None."""
+        if len(self.final_fc.net) != 1:
+            return None
+        lin = self.final_fc.net[0]
+        return lin.weight, lin.bias, False, True, self.final_fc.dropout_p
+
+    def features(self, x: Tensor, labels: Tensor = None):
+        """Everything up to the pooled seed: ([B, 1, E], None)."""
         mask = None
         if self.use_mask:
             mask = x[..., -1:] + 0.5
@@ -188,5 +216,13 @@ class GAPT_D(nn.Module):
         x = self.input_embedding(x.contiguous())
         for sab in self.sabs:
             x = sab(x, am)
-        pooled = self.pma(x, am)
-        return torch.sigmoid(self.final_fc(pooled.squeeze()))  # .squeeze() as the reference (:344)
+        return self.pma(x, am), None
+
+    def forward(self, x: Tensor, labels: Tensor = None):
+        pooled, _ = self.features(x, labels)
+        head = self.fused_head() if pooled.is_cuda else None
+        if head is None:
+            return torch.sigmoid(self.final_fc(pooled.squeeze()))  # .squeeze() as the reference (:344)
+        w, b, mean, sigmoid, p = head
+        out = ops.DiscHeadFn.apply(pooled, None, w, b, mean, sigmoid, p, self.training)
+        return out.unsqueeze(1) if out.shape[0] > 1 else out   # shapes of the reference's .squeeze() path

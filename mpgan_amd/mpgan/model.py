@@ -147,6 +147,10 @@ class MPNet(nn.Module):
         for layer in self.mp_layers:
             x = layer(x, use_mask, mask, labels, njp)
         x = self._post_mp(x, labels, use_mask, mask, njp)
+        return self._finish(x, mask)
+
+    def _finish(self, x, mask):
+        """Final activation (reference ``_final_activation``, :533-538) and ``_final_mask``."""
         if self.final_activation == "tanh":
             x = torch.tanh(x)
         elif self.final_activation == "sigmoid":
@@ -206,7 +210,25 @@ class MPGenerator(MPNet):
                   mask_fne_np=False, **mask_args):
         if not mask_c:
             return x, False, None, None
+        if x.is_cuda:  # one launch (ops.rank_mask) instead of the comparison / sum / compare chain below
+            return x, True, ops.rank_mask(x[:, :, 0], labels, self.num_particles).unsqueeze(2), None
         return x, True, _rank_mask(x[:, :, 0], labels, self.num_particles), None
+
+    def _finish(self, x, mask):
+        if x.is_cuda and self.final_activation in ops.ACT_CODES and not self.mask_args.get("mask_feat_bin", False):
+            # tanh + the (mask - 0.5) column in one launch each way
+            return ops.GenTailFn.apply(x, mask, ops.ACT_CODES[self.final_activation])
+        return super()._finish(x, mask)
+
+    def generate_into(self, x: Tensor, labels: Tensor, out: Tensor) -> Tensor:
+        """``forward`` for callers that own the output rows (``out`` [B, N, F+1], e.g. the second half of a
+        discriminator batch) and need no gradient: ``train.TrainStep``'s D step and bulk generation."""
+        assert not torch.is_grad_enabled() and x.is_cuda
+        x = self._pre_mp(x, labels)
+        x, use_mask, mask, njp = self._get_mask(x, labels, **self.mask_args)
+        for layer in self.mp_layers:
+            x = layer(x, use_mask, mask, labels, njp)
+        return ops.gen_tail_into(x, mask, ops.ACT_CODES[self.final_activation], out)
 
     def _final_mask(self, x, mask, mask_feat_bin: bool = False, **mask_args):
         _unsupported(mask_feat_bin=mask_feat_bin)
@@ -232,6 +254,30 @@ class MPDiscriminator(MPNet):
         if not (mask_manual or mask_learn or mask_c or mask_learn_sep):
             return x, False, None, None
         return x[:, :, :-1], True, x[:, :, -1:] + 0.5, None
+
+    def fused_head(self):
+        """(weight [1, F], bias, mean-pooling?, sigmoid?, dropout p) when pooling + ``fnd_layer`` + final activation are
+        the single-launch head of ``ops.DiscHeadFn`` (``dea`` with an empty ``fnd`` list: the reference default), else None."""
+        if not self.dea or len(self.fnd_layer.net) != 1 or self.final_activation not in ("", "sigmoid"):
+            return None
+        lin = self.fnd_layer.net[0]
+        return lin.weight, lin.bias, not self.dea_sum, self.final_activation == "sigmoid", self.fnd_layer.dropout_p
+
+    def features(self, x: Tensor, labels: Tensor = None):
+        """The message-passing part of ``forward``: (last layer's node features [B, N, F], mask [B, N, 1] or None)."""
+        x = self._pre_mp(x, labels)
+        x, use_mask, mask, njp = self._get_mask(x, labels, **self.mask_args)
+        for layer in self.mp_layers:
+            x = layer(x, use_mask, mask, labels, njp)
+        return x, (mask if use_mask else None)
+
+    def forward(self, x: Tensor, labels: Tensor = None) -> Tensor:
+        head = self.fused_head() if x.is_cuda else None
+        if head is None:
+            return super().forward(x, labels)
+        y, mask = self.features(x, labels)
+        w, b, mean, sigmoid, p = head
+        return ops.DiscHeadFn.apply(y, mask, w, b, mean, sigmoid, p, self.training).unsqueeze(1)
 
     def _post_mp(self, x, labels, use_mask, mask, num_jet_particles):
         mean = not (self.dea and self.dea_sum)

@@ -18,6 +18,10 @@ from . import _lib
 from ._lib import MpgGemm, MpgEdgeFwd, MpgEdgeBwd, MpgEdgeDw, MpgPackJob, MpgChain, MpgReduceJob, check
 
 H1, H2, H3 = 96, 160, 192
+# Exact power-of-two operand scales of the forward products (csrc/edge_common.h): fp16 hi/lo pairs keep their 22 bits
+# only for |x| >= 2^-3, so the forward images hold SC * W and the activations are split as ascale * x.
+SC_W2, SC_W3 = 16.0, 64.0          # = SC_W2 / SC_W3 of csrc/edge_common.h
+SC_WN, SC_ACT = 64.0, 8.0          # node-network (mpg_chain) images / activations
 TAG_E0, TAG_E1, TAG_E2, TAG_N0, TAG_N1, TAG_N2, TAG_GENERIC = 1, 2, 3, 4, 5, 6, 7
 
 # ------------------------------------------------------------------------------------- state
@@ -306,13 +310,13 @@ class PackedMPLayer:
         KN = H3 + F
         # name: (W, packed rows, packed cols, transpose, scale, f16, row_split, split_cols)
         spec = {
-            "W2": (W2, H2, H1, 0, dscale, f16, 0, 0), "W3": (W3, H3, H2, 0, dscale, f16, 0, 0),
+            "W2": (W2, H2, H1, 0, dscale * SC_W2, f16, 0, 0), "W3": (W3, H3, H2, 0, dscale * SC_W3, f16, 0, 0),
             "W3T": (W3, H2, H3, 1, dscale, False, 0, 0), "W2T": (W2, H1, H2, 1, dscale, False, 0, 0),
-            "V1": (V1, V1.shape[0], KN, 0, 1.0, f16, 0, 0), "V2": (V2, V2.shape[0], V2.shape[1], 0, 1.0, f16, 0, 0),
-            "V3": (V3, out, V3.shape[1], 0, 1.0, f16, 0, 0),
+            "V1": (V1, V1.shape[0], KN, 0, SC_WN, f16, 0, 0), "V2": (V2, V2.shape[0], V2.shape[1], 0, SC_WN, f16, 0, 0),
+            "V3": (V3, out, V3.shape[1], 0, SC_WN, f16, 0, 0),
             "V3T": (V3, V3.shape[1], out, 1, 1.0, False, 0, 0), "V2T": (V2, V2.shape[1], V2.shape[0], 1, 1.0, False, 0, 0),
             "V1T": (V1, KN, V1.shape[0], 1, 1.0, False, 0, 0),
-            "W1S": (W1, 2 * H1, F, 0, 1.0, f16, H1, F),          # [a-half ; c-half] of fe.net.0.weight
+            "W1S": (W1, 2 * H1, F, 0, SC_WN, f16, H1, F),        # [a-half ; c-half] of fe.net.0.weight
             "W1ST": (W1, F, 2 * H1, 1, 1.0, False, H1, F),
         }
         self.img = {k: torch.empty((_img_elems(v[1], v[2]),), device=dev, dtype=torch.bfloat16) for k, v in spec.items()}
@@ -341,9 +345,9 @@ class PackedMPLayer:
 
 
 def chain(M, layers, *, A, lda, K1, A2=None, lda2=0, a_slabs=1, a_slab_stride=0, in_gate=None, in_out=None,
-          alpha=0.2, seed_t=None, f16=False):
+          alpha=0.2, seed_t=None, f16=False, ascale=1.0):
     """mpg_chain front-end.  ``layers``: dicts with img, K, N and optionally bias, nbias, act, drop=(tag,thr,scale),
-    gate=(H, act, tag, thr, scale), out (tensor [M, >=N])."""
+    gate=(H, act, tag, thr, scale), out (tensor [M, >=N]), wscale (the image holds wscale * W)."""
     c = MpgChain()
     c.A, c.lda, c.K1 = _p(A), lda, K1
     c.A2, c.lda2 = _p(A2), lda2
@@ -353,9 +357,11 @@ def chain(M, layers, *, A, lda, K1, A2=None, lda2=0, a_slabs=1, a_slab_stride=0,
     if in_out is not None:
         c.in_out, c.ld_in_out = _p(in_out), in_out.stride(0)
     c.M, c.nlayers, c.alpha, c.seed, c.f16 = M, len(layers), alpha, _p(seed_t), int(f16)
+    c.ascale = ascale
     for i, d in enumerate(layers):
         L = c.L[i]
         L.Wimg, L.K, L.N = d["img"], d["K"], d["N"]
+        L.wscale = d.get("wscale", 1.0)
         L.bias, L.nbias, L.act = _p(d.get("bias")), d.get("nbias", 0), int(d.get("act", False))
         if d.get("drop") is not None and d["drop"][1]:
             L.drop_tag, L.drop_thr, L.drop_scale = d["drop"]
@@ -371,14 +377,20 @@ def chain(M, layers, *, A, lda, K1, A2=None, lda2=0, a_slabs=1, a_slab_stride=0,
     check(_lib.lib().mpg_chain(C.byref(c), _stream()), "mpg_chain")
 
 
+MAX_CHUNK_SENDERS = 188   # mpg_edge_bwd keeps the list of a chunk's unmasked senders in LDS (csrc/edge_bwd2.hip)
+
+
 def _sender_chunks(B, N):
     """Sender chunks per (jet, receiver block): 1 when those alone give every CU a workgroup (each
-    workgroup pays a 150 KiB LDS fill), else enough to cover the 256 CUs about twice."""
+    workgroup pays a 150 KiB LDS fill), else enough to cover the 256 CUs about twice; always enough that a
+    chunk holds at most MAX_CHUNK_SENDERS senders."""
     RB = (N + 31) // 32
     wg = B * RB
     sc = 1
     while wg * sc < 224 and (N + sc - 1) // sc > 8:
         sc *= 2
+    while (N + sc - 1) // sc > MAX_CHUNK_SENDERS:
+        sc += 1
     return sc
 
 
@@ -411,8 +423,8 @@ class FusedMPLayerFn(torch.autograd.Function):
 
         # layer-1 node terms a | c = x [W1a ; W1c]^T (+ b1 on the a half), one launch
         ac = torch.empty((V, 2 * H1), device=dev, dtype=torch.float32)
-        chain(V, [dict(img=pk.ptr("W1S"), K=F, N=2 * H1, bias=b1, nbias=H1, out=ac)], A=x2, lda=x2.stride(0), K1=F,
-              alpha=alpha, f16=f16)
+        chain(V, [dict(img=pk.ptr("W1S"), K=F, N=2 * H1, bias=b1, nbias=H1, out=ac, wscale=SC_WN)], A=x2, lda=x2.stride(0), K1=F,
+              alpha=alpha, f16=f16, ascale=SC_ACT)
         SC = _sender_chunks(B, N)
         aggp = torch.empty((SC, V, H3), device=dev, dtype=torch.float32)
         e = MpgEdgeFwd()
@@ -436,10 +448,10 @@ class FusedMPLayerFn(torch.autograd.Function):
         h1 = torch.empty((V, n1), device=dev, dtype=torch.float32)
         h2 = torch.empty((V, n2), device=dev, dtype=torch.float32)
         y = torch.empty((V, out_f), device=dev, dtype=torch.float32)
-        chain(V, [dict(img=pk.ptr("V1"), K=H3 + F, N=n1, bias=c1, act=True, drop=dr(TAG_N0), out=h1),
-                  dict(img=pk.ptr("V2"), K=n1, N=n2, bias=c2, act=True, drop=dr(TAG_N1), out=h2),
-                  dict(img=pk.ptr("V3"), K=n2, N=out_f, bias=c3, act=False, drop=dr(TAG_N2), out=y)],
-              A=agg, lda=H3, K1=H3, A2=x2, lda2=x2.stride(0), alpha=alpha, seed_t=seed_t, f16=f16)
+        chain(V, [dict(img=pk.ptr("V1"), K=H3 + F, N=n1, bias=c1, act=True, drop=dr(TAG_N0), out=h1, wscale=SC_WN),
+                  dict(img=pk.ptr("V2"), K=n1, N=n2, bias=c2, act=True, drop=dr(TAG_N1), out=h2, wscale=SC_WN),
+                  dict(img=pk.ptr("V3"), K=n2, N=out_f, bias=c3, act=False, drop=dr(TAG_N2), out=y, wscale=SC_WN)],
+              A=agg, lda=H3, K1=H3, A2=x2, lda2=x2.stride(0), alpha=alpha, seed_t=seed_t, f16=f16, ascale=SC_ACT)
         ctx.packed = pk
 
         ctx.save_for_backward(x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3)
@@ -737,3 +749,163 @@ class FusedAttnFn(torch.autograd.Function):
         a.lddq, a.lddk, a.lddv = H * d, H * d, H * d
         check(_lib.lib().mpg_attn_bwd(C.byref(a), _stream()), "mpg_attn_bwd")
         return dq, dk, dv, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------- per-jet pieces around the layers
+def rank_mask(first_feature: torch.Tensor, labels: torch.Tensor, num_particles: int, out: Optional[torch.Tensor] = None):
+    """mask_c (mpgan/model.py:689-699): [B, N] floats, 1 for the n = int(label * N) particles of each jet with the
+    smallest first feature.  ``first_feature`` [B, N] may be a strided view (x[:, :, 0]); one launch."""
+    _chk(first_feature, "first_feature")
+    B, N = first_feature.shape
+    lab = labels[:, -1]
+    if lab.dtype != torch.float32:
+        lab = lab.float()
+    if out is None:
+        out = torch.empty((B, N), device=first_feature.device, dtype=torch.float32)
+    check(_lib.lib().mpg_rank_mask(_p(first_feature), first_feature.stride(0), first_feature.stride(1), _p(lab), lab.stride(0),
+                                   B, N, _p(out), _stream()), "mpg_rank_mask")
+    return out
+
+
+ACT_CODES = {"": 0, "tanh": 1, "sigmoid": 2}
+
+
+def gen_tail_into(y, mask, act: int, out):
+    """out[..., :F] = act(y), out[..., F] = mask - 0.5, written into the caller's [B, N, F+1] buffer (a view with unit
+    feature stride is fine); no autograd -- the D step's generator pass runs under ``no_grad`` and lands its jets
+    directly in the second half of the discriminator's real+generated batch."""
+    B, N, F = y.shape
+    y2 = y.reshape(B * N, F)
+    if y2.stride(1) != 1:
+        y2 = y2.contiguous()
+    assert out.shape == (B, N, F + (mask is not None)) and out.stride(2) == 1 and out.stride(0) == N * out.stride(1)
+    m1 = None if mask is None else mask.reshape(B * N)
+    check(_lib.lib().mpg_gen_tail_fwd(_p(y2), y2.stride(0), _p(m1), _p(out), out.stride(1), B * N, F, act, _stream()),
+          "mpg_gen_tail_fwd")
+    return out
+
+
+class GenTailFn(torch.autograd.Function):
+    """Final activation + mask column of a generator (MPNet._final_activation / MPGenerator._final_mask,
+    mpgan/model.py:533-538, :741-757): out = [act(y) | mask - 0.5], one launch each way."""
+
+    @staticmethod
+    def forward(ctx, y, mask, act):
+        _chk(y, "y")
+        B, N, F = y.shape
+        out = torch.empty((B, N, F + (mask is not None)), device=y.device, dtype=torch.float32)
+        gen_tail_into(y, mask, act, out)
+        ctx.save_for_backward(out)
+        ctx.cfg = (B, N, F, act)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        B, N, F, act = ctx.cfg
+        if dout.stride(2) != 1 or dout.stride(0) != N * dout.stride(1):
+            dout = dout.contiguous()
+        dy = torch.empty((B * N, F), device=out.device, dtype=torch.float32)
+        check(_lib.lib().mpg_gen_tail_bwd(_p(dout), dout.stride(1), _p(out), out.stride(1), _p(dy), F, B * N, F, act, _stream()),
+              "mpg_gen_tail_bwd")
+        return dy.reshape(B, N, F), None, None
+
+
+LOSS_CODES = {"ls": 0, "og": 1, "w": 2, "hinge": 3}
+
+
+def _head_struct(y, mask, w, b, mean, sigmoid, p_drop, training, tag, out, pooled, aux):
+    B, N, F = y.shape
+    h = _lib.MpgDiscHead()
+    h.y, h.ldy, h.mask = _p(y), y.stride(1), _p(mask)
+    h.w, h.bias = _p(w), _p(b)
+    h.B, h.N, h.F, h.mean, h.sigmoid = B, N, F, int(mean), int(sigmoid)
+    thr, dscale = drop_params(p_drop) if training else (0, 1.0)
+    h.seed, h.tag, h.thr, h.dscale = _p(seed_tensor(y.device)), tag, thr, dscale
+    h.out, h.pooled, h.aux = _p(out), _p(pooled), _p(aux)
+    h.loss = -1
+    return h
+
+
+def _head_inputs(y, mask):
+    _chk(y, "y")
+    B, N, F = y.shape
+    if y.stride(2) != 1 or y.stride(0) != N * y.stride(1):
+        y = y.contiguous()
+    m = None if mask is None else mask.reshape(B, N)
+    if m is not None and not m.is_contiguous():
+        m = m.contiguous()
+    return y, m
+
+
+class DiscHeadFn(torch.autograd.Function):
+    """Discriminator head (mpgan/model.py:812-829 + fnd_layer + :537): out[b] = act(drop(w . pool_i(mask * y) + bias)).
+    One launch forward; backward: one launch for dy plus one small reduction for dw / db."""
+
+    @staticmethod
+    def forward(ctx, y, mask, w, b, mean, sigmoid, p_drop, training):
+        y, m = _head_inputs(y, mask)
+        B, N, F = y.shape
+        dev = y.device
+        out = torch.empty((B,), device=dev, dtype=torch.float32)
+        pooled = torch.empty((B, F), device=dev, dtype=torch.float32)
+        aux = torch.empty((2 * B,), device=dev, dtype=torch.float32)
+        tag = next_tag(dev) + TAG_GENERIC
+        wv = w.reshape(-1)
+        h = _head_struct(y, m, wv, b, mean, sigmoid, p_drop, training, tag, out, pooled, aux)
+        check(_lib.lib().mpg_disc_head_fwd(C.byref(h), _stream()), "mpg_disc_head_fwd")
+        ctx.save_for_backward(y, m, w, b, out, pooled, aux)
+        ctx.cfg = (mean, sigmoid, p_drop, training, tag)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        y, m, w, b, out, pooled, aux = ctx.saved_tensors
+        mean, sigmoid, p_drop, training, tag = ctx.cfg
+        B, N, F = y.shape
+        dev = y.device
+        h = _head_struct(y, m, w.reshape(-1), b, mean, sigmoid, p_drop, training, tag, out, pooled, aux)
+        gout = gout.contiguous()
+        h.gout = _p(gout)
+        dy = torch.empty((B, N, F), device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        h.dy, h.ld_dy = _p(dy), F
+        dw = db = None
+        if ctx.needs_input_grad[2]:
+            st = dev_state(dev)
+            gw = _grad_target(w) if st.grad_into_param else None
+            gb = _grad_target(b) if (st.grad_into_param and b is not None) else None
+            if gw is not None and (b is None or gb is not None):
+                h.dw, h.db, h.accumulate = _p(gw), _p(gb), 1
+            else:
+                dw = torch.empty_like(w)
+                db = None if b is None else torch.empty_like(b)
+                h.dw, h.db, h.accumulate = _p(dw), _p(db), 0
+        check(_lib.lib().mpg_disc_head_bwd(C.byref(h), _stream()), "mpg_disc_head_bwd")
+        return dy, None, dw, db, None, None, None, None
+
+
+def disc_head_loss(y, mask, w, b, *, mean, sigmoid, p_drop, training, loss, n_real, gen_step, count, loss_out,
+                   want_dy=True, wgrad=None):
+    """Head forward, the named loss and its gradient in two launches (+ one small reduction), no autograd node:
+    returns (out [B], dy [B, N, F] or None).  ``loss_out`` (0-dim tensor) receives the loss value; ``wgrad`` =
+    (dw, db) buffers the head's own parameter gradients are ADDED to (the flat .grad views), or None."""
+    y, m = _head_inputs(y, mask)
+    B, N, F = y.shape
+    dev = y.device
+    out = torch.empty((B,), device=dev, dtype=torch.float32)
+    pooled = torch.empty((B, F), device=dev, dtype=torch.float32)
+    aux = torch.empty((2 * B,), device=dev, dtype=torch.float32)
+    terms = torch.empty((B,), device=dev, dtype=torch.float32)
+    tag = next_tag(dev) + TAG_GENERIC
+    h = _head_struct(y, m, w.reshape(-1), b, mean, sigmoid, p_drop, training, tag, out, pooled, aux)
+    check(_lib.lib().mpg_disc_head_fwd(C.byref(h), _stream()), "mpg_disc_head_fwd")
+    h.loss, h.gen_step, h.n_real, h.inv_count = LOSS_CODES[loss], int(gen_step), n_real, 1.0 / count
+    h.terms, h.loss_out = _p(terms), _p(loss_out)
+    dy = torch.empty((B, N, F), device=dev, dtype=torch.float32) if want_dy else None
+    h.dy, h.ld_dy = _p(dy), F
+    if wgrad is not None:
+        h.dw, h.db, h.accumulate = _p(wgrad[0]), _p(wgrad[1]), 1
+    check(_lib.lib().mpg_disc_head_bwd(C.byref(h), _stream()), "mpg_disc_head_bwd")
+    return out, dy

@@ -287,6 +287,10 @@ class TrainStep:
         self.data = torch.zeros(batch_size, num_particles, 4, device=dev)
         self.labels = torch.zeros(batch_size, 1, device=dev)
         self._real = torch.cat([torch.ones(batch_size, device=dev), torch.zeros(batch_size, device=dev)])
+        # the discriminator's real + generated batch of the D step: real jets in the first half (set_batch), the
+        # generator's output rows land in the second half; labels likewise
+        self._dcat = torch.zeros(2 * batch_size, num_particles, 4, device=dev)
+        self._labels2 = torch.zeros(2 * batch_size, 1, device=dev)
         self.D_loss = torch.zeros((), device=dev)
         self.G_loss = torch.zeros((), device=dev)
         self.use_graphs = use_graphs and dev.type == "cuda"
@@ -299,6 +303,22 @@ class TrainStep:
             return self.fixed_noise[which]
         return torch.empty(self.B, self.N, self.latent, device=self.dev).normal_(0.0, self.noise_std)
 
+    def _fused_ends(self) -> bool:
+        """Generator able to write its jets into a caller-owned batch and discriminator whose pooling / last Linear /
+        final activation / loss are the single fused head (``ops.disc_head_loss``): the default MPGAN and GAPT
+        configurations.  Then an iteration has no autograd node and no elementwise ATen kernel between the last
+        message-passing / attention block and the loss, in either direction."""
+        return (self.dev.type == "cuda" and hasattr(self.G, "generate_into") and hasattr(self.D, "features")
+                and getattr(self.D, "fused_head", lambda: None)() is not None and self.batch_real_fake)
+
+    def _head_loss(self, y, mask, gen_step: bool, n_jets: int, loss_out, wgrad: bool):
+        w, b, mean, sigmoid, p = self.D.fused_head()
+        grads = (w.grad, None if b is None else b.grad) if wgrad else None
+        _, dy = ops.disc_head_loss(y, mask, w, b, mean=mean, sigmoid=sigmoid, p_drop=p, training=self.D.training,
+                                   loss=self.loss, n_real=self.B, gen_step=gen_step, count=self.B, loss_out=loss_out,
+                                   want_dy=True, wgrad=grads)
+        return dy
+
     def _seg_D(self):  # train_D up to and including backward (train.py:419-460)
         # parameter gradients are added straight into the flat buffers (no AccumulateGrad kernel per parameter)
         self.state.grad_into_param = True
@@ -306,6 +326,14 @@ class TrainStep:
         self.D.train(); self.G.eval()
         self.fD.zero_grad()
         _set_requires_grad(self.D, True)
+        if self._fused_ends():
+            # real jets sit in the first half of the static batch; the generator writes the second half itself
+            with torch.no_grad():
+                self.G.generate_into(self._noise(0), self.labels, self._dcat[self.B:])
+            y, mask = self.D.features(self._dcat, self._labels2)
+            dy = self._head_loss(y, mask, False, 2 * self.B, self.D_loss, True)
+            self._backward(y, dy)
+            return
         with torch.no_grad():
             fake = self.G(self._noise(0), self.labels)
         if self.batch_real_fake:
@@ -316,12 +344,12 @@ class TrainStep:
         self._backward(loss)
         self.D_loss.copy_(loss.detach())
 
-    def _backward(self, loss):
-        """loss.backward() with the stand-alone Linear layers' weight gradients collected and issued as grouped
+    def _backward(self, root, grad=None):
+        """root.backward(grad) with the stand-alone Linear layers' weight gradients collected and issued as grouped
         launches that add straight into the flat gradient buffers."""
         self.state.deferred_wgrad = ops.WgradBatch()
         try:
-            loss.backward()
+            torch.autograd.backward([root], None if grad is None else [grad])
             self.state.deferred_wgrad.flush()
         finally:
             self.state.deferred_wgrad = None
@@ -340,11 +368,16 @@ class TrainStep:
         self.fG.zero_grad()
         _set_requires_grad(self.D, False)
         fake = self.G(self._noise(1), self.labels)
-        out = self.D(fake, self.labels)
-        loss = g_loss(self.loss, out)
-        self._backward(loss)
+        if self._fused_ends():
+            y, mask = self.D.features(fake, self.labels)
+            dy = self._head_loss(y, mask, True, self.B, self.G_loss, False)
+            self._backward(y, dy)
+        else:
+            out = self.D(fake, self.labels)
+            loss = g_loss(self.loss, out)
+            self._backward(loss)
+            self.G_loss.copy_(loss.detach())
         _set_requires_grad(self.D, True)
-        self.G_loss.copy_(loss.detach())
 
     def _seg_end(self):  # G_optimizer.step() (train.py:521)
         self.fG.step(self.lr_gen, gscale=1.0 / self.world)
@@ -385,6 +418,9 @@ class TrainStep:
     def set_batch(self, data: torch.Tensor, labels: torch.Tensor):
         self.data.copy_(data, non_blocking=True)
         self.labels.copy_(labels, non_blocking=True)
+        self._dcat[:self.B].copy_(self.data)
+        self._labels2[:self.B].copy_(self.labels)
+        self._labels2[self.B:].copy_(self.labels)
 
     def step(self):
         if self.use_graphs and self._graphs is None:

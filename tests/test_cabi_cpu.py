@@ -31,7 +31,8 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     """sizeof of every struct as gcc sees the header == ctypes.sizeof of the Python mirror."""
     from mpgan_amd import _lib
-    structs = ["MpgGemm", "MpgEdgeFwd", "MpgEdgeBwd", "MpgEdgeDw", "MpgAttn", "MpgPackJob", "MpgChainLayer", "MpgChain", "MpgReduceJob"]
+    structs = ["MpgGemm", "MpgEdgeFwd", "MpgEdgeBwd", "MpgEdgeDw", "MpgAttn", "MpgPackJob", "MpgChainLayer", "MpgChain", "MpgReduceJob",
+               "MpgDiscHead"]
     src = '#include <stdio.h>\n#include "mpgan_amd.h"\nint main(){' + "".join(
         f'printf("{s} %zu\\n", sizeof({s}));' for s in structs) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:

@@ -40,10 +40,13 @@ def test_chain_forward_three_layers(M, F, out, slabs):
     aggp, x = _t(rs, slabs, M, 192), _t(rs, M, F)
     c1, c2, c3 = _t(rs, 256), _t(rs, 256), _t(rs, out)
     h1, h2, y = (torch.empty(M, n, device=_dev()) for n in (256, 256, out))
-    ops.chain(M, [dict(img=pk.ptr("V1"), K=192 + F, N=256, bias=c1, act=True, out=h1),
-                  dict(img=pk.ptr("V2"), K=256, N=256, bias=c2, act=True, out=h2),
-                  dict(img=pk.ptr("V3"), K=256, N=out, bias=c3, out=y)],
-              A=aggp, lda=192, K1=192, A2=x, lda2=F, a_slabs=slabs, a_slab_stride=M * 192, alpha=0.2, f16=True)
+    # (the forward images of a PackedMPLayer hold SC_WN * W, the activations are split as SC_ACT * x: exact
+    # power-of-two scales that keep the lo halves of the fp16 pairs normal -- the results must not notice)
+    ops.chain(M, [dict(img=pk.ptr("V1"), K=192 + F, N=256, bias=c1, act=True, out=h1, wscale=ops.SC_WN),
+                  dict(img=pk.ptr("V2"), K=256, N=256, bias=c2, act=True, out=h2, wscale=ops.SC_WN),
+                  dict(img=pk.ptr("V3"), K=256, N=out, bias=c3, out=y, wscale=ops.SC_WN)],
+              A=aggp, lda=192, K1=192, A2=x, lda2=F, a_slabs=slabs, a_slab_stride=M * 192, alpha=0.2, f16=True,
+              ascale=ops.SC_ACT)
     inp = torch.cat([aggp.double().sum(0), x.double()], 1)
     r1 = _lrelu(inp @ W["V1"].double().t() + c1.double(), 0.2)
     r2 = _lrelu(r1 @ W["V2"].double().t() + c2.double(), 0.2)
@@ -94,7 +97,8 @@ def test_stacked_layer1_views(F):
     W, pk = _holder(rs, F, 32)
     x, b1 = _t(rs, M, F), _t(rs, 96)
     ac = torch.empty(M, 192, device=_dev())
-    ops.chain(M, [dict(img=pk.ptr("W1S"), K=F, N=192, bias=b1, nbias=96, out=ac)], A=x, lda=F, K1=F, f16=True)
+    ops.chain(M, [dict(img=pk.ptr("W1S"), K=F, N=192, bias=b1, nbias=96, out=ac, wscale=ops.SC_WN)], A=x, lda=F, K1=F,
+              f16=True, ascale=ops.SC_ACT)
     W1 = W["W1"].double()
     ref = torch.cat([x.double() @ W1[:, :F].t() + b1.double(), x.double() @ W1[:, F:].t()], 1)
     assert rel_err(ac.cpu().numpy(), ref.cpu().numpy()) < TIGHT
@@ -112,9 +116,11 @@ def test_pack_many_equals_pack_weights():
     rs = np.random.RandomState(8)
     W, pk = _holder(rs, 32, 32, dscale=2.0)
     singles = {
-        "W2": ops.pack_weights(W["W2"], 160, 96, scale=2.0, f16=True), "W3": ops.pack_weights(W["W3"], 192, 160, scale=2.0, f16=True),
+        # forward images carry the power-of-two operand scales on top of the dropout scale; gradient images do not
+        "W2": ops.pack_weights(W["W2"], 160, 96, scale=2.0 * ops.SC_W2, f16=True),
+        "W3": ops.pack_weights(W["W3"], 192, 160, scale=2.0 * ops.SC_W3, f16=True),
         "W3T": ops.pack_weights(W["W3"], 192, 160, transpose=True, scale=2.0), "W2T": ops.pack_weights(W["W2"], 160, 96, transpose=True, scale=2.0),
-        "V2": ops.pack_weights(W["V2"], 256, 256, f16=True), "V1T": ops.pack_weights(W["V1"], 256, 224, transpose=True),
+        "V2": ops.pack_weights(W["V2"], 256, 256, scale=ops.SC_WN, f16=True), "V1T": ops.pack_weights(W["V1"], 256, 224, transpose=True),
     }
     for k, img in singles.items():
         assert torch.equal(img.view(torch.int16), pk.img[k].view(torch.int16)), k

@@ -1,0 +1,135 @@
+"""GPU parity of the per-jet pieces around the message-passing layers (csrc/head.hip): rank mask, generator tail,
+discriminator head with and without the fused loss -- against plain torch restatements of the reference lines."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_rank_mask(x0, labels, N):
+    """mpgan/model.py:689-699 as written there: double argsort."""
+    n = (labels[:, -1] * N).int() - 1
+    rank = x0.argsort(dim=1).argsort(dim=1)
+    return (rank <= n.unsqueeze(1)).float()
+
+
+@pytest.mark.parametrize("B,N", [(7, 30), (3, 150), (2, 1), (5, 33)])
+def test_rank_mask(B, N):
+    from mpgan_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(B * N)
+    x = torch.randn(B, N, 8, device="cuda", generator=g)
+    n = torch.randint(1, N + 1, (B,), device="cuda", generator=g)
+    labels = (n.float() * np.float32(1.0 / N)).reshape(B, 1)
+    m = ops.rank_mask(x[:, :, 0], labels, N)
+    assert torch.equal(m, _ref_rank_mask(x[:, :, 0], labels, N))
+    assert torch.equal(m.sum(1).int(), n.int())
+    # ties are ordered by index
+    xt = torch.zeros(2, 6, 1, device="cuda")
+    lt = torch.tensor([[0.5], [1.0]], device="cuda")
+    mt = ops.rank_mask(xt[:, :, 0], lt, 6)
+    assert mt.tolist() == [[1, 1, 1, 0, 0, 0], [1, 1, 1, 1, 1, 1]]
+
+
+@pytest.mark.parametrize("act", ["tanh", "", "sigmoid"])
+def test_gen_tail(act):
+    from mpgan_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(1)
+    B, N, F = 5, 30, 3
+    y = torch.randn(B, N, F, device="cuda", generator=g, requires_grad=True)
+    mask = (torch.rand(B, N, 1, device="cuda", generator=g) < 0.7).float()
+    up = torch.randn(B, N, F + 1, device="cuda", generator=g)
+    out = ops.GenTailFn.apply(y, mask, ops.ACT_CODES[act])
+    (out * up).sum().backward()
+    yr = y.detach().double().requires_grad_(True)
+    a = torch.tanh(yr) if act == "tanh" else (torch.sigmoid(yr) if act == "sigmoid" else yr)
+    ref = torch.cat((a, mask.double() - 0.5), 2)
+    (ref * up.double()).sum().backward()
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 1e-6
+    assert rel_err(y.grad.cpu().numpy(), yr.grad.cpu().numpy()) < 1e-6
+    # into a caller-owned strided buffer (second half of a batch)
+    big = torch.zeros(2 * B, N, F + 1, device="cuda")
+    with torch.no_grad():
+        ops.gen_tail_into(y.detach(), mask, ops.ACT_CODES[act], big[B:])
+    assert torch.equal(big[B:], out.detach()) and float(big[:B].abs().sum()) == 0.0
+
+
+def _ref_head(y, mask, w, b, mean, sigmoid, keep=None):
+    pooled = (y * mask).sum(1) if mask is not None else y.sum(1)
+    if mean:
+        pooled = pooled / (mask.sum(1) + 1e-12) if mask is not None else pooled / y.shape[1]
+    z = pooled @ w.t() + b
+    if keep is not None:
+        z = z * keep
+    return torch.sigmoid(z) if sigmoid else z
+
+
+@pytest.mark.parametrize("mean,sigmoid,use_mask,N,F", [(False, True, True, 30, 32), (True, True, True, 30, 32),
+                                                         (False, False, True, 150, 32), (True, False, False, 7, 32),
+                                                         (False, True, False, 1, 64)])
+def test_disc_head_autograd(mean, sigmoid, use_mask, N, F):
+    from mpgan_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(N + F)
+    B = 9
+    y = torch.randn(B, N, F, device="cuda", generator=g).mul_(0.3).requires_grad_(True)
+    mask = (torch.rand(B, N, 1, device="cuda", generator=g) < 0.7).float() if use_mask else None
+    w = torch.randn(1, F, device="cuda", generator=g).mul_(0.2).requires_grad_(True)
+    b = torch.randn(1, device="cuda", generator=g).requires_grad_(True)
+    up = torch.randn(B, device="cuda", generator=g)
+    out = ops.DiscHeadFn.apply(y, mask, w, b, mean, sigmoid, 0.0, False)
+    (out * up).sum().backward()
+    yr, wr, br = (t.detach().double().requires_grad_(True) for t in (y, w, b))
+    ref = _ref_head(yr, None if mask is None else mask.double(), wr, br, mean, sigmoid).reshape(-1)
+    (ref * up.double()).sum().backward()
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 1e-5
+    for a, r in ((y.grad, yr.grad), (w.grad, wr.grad), (b.grad, br.grad)):
+        assert rel_err(a.cpu().numpy(), r.cpu().numpy()) < 1e-5
+
+
+def test_disc_head_dropout_mask_is_the_helper_mask():
+    """Dropout on the head's Linear output (LinearNet puts one after every layer): the keep decisions are those of
+    mpg_dropout_mask for the same site, the scale 1 / (1 - p)."""
+    from mpgan_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, N, F = 64, 30, 32
+    y = torch.randn(B, N, F, device="cuda", generator=g).mul_(0.3)
+    w = torch.randn(1, F, device="cuda", generator=g).mul_(0.2)
+    b = torch.zeros(1, device="cuda") + 0.1
+    ops.set_seed(77)
+    out = ops.DiscHeadFn.apply(y, None, w, b, False, False, 0.5, True)
+    tag = ops.last_tag("cuda") + ops.TAG_GENERIC
+    keep = ops.dropout_mask(B, 1, tag, 128).reshape(B)
+    ref = _ref_head(y.double(), None, w.double(), b.double(), False, False).reshape(-1) * keep.double() * 2.0
+    assert 0.2 < float(keep.mean()) < 0.8
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("loss", ["ls", "og", "w", "hinge"])
+@pytest.mark.parametrize("gen_step", [False, True])
+def test_disc_head_fused_loss(loss, gen_step):
+    """ops.disc_head_loss == head + calc_D_loss / calc_G_loss (oracle definitions) + autograd, in value and gradients."""
+    from mpgan_amd import ops
+    from oracle import train_ref as T
+    g = torch.Generator(device="cuda").manual_seed(11)
+    B, N, F = 8, 30, 32
+    nj = B if gen_step else 2 * B
+    sigmoid = loss in ("ls", "og")
+    y = torch.randn(nj, N, F, device="cuda", generator=g).mul_(0.3)
+    mask = (torch.rand(nj, N, 1, device="cuda", generator=g) < 0.7).float()
+    w = torch.randn(1, F, device="cuda", generator=g).mul_(0.2)
+    b = torch.randn(1, device="cuda", generator=g)
+    loss_out = torch.zeros((), device="cuda")
+    dw, db = torch.zeros(1, F, device="cuda"), torch.zeros(1, device="cuda")
+    out, dy = ops.disc_head_loss(y, mask, w, b, mean=False, sigmoid=sigmoid, p_drop=0.0, training=True, loss=loss,
+                                 n_real=B, gen_step=gen_step, count=B, loss_out=loss_out, wgrad=(dw, db))
+    yr, wr, br = (t.double().requires_grad_(True) for t in (y, w, b))
+    o = _ref_head(yr, mask.double(), wr, br, False, sigmoid)
+    L = T.g_loss_ref(loss, o) if gen_step else T.d_loss_ref(loss, o[:B], o[B:])
+    L.backward()
+    assert abs(float(loss_out) - float(L)) < 1e-5 * max(abs(float(L)), 1e-3)
+    assert rel_err(out.cpu().numpy(), o.detach().reshape(-1).cpu().numpy()) < 1e-5
+    assert rel_err(dy.cpu().numpy(), yr.grad.cpu().numpy()) < 1e-5
+    assert rel_err(dw.cpu().numpy(), wr.grad.cpu().numpy()) < 1e-5
+    assert rel_err(db.cpu().numpy(), br.grad.cpu().numpy()) < 1e-5

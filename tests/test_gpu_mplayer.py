@@ -72,12 +72,65 @@ def _mplayer_shapes(F, out):
     return mplayer_shapes(F, out)
 
 
-def _run_case(B, N, F, out, use_mask, sum_agg, seed, skip=True, alpha=0.2, control=None):
+def _fused_node(y):
+    """The FusedMPLayerFn backward node behind an MPLayer output (its saved tensors hold the forward's by-products)."""
+    todo, seen = [y.grad_fn], set()
+    while todo:
+        fn = todo.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        if "FusedMPLayerFn" in type(fn).__name__:
+            return fn
+        todo.extend(f for f, _ in fn.next_functions)
+    raise AssertionError("no FusedMPLayerFn node behind the output")
+
+
+def _hip_signs(y, B, N):
+    """Signs (True = negative) of the pre-activations the HIP forward saw, where it keeps them: fe layer 1 from the
+    saved a|c terms (z1 = a_i + c_j in fp32, as the kernel adds them), fe layer 3 from the packed sign words
+    (edge.hip: word q of lane (r, h), bit 31 - (16 (tile & 1) + reg) for tile >> 1 == q; reg 4g+t <-> feature
+    32 tile + 8g + 4h + t), the node network from the signs of its saved outputs.  [B,N,N,*] / [B,N,*] like the
+    oracle's probes; fe layer 3 is only defined for unmasked senders."""
+    x2, m1, ac, agg, h1, h2, *_, sign3 = _fused_node(y).saved_tensors
+    a, c = ac[:, :96].reshape(B, N, 96), ac[:, 96:].reshape(B, N, 96)
+    z1neg = ((a.unsqueeze(2) + c.unsqueeze(1)) < 0).cpu()
+    RB = (N + 31) // 32
+    w = sign3.reshape(B, RB, N, 3, 64).cpu().numpy().astype(np.uint32)           # [b, rb, j, q, lane]
+    z3neg = np.zeros((B, N, N, 192), dtype=bool)
+    for tile in range(6):
+        for reg in range(16):
+            bit = (w[:, :, :, tile >> 1, :] >> np.uint32(31 - (16 * (tile & 1) + reg))) & 1   # [b, rb, j, lane]
+            g, t = reg >> 2, reg & 3
+            for hh in range(2):
+                f = 32 * tile + 8 * g + 4 * hh + t
+                for rb in range(RB):
+                    n_i = min(32, N - 32 * rb)
+                    z3neg[:, 32 * rb:32 * rb + n_i, :, f] = bit[:, rb, :, 32 * hh:32 * hh + n_i].transpose(0, 2, 1) != 0
+    return {"fe1": z1neg, "fe3": torch.from_numpy(z3neg), "fn1": (h1.reshape(B, N, -1) < 0).cpu(),
+            "fn2": (h2.reshape(B, N, -1) < 0).cpu()}
+
+
+def _sign_disagreements(neg, probe64, mask64):
+    """How many pre-activations have another sign than in the fp64 oracle (layers as _hip_signs; fe: unmasked senders)."""
+    ref = {"fe1": probe64[0] < 0, "fe3": probe64[2] < 0, "fn1": probe64[3] < 0, "fn2": probe64[4] < 0}
+    out = {}
+    for k, r in ref.items():
+        d = neg[k] != r
+        if k.startswith("fe") and mask64 is not None:
+            d = d & (mask64.reshape(mask64.shape[0], 1, -1, 1) != 0)
+        out[k] = int(d.sum())
+    return out
+
+
+def _run_case(B, N, F, out, use_mask, sum_agg, seed, skip=True, alpha=0.2, control=None, flips=None):
     """HIP MPLayer vs fp64 oracle on the same inputs.  Returns per-tensor
     (max-norm error, fraction of elements off by more than 1e-3 of the max) and the oracle's
     kink margin = min |pre-activation| / max |pre-activation| over all LeakyReLU inputs.
     ``control`` (a dict): also run the oracle in plain fp32 -- the reference's own arithmetic -- on the same inputs
-    and store ITS errors / off-fractions against the fp64 run there: the yardstick for kink flips."""
+    and store ITS errors / off-fractions against the fp64 run there: the yardstick for kink flips.
+    ``flips`` (a dict, needs ``control``): receives the sign-disagreement counts against fp64 of the HIP forward
+    (``hip``) and of the fp32 oracle (``fp32``), per layer."""
     import oracle
     from oracle import train_ref as T
     from mpgan_amd import ops
@@ -104,8 +157,12 @@ def _run_case(B, N, F, out, use_mask, sum_agg, seed, skip=True, alpha=0.2, contr
     if control is not None:
         sd32 = {"L." + k: v.float().requires_grad_(True) for k, v in sd64.items()}
         x32 = x64.float().requires_grad_(True)
+        probe32 = []
         y32 = oracle.mplayer_forward(sd32, "L", x32, None if mask64 is None else mask64.float(), sum_agg=sum_agg,
-                                     alpha=alpha)
+                                     alpha=alpha, probe=probe32)
+        if flips is not None:
+            neg32 = {"fe1": probe32[0] < 0, "fe3": probe32[2] < 0, "fn1": probe32[3] < 0, "fn2": probe32[4] < 0}
+            flips["fp32"] = _sign_disagreements(neg32, probe, mask64)
         (y32 * g64.float()).sum().backward()
         cpairs = {"y": (y32.detach(), yo.detach()), "dx": (x32.grad, xo.grad)}
         cpairs.update({k[2:]: (sd32[k].grad, sdo[k].grad) for k in sd32})
@@ -115,6 +172,8 @@ def _run_case(B, N, F, out, use_mask, sum_agg, seed, skip=True, alpha=0.2, contr
     x = x64.float().to(_dev()).requires_grad_(True)
     mask = None if mask64 is None else mask64.float().to(_dev())
     y = layer(x, use_mask, mask)
+    if flips is not None:
+        flips["hip"] = _sign_disagreements(_hip_signs(y, B, N), probe, mask64)
     (y * g64.float().to(_dev())).sum().backward()
     torch.cuda.synchronize()
     ops.OPTIONS["skip_masked"] = True
@@ -250,21 +309,47 @@ def test_mplayer_vs_reference_golden(name, F, out, ci):
         assert e < max(TOL, 3 * c), (k, e, c)
 
 
+def test_mplayer_full_size_smooth():
+    """BASELINE config 2 (B = 256, N = 30, F = 32) with slope 1 (no kink): every product, reduction and layout of
+    forward and backward at full size, strict."""
+    errs, _, _ = _run_case(256, 30, 32, 32, True, True, seed=7, alpha=1.0)
+    bad = {k: v for k, v in errs.items() if not v < TIGHT}
+    assert not bad, (bad, errs)
+
+
 def test_mplayer_full_size():
-    """BASELINE config 2 (B = 256, N = 30, F = 32): forward strict; parameter gradients (sums over
-    230,400 edges) within the 1e-3 bar; input gradient: all but a tiny fraction of elements."""
-    control = {}
-    errs, frac, margin = _run_case(256, 30, 32, 32, True, True, seed=7, control=control)
-    print("full-size errors", errs, "\nfrac>1e-3", frac, "margin", margin, "\nfp32 control (err, frac)", control)
-    assert errs["y"] < TIGHT
-    for k, v in errs.items():
-        if k not in ("y", "dx"):
-            assert v < TOL, (k, v)
-    # input gradient: a kink flip moves one row of dx by O(1) of that row -- rare isolated elements, also in the
-    # reference's own fp32 arithmetic (control).  The HIP path must stay within 3x of fp32's off-fraction.
-    assert errs["dx"] < 5e-3, errs["dx"]
-    assert frac["dx"] < 1e-3, frac["dx"]
-    assert frac["dx"] <= max(3 * control["dx"][1], 5e-5), (frac["dx"], control["dx"])
+    """BASELINE config 2 with the default slope, three seeds.  Forward strict.  Gradients: LeakyReLU' jumps at 0, and
+    a pre-activation within rounding of zero takes the other slope -- in the reference's own fp32 arithmetic as well
+    (against fp64 the fp32 oracle disagrees on a few signs per layer at this size, and one such sign in the node
+    network moves whole rows of dx and columns of the weight gradients by ~1e-2: fp32 itself shows 3e-3 on dx and
+    1e-3 on a bias for seed 8).  So the test pins
+      (1) the RATE of such disagreements: counted directly from the signs the HIP forward saw (a|c terms, the packed
+          sign words, the node network's outputs) against the fp64 oracle, it must stay within 3x of the fp32
+          oracle's own count (+10 for Poisson noise) -- a kernel whose forward were less accurate than fp32 fails;
+      (2) the size of their effect: every parameter gradient within the 1e-3 bar for most seeds (median), never a gross
+          error (5e-2); dx -- where one flipped sign in the node network shows at ~1e-2 in that node's rows, for fp32
+          as for the kernels -- with less than 1e-3 of its elements off by more than 1e-3."""
+    seeds = (7, 8, 9)
+    all_errs, n_hip, n_ctl = [], {}, {}
+    for seed in seeds:
+        control, flips = {}, {}
+        errs, frac, margin = _run_case(256, 30, 32, 32, True, True, seed=seed, control=control, flips=flips)
+        print("full-size seed", seed, "errors", errs, "\nfrac>1e-3", frac, "margin", margin, "\nfp32 control (err, frac)",
+              control, "\nsign disagreements vs fp64", flips)
+        assert errs["y"] < TIGHT
+        assert max(errs.values()) < 5e-2, errs
+        assert frac["dx"] < 1e-3, frac["dx"]
+        all_errs.append(errs)
+        for k in flips["hip"]:
+            n_hip[k] = n_hip.get(k, 0) + flips["hip"][k]
+            n_ctl[k] = n_ctl.get(k, 0) + flips["fp32"][k]
+    print("sign disagreements summed over seeds: HIP", n_hip, "fp32 oracle", n_ctl)
+    assert sum(n_hip.values()) <= 3 * sum(n_ctl.values()) + 10, (n_hip, n_ctl)
+    for k in all_errs[0]:
+        if k == "dx":
+            continue
+        med = sorted(e[k] for e in all_errs)[len(seeds) // 2]
+        assert med < TOL, (k, [e[k] for e in all_errs])
 
 
 @pytest.mark.parametrize("p_drop", [0.5, 0.3])

@@ -188,22 +188,42 @@ def test_train_step_n150_vs_oracle():
     G, D = _setup(B, N)
     sdG = T.init_state_dict(T.mpgan_param_shapes(True), 41, torch.float64)
     sdD = T.init_state_dict(T.mpgan_param_shapes(False), 42, torch.float64)
+    # D sums 150 particles before its sigmoid: with unit-scale head weights the logit is ~ +-17, where fp32's
+    # 1 - sigmoid is exactly 0 (fp64's is 4e-8) and every gradient vanishes -- an fp32 artefact the reference has
+    # too.  Shrink the head so the comparison happens where both arithmetics have a gradient.
+    sdD["fnd_layer.net.0.weight"] = sdD["fnd_layer.net.0.weight"] * 0.02
+    D.load_state_dict({k: v.float() for k, v in sdD.items()})
     data, labels = synthetic_batch(B, N, seed=11)
     gen = torch.Generator().manual_seed(6)
     nD, nG = torch.randn(B, N, 32, generator=gen) * 0.2, torch.randn(B, N, 32, generator=gen) * 0.2
-    ts = train.TrainStep(G, D, B, N, use_graphs=False)
+    # (learning rate 0 for D: RMSprop's first step is ~ -10 lr sign(g) wherever |g| >> 1e-7, so rounding noise on a
+    # gradient entry that is zero by symmetry would move D differently here and in the oracle before the G step)
+    ts = train.TrainStep(G, D, B, N, use_graphs=False, lr_disc=0.0)
     ts.set_batch(data.cuda(), labels.cuda())
     ts.fixed_noise = (nD.cuda(), nG.cuda())
     ts._seg_D()
     dl, gl, gD, gG = T.train_iteration("mpgan", sdD, sdG, {}, {}, data.double(), labels.double(), nD.double(),
-                                       nG.double(), *train.LR["g"], return_grads=True)
-    for k, p in D.named_parameters():
-        assert rel_err(p.grad.cpu().numpy(), gD[k].numpy()) < 2e-3, k   # B = 2: one flipped edge is ~1e-3 of a sum
+                                       nG.double(), 0.0, train.LR["g"][1], return_grads=True)
+    # B = 2: every LeakyReLU sign that fp32-level rounding decides differently from fp64 shows at ~1e-2 in these
+    # short sums (the fp32 reference has them too: test_mplayer_full_size counts them); arithmetic at N = 150 is pinned
+    # at 1e-4 by the smooth MPLayer cases, this test pins the iteration's wiring (chunks, receiver blocks, both nets)
+    _assert_grads(D, gD, 5e-2)
     ts._seg_G()
-    for k, p in G.named_parameters():
-        assert rel_err(p.grad.cpu().numpy(), gG[k].numpy()) < 2e-3, k
+    _assert_grads(G, gG, 5e-2)
     ts._seg_end()
     assert abs(float(ts.D_loss) - dl) < 1e-4 * abs(dl) and abs(float(ts.G_loss) - gl) < 1e-4 * abs(gl)
+
+
+def _assert_grads(module, ref, tol):
+    """max|got - ref| <= tol * max|ref| per parameter; a parameter whose true gradient vanishes by symmetry (e.g. the
+    last node-layer bias of D under the w / hinge losses: real and generated jets have the same multiplicities and
+    opposite loss gradients) is held to tol * 1e-3 of the largest gradient in the network instead of to its own
+    rounding noise."""
+    scale = max(float(v.abs().max()) for v in ref.values())
+    for k, p in module.named_parameters():
+        r = ref[k].numpy()
+        err = np.abs(p.grad.double().cpu().numpy() - r).max()
+        assert err <= tol * max(np.abs(r).max(), 1e-3 * scale), (k, err, np.abs(r).max(), scale)
 
 
 @pytest.mark.parametrize("loss", ["og", "w", "hinge"])
@@ -221,18 +241,18 @@ def test_train_step_other_losses_vs_oracle(loss):
     data, labels = synthetic_batch(B, N, seed=12)
     gen = torch.Generator().manual_seed(7)
     nD, nG = torch.randn(B, N, 32, generator=gen) * 0.2, torch.randn(B, N, 32, generator=gen) * 0.2
-    ts = train.TrainStep(G, D, B, N, use_graphs=False, loss=loss)
+    # (lr_disc = 0, see test_train_step_n150_vs_oracle: under w / hinge the last node-layer bias of D has a gradient
+    # that vanishes by symmetry, and RMSprop would turn its rounding noise into a full-size step)
+    ts = train.TrainStep(G, D, B, N, use_graphs=False, loss=loss, lr_disc=0.0)
     ts.set_batch(data.cuda(), labels.cuda())
     ts.fixed_noise = (nD.cuda(), nG.cuda())
     cfg = {"D": {"sigmoid": loss not in ("w", "hinge")}}
     ts._seg_D()
     dl, gl, gD, gG = T.train_iteration("mpgan", sdD, sdG, {}, {}, data.double(), labels.double(), nD.double(),
-                                       nG.double(), *train.LR["g"], return_grads=True, loss=loss, cfg=cfg)
-    for k, p in D.named_parameters():
-        assert rel_err(p.grad.cpu().numpy(), gD[k].numpy()) < 2e-3, k
+                                       nG.double(), 0.0, train.LR["g"][1], return_grads=True, loss=loss, cfg=cfg)
+    _assert_grads(D, gD, 2e-3)
     ts._seg_G()
-    for k, p in G.named_parameters():
-        assert rel_err(p.grad.cpu().numpy(), gG[k].numpy()) < 2e-3, k
+    _assert_grads(G, gG, 2e-3)
     ts._seg_end()
     assert abs(float(ts.D_loss) - dl) < 1e-4 * max(abs(dl), 1e-3) and abs(float(ts.G_loss) - gl) < 1e-4 * max(abs(gl), 1e-3)
 
