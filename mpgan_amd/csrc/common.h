@@ -195,7 +195,10 @@ MPG_DEV bool drop_keep_f(uint32_t seed_lo, uint32_t seed_hi, uint32_t tag, uint3
 template <int DM>
 MPG_DEV float drop_apply(float x, uint32_t w, int k_bit, int t_byte, uint32_t thr) {
     if constexpr (DM == 2) {
-        const int m = __builtin_amdgcn_sbfe((int)w, k_bit, 1);  // 0 or -1
+        int m = __builtin_amdgcn_sbfe((int)w, k_bit, 1);  // 0 or -1
+        // (opaque to the optimiser: it would turn "x & mask" into v_and + v_cmp + v_cndmask through an SGPR pair per
+        // element -- three instructions instead of two, and enough live SGPR pairs to spill them into VGPR lanes)
+        asm("" : "+v"(m));
         return __builtin_bit_cast(float, __builtin_bit_cast(int, x) & m);
     } else if constexpr (DM == 1) {
         return drop_keep(w, t_byte, thr) ? x : 0.f;

@@ -171,6 +171,8 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(p.stageE2, 0, NEEDW ? nblk * (2 * NFR2 * 1024) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(p.stageZ2, 0, NEEDW ? nblk * (2 * NFR2 * 1024) : 0, 0x00020000);
 
+    uint32_t opaque_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
     float valpha = p.alpha, vone = 1.f;   // the two slopes in vector registers (operands of v_bfi)
     asm volatile("" : "+v"(valpha), "+v"(vone));
     float dacc[T1][16];
@@ -189,7 +191,10 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
         jj[0] = __builtin_amdgcn_readfirstlane((int)lst[2 * pq]);
         jj[1] = has2 ? __builtin_amdgcn_readfirstlane((int)lst[2 * pq + 1]) : jj[0];
         float cpos[2], cneg[2];     // slope of layer 3 times m_j * dscale: one select between two uniform constants
-        uint32_t erow[2];
+        // erow2 == erow, in a form the optimiser cannot prove equal: every dropout word is needed twice per pair, phases
+        // apart (forward recomputation, then the gate of the matching gradient), and with one visible value it keeps
+        // all the one-instruction keep-masks of the first use alive for the second (hundreds of registers, spilled)
+        uint32_t erow[2], erow2[2];
         int stoff[2];               // byte offset of the sender's staging block (out of range for an idle half)
         uint32_t sw[2][T3 / 2];     // this lane's 96 sign bits of Z3 per sender
 #pragma unroll
@@ -198,6 +203,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             const float mjs = (sd == 0 || has2) ? mj * p.dscale : 0.f;
             cpos[sd] = mjs; cneg[sd] = mjs * p.alpha;
             erow[sd] = (uint32_t)((b * p.N + i) * p.N + jj[sd]);
+            erow2[sd] = erow[sd] + opaque_zero;
             const int blk = (b * RB + rb) * p.N + jj[sd];
             stoff[sd] = (sd == 0 || has2) ? blk * (2 * NFR2 * 1024) + lane16 : (int)0x7ffffff0;
 #pragma unroll
@@ -419,6 +425,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             float v2[2][8];
             PairBf pb[2][4];
             bf16x8 ah[3][T1], al[3][T1];  // ring of three k-steps of W2^T fragments (L2 is more than one k-step away)
+            uint32_t wd2c[2] = {0u, 0u};  // bit-mode dropout word of the layer-2 tile being gated (hashed again: see erow2)
             auto load_w = [&](auto kc) {
                 MPG_CI(k, kc);
 #pragma unroll
@@ -440,8 +447,10 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                     float gt = sel_by_bit<nb - 1 - (16 * (m2 & 1) + r16)>(neg2[sd][m2 >> 1], valpha, vone);
                     if constexpr (DROP != 0) {
                         uint32_t wd;
-                        if constexpr (DROP == 2) wd = wd2[sd][m2];
-                        else wd = drop_tile_word<1>(seed_lo, seed_hi, p.tag_base + TAG_E1, erow[sd], m2, 2 * g + h, h);
+                        if constexpr (DROP == 2) {
+                            if constexpr (u == 0 && s == 0) wd2c[sd] = drop_tile_word<2>(seed_lo, seed_hi, p.tag_base + TAG_E1, erow2[sd], m2, 0, h);
+                            wd = wd2c[sd];
+                        } else wd = drop_tile_word<1>(seed_lo, seed_hi, p.tag_base + TAG_E1, erow2[sd], m2, 2 * g + h, h);
                         gt = drop_apply<DROP>(gt, wd, 8 * g + t, t, p.thr);
                     }
                     v2[sd][u] = accB[m2][sd][r16] * gt;
@@ -505,7 +514,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                     static_for<0, 4>([&](auto suc) {
                         MPG_CI(su, suc);
                         constexpr int s = su >> 1, u = su & 1;
-                        const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow[sd], mm, 4 * s + 2 * u + h, h);
+                        const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow2[sd], mm, 4 * s + 2 * u + h, h);
                         float dz[4];
                         static_for<0, 4>([&](auto tc) {
                             MPG_CI(t, tc);
