@@ -357,13 +357,16 @@ def cpu_baseline(torch, model, N, B_gpu):
         log(f"cpu B={B}: {len(timed)} timed iterations, {dt:.3f} s each")
         return {"value": B / dt, "ms_per_step": 1e3 * dt, "iterations": len(timed), "batch": B}
 
-    small = sample(32, 10, 8.0)
+    # BASELINE config 1's batch (32) where an iteration takes a fraction of a second (N = 30); at N = 150 one
+    # iteration of 32 jets is ~20 s of CPU: the sample there is the GPU leg's own batch alone
+    small = sample(32, 10, 8.0) if N <= 40 else sample(B_gpu, 3, 15.0)
     res = {"value": small["value"], "unit": "jets/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"{small['iterations']} timed G+D iterations (after 1 warm-up) at B=32, N={N} (BASELINE config 1 "
-                     f"batch), {model}, fp32, torch {torch.__version__} CPU ops, D dropout 0.5; the port skips the "
-                     "reference's results-neutral wasted work (G backward in train_D, D weight gradients in train_G)",
+           "sample": f"{small['iterations']} timed G+D iterations (after 1 warm-up) at B={small['batch']}, N={N}"
+                     f"{' (BASELINE config 1 batch)' if small['batch'] == 32 else ''}, {model}, fp32, torch {torch.__version__} "
+                     "CPU ops, D dropout 0.5; the port skips the reference's results-neutral wasted work (G backward in "
+                     "train_D, D weight gradients in train_G)",
            "ms_per_step": small["ms_per_step"], "iterations": small["iterations"]}
-    if B_gpu != 32:
+    if B_gpu != small["batch"]:
         big = sample(B_gpu, 3, 15.0)
         res["at_gpu_batch"] = {"value": big["value"], "unit": "jets/s", "batch": B_gpu, "ms_per_step": big["ms_per_step"],
                                "iterations": big["iterations"]}

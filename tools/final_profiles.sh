@@ -1,23 +1,35 @@
 #!/bin/bash
-# Round-end evidence: rocprofv3 kernel stats of the default bench, HBM traffic counters of the edge kernels,
-# and the MFMA issue/power micro-benchmarks.  Run on the GPU box from the repo root; results in gpurun_out/final.
+# Round-end evidence: rocprofv3 kernel stats of the default bench, HBM traffic counters and SQ counters of the edge
+# kernels, the MFMA issue/power micro-benchmarks.  Run on the GPU box from the repo root; results in gpurun_out/final
+# (tools/make_profiles.py <tag> then writes the committed summaries under profiles/).
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/final
+# build BEFORE any profiled process: a profiled python must never start hipcc (the profiler's preload initialises the
+# GPU in every child; hipcc then execs clang -- a GPU-initialised exec, forbidden on this pool)
+python3 $R/__graft_entry__.py || exit 1
 cd /tmp && export TMPDIR=/tmp
 out=$R/gpurun_out/final/bench_stats
 rm -rf $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o b -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/final/bench_under_rocprof.log 2>&1 || exit 1
-python3 $R/tools/prof_summary.py $out 30 > $R/gpurun_out/final/bench_stats_summary.txt
+python3 $R/tools/prof_summary.py $out 40 > $R/gpurun_out/final/bench_stats_summary.txt
 echo "stats done"
+KERNELS=("edge_fwd_kernel<0" "edge_fwd_kernel<2" "edge_bwd_kernel<0, true, true" "edge_bwd_kernel<0, true, false" "edge_bwd_kernel<2, true, true" "edge_bwd_kernel<2, true, false" "edge_dw_kernel<0" "edge_dw_kernel<2" chain_kernel gemm_group_kernel)
 for c in FETCH_SIZE WRITE_SIZE; do
   o=$R/gpurun_out/final/pmc_$c
   rm -rf $o
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $o -o p -- python3 $R/tools/kbwd.py > $o.log 2>&1 || exit 1
-  for k in "edge_fwd_kernel<0" "edge_fwd_kernel<2" "edge_bwd_kernel<0, true, true" "edge_bwd_kernel<0, true, false" "edge_bwd_kernel<2, true, true" "edge_bwd_kernel<2, true, false" "edge_dw_kernel<0" "edge_dw_kernel<2" chain_kernel gemm_group_kernel; do
+  for k in "${KERNELS[@]}"; do
     echo "== $c $k"; python3 $R/tools/pmc_summary.py $o "$k"
   done
 done > $R/gpurun_out/final/pmc_summary.txt 2>&1
 echo "pmc done"
+o=$R/gpurun_out/final/pmc_sq
+rm -rf $o
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $o -o p -- python3 $R/tools/kbwd.py > $o.log 2>&1 || { tail -5 $o.log; exit 1; }
+for k in "edge_fwd_kernel<0" "edge_fwd_kernel<2" "edge_bwd_kernel<0, true, true" "edge_bwd_kernel<0, true, false" "edge_bwd_kernel<2, true, true" "edge_bwd_kernel<2, true, false" "edge_dw_kernel<0" "edge_dw_kernel<2"; do
+  echo "== $k"; python3 $R/tools/pmc_summary.py $o "$k"
+done > $R/gpurun_out/final/pmc_sq_summary.txt 2>&1
+echo "sq done"
 cd $R
 (timeout -k 10 120 tools/ubench/mfma_model; timeout -k 10 120 tools/ubench/mfma_model2; timeout -k 10 120 tools/ubench/mfma_power) > gpurun_out/final/ubench.txt 2>&1
 echo "ubench done"

@@ -1,4 +1,6 @@
 #!/bin/bash
+# build first: a profiled python must never compile (see tools/final_profiles.sh)
+python3 $GRAFT_REPO_ROOT/__graft_entry__.py || exit 1
 # Per-kernel times of MPLayer fwd+bwd (tools/kbwd.py) under rocprofv3; run on the GPU box from the repo root.
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/kprof

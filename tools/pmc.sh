@@ -1,4 +1,6 @@
 #!/bin/bash
+# build first: a profiled python must never compile (see tools/final_profiles.sh)
+python3 $GRAFT_REPO_ROOT/__graft_entry__.py || exit 1
 # HBM traffic counters of the edge kernels (tools/kbwd.py workload), one counter per pass as the guide prescribes.
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do

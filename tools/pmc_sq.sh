@@ -1,4 +1,6 @@
 #!/bin/bash
+# build first: a profiled python must never compile (see tools/final_profiles.sh)
+python3 $GRAFT_REPO_ROOT/__graft_entry__.py || exit 1
 # SQ counters of the edge kernels (tools/kbwd.py workload): MFMA busy cycles, waits, VALU activity.
 cd /tmp && export TMPDIR=/tmp
 o=$GRAFT_REPO_ROOT/gpurun_out/final/pmc_sq
