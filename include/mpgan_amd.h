@@ -261,6 +261,15 @@ typedef struct MpgDiscHead {
 int mpg_disc_head_fwd(const MpgDiscHead* p, void* stream);
 int mpg_disc_head_bwd(const MpgDiscHead* p, void* stream);
 
+/* mpg_layernorm_fwd / _bwd: nn.LayerNorm(E) over the rows of x [M, E] -- MAB.norm1 / norm2 of GAPT with layer_norm
+ * (gapt/model.py:118-120, :131-136).  fwd writes y and stats [M][mean, rstd]; bwd writes dx and, through `part`
+ * (scratch of nwaves * 2 * E floats, nwaves a multiple of 4 = waves of the launch), dw = sum_rows g * xhat and
+ * db = sum_rows g in a fixed summation order (added to when accumulate). */
+int mpg_layernorm_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, float* stats, int M,
+                      int E, float eps, void* stream);
+int mpg_layernorm_bwd(const float* g, int ldg, const float* x, int ldx, const float* w, const float* stats, float* dx,
+                      int lddx, float* part, int nwaves, float* dw, float* db, int accumulate, int M, int E, void* stream);
+
 /* ---- optimisers --------------------------------------------------------------------------------
  * One launch over one flat buffer of n parameters; `gscale` multiplies the gradient first (1/world after a
  * summing all-reduce).  They replace torch.optim.*.step() as the reference builds them (setup_training.py:1511-1523):

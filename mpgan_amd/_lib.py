@@ -164,6 +164,9 @@ SIGNATURES = {
     "mpg_gen_tail_bwd": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mpg_disc_head_fwd": (C.c_int, [C.POINTER(MpgDiscHead), C.c_void_p]),
     "mpg_disc_head_bwd": (C.c_int, [C.POINTER(MpgDiscHead), C.c_void_p]),
+    "mpg_layernorm_fwd": (C.c_int, [_fp, C.c_int, _fp, _fp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "mpg_layernorm_bwd": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int,
+                                    C.c_int, C.c_int, C.c_void_p]),
     "mpg_rmsprop": (C.c_int, [_fp, _fp, _fp, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "mpg_adam": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                            C.c_float, C.c_void_p]),

@@ -176,7 +176,95 @@ __global__ __launch_bounds__(256) void disc_head_reduce_kernel(const MpgDiscHead
     }
 }
 
+// ---- LayerNorm over the last dimension (GAPT's MAB with layer_norm: gapt/model.py:118-120, :131-136)
+// one wave per row; lane = feature (looped for E > 64); mean / rstd saved for the backward
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float* __restrict__ y, int ldy,
+                                                            float* __restrict__ stats, int M, int E, float eps) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * ldx;
+    float s = 0.f;
+    for (int f = lane; f < E; f += 64) s += xr[f];
+    const float mean = wave_sum(s) / (float)E;
+    float v = 0.f;
+    for (int f = lane; f < E; f += 64) { const float d = xr[f] - mean; v += d * d; }
+    const float rstd = rsqrtf(wave_sum(v) / (float)E + eps);
+    for (int f = lane; f < E; f += 64) y[(size_t)row * ldy + f] = (xr[f] - mean) * rstd * w[f] + b[f];
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
+// dx per row; the waves of a workgroup walk rows (stride = all waves of the grid) and keep their share of
+// dw = sum_rows g * xhat and db = sum_rows g in registers: partial sums [wave][2][E], reduced in fixed order afterwards
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ w, const float* __restrict__ stats,
+                                                            float* __restrict__ dx, int lddx, float* __restrict__ part,
+                                                            int M, int E) {
+    const int lane = threadIdx.x & 63, wv = blockIdx.x * 4 + (threadIdx.x >> 6), nwv = gridDim.x * 4;
+    float aw[16], ab[16];   // E <= 1024
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { aw[k] = 0.f; ab[k] = 0.f; }
+    for (int row = wv; row < M; row += nwv) {
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        const float* gr = g + (size_t)row * ldg;
+        const float* xr = x + (size_t)row * ldx;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int f = lane + 64 * k;
+            if (f < E) {
+                const float xh = (xr[f] - mean) * rstd, gw = gr[f] * w[f];
+                s1 += gw; s2 += gw * xh;
+                aw[k] += gr[f] * xh; ab[k] += gr[f];
+            }
+        }
+        s1 = wave_sum(s1) / (float)E; s2 = wave_sum(s2) / (float)E;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int f = lane + 64 * k;
+            if (f < E) {
+                const float xh = (xr[f] - mean) * rstd;
+                dx[(size_t)row * lddx + f] = rstd * (gr[f] * w[f] - s1 - xh * s2);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int f = lane + 64 * k;
+        if (f < E) { part[((size_t)wv * 2 + 0) * E + f] = aw[k]; part[((size_t)wv * 2 + 1) * E + f] = ab[k]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_reduce_kernel(const float* __restrict__ part, int nwv, int E, float* __restrict__ dw,
+                                                               float* __restrict__ db, int accumulate) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= 2 * E) return;
+    const int which = f / E, ff = f % E;
+    float s = 0.f;
+    for (int v = 0; v < nwv; ++v) s += part[((size_t)v * 2 + which) * E + ff];
+    float* dst = which == 0 ? dw : db;
+    dst[ff] = s + (accumulate ? dst[ff] : 0.f);
+}
+
 }  // namespace
+
+extern "C" int mpg_layernorm_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, float* stats,
+                                 int M, int E, float eps, void* stream) {
+    if (M <= 0 || E <= 0) return -1;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, y, ldy, stats, M, E, eps);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mpg_layernorm_bwd(const float* g, int ldg, const float* x, int ldx, const float* w, const float* stats, float* dx,
+                                 int lddx, float* part, int nwaves, float* dw, float* db, int accumulate, int M, int E,
+                                 void* stream) {
+    if (M <= 0 || E <= 0 || E > 1024 || nwaves <= 0 || nwaves % 4 != 0) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nwaves / 4), dim3(256), 0, st, g, ldg, x, ldx, w, stats, dx, lddx, part, M, E);
+    if (dw != nullptr)
+        hipLaunchKernelGGL(layernorm_reduce_kernel, dim3((2 * E + 255) / 256), dim3(256), 0, st, part, nwaves, E, dw, db, accumulate);
+    return (int)hipGetLastError();
+}
 
 extern "C" int mpg_rank_mask(const float* x, int ld_jet, int ld_part, const float* labels, int ld_lab, int B, int N,
                              float* mask, void* stream) {

@@ -6,7 +6,8 @@ ISAB :178-191, GAPT_G :205-274, GAPT_D :277-344).  ``MAB.attention`` keeps the p
 ``nn.MultiheadAttention`` (``in_proj_weight [3E,E]``, ``in_proj_bias``, ``out_proj.weight|bias``) so
 reference checkpoints load; the arithmetic runs in libmpgan_amd.so: projections and the feed-forward
 on the split-16-bit MFMA GEMM, softmax(QK^T)V in the attention-core kernel.
-LayerNorm / batch norm / spectral norm variants are outside the fused path (NotImplementedError).
+LayerNorm (``layer_norm=True``) runs on ``ops.LayerNormFn``; batch norm / spectral norm variants are outside the fused
+path (NotImplementedError).
 """
 from __future__ import annotations
 
@@ -41,12 +42,14 @@ class MAB(nn.Module):
     def __init__(self, embed_dim: int, num_heads: int, ff_layers: list = [], layer_norm: bool = False,
                  dropout_p: float = 0.0, final_linear: bool = True, linear_args={}):
         super().__init__()
-        _unsupported(layer_norm=layer_norm)
         self.embed_dim, self.num_heads = embed_dim, num_heads
         self.attention = _MHAParams(embed_dim)
         self.ff = LinearNet(ff_layers, input_size=embed_dim, output_size=embed_dim, final_linear=final_linear,
                             **linear_args)
         self.layer_norm = layer_norm
+        if layer_norm:  # (registered after ``ff`` as in the reference, so state-dict order matches)
+            self.norm1 = nn.LayerNorm(embed_dim)
+            self.norm2 = nn.LayerNorm(embed_dim)
         self.dropout_p = float(dropout_p)
 
     def forward(self, x: Tensor, y: Tensor, y_mask: Tensor = None):
@@ -71,8 +74,13 @@ class MAB(nn.Module):
             o = ops.FusedPackedAttnFn.apply(q, kv, ignore, B, L, S, self.num_heads)
         # x + out_proj(attention): the residual is added in the projection's own launch
         za = ops.FusedLinearFn.apply(o, att.out_proj.weight, att.out_proj.bias, False, 0.2, 0.0, False, x2)
+        if self.layer_norm:
+            za = ops.LayerNormFn.apply(za, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         z = ops.FusedDropoutFn.apply(za, self.dropout_p, self.training)
-        out = ops.FusedDropoutFn.apply(self.ff(z, resid=z), self.dropout_p, self.training)
+        zf = self.ff(z, resid=z)
+        if self.layer_norm:
+            zf = ops.LayerNormFn.apply(zf, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        out = ops.FusedDropoutFn.apply(zf, self.dropout_p, self.training)
         return out.reshape(B, L, E)
 
 

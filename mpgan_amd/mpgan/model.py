@@ -70,6 +70,9 @@ class MPLayer(nn.Module):
                  fully_connected: bool = True, num_knn: int = 20, self_loops: bool = True, sum: bool = True,
                  **linear_args):
         super().__init__()
+        # clabels / mask_fne_np: the reference appends them with ``labels.repeat(num_nodes * num_knn, 1)`` (:249, :253,
+        # :272, :276), which tiles the [B, C] block: edge row r receives the labels of jet r mod B, not of its own jet.
+        # Reproducing that needs a per-EDGE input of the edge network, not a per-jet one (out of scope).
         _unsupported(pos_diffs=pos_diffs, int_diffs=int_diffs, clabels=clabels, mask_fne_np=mask_fne_np,
                      knn_graph=not fully_connected)
         if list(fe_layers) != [ops.H1, ops.H2, ops.H3] or len(fn_layers) != 2:

@@ -909,3 +909,51 @@ def disc_head_loss(y, mask, w, b, *, mean, sigmoid, p_drop, training, loss, n_re
         h.dw, h.db, h.accumulate = _p(wgrad[0]), _p(wgrad[1]), 1
     check(_lib.lib().mpg_disc_head_bwd(C.byref(h), _stream()), "mpg_disc_head_bwd")
     return out, dy
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dimension (GAPT's MAB.norm1 / norm2, gapt/model.py:118-120, :131-136): one launch
+    forward, one launch + a fixed-order reduction of the weight / bias gradients backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        _chk(x, "x")
+        shp = x.shape
+        E = shp[-1]
+        x2 = x.reshape(-1, E)
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        y = torch.empty((M, E), device=x.device, dtype=torch.float32)
+        stats = torch.empty((M, 2), device=x.device, dtype=torch.float32)
+        check(_lib.lib().mpg_layernorm_fwd(_p(x2), x2.stride(0), _p(w), _p(b), _p(y), E, _p(stats), M, E, eps, _stream()),
+              "mpg_layernorm_fwd")
+        ctx.save_for_backward(x2, w, stats)
+        ctx.params = (w, b)
+        ctx.shp = shp
+        return y.reshape(shp)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x2, w, stats = ctx.saved_tensors
+        M, E = x2.shape
+        g2 = g.reshape(M, E)
+        if g2.stride(1) != 1:
+            g2 = g2.contiguous()
+        dx = torch.empty((M, E), device=g.device, dtype=torch.float32)
+        nwaves = 4 * min(256, (M + 3) // 4)
+        part = torch.empty((nwaves, 2, E), device=g.device, dtype=torch.float32)
+        st = dev_state(g.device)
+        wp, bp = ctx.params
+        gw = _grad_target(wp) if st.grad_into_param else None
+        gb = _grad_target(bp) if st.grad_into_param else None
+        dw = db = None
+        if gw is not None and gb is not None:
+            tw, tb, acc = gw, gb, 1
+        else:
+            dw, db = torch.empty_like(w), torch.empty_like(w)
+            tw, tb, acc = dw, db, 0
+        check(_lib.lib().mpg_layernorm_bwd(_p(g2), g2.stride(0), _p(x2), x2.stride(0), _p(w), _p(stats), _p(dx), E, _p(part),
+                                           nwaves, _p(tw), _p(tb), acc, M, E, _stream()), "mpg_layernorm_bwd")
+        return dx.reshape(ctx.shp), dw, db, None

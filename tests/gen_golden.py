@@ -198,6 +198,26 @@ def main():
             np.savez_compressed(os.path.join(OUT, f"gapt_blocks_{name}_{dt_name}.npz"), **rec)
             print("gapt blocks", name, dt_name)
 
+        # 4b. SAB with LayerNorm (layer_norm=True: gapt/model.py:118-120, :131-136), fp64 only
+        if dt_name == "f64":
+            ln_args = dict(sab_args, layer_norm=True)
+            B, N = 4, 30
+            mask = rand_mask(B, N, 460).to(dt)
+            x0 = seeded((B, N, E), 461, 0.5).to(dt)
+            blk = rga.SAB(**ln_args).to(dt)
+            shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+            blk.load_state_dict(init_state_dict(shapes, seed=60, dtype=dt))
+            x = x0.clone().requires_grad_(True)
+            y = blk(x, rga.model._attn_mask(mask))
+            g = seeded(y.shape, 462).to(dt)
+            (y * g).sum().backward()
+            rec = dict(x=x0.numpy(), mask=mask.numpy(), y=y.detach().numpy(), g=g.numpy(), dx=x.grad.numpy(),
+                       keys=np.array(sorted(shapes)), shapes=np.array([str(shapes[k]) for k in sorted(shapes)]))
+            for k, p in blk.named_parameters():
+                rec["grad__" + k] = summarize(k, p.grad)
+            np.savez_compressed(os.path.join(OUT, "gapt_sab_layernorm_f64.npz"), **rec)
+            print("gapt sab layer_norm", float(y.abs().max()))
+
         B, N = 6, 30
         Gg.to(dt).eval(); Dg.to(dt).eval()
         Gg.load_state_dict(init_state_dict(gapt_param_shapes(True), seed=31, dtype=dt))

@@ -96,8 +96,10 @@ def test_unsupported_options_raise():
         MPLayer(32, [64, 64], [256, 256], 32)
     with pytest.raises(NotImplementedError):
         LinearNet([8, 8], batch_norm=True)
-    with pytest.raises(NotImplementedError):
-        MAB(64, 4, layer_norm=True)
+    with pytest.raises(NotImplementedError):   # the reference tiles these over EDGES (labels of jet r mod B on edge row r)
+        MPLayer(32, [96, 160, 192], [256, 256], 32, clabels=1)
+    m = MAB(64, 4, layer_norm=True)            # LayerNorm is on the HIP path (ops.LayerNormFn)
+    assert [k for k in m.state_dict() if "norm" in k] == ["norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"]
 
 
 def test_product_does_not_import_the_oracle():

@@ -127,3 +127,41 @@ def test_gapt_full_size_graph_equals_eager():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2:] == b[2:]
     c = _three_steps(512, 30, use_graphs=True, model="gapt", disc_dropout=0.5)
     assert all(np.isfinite(v) for v in c[2:]) and not torch.equal(c[0], a[0])
+
+
+def test_sab_layer_norm_vs_reference_golden():
+    """layer_norm=True (gapt/model.py:118-120, :131-136): ops.LayerNormFn behind both residuals, forward and backward
+    against the reference's fp64 run; then nn.LayerNorm itself as a second opinion on the op alone."""
+    from oracle import train_ref as T
+    from test_oracle_golden import ln_sab_shapes
+    from mpgan_amd.gapt import SAB, _attn_mask
+    from mpgan_amd import ops
+    g = load_golden("gapt_sab_layernorm_f64.npz")
+    blk = SAB(**dict(SAB_ARGS, layer_norm=True)).cuda()
+    blk.load_state_dict(T.init_state_dict(ln_sab_shapes(), 60, torch.float32))
+    assert list(blk.state_dict().keys())[-4:] == ["mab.norm1.weight", "mab.norm1.bias", "mab.norm2.weight", "mab.norm2.bias"]
+    x = torch.from_numpy(g["x"]).float().cuda().requires_grad_(True)
+    y = blk(x, _attn_mask(torch.from_numpy(g["mask"]).float().cuda()))
+    (y * torch.from_numpy(g["g"]).float().cuda()).sum().backward()
+    assert rel_err(y.detach().cpu().numpy(), g["y"]) < TIGHT
+    assert rel_err(x.grad.cpu().numpy(), g["dx"]) < 1e-3
+    for k, p in blk.named_parameters():
+        assert rel_err(summarize(k, p.grad), g["grad__" + k]) < 1e-3, k
+    # the op alone, odd sizes (E not a multiple of 64, rows not a multiple of 4)
+    for M, E in ((37, 64), (5, 100), (1030, 32)):
+        gen = torch.Generator(device="cuda").manual_seed(M)
+        xx = torch.randn(M, E, device="cuda", generator=gen).requires_grad_(True)
+        ln = torch.nn.LayerNorm(E).cuda().double()
+        with torch.no_grad():
+            ln.weight.copy_(torch.randn(E, device="cuda", generator=gen)); ln.bias.copy_(torch.randn(E, device="cuda", generator=gen))
+        w, b = ln.weight.detach().float().requires_grad_(True), ln.bias.detach().float().requires_grad_(True)
+        up = torch.randn(M, E, device="cuda", generator=gen)
+        out = ops.LayerNormFn.apply(xx, w, b, ln.eps)
+        (out * up).sum().backward()
+        xr = xx.detach().double().requires_grad_(True)
+        ref = ln(xr)
+        (ref * up.double()).sum().backward()
+        assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 1e-5
+        assert rel_err(xx.grad.cpu().numpy(), xr.grad.cpu().numpy()) < 1e-5
+        assert rel_err(w.grad.cpu().numpy(), ln.weight.grad.cpu().numpy()) < 1e-5
+        assert rel_err(b.grad.cpu().numpy(), ln.bias.grad.cpu().numpy()) < 1e-5

@@ -169,3 +169,26 @@ def test_train_step(model):
         assert rel_err(summarize(k, v), g["postD__" + k]) < 1e-10, k
     for k, v in sdG.items():
         assert rel_err(summarize(k, v), g["postG__" + k]) < 1e-10, k
+
+
+def ln_sab_shapes(E=64):
+    sh = dict(T._mab_shapes("mab", E))
+    for n in ("norm1", "norm2"):
+        sh[f"mab.{n}.weight"] = (E,)
+        sh[f"mab.{n}.bias"] = (E,)
+    return sh
+
+
+def test_sab_layer_norm_f64():
+    """MAB with layer_norm=True (gapt/model.py:118-120, :131-136) against the reference's own run."""
+    from oracle.gapt_ref import sab_forward
+    g = load_golden("gapt_sab_layernorm_f64.npz")
+    sd = T.init_state_dict(ln_sab_shapes(), seed=60, dtype=torch.float64)
+    sd = {"S." + k: v.requires_grad_(True) for k, v in sd.items()}
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = sab_forward(sd, "S", x, torch.from_numpy(g["mask"]), num_heads=4, layer_norm=True)
+    assert rel_err(y.detach().numpy(), g["y"]) < 1e-12
+    (y * torch.from_numpy(g["g"])).sum().backward()
+    assert rel_err(x.grad.numpy(), g["dx"]) < 1e-10
+    for k, v in sd.items():
+        assert rel_err(summarize(k[2:], v.grad), g["grad__" + k[2:]]) < 1e-9, k
