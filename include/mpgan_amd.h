@@ -153,8 +153,19 @@ typedef struct MpgEdgeFwd {
     int skip_masked;                      /* skip senders with mask == 0 (exact: they add 0)   */
     int f16;                              /* images and activations are fp16 hi/lo (else bf16)  */
     unsigned int* sign3;                  /* optional [B*RB*N][3][64] per-lane sign words of Z3 for the backward (NULL = off) */
+    const unsigned int* nbr;              /* optional k-nearest-neighbour graph: [B*N][ceil(N/32)] words, bit j of row (b, i) set
+                                             <=> sender j is a neighbour of receiver i (mpg_knn_sets); NULL = fully connected */
 } MpgEdgeFwd;
 int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream);
+
+/* mpg_knn_sets: the neighbour sets of MPLayer._getA_knn (mpgan/model.py:319-381) as bit masks for the fused edge kernels.
+ * Per jet: d(i, j) = || s_j x_j - x_i + 1e-12 || over the F node features, s_j = 1 for a real sender and 1e4 for a
+ * zero-masked one (:333-335); the senders of receiver i are those of rank [first, first + k) in ascending distance
+ * (first = 0 with self loops, 1 without; equal distances in index order).  nbr is [B*N][ceil(N/32)] words.  Running
+ * the fully-connected kernels over all N senders with these bits as a per-edge factor gives the reference's
+ * gather / fe / sum over the k gathered neighbours (mean: agg_scale = 1/k); N <= 192. */
+int mpg_knn_sets(const float* x, int ldx, const float* mask, int B, int N, int F, int k, int self_loops,
+                 unsigned int* nbr, void* stream);
 
 /* mpg_edge_bwd: autograd backward of the same span, data path.  Given dagg = dL/dagg and the
  * forward's sign words it produces
@@ -176,6 +187,7 @@ typedef struct MpgEdgeBwd {
     float alpha, agg_scale;
     const uint64_t* seed; uint32_t tag_base, thr; float dscale;
     int f16;
+    const unsigned int* nbr;              /* as MpgEdgeFwd.nbr */
 } MpgEdgeBwd;
 int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream);
 
@@ -196,6 +208,7 @@ typedef struct MpgEdgeDw {
     float alpha, agg_scale;
     const uint64_t* seed; uint32_t tag_base, thr; float dscale;
     int f16;
+    const unsigned int* nbr;              /* as MpgEdgeFwd.nbr */
 } MpgEdgeDw;
 int mpg_edge_dw(const MpgEdgeDw* p, void* stream);
 

@@ -47,7 +47,7 @@ class MpgEdgeFwd(C.Structure):
         ("alpha", C.c_float), ("agg_scale", C.c_float),
         ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
         ("skip_masked", C.c_int), ("f16", C.c_int),
-        ("sign3", _fp),
+        ("sign3", _fp), ("nbr", _fp),
     ]
 
 
@@ -63,7 +63,7 @@ class MpgEdgeBwd(C.Structure):
         ("B", C.c_int), ("N", C.c_int), ("SC", C.c_int),
         ("alpha", C.c_float), ("agg_scale", C.c_float),
         ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
-        ("f16", C.c_int),
+        ("f16", C.c_int), ("nbr", _fp),
     ]
 
 
@@ -77,7 +77,7 @@ class MpgEdgeDw(C.Structure):
         ("B", C.c_int), ("N", C.c_int),
         ("alpha", C.c_float), ("agg_scale", C.c_float),
         ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
-        ("f16", C.c_int),
+        ("f16", C.c_int), ("nbr", _fp),
     ]
 
 
@@ -159,6 +159,7 @@ SIGNATURES = {
     "mpg_edge_dw": (C.c_int, [C.POINTER(MpgEdgeDw), C.c_void_p]),
     "mpg_attn_fwd": (C.c_int, [C.POINTER(MpgAttn), C.c_void_p]),
     "mpg_attn_bwd": (C.c_int, [C.POINTER(MpgAttn), C.c_void_p]),
+    "mpg_knn_sets": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_void_p]),
     "mpg_rank_mask": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, C.c_void_p]),
     "mpg_gen_tail_fwd": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mpg_gen_tail_bwd": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -129,7 +129,11 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
     for (int j = j0 + w; j < j1; j += 4) {
         const float mj = p.mask ? p.mask[b * p.N + j] : 1.f;
         if ((p.skip_masked & 1) && mj == 0.f) continue;  // wave-uniform
-        const float mjs = mj * p.dscale * (1.f / SC_E3);  // (the layer-3 output carries SC_E3)
+        float mjs = mj * p.dscale * (1.f / SC_E3);  // (the layer-3 output carries SC_E3)
+        if (p.nbr != nullptr) {  // k-nearest-neighbour graph: sender j counts for this lane's receiver only if its bit is set
+            const unsigned int wb = p.nbr[(size_t)(b * p.N + (vi ? i : 0)) * ((p.N + 31) >> 5) + (j >> 5)];
+            mjs = ((wb >> (j & 31)) & 1u) ? mjs : 0.f;
+        }
         const uint32_t erow = (uint32_t)((b * p.N + i) * p.N + j);
         const float* cj = lc + (j - j0) * H1;
 

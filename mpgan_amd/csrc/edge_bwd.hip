@@ -606,6 +606,12 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsi
             areg[n][4] = v.x; areg[n][5] = v.y; areg[n][6] = v.z; areg[n][7] = v.w;
         }
     };
+    unsigned int nbw = 0xffffffffu;  // this receiver's neighbour word holding the block's sender (k-NN graphs)
+    const __amdgpu_buffer_rsrc_t rN = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int*>(p.nbr), 0, p.nbr ? p.B * p.N * ((p.N + 31) >> 5) * 4 : 0, 0x00020000);
+    auto load_nb = [&](int blk) {  // (with no graph the resource is empty: the load returns 0 and is ignored below)
+        const int j = blk % p.N, brb = blk / p.N, rb = brb % RB, b = brb / RB, ii = rb * 32 + r;
+        nbw = __builtin_amdgcn_raw_buffer_load_b32(rN, ((b * p.N + (ii < p.N ? ii : 0)) * ((p.N + 31) >> 5) + (j >> 5)) * 4, 0, 0);
+    };
     auto load_sw = [&](int blk) {  // word (tile >> 1) = n of lane (r, h)
 #pragma unroll
         for (int n = 0; n < 3; ++n) sw[n] = __builtin_amdgcn_raw_buffer_load_b32(rS, voS, blk * (T3 * 32 * 4) + n * 256, 0);
@@ -664,7 +670,8 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsi
             if (!exp_noload) load_e2(pre, n);
         }
         // dZ3 = dagg * slope(sign bit) * keep3
-        const float dscl_1 = dscl, dscl_a = dscl * p.alpha;
+        const float in_set = (p.nbr == nullptr || ((nbw >> (j & 31)) & 1u)) ? 1.f : 0.f;
+        const float dscl_1 = dscl * in_set, dscl_a = dscl * p.alpha * in_set;
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
             const int m = 2 * n + (cg >> 2), c = cg + 8 * n;
@@ -685,7 +692,7 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsi
                 *reinterpret_cast<bf16x8*>(buf + DW_Z3L + r * DW_RS3 + c * 16) = ll;
             } else if (hh[0] == (__bf16)123.f) db2[0][0] += (float)ll[1];
         }
-        if (!exp_noload) load_sw(pre);
+        if (!exp_noload) { load_sw(pre); load_nb(pre); }
         // E1 = keep1 * lrelu(a_i + c_j)   (chunk groups 4..7: the second chunk repeats the first)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
@@ -713,7 +720,7 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsi
     int nxt = dw_next_valid(vbits, blk0, cur + 1, blk1);
     // `pre` is clamped to the last block of the range: past the end the prefetches fetch that block again, unused
     if (cur < blk1) {
-        load_jet(cur); load_sw(cur); load_c(cur);
+        load_jet(cur); load_sw(cur); load_nb(cur); load_c(cur);
 #pragma unroll
         for (int n = 0; n < 3; ++n) { load_e2(cur, n); load_z2(cur, n); }
         build(cur, smem, min(nxt, blk1 - 1));

@@ -201,7 +201,12 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
         for (int sd = 0; sd < 2; ++sd) {
             const float mj = p.mask ? p.mask[b * p.N + jj[sd]] : 1.f;
             const float mjs = (sd == 0 || has2) ? mj * p.dscale : 0.f;
-            cpos[sd] = mjs; cneg[sd] = mjs * p.alpha;
+            float in_set = 1.f;
+            if (p.nbr != nullptr) {  // k-nearest-neighbour graph: the edge (i, j) exists only if j's bit is set in i's row
+                const unsigned int wb = p.nbr[(size_t)(b * p.N + (i < p.N ? i : 0)) * ((p.N + 31) >> 5) + (jj[sd] >> 5)];
+                in_set = ((wb >> (jj[sd] & 31)) & 1u) ? 1.f : 0.f;
+            }
+            cpos[sd] = mjs * in_set; cneg[sd] = mjs * p.alpha * in_set;
             erow[sd] = (uint32_t)((b * p.N + i) * p.N + jj[sd]);
             erow2[sd] = erow[sd] + opaque_zero;
             const int blk = (b * RB + rb) * p.N + jj[sd];

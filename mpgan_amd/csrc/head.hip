@@ -176,6 +176,41 @@ __global__ __launch_bounds__(256) void disc_head_reduce_kernel(const MpgDiscHead
     }
 }
 
+// ---- k-nearest-neighbour sets (MPLayer._getA_knn, mpgan/model.py:319-381) as bit masks; one workgroup per jet
+__global__ __launch_bounds__(256) void knn_sets_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ mask, int N, int F,
+                                                       int k, int first, unsigned int* __restrict__ nbr) {
+    extern __shared__ float dist[];   // [N][N]: d(i, j)
+    const int b = blockIdx.x, NW = (N + 31) >> 5;
+    const float* xb = x + (size_t)b * N * ldx;
+    for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
+        const int i = e / N, j = e % N;
+        const float sj = (mask != nullptr && mask[(size_t)b * N + j] == 0.f) ? 1e4f : 1.f;   // ((1 - mul) mask + mul), mul = 1e4
+        float acc = 0.f;
+        for (int f = 0; f < F; ++f) {
+            const float d = sj * xb[(size_t)j * ldx + f] - xb[(size_t)i * ldx + f] + 1e-12f;
+            acc += d * d;
+        }
+        dist[e] = sqrtf(acc);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < N * NW; e += blockDim.x) {
+        const int i = e / NW, wq = e % NW;
+        unsigned int bits = 0u;
+        for (int jj = 0; jj < 32; ++jj) {
+            const int j = wq * 32 + jj;
+            if (j >= N) break;
+            const float dij = dist[i * N + j];
+            int rank = 0;
+            for (int l = 0; l < N; ++l) {
+                const float dil = dist[i * N + l];
+                rank += (dil < dij) || (dil == dij && l < j);
+            }
+            if (rank >= first && rank < first + k) bits |= 1u << jj;
+        }
+        nbr[((size_t)b * N + i) * NW + wq] = bits;
+    }
+}
+
 // ---- LayerNorm over the last dimension (GAPT's MAB with layer_norm: gapt/model.py:118-120, :131-136)
 // one wave per row; lane = feature (looped for E > 64); mean / rstd saved for the backward
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
@@ -247,6 +282,15 @@ __global__ __launch_bounds__(256) void layernorm_reduce_kernel(const float* __re
 }
 
 }  // namespace
+
+extern "C" int mpg_knn_sets(const float* x, int ldx, const float* mask, int B, int N, int F, int k, int self_loops,
+                            unsigned int* nbr, void* stream) {
+    if (B <= 0 || N <= 0 || F <= 0 || k <= 0 || N > 192) return -1;
+    const int lds = N * N * (int)sizeof(float);
+    MPG_ENSURE_LDS(knn_sets_kernel, lds);
+    hipLaunchKernelGGL(knn_sets_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, x, ldx, mask, N, F, k, self_loops ? 0 : 1, nbr);
+    return (int)hipGetLastError();
+}
 
 extern "C" int mpg_layernorm_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, float* stats,
                                  int M, int E, float eps, void* stream) {

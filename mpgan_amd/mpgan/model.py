@@ -7,9 +7,10 @@ MPGenerator :572-757, MPDiscriminator :760-894), so ``setup_training.setup_mpgan
 libmpgan_amd.so (HIP, gfx950); there is no composite/CPU fallback -- option combinations the
 fused path does not cover raise ``NotImplementedError`` at construction time.
 
-Covered (= the reference's default and every published ``mp_*`` configuration): fully connected
-graph, no edge features, ``clabels=0``, ``mask_fne_np=False``, no batch/spectral norm,
-``fe=[96,160,192]``, two hidden ``fn`` layers, ``mask_c`` masking, ``dea`` pooling.
+Covered (= the reference's default and every published ``mp_*`` configuration, plus the k-nearest-neighbour
+graph): fully connected or ``fully_connected=False`` with ``num_knn`` / ``self_loops``, no edge features,
+``clabels=0``, ``mask_fne_np=False``, no batch/spectral norm, ``fe=[96,160,192]``, two hidden ``fn`` layers,
+``mask_c`` masking, ``dea`` pooling.
 """
 from __future__ import annotations
 
@@ -73,14 +74,16 @@ class MPLayer(nn.Module):
         # clabels / mask_fne_np: the reference appends them with ``labels.repeat(num_nodes * num_knn, 1)`` (:249, :253,
         # :272, :276), which tiles the [B, C] block: edge row r receives the labels of jet r mod B, not of its own jet.
         # Reproducing that needs a per-EDGE input of the edge network, not a per-jet one (out of scope).
-        _unsupported(pos_diffs=pos_diffs, int_diffs=int_diffs, clabels=clabels, mask_fne_np=mask_fne_np,
-                     knn_graph=not fully_connected)
+        _unsupported(pos_diffs=pos_diffs, int_diffs=int_diffs, clabels=clabels, mask_fne_np=mask_fne_np)
         if list(fe_layers) != [ops.H1, ops.H2, ops.H3] or len(fn_layers) != 2:
             raise NotImplementedError("mpgan_amd: the fused edge kernel is built for fe_layers=[96,160,192] and two "
                                       f"hidden fn layers (got fe={list(fe_layers)}, fn={list(fn_layers)})")
         self.input_node_size, self.output_node_size = input_node_size, output_node_size
         self.fe_layers, self.fn_layers = list(fe_layers), list(fn_layers)
         self.sum = sum
+        # fully_connected=False: every receiver aggregates over its num_knn nearest senders only (reference _getA_knn);
+        # here the fused kernels still walk all N senders with the neighbour sets as a per-edge 0/1 factor
+        self.fully_connected, self.num_knn, self.self_loops = fully_connected, int(num_knn), bool(self_loops)
         self.fe = LinearNet(self.fe_layers, input_size=2 * input_node_size, final_linear=False, **linear_args)
         self.fn = LinearNet(self.fn_layers, input_size=self.fe_layers[-1] + input_node_size,
                             output_size=output_node_size, final_linear=True, **linear_args)
@@ -89,11 +92,17 @@ class MPLayer(nn.Module):
                 num_jet_particles: Tensor = None) -> Tensor:
         assert not (use_mask and mask is None), "need ``mask`` tensor if using ``use_mask`` option"
         fe, fn = self.fe.net, self.fn.net
+        nbr = None
+        if not self.fully_connected:
+            if self.num_knn + int(not self.self_loops) > x.shape[1]:
+                raise ValueError(f"num_knn = {self.num_knn} neighbours (self_loops = {self.self_loops}) out of {x.shape[1]} nodes")
+            with torch.no_grad():
+                nbr = ops.knn_sets(x, mask if use_mask else None, self.num_knn, self.self_loops)
         return ops.FusedMPLayerFn.apply(
             x, mask if use_mask else None,
             fe[0].weight, fe[0].bias, fe[1].weight, fe[1].bias, fe[2].weight, fe[2].bias,
             fn[0].weight, fn[0].bias, fn[1].weight, fn[1].bias, fn[2].weight, fn[2].bias,
-            self.sum, self.fe.leaky_relu_alpha, self.fe.dropout_p, self.training, self._packed())
+            self.sum, self.fe.leaky_relu_alpha, self.fe.dropout_p, self.training, self._packed(), nbr, self.num_knn)
 
     def _packed(self) -> "ops.PackedMPLayer":
         """Persistent weight images of this layer for the current mode (dropout scale) -- rebuilt when a

@@ -400,7 +400,9 @@ class FusedMPLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mask, W1, b1, W2, b2, W3, b3, V1, c1, V2, c2, V3, c3, sum_agg, alpha, p_drop, training,
-                packed=None):
+                packed=None, nbr=None, num_knn=0):
+        """``nbr`` (from ``knn_sets``) restricts receiver i's senders to its ``num_knn`` nearest neighbours
+        (``fully_connected=False``, mpgan/model.py:319-381); the mean then divides by ``num_knn`` (:267)."""
         _chk(x, "x")
         B, N, F = x.shape
         V = B * N
@@ -432,7 +434,9 @@ class FusedMPLayerFn(torch.autograd.Function):
         e.W2img, e.W3img = pk.ptr("W2"), pk.ptr("W3")
         e.b2, e.b3, e.agg = _p(b2), _p(b3), _p(aggp)
         e.B, e.N, e.SC = B, N, SC
-        e.alpha, e.agg_scale = alpha, 1.0 if sum_agg else 1.0 / N
+        agg_scale = 1.0 if sum_agg else 1.0 / (num_knn if nbr is not None else N)
+        e.alpha, e.agg_scale = alpha, agg_scale
+        e.nbr = None if nbr is None else C.c_void_p(nbr.data_ptr())
         e.seed, e.tag_base, e.thr, e.dscale = _p(seed_t), tag, thr, dscale
         e.skip_masked = int(OPTIONS["skip_masked"])
         e.f16 = int(f16)
@@ -454,16 +458,17 @@ class FusedMPLayerFn(torch.autograd.Function):
               A=agg, lda=H3, K1=H3, A2=x2, lda2=x2.stride(0), alpha=alpha, seed_t=seed_t, f16=f16, ascale=SC_ACT)
         ctx.packed = pk
 
-        ctx.save_for_backward(x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3)
-        ctx.cfg = (B, N, F, sum_agg, alpha, thr, dscale, tag, SC, f16)
+        ctx.save_for_backward(x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3, nbr)
+        ctx.cfg = (B, N, F, agg_scale, alpha, thr, dscale, tag, SC, f16)
         return y.reshape(B, N, V3.shape[0])
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3 = ctx.saved_tensors
+        x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3, nbr = ctx.saved_tensors
         pk = ctx.packed
-        B, N, F, sum_agg, alpha, thr, dscale, tag, SC, f16 = ctx.cfg
+        B, N, F, agg_scale, alpha, thr, dscale, tag, SC, f16 = ctx.cfg
+        nbr_p = None if nbr is None else C.c_void_p(nbr.data_ptr())
         V = B * N
         dev = x2.device
         seed_t = seed_tensor(dev)
@@ -522,7 +527,7 @@ class FusedMPLayerFn(torch.autograd.Function):
         e.stageE2 = None if stE2 is None else C.c_void_p(stE2.data_ptr())
         e.stageZ2 = None if stZ2 is None else C.c_void_p(stZ2.data_ptr())
         e.B, e.N, e.SC = B, N, SC
-        e.alpha, e.agg_scale = alpha, 1.0 if sum_agg else 1.0 / N
+        e.alpha, e.agg_scale, e.nbr = alpha, agg_scale, nbr_p
         e.seed, e.tag_base, e.thr, e.dscale = _p(seed_t), tag, thr, dscale
         e.f16 = int(f16)
         check(_lib.lib().mpg_edge_bwd(C.byref(e), _stream()), "mpg_edge_bwd")
@@ -545,7 +550,7 @@ class FusedMPLayerFn(torch.autograd.Function):
             d.part, d.nwg = _p(part), nwg
             d.dW3, d.dW2, d.db3, d.db2, d.accumulate = _p(dW3), _p(dW2), _p(db3), _p(db2), int(direct)
             d.B, d.N = B, N
-            d.alpha, d.agg_scale = alpha, 1.0 if sum_agg else 1.0 / N
+            d.alpha, d.agg_scale, d.nbr = alpha, agg_scale, nbr_p
             d.seed, d.tag_base, d.thr, d.dscale = _p(seed_t), tag, thr, dscale
             d.f16 = int(f16)
             check(_lib.lib().mpg_edge_dw(C.byref(d), _stream()), "mpg_edge_dw")
@@ -569,7 +574,7 @@ class FusedMPLayerFn(torch.autograd.Function):
                   A=dap, lda=H1, K1=H1, a_slabs=SC, a_slab_stride=V * H1, A2=dc, lda2=dc.stride(0), alpha=alpha, f16=False)
             dx = dx.reshape(B, N, F)
         return (dx, None, dW1, db1, dW2, db2, dW3, db3, dV1, dc1, dV2, dc2, dV3, dc3,
-                None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 def _grad_target(t):
@@ -765,6 +770,22 @@ def rank_mask(first_feature: torch.Tensor, labels: torch.Tensor, num_particles: 
     check(_lib.lib().mpg_rank_mask(_p(first_feature), first_feature.stride(0), first_feature.stride(1), _p(lab), lab.stride(0),
                                    B, N, _p(out), _stream()), "mpg_rank_mask")
     return out
+
+
+def knn_sets(x: torch.Tensor, mask: Optional[torch.Tensor], num_knn: int, self_loops: bool = True):
+    """The k-nearest-neighbour graph of MPLayer._getA_knn (mpgan/model.py:319-381) as bit masks [B * N, ceil(N / 32)]
+    (int32): bit j of row (b, i) is set when sender j is among the ``num_knn`` nearest neighbours of receiver i
+    (zero-masked senders pushed 1e4 times further away, :333-335).  One launch; no gradient (the selection is discrete)."""
+    _chk(x, "x")
+    B, N, F = x.shape
+    x2 = x.reshape(B * N, F)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    m1 = None if mask is None else mask.reshape(B * N).contiguous()
+    nbr = torch.empty((B * N, (N + 31) // 32), device=x.device, dtype=torch.int32)
+    check(_lib.lib().mpg_knn_sets(_p(x2), x2.stride(0), _p(m1), B, N, F, num_knn, int(self_loops),
+                                  C.c_void_p(nbr.data_ptr()), _stream()), "mpg_knn_sets")
+    return nbr
 
 
 ACT_CODES = {"": 0, "tanh": 1, "sigmoid": 2}

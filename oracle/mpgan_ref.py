@@ -104,8 +104,11 @@ def mplayer_forward(
     n_fn: int = 3,
     exact_concat: bool = False,
     probe: Optional[list] = None,
+    knn: Optional[tuple] = None,
 ) -> Tensor:
-    """One fully-connected message-passing layer.
+    """One message-passing layer, fully connected or (``knn`` = (num_knn, self_loops)) over each node's nearest
+    neighbours as ``MPLayer._getA_knn`` picks them (mpgan/model.py:319-381): distances || s_j x_j - x_i + 1e-12 || with
+    s_j = 1e4 for zero-masked senders, ascending sort, the ``num_knn`` entries from position 0 (self loops) or 1.
 
     x    [B,N,F]; mask [B,N,1] (1 real / 0 padded) or None
     keeps: optional dict of keep masks 'e0','e1','e2' with shape [B,N,N,H_l] and
@@ -117,6 +120,29 @@ def mplayer_forward(
     k = keeps or {}
     w1 = sd[f"{prefix}.fe.net.0.weight"]
     b1 = sd[f"{prefix}.fe.net.0.bias"]
+    if knn is not None:
+        num_knn, self_loops = knn
+        xs = x if mask is None else ((1 - 1e4) * mask + 1e4) * x               # (:333-335)
+        dists = torch.norm(xs.unsqueeze(1) - x.unsqueeze(2) + 1e-12, dim=3)    # [B, i, j]
+        first = 0 if self_loops else 1
+        idx = torch.sort(dists, dim=2)[1][:, :, first:first + num_knn]         # [B, N, k]
+        gather = lambda t: torch.gather(t.unsqueeze(1).expand(B, N, N, t.shape[-1]), 2,
+                                        idx.unsqueeze(3).expand(B, N, num_knn, t.shape[-1]))
+        xg = gather(x)                                                         # neighbours' features [B, N, k, F]
+        a = x @ w1[:, :F].t() + b1
+        e = a.unsqueeze(2) + xg @ w1[:, F:].t()
+        if probe is not None:
+            probe.append(e.detach())
+        e = _drop(leaky(e, alpha), k.get("e0"), p)
+        for l in range(1, n_fe):
+            e = e @ sd[f"{prefix}.fe.net.{l}.weight"].t() + sd[f"{prefix}.fe.net.{l}.bias"]
+            if probe is not None:
+                probe.append(e.detach())
+            e = _drop(leaky(e, alpha), k.get(f"e{l}"), p)
+        if mask is not None:
+            e = e * gather(mask)
+        agg = e.sum(dim=2) if sum_agg else e.mean(dim=2)
+        return _node_net(sd, prefix, agg, x, n_fn, alpha, p, k, probe)
     if exact_concat:
         xi = x.unsqueeze(2).expand(B, N, N, F)
         xj = x.unsqueeze(1).expand(B, N, N, F)
@@ -140,6 +166,11 @@ def mplayer_forward(
     agg = e.sum(dim=2)
     if not sum_agg:
         agg = agg / N
+    return _node_net(sd, prefix, agg, x, n_fn, alpha, p, k, probe)
+
+
+def _node_net(sd, prefix, agg, x, n_fn, alpha, p, k, probe):
+    """fn on [agg ; x] (mpgan/model.py:268-279)."""
     h = torch.cat((agg, x), dim=2)
     for l in range(n_fn):
         w = sd[f"{prefix}.fn.net.{l}.weight"]

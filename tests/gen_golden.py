@@ -97,6 +97,28 @@ def main():
             np.savez_compressed(os.path.join(OUT, f"mplayer_{name}_{dt_name}.npz"), **rec)
             print("mplayer", name, dt_name, float(y.abs().max()))
 
+    # ------------------------------------------------------------------ 1b. MPLayer on the k-nearest-neighbour graph
+    for ci, (name, B, N, F, out, knn, loops, sm, use_mask) in enumerate([
+            ("knn10", 3, 30, 32, 32, 10, True, True, True), ("knn5nl", 3, 30, 3, 32, 5, False, False, True),
+            ("knn20u", 2, 30, 32, 32, 20, True, True, False)]):
+        dt = torch.float64
+        layer = rmp.MPLayer(F, fe, fn, out, sum=sm, fully_connected=False, num_knn=knn, self_loops=loops).to(dt)
+        shapes = {k: tuple(v.shape) for k, v in layer.state_dict().items()}
+        layer.load_state_dict(init_state_dict(shapes, seed=80 + ci, dtype=dt))
+        x = seeded((B, N, F), 180 + ci, 0.5).to(dt).requires_grad_(True)
+        mask = rand_mask(B, N, 280 + ci).to(dt) if use_mask else None
+        g = seeded((B, N, out), 380 + ci).to(dt)
+        y = layer(x, use_mask, mask)
+        (y * g).sum().backward()
+        rec = dict(x=x.detach().numpy(), g=g.numpy(), y=y.detach().numpy(), dx=x.grad.numpy(), seed=80 + ci, sum=int(sm),
+                   out=out, num_knn=knn, self_loops=int(loops))
+        if mask is not None:
+            rec["mask"] = mask.numpy()
+        for k, p in layer.named_parameters():
+            rec["grad__" + k] = summarize(k, p.grad)
+        np.savez_compressed(os.path.join(OUT, f"mplayer_{name}_f64.npz"), **rec)
+        print("mplayer", name, float(y.abs().max()))
+
     # ------------------------------------------------------------------ default args / manifests
     sys.argv = ["gen_golden"]
     args = st.process_args(st.parse_args())

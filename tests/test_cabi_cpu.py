@@ -91,7 +91,8 @@ def test_unsupported_options_raise():
     from mpgan_amd.mpgan import MPLayer, LinearNet
     from mpgan_amd.gapt import MAB
     with pytest.raises(NotImplementedError):
-        MPLayer(32, [96, 160, 192], [256, 256], 32, fully_connected=False)
+        MPLayer(32, [96, 160, 192], [256, 256], 32, pos_diffs=True)
+    assert MPLayer(32, [96, 160, 192], [256, 256], 32, fully_connected=False, num_knn=10).num_knn == 10   # k-NN graphs are on the path
     with pytest.raises(NotImplementedError):
         MPLayer(32, [64, 64], [256, 256], 32)
     with pytest.raises(NotImplementedError):

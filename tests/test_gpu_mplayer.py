@@ -92,7 +92,9 @@ def _hip_signs(y, B, N):
     (edge.hip: word q of lane (r, h), bit 31 - (16 (tile & 1) + reg) for tile >> 1 == q; reg 4g+t <-> feature
     32 tile + 8g + 4h + t), the node network from the signs of its saved outputs.  [B,N,N,*] / [B,N,*] like the
     oracle's probes; fe layer 3 is only defined for unmasked senders."""
-    x2, m1, ac, agg, h1, h2, *_, sign3 = _fused_node(y).saved_tensors
+    saved = _fused_node(y).saved_tensors   # (x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3, nbr)
+    x2, m1, ac, agg, h1, h2 = saved[:6]
+    sign3 = saved[14]
     a, c = ac[:, :96].reshape(B, N, 96), ac[:, 96:].reshape(B, N, 96)
     z1neg = ((a.unsqueeze(2) + c.unsqueeze(1)) < 0).cpu()
     RB = (N + 31) // 32
@@ -307,6 +309,93 @@ def test_mplayer_vs_reference_golden(name, F, out, ci):
         e = rel_err(summarize(k, p.grad), g64["grad__" + k])
         c = rel_err(g["grad__" + k], g64["grad__" + k])
         assert e < max(TOL, 3 * c), (k, e, c)
+
+
+def _ref_knn_bits(x, mask, k, self_loops):
+    """Neighbour sets as the reference picks them (mpgan/model.py:319-381), as a boolean [B, N(i), N(j)] matrix."""
+    B, N, _ = x.shape
+    xs = x if mask is None else ((1 - 1e4) * mask + 1e4) * x
+    d = torch.norm(xs.unsqueeze(1) - x.unsqueeze(2) + 1e-12, dim=3)
+    first = 0 if self_loops else 1
+    idx = torch.sort(d, dim=2)[1][:, :, first:first + k]
+    m = torch.zeros(B, N, N, dtype=torch.bool)
+    m.scatter_(2, idx, True)
+    return m
+
+
+@pytest.mark.parametrize("name,F", [("knn10", 32), ("knn5nl", 3), ("knn20u", 32)])
+def test_mplayer_knn_vs_reference_golden(name, F):
+    """fully_connected=False: the neighbour sets (mpg_knn_sets) are exactly the reference's, and the fused layer with the
+    sets as a per-edge factor reproduces the reference's gather / fe / sum (or mean over k) forward and backward."""
+    from oracle import train_ref as T
+    from conftest import summarize
+    from mpgan_amd import ops
+    from mpgan_amd.mpgan import MPLayer
+    g = load_golden(f"mplayer_{name}_f64.npz")
+    k, loops, sm, out = int(g["num_knn"]), bool(g["self_loops"]), bool(g["sum"]), int(g["out"])
+    x64 = torch.from_numpy(g["x"])
+    mask64 = torch.from_numpy(g["mask"]) if "mask" in g else None
+    x = x64.float().to(_dev()).requires_grad_(True)
+    mask = None if mask64 is None else mask64.float().to(_dev())
+    B, N, _ = x.shape
+    bits = ops.knn_sets(x.detach(), mask, k, loops).cpu().numpy().astype(np.uint32).reshape(B, N)   # N <= 32: one word
+    got = ((bits[:, :, None] >> np.arange(N, dtype=np.uint32)[None, None, :]) & 1).astype(bool)
+    ref = _ref_knn_bits(x64, mask64, k, loops).numpy()
+    # zero-masked padded senders coincide after the 1e4 scaling only if their features are identical (not the case for
+    # these random features), so the sets must agree exactly
+    assert (got == ref).all() and (got.sum(2) == k).all()
+    for alpha, strict in ((1.0, True), (0.2, False)):
+        sd64 = T.init_state_dict(_mplayer_shapes(F, out), seed=int(g["seed"]), dtype=torch.float64)
+        layer = MPLayer(F, [96, 160, 192], [256, 256], out, sum=sm, fully_connected=False, num_knn=k, self_loops=loops,
+                        leaky_relu_alpha=alpha).to(_dev())
+        layer.load_state_dict({kk: v.float() for kk, v in sd64.items()})
+        xx = x64.float().to(_dev()).requires_grad_(True)
+        y = layer(xx, mask is not None, mask)
+        (y * torch.from_numpy(g["g"]).float().to(_dev())).sum().backward()
+        if strict:  # slope 1: smooth, against the oracle's kNN branch, everything at 1e-4
+            import oracle
+            sdo = {"L." + kk: v.clone().requires_grad_(True) for kk, v in sd64.items()}
+            xo = x64.clone().requires_grad_(True)
+            yo = oracle.mplayer_forward(sdo, "L", xo, mask64, sum_agg=sm, alpha=1.0, knn=(k, loops))
+            (yo * torch.from_numpy(g["g"])).sum().backward()
+            assert rel_err(y.detach().cpu().numpy(), yo.detach().numpy()) < TIGHT
+            assert rel_err(xx.grad.cpu().numpy(), xo.grad.numpy()) < TIGHT
+            for kk, p in layer.named_parameters():
+                assert rel_err(p.grad.cpu().numpy(), sdo["L." + kk].grad.numpy()) < TIGHT, kk
+        else:       # default slope: the reference's own fp64 outputs (kink flips allowed on a few % of dx)
+            assert rel_err(y.detach().cpu().numpy(), g["y"]) < TIGHT
+            dx, rdx = xx.grad.cpu().numpy().astype(np.float64), g["dx"]
+            assert np.abs(dx - rdx).max() < 2e-2 * np.abs(rdx).max()
+            assert float((np.abs(dx - rdx) > 1e-3 * np.abs(rdx).max()).mean()) < 0.05
+            for kk, p in layer.named_parameters():
+                assert rel_err(summarize(kk, p.grad), g["grad__" + kk]) < 2e-2, kk
+
+
+def test_mplayer_knn_n150_and_dropout():
+    """Five receiver blocks / five neighbour words per row, sender chunks, dropout on: runs, finite, and the graph only
+    matters through the sets (k = N with self loops == fully connected, bit for bit)."""
+    from mpgan_amd.mpgan import MPLayer
+    torch.manual_seed(0)
+    B, N, F = 2, 150, 32
+    x = (torch.randn(B, N, F, device=_dev()) * 0.5).requires_grad_(True)
+    mask = (torch.rand(B, N, 1, device=_dev()) < 0.7).float()
+    up = torch.randn(B, N, 32, device=_dev())
+    full = MPLayer(F, [96, 160, 192], [256, 256], 32).to(_dev())
+    knn_all = MPLayer(F, [96, 160, 192], [256, 256], 32, fully_connected=False, num_knn=N, self_loops=True).to(_dev())
+    knn_all.load_state_dict(full.state_dict())
+    outs = []
+    for lay in (full, knn_all):
+        x.grad = None
+        y = lay(x, True, mask)
+        (y * up).sum().backward()
+        outs.append((y.detach().clone(), x.grad.clone(), lay.fe.net[1].weight.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    lay = MPLayer(F, [96, 160, 192], [256, 256], 32, fully_connected=False, num_knn=20, dropout_p=0.5).to(_dev())
+    lay.train()
+    y = lay(x, True, mask)
+    (y * up).sum().backward()
+    assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(lay.fe.net[2].weight.grad).all())
 
 
 def test_mplayer_full_size_smooth():

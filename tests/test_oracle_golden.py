@@ -192,3 +192,19 @@ def test_sab_layer_norm_f64():
     assert rel_err(x.grad.numpy(), g["dx"]) < 1e-10
     for k, v in sd.items():
         assert rel_err(summarize(k[2:], v.grad), g["grad__" + k[2:]]) < 1e-9, k
+
+
+@pytest.mark.parametrize("name,F", [("knn10", 32), ("knn5nl", 3), ("knn20u", 32)])
+def test_mplayer_knn_f64(name, F):
+    """fully_connected=False (MPLayer._getA_knn, mpgan/model.py:319-381): neighbour selection, gather, masked sum / mean."""
+    g = load_golden(f"mplayer_{name}_f64.npz")
+    sd = T.init_state_dict(mplayer_shapes(F, int(g["out"])), seed=int(g["seed"]), dtype=torch.float64)
+    sd = {"L." + k: v.requires_grad_(True) for k, v in sd.items()}
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    mask = torch.from_numpy(g["mask"]) if "mask" in g else None
+    y = mplayer_forward(sd, "L", x, mask, sum_agg=bool(g["sum"]), knn=(int(g["num_knn"]), bool(g["self_loops"])))
+    assert rel_err(y.detach().numpy(), g["y"]) < 1e-12
+    (y * torch.from_numpy(g["g"])).sum().backward()
+    assert rel_err(x.grad.numpy(), g["dx"]) < 1e-11
+    for k, v in sd.items():
+        assert rel_err(summarize(k[2:], v.grad), g["grad__" + k[2:]]) < 1e-10, k
