@@ -139,11 +139,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would misreport n_gpus")
+    # Rehearsal on a one-GPU box (tests/test_gpu_dist.py): MPGAN_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and the
+    # exchange on gloo (RCCL refuses two ranks on one device).  Never set in a real run.
+    share = os.environ.get("MPGAN_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     if torch.cuda.device_count() < (local_rank + 1):
         raise SystemExit(f"rank with LOCAL_RANK={local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    rank, world, pg = mdist.init_from_env("nccl", dev)
+    rank, world, pg = mdist.init_from_env("gloo" if share else "nccl", dev)
     if world > 1:
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
@@ -199,7 +204,8 @@ def main():
         "config": {"workload": f"{args.model.upper()} gluon-like jets, N={N} particles, B={B} per GPU, one "
                                "train_D+train_G iteration (LSGAN, RMSprop, D dropout 0.5)",
                    "global_batch": world * B, "particles": N, "multiplicity": args.dist,
-                   "mean_multiplicity": valid_frac * N, "parallelism": f"dp{world}", "hip_graphs": not args.no_graphs},
+                   "mean_multiplicity": valid_frac * N, "parallelism": f"dp{world}", "hip_graphs": not args.no_graphs,
+                   **({"rehearsal": "all ranks share cuda:0, gloo exchange (MPGAN_BENCH_SHARE_GPU)"} if share else {})},
         "losses": {"D": d_loss, "G": g_loss},
     }
     if args.model == "mpgan":
@@ -212,7 +218,7 @@ def main():
     # rank 0 only, after the timed region, with the collectives switched off (the other ranks are not taking part)
     if rank == 0 and not args.no_roofline:
         ts.world, ts.pg = 1, None
-        out["roofline"], out["kernels"] = roofline(torch, ts, args.model, dev)
+        out["roofline"], out["kernels"] = roofline(torch, ts, args.model, dev, measured_traffic=headline)
         log("roofline leg done", out["roofline"]["kernel"], out["roofline"]["frac"])
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
@@ -254,7 +260,7 @@ def _work(name, a):
     return 0, 0
 
 
-def roofline(torch, ts, model, dev):
+def roofline(torch, ts, model, dev, measured_traffic=True):
     """Time every launch of every C-ABI entry point with HIP events on the launch stream during a few eager
     (un-captured) iterations of the same step, and price the one that takes the most time."""
     from mpgan_amd import _lib
@@ -298,7 +304,9 @@ def roofline(torch, ts, model, dev):
     kname = name.replace("mpg_", "") + "_kernel"
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.isfile(tpath):  # PMC measurement of this kernel (tools/pmc.sh, FETCH_SIZE x2 + WRITE_SIZE), bytes per launch
+    # PMC measurement of this kernel (tools/pmc.sh, FETCH_SIZE x2 + WRITE_SIZE), bytes per launch; it belongs to the
+    # headline workload the counters were collected on and is left null for any other
+    if measured_traffic and os.path.isfile(tpath):
         traffic = json.load(open(tpath)).get(kname, {}).get("bytes_per_launch")
     # MPGAN's fused edge kernels are MFMA-bound by >100x; GAPT's launches are HBM / latency bound
     mfma = name.startswith("mpg_edge") or (flop_sum / max(byte_sum, 1) > PEAK_MFMA_16BIT / PEAK_HBM)

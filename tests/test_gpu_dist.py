@@ -102,3 +102,24 @@ def test_two_ranks_on_one_gpu_equal_global_batch():
         # a gradient entry is within rounding of zero (RMSprop's first steps are sign-like)
         off = ((ours - ref).abs() > 2e-2 * step).float().mean()
         assert float(off) < 0.02, float(off)
+
+
+def test_bench_self_launch_two_ranks_rehearsal():
+    """``python bench.py --gpus 2`` without torchrun: the launcher path the driver's scaling run takes (ranks started
+    before any GPU call, process group, parameter broadcast, three graph segments with the gradient exchange between
+    them, max-over-ranks timing, one JSON line with n_gpus = 2, the roofline leg with collectives off, clean teardown).
+    On this one-GPU box both ranks share cuda:0 and exchange over gloo (MPGAN_BENCH_SHARE_GPU)."""
+    import json
+    import subprocess
+    env = dict(os.environ, MPGAN_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--batch", "32"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and "roofline" in d and "cpu_baseline" not in d
+    assert np.isfinite(d["losses"]["D"]) and np.isfinite(d["losses"]["G"])

@@ -82,6 +82,34 @@ traffic = {
     "edge_dw_kernel": {"bytes_per_launch": int(tot("edge_dw_kernel<2"))},
 }
 json.dump(traffic, open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
+# ---- SQ counters (tools/final_profiles.sh: pmc_sq_summary.txt)
+sq_path = os.path.join(F, "pmc_sq_summary.txt")
+if os.path.isfile(sq_path):
+    sq = open(sq_path).read()
+    cur, tab = None, {}
+    for l in sq.splitlines():
+        m = re.match(r"== (.*)", l)
+        if m:
+            cur = m.group(1); tab[cur] = {}; continue
+        m = re.match(r"(\w+)\s+n=\s*(\d+) avg=\s*([\d.]+)", l)
+        if m and cur:
+            tab[cur][m.group(1)] = float(m.group(3))
+    txt = ("# SQ counters of the fused edge kernels (rocprofv3 --kernel-trace --pmc ..., workload tools/kbwd.py, B=256, N=30),\n"
+           "# per dispatch.  Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over\n"
+           "# waves; SQ_VALU_MFMA_BUSY_CYCLES counts cycles (= 32 x number of 32x32x16 MFMAs) summed over SIMDs.  One wave per SIMD\n"
+           "# (two in edge_dw_kernel), so  MFMA share of wave time = MFMA_BUSY / (4 x WAVE_CYCLES / waves_per_SIMD).\n#\n"
+           "#   kernel                               MFMA busy / wave time   wave parked (WAIT_ANY)   issue stalled (WAIT_INST_ANY)   VALU active   VALU instr per MFMA\n")
+    for k, v in tab.items():
+        if not v.get("SQ_WAVE_CYCLES"):
+            continue
+        wps = 2.0 if "edge_dw" in k else 1.0
+        wc = v["SQ_WAVE_CYCLES"]
+        nm = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 32.0
+        txt += (f"#   {k:38s} {v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (4 * wc / wps):8.2f} {v.get('SQ_WAIT_ANY', 0) / wc:22.2f} "
+                f"{v.get('SQ_WAIT_INST_ANY', 0) / wc:24.2f} {v.get('SQ_ACTIVE_INST_VALU', 0) / wc:22.2f} "
+                f"{(v.get('SQ_INSTS_VALU', 0) / nm if nm else 0):16.1f}\n")
+    open(os.path.join(P, f"{tag}_pmc_sq_counters.txt"), "w").write(txt + "#\n" + sq)
+
 ub = open(os.path.join(F, "ubench.txt")).read()
 open(os.path.join(P, f"{tag}_ubench_mfma.txt"), "w").write(
     "# tools/ubench/mfma_model, mfma_model2, mfma_power on MI355X (the machine model the fused kernels are scheduled against).\n"
