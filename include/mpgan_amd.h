@@ -274,6 +274,40 @@ typedef struct MpgDiscHead {
 int mpg_disc_head_fwd(const MpgDiscHead* p, void* stream);
 int mpg_disc_head_bwd(const MpgDiscHead* p, void* stream);
 
+/* mpg_mab_fwd / mpg_mab_bwd: one launch per MAB.forward (gapt/model.py:124-139) and one for its backward, for sets of at
+ * most 32 tokens, E in {32, 64}, heads of 16 features, no layer norm (csrc/mab.hip; anything else runs block by block
+ * through mpg_gemm / mpg_attn_* / mpg_gate):
+ *   q = x Wq' + bq, k|v = y Wkv' + bkv ; o = softmax(q k' / 4 + key mask) v per head ; za = x + o Wo' + bo ;
+ *   z = dropout(za, site tag) ; u = z Wf' + bf ; out = dropout(z + dropout(act(u), site tag+1), site tag+2)
+ * x [B*L, E] queries, y [B*S, E] keys/values (y == x: self-attention), ignore [B*S] floats (1 = padded key) or NULL.
+ * Win / Wo / Wf: fp16 hi|lo images (mpg_pack_weights, scale wscale) of in_proj_weight [3E, E], out_proj.weight and
+ * ff.net.0.weight [E, E]; activations are split as ascale * value.  fwd writes out and, when given, save_o (attention
+ * output before the out-projection) and save_z [B*L, E] -- the two activations the weight gradients and the backward need.
+ * bwd recomputes q, k, v, P and u from x, y and save_z, and writes the input gradients dx (dy when y != x) and the three
+ * pre-activation gradients whose products with (x | y, save_o, save_z) are the weight gradients:
+ *   dq [B*L, :E] / dk, dv [B*S] (row strides lddq / lddkv), dza, du [B*L, E].
+ * WinT / WoT / WfT: bf16 images of the transposed weights ([E, 3E], [E, E], [E, E], scale 1). */
+typedef struct MpgMab {
+    const float* x; int ldx;
+    const float* y; int ldy;
+    const float* ignore;
+    const void* Win; const float* bin;
+    const void* Wo; const float* bo;
+    const void* Wf; const float* bf;
+    int B, L, S, E, H;
+    float alpha; int ff_act;
+    const uint64_t* seed; uint32_t tag; uint32_t thr_mab; float sc_mab; uint32_t thr_ff; float sc_ff;
+    float wscale, ascale;
+    float* out; int ldo;
+    float* save_o; float* save_z;
+    const void* WinT; const void* WoT; const void* WfT;
+    const float* dout; int lddout;
+    float* dx; int lddx; float* dy; int lddy;
+    float* dq; int lddq; float* dk; float* dv; int lddkv;
+    float* dza; float* du;
+} MpgMab;
+int mpg_mab_fwd(const MpgMab* p, void* stream);
+
 /* mpg_layernorm_fwd / _bwd: nn.LayerNorm(E) over the rows of x [M, E] -- MAB.norm1 / norm2 of GAPT with layer_norm
  * (gapt/model.py:118-120, :131-136).  fwd writes y and stats [M][mean, rstd]; bwd writes dx and, through `part`
  * (scratch of nwaves * 2 * E floats, nwaves a multiple of 4 = waves of the launch), dw = sum_rows g * xhat and

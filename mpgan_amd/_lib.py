@@ -142,6 +142,22 @@ class MpgDiscHead(C.Structure):
     ]
 
 
+class MpgMab(C.Structure):
+    _fields_ = [
+        ("x", _fp), ("ldx", C.c_int), ("y", _fp), ("ldy", C.c_int), ("ignore", _fp),
+        ("Win", _fp), ("bin", _fp), ("Wo", _fp), ("bo", _fp), ("Wf", _fp), ("bf", _fp),
+        ("B", C.c_int), ("L", C.c_int), ("S", C.c_int), ("E", C.c_int), ("H", C.c_int),
+        ("alpha", C.c_float), ("ff_act", C.c_int),
+        ("seed", _fp), ("tag", C.c_uint32), ("thr_mab", C.c_uint32), ("sc_mab", C.c_float),
+        ("thr_ff", C.c_uint32), ("sc_ff", C.c_float), ("wscale", C.c_float), ("ascale", C.c_float),
+        ("out", _fp), ("ldo", C.c_int), ("save_o", _fp), ("save_z", _fp),
+        ("WinT", _fp), ("WoT", _fp), ("WfT", _fp),
+        ("dout", _fp), ("lddout", C.c_int), ("dx", _fp), ("lddx", C.c_int), ("dy", _fp), ("lddy", C.c_int),
+        ("dq", _fp), ("lddq", C.c_int), ("dk", _fp), ("dv", _fp), ("lddkv", C.c_int),
+        ("dza", _fp), ("du", _fp),
+    ]
+
+
 # name -> (restype, argtypes); kept in step with include/mpgan_amd.h (tests check the symbol list)
 SIGNATURES = {
     "mpg_gemm": (C.c_int, [C.POINTER(MpgGemm), C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -159,6 +175,7 @@ SIGNATURES = {
     "mpg_edge_dw": (C.c_int, [C.POINTER(MpgEdgeDw), C.c_void_p]),
     "mpg_attn_fwd": (C.c_int, [C.POINTER(MpgAttn), C.c_void_p]),
     "mpg_attn_bwd": (C.c_int, [C.POINTER(MpgAttn), C.c_void_p]),
+    "mpg_mab_fwd": (C.c_int, [C.POINTER(MpgMab), C.c_void_p]),
     "mpg_knn_sets": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_void_p]),
     "mpg_rank_mask": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, C.c_void_p]),
     "mpg_gen_tail_fwd": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -1,0 +1,272 @@
+// One launch per multihead attention block of GAPT (MAB.forward, gapt/model.py:124-139), for sets of up to 32 tokens:
+//
+//   q = x Wq' + bq ; k = y Wk' + bk ; v = y Wv' + bv            (nn.MultiheadAttention in-projection, packed [3E, E])
+//   P_h = softmax(q_h k_h' / sqrt(d) + key mask) ; o_h = P_h v_h (per head, d = 16)
+//   za = x + o Wo' + bo ; z = dropout(za)
+//   u = z Wf' + bf ; out = dropout(z + dropout_ff(LeakyReLU(u)))  (MAB.ff = one Linear(E, E) [+ LeakyReLU])
+//
+// ONE WAVE PER JET; nothing but the weights is read twice and no intermediate leaves the registers.  Everything is a
+// chain of 32x32x16 MFMAs in the chain layout of common.h: a tile is [32 features (registers) x 32 tokens (lanes)], and
+// registers 8s..8s+7 of a tile ARE the B fragment of k-step s of the next product.  The attention itself stays in that
+// layout because A and B fragments of this instruction have the same shape (lane = row or column, 8 k-values):
+//   * S' = K Q'    : A = registers of the K tile, B = registers of the Q tile (one k-step = the 16 features of a head);
+//                    the result has keys in registers and queries on lanes, so the softmax is a register reduction
+//                    plus one exchange between the two lane halves
+//   * O' = V' P'   : needs V with keys in registers and features on lanes -- that is the V projection with its two MFMA
+//                    operands SWAPPED (activations as A, weights as B), so no transpose is ever made; P's registers are
+//                    its B fragments.  The 16 valid rows of the two heads of a 32-feature tile are merged into one
+//                    tile, which is again the B operand of the out-projection.
+// Products run as fp16 hi/lo 3-term splits (common.h) with power-of-two operand scales; the backward kernel recomputes
+// the same values and carries gradients as bf16 hi/lo.
+#include "common.h"
+#include "../../include/mpgan_amd.h"
+
+namespace {
+
+constexpr float MAB_SP = 256.f;   // attention probabilities are split as 256 P (an fp16 lo half stays normal down to P ~ 1e-3)
+
+MPG_DEV float4 mld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <typename V>
+MPG_DEV V mab_wfrag(const __amdgpu_buffer_rsrc_t rw, int frag, int lane16) {
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, frag * 1024, 0));
+}
+
+// rows of a [*, E] matrix as B (or A) fragments: k-step ks, element j of lane half h = feature 16 ks + 8 (j >> 2) + 4 h + (j & 3)
+template <int KS, typename V>
+MPG_DEV void rows_to_frags(const float* base, int ld, long row, float scale, int h, V* hi, V* lo) {
+    static_for<0, KS>([&](auto kc) {
+        MPG_CI(ks, kc);
+        const float4 a = mld4(base + row * ld + 16 * ks + 4 * h), b = mld4(base + row * ld + 16 * ks + 8 + 4 * h);
+        const float v[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, b.x * scale, b.y * scale, b.z * scale, b.w * scale};
+        split8(v, hi[ks], lo[ks]);
+    });
+}
+// rows of a [*, E] matrix as an accumulator-layout tile: register 4g+e = feature 32 tile + 8g + 4h + e of the lane's row
+MPG_DEV f32x16 rows_to_tile(const float* base, int ld, long row, int tile, int h) {
+    f32x16 t;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 a = mld4(base + row * ld + 32 * tile + 8 * g + 4 * h);
+        t[4 * g] = a.x; t[4 * g + 1] = a.y; t[4 * g + 2] = a.z; t[4 * g + 3] = a.w;
+    }
+    return t;
+}
+MPG_DEV void tile_to_rows(float* base, int ld, long row, int tile, int h, const f32x16& t, float scale) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(base + row * ld + 32 * tile + 8 * g + 4 * h) =
+            make_float4(t[4 * g] * scale, t[4 * g + 1] * scale, t[4 * g + 2] * scale, t[4 * g + 3] * scale);
+}
+// registers 8s..8s+7 of a tile, scaled, as one hi/lo fragment pair
+template <typename V>
+MPG_DEV void tile_frag(const f32x16& t, int s, float scale, V& hi, V& lo) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = t[8 * s + j] * scale;
+    split8(v, hi, lo);
+}
+// bias of the features a lane's accumulator registers hold (features in registers), times `scale`
+MPG_DEV f32x16 bias_regs(const float* bias, int tile, int h, float scale) {
+    f32x16 t;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 a = mld4(bias + 32 * tile + 8 * g + 4 * h);
+        t[4 * g] = a.x * scale; t[4 * g + 1] = a.y * scale; t[4 * g + 2] = a.z * scale; t[4 * g + 3] = a.w * scale;
+    }
+    return t;
+}
+// ... and with the features on the lanes (swapped-operand products)
+MPG_DEV f32x16 bias_lanes(const float* bias, int tile, int r, float scale) {
+    const float b = bias[32 * tile + r] * scale;
+    f32x16 t;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = b;
+    return t;
+}
+// acc += W_tile x  (features of W's row tile `m` in registers, tokens on lanes): W image as A, activation fragments as B
+template <int KS, typename V>
+MPG_DEV f32x16 proj_n(const __amdgpu_buffer_rsrc_t rw, int nfrag, int m, const V* xh, const V* xl, f32x16 acc, int lane16) {
+    static_for<0, KS>([&](auto kc) {
+        MPG_CI(ks, kc);
+        const V wh = mab_wfrag<V>(rw, m * KS + ks, lane16), wl = mab_wfrag<V>(rw, nfrag + m * KS + ks, lane16);
+        acc = mfma3(wh, wl, xh[ks], xl[ks], acc);
+    });
+    return acc;
+}
+// the same product with the operands swapped: tokens in registers, W's row tile on the lanes
+template <int KS, typename V>
+MPG_DEV f32x16 proj_t(const __amdgpu_buffer_rsrc_t rw, int nfrag, int m, const V* xh, const V* xl, f32x16 acc, int lane16) {
+    static_for<0, KS>([&](auto kc) {
+        MPG_CI(ks, kc);
+        const V wh = mab_wfrag<V>(rw, m * KS + ks, lane16), wl = mab_wfrag<V>(rw, nfrag + m * KS + ks, lane16);
+        acc = mfma3(xh[ks], xl[ks], wh, wl, acc);
+    });
+    return acc;
+}
+MPG_DEV f32x16 zero16() {
+    f32x16 t;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = 0.f;
+    return t;
+}
+MPG_DEV float other_half(float v) { return __shfl_xor(v, 32); }
+
+// dropout keep mask times scale on an accumulator-layout tile (the hash of common.h: drop_keep_f(row, feature))
+MPG_DEV void drop_tile(f32x16& t, uint32_t seed_lo, uint32_t seed_hi, uint32_t tag, uint32_t row, int tile, int h, uint32_t thr, float scale) {
+    if (thr == 0u) return;
+    if (thr == 128u) {
+        const uint32_t w = drop_word(seed_lo, seed_hi, tag, row, DROP_BIT_GRP + (uint32_t)tile) >> (4 * h);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[4 * g + e] = ((w >> (8 * g + e)) & 1u) ? t[4 * g + e] * scale : 0.f;
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t w = drop_word(seed_lo, seed_hi, tag, row, (uint32_t)(8 * tile + 2 * g + h));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[4 * g + e] = drop_keep(w, e, thr) ? t[4 * g + e] * scale : 0.f;
+        }
+    }
+}
+
+// additive key mask for the registers of a score tile with KEYS in registers: register 4g+e = key 8g + 4h + e
+MPG_DEV f32x16 key_mask_regs(const float* ignore, long jet, int S, int h) {
+    f32x16 t;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = 8 * g + 4 * h + e;
+            bool off = key >= S;
+            if (ignore != nullptr) off = off || ignore[jet * S + min(key, S - 1)] != 0.f;
+            t[4 * g + e] = off ? -INFINITY : 0.f;
+        }
+    return t;
+}
+
+struct MabScales { float sa, zs, inv_zs; };
+
+template <int NT, bool CROSS>
+__global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
+    typedef f16x8 V;
+    constexpr int KS = 2 * NT;            // k-steps of 16 over E = 32 NT features
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5, lane16 = lane * 16;
+    const long jet = (long)blockIdx.x * 4 + w;
+    if (jet >= p.B) return;               // whole waves leave; the kernel has no barrier
+    uint32_t seed_lo = 0, seed_hi = 0;
+    if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+    const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
+    const float zs = sa * ws, inv_zs = 1.f / zs;
+    const int nfIn = 3 * NT * KS, nfE = NT * KS;
+    const __amdgpu_buffer_rsrc_t rIn = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Win), 0, 2 * nfIn * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wo), 0, 2 * nfE * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wf), 0, 2 * nfE * 1024, 0x00020000);
+
+    // rows past the end of a set are read from its last row and never stored; as keys they are masked
+    const long xrow = jet * p.L + min(r, p.L - 1), yrow = jet * p.S + min(r, p.S - 1);
+    const bool xvalid = r < p.L;
+    V xh[KS], xl[KS], yh_[CROSS ? KS : 1], yl_[CROSS ? KS : 1];
+    rows_to_frags<KS>(p.x, p.ldx, xrow, sa, h, xh, xl);
+    if constexpr (CROSS) rows_to_frags<KS>(p.y, p.ldy, yrow, sa, h, yh_, yl_);
+    const V* yh = CROSS ? yh_ : xh;
+    const V* yl = CROSS ? yl_ : xl;
+    const f32x16 kneg = key_mask_regs(p.ignore, jet, p.S, h);
+
+    V oh[KS], ol[KS];                     // attention output as B fragments of the out-projection
+    static_for<0, NT>([&](auto tc) {
+        MPG_CI(t, tc);
+        const f32x16 Qn = proj_n<KS>(rIn, nfIn, t, xh, xl, bias_regs(p.bin, t, h, zs), lane16);
+        const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(p.bin, NT + t, h, zs), lane16);
+        const f32x16 Vt = proj_t<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_lanes(p.bin, 2 * NT + t, r, zs), lane16);
+        V vh[2], vl[2];
+        tile_frag(Vt, 0, inv_zs * sa, vh[0], vl[0]);
+        tile_frag(Vt, 1, inv_zs * sa, vh[1], vl[1]);
+        f32x16 Ot;
+        static_for<0, 2>([&](auto ac) {
+            MPG_CI(a, ac);                // head 2t + a = features 16a .. 16a+15 of the tile = registers 8a .. 8a+7
+            V qh, ql, kh, kl;
+            tile_frag(Qn, a, inv_zs * sa * 0.25f, qh, ql);   // 1/sqrt(d), d = 16
+            tile_frag(Kn, a, inv_zs * sa, kh, kl);
+            f32x16 s = mfma3(kh, kl, qh, ql, zero16());      // keys in registers, queries on lanes
+            const float inv_sa2 = 1.f / (sa * sa);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] = s[i] * inv_sa2 + kneg[i]; mx = fmaxf(mx, s[i]); }
+            mx = fmaxf(mx, other_half(mx));
+            float den = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] = __expf(s[i] - mx); den += s[i]; }
+            den += other_half(den);
+            const float pn = MAB_SP / den;
+            V ph[2], pl[2];
+            tile_frag(s, 0, pn, ph[0], pl[0]);
+            tile_frag(s, 1, pn, ph[1], pl[1]);
+            f32x16 oa = mfma3(vh[0], vl[0], ph[0], pl[0], zero16());
+            oa = mfma3(vh[1], vl[1], ph[1], pl[1], oa);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Ot[8 * a + j] = oa[8 * a + j];
+        });
+        // Ot = 256 sa o  (features 32t .. 32t+31 x queries)
+        if (p.save_o != nullptr && xvalid) tile_to_rows(p.save_o, p.E, xrow, t, h, Ot, 1.f / (MAB_SP * sa));
+        tile_frag(Ot, 0, 1.f / MAB_SP, oh[2 * t], ol[2 * t]);
+        tile_frag(Ot, 1, 1.f / MAB_SP, oh[2 * t + 1], ol[2 * t + 1]);
+    });
+
+    // za = x + o Wo' + bo ; z = dropout(za)
+    f32x16 z[NT];
+    V zh[KS], zl[KS];
+    static_for<0, NT>([&](auto tc) {
+        MPG_CI(t, tc);
+        const f32x16 acc = proj_n<KS>(rO, nfE, t, oh, ol, bias_regs(p.bo, t, h, zs), lane16);
+        const f32x16 xr = rows_to_tile(p.x, p.ldx, xrow, t, h);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) z[t][i] = acc[i] * inv_zs + xr[i];
+        drop_tile(z[t], seed_lo, seed_hi, p.tag + 0, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
+        if (p.save_z != nullptr && xvalid) tile_to_rows(p.save_z, p.E, xrow, t, h, z[t], 1.f);
+        tile_frag(z[t], 0, sa, zh[2 * t], zl[2 * t]);
+        tile_frag(z[t], 1, sa, zh[2 * t + 1], zl[2 * t + 1]);
+    });
+    // out = dropout(z + dropout_ff(LeakyReLU(z Wf' + bf)))
+    static_for<0, NT>([&](auto tc) {
+        MPG_CI(t, tc);
+        f32x16 u = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(p.bf, t, h, zs), lane16);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = u[i] * inv_zs;
+            u[i] = p.ff_act ? lrelu(v, p.alpha) : v;
+        }
+        drop_tile(u, seed_lo, seed_hi, p.tag + 1, (uint32_t)xrow, t, h, p.thr_ff, p.sc_ff);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) u[i] += z[t][i];
+        drop_tile(u, seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
+        if (xvalid) tile_to_rows(p.out, p.ldo, xrow, t, h, u, 1.f);
+    });
+}
+
+int mab_check(const MpgMab* p) {
+    if (p->B < 1 || p->L < 1 || p->S < 1 || p->L > 32 || p->S > 32) return -1;
+    if ((p->E != 32 && p->E != 64) || p->H * 16 != p->E) return -2;
+    if (!(p->alpha >= 0.f && p->alpha <= 1.f)) return -4;
+    if (p->ldx % 4 || p->ldy % 4 || p->ldo % 4) return -3;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mpg_mab_fwd(const MpgMab* p, void* stream) {
+    if (const int rc = mab_check(p)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((p->B + 3) / 4), block(256);
+    const bool cross = p->y != p->x;
+    if (p->E == 64) {
+        if (cross) hipLaunchKernelGGL((mab_fwd_kernel<2, true>), grid, block, 0, st, *p);
+        else hipLaunchKernelGGL((mab_fwd_kernel<2, false>), grid, block, 0, st, *p);
+    } else {
+        if (cross) hipLaunchKernelGGL((mab_fwd_kernel<1, true>), grid, block, 0, st, *p);
+        else hipLaunchKernelGGL((mab_fwd_kernel<1, false>), grid, block, 0, st, *p);
+    }
+    return (int)hipGetLastError();
+}

@@ -39,6 +39,8 @@ def _lin(x2, W, b, row0, rows):
 
 
 class MAB(nn.Module):
+    fused = True   # class-wide switch: eligible blocks run as one launch (tests compare both paths)
+
     def __init__(self, embed_dim: int, num_heads: int, ff_layers: list = [], layer_norm: bool = False,
                  dropout_p: float = 0.0, final_linear: bool = True, linear_args={}):
         super().__init__()
@@ -65,6 +67,8 @@ class MAB(nn.Module):
                 km = y_mask if y_mask.dim() == 2 else y_mask[:, 0, :]
                 ignore = km.reshape(B * S).float().contiguous()
         x2 = x.reshape(B * L, E)
+        if self._fused_ok(x, L, S):
+            return self._fused(x, y, ignore, B, L, S)
         if x is y:   # the packed projections go to the attention core as they are (no q/k/v slices in autograd)
             qkv = _lin(x2, att.in_proj_weight, att.in_proj_bias, 0, 3 * E)
             o = ops.FusedPackedAttnFn.apply(qkv, None, ignore, B, L, S, self.num_heads)
@@ -81,6 +85,36 @@ class MAB(nn.Module):
         if self.layer_norm:
             zf = ops.LayerNormFn.apply(zf, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         out = ops.FusedDropoutFn.apply(zf, self.dropout_p, self.training)
+        return out.reshape(B, L, E)
+
+
+    # -- the whole block as one launch (ops.mab_forward; csrc/mab.hip) ------------------------------------------
+    def _fused_ok(self, x: Tensor, L: int, S: int) -> bool:
+        return (MAB.fused and x.is_cuda and not self.layer_norm and len(self.ff.net) == 1
+                and ops.mab_fusable(self.embed_dim, self.num_heads, L, S) and not torch.is_grad_enabled())
+
+    def _packed(self) -> "ops.PackedMAB":
+        pk = self.__dict__.get("_pack")
+        att = self.attention
+        if pk is None or pk.params[0] is not att.in_proj_weight:
+            pk = self.__dict__["_pack"] = ops.PackedMAB(att.in_proj_weight, att.out_proj.weight, self.ff.net[0].weight)
+        return pk.ensure()
+
+    def refresh_packed(self):
+        """Re-pack after an update torch cannot see (``train.TrainStep``'s fused optimizer step)."""
+        pk = self.__dict__.get("_pack")
+        if pk is not None:
+            pk.refresh()
+
+    def _fused(self, x, y, ignore, B, L, S):
+        att, lin = self.attention, self.ff.net[0]
+        E = self.embed_dim
+        x2 = x.reshape(B * L, E).contiguous()
+        y2 = None if x is y else y.reshape(B * S, E).contiguous()
+        out, _, _, _ = ops.mab_forward(x2, y2, ignore, self._packed(), att.in_proj_bias, att.out_proj.bias, lin.bias,
+                                       B, L, S, self.num_heads, alpha=self.ff.leaky_relu_alpha,
+                                       ff_act=not self.ff.final_linear, p_mab=self.dropout_p, p_ff=self.ff.dropout_p,
+                                       training=self.training)
         return out.reshape(B, L, E)
 
 

@@ -756,6 +756,84 @@ class FusedAttnFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None, None
 
 
+# ------------------------------------------------------------------------------------- one launch per MAB
+class PackedMAB:
+    """Weight images of one MAB for ``mpg_mab_fwd`` / ``mpg_mab_bwd`` (fp16 images of the three weights for the forward
+    products, bf16 images of their transposes for the gradient products), rebuilt by ONE ``mpg_pack_many`` launch;
+    ``ensure`` / ``refresh`` as ``PackedMPLayer``."""
+
+    def __init__(self, Win, Wo, Wf):
+        E = Wo.shape[0]
+        self.params = (Win, Wo, Wf)
+        self._spec = {
+            "Win": (Win, 3 * E, E, 0, SC_WN, True), "Wo": (Wo, E, E, 0, SC_WN, True), "Wf": (Wf, E, E, 0, SC_WN, True),
+            "WinT": (Win, E, 3 * E, 1, 1.0, False), "WoT": (Wo, E, E, 1, 1.0, False), "WfT": (Wf, E, E, 1, 1.0, False),
+        }
+        self.img = {k: torch.empty((_img_elems(v[1], v[2]),), device=Wo.device, dtype=torch.bfloat16)
+                    for k, v in self._spec.items()}
+        self._key = None
+
+    def _current_key(self):
+        return tuple((q.data_ptr(), q._version) for q in self.params)
+
+    def refresh(self):
+        jobs = (MpgPackJob * len(self._spec))()
+        for i, (k, (W, rows, cols, tr, scale, f16)) in enumerate(self._spec.items()):
+            j = jobs[i]
+            j.W, j.ldw, j.rows, j.cols, j.transpose = _p(W), W.stride(0), rows, cols, tr
+            j.scale, j.f16, j.img, j.row_split, j.split_cols = scale, int(f16), C.c_void_p(self.img[k].data_ptr()), 0, 0
+        check(_lib.lib().mpg_pack_many(jobs, len(self._spec), _stream()), "mpg_pack_many")
+        self._key = self._current_key()
+
+    def ensure(self):
+        if self._key != self._current_key():
+            self.refresh()
+        return self
+
+    def ptr(self, name):
+        return C.c_void_p(self.img[name].data_ptr())
+
+
+def mab_fusable(E: int, H: int, L: int, S: int) -> bool:
+    """Shapes ``mpg_mab_fwd`` / ``mpg_mab_bwd`` take: sets of at most 32 tokens, E = 32 or 64, heads of 16 features."""
+    return E in (32, 64) and H * 16 == E and 1 <= L <= 32 and 1 <= S <= 32
+
+
+def _mab_struct(x2, y2, ignore, pk, bin_, bo, bf, B, L, S, E, H, alpha, ff_act, tag, thr_mab, sc_mab, thr_ff, sc_ff):
+    m = _lib.MpgMab()
+    m.x, m.ldx = _p(x2), x2.stride(0)
+    m.y, m.ldy = (_p(x2), x2.stride(0)) if y2 is None else (_p(y2), y2.stride(0))
+    m.ignore = _p(ignore)
+    m.Win, m.bin, m.Wo, m.bo, m.Wf, m.bf = pk.ptr("Win"), _p(bin_), pk.ptr("Wo"), _p(bo), pk.ptr("Wf"), _p(bf)
+    m.WinT, m.WoT, m.WfT = pk.ptr("WinT"), pk.ptr("WoT"), pk.ptr("WfT")
+    m.B, m.L, m.S, m.E, m.H = B, L, S, E, H
+    m.alpha, m.ff_act = alpha, int(ff_act)
+    m.seed, m.tag = _p(seed_tensor(x2.device)), tag
+    m.thr_mab, m.sc_mab, m.thr_ff, m.sc_ff = thr_mab, sc_mab, thr_ff, sc_ff
+    m.wscale, m.ascale = SC_WN, SC_ACT
+    return m
+
+
+def mab_forward(x2, y2, ignore, pk, bin_, bo, bf, B, L, S, H, *, alpha=0.2, ff_act=True, p_mab=0.0, p_ff=0.0,
+                training=False, tag=None, save=False):
+    """``mpg_mab_fwd``: x2 [B*L, E] queries, y2 [B*S, E] keys/values or None (self-attention), ignore [B*S] floats or
+    None.  Returns (out [B*L, E], o, z, tag) -- o and z only with ``save`` (what the backward needs)."""
+    _chk(x2, "x")
+    E = x2.shape[1]
+    dev = x2.device
+    thr_mab, sc_mab = drop_params(p_mab) if training else (0, 1.0)
+    thr_ff, sc_ff = drop_params(p_ff) if training else (0, 1.0)
+    if tag is None:
+        tag = next_tag(dev)
+    out = torch.empty((B * L, E), device=dev, dtype=torch.float32)
+    o = torch.empty_like(out) if save else None
+    z = torch.empty_like(out) if save else None
+    m = _mab_struct(x2, y2, ignore, pk, bin_, bo, bf, B, L, S, E, H, alpha, ff_act, tag, thr_mab, sc_mab, thr_ff, sc_ff)
+    m.out, m.ldo, m.save_o, m.save_z = _p(out), out.stride(0), _p(o), _p(z)
+    check(_lib.lib().mpg_mab_fwd(C.byref(m), _stream()), "mpg_mab_fwd")
+    return out, o, z, tag
+
+
 # ------------------------------------------------------------------------------------- per-jet pieces around the layers
 def rank_mask(first_feature: torch.Tensor, labels: torch.Tensor, num_particles: int, out: Optional[torch.Tensor] = None):
     """mask_c (mpgan/model.py:689-699): [B, N] floats, 1 for the n = int(label * N) particles of each jet with the

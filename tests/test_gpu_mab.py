@@ -1,0 +1,98 @@
+"""GPU parity of the one-launch attention block (mpg_mab_fwd / mpg_mab_bwd, csrc/mab.hip) against the reference goldens,
+the fp64 oracle (exact dropout masks) and the block-by-block path."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, summarize, rel_err
+
+pytestmark = pytest.mark.gpu
+TIGHT = 1e-4
+LA = {"leaky_relu_alpha": 0.2, "dropout_p": 0.0, "batch_norm": False, "spectral_norm": False}
+SAB_ARGS = dict(embed_dim=64, ff_layers=[], final_linear=False, num_heads=4, layer_norm=False, dropout_p=0.0,
+                linear_args=LA)
+
+
+def _blocks(args=SAB_ARGS):
+    from mpgan_amd.gapt import SAB, PMA, ISAB
+    from oracle import train_ref as T
+    E = args["embed_dim"]
+    return {
+        "sab": (lambda: SAB(**args), T._mab_shapes("mab", E)),
+        "pma": (lambda: PMA(num_seeds=1, **args), {"S": (1, 1, E), **T._mab_shapes("mab", E)}),
+        "isab": (lambda: ISAB(10, **args), {"I": (1, 10, E), **T._mab_shapes("mab0", E), **T._mab_shapes("mab1", E)}),
+    }
+
+
+@pytest.fixture
+def launches():
+    """Counts the calls of every C-ABI entry point while the test runs."""
+    from mpgan_amd import _lib
+    lib = _lib.lib()
+    seen = {}
+
+    class Proxy:
+        def __getattr__(self, k):
+            fn = getattr(lib, k)
+            if not k.startswith("mpg_"):
+                return fn
+
+            def counted(*a):
+                seen[k] = seen.get(k, 0) + 1
+                return fn(*a)
+            return counted
+
+    saved = _lib._lib
+    _lib._lib = Proxy()
+    try:
+        yield seen
+    finally:
+        _lib._lib = saved
+
+
+@pytest.mark.parametrize("name,ci", [("m30", 0), ("u30", 1)])
+def test_forward_vs_reference_golden(name, ci, launches):
+    """SAB / PMA / ISAB outputs of the fused launch (no autograd) against the reference's own outputs."""
+    from oracle import train_ref as T
+    from mpgan_amd.gapt import _attn_mask
+    g = load_golden(f"gapt_blocks_{name}_f64.npz")
+    mask = torch.from_numpy(g["mask"]).float().cuda() if "mask" in g else None
+    for bname, (ctor, shapes) in _blocks().items():
+        blk = ctor().cuda()
+        blk.load_state_dict(T.init_state_dict(shapes, 50 + ci, torch.float32))
+        x = torch.from_numpy(g["x"]).float().cuda()
+        launches.clear()
+        with torch.no_grad():
+            y = blk(x, _attn_mask(mask))
+        n_mab = 2 if bname == "isab" else 1
+        assert launches.get("mpg_mab_fwd") == n_mab and "mpg_gemm" not in launches and "mpg_attn_fwd" not in launches, launches
+        assert rel_err(y.cpu().numpy(), g[f"{bname}_y"]) < TIGHT, bname
+
+
+def test_forward_exact_dropout_and_embed32():
+    """Dropout at its three sites with the exact masks (mpg_dropout_mask) fed to the fp64 oracle; E = 32 / 2 heads."""
+    from oracle import train_ref as T, gapt_ref as R
+    from mpgan_amd import ops
+    from mpgan_amd.gapt import SAB, _attn_mask
+    for E, H, p in ((64, 4, 0.5), (32, 2, 0.3)):
+        la = dict(LA, dropout_p=p)
+        args = dict(SAB_ARGS, embed_dim=E, num_heads=H, dropout_p=p, linear_args=la)
+        blk = SAB(**args).cuda().train()
+        sd = T.init_state_dict(T._mab_shapes("mab", E), 7, torch.float32)
+        blk.load_state_dict(sd)
+        B, N = 9, 30
+        gen = torch.Generator().manual_seed(3)
+        x = torch.randn(B, N, E, generator=gen)
+        mask = (torch.rand(B, N, 1, generator=gen) < 0.8).float()
+        mask[:, 0] = 1
+        with torch.no_grad():
+            y = blk(x.cuda(), _attn_mask(mask.cuda()))
+        tag = ops.last_tag()
+        thr, _ = ops.drop_params(p)
+        keeps = {k: ops.dropout_mask(B * N, E, tag + site, thr).double().cpu().reshape(B, N, E)
+                 for site, k in enumerate(("a", "f", "o"))}
+        sd64 = {k: v.double() for k, v in sd.items()}
+        ref = R.mab_forward(sd64, "mab", x.double(), x.double(), (1 - mask[:, :, 0]).bool(), num_heads=H, p=thr / 256.0, keeps=keeps)   # (byte-mode dropout quantises p to thr / 256)
+        assert rel_err(y.cpu().numpy(), ref.numpy()) < TIGHT, (E, p)
+        frac = float(sum(k.mean() for k in keeps.values()) / 3)
+        assert abs(frac - (1 - p)) < 0.02
