@@ -307,6 +307,7 @@ typedef struct MpgMab {
     float* dza; float* du;
 } MpgMab;
 int mpg_mab_fwd(const MpgMab* p, void* stream);
+int mpg_mab_bwd(const MpgMab* p, void* stream);
 
 /* mpg_layernorm_fwd / _bwd: nn.LayerNorm(E) over the rows of x [M, E] -- MAB.norm1 / norm2 of GAPT with layer_norm
  * (gapt/model.py:118-120, :131-136).  fwd writes y and stats [M][mean, rstd]; bwd writes dx and, through `part`

@@ -246,6 +246,202 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
     });
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the block, one wave per jet again.  q, k, v, P and u are recomputed from x, y and the saved z with the
+// forward's own arithmetic; gradients run as bf16 hi/lo products.  With S' = K Q' (keys in registers) the softmax
+// statistics are per lane, and everything that contracts over KEYS follows from it directly:
+//     dP = V dO'   (A = V tile registers, B = dO tile registers)      dS = P (dP - sum_keys dP P) / 4
+//     dQ' = K' dS  (A = the K projection with swapped operands: features on lanes, keys in registers)
+// What contracts over QUERIES needs the transposed tiles, and those are the SAME MFMAs with A and B exchanged:
+//     S^T = Q K'   -> P^T = exp(S^T - c_query), c = max + log(sum) fetched per register from the lane that owns the query
+//     dP^T = dO V' -> dS^T ;  dK' = Q' dS^T  (A = swapped-operand Q projection) ;  dV' = dO' P^T  (A = swapped-operand dO)
+// so no tile is ever transposed through memory.  Rows of x past L carry a zero output gradient and keys past S or
+// masked have P = 0, so padding contributes nothing.
+template <int NT, typename V>
+MPG_DEV void acc_wt(const __amdgpu_buffer_rsrc_t rT, int nfragT, int KST, int ks0, const V* fh, const V* fl, f32x16* acc, int lane16) {
+    static_for<0, NT>([&](auto tc) {
+        MPG_CI(t, tc);
+        static_for<0, 2>([&](auto sc) {
+            MPG_CI(s, sc);
+            const V wh = mab_wfrag<V>(rT, t * KST + ks0 + s, lane16), wl = mab_wfrag<V>(rT, nfragT + t * KST + ks0 + s, lane16);
+            acc[t] = mfma3(wh, wl, fh[s], fl[s], acc[t]);
+        });
+    });
+}
+
+template <int NT, bool CROSS>
+__global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
+    typedef f16x8 VF;
+    typedef bf16x8 VB;
+    constexpr int KS = 2 * NT;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5, lane16 = lane * 16;
+    const long jet = (long)blockIdx.x * 4 + w;
+    if (jet >= p.B) return;
+    uint32_t seed_lo = 0, seed_hi = 0;
+    if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+    const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
+    const float zs = sa * ws, inv_zs = 1.f / zs, inv_sa2 = 1.f / (sa * sa);
+    const int nfIn = 3 * NT * KS, nfE = NT * KS, nfInT = NT * 3 * KS;
+    const __amdgpu_buffer_rsrc_t rIn = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Win), 0, 2 * nfIn * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wf), 0, 2 * nfE * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rInT = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.WinT), 0, 2 * nfInT * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rOT = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.WoT), 0, 2 * nfE * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rFT = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.WfT), 0, 2 * nfE * 1024, 0x00020000);
+
+    const long xrow = jet * p.L + min(r, p.L - 1), yrow = jet * p.S + min(r, p.S - 1);
+    const bool xvalid = r < p.L, yvalid = r < p.S;
+    const float xlive = xvalid ? 1.f : 0.f;
+    const f32x16 kneg = key_mask_regs(p.ignore, jet, p.S, h);
+    bool key_off = !yvalid;               // this lane as a KEY (transposed tiles)
+    if (p.ignore != nullptr) key_off = key_off || p.ignore[jet * p.S + min(r, p.S - 1)] != 0.f;
+
+    // ---- feed-forward half: dzf = dropout'(dout) ; du = dzf drop_ff' act'(u) ; dz = dzf + du Wf ; dza = dropout'(dz)
+    VB dzah[KS], dzal[KS];
+    f32x16 dxa[NT];                       // gradient with respect to x: starts as the residual path
+    {
+        VF zh[KS], zl[KS];
+        rows_to_frags<KS>(p.save_z, p.E, xrow, sa, h, zh, zl);
+        f32x16 dzf[NT];
+        VB duh[KS], dul[KS];
+        static_for<0, NT>([&](auto tc) {
+            MPG_CI(t, tc);
+            dzf[t] = rows_to_tile(p.dout, p.lddout, xrow, t, h);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dzf[t][i] *= xlive;
+            drop_tile(dzf[t], seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
+            const f32x16 u = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(p.bf, t, h, zs), lane16);
+            f32x16 du;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) du[i] = dzf[t][i] * ((p.ff_act && !(u[i] > 0.f)) ? p.alpha : 1.f);
+            drop_tile(du, seed_lo, seed_hi, p.tag + 1, (uint32_t)xrow, t, h, p.thr_ff, p.sc_ff);
+            if (p.du != nullptr && xvalid) tile_to_rows(p.du, p.E, xrow, t, h, du, 1.f);
+            tile_frag(du, 0, 1.f, duh[2 * t], dul[2 * t]);
+            tile_frag(du, 1, 1.f, duh[2 * t + 1], dul[2 * t + 1]);
+        });
+        static_for<0, NT>([&](auto tc) {
+            MPG_CI(t, tc);
+            f32x16 dz = proj_n<KS>(rFT, nfE, t, duh, dul, dzf[t], lane16);
+            drop_tile(dz, seed_lo, seed_hi, p.tag + 0, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
+            if (p.dza != nullptr && xvalid) tile_to_rows(p.dza, p.E, xrow, t, h, dz, 1.f);
+            tile_frag(dz, 0, 1.f, dzah[2 * t], dzal[2 * t]);
+            tile_frag(dz, 1, 1.f, dzah[2 * t + 1], dzal[2 * t + 1]);
+            dxa[t] = dz;
+        });
+    }
+    f32x16 dya[CROSS ? NT : 1];
+    if constexpr (CROSS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) dya[t] = zero16();
+    }
+    f32x16* dkv_acc = CROSS ? dya : dxa;
+
+    VF xh[KS], xl[KS], yh_[CROSS ? KS : 1], yl_[CROSS ? KS : 1];
+    rows_to_frags<KS>(p.x, p.ldx, xrow, sa, h, xh, xl);
+    if constexpr (CROSS) rows_to_frags<KS>(p.y, p.ldy, yrow, sa, h, yh_, yl_);
+    const VF* yh = CROSS ? yh_ : xh;
+    const VF* yl = CROSS ? yl_ : xl;
+
+    static_for<0, NT>([&](auto tc) {
+        MPG_CI(t, tc);
+        // gradient of the attention output of this tile's two heads, both orientations
+        const f32x16 dOn = proj_n<KS>(rOT, nfE, t, dzah, dzal, zero16(), lane16);
+        const f32x16 dOp = proj_t<KS>(rOT, nfE, t, dzah, dzal, zero16(), lane16);
+        const f32x16 Qn = proj_n<KS>(rIn, nfIn, t, xh, xl, bias_regs(p.bin, t, h, zs), lane16);
+        const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(p.bin, NT + t, h, zs), lane16);
+        const f32x16 Vn = proj_n<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_regs(p.bin, 2 * NT + t, h, zs), lane16);
+        const f32x16 Qp = proj_t<KS>(rIn, nfIn, t, xh, xl, bias_lanes(p.bin, t, r, zs), lane16);
+        const f32x16 Kp = proj_t<KS>(rIn, nfIn, NT + t, yh, yl, bias_lanes(p.bin, NT + t, r, zs), lane16);
+        VB kph[2], kpl[2], qph[2], qpl[2], doph[2], dopl[2];
+        static_for<0, 2>([&](auto sc) {
+            MPG_CI(s, sc);
+            tile_frag(Kp, s, inv_zs, kph[s], kpl[s]);
+            tile_frag(Qp, s, inv_zs, qph[s], qpl[s]);
+            tile_frag(dOp, s, 1.f, doph[s], dopl[s]);
+        });
+        f32x16 dQt, dKt, dVt;
+        static_for<0, 2>([&](auto ac) {
+            MPG_CI(a, ac);
+            VF qh, ql, kh, kl;
+            tile_frag(Qn, a, inv_zs * sa * 0.25f, qh, ql);
+            tile_frag(Kn, a, inv_zs * sa, kh, kl);
+            VB vbh, vbl, dobh, dobl;
+            tile_frag(Vn, a, inv_zs, vbh, vbl);
+            tile_frag(dOn, a, 1.f, dobh, dobl);
+            // ---- keys in registers, queries on lanes
+            f32x16 s = mfma3(kh, kl, qh, ql, zero16());
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] = s[i] * inv_sa2 + kneg[i]; mx = fmaxf(mx, s[i]); }
+            mx = fmaxf(mx, other_half(mx));
+            float den = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] = __expf(s[i] - mx); den += s[i]; }
+            den += other_half(den);
+            const float inv_den = 1.f / den, cq = mx + __logf(den);
+            const f32x16 dP = mfma3(vbh, vbl, dobh, dobl, zero16());
+            float D = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] *= inv_den; D += s[i] * dP[i]; }
+            D += other_half(D);
+            f32x16 dS;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dS[i] = s[i] * (dP[i] - D) * 0.25f;
+            VB dsh[2], dsl[2];
+            tile_frag(dS, 0, 1.f, dsh[0], dsl[0]);
+            tile_frag(dS, 1, 1.f, dsh[1], dsl[1]);
+            f32x16 dq = mfma3(kph[0], kpl[0], dsh[0], dsl[0], zero16());
+            dq = mfma3(kph[1], kpl[1], dsh[1], dsl[1], dq);
+            // ---- queries in registers, keys on lanes
+            f32x16 sT = mfma3(qh, ql, kh, kl, zero16());
+            const f32x16 dPT = mfma3(dobh, dobl, vbh, vbl, zero16());
+            f32x16 pT, dST;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * g + e, qi = 8 * g + 4 * h + e;   // the query this register belongs to
+                    const float c_q = __shfl(cq, qi), D_q = __shfl(D, qi);
+                    const float pr = key_off ? 0.f : __expf(sT[i] * inv_sa2 - c_q);
+                    pT[i] = pr;
+                    dST[i] = pr * (dPT[i] - D_q) * 0.25f;
+                }
+            VB pth[2], ptl[2], dsth[2], dstl[2];
+            static_for<0, 2>([&](auto sc) {
+                MPG_CI(s2, sc);
+                tile_frag(pT, s2, 1.f, pth[s2], ptl[s2]);
+                tile_frag(dST, s2, 1.f, dsth[s2], dstl[s2]);
+            });
+            f32x16 dk = mfma3(qph[0], qpl[0], dsth[0], dstl[0], zero16());
+            dk = mfma3(qph[1], qpl[1], dsth[1], dstl[1], dk);
+            f32x16 dv = mfma3(doph[0], dopl[0], pth[0], ptl[0], zero16());
+            dv = mfma3(doph[1], dopl[1], pth[1], ptl[1], dv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dQt[8 * a + j] = dq[8 * a + j]; dKt[8 * a + j] = dk[8 * a + j]; dVt[8 * a + j] = dv[8 * a + j]; }
+        });
+        if (p.dq != nullptr && xvalid) tile_to_rows(p.dq, p.lddq, xrow, t, h, dQt, 1.f);
+        if (p.dk != nullptr && yvalid) {
+            tile_to_rows(p.dk, p.lddkv, yrow, t, h, dKt, 1.f);
+            tile_to_rows(p.dv, p.lddkv, yrow, t, h, dVt, 1.f);
+        }
+        // input gradients: dx += dq Wq ; (dy or dx) += dk Wk + dv Wv
+        VB fh[2], fl[2];
+        tile_frag(dQt, 0, 1.f, fh[0], fl[0]); tile_frag(dQt, 1, 1.f, fh[1], fl[1]);
+        acc_wt<NT>(rInT, nfInT, 3 * KS, 2 * t, fh, fl, dxa, lane16);
+        tile_frag(dKt, 0, 1.f, fh[0], fl[0]); tile_frag(dKt, 1, 1.f, fh[1], fl[1]);
+        acc_wt<NT>(rInT, nfInT, 3 * KS, 2 * (NT + t), fh, fl, dkv_acc, lane16);
+        tile_frag(dVt, 0, 1.f, fh[0], fl[0]); tile_frag(dVt, 1, 1.f, fh[1], fl[1]);
+        acc_wt<NT>(rInT, nfInT, 3 * KS, 2 * (2 * NT + t), fh, fl, dkv_acc, lane16);
+    });
+    static_for<0, NT>([&](auto tc) {
+        MPG_CI(t, tc);
+        if (p.dx != nullptr && xvalid) tile_to_rows(p.dx, p.lddx, xrow, t, h, dxa[t], 1.f);
+        if constexpr (CROSS) {
+            if (p.dy != nullptr && yvalid) tile_to_rows(p.dy, p.lddy, yrow, t, h, dya[t], 1.f);
+        }
+    });
+}
+
 int mab_check(const MpgMab* p) {
     if (p->B < 1 || p->L < 1 || p->S < 1 || p->L > 32 || p->S > 32) return -1;
     if ((p->E != 32 && p->E != 64) || p->H * 16 != p->E) return -2;
@@ -255,6 +451,23 @@ int mab_check(const MpgMab* p) {
 }
 
 }  // namespace
+
+extern "C" int mpg_mab_bwd(const MpgMab* p, void* stream) {
+    if (const int rc = mab_check(p)) return rc;
+    if (p->dout == nullptr || p->save_z == nullptr || (p->dk == nullptr) != (p->dv == nullptr)) return -5;
+    if (p->lddout % 4 || (p->dq != nullptr && p->lddq % 4) || (p->dk != nullptr && p->lddkv % 4) || (p->dx != nullptr && p->lddx % 4) || (p->dy != nullptr && p->lddy % 4)) return -3;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((p->B + 3) / 4), block(256);
+    const bool cross = p->y != p->x;
+    if (p->E == 64) {
+        if (cross) hipLaunchKernelGGL((mab_bwd_kernel<2, true>), grid, block, 0, st, *p);
+        else hipLaunchKernelGGL((mab_bwd_kernel<2, false>), grid, block, 0, st, *p);
+    } else {
+        if (cross) hipLaunchKernelGGL((mab_bwd_kernel<1, true>), grid, block, 0, st, *p);
+        else hipLaunchKernelGGL((mab_bwd_kernel<1, false>), grid, block, 0, st, *p);
+    }
+    return (int)hipGetLastError();
+}
 
 extern "C" int mpg_mab_fwd(const MpgMab* p, void* stream) {
     if (const int rc = mab_check(p)) return rc;

@@ -91,7 +91,7 @@ class MAB(nn.Module):
     # -- the whole block as one launch (ops.mab_forward; csrc/mab.hip) ------------------------------------------
     def _fused_ok(self, x: Tensor, L: int, S: int) -> bool:
         return (MAB.fused and x.is_cuda and not self.layer_norm and len(self.ff.net) == 1
-                and ops.mab_fusable(self.embed_dim, self.num_heads, L, S) and not torch.is_grad_enabled())
+                and ops.mab_fusable(self.embed_dim, self.num_heads, L, S))
 
     def _packed(self) -> "ops.PackedMAB":
         pk = self.__dict__.get("_pack")
@@ -109,13 +109,17 @@ class MAB(nn.Module):
     def _fused(self, x, y, ignore, B, L, S):
         att, lin = self.attention, self.ff.net[0]
         E = self.embed_dim
-        x2 = x.reshape(B * L, E).contiguous()
-        y2 = None if x is y else y.reshape(B * S, E).contiguous()
-        out, _, _, _ = ops.mab_forward(x2, y2, ignore, self._packed(), att.in_proj_bias, att.out_proj.bias, lin.bias,
-                                       B, L, S, self.num_heads, alpha=self.ff.leaky_relu_alpha,
-                                       ff_act=not self.ff.final_linear, p_mab=self.dropout_p, p_ff=self.ff.dropout_p,
-                                       training=self.training)
-        return out.reshape(B, L, E)
+        kw = dict(alpha=self.ff.leaky_relu_alpha, ff_act=not self.ff.final_linear, p_mab=self.dropout_p,
+                  p_ff=self.ff.dropout_p, training=self.training)
+        if not torch.is_grad_enabled():
+            x2 = x.reshape(B * L, E).contiguous()
+            y2 = None if x is y else y.reshape(B * S, E).contiguous()
+            out, _, _, _ = ops.mab_forward(x2, y2, ignore, self._packed(), att.in_proj_bias, att.out_proj.bias, lin.bias,
+                                           B, L, S, self.num_heads, **kw)
+            return out.reshape(B, L, E)
+        return ops.FusedMABFn.apply(x, None if x is y else y, ignore, att.in_proj_weight, att.in_proj_bias,
+                                    att.out_proj.weight, att.out_proj.bias, lin.weight, lin.bias, self.num_heads,
+                                    kw["alpha"], kw["ff_act"], kw["p_mab"], kw["p_ff"], kw["training"], self._packed())
 
 
 class SAB(nn.Module):

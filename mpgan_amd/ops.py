@@ -834,6 +834,88 @@ def mab_forward(x2, y2, ignore, pk, bin_, bo, bf, B, L, S, H, *, alpha=0.2, ff_a
     return out, o, z, tag
 
 
+class FusedMABFn(torch.autograd.Function):
+    """MAB.forward (gapt/model.py:124-139) as ONE launch each way (``mpg_mab_fwd`` / ``mpg_mab_bwd``).  x [B, L, E]
+    queries, y [B, S, E] keys/values or None for self-attention.  The forward keeps only o (attention output) and z
+    (input of the feed-forward layer); the backward recomputes the rest and hands the three pre-activation gradients to
+    the grouped weight-gradient launches (``TrainStep``) or computes the weight gradients itself."""
+
+    @staticmethod
+    def forward(ctx, x, y, ignore, Win, bin_, Wo, bo, Wf, bf, H, alpha, ff_act, p_mab, p_ff, training, pk):
+        B, L, E = x.shape
+        S = L if y is None else y.shape[1]
+        x2 = x.reshape(B * L, E).contiguous()
+        y2 = None if y is None else y.reshape(B * S, E).contiguous()
+        out, o, z, tag = mab_forward(x2, y2, ignore, pk, bin_, bo, bf, B, L, S, H, alpha=alpha, ff_act=ff_act,
+                                     p_mab=p_mab, p_ff=p_ff, training=training, save=True)
+        ctx.save_for_backward(x2, y2, ignore, o, z, bin_, bo, bf)
+        ctx.pk, ctx.params = pk, (Win, bin_, Wo, bo, Wf, bf)
+        ctx.cfg = (B, L, S, E, H, alpha, ff_act, tag, p_mab if training else 0.0, p_ff if training else 0.0)
+        return out.reshape(B, L, E)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x2, y2, ignore, o, z, bin_, bo, bf = ctx.saved_tensors
+        B, L, S, E, H, alpha, ff_act, tag, p_mab, p_ff = ctx.cfg
+        dev = x2.device
+        cross = y2 is not None
+        need_w = any(ctx.needs_input_grad[3:9])
+        thr_mab, sc_mab = drop_params(p_mab)
+        thr_ff, sc_ff = drop_params(p_ff)
+        dout = gout.reshape(B * L, E).contiguous()
+        m = _mab_struct(x2, y2, ignore, ctx.pk, bin_, bo, bf, B, L, S, E, H, alpha, ff_act, tag, thr_mab, sc_mab, thr_ff, sc_ff)
+        m.save_o, m.save_z = _p(o), _p(z)
+        m.dout, m.lddout = _p(dout), dout.stride(0)
+        dx = torch.empty((B * L, E), device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dy = torch.empty((B * S, E), device=dev, dtype=torch.float32) if (cross and ctx.needs_input_grad[1]) else None
+        m.dx, m.lddx, m.dy, m.lddy = _p(dx), E, _p(dy), E
+        dqkv = dq = dkv = dza = du = None
+        if need_w:
+            if cross:
+                dq = torch.empty((B * L, E), device=dev, dtype=torch.float32)
+                dkv = torch.empty((B * S, 2 * E), device=dev, dtype=torch.float32)
+                m.dq, m.lddq, m.dk, m.dv, m.lddkv = _p(dq), E, _p(dkv), _p(dkv, E), 2 * E
+            else:
+                dqkv = torch.empty((B * L, 3 * E), device=dev, dtype=torch.float32)
+                m.dq, m.lddq, m.dk, m.dv, m.lddkv = _p(dqkv), 3 * E, _p(dqkv, E), _p(dqkv, 2 * E), 3 * E
+            dza, du = torch.empty_like(dout), torch.empty_like(dout)
+            m.dza, m.du = _p(dza), _p(du)
+        check(_lib.lib().mpg_mab_bwd(C.byref(m), _stream()), "mpg_mab_bwd")
+        grads = [None] * 6
+        if need_w:
+            Win, bin_p, Wo, bo_p, Wf, bf_p = ctx.params
+            st = dev_state(dev)
+            tg = None
+            if st.grad_into_param and st.deferred_wgrad is not None:
+                tg = [_grad_target(q) for q in ctx.params]
+                if any(t is None for t in tg):
+                    tg = None
+            if tg is not None:      # TrainStep: queued for the grouped launches, added into the flat gradient buffers
+                gWin, gbin, gWo, gbo, gWf, gbf = tg
+                wb = st.deferred_wgrad
+                if cross:
+                    wb.add(dq, x2, out=gWin[:E], bias_out=gbin[:E], accumulate=True)
+                    wb.add(dkv, y2, out=gWin[E:], bias_out=gbin[E:], accumulate=True)
+                else:
+                    wb.add(dqkv, x2, out=gWin, bias_out=gbin, accumulate=True)
+                wb.add(dza, o, out=gWo, bias_out=gbo, accumulate=True)
+                wb.add(du, z, out=gWf, bias_out=gbf, accumulate=True)
+            else:
+                def wgrad(dyv, xv):
+                    db = torch.empty(dyv.shape[1], device=dev, dtype=torch.float32)
+                    return linear_bwd_weight(dyv, xv, bias_out=db), db
+                if cross:
+                    (wq, bq), (wkv, bkv) = wgrad(dq, x2), wgrad(dkv, y2)
+                    grads[0], grads[1] = torch.cat([wq, wkv], 0), torch.cat([bq, bkv], 0)
+                else:
+                    grads[0], grads[1] = wgrad(dqkv, x2)
+                grads[2], grads[3] = wgrad(dza, o)
+                grads[4], grads[5] = wgrad(du, z)
+        return (None if dx is None else dx.reshape(B, L, E), None if dy is None else dy.reshape(B, S, E), None,
+                *grads, None, None, None, None, None, None, None)
+
+
 # ------------------------------------------------------------------------------------- per-jet pieces around the layers
 def rank_mask(first_feature: torch.Tensor, labels: torch.Tensor, num_particles: int, out: Optional[torch.Tensor] = None):
     """mask_c (mpgan/model.py:689-699): [B, N] floats, 1 for the n = int(label * N) particles of each jet with the

@@ -96,3 +96,93 @@ def test_forward_exact_dropout_and_embed32():
         assert rel_err(y.cpu().numpy(), ref.numpy()) < TIGHT, (E, p)
         frac = float(sum(k.mean() for k in keeps.values()) / 3)
         assert abs(frac - (1 - p)) < 0.02
+
+
+@pytest.mark.parametrize("name,ci", [("m30", 0), ("u30", 1)])
+def test_blocks_forward_backward_vs_reference_golden(name, ci, launches):
+    """SAB / PMA / ISAB through autograd: one launch each way per block, gradients against the reference's."""
+    from oracle import train_ref as T
+    from mpgan_amd.gapt import _attn_mask
+    g = load_golden(f"gapt_blocks_{name}_f64.npz")
+    mask = torch.from_numpy(g["mask"]).float().cuda() if "mask" in g else None
+    for bname, (ctor, shapes) in _blocks().items():
+        blk = ctor().cuda()
+        blk.load_state_dict(T.init_state_dict(shapes, 50 + ci, torch.float32))
+        x = torch.from_numpy(g["x"]).float().cuda().requires_grad_(True)
+        launches.clear()
+        y = blk(x, _attn_mask(mask))
+        (y * torch.from_numpy(g[f"{bname}_g"]).float().cuda()).sum().backward()
+        n_mab = 2 if bname == "isab" else 1
+        assert launches.get("mpg_mab_fwd") == n_mab and launches.get("mpg_mab_bwd") == n_mab, launches
+        assert "mpg_attn_bwd" not in launches and "mpg_gate" not in launches, launches
+        assert rel_err(y.detach().cpu().numpy(), g[f"{bname}_y"]) < TIGHT, bname
+        assert rel_err(x.grad.cpu().numpy(), g[f"{bname}_dx"]) < TIGHT, bname
+        for k, p in blk.named_parameters():
+            assert rel_err(summarize(k, p.grad), g[f"{bname}_grad__{k}"]) < TIGHT, (bname, k)
+
+
+def test_backward_exact_dropout_vs_oracle():
+    """Training-mode block (dropout at all three sites, p = 1/2 and 0.3; E = 64 and 32; cross attention with 10 queries)
+    against autograd on the fp64 oracle fed with the very masks the kernels drew."""
+    from oracle import train_ref as T, gapt_ref as R
+    from mpgan_amd import ops
+    from mpgan_amd.gapt import MAB
+    for E, H, p, L in ((64, 4, 0.5, 30), (32, 2, 0.3, 30), (64, 4, 0.5, 10)):
+        la = dict(LA, dropout_p=p)
+        blk = MAB(E, H, ff_layers=[], final_linear=False, layer_norm=False, dropout_p=p, linear_args=la).cuda().train()
+        sd = T.init_state_dict(T._mab_shapes("mab", E), 11, torch.float32)
+        blk.load_state_dict({k[len("mab."):]: v for k, v in sd.items()})
+        B, N = 7, 30
+        gen = torch.Generator().manual_seed(5)
+        yk = torch.randn(B, N, E, generator=gen)
+        xq = yk if L == N else torch.randn(B, L, E, generator=gen)
+        ign = torch.rand(B, N, generator=gen) > 0.8
+        ign[:, 0] = False
+        gy = torch.randn(B, L, E, generator=gen)
+        xg = xq.cuda().requires_grad_(True)
+        yg = xg if L == N else yk.cuda().requires_grad_(True)
+        out = blk(xg, yg, ign.cuda())
+        tag = ops.last_tag()
+        (out * gy.cuda()).sum().backward()
+        thr, _ = ops.drop_params(p)
+        keeps = {k: ops.dropout_mask(B * L, E, tag + site, thr).double().cpu().reshape(B, L, E)
+                 for site, k in enumerate(("a", "f", "o"))}
+        sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+        xo = xq.double().requires_grad_(True)
+        yo = xo if L == N else yk.double().requires_grad_(True)
+        ref = R.mab_forward(sd64, "mab", xo, yo, ign, num_heads=H, p=thr / 256.0, keeps=keeps)
+        (ref * gy.double()).sum().backward()
+        assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < TIGHT, (E, p, L)
+        assert rel_err(xg.grad.cpu().numpy(), xo.grad.numpy()) < TIGHT, (E, p, L)
+        if L != N:
+            assert rel_err(yg.grad.cpu().numpy(), yo.grad.numpy()) < TIGHT, (E, p, L)
+        for k, q in blk.named_parameters():
+            assert rel_err(q.grad.cpu().numpy(), sd64["mab." + k].grad.numpy()) < TIGHT, (E, p, L, k)
+
+
+def test_fused_equals_block_by_block():
+    """The same module with the fused launches switched off (mpg_gemm / mpg_attn_* / mpg_gate): outputs and gradients agree."""
+    from oracle import train_ref as T
+    from mpgan_amd.gapt import MAB, ISAB, _attn_mask
+    blk = ISAB(10, **SAB_ARGS).cuda()
+    blk.load_state_dict(T.init_state_dict({"I": (1, 10, 64), **T._mab_shapes("mab0", 64), **T._mab_shapes("mab1", 64)}, 3, torch.float32))
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(5, 30, 64, generator=gen).cuda()
+    mask = (torch.rand(5, 30, 1, generator=gen) < 0.7).float().cuda()
+    mask[:, 0] = 1
+    res = []
+    for fused in (True, False):
+        MAB.fused = fused
+        try:
+            blk.zero_grad()
+            xx = x.clone().requires_grad_(True)
+            y = blk(xx, _attn_mask(mask))
+            y.square().sum().backward()
+            res.append((y.detach(), xx.grad, {k: p.grad.clone() for k, p in blk.named_parameters()}))
+        finally:
+            MAB.fused = True
+    (y1, dx1, g1), (y0, dx0, g0) = res
+    assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < TIGHT
+    assert rel_err(dx1.cpu().numpy(), dx0.cpu().numpy()) < TIGHT
+    for k in g1:
+        assert rel_err(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < TIGHT, k
