@@ -248,6 +248,17 @@ def _work(name, a):
         fl = 4 * o.B * o.H * o.L * o.S * o.d
         by = 4 * (o.B * (o.L + 2 * o.S) * E + o.B * o.L * E + o.B * o.H * o.L * o.S)
         return (fl, by) if name == "mpg_attn_fwd" else (2 * fl, 2 * by)
+    if name in ("mpg_mab_fwd", "mpg_mab_bwd"):
+        # one attention block per jet: in-projection (3E x E on L | S tokens), scores and weighted sum per head,
+        # out-projection and feed-forward layer (E x E each); bytes = x, y in and out (+ o, z kept for the backward) one
+        # way, x, y, z, dout in and dx, dy, dq|dk|dv, dza, du out the other, plus the weights once
+        E, L, S, cross = o.E, o.L, o.S, int(o.y != o.x)
+        fl = o.B * (2 * E * E * (L + 2 * S) + 4 * L * S * E + 4 * L * E * E)
+        wts = 4 * 5 * E * E
+        if name == "mpg_mab_fwd":
+            return fl, 4 * o.B * E * (L + cross * S + L + (2 * L if o.save_z else 0)) + wts
+        rows_out = (L if o.dx else 0) + (S if o.dy else 0) + ((L + 2 * S + 2 * L) if o.dza else 0)
+        return 2 * fl, 4 * o.B * E * (L + cross * S + 2 * L + rows_out) + 2 * wts
     if name == "mpg_gemm":
         return 2 * o.M * o.N * o.K, 4 * (o.M * o.K + o.N * o.K + o.M * o.N * (2 if o.resid else 1))
     if name == "mpg_chain":

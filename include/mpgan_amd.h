@@ -56,7 +56,7 @@ int mpg_splitk_reduce(const float* part, int S, int N, int K, int has_bias, floa
 
 /* Several weight-gradient GEMMs (dW = dY^T X: AK = BK = 0, split-K partials) / their split-K reductions in ONE
  * launch each: the six weight gradients of an MPLayer are each too small to fill the chip on their own. */
-#define MPG_GROUP_MAX 8
+#define MPG_GROUP_MAX 16
 typedef struct MpgReduceJob {
     const float* part; int S, N, K, has_bias; float* out; int ldo; float* bias;
     int accumulate;      /* add to out / bias instead of overwriting (gradient accumulation into .grad) */
@@ -89,7 +89,7 @@ int mpg_pack_weights(const float* W, int ldw, int rows, int cols, int transpose,
  * rows/cols are those of the PACKED matrix, which is W (transpose = 0) or W^T (transpose = 1).  row_split > 0
  * reads a stacked view of W: logical row n of the un-transposed matrix is W[n % row_split, (n / row_split) *
  * split_cols + col] -- fe.net.0.weight [96, 2F] seen as [a-half ; c-half] = [192, F]. */
-#define MPG_PACK_MAX_JOBS 12
+#define MPG_PACK_MAX_JOBS 24
 typedef struct MpgPackJob {
     const float* W; int ldw, rows, cols, transpose; float scale; int f16; void* img;
     int row_split, split_cols;

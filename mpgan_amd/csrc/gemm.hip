@@ -160,12 +160,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const MpgGemm g) {
 
 // Several independent weight-gradient GEMMs (dW = dY^T X, split-K) in ONE launch: each of these is a few hundred
 // short workgroups that cannot fill the chip or hide their own latencies; side by side they do.
-struct GemmGroup { MpgGemm g[MPG_GROUP_MAX]; int splitk[MPG_GROUP_MAX]; int wg0[MPG_GROUP_MAX + 1]; int n; };
+// (only the fields the weight-gradient form uses travel as kernel arguments: 16 whole MpgGemm would not fit the 4 KiB)
+struct GemmSlim { const float* A; const float* B; float* C; long long split_stride; int lda, ldb, ldc, M, N, K; float out_scale; int ones_col; };
+struct GemmGroup { GemmSlim g[MPG_GROUP_MAX]; int splitk[MPG_GROUP_MAX]; int wg0[MPG_GROUP_MAX + 1]; int n; };
 template <bool F16>
 __global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup G) {
     int q = 0;
     while ((int)blockIdx.x >= G.wg0[q + 1]) ++q;
-    const MpgGemm& g = G.g[q];
+    const GemmSlim& e = G.g[q];
+    MpgGemm g = {};
+    g.A = e.A; g.B = e.B; g.C = e.C; g.split_stride = e.split_stride;
+    g.lda = e.lda; g.ldb = e.ldb; g.ldc = e.ldc; g.M = e.M; g.N = e.N; g.K = e.K;
+    g.out_scale = e.out_scale; g.ones_col = e.ones_col; g.alpha = 0.2f; g.f16 = F16;
     const int local = blockIdx.x - G.wg0[q];
     const int tx = (g.N + 63) / 64, ty = (g.M + 63) / 64;
     gemm_body<false, false, F16>(g, local % tx, (local / tx) % ty, local / (tx * ty), G.splitk[q]);
@@ -256,7 +262,12 @@ extern "C" int mpg_gemm_wgrad_group(const MpgGemm* g, const int* splitk, int n, 
     G.wg0[0] = 0;
     for (int q = 0; q < n; ++q) {
         if (g[q].M <= 0 || g[q].N <= 0 || g[q].K < 0 || splitk[q] < 1 || g[q].f16 != g[0].f16) return -1;
-        G.g[q] = g[q];
+        if (g[q].A2 != nullptr || g[q].bias != nullptr || g[q].act || g[q].gateH != nullptr || g[q].resid != nullptr ||
+            g[q].accumulate || g[q].drop_thr) return -2;   // the grouped launch is the plain dW = scale * A^T B form
+        GemmSlim& e = G.g[q];
+        e.A = g[q].A; e.B = g[q].B; e.C = g[q].C; e.split_stride = g[q].split_stride;
+        e.lda = g[q].lda; e.ldb = g[q].ldb; e.ldc = g[q].ldc; e.M = g[q].M; e.N = g[q].N; e.K = g[q].K;
+        e.out_scale = g[q].out_scale; e.ones_col = g[q].ones_col;
         G.splitk[q] = splitk[q];
         G.wg0[q + 1] = G.wg0[q] + ((g[q].N + 63) / 64) * ((g[q].M + 63) / 64) * splitk[q];
     }

@@ -142,37 +142,40 @@ __global__ __launch_bounds__(256) void disc_head_bwd_kernel(const MpgDiscHead p)
     }
 }
 
-// one workgroup: the loss value (sum of the per-jet terms, fixed order) and the head's own parameter gradients
+// workgroup 0: the loss value (sum of the per-jet terms, fixed order); workgroups 1..: the head's own parameter gradients,
+// eight outputs each, 32 lanes per output striding over the jets (fixed summation order)
 __global__ __launch_bounds__(256) void disc_head_reduce_kernel(const MpgDiscHead p) {
     __shared__ float red[256];
     const int tid = threadIdx.x;
-    if (p.loss >= 0 && p.loss_out != nullptr) {
-        float s = 0.f;
-        for (int b = tid; b < p.B; b += 256) s += p.terms[b];
-        red[tid] = s;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-        if (tid == 0) *p.loss_out = red[0];
-        __syncthreads();
+    if (blockIdx.x == 0) {
+        if (p.loss >= 0 && p.loss_out != nullptr) {
+            float s = 0.f;
+            for (int b = tid; b < p.B; b += 256) s += p.terms[b];
+            red[tid] = s;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+            if (tid == 0) *p.loss_out = red[0];
+        }
+        return;
     }
     if (p.dw == nullptr) return;
     // dw_f = sum_b gzpre_b * pool_scale_b * pooled[b, f] ;  db = sum_b gzpre_b
-    for (int f = tid >> 3; f <= p.F; f += 32) {   // 8 threads per output (f == F: the bias)
-        float s = 0.f;
-        for (int b = tid & 7; b < p.B; b += 8) {
-            const float gzp = p.aux[2 * b + 1];
-            if (f < p.F) {
-                const float ps = p.aux[2 * b] != 0.f ? p.aux[2 * b] / (p.thr ? p.dscale : 1.f) : 0.f;   // pooling normalisation alone
-                s += gzp * ps * p.pooled[(size_t)b * p.F + f];
-            } else {
-                s += gzp;
-            }
+    const int f = (blockIdx.x - 1) * 8 + (tid >> 5);   // (f == F: the bias)
+    if (f > p.F) return;
+    float s = 0.f;
+    for (int b = tid & 31; b < p.B; b += 32) {
+        const float gzp = p.aux[2 * b + 1];
+        if (f < p.F) {
+            const float ps = p.aux[2 * b] != 0.f ? p.aux[2 * b] / (p.thr ? p.dscale : 1.f) : 0.f;   // pooling normalisation alone
+            s += gzp * ps * p.pooled[(size_t)b * p.F + f];
+        } else {
+            s += gzp;
         }
-        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-        if ((tid & 7) == 0) {
-            if (f < p.F) p.dw[f] = s + (p.accumulate ? p.dw[f] : 0.f);
-            else if (p.db != nullptr) p.db[0] = s + (p.accumulate ? p.db[0] : 0.f);
-        }
+    }
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
+    if ((tid & 31) == 0) {
+        if (f < p.F) p.dw[f] = s + (p.accumulate ? p.dw[f] : 0.f);
+        else if (p.db != nullptr) p.db[0] = s + (p.accumulate ? p.db[0] : 0.f);
     }
 }
 
@@ -345,6 +348,6 @@ extern "C" int mpg_disc_head_bwd(const MpgDiscHead* p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(disc_head_bwd_kernel, dim3((p->B + 3) / 4), dim3(256), 0, st, *p);
     if ((p->loss >= 0 && p->loss_out != nullptr) || p->dw != nullptr)
-        hipLaunchKernelGGL(disc_head_reduce_kernel, dim3(1), dim3(256), 0, st, *p);
+        hipLaunchKernelGGL(disc_head_reduce_kernel, dim3(1 + (p->dw != nullptr ? (p->F + 1 + 7) / 8 : 0)), dim3(256), 0, st, *p);
     return (int)hipGetLastError();
 }

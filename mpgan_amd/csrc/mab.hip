@@ -20,6 +20,7 @@
 // the same values and carries gradients as bf16 hi/lo.
 #include "common.h"
 #include "../../include/mpgan_amd.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -27,9 +28,19 @@ constexpr float MAB_SP = 256.f;   // attention probabilities are split as 256 P 
 
 MPG_DEV float4 mld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// Weight images live in LDS for the lifetime of a workgroup (a fragment fetched from L2 is ~1 us away and every product
+// of the chain waits for its own): one cooperative copy, then ds_read_b128 per fragment.
+typedef const char* WImg;
 template <typename V>
-MPG_DEV V mab_wfrag(const __amdgpu_buffer_rsrc_t rw, int frag, int lane16) {
-    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, frag * 1024, 0));
+MPG_DEV V mab_wfrag(WImg w, int frag, int lane16) {
+    return *reinterpret_cast<const V*>(w + frag * 1024 + lane16);
+}
+// (LDS-DMA: 1 KiB per wave-instruction straight into LDS, no register staging, all of a wave's pieces in flight at once)
+MPG_DEV void mab_fill(char* dst, const void* src, int bytes) {
+    const int wave = threadIdx.x >> 6, nwav = blockDim.x >> 6, lane = threadIdx.x & 63;
+    for (int c = wave; c < bytes / 1024; c += nwav)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(src) + c * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
 }
 
 // rows of a [*, E] matrix as B (or A) fragments: k-step ks, element j of lane half h = feature 16 ks + 8 (j >> 2) + 4 h + (j & 3)
@@ -66,6 +77,15 @@ MPG_DEV void tile_frag(const f32x16& t, int s, float scale, V& hi, V& lo) {
     for (int j = 0; j < 8; ++j) v[j] = t[8 * s + j] * scale;
     split8(v, hi, lo);
 }
+// all 2 NT fragments of NT row tiles (register 8s+j of tile t = element j of k-step 2t+s: the two layouts hold the same values)
+template <int NT, typename V>
+MPG_DEV void tiles_to_frags(const f32x16* t, float scale, V* hi, V* lo) {
+    static_for<0, NT>([&](auto tc) {
+        MPG_CI(tt, tc);
+        tile_frag(t[tt], 0, scale, hi[2 * tt], lo[2 * tt]);
+        tile_frag(t[tt], 1, scale, hi[2 * tt + 1], lo[2 * tt + 1]);
+    });
+}
 // bias of the features a lane's accumulator registers hold (features in registers), times `scale`
 MPG_DEV f32x16 bias_regs(const float* bias, int tile, int h, float scale) {
     f32x16 t;
@@ -86,7 +106,7 @@ MPG_DEV f32x16 bias_lanes(const float* bias, int tile, int r, float scale) {
 }
 // acc += W_tile x  (features of W's row tile `m` in registers, tokens on lanes): W image as A, activation fragments as B
 template <int KS, typename V>
-MPG_DEV f32x16 proj_n(const __amdgpu_buffer_rsrc_t rw, int nfrag, int m, const V* xh, const V* xl, f32x16 acc, int lane16) {
+MPG_DEV f32x16 proj_n(WImg rw, int nfrag, int m, const V* xh, const V* xl, f32x16 acc, int lane16) {
     static_for<0, KS>([&](auto kc) {
         MPG_CI(ks, kc);
         const V wh = mab_wfrag<V>(rw, m * KS + ks, lane16), wl = mab_wfrag<V>(rw, nfrag + m * KS + ks, lane16);
@@ -96,7 +116,7 @@ MPG_DEV f32x16 proj_n(const __amdgpu_buffer_rsrc_t rw, int nfrag, int m, const V
 }
 // the same product with the operands swapped: tokens in registers, W's row tile on the lanes
 template <int KS, typename V>
-MPG_DEV f32x16 proj_t(const __amdgpu_buffer_rsrc_t rw, int nfrag, int m, const V* xh, const V* xl, f32x16 acc, int lane16) {
+MPG_DEV f32x16 proj_t(WImg rw, int nfrag, int m, const V* xh, const V* xl, f32x16 acc, int lane16) {
     static_for<0, KS>([&](auto kc) {
         MPG_CI(ks, kc);
         const V wh = mab_wfrag<V>(rw, m * KS + ks, lane16), wl = mab_wfrag<V>(rw, nfrag + m * KS + ks, lane16);
@@ -154,33 +174,52 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
     constexpr int KS = 2 * NT;            // k-steps of 16 over E = 32 NT features
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5, lane16 = lane * 16;
-    const long jet = (long)blockIdx.x * 4 + w;
-    if (jet >= p.B) return;               // whole waves leave; the kernel has no barrier
     uint32_t seed_lo = 0, seed_hi = 0;
     if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
     const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
     const float zs = sa * ws, inv_zs = 1.f / zs;
-    const int nfIn = 3 * NT * KS, nfE = NT * KS;
-    const __amdgpu_buffer_rsrc_t rIn = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Win), 0, 2 * nfIn * 1024, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wo), 0, 2 * nfE * 1024, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wf), 0, 2 * nfE * 1024, 0x00020000);
+    constexpr int nfIn = 3 * NT * KS, nfE = NT * KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sIn = smem;
+    char* const sO = sIn + 2 * nfIn * 1024;
+    char* const sF = sO + 2 * nfE * 1024;
+    float* const sBin = reinterpret_cast<float*>(sF + 2 * nfE * 1024);   // biases: in_proj [3E] | out_proj [E] | ff [E]
+    float* const sBo = sBin + 96 * NT;
+    float* const sBf = sBo + 32 * NT;
+    mab_fill(sIn, p.Win, 2 * nfIn * 1024);
+    mab_fill(sO, p.Wo, 2 * nfE * 1024);
+    mab_fill(sF, p.Wf, 2 * nfE * 1024);
+    for (int i = threadIdx.x; i < 160 * NT; i += blockDim.x)
+        sBin[i] = i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT]);
+    __syncthreads();
+    const WImg rIn = sIn, rO = sO, rF = sF;
+    const int nw = blockDim.x >> 6;
+    for (long jet = (long)blockIdx.x * nw + w; jet < p.B; jet += (long)gridDim.x * nw) {   // (no barrier inside)
 
     // rows past the end of a set are read from its last row and never stored; as keys they are masked
     const long xrow = jet * p.L + min(r, p.L - 1), yrow = jet * p.S + min(r, p.S - 1);
     const bool xvalid = r < p.L;
+    // every global load of the jet is issued here, together: x (kept as tiles for the residual), y, the key mask
+    f32x16 xt[NT], yt[CROSS ? NT : 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p.x, p.ldx, xrow, t, h);
+    if constexpr (CROSS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) yt[t] = rows_to_tile(p.y, p.ldy, yrow, t, h);
+    }
+    const f32x16 kneg = key_mask_regs(p.ignore, jet, p.S, h);
     V xh[KS], xl[KS], yh_[CROSS ? KS : 1], yl_[CROSS ? KS : 1];
-    rows_to_frags<KS>(p.x, p.ldx, xrow, sa, h, xh, xl);
-    if constexpr (CROSS) rows_to_frags<KS>(p.y, p.ldy, yrow, sa, h, yh_, yl_);
+    tiles_to_frags<NT>(xt, sa, xh, xl);
+    if constexpr (CROSS) tiles_to_frags<NT>(yt, sa, yh_, yl_);
     const V* yh = CROSS ? yh_ : xh;
     const V* yl = CROSS ? yl_ : xl;
-    const f32x16 kneg = key_mask_regs(p.ignore, jet, p.S, h);
 
     V oh[KS], ol[KS];                     // attention output as B fragments of the out-projection
     static_for<0, NT>([&](auto tc) {
         MPG_CI(t, tc);
-        const f32x16 Qn = proj_n<KS>(rIn, nfIn, t, xh, xl, bias_regs(p.bin, t, h, zs), lane16);
-        const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(p.bin, NT + t, h, zs), lane16);
-        const f32x16 Vt = proj_t<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_lanes(p.bin, 2 * NT + t, r, zs), lane16);
+        const f32x16 Qn = proj_n<KS>(rIn, nfIn, t, xh, xl, bias_regs(sBin, t, h, zs), lane16);
+        const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(sBin, NT + t, h, zs), lane16);
+        const f32x16 Vt = proj_t<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_lanes(sBin, 2 * NT + t, r, zs), lane16);
         V vh[2], vl[2];
         tile_frag(Vt, 0, inv_zs * sa, vh[0], vl[0]);
         tile_frag(Vt, 1, inv_zs * sa, vh[1], vl[1]);
@@ -220,10 +259,9 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
     V zh[KS], zl[KS];
     static_for<0, NT>([&](auto tc) {
         MPG_CI(t, tc);
-        const f32x16 acc = proj_n<KS>(rO, nfE, t, oh, ol, bias_regs(p.bo, t, h, zs), lane16);
-        const f32x16 xr = rows_to_tile(p.x, p.ldx, xrow, t, h);
+        const f32x16 acc = proj_n<KS>(rO, nfE, t, oh, ol, bias_regs(sBo, t, h, zs), lane16);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) z[t][i] = acc[i] * inv_zs + xr[i];
+        for (int i = 0; i < 16; ++i) z[t][i] = acc[i] * inv_zs + xt[t][i];
         drop_tile(z[t], seed_lo, seed_hi, p.tag + 0, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
         if (p.save_z != nullptr && xvalid) tile_to_rows(p.save_z, p.E, xrow, t, h, z[t], 1.f);
         tile_frag(z[t], 0, sa, zh[2 * t], zl[2 * t]);
@@ -232,7 +270,7 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
     // out = dropout(z + dropout_ff(LeakyReLU(z Wf' + bf)))
     static_for<0, NT>([&](auto tc) {
         MPG_CI(t, tc);
-        f32x16 u = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(p.bf, t, h, zs), lane16);
+        f32x16 u = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(sBf, t, h, zs), lane16);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float v = u[i] * inv_zs;
@@ -244,6 +282,7 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
         drop_tile(u, seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
         if (xvalid) tile_to_rows(p.out, p.ldo, xrow, t, h, u, 1.f);
     });
+    }  // jets of this wave
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -258,7 +297,7 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
 // so no tile is ever transposed through memory.  Rows of x past L carry a zero output gradient and keys past S or
 // masked have P = 0, so padding contributes nothing.
 template <int NT, typename V>
-MPG_DEV void acc_wt(const __amdgpu_buffer_rsrc_t rT, int nfragT, int KST, int ks0, const V* fh, const V* fl, f32x16* acc, int lane16) {
+MPG_DEV void acc_wt(WImg rT, int nfragT, int KST, int ks0, const V* fh, const V* fl, f32x16* acc, int lane16) {
     static_for<0, NT>([&](auto tc) {
         MPG_CI(t, tc);
         static_for<0, 2>([&](auto sc) {
@@ -276,18 +315,29 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
     constexpr int KS = 2 * NT;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5, lane16 = lane * 16;
-    const long jet = (long)blockIdx.x * 4 + w;
-    if (jet >= p.B) return;
     uint32_t seed_lo = 0, seed_hi = 0;
     if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
     const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
     const float zs = sa * ws, inv_zs = 1.f / zs, inv_sa2 = 1.f / (sa * sa);
-    const int nfIn = 3 * NT * KS, nfE = NT * KS, nfInT = NT * 3 * KS;
-    const __amdgpu_buffer_rsrc_t rIn = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Win), 0, 2 * nfIn * 1024, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wf), 0, 2 * nfE * 1024, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rInT = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.WinT), 0, 2 * nfInT * 1024, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rOT = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.WoT), 0, 2 * nfE * 1024, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rFT = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.WfT), 0, 2 * nfE * 1024, 0x00020000);
+    constexpr int nfIn = 3 * NT * KS, nfE = NT * KS, nfInT = NT * 3 * KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sIn = smem;
+    char* const sF = sIn + 2 * nfIn * 1024;
+    char* const sInT = sF + 2 * nfE * 1024;
+    char* const sOT = sInT + 2 * nfInT * 1024;
+    char* const sFT = sOT + 2 * nfE * 1024;
+    mab_fill(sIn, p.Win, 2 * nfIn * 1024);
+    mab_fill(sF, p.Wf, 2 * nfE * 1024);
+    mab_fill(sInT, p.WinT, 2 * nfInT * 1024);
+    mab_fill(sOT, p.WoT, 2 * nfE * 1024);
+    mab_fill(sFT, p.WfT, 2 * nfE * 1024);
+    float* const sBin = reinterpret_cast<float*>(sFT + 2 * nfE * 1024);  // biases: in_proj [3E] | ff [E]
+    float* const sBf = sBin + 96 * NT;
+    for (int i = threadIdx.x; i < 128 * NT; i += blockDim.x) sBin[i] = i < 96 * NT ? p.bin[i] : p.bf[i - 96 * NT];
+    __syncthreads();
+    const WImg rIn = sIn, rF = sF, rInT = sInT, rOT = sOT, rFT = sFT;
+    const int nw = blockDim.x >> 6;
+    for (long jet = (long)blockIdx.x * nw + w; jet < p.B; jet += (long)gridDim.x * nw) {   // (no barrier inside)
 
     const long xrow = jet * p.L + min(r, p.L - 1), yrow = jet * p.S + min(r, p.S - 1);
     const bool xvalid = r < p.L, yvalid = r < p.S;
@@ -296,21 +346,34 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
     bool key_off = !yvalid;               // this lane as a KEY (transposed tiles)
     if (p.ignore != nullptr) key_off = key_off || p.ignore[jet * p.S + min(r, p.S - 1)] != 0.f;
 
+    // every global load of the jet is issued here, together: dout, z, x, y (the key mask above)
+    f32x16 dzf[NT], zt[NT], xt[NT], yt[CROSS ? NT : 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        dzf[t] = rows_to_tile(p.dout, p.lddout, xrow, t, h);
+        zt[t] = rows_to_tile(p.save_z, p.E, xrow, t, h);
+        xt[t] = rows_to_tile(p.x, p.ldx, xrow, t, h);
+        if constexpr (CROSS) yt[t] = rows_to_tile(p.y, p.ldy, yrow, t, h);
+    }
+    VF xh[KS], xl[KS], yh_[CROSS ? KS : 1], yl_[CROSS ? KS : 1];
+    tiles_to_frags<NT>(xt, sa, xh, xl);
+    if constexpr (CROSS) tiles_to_frags<NT>(yt, sa, yh_, yl_);
+    const VF* yh = CROSS ? yh_ : xh;
+    const VF* yl = CROSS ? yl_ : xl;
+
     // ---- feed-forward half: dzf = dropout'(dout) ; du = dzf drop_ff' act'(u) ; dz = dzf + du Wf ; dza = dropout'(dz)
     VB dzah[KS], dzal[KS];
     f32x16 dxa[NT];                       // gradient with respect to x: starts as the residual path
     {
         VF zh[KS], zl[KS];
-        rows_to_frags<KS>(p.save_z, p.E, xrow, sa, h, zh, zl);
-        f32x16 dzf[NT];
+        tiles_to_frags<NT>(zt, sa, zh, zl);
         VB duh[KS], dul[KS];
         static_for<0, NT>([&](auto tc) {
             MPG_CI(t, tc);
-            dzf[t] = rows_to_tile(p.dout, p.lddout, xrow, t, h);
 #pragma unroll
             for (int i = 0; i < 16; ++i) dzf[t][i] *= xlive;
             drop_tile(dzf[t], seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
-            const f32x16 u = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(p.bf, t, h, zs), lane16);
+            const f32x16 u = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(sBf, t, h, zs), lane16);
             f32x16 du;
 #pragma unroll
             for (int i = 0; i < 16; ++i) du[i] = dzf[t][i] * ((p.ff_act && !(u[i] > 0.f)) ? p.alpha : 1.f);
@@ -336,22 +399,16 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
     }
     f32x16* dkv_acc = CROSS ? dya : dxa;
 
-    VF xh[KS], xl[KS], yh_[CROSS ? KS : 1], yl_[CROSS ? KS : 1];
-    rows_to_frags<KS>(p.x, p.ldx, xrow, sa, h, xh, xl);
-    if constexpr (CROSS) rows_to_frags<KS>(p.y, p.ldy, yrow, sa, h, yh_, yl_);
-    const VF* yh = CROSS ? yh_ : xh;
-    const VF* yl = CROSS ? yl_ : xl;
-
     static_for<0, NT>([&](auto tc) {
         MPG_CI(t, tc);
         // gradient of the attention output of this tile's two heads, both orientations
         const f32x16 dOn = proj_n<KS>(rOT, nfE, t, dzah, dzal, zero16(), lane16);
         const f32x16 dOp = proj_t<KS>(rOT, nfE, t, dzah, dzal, zero16(), lane16);
-        const f32x16 Qn = proj_n<KS>(rIn, nfIn, t, xh, xl, bias_regs(p.bin, t, h, zs), lane16);
-        const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(p.bin, NT + t, h, zs), lane16);
-        const f32x16 Vn = proj_n<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_regs(p.bin, 2 * NT + t, h, zs), lane16);
-        const f32x16 Qp = proj_t<KS>(rIn, nfIn, t, xh, xl, bias_lanes(p.bin, t, r, zs), lane16);
-        const f32x16 Kp = proj_t<KS>(rIn, nfIn, NT + t, yh, yl, bias_lanes(p.bin, NT + t, r, zs), lane16);
+        const f32x16 Qn = proj_n<KS>(rIn, nfIn, t, xh, xl, bias_regs(sBin, t, h, zs), lane16);
+        const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(sBin, NT + t, h, zs), lane16);
+        const f32x16 Vn = proj_n<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_regs(sBin, 2 * NT + t, h, zs), lane16);
+        const f32x16 Qp = proj_t<KS>(rIn, nfIn, t, xh, xl, bias_lanes(sBin, t, r, zs), lane16);
+        const f32x16 Kp = proj_t<KS>(rIn, nfIn, NT + t, yh, yl, bias_lanes(sBin, NT + t, r, zs), lane16);
         VB kph[2], kpl[2], qph[2], qpl[2], doph[2], dopl[2];
         static_for<0, 2>([&](auto sc) {
             MPG_CI(s, sc);
@@ -440,6 +497,7 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
             if (p.dy != nullptr && yvalid) tile_to_rows(p.dy, p.lddy, yrow, t, h, dya[t], 1.f);
         }
     });
+    }  // jets of this wave
 }
 
 int mab_check(const MpgMab* p) {
@@ -450,36 +508,53 @@ int mab_check(const MpgMab* p) {
     return 0;
 }
 
+
+// waves (= jets in flight) per workgroup: as many workgroups as CUs first, then up to four waves each
+int mab_waves(int B) {
+    static const int forced = getenv("MPG_MAB_WAVES") ? atoi(getenv("MPG_MAB_WAVES")) : 0;   // (experiments)
+    if (forced >= 1 && forced <= 4) return forced;
+    return B <= 256 ? 1 : (B <= 512 ? 2 : 4);
+}
+
+template <typename K>
+int mab_launch(K kernel, const MpgMab* p, int lds_bytes, hipStream_t st) {
+    const int nw = mab_waves(p->B);
+    const int grid = (p->B + nw - 1) / nw < 1024 ? (p->B + nw - 1) / nw : 1024;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * nw), lds_bytes, st, *p);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" int mpg_mab_bwd(const MpgMab* p, void* stream) {
     if (const int rc = mab_check(p)) return rc;
     if (p->dout == nullptr || p->save_z == nullptr || (p->dk == nullptr) != (p->dv == nullptr)) return -5;
-    if (p->lddout % 4 || (p->dq != nullptr && p->lddq % 4) || (p->dk != nullptr && p->lddkv % 4) || (p->dx != nullptr && p->lddx % 4) || (p->dy != nullptr && p->lddy % 4)) return -3;
+    if (p->lddout % 4 || (p->dq != nullptr && p->lddq % 4) || (p->dk != nullptr && p->lddkv % 4) ||
+        (p->dx != nullptr && p->lddx % 4) || (p->dy != nullptr && p->lddy % 4)) return -3;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((p->B + 3) / 4), block(256);
     const bool cross = p->y != p->x;
+    const int NT = p->E / 32;
+    const int lds = 2 * 1024 * (2 * 3 * NT * 2 * NT + 3 * NT * 2 * NT) + 4 * 128 * NT;   // Win, WinT (3E x E) + Wf, WoT, WfT (E x E) + biases
     if (p->E == 64) {
-        if (cross) hipLaunchKernelGGL((mab_bwd_kernel<2, true>), grid, block, 0, st, *p);
-        else hipLaunchKernelGGL((mab_bwd_kernel<2, false>), grid, block, 0, st, *p);
-    } else {
-        if (cross) hipLaunchKernelGGL((mab_bwd_kernel<1, true>), grid, block, 0, st, *p);
-        else hipLaunchKernelGGL((mab_bwd_kernel<1, false>), grid, block, 0, st, *p);
+        if (cross) { MPG_ENSURE_LDS((mab_bwd_kernel<2, true>), lds); return mab_launch(mab_bwd_kernel<2, true>, p, lds, st); }
+        MPG_ENSURE_LDS((mab_bwd_kernel<2, false>), lds);
+        return mab_launch(mab_bwd_kernel<2, false>, p, lds, st);
     }
-    return (int)hipGetLastError();
+    if (cross) return mab_launch(mab_bwd_kernel<1, true>, p, lds, st);
+    return mab_launch(mab_bwd_kernel<1, false>, p, lds, st);
 }
 
 extern "C" int mpg_mab_fwd(const MpgMab* p, void* stream) {
     if (const int rc = mab_check(p)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((p->B + 3) / 4), block(256);
     const bool cross = p->y != p->x;
+    const int NT = p->E / 32;
+    const int lds = 2 * 1024 * (3 * NT * 2 * NT + 2 * NT * 2 * NT) + 4 * 160 * NT;   // Win + Wo, Wf + biases
     if (p->E == 64) {
-        if (cross) hipLaunchKernelGGL((mab_fwd_kernel<2, true>), grid, block, 0, st, *p);
-        else hipLaunchKernelGGL((mab_fwd_kernel<2, false>), grid, block, 0, st, *p);
-    } else {
-        if (cross) hipLaunchKernelGGL((mab_fwd_kernel<1, true>), grid, block, 0, st, *p);
-        else hipLaunchKernelGGL((mab_fwd_kernel<1, false>), grid, block, 0, st, *p);
+        if (cross) { MPG_ENSURE_LDS((mab_fwd_kernel<2, true>), lds); return mab_launch(mab_fwd_kernel<2, true>, p, lds, st); }
+        MPG_ENSURE_LDS((mab_fwd_kernel<2, false>), lds);
+        return mab_launch(mab_fwd_kernel<2, false>, p, lds, st);
     }
-    return (int)hipGetLastError();
+    if (cross) return mab_launch(mab_fwd_kernel<1, true>, p, lds, st);
+    return mab_launch(mab_fwd_kernel<1, false>, p, lds, st);
 }

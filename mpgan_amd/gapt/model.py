@@ -100,10 +100,13 @@ class MAB(nn.Module):
             pk = self.__dict__["_pack"] = ops.PackedMAB(att.in_proj_weight, att.out_proj.weight, self.ff.net[0].weight)
         return pk.ensure()
 
+    def packed_sets(self):
+        pk = self.__dict__.get("_pack")
+        return [] if pk is None else [pk]
+
     def refresh_packed(self):
         """Re-pack after an update torch cannot see (``train.TrainStep``'s fused optimizer step)."""
-        pk = self.__dict__.get("_pack")
-        if pk is not None:
+        for pk in self.packed_sets():
             pk.refresh()
 
     def _fused(self, x, y, ignore, B, L, S):

@@ -117,9 +117,13 @@ class MPLayer(nn.Module):
             pk = cache[key] = ops.PackedMPLayer(params, self.input_node_size, self.output_node_size, *key, plist=plist)
         return pk
 
+    def packed_sets(self):
+        """The weight-image sets built so far (``train.TrainStep`` rebuilds those of a whole network together)."""
+        return list(self.__dict__.get("_pack_cache", {}).values())
+
     def refresh_packed(self):
         """Re-pack after an update torch cannot see (a kernel writing the parameters' storage directly)."""
-        for pk in self.__dict__.get("_pack_cache", {}).values():
+        for pk in self.packed_sets():
             pk.refresh()
 
     def __repr__(self):

@@ -223,6 +223,9 @@ def linear_bwd_weight(dy, x, *, out=None, out_col0=0, out_scale=1.0, bias_out=No
 WGRAD_TARGET_WGS = int(__import__("os").environ.get("MPG_WGRAD_TARGET", "512"))
 
 
+GROUP_MAX = 16   # MPG_GROUP_MAX of include/mpgan_amd.h
+
+
 class WgradBatch:
     """Weight gradients dW[:, col0:col0+K] = scale * dy^T @ x (+ bias = column sums of dy) collected and issued as
     ONE grouped split-K GEMM launch plus ONE grouped reduction (``linear_bwd_weight`` does one at a time)."""
@@ -240,8 +243,8 @@ class WgradBatch:
         self.jobs.append((dy, x, out, out_col0, out_scale, bias_out, splitk, part, accumulate))
 
     def flush(self):
-        for i0 in range(0, len(self.jobs), 8):
-            jobs = self.jobs[i0:i0 + 8]
+        for i0 in range(0, len(self.jobs), GROUP_MAX):
+            jobs = self.jobs[i0:i0 + GROUP_MAX]
             n = len(jobs)
             gs, sk, rj = (MpgGemm * n)(), (C.c_int * n)(), (MpgReduceJob * n)()
             for i, (dy, x, out, col0, scale, bias_out, splitk, part, acc) in enumerate(jobs):
@@ -293,6 +296,24 @@ def _img_elems(rows, cols):
     return 2 * ((rows + 31) // 32) * ((cols + 31) // 32) * 2 * 512   # 16-bit elements of a hi|lo image
 
 
+PACK_MAX = 24    # MPG_PACK_MAX_JOBS of include/mpgan_amd.h
+
+
+def refresh_many(packs):
+    """Rebuild the weight images of several ``Packed*`` sets (all layers of a network after an optimizer step) with as
+    few ``mpg_pack_many`` launches as the job limit allows."""
+    todo = [j for pk in packs for j in pk.jobs()]
+    for i0 in range(0, len(todo), PACK_MAX):
+        chunk = todo[i0:i0 + PACK_MAX]
+        jobs = (MpgPackJob * len(chunk))()
+        for j, (W, rows, cols, tr, scale, f16, rs, sc, img) in zip(jobs, chunk):
+            j.W, j.ldw, j.rows, j.cols, j.transpose = _p(W), W.stride(0), rows, cols, tr
+            j.scale, j.f16, j.img, j.row_split, j.split_cols = scale, int(f16), C.c_void_p(img.data_ptr()), rs, sc
+        check(_lib.lib().mpg_pack_many(jobs, len(chunk), _stream()), "mpg_pack_many")
+    for pk in packs:
+        pk._key = pk._current_key()
+
+
 class PackedMPLayer:
     """All weight images one MPLayer call needs (edge network, node network, their transposes and the stacked
     a|c view of fe.net.0), in persistent buffers, rebuilt by ONE ``mpg_pack_many`` launch.
@@ -326,14 +347,12 @@ class PackedMPLayer:
     def _current_key(self):
         return tuple((q.data_ptr(), q._version) for q in self.params)
 
+    def jobs(self):
+        """(W, rows, cols, transpose, scale, f16, row_split, split_cols, image) per image."""
+        return [v + (self.img[k],) for k, v in self._spec.items()]
+
     def refresh(self):
-        jobs = (MpgPackJob * len(self._spec))()
-        for i, (k, (W, rows, cols, tr, scale, f16, rs, sc)) in enumerate(self._spec.items()):
-            j = jobs[i]
-            j.W, j.ldw, j.rows, j.cols, j.transpose = _p(W), W.stride(0), rows, cols, tr
-            j.scale, j.f16, j.img, j.row_split, j.split_cols = scale, int(f16), C.c_void_p(self.img[k].data_ptr()), rs, sc
-        check(_lib.lib().mpg_pack_many(jobs, len(self._spec), _stream()), "mpg_pack_many")
-        self._key = self._current_key()
+        refresh_many([self])
 
     def ensure(self):
         if self._key != self._current_key():
@@ -776,14 +795,11 @@ class PackedMAB:
     def _current_key(self):
         return tuple((q.data_ptr(), q._version) for q in self.params)
 
+    def jobs(self):
+        return [v + (0, 0, self.img[k]) for k, v in self._spec.items()]
+
     def refresh(self):
-        jobs = (MpgPackJob * len(self._spec))()
-        for i, (k, (W, rows, cols, tr, scale, f16)) in enumerate(self._spec.items()):
-            j = jobs[i]
-            j.W, j.ldw, j.rows, j.cols, j.transpose = _p(W), W.stride(0), rows, cols, tr
-            j.scale, j.f16, j.img, j.row_split, j.split_cols = scale, int(f16), C.c_void_p(self.img[k].data_ptr()), 0, 0
-        check(_lib.lib().mpg_pack_many(jobs, len(self._spec), _stream()), "mpg_pack_many")
-        self._key = self._current_key()
+        refresh_many([self])
 
     def ensure(self):
         if self._key != self._current_key():

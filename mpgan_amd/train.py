@@ -356,10 +356,16 @@ class TrainStep:
 
     @staticmethod
     def _refresh_packed(module: nn.Module):
-        # the fused optimiser wrote the parameters behind autograd's back: rebuild the layers' cached weight images
+        # the fused optimiser wrote the parameters behind autograd's back: rebuild the layers' cached weight images,
+        # all layers of the network in as few launches as the pack-job limit allows
+        packs = []
         for m in module.modules():
-            if hasattr(m, "refresh_packed"):
+            if hasattr(m, "packed_sets"):
+                packs += m.packed_sets()
+            elif hasattr(m, "refresh_packed"):
                 m.refresh_packed()
+        if packs:
+            ops.refresh_many(packs)
 
     def _seg_G(self):  # D_optimizer.step() (train.py:461) + train_G up to backward (:494-520)
         self.fD.step(self.lr_disc, gscale=1.0 / self.world)
