@@ -14,16 +14,28 @@
 #include "common.h"
 #include "../../include/mpgan_amd.h"
 
+#ifdef MPG_CHSTAMP  // diagnostic build (tools/chain_stamps.py): s_memtime at the phase boundaries, every wave of workgroup 0
+__device__ unsigned long long g_ch_stamps[8 * 16];
+#define CH_STAMP(i) do { ch_st[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CH_STAMP(i) do {} while (0)
+#endif
+
 namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int CH_MAXKS = 16;                       // k-steps of 16 features: K <= 256
 constexpr int CH_FB_BYTES = CH_MAXKS * 2 * 1024;   // one fragment buffer: [k-step][hi|lo][lane] 16 B
-constexpr int CH_LDS_BYTES = 2 * CH_FB_BYTES;      // 65,536
+constexpr int CH_BIAS_FLOATS = 3 * 256;            // biases of the first 256 outputs of each layer
+constexpr int CH_LDS_BYTES = 2 * CH_FB_BYTES + CH_BIAS_FLOATS * 4;   // 68,608
 
 MPG_DEV float4 chld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <bool F16>
+// KS0 / KS1 / KS2: the number of 16-feature k-steps of each layer when known at compile time (0 = run-time loop).  With
+// them the k loop is straight-line code, which is what lets the prefetched weight fragments stay in flight: a branch
+// inside the loop makes the compiler wait for EVERY outstanding load at each k-step (~600 clk of L2 latency each,
+// measured with the MPG_CHSTAMP build: 9.5k clk for 48 MFMAs), the straight-line form waits for the oldest only.
+template <bool F16, int KS0, int KS1, int KS2>
 __global__ __launch_bounds__(512, 1) void chain_kernel(const MpgChain p) {
     typedef typename FragT<F16>::type V;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -31,6 +43,10 @@ __global__ __launch_bounds__(512, 1) void chain_kernel(const MpgChain p) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * 32;
+#ifdef MPG_CHSTAMP
+    unsigned long long ch_st[16] = {};
+#endif
+    CH_STAMP(0);
     uint32_t seed_lo = 0, seed_hi = 0;
     if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
 
@@ -39,6 +55,15 @@ __global__ __launch_bounds__(512, 1) void chain_kernel(const MpgChain p) {
     // wscale_l * W, so its accumulators hold wscale_l * ascale * z
     const float ascale = p.ascale > 0.f ? p.ascale : 1.f;
     const int lane16 = lane * 16;
+    // biases: one copy in LDS for the whole workgroup (zero where a layer has none / beyond nbias); visible after the
+    // barrier that follows the input staging
+    float* const sbias = reinterpret_cast<float*>(smem + 2 * CH_FB_BYTES);
+    for (int i = tid; i < CH_BIAS_FLOATS; i += 512) {
+        const int l = i >> 8, n = i & 255;
+        float b = 0.f;
+        if (l < p.nlayers && p.L[l].bias != nullptr && n < (p.L[l].nbias ? p.L[l].nbias : p.L[l].N)) b = p.L[l].bias[n];
+        sbias[i] = b;
+    }
     // Weight fragments come from L2 (~700 ns away): a wave keeps the first 8 k-steps of its NEXT tile in flight
     // while it works on the current one -- the preload of layer l+1's tile is issued before layer l's MFMAs (the
     // weights do not depend on the data), layer 0's before the input staging -- and refills each slot with
@@ -62,7 +87,7 @@ __global__ __launch_bounds__(512, 1) void chain_kernel(const MpgChain p) {
     {
         int KS, MT, nfrag;
         layer_geom(0, KS, MT, nfrag);
-        if (w < MT) preload(std::integral_constant<int, 0>{}, w);
+        preload(std::integral_constant<int, 0>{}, min(w, MT - 1));   // (idle waves load a valid tile: no branch)
     }
 
     // ---- stage the input rows as B fragments: unit = (k-step, lane) = 8 features of one row
@@ -121,7 +146,9 @@ __global__ __launch_bounds__(512, 1) void chain_kernel(const MpgChain p) {
         }
     }
 
+    CH_STAMP(1);
     __syncthreads();  // input fragments staged
+    CH_STAMP(2);
 
     static_for<0, 3>([&](auto lc) {
         MPG_CI(l, lc);
@@ -132,42 +159,72 @@ __global__ __launch_bounds__(512, 1) void chain_kernel(const MpgChain p) {
             int KS, MT, nfrag;
             layer_geom(l, KS, MT, nfrag);
             const bool last = l + 1 == p.nlayers;
-            if constexpr (l + 1 < 3) {
-                if (!last) {
-                    int KSn, MTn, nfn;
-                    layer_geom(l + 1, KSn, MTn, nfn);
-                    if (w < MTn) preload(std::integral_constant<int, l + 1>{}, w);
+            // The next layer's first fragments are requested AFTER this tile's bias / gate operands: loads complete in
+            // issue order, so whatever the k loop or the epilogue waits for must not sit behind 16 KiB of prefetch.
+            auto preload_next = [&]() {
+                if constexpr (l + 1 < 3) {
+                    if (!last) {
+                        int KSn, MTn, nfn;
+                        layer_geom(l + 1, KSn, MTn, nfn);
+                        preload(std::integral_constant<int, l + 1>{}, min(w, MTn - 1));
+                    }
                 }
-            }
+            };
+            if (w >= MT) preload_next();          // a wave without a tile in this layer may have one in the next
             for (int tile = w; tile < MT; tile += 8) {
                 if (tile != w) preload(lc, tile);  // more than 8 tiles in a layer: later tiles load late
                 f32x16 acc;
                 const float zscale = (L.wscale > 0.f ? L.wscale : 1.f) * ascale, inv_zscale = 1.f / zscale;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = 32 * tile + 8 * g + 4 * h;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[4 * g + t] = (L.bias != nullptr && n + t < (L.nbias ? L.nbias : L.N)) ? L.bias[n + t] * zscale : 0.f;
-                }
+                for (int k = 0; k < 16; ++k) acc[k] = 0.f;
                 // the gate operand (an activation saved by the forward, in HBM) is requested before the MFMAs
-                float hv[16];
+                // (and so is the residual the epilogue adds).  Rows of 16-byte aligned groups of four take one float4 load per
+                // group with clamped addresses and no branch in between -- all of a tile's loads are then in flight together.
+                auto tile_rows = [&](const float* base, int ld, float (&out)[16]) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) hv[k] = 0.f;
-                if (L.gateH != nullptr && m0 + r < p.M) {
+                    for (int k = 0; k < 16; ++k) out[k] = 0.f;
+                    if (base == nullptr) return;
+                    const int mr = m0 + r;
+                    if ((ld % 4 == 0) && (L.N % 4 == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0)) {
+                        const float live = mr < p.M ? 1.f : 0.f;
+                        const float* row = base + (size_t)min(mr, p.M - 1) * ld;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int n = 32 * tile + 8 * g + 4 * h;
-                        if (n + 4 <= L.N && (L.ldh % 4 == 0)) {
-                            const float4 t4 = chld4(L.gateH + (size_t)(m0 + r) * L.ldh + n);
-                            hv[4 * g + 0] = t4.x; hv[4 * g + 1] = t4.y; hv[4 * g + 2] = t4.z; hv[4 * g + 3] = t4.w;
-                        } else {
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) if (n + t < L.N) hv[4 * g + t] = L.gateH[(size_t)(m0 + r) * L.ldh + n + t];
+                        for (int g = 0; g < 4; ++g) {
+                            const int n = 32 * tile + 8 * g + 4 * h;
+                            const float4 t4 = chld4(row + min(n, L.N - 4));
+                            const float lv = n < L.N ? live : 0.f;
+                            out[4 * g + 0] = t4.x * lv; out[4 * g + 1] = t4.y * lv; out[4 * g + 2] = t4.z * lv; out[4 * g + 3] = t4.w * lv;
                         }
+                    } else if (mr < p.M) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const int n = 32 * tile + 8 * g + 4 * h + t;
+                                if (n < L.N) out[4 * g + t] = base[(size_t)mr * ld + n];
+                            }
                     }
-                }
+                };
+                float hv[16], rv[16];
+                tile_rows(L.gateH, L.ldh, hv);
+                tile_rows(L.resid, L.ldr, rv);
+                if (tile == w) preload_next();
                 // B fragments (activations, LDS) are read one k-step ahead of their MFMAs
                 V bh = fin[0 * 64 + lane], bl = fin[1 * 64 + lane];
+                constexpr int KSC = l == 0 ? KS0 : (l == 1 ? KS1 : KS2);
+                if constexpr (KSC > 0) {
+                    static_for<0, KSC>([&](auto kc) {
+                        MPG_CI(ks, kc);
+                        constexpr int u = ks & 7, kn = ks + 1 < KSC ? ks + 1 : KSC - 1;
+                        const V nh = fin[(kn * 2 + 0) * 64 + lane], nl = fin[(kn * 2 + 1) * 64 + lane];
+                        acc = mfma3(wbuf[l & 1][u][0], wbuf[l & 1][u][1], bh, bl, acc);
+                        bh = nh; bl = nl;
+                        if constexpr (ks + 8 < KSC) { wbuf[l & 1][u][0] = wfrag(l, tile, ks + 8, 0); wbuf[l & 1][u][1] = wfrag(l, tile, ks + 8, 1); }
+                        // (left alone the scheduler sinks each refill down to its use, eight k-steps later, to shorten
+                        // its live range -- and the k-step then waits out the whole L2 latency)
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                } else
                 for (int k0 = 0; k0 < KS; k0 += 8) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
@@ -181,36 +238,59 @@ __global__ __launch_bounds__(512, 1) void chain_kernel(const MpgChain p) {
                         }
                     }
                 }
+                CH_STAMP(3 + 3 * l);
                 // ---- epilogue: register 4g+t  <->  feature 32 tile + 8g + 4h + t of row m0 + r
                 const int m = m0 + r;
                 float v[16];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int n = 32 * tile + 8 * g + 4 * h;
+                    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (tile < 8) {   // (wave-uniform) the staged copy
+                        const float4 b4 = *reinterpret_cast<const float4*>(sbias + 256 * l + n);
+                        bias4[0] = b4.x; bias4[1] = b4.y; bias4[2] = b4.z; bias4[3] = b4.w;
+                    } else if (L.bias != nullptr) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) if (n + t < (L.nbias ? L.nbias : L.N)) bias4[t] = L.bias[n + t];
+                    }
                     float x4[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        float x = acc[4 * g + t] * inv_zscale;
+                        float x = acc[4 * g + t] * inv_zscale + bias4[t];
                         if (L.act) x = lrelu(x, p.alpha);
                         x4[t] = x;
                     }
-                    if (L.drop_thr) {
+                    // dropout masks: ONE hash word per (row, tile) in bit mode (p = 1/2), one per group of four features
+                    // otherwise -- the same words drop_keep_f(row, feature) reads (common.h)
+                    auto keep4 = [&](uint32_t tag, uint32_t thr, bool (&keep)[4]) {
+                        if (thr == 128u) {
+                            const uint32_t wd = drop_word(seed_lo, seed_hi, tag, (uint32_t)m, DROP_BIT_GRP + (uint32_t)tile) >> (8 * g + 4 * h);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            x4[t] = drop_keep_f(seed_lo, seed_hi, L.drop_tag, (uint32_t)m, n + t, L.drop_thr) ? x4[t] * L.drop_scale : 0.f;
+                            for (int t = 0; t < 4; ++t) keep[t] = (wd >> t) & 1u;
+                        } else {
+                            const uint32_t wd = drop_word(seed_lo, seed_hi, tag, (uint32_t)m, (uint32_t)(8 * tile + 2 * g + h));
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) keep[t] = drop_keep(wd, t, thr);
+                        }
+                    };
+                    if (L.drop_thr) {
+                        bool keep[4];
+                        keep4(L.drop_tag, L.drop_thr, keep);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) x4[t] = keep[t] ? x4[t] * L.drop_scale : 0.f;
                     }
                     if (L.gateH != nullptr) {  // backward through (dropout o LeakyReLU) of the layer that produced H
+                        bool keep[4] = {true, true, true, true};
+                        if (L.gate_thr) keep4(L.gate_tag, L.gate_thr, keep);
+                        const float gs = L.gate_thr ? L.gate_scale : 1.f;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
-                            float gt = L.gate_act ? lrelu_grad(hv[4 * g + t], p.alpha) : 1.f;
-                            if (L.gate_thr) gt = drop_keep_f(seed_lo, seed_hi, L.gate_tag, (uint32_t)m, n + t, L.gate_thr) ? gt * L.gate_scale : 0.f;
-                            x4[t] *= gt;
+                            const float gt = L.gate_act ? lrelu_grad(hv[4 * g + t], p.alpha) : 1.f;
+                            x4[t] *= keep[t] ? gt * gs : 0.f;
                         }
                     }
-                    if (L.resid != nullptr && m < p.M) {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) if (n + t < L.N) x4[t] += L.resid[(size_t)m * L.ldr + n + t];
-                    }
+                    for (int t = 0; t < 4; ++t) x4[t] += rv[4 * g + t];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) if (n + t >= L.N || m >= p.M) x4[t] = 0.f;  // padding stays exactly zero
                     if (L.out != nullptr && m < p.M) {
@@ -236,9 +316,17 @@ __global__ __launch_bounds__(512, 1) void chain_kernel(const MpgChain p) {
                     fout[((2 * tile + 1) * 2 + 1) * 64 + lane] = lo;
                 }
             }
+            CH_STAMP(4 + 3 * l);
             __syncthreads();
+            CH_STAMP(5 + 3 * l);
         }
     });
+#ifdef MPG_CHSTAMP
+    if (blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g_ch_stamps[w * 16 + i] = ch_st[i];
+    }
+#endif
 }
 
 struct PackJobs { MpgPackJob j[MPG_PACK_MAX_JOBS]; int n; int frag0[MPG_PACK_MAX_JOBS + 1]; };
@@ -286,6 +374,12 @@ __global__ void pack_many_kernel(const PackJobs jobs) {
 
 }  // namespace
 
+#ifdef MPG_CHSTAMP
+extern "C" int mpg_debug_chain_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ch_stamps), sizeof(unsigned long long) * 8 * 16);
+}
+#endif
+
 extern "C" int mpg_chain(const MpgChain* p, void* stream) {
     if (p->M <= 0 || p->nlayers < 1 || p->nlayers > 3) return -1;
     if (!(p->alpha >= 0.f && p->alpha <= 1.f)) return -4;
@@ -296,14 +390,24 @@ extern "C" int mpg_chain(const MpgChain* p, void* stream) {
     if (p->a_slabs < 1 || p->K1 > p->L[0].K || (p->K1 < p->L[0].K && p->A2 == nullptr)) return -2;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((p->M + 31) / 32), block(512);
+    // k-steps per layer; the shapes MPLayer uses have straight-line instantiations, anything else the run-time loops
+    int ks[3] = {0, 0, 0};
+    for (int l = 0; l < p->nlayers; ++l) ks[l] = 2 * ((p->L[l].K + 31) / 32);
+#define MPG_CHAIN_LAUNCH(F16V, A, B, C)                                                               \
+    do {                                                                                              \
+        MPG_ENSURE_LDS((chain_kernel<F16V, A, B, C>), CH_LDS_BYTES);                                  \
+        hipLaunchKernelGGL((chain_kernel<F16V, A, B, C>), grid, block, CH_LDS_BYTES, st, *p);         \
+        return (int)hipGetLastError();                                                                \
+    } while (0)
     if (p->f16) {
-        MPG_ENSURE_LDS((chain_kernel<true>), CH_LDS_BYTES);
-        hipLaunchKernelGGL((chain_kernel<true>), grid, block, CH_LDS_BYTES, st, *p);
-    } else {
-        MPG_ENSURE_LDS((chain_kernel<false>), CH_LDS_BYTES);
-        hipLaunchKernelGGL((chain_kernel<false>), grid, block, CH_LDS_BYTES, st, *p);
+        if (ks[0] == 14 && ks[1] == 16 && ks[2] == 16) MPG_CHAIN_LAUNCH(true, 14, 16, 16);   // fn forward
+        if (ks[0] == 2 && p->nlayers == 1) MPG_CHAIN_LAUNCH(true, 2, 0, 0);                   // a | c projection
+        MPG_CHAIN_LAUNCH(true, 0, 0, 0);
     }
-    return (int)hipGetLastError();
+    if (ks[0] == 2 && ks[1] == 16 && ks[2] == 16) MPG_CHAIN_LAUNCH(false, 2, 16, 16);         // fn input-gradient chain
+    if (ks[0] == 12 && p->nlayers == 1) MPG_CHAIN_LAUNCH(false, 12, 0, 0);                     // dx from da | dc
+    MPG_CHAIN_LAUNCH(false, 0, 0, 0);
+#undef MPG_CHAIN_LAUNCH
 }
 
 extern "C" int mpg_pack_many(const MpgPackJob* jobs, int njobs, void* stream) {
