@@ -13,6 +13,7 @@
 // 32-feature output tiles; two waves per SIMD overlap one wave's epilogue with the other's MFMAs.
 #include "common.h"
 #include "../../include/mpgan_amd.h"
+#include "chain_int.h"
 
 #ifdef MPG_CHSTAMP  // diagnostic build (tools/chain_stamps.py): s_memtime at the phase boundaries, every wave of workgroup 0
 __device__ unsigned long long g_ch_stamps[8 * 16];
@@ -389,6 +390,10 @@ extern "C" int mpg_chain(const MpgChain* p, void* stream) {
     }
     if (p->a_slabs < 1 || p->K1 > p->L[0].K || (p->K1 < p->L[0].K && p->A2 == nullptr)) return -2;
     hipStream_t st = (hipStream_t)stream;
+    {   // the MPLayer shapes have their own schedule (chain2.hip)
+        const int rc = mpg_chain2_try(p, st);
+        if (rc != MPG_CHAIN2_NA) return rc;
+    }
     dim3 grid((p->M + 31) / 32), block(512);
     // k-steps per layer; the shapes MPLayer uses have straight-line instantiations, anything else the run-time loops
     int ks[3] = {0, 0, 0};

@@ -1,0 +1,393 @@
+// Chained per-node MLP, the form the MPLayer shapes run (mpg_chain's description: include/mpgan_amd.h; the general
+// kernel and the layouts: chain.hip).  Same arithmetic, different schedule:
+//
+//   * four waves, one per SIMD, each owning up to TWO 32-feature output tiles of a layer (tiles w and w + 4).  A whole
+//     tile of weight fragments (up to 16 k-steps, hi and lo) sits in registers; the buffer a tile frees is refilled at
+//     once with the same slot's tile of the NEXT layer, so a fragment is requested a full tile (>= 1,500 clk) before
+//     its MFMA and nothing in a k loop ever waits for L2.
+//   * the k loops are straight-line code cut into MFMA slots (common idiom of the edge kernels: one MFMA, a few VALU
+//     instructions, a scheduling fence): the epilogue of a wave's first tile -- bias, LeakyReLU, dropout, gate, residual,
+//     store, hi/lo split into the next layer's fragments -- runs in the slots of its second tile's MFMAs, element by
+//     element.  Only the second tile's epilogue is exposed.  (Measured on the general kernel with MPG_CHSTAMP: per
+//     layer 5k clk of MFMA loop + 5.5k clk of epilogue on two waves per SIMD in lock step, against 3k clk of MFMAs.)
+//   * no branch inside a loop or an epilogue unit: options are uniform selects, stores go through buffer descriptors
+//     whose bounds check drops what must not be written, the dropout mode is a template parameter.
+#include "common.h"
+#include "../../include/mpgan_amd.h"
+#include "chain_int.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef unsigned int c2_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int C2_FB = 16 * 2 * 1024;               // one fragment buffer: [k-step][hi|lo][lane] 16 B
+constexpr int C2_BIAS = 3 * 256;
+constexpr int C2_LDS = 2 * C2_FB + C2_BIAS * 4;    // 68,608
+
+template <int NU, int NS, int SL, typename F>
+MPG_DEV void c2_slot(F&& unit) {                   // units u of [0, NU) that fall into slot SL of NS
+    if constexpr (NU > 0) {
+        constexpr int u0 = (SL * NU) / NS, u1 = ((SL + 1) * NU) / NS;
+        static_for<u0, u1>(unit);
+    }
+}
+template <bool F16, typename V>
+MPG_DEV f32x16 c2_mma(const V a, const V b, const f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+MPG_DEV float4 c2_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// state of a tile between its k loop and the end of its epilogue
+struct C2Tile {
+    f32x16 acc;
+    float hv[16], rv[16], v[16];
+    float b4[4];
+    uint32_t wdrop, wgate;
+    int tile;
+};
+
+// keep decision of element (g, t) from the word(s) of its tile / group; DM 1 = byte mode, 2 = bit mode (common.h)
+template <int DM>
+MPG_DEV bool c2_keep(uint32_t word, int g, int t, uint32_t thr) {
+    if constexpr (DM == 2) return (word >> (8 * g + t)) & 1u;   // word already shifted right by 4h
+    else return drop_keep(word, t, thr);
+}
+
+template <bool F16, int KS0, int KS1, int KS2, int DROP>
+__global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
+    typedef typename FragT<F16>::type V;
+    constexpr int NL = 1 + (KS1 > 0) + (KS2 > 0);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5, lane16 = lane * 16;
+    const int m0 = blockIdx.x * 32, m = m0 + r;
+    const bool mvalid = m < p.M;
+    const int mc = min(m, p.M - 1);
+    uint32_t seed_lo = 0, seed_hi = 0;
+    if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+    const float ascale = p.ascale > 0.f ? p.ascale : 1.f;
+
+    float* const sbias = reinterpret_cast<float*>(smem + 2 * C2_FB);
+    static_for<0, NL>([&](auto lc) {   // (a run-time index into p.L would move the whole argument block to scratch)
+        MPG_CI(l, lc);
+        const int nb = p.L[l].bias != nullptr ? (p.L[l].nbias ? p.L[l].nbias : p.L[l].N) : 0;
+        sbias[256 * l + tid] = tid < nb ? p.L[l].bias[min(tid, max(nb - 1, 0))] : 0.f;
+    });
+
+    V wb[2][16][2];   // [slot A | slot B][k-step][hi | lo]: whole tiles
+    auto load_tile = [&](auto lc, auto bc, int tile) {
+        MPG_CI(l, lc);
+        MPG_CI(b, bc);
+        constexpr int KSC = l == 0 ? KS0 : (l == 1 ? KS1 : KS2);
+        const int nfrag = ((p.L[l].N + 31) / 32) * KSC;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.L[l].Wimg), 0, 2 * nfrag * 1024, 0x00020000);
+        static_for<0, KSC>([&](auto kc) {
+            MPG_CI(ks, kc);
+            wb[b][ks][0] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, (tile * KSC + ks) * 1024, 0));
+            wb[b][ks][1] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, (nfrag + tile * KSC + ks) * 1024, 0));
+        });
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    {
+        const int MT = (p.L[0].N + 31) / 32;
+        if (w < MT) load_tile(I0{}, I0{}, w);
+        if (w + 4 < MT) load_tile(I0{}, I1{}, w + 4);
+    }
+
+    // ---- stage the input rows as B fragments: unit = (k-step, lane) = 8 features of one row
+    {
+        const int K = p.L[0].K;
+        V* fb = reinterpret_cast<V*>(smem);
+        const bool fast = (p.lda % 4 == 0) && (p.K1 % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0) &&
+                          p.a_slabs == 1 && (p.K1 == K || ((p.lda2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.A2) & 15) == 0)));
+        if (fast) {
+            // every load of the thread's (up to four) units first, then the arithmetic
+            constexpr int NI = (KS0 * 64 + 255) / 256;
+            float4 x[NI][2];
+            const float* a2 = p.A2 != nullptr ? p.A2 : p.A;
+            static_for<0, NI>([&](auto ic) {
+                MPG_CI(i, ic);
+                const int u = min(tid + 256 * i, KS0 * 64 - 1), ks = u >> 6, ln = u & 63, rr = ln & 31, hh = ln >> 5;
+                const size_t row = (size_t)min(m0 + rr, p.M - 1);
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int f = 16 * ks + 8 * half + 4 * hh;
+                    const int fc = min(f, K - 4);
+                    x[i][half] = fc < p.K1 ? c2_ld4(p.A + row * p.lda + fc) : c2_ld4(a2 + row * p.lda2 + (fc - p.K1));
+                }
+            });
+            const uint32_t in_thr = p.in_thr;
+            const bool in_on = in_thr != 0u;
+            const float in_s = in_on ? p.in_scale : 1.f;
+            const __amdgpu_buffer_rsrc_t rio = __builtin_amdgcn_make_buffer_rsrc(
+                p.in_out, 0, p.in_out != nullptr ? (int)((size_t)p.M * p.ld_in_out * 4) : 0, 0x00020000);
+            static_for<0, NI>([&](auto ic) {
+                MPG_CI(i, ic);
+                const int u = tid + 256 * i, uc = min(u, KS0 * 64 - 1), ks = uc >> 6, ln = uc & 63, rr = ln & 31, hh = ln >> 5;
+                const int mm = m0 + rr;
+                const bool live = mm < p.M;
+                float v[8];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int f = 16 * ks + 8 * half + 4 * hh;
+                    float x4[4] = {x[i][half].x, x[i][half].y, x[i][half].z, x[i][half].w};
+                    uint32_t wd = 0;
+                    if constexpr (DROP == 2) wd = drop_word(seed_lo, seed_hi, p.in_tag, (uint32_t)mm, DROP_BIT_GRP + (uint32_t)(f >> 5)) >> (f & 31);
+                    if constexpr (DROP == 1) wd = drop_word(seed_lo, seed_hi, p.in_tag, (uint32_t)mm, (uint32_t)(f >> 2));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float xv = (live && f + e < K) ? x4[e] : 0.f;
+                        if constexpr (DROP != 0) {
+                            const bool keep = (DROP == 2 ? ((wd >> e) & 1u) != 0u : drop_keep(wd, e, in_thr)) || !in_on;
+                            xv = keep ? xv * in_s : 0.f;
+                        }
+                        x4[e] = xv;
+                        v[4 * half + e] = xv * ascale;
+                    }
+                    const bool st = live && f + 4 <= K && u < KS0 * 64;
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        c2_u32x4{__builtin_bit_cast(uint32_t, x4[0]), __builtin_bit_cast(uint32_t, x4[1]), __builtin_bit_cast(uint32_t, x4[2]),
+                                 __builtin_bit_cast(uint32_t, x4[3])},
+                        rio, st ? (int)(((size_t)mm * p.ld_in_out + f) * 4) : -1, 0, 0);
+                }
+                V hi, lo;
+                split8(v, hi, lo);
+                if (u < KS0 * 64) {
+                    fb[(ks * 2 + 0) * 64 + ln] = hi;
+                    fb[(ks * 2 + 1) * 64 + ln] = lo;
+                }
+            });
+        } else {
+            for (int u = tid; u < KS0 * 64; u += 256) {
+                const int ks = u >> 6, ln = u & 63, rr = ln & 31, hh = ln >> 5;
+                const int mm = m0 + rr;
+                float v[8];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int f = 16 * ks + 8 * half + 4 * hh;
+                    float x4[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (mm < p.M) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = f + e;
+                            if (k < p.K1) {
+                                for (int sl = 0; sl < p.a_slabs; ++sl) x4[e] += p.A[sl * p.a_slab_stride + (size_t)mm * p.lda + k];
+                            } else if (k < K) {
+                                x4[e] = p.A2[(size_t)mm * p.lda2 + (k - p.K1)];
+                            }
+                        }
+                        if (p.in_thr) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                x4[e] = (f + e < K && drop_keep_f(seed_lo, seed_hi, p.in_tag, (uint32_t)mm, f + e, p.in_thr)) ? x4[e] * p.in_scale : 0.f;
+                        }
+                        if (p.in_out != nullptr) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (f + e < K) p.in_out[(size_t)mm * p.ld_in_out + f + e] = x4[e];
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * half + e] = x4[e] * ascale;
+                }
+                V hi, lo;
+                split8(v, hi, lo);
+                fb[(ks * 2 + 0) * 64 + ln] = hi;
+                fb[(ks * 2 + 1) * 64 + ln] = lo;
+            }
+        }
+    }
+    __syncthreads();
+
+    static_for<0, NL>([&](auto lc) {
+        MPG_CI(l, lc);
+        constexpr int KSC = l == 0 ? KS0 : (l == 1 ? KS1 : KS2);
+        constexpr bool last = l + 1 == NL;
+        constexpr int NU = last ? 16 : 18;      // epilogue units of a tile: 16 elements (+ 2 fragment splits)
+        const MpgChainLayer& L = p.L[l];
+        const V* fin = reinterpret_cast<const V*>(smem + (l & 1) * C2_FB);
+        V* fout = reinterpret_cast<V*>(smem + ((l + 1) & 1) * C2_FB);
+        const int MT = (L.N + 31) / 32;
+        const bool actA = w < MT, actB = w + 4 < MT;
+        const float zscale = (L.wscale > 0.f ? L.wscale : 1.f) * ascale, inv_z = 1.f / zscale;
+        const float alpha_eff = L.act ? p.alpha : 1.f;
+        const bool has_gate = L.gateH != nullptr;
+        // options as uniform values for selects (a `thr ? .. : ..` per element becomes a branch per element)
+        const uint32_t drop_thr = L.drop_thr, gate_thr = L.gate_thr;
+        const bool drop_on = drop_thr != 0u, gdrop_on = has_gate && gate_thr != 0u;
+        const float drop_s = drop_on ? L.drop_scale : 1.f;
+        const float g_neg = L.gate_act ? p.alpha : 1.f, g_scale = gdrop_on ? L.gate_scale : 1.f;
+        const uint32_t drop_tag = L.drop_tag, gate_tag = L.gate_tag;
+        const int LN = L.N, ldo = L.ldo;
+        const __amdgpu_buffer_rsrc_t rgate = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(L.gateH), 0, L.gateH != nullptr ? (int)((size_t)p.M * L.ldh * 4) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(L.resid), 0, L.resid != nullptr ? (int)((size_t)p.M * L.ldr * 4) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+            L.out, 0, L.out != nullptr ? (int)((size_t)p.M * L.ldo * 4) : 0, 0x00020000);
+
+        // operands of a tile's epilogue that live in memory: requested before the tile's k loop
+        auto request = [&](C2Tile& T, int tile) {
+            T.tile = tile;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) T.acc[k] = 0.f;
+            // (buffer loads: a NULL operand has a zero-length descriptor and reads zeros -- no branch, and a branch around
+            // loads makes the compiler wait for every load in flight at its end, the weight prefetch included)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = min(32 * tile + 8 * g + 4 * h, LN - 4);
+                const f32x4 hq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgate, (int)(((size_t)mc * L.ldh + n) * 4), 0, 0));
+                const f32x4 rq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)(((size_t)mc * L.ldr + n) * 4), 0, 0));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    T.hv[4 * g + t] = hq[t];   // (whole-vector cast above: a per-element __builtin_bit_cast(float, v[t]) of an
+                    T.rv[4 * g + t] = rq[t];   //  integer vector reads element 0 four times with this compiler)
+                }
+            }
+        };
+        // epilogue unit u of tile T: u < 16 element (g, t) = accumulator register u; 16, 17: the two fragment pairs
+        auto unit = [&](auto uc, C2Tile& T) {
+            MPG_CI(u, uc);
+            if constexpr (u < 16) {
+                constexpr int g = u >> 2, t = u & 3;
+                const int n0 = 32 * T.tile + 8 * g + 4 * h;
+                if constexpr (t == 0) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(sbias + 256 * l + n0);
+                    T.b4[0] = b4.x; T.b4[1] = b4.y; T.b4[2] = b4.z; T.b4[3] = b4.w;
+                    if constexpr (DROP == 1) {
+                        T.wdrop = drop_word(seed_lo, seed_hi, drop_tag, (uint32_t)m, (uint32_t)(8 * T.tile + 2 * g + h));
+                        T.wgate = drop_word(seed_lo, seed_hi, gate_tag, (uint32_t)m, (uint32_t)(8 * T.tile + 2 * g + h));
+                    }
+                }
+                if constexpr (u == 0 && DROP == 2) {
+                    T.wdrop = drop_word(seed_lo, seed_hi, drop_tag, (uint32_t)m, DROP_BIT_GRP + (uint32_t)T.tile) >> (4 * h);
+                    T.wgate = drop_word(seed_lo, seed_hi, gate_tag, (uint32_t)m, DROP_BIT_GRP + (uint32_t)T.tile) >> (4 * h);
+                }
+                float x = T.acc[u] * inv_z + T.b4[t];
+                x = lrelu(x, alpha_eff);
+                if constexpr (DROP != 0) {
+                    const bool keep = c2_keep<DROP>(T.wdrop, g, t, drop_thr) || !drop_on;
+                    x = keep ? x * drop_s : 0.f;
+                }
+                float gt = T.hv[u] > 0.f ? 1.f : g_neg;       // derivative of the forward layer's LeakyReLU (slope at <= 0)
+                if constexpr (DROP != 0) {
+                    const bool gkeep = c2_keep<DROP>(T.wgate, g, t, gate_thr) || !gdrop_on;
+                    gt = gkeep ? gt * g_scale : 0.f;
+                }
+                x = has_gate ? x * gt : x;
+                x += T.rv[u];
+                x = (mvalid && n0 + t < LN) ? x : 0.f;          // padding stays exactly zero
+                T.v[u] = x;
+                if constexpr (t == 3) {
+                    const bool st = mvalid && n0 + 4 <= LN;
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        c2_u32x4{__builtin_bit_cast(uint32_t, T.v[4 * g]), __builtin_bit_cast(uint32_t, T.v[4 * g + 1]),
+                                 __builtin_bit_cast(uint32_t, T.v[4 * g + 2]), __builtin_bit_cast(uint32_t, T.v[4 * g + 3])},
+                        rout, st ? (int)(((size_t)m * ldo + n0) * 4) : -1, 0, 0);
+                }
+            } else if constexpr (!last) {
+                constexpr int s = u - 16;   // registers 8s .. 8s+7 are the B fragment of k-step (2 tile + s) of the next layer
+                float vv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vv[j] = T.v[8 * s + j] * ascale;
+                V hi, lo;
+                split8(vv, hi, lo);
+                fout[((2 * T.tile + s) * 2 + 0) * 64 + lane] = hi;
+                fout[((2 * T.tile + s) * 2 + 1) * 64 + lane] = lo;
+            }
+        };
+        // k loop of one tile (weights wb[B]); the units of tile E's epilogue ride in its 3 KSC MFMA slots (NUE = 0: none)
+        auto kloop = [&](auto bc, auto nue, C2Tile& T, C2Tile& E) {
+            MPG_CI(B, bc);
+            MPG_CI(NUE, nue);
+            V bh = fin[0 * 64 + lane], bl = fin[1 * 64 + lane];
+            static_for<0, KSC>([&](auto kc) {
+                MPG_CI(ks, kc);
+                constexpr int kn = ks + 1 < KSC ? ks + 1 : KSC - 1;
+                const V nh = fin[(kn * 2 + 0) * 64 + lane], nl = fin[(kn * 2 + 1) * 64 + lane];
+                T.acc = c2_mma<F16>(wb[B][ks][1], bh, T.acc);
+                c2_slot<NUE, 3 * KSC, 3 * ks>([&](auto uc) { unit(uc, E); });
+                __builtin_amdgcn_sched_barrier(0);
+                T.acc = c2_mma<F16>(wb[B][ks][0], bl, T.acc);
+                c2_slot<NUE, 3 * KSC, 3 * ks + 1>([&](auto uc) { unit(uc, E); });
+                __builtin_amdgcn_sched_barrier(0);
+                T.acc = c2_mma<F16>(wb[B][ks][0], bh, T.acc);
+                c2_slot<NUE, 3 * KSC, 3 * ks + 2>([&](auto uc) { unit(uc, E); });
+                __builtin_amdgcn_sched_barrier(0);
+                bh = nh; bl = nl;
+            });
+        };
+        int MTn = 0;
+        if constexpr (!last) MTn = (p.L[l + 1].N + 31) / 32;
+
+        C2Tile TA, TB;
+        if (actA) {
+            request(TA, w);
+            kloop(I0{}, I0{}, TA, TA);
+        }
+        if constexpr (!last) {
+            if (w < MTn) load_tile(std::integral_constant<int, l + 1>{}, I0{}, w);            // slot A's registers are free
+        }
+        if (actB) {
+            request(TB, w + 4);
+            kloop(I1{}, std::integral_constant<int, NU>{}, TB, TA);                           // ... with tile A's epilogue
+        }
+        if constexpr (!last) {
+            if (w + 4 < MTn) load_tile(std::integral_constant<int, l + 1>{}, I1{}, w + 4);
+        }
+        if (actB) static_for<0, NU>([&](auto uc) { unit(uc, TB); });
+        else if (actA) static_for<0, NU>([&](auto uc) { unit(uc, TA); });
+        __syncthreads();
+    });
+}
+
+template <bool F16, int A, int B, int C, int DROP>
+int c2_launch(const MpgChain* p, hipStream_t st) {
+    MPG_ENSURE_LDS((chain2_kernel<F16, A, B, C, DROP>), C2_LDS);
+    hipLaunchKernelGGL((chain2_kernel<F16, A, B, C, DROP>), dim3((p->M + 31) / 32), dim3(256), C2_LDS, st, *p);
+    return (int)hipGetLastError();
+}
+template <bool F16, int A, int B, int C>
+int c2_launch_drop(const MpgChain* p, int drop, hipStream_t st) {
+    if (drop == 2) return c2_launch<F16, A, B, C, 2>(p, st);
+    if (drop == 1) return c2_launch<F16, A, B, C, 1>(p, st);
+    return c2_launch<F16, A, B, C, 0>(p, st);
+}
+
+}  // namespace
+
+int mpg_chain2_try(const MpgChain* p, hipStream_t st) {
+    if (getenv("MPG_CHAIN_GENERAL")) return MPG_CHAIN2_NA;
+    int ks[3] = {0, 0, 0};
+    int drop = 0;   // 0 none, 1 byte mode, 2 bit mode -- one mode for every site of the call
+    auto site = [&](uint32_t thr) {
+        if (!thr) return true;
+        const int mode = thr == 128u ? 2 : 1;
+        if (drop && drop != mode) return false;
+        drop = mode;
+        return true;
+    };
+    if (!site(p->in_thr)) return MPG_CHAIN2_NA;
+    for (int l = 0; l < p->nlayers; ++l) {
+        const MpgChainLayer& L = p->L[l];
+        ks[l] = 2 * ((L.K + 31) / 32);
+        if (L.N > 256 || L.N % 4) return MPG_CHAIN2_NA;
+        if (L.out != nullptr && (L.ldo % 4 || ((uintptr_t)L.out & 15) || (size_t)p->M * L.ldo * 4 >= 0x7fffffffull)) return MPG_CHAIN2_NA;
+        if (L.gateH != nullptr && (L.ldh % 4 || ((uintptr_t)L.gateH & 15) || (size_t)p->M * L.ldh * 4 >= 0x7fffffffull)) return MPG_CHAIN2_NA;
+        if (L.resid != nullptr && (L.ldr % 4 || ((uintptr_t)L.resid & 15) || (size_t)p->M * L.ldr * 4 >= 0x7fffffffull)) return MPG_CHAIN2_NA;
+        if (!site(L.drop_thr) || !site(L.gateH != nullptr ? L.gate_thr : 0)) return MPG_CHAIN2_NA;
+    }
+    if (p->in_out != nullptr && (p->ld_in_out % 4 || ((uintptr_t)p->in_out & 15) || (size_t)p->M * p->ld_in_out * 4 >= 0x7fffffffull))
+        return MPG_CHAIN2_NA;
+    if (p->f16) {
+        if (p->nlayers == 3 && ks[0] == 14 && ks[1] == 16 && ks[2] == 16) return c2_launch_drop<true, 14, 16, 16>(p, drop, st);   // fn forward
+        if (p->nlayers == 1 && ks[0] == 2 && drop == 0) return c2_launch<true, 2, 0, 0, 0>(p, st);                                // a | c projection
+        return MPG_CHAIN2_NA;
+    }
+    if (p->nlayers == 3 && ks[0] == 2 && ks[1] == 16 && ks[2] == 16) return c2_launch_drop<false, 2, 16, 16>(p, drop, st);        // fn input gradients
+    if (p->nlayers == 1 && ks[0] == 12 && drop == 0) return c2_launch<false, 12, 0, 0, 0>(p, st);                                 // dx from da | dc
+    return MPG_CHAIN2_NA;
+}
