@@ -17,6 +17,13 @@
 #include "chain_int.h"
 #include <stdlib.h>
 
+#ifdef MPG_CHSTAMP  // diagnostic build (tools/chain_stamps.py): s_memtime at the phase boundaries, every wave of workgroup 0
+__device__ unsigned long long g_c2_stamps[4 * 24];
+#define C2_STAMP(i) do { c2_st[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define C2_STAMP(i) do {} while (0)
+#endif
+
 namespace {
 
 typedef unsigned int c2_u32x4 __attribute__((ext_vector_type(4)));
@@ -54,7 +61,8 @@ MPG_DEV bool c2_keep(uint32_t word, int g, int t, uint32_t thr) {
     else return drop_keep(word, t, thr);
 }
 
-template <bool F16, int KS0, int KS1, int KS2, int DROP>
+// GATES / RESID: bit l set = layer l multiplies by a gate operand / adds a residual (known per shape: no dead arithmetic)
+template <bool F16, int KS0, int KS1, int KS2, int DROP, int GATES, int RESID>
 __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
     typedef typename FragT<F16>::type V;
     constexpr int NL = 1 + (KS1 > 0) + (KS2 > 0);
@@ -68,14 +76,20 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
     uint32_t seed_lo = 0, seed_hi = 0;
     if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
     const float ascale = p.ascale > 0.f ? p.ascale : 1.f;
+#ifdef MPG_CHSTAMP
+    unsigned long long c2_st[24] = {};
+#endif
+    C2_STAMP(0);
 
     float* const sbias = reinterpret_cast<float*>(smem + 2 * C2_FB);
     static_for<0, NL>([&](auto lc) {   // (a run-time index into p.L would move the whole argument block to scratch)
         MPG_CI(l, lc);
         const int nb = p.L[l].bias != nullptr ? (p.L[l].nbias ? p.L[l].nbias : p.L[l].N) : 0;
-        sbias[256 * l + tid] = tid < nb ? p.L[l].bias[min(tid, max(nb - 1, 0))] : 0.f;
+        const float so = p.L[l].drop_thr ? p.L[l].drop_scale : 1.f;   // the layer's dropout scale rides on bias and product
+        sbias[256 * l + tid] = tid < nb ? p.L[l].bias[min(tid, max(nb - 1, 0))] * so : 0.f;
     });
 
+    C2_STAMP(18);
     V wb[2][16][2];   // [slot A | slot B][k-step][hi | lo]: whole tiles
     auto load_tile = [&](auto lc, auto bc, int tile) {
         MPG_CI(l, lc);
@@ -91,11 +105,12 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    {
-        const int MT = (p.L[0].N + 31) / 32;
-        if (w < MT) load_tile(I0{}, I0{}, w);
-        if (w + 4 < MT) load_tile(I0{}, I1{}, w + 4);
-    }
+    // layer 0's tiles are requested AFTER the input rows: loads return in issue order, and the staging must not queue
+    // behind 64 KiB of weights per wave
+    auto first_tile = [&](auto bc) {
+        MPG_CI(b, bc);
+        if (w + 4 * b < (p.L[0].N + 31) / 32) load_tile(I0{}, bc, w + 4 * b);
+    };
 
     // ---- stage the input rows as B fragments: unit = (k-step, lane) = 8 features of one row
     {
@@ -119,6 +134,9 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
                     x[i][half] = fc < p.K1 ? c2_ld4(p.A + row * p.lda + fc) : c2_ld4(a2 + row * p.lda2 + (fc - p.K1));
                 }
             });
+            C2_STAMP(19);
+            first_tile(I0{});     // (its 28+ KiB per wave arrive while the rows are converted)
+            C2_STAMP(20);
             const uint32_t in_thr = p.in_thr;
             const bool in_on = in_thr != 0u;
             const float in_s = in_on ? p.in_scale : 1.f;
@@ -160,6 +178,7 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
                     fb[(ks * 2 + 1) * 64 + ln] = lo;
                 }
             });
+            first_tile(I1{});
         } else {
             for (int u = tid; u < KS0 * 64; u += 256) {
                 const int ks = u >> 6, ln = u & 63, rr = ln & 31, hh = ln >> 5;
@@ -198,9 +217,13 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
                 fb[(ks * 2 + 0) * 64 + ln] = hi;
                 fb[(ks * 2 + 1) * 64 + ln] = lo;
             }
+            first_tile(I0{});
+            first_tile(I1{});
         }
     }
+    C2_STAMP(1);
     __syncthreads();
+    C2_STAMP(2);
 
     static_for<0, NL>([&](auto lc) {
         MPG_CI(l, lc);
@@ -220,6 +243,10 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
         const bool drop_on = drop_thr != 0u, gdrop_on = has_gate && gate_thr != 0u;
         const float drop_s = drop_on ? L.drop_scale : 1.f;
         const float g_neg = L.gate_act ? p.alpha : 1.f, g_scale = gdrop_on ? L.gate_scale : 1.f;
+        constexpr bool GATE = (GATES >> l) & 1, RES = (RESID >> l) & 1;
+        const float zf = inv_z * drop_s;                       // (LeakyReLU commutes with a positive scale)
+        const float g_pos = g_scale, g_ng = g_neg * g_scale;   // gate factor at h > 0 / h <= 0
+        const int rowoff = m * L.ldo * 4;                      // (the launcher checks M * ldo * 4 < 2^31)
         const uint32_t drop_tag = L.drop_tag, gate_tag = L.gate_tag;
         const int LN = L.N, ldo = L.ldo;
         const __amdgpu_buffer_rsrc_t rgate = __builtin_amdgcn_make_buffer_rsrc(
@@ -239,12 +266,15 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = min(32 * tile + 8 * g + 4 * h, LN - 4);
-                const f32x4 hq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgate, (int)(((size_t)mc * L.ldh + n) * 4), 0, 0));
-                const f32x4 rq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)(((size_t)mc * L.ldr + n) * 4), 0, 0));
+                if constexpr (GATE) {
+                    const f32x4 hq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgate, (mc * L.ldh + n) * 4, 0, 0));
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    T.hv[4 * g + t] = hq[t];   // (whole-vector cast above: a per-element __builtin_bit_cast(float, v[t]) of an
-                    T.rv[4 * g + t] = rq[t];   //  integer vector reads element 0 four times with this compiler)
+                    for (int t = 0; t < 4; ++t) T.hv[4 * g + t] = hq[t];   // (whole-vector cast: a per-element __builtin_bit_cast(float, v[t])
+                }                                                          //  of an integer vector reads element 0 four times with this compiler)
+                if constexpr (RES) {
+                    const f32x4 rq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (mc * L.ldr + n) * 4, 0, 0));
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) T.rv[4 * g + t] = rq[t];
                 }
             }
         };
@@ -257,36 +287,36 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
                 if constexpr (t == 0) {
                     const float4 b4 = *reinterpret_cast<const float4*>(sbias + 256 * l + n0);
                     T.b4[0] = b4.x; T.b4[1] = b4.y; T.b4[2] = b4.z; T.b4[3] = b4.w;
-                    if constexpr (DROP == 1) {
+                    if constexpr (DROP == 1) {   // byte mode: one word per group of four features (thr = 0 keeps everything)
                         T.wdrop = drop_word(seed_lo, seed_hi, drop_tag, (uint32_t)m, (uint32_t)(8 * T.tile + 2 * g + h));
-                        T.wgate = drop_word(seed_lo, seed_hi, gate_tag, (uint32_t)m, (uint32_t)(8 * T.tile + 2 * g + h));
+                        if constexpr (GATE) T.wgate = drop_word(seed_lo, seed_hi, gate_tag, (uint32_t)m, (uint32_t)(8 * T.tile + 2 * g + h));
                     }
                 }
-                if constexpr (u == 0 && DROP == 2) {
-                    T.wdrop = drop_word(seed_lo, seed_hi, drop_tag, (uint32_t)m, DROP_BIT_GRP + (uint32_t)T.tile) >> (4 * h);
-                    T.wgate = drop_word(seed_lo, seed_hi, gate_tag, (uint32_t)m, DROP_BIT_GRP + (uint32_t)T.tile) >> (4 * h);
+                if constexpr (u == 0 && DROP == 2) {   // bit mode: one word per tile; a site without dropout keeps every bit
+                    const uint32_t wd = drop_word(seed_lo, seed_hi, drop_tag, (uint32_t)m, DROP_BIT_GRP + (uint32_t)T.tile) >> (4 * h);
+                    T.wdrop = drop_on ? wd : 0xffffffffu;
+                    if constexpr (GATE) {
+                        const uint32_t wg = drop_word(seed_lo, seed_hi, gate_tag, (uint32_t)m, DROP_BIT_GRP + (uint32_t)T.tile) >> (4 * h);
+                        T.wgate = gdrop_on ? wg : 0xffffffffu;
+                    }
                 }
-                float x = T.acc[u] * inv_z + T.b4[t];
+                float x = fmaf(T.acc[u], zf, T.b4[t]);
                 x = lrelu(x, alpha_eff);
-                if constexpr (DROP != 0) {
-                    const bool keep = c2_keep<DROP>(T.wdrop, g, t, drop_thr) || !drop_on;
-                    x = keep ? x * drop_s : 0.f;
+                if constexpr (DROP != 0) x = drop_apply<DROP>(x, T.wdrop, 8 * g + t, t, drop_thr);
+                if constexpr (GATE) {   // derivative of the forward layer's Dropout o LeakyReLU (slope alpha at h <= 0)
+                    x *= T.hv[u] > 0.f ? g_pos : g_ng;
+                    if constexpr (DROP != 0) x = drop_apply<DROP>(x, T.wgate, 8 * g + t, t, gate_thr);
                 }
-                float gt = T.hv[u] > 0.f ? 1.f : g_neg;       // derivative of the forward layer's LeakyReLU (slope at <= 0)
-                if constexpr (DROP != 0) {
-                    const bool gkeep = c2_keep<DROP>(T.wgate, g, t, gate_thr) || !gdrop_on;
-                    gt = gkeep ? gt * g_scale : 0.f;
-                }
-                x = has_gate ? x * gt : x;
-                x += T.rv[u];
-                x = (mvalid && n0 + t < LN) ? x : 0.f;          // padding stays exactly zero
+                if constexpr (RES) x += T.rv[u];
+                // (rows >= M and features >= N need no zeroing: their products are finite -- packed images and staged
+                // biases are zero there -- they meet only zero weights downstream, and their stores are dropped)
                 T.v[u] = x;
                 if constexpr (t == 3) {
                     const bool st = mvalid && n0 + 4 <= LN;
                     __builtin_amdgcn_raw_buffer_store_b128(
                         c2_u32x4{__builtin_bit_cast(uint32_t, T.v[4 * g]), __builtin_bit_cast(uint32_t, T.v[4 * g + 1]),
                                  __builtin_bit_cast(uint32_t, T.v[4 * g + 2]), __builtin_bit_cast(uint32_t, T.v[4 * g + 3])},
-                        rout, st ? (int)(((size_t)m * ldo + n0) * 4) : -1, 0, 0);
+                        rout, st ? rowoff + 4 * n0 : -1, 0, 0);
                 }
             } else if constexpr (!last) {
                 constexpr int s = u - 16;   // registers 8s .. 8s+7 are the B fragment of k-step (2 tile + s) of the next layer
@@ -300,7 +330,20 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
             }
         };
         // k loop of one tile (weights wb[B]); the units of tile E's epilogue ride in its 3 KSC MFMA slots (NUE = 0: none)
-        auto kloop = [&](auto bc, auto nue, C2Tile& T, C2Tile& E) {
+        // ... and each k-step, once its three MFMAs are issued, requests the same k-step of the slot's tile of the NEXT
+        // layer into the registers it has just freed: the 2 KiB per k-step and wave then trickle through the CU's L1
+        // (64 B/clk for four waves) behind the MFMAs instead of blocking the wave for ~2,500 clk when asked for at once
+        // (a wave without a tile there reads through a zero-length descriptor: zeros, no traffic, no branch).
+        constexpr int KSN = last ? 0 : (l == 0 ? KS1 : KS2);
+        int nfragn = 0;
+        if constexpr (!last) nfragn = ((p.L[last ? l : l + 1].N + 31) / 32) * KSN;
+        auto next_frag = [&](auto bc, auto kc, const __amdgpu_buffer_rsrc_t& rwn, int tile_n) {
+            MPG_CI(B, bc);
+            MPG_CI(ks, kc);
+            wb[B][ks][0] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rwn, lane16, (tile_n * KSN + ks) * 1024, 0));
+            wb[B][ks][1] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rwn, lane16, (nfragn + tile_n * KSN + ks) * 1024, 0));
+        };
+        auto kloop = [&](auto bc, auto nue, C2Tile& T, C2Tile& E, const __amdgpu_buffer_rsrc_t& rwn, int tile_n) {
             MPG_CI(B, bc);
             MPG_CI(NUE, nue);
             V bh = fin[0 * 64 + lane], bl = fin[1 * 64 + lane];
@@ -316,48 +359,68 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
                 __builtin_amdgcn_sched_barrier(0);
                 T.acc = c2_mma<F16>(wb[B][ks][0], bh, T.acc);
                 c2_slot<NUE, 3 * KSC, 3 * ks + 2>([&](auto uc) { unit(uc, E); });
+                if constexpr (ks < KSN) next_frag(bc, kc, rwn, tile_n);
                 __builtin_amdgcn_sched_barrier(0);
                 bh = nh; bl = nl;
             });
+            static_for<(KSC < KSN ? KSC : KSN), KSN>([&](auto kc) { next_frag(bc, kc, rwn, tile_n); });   // a longer next layer
         };
         int MTn = 0;
         if constexpr (!last) MTn = (p.L[l + 1].N + 31) / 32;
 
+        // descriptors of the next layer's image for this wave's two slots (zero length where it has no tile there)
+        const void* imgn = last ? p.L[l].Wimg : p.L[last ? l : l + 1].Wimg;
+        const __amdgpu_buffer_rsrc_t rwnA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(imgn), 0, (!last && w < MTn) ? 2 * nfragn * 1024 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rwnB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(imgn), 0, (!last && w + 4 < MTn) ? 2 * nfragn * 1024 : 0, 0x00020000);
         C2Tile TA, TB;
         if (actA) {
             request(TA, w);
-            kloop(I0{}, I0{}, TA, TA);
+            kloop(I0{}, I0{}, TA, TA, rwnA, w);
+        } else if constexpr (!last) {
+            if (w < MTn) load_tile(std::integral_constant<int, l + 1>{}, I0{}, w);            // (no loop to ride in)
         }
-        if constexpr (!last) {
-            if (w < MTn) load_tile(std::integral_constant<int, l + 1>{}, I0{}, w);            // slot A's registers are free
-        }
+        C2_STAMP(3 + 5 * l);
         if (actB) {
             request(TB, w + 4);
-            kloop(I1{}, std::integral_constant<int, NU>{}, TB, TA);                           // ... with tile A's epilogue
-        }
-        if constexpr (!last) {
+            kloop(I1{}, std::integral_constant<int, NU>{}, TB, TA, rwnB, w + 4);              // ... with tile A's epilogue
+        } else if constexpr (!last) {
             if (w + 4 < MTn) load_tile(std::integral_constant<int, l + 1>{}, I1{}, w + 4);
         }
+        C2_STAMP(4 + 5 * l);
         if (actB) static_for<0, NU>([&](auto uc) { unit(uc, TB); });
         else if (actA) static_for<0, NU>([&](auto uc) { unit(uc, TA); });
+        C2_STAMP(5 + 5 * l);
         __syncthreads();
+        C2_STAMP(6 + 5 * l);
     });
+#ifdef MPG_CHSTAMP
+    if (blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) g_c2_stamps[w * 24 + i] = c2_st[i];
+    }
+#endif
 }
 
-template <bool F16, int A, int B, int C, int DROP>
+template <bool F16, int A, int B, int C, int DROP, int GATES, int RESID>
 int c2_launch(const MpgChain* p, hipStream_t st) {
-    MPG_ENSURE_LDS((chain2_kernel<F16, A, B, C, DROP>), C2_LDS);
-    hipLaunchKernelGGL((chain2_kernel<F16, A, B, C, DROP>), dim3((p->M + 31) / 32), dim3(256), C2_LDS, st, *p);
+    MPG_ENSURE_LDS((chain2_kernel<F16, A, B, C, DROP, GATES, RESID>), C2_LDS);
+    hipLaunchKernelGGL((chain2_kernel<F16, A, B, C, DROP, GATES, RESID>), dim3((p->M + 31) / 32), dim3(256), C2_LDS, st, *p);
     return (int)hipGetLastError();
 }
-template <bool F16, int A, int B, int C>
+template <bool F16, int A, int B, int C, int GATES, int RESID>
 int c2_launch_drop(const MpgChain* p, int drop, hipStream_t st) {
-    if (drop == 2) return c2_launch<F16, A, B, C, 2>(p, st);
-    if (drop == 1) return c2_launch<F16, A, B, C, 1>(p, st);
-    return c2_launch<F16, A, B, C, 0>(p, st);
+    if (drop == 2) return c2_launch<F16, A, B, C, 2, GATES, RESID>(p, st);
+    if (drop == 1) return c2_launch<F16, A, B, C, 1, GATES, RESID>(p, st);
+    return c2_launch<F16, A, B, C, 0, GATES, RESID>(p, st);
 }
 
 }  // namespace
+
+#ifdef MPG_CHSTAMP
+extern "C" int mpg_debug_chain2_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_c2_stamps), sizeof(unsigned long long) * 4 * 24);
+}
+#endif
 
 int mpg_chain2_try(const MpgChain* p, hipStream_t st) {
     if (getenv("MPG_CHAIN_GENERAL")) return MPG_CHAIN2_NA;
@@ -382,12 +445,19 @@ int mpg_chain2_try(const MpgChain* p, hipStream_t st) {
     }
     if (p->in_out != nullptr && (p->ld_in_out % 4 || ((uintptr_t)p->in_out & 15) || (size_t)p->M * p->ld_in_out * 4 >= 0x7fffffffull))
         return MPG_CHAIN2_NA;
+    int gates = 0, resid = 0;
+    for (int l = 0; l < p->nlayers; ++l) {
+        gates |= (p->L[l].gateH != nullptr) << l;
+        resid |= (p->L[l].resid != nullptr) << l;
+    }
     if (p->f16) {
-        if (p->nlayers == 3 && ks[0] == 14 && ks[1] == 16 && ks[2] == 16) return c2_launch_drop<true, 14, 16, 16>(p, drop, st);   // fn forward
-        if (p->nlayers == 1 && ks[0] == 2 && drop == 0) return c2_launch<true, 2, 0, 0, 0>(p, st);                                // a | c projection
+        if (p->nlayers == 3 && ks[0] == 14 && ks[1] == 16 && ks[2] == 16 && !gates && !resid)
+            return c2_launch_drop<true, 14, 16, 16, 0, 0>(p, drop, st);                                                   // fn forward
+        if (p->nlayers == 1 && ks[0] == 2 && drop == 0 && !gates && !resid) return c2_launch<true, 2, 0, 0, 0, 0, 0>(p, st);  // a | c projection
         return MPG_CHAIN2_NA;
     }
-    if (p->nlayers == 3 && ks[0] == 2 && ks[1] == 16 && ks[2] == 16) return c2_launch_drop<false, 2, 16, 16>(p, drop, st);        // fn input gradients
-    if (p->nlayers == 1 && ks[0] == 12 && drop == 0) return c2_launch<false, 12, 0, 0, 0>(p, st);                                 // dx from da | dc
+    if (p->nlayers == 3 && ks[0] == 2 && ks[1] == 16 && ks[2] == 16 && gates == 3 && !resid)
+        return c2_launch_drop<false, 2, 16, 16, 3, 0>(p, drop, st);                                                       // fn input gradients
+    if (p->nlayers == 1 && ks[0] == 12 && drop == 0 && !gates && resid == 1) return c2_launch<false, 12, 0, 0, 0, 0, 1>(p, st);   // dx from da | dc
     return MPG_CHAIN2_NA;
 }
