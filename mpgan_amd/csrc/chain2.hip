@@ -16,6 +16,7 @@
 #include "../../include/mpgan_amd.h"
 #include "chain_int.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 #ifdef MPG_CHSTAMP  // diagnostic build (tools/chain_stamps.py): s_memtime at the phase boundaries, every wave of workgroup 0
 __device__ unsigned long long g_c2_stamps[4 * 24];
@@ -62,7 +63,9 @@ MPG_DEV bool c2_keep(uint32_t word, int g, int t, uint32_t thr) {
 }
 
 // GATES / RESID: bit l set = layer l multiplies by a gate operand / adds a residual (known per shape: no dead arithmetic)
-template <bool F16, int KS0, int KS1, int KS2, int DROP, int GATES, int RESID>
+// SL: the LAST layer's rows are not whole 16-byte groups (N or a row stride not a multiple of 4): its output and residual
+// go element by element
+template <bool F16, int KS0, int KS1, int KS2, int DROP, int GATES, int RESID, bool SL>
 __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
     typedef typename FragT<F16>::type V;
     constexpr int NL = 1 + (KS1 > 0) + (KS2 > 0);
@@ -117,7 +120,8 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
         const int K = p.L[0].K;
         V* fb = reinterpret_cast<V*>(smem);
         const bool fast = (p.lda % 4 == 0) && (p.K1 % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0) &&
-                          p.a_slabs == 1 && (p.K1 == K || ((p.lda2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.A2) & 15) == 0)));
+                          p.a_slabs == 1 && (p.K1 == K || ((p.lda2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.A2) & 15) == 0))) &&
+                          (p.in_out == nullptr || ((p.ld_in_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in_out) & 15) == 0)));
         if (fast) {
             // every load of the thread's (up to four) units first, then the arithmetic
             constexpr int NI = (KS0 * 64 + 255) / 256;
@@ -271,10 +275,17 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) T.hv[4 * g + t] = hq[t];   // (whole-vector cast: a per-element __builtin_bit_cast(float, v[t])
                 }                                                          //  of an integer vector reads element 0 four times with this compiler)
-                if constexpr (RES) {
+                if constexpr (RES && !(SL && last)) {
                     const f32x4 rq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (mc * L.ldr + n) * 4, 0, 0));
 #pragma unroll
                     for (int t = 0; t < 4; ++t) T.rv[4 * g + t] = rq[t];
+                }
+                if constexpr (RES && SL && last) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int nn = 32 * tile + 8 * g + 4 * h + t;
+                        T.rv[4 * g + t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, nn < LN ? (mc * L.ldr + nn) * 4 : -1, 0, 0));
+                    }
                 }
             }
         };
@@ -311,7 +322,10 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
                 // (rows >= M and features >= N need no zeroing: their products are finite -- packed images and staged
                 // biases are zero there -- they meet only zero weights downstream, and their stores are dropped)
                 T.v[u] = x;
-                if constexpr (t == 3) {
+                if constexpr (SL && last) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, x), rout,
+                                                          (mvalid && n0 + t < LN) ? rowoff + 4 * (n0 + t) : -1, 0, 0);
+                } else if constexpr (t == 3) {
                     const bool st = mvalid && n0 + 4 <= LN;
                     __builtin_amdgcn_raw_buffer_store_b128(
                         c2_u32x4{__builtin_bit_cast(uint32_t, T.v[4 * g]), __builtin_bit_cast(uint32_t, T.v[4 * g + 1]),
@@ -401,17 +415,21 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
 #endif
 }
 
-template <bool F16, int A, int B, int C, int DROP, int GATES, int RESID>
+template <bool F16, int A, int B, int C, int DROP, int GATES, int RESID, bool SL>
 int c2_launch(const MpgChain* p, hipStream_t st) {
-    MPG_ENSURE_LDS((chain2_kernel<F16, A, B, C, DROP, GATES, RESID>), C2_LDS);
-    hipLaunchKernelGGL((chain2_kernel<F16, A, B, C, DROP, GATES, RESID>), dim3((p->M + 31) / 32), dim3(256), C2_LDS, st, *p);
+    MPG_ENSURE_LDS((chain2_kernel<F16, A, B, C, DROP, GATES, RESID, SL>), C2_LDS);
+    hipLaunchKernelGGL((chain2_kernel<F16, A, B, C, DROP, GATES, RESID, SL>), dim3((p->M + 31) / 32), dim3(256), C2_LDS, st, *p);
     return (int)hipGetLastError();
 }
+template <bool F16, int A, int B, int C, int DROP, int GATES, int RESID>
+int c2_launch_sl(const MpgChain* p, bool sl, hipStream_t st) {
+    return sl ? c2_launch<F16, A, B, C, DROP, GATES, RESID, true>(p, st) : c2_launch<F16, A, B, C, DROP, GATES, RESID, false>(p, st);
+}
 template <bool F16, int A, int B, int C, int GATES, int RESID>
-int c2_launch_drop(const MpgChain* p, int drop, hipStream_t st) {
-    if (drop == 2) return c2_launch<F16, A, B, C, 2, GATES, RESID>(p, st);
-    if (drop == 1) return c2_launch<F16, A, B, C, 1, GATES, RESID>(p, st);
-    return c2_launch<F16, A, B, C, 0, GATES, RESID>(p, st);
+int c2_launch_drop(const MpgChain* p, int drop, bool sl, hipStream_t st) {
+    if (drop == 2) return c2_launch_sl<F16, A, B, C, 2, GATES, RESID>(p, sl, st);
+    if (drop == 1) return c2_launch_sl<F16, A, B, C, 1, GATES, RESID>(p, sl, st);
+    return c2_launch_sl<F16, A, B, C, 0, GATES, RESID>(p, sl, st);
 }
 
 }  // namespace
@@ -422,8 +440,12 @@ extern "C" int mpg_debug_chain2_stamps(unsigned long long* host_out) {
 }
 #endif
 
+#define C2_NA(why) do { if (dbg) fprintf(stderr, "mpg_chain: general kernel (%s; M %d, layers %d, K %d %d %d, N %d %d %d)\n", why, p->M, p->nlayers, \
+        p->L[0].K, p->L[1].K, p->L[2].K, p->L[0].N, p->L[1].N, p->L[2].N); return MPG_CHAIN2_NA; } while (0)
+
 int mpg_chain2_try(const MpgChain* p, hipStream_t st) {
     if (getenv("MPG_CHAIN_GENERAL")) return MPG_CHAIN2_NA;
+    static const bool dbg = getenv("MPG_CHAIN_DEBUG") != nullptr;
     int ks[3] = {0, 0, 0};
     int drop = 0;   // 0 none, 1 byte mode, 2 bit mode -- one mode for every site of the call
     auto site = [&](uint32_t thr) {
@@ -433,18 +455,24 @@ int mpg_chain2_try(const MpgChain* p, hipStream_t st) {
         drop = mode;
         return true;
     };
-    if (!site(p->in_thr)) return MPG_CHAIN2_NA;
+    if (!site(p->in_thr)) C2_NA("mixed dropout modes");
+    bool sl = false;   // the last layer's rows are not whole 16-byte groups
     for (int l = 0; l < p->nlayers; ++l) {
         const MpgChainLayer& L = p->L[l];
         ks[l] = 2 * ((L.K + 31) / 32);
-        if (L.N > 256 || L.N % 4) return MPG_CHAIN2_NA;
-        if (L.out != nullptr && (L.ldo % 4 || ((uintptr_t)L.out & 15) || (size_t)p->M * L.ldo * 4 >= 0x7fffffffull)) return MPG_CHAIN2_NA;
-        if (L.gateH != nullptr && (L.ldh % 4 || ((uintptr_t)L.gateH & 15) || (size_t)p->M * L.ldh * 4 >= 0x7fffffffull)) return MPG_CHAIN2_NA;
-        if (L.resid != nullptr && (L.ldr % 4 || ((uintptr_t)L.resid & 15) || (size_t)p->M * L.ldr * 4 >= 0x7fffffffull)) return MPG_CHAIN2_NA;
-        if (!site(L.drop_thr) || !site(L.gateH != nullptr ? L.gate_thr : 0)) return MPG_CHAIN2_NA;
+        if (L.N > 256) C2_NA("N");
+        const bool vec = L.N % 4 == 0 && (L.out == nullptr || (L.ldo % 4 == 0 && ((uintptr_t)L.out & 15) == 0)) &&
+                         (L.resid == nullptr || (L.ldr % 4 == 0 && ((uintptr_t)L.resid & 15) == 0));
+        if (!vec) {
+            if (l + 1 != p->nlayers) C2_NA("row groups of an inner layer");
+            sl = true;
+        }
+        if (L.out != nullptr && (size_t)p->M * L.ldo * 4 >= 0x7fffffffull) C2_NA("out");
+        if (L.gateH != nullptr && (L.ldh % 4 || ((uintptr_t)L.gateH & 15) || (size_t)p->M * L.ldh * 4 >= 0x7fffffffull)) C2_NA("gate");
+        if (L.resid != nullptr && (size_t)p->M * L.ldr * 4 >= 0x7fffffffull) C2_NA("resid");
+        if (!site(L.drop_thr) || !site(L.gateH != nullptr ? L.gate_thr : 0)) C2_NA("mixed dropout modes");
     }
-    if (p->in_out != nullptr && (p->ld_in_out % 4 || ((uintptr_t)p->in_out & 15) || (size_t)p->M * p->ld_in_out * 4 >= 0x7fffffffull))
-        return MPG_CHAIN2_NA;
+    if (p->in_out != nullptr && (size_t)p->M * p->ld_in_out * 4 >= 0x7fffffffull) C2_NA("in_out");
     int gates = 0, resid = 0;
     for (int l = 0; l < p->nlayers; ++l) {
         gates |= (p->L[l].gateH != nullptr) << l;
@@ -452,12 +480,12 @@ int mpg_chain2_try(const MpgChain* p, hipStream_t st) {
     }
     if (p->f16) {
         if (p->nlayers == 3 && ks[0] == 14 && ks[1] == 16 && ks[2] == 16 && !gates && !resid)
-            return c2_launch_drop<true, 14, 16, 16, 0, 0>(p, drop, st);                                                   // fn forward
-        if (p->nlayers == 1 && ks[0] == 2 && drop == 0 && !gates && !resid) return c2_launch<true, 2, 0, 0, 0, 0, 0>(p, st);  // a | c projection
-        return MPG_CHAIN2_NA;
+            return c2_launch_drop<true, 14, 16, 16, 0, 0>(p, drop, sl, st);                                                   // fn forward
+        if (p->nlayers == 1 && ks[0] == 2 && drop == 0 && !gates && !resid && !sl) return c2_launch<true, 2, 0, 0, 0, 0, 0, false>(p, st);  // a | c projection
+        C2_NA("f16 shape");
     }
     if (p->nlayers == 3 && ks[0] == 2 && ks[1] == 16 && ks[2] == 16 && gates == 3 && !resid)
-        return c2_launch_drop<false, 2, 16, 16, 3, 0>(p, drop, st);                                                       // fn input gradients
-    if (p->nlayers == 1 && ks[0] == 12 && drop == 0 && !gates && resid == 1) return c2_launch<false, 12, 0, 0, 0, 0, 1>(p, st);   // dx from da | dc
-    return MPG_CHAIN2_NA;
+        return c2_launch_drop<false, 2, 16, 16, 3, 0>(p, drop, sl, st);                                                       // fn input gradients
+    if (p->nlayers == 1 && ks[0] == 12 && drop == 0 && !gates && resid == 1) return c2_launch_sl<false, 12, 0, 0, 0, 0, 1>(p, sl, st);   // dx from da | dc
+    C2_NA("shape");
 }
