@@ -12,8 +12,12 @@ out=$R/gpurun_out/final/bench_stats
 rm -rf $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o b -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/final/bench_under_rocprof.log 2>&1 || exit 1
 python3 $R/tools/prof_summary.py $out 40 > $R/gpurun_out/final/bench_stats_summary.txt
+out=$R/gpurun_out/final/gapt_stats
+rm -rf $out
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o b -- python3 $R/bench.py --model gapt --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/final/gapt_under_rocprof.log 2>&1 || exit 1
+python3 $R/tools/prof_summary.py $out 40 > $R/gpurun_out/final/gapt_stats_summary.txt
 echo "stats done"
-KERNELS=("edge_fwd_kernel<0" "edge_fwd_kernel<2" "edge_bwd_kernel<0, true, true" "edge_bwd_kernel<0, true, false" "edge_bwd_kernel<2, true, true" "edge_bwd_kernel<2, true, false" "edge_dw_kernel<0" "edge_dw_kernel<2" chain_kernel gemm_group_kernel)
+KERNELS=("edge_fwd_kernel<0" "edge_fwd_kernel<2" "edge_bwd_kernel<0, true, true" "edge_bwd_kernel<0, true, false" "edge_bwd_kernel<2, true, true" "edge_bwd_kernel<2, true, false" "edge_dw_kernel<0" "edge_dw_kernel<2" chain2_kernel gemm_group_kernel)
 for c in FETCH_SIZE WRITE_SIZE; do
   o=$R/gpurun_out/final/pmc_$c
   rm -rf $o

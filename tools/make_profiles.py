@@ -29,6 +29,15 @@ open(os.path.join(P, f"{tag}_bench_kernel_stats.txt"), "w").write(
     "# the 4 eager roofline iterations all land in the trace).  Full table: " + f"{tag}_bench_kernel_stats.csv.\n"
     "# The bench line printed by this very run:\n# " + line + "\n#\n" + agree + summ)
 
+# ---- GAPT kernel stats of the same round
+gl = os.path.join(F, "gapt_under_rocprof.log")
+if os.path.isfile(gl):
+    gline = [l for l in open(gl).read().splitlines() if l.startswith('{"metric"')][-1]
+    gs = re.sub(r"/\S*/gpurun_out/", "gpurun_out/", open(os.path.join(F, "gapt_stats_summary.txt")).read())
+    open(os.path.join(P, f"{tag}_bench_gapt_kernel_stats.txt"), "w").write(
+        "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --model gapt --steps 20 --warmup 5 --no-cpu-baseline\n"
+        "# (MI355X, 1 GPU, GAPT N=30, B=512, D dropout 0.5).  The bench line printed by this very run:\n# " + gline + "\n#\n" + gs)
+
 # ---- HBM traffic
 pm = open(os.path.join(F, "pmc_summary.txt")).read()
 vals = {}
@@ -46,7 +55,7 @@ rows = [("edge_fwd_kernel<0", "forward, no dropout"), ("edge_fwd_kernel<2", "for
         ("edge_bwd_kernel<0, true, true", "backward + staging"), ("edge_bwd_kernel<0, true, false", "backward, data path only"),
         ("edge_bwd_kernel<2, true, true", "backward + staging, p = 1/2"), ("edge_bwd_kernel<2, true, false", "backward, data path, p = 1/2"),
         ("edge_dw_kernel<0", "weight gradients"), ("edge_dw_kernel<2", "weight gradients, p = 1/2"),
-        ("chain_kernel", "chained node layers (all uses)"), ("gemm_group_kernel", "grouped dense weight gradients")]
+        ("chain2_kernel", "chained node layers (all uses)"), ("gemm_group_kernel", "grouped dense weight gradients")]
 txt = ("# HBM traffic of the fused kernels: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (one counter per pass, as\n"
        "# MI355X_MICROARCH.md prescribes); workload tools/kbwd.py = MPLayer forward+backward at B=256, N=30 (one launch = 256 jets,\n"
        "# 230,400 edges).  Counters are KiB per dispatch, averaged over the kernel's dispatches.  gfx950 correction: FETCH_SIZE\n"
