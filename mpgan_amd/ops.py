@@ -400,17 +400,24 @@ MAX_CHUNK_SENDERS = 188   # mpg_edge_bwd keeps the list of a chunk's unmasked se
 
 
 def _sender_chunks(B, N):
-    """Sender chunks per (jet, receiver block): 1 when those alone give every CU a workgroup (each
-    workgroup pays a 150 KiB LDS fill), else enough to cover the 256 CUs about twice; always enough that a
-    chunk holds at most MAX_CHUNK_SENDERS senders."""
+    """Sender chunks per (jet, receiver block).  A workgroup costs a 150 KiB LDS fill (about five senders' worth of
+    time) plus its chunk's senders, and the 256 CUs take the workgroups of a launch in rounds: the chunk count that
+    minimises  rounds * (fill + senders per chunk), with chunks of at least 8 and at most MAX_CHUNK_SENDERS senders
+    (B = 256, N = 30: 1 -- every CU already has a workgroup; B = 16, N = 150: 3 -- 240 workgroups in one round, where
+    doubling up to 320 workgroups would run two rounds at 62 % occupancy)."""
     RB = (N + 31) // 32
     wg = B * RB
-    sc = 1
-    while wg * sc < 224 and (N + sc - 1) // sc > 8:
-        sc *= 2
-    while (N + sc - 1) // sc > MAX_CHUNK_SENDERS:
-        sc += 1
-    return sc
+    best, best_cost = 1, None
+    for sc in range(1, max(1, N // 8) + 1):
+        per = -(-N // sc)
+        if per > MAX_CHUNK_SENDERS:
+            continue
+        cost = -(-wg * sc // 256) * (5 + per)
+        if best_cost is None or cost < best_cost:
+            best, best_cost = sc, cost
+    if best_cost is None:   # (N > 8 * MAX_CHUNK_SENDERS cannot happen below the kernels' own limits; be safe)
+        best = -(-N // MAX_CHUNK_SENDERS)
+    return best
 
 
 class FusedMPLayerFn(torch.autograd.Function):
