@@ -471,9 +471,13 @@ MPG_DEV void dw_store(const f32x16* acc, float* part3, float* part2, int lane) {
 // A workgroup walks at most 64 blocks (the launcher sizes the grid for that); their valid-sender bits are one
 // ballot taken at kernel start, so stepping to the next unmasked block is pure scalar arithmetic -- no memory
 // access and no loop inside the pipelined loops (either would make the compiler drain vmcnt there).
-MPG_DEV unsigned long long dw_valid_bits(const MpgEdgeDw& p, int blk0, int blk1) {
-    const int RB = (p.N + 31) / 32, x = blk0 + (int)(threadIdx.x & 63);
-    bool ok = x < blk1;
+// The blocks of a workgroup are STRIDED over the launch (slot t of workgroup g is block g + t * gridDim.x): a contiguous
+// range would be one jet's senders, and a launch would last as long as its fullest jet (masks sorted to the end of a
+// jet left whole workgroups idle at N = 150); strided, every workgroup samples all jets.
+MPG_DEV int dw_block(int t) { return (int)blockIdx.x + t * (int)gridDim.x; }
+MPG_DEV unsigned long long dw_valid_bits(const MpgEdgeDw& p, int blk0, int blk1) {   // over the slots [blk0, blk1)
+    const int RB = (p.N + 31) / 32, t = blk0 + (int)(threadIdx.x & 63), x = dw_block(t);
+    bool ok = t < blk1;
     if (ok && p.mask != nullptr) ok = p.mask[((x / p.N) / RB) * p.N + x % p.N] != 0.f;
     return __ballot(ok);
 }
@@ -720,15 +724,16 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsi
     int nxt = dw_next_valid(vbits, blk0, cur + 1, blk1);
     // `pre` is clamped to the last block of the range: past the end the prefetches fetch that block again, unused
     if (cur < blk1) {
-        load_jet(cur); load_sw(cur); load_nb(cur); load_c(cur);
+        const int b0 = dw_block(cur);
+        load_jet(b0); load_sw(b0); load_nb(b0); load_c(b0);
 #pragma unroll
-        for (int n = 0; n < 3; ++n) { load_e2(cur, n); load_z2(cur, n); }
-        build(cur, smem, min(nxt, blk1 - 1));
+        for (int n = 0; n < 3; ++n) { load_e2(b0, n); load_z2(b0, n); }
+        build(b0, smem, dw_block(min(nxt, blk1 - 1)));
     }
     lds_barrier();
     while (cur < blk1) {
         const int nxt2 = dw_next_valid(vbits, blk0, nxt + 1, blk1);
-        if (nxt < blk1 && !(MPG_DW_EXP & 2)) build(nxt, smem + ((it + 1) & 1) * DW_BUF, min(nxt2, blk1 - 1));
+        if (nxt < blk1 && !(MPG_DW_EXP & 2)) build(dw_block(nxt), smem + ((it + 1) & 1) * DW_BUF, dw_block(min(nxt2, blk1 - 1)));
         lds_barrier();
         cur = nxt;
         nxt = nxt2;
@@ -759,8 +764,7 @@ __global__ __launch_bounds__(512, 1) void edge_dw_kernel(const MpgEdgeDw p) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int RB = (p.N + 31) / 32;
     const int nblk = p.B * RB * p.N;
-    const int per = (nblk + gridDim.x - 1) / gridDim.x;
-    const int blk0 = blockIdx.x * per, blk1 = min(nblk, blk0 + per);
+    const int blk0 = 0, blk1 = (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // slots of this workgroup
     const unsigned long long vbits = dw_valid_bits(p, blk0, blk1);
     if (w == 0) dw_consumer<0, 12>(p, blk0, blk1, vbits);
     else if (w == 1) dw_consumer<12, 23>(p, blk0, blk1, vbits);
