@@ -55,8 +55,14 @@ def test_host_helpers():
     with pytest.raises(ValueError):
         ops.drop_params(0.9999)
     assert ops._sender_chunks(256, 30) == 1        # every CU already has a workgroup
-    assert ops._sender_chunks(16, 150) * 16 * 5 >= 224
+    assert ops._sender_chunks(512, 30) == 1
+    assert ops._sender_chunks(16, 150) == 3        # 240 workgroups: one round of the 256 CUs (4 chunks would run two)
     assert ops._sender_chunks(1, 1) == 1
+    for B, N in ((1, 150), (3, 40), (16, 150), (2, 1000)):   # chunks never exceed what mpg_edge_bwd's sender list holds
+        sc = ops._sender_chunks(B, N)
+        assert -(-N // sc) <= ops.MAX_CHUNK_SENDERS
+    assert ops.mab_fusable(64, 4, 30, 30) and ops.mab_fusable(32, 2, 1, 30) and ops.mab_fusable(64, 4, 10, 30)
+    assert not ops.mab_fusable(64, 4, 150, 150) and not ops.mab_fusable(64, 8, 30, 30) and not ops.mab_fusable(128, 8, 30, 30)
     a, b = ops.next_tag(), ops.next_tag()
     assert b - a == 8
 
