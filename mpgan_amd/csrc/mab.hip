@@ -86,19 +86,19 @@ MPG_DEV void tiles_to_frags(const f32x16* t, float scale, V* hi, V* lo) {
         tile_frag(t[tt], 1, scale, hi[2 * tt + 1], lo[2 * tt + 1]);
     });
 }
-// bias of the features a lane's accumulator registers hold (features in registers), times `scale`
-MPG_DEV f32x16 bias_regs(const float* bias, int tile, int h, float scale) {
+// bias of the features a lane's accumulator registers hold (features in registers); the staged copies are pre-scaled
+MPG_DEV f32x16 bias_regs(const float* bias, int tile, int h) {
     f32x16 t;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const float4 a = mld4(bias + 32 * tile + 8 * g + 4 * h);
-        t[4 * g] = a.x * scale; t[4 * g + 1] = a.y * scale; t[4 * g + 2] = a.z * scale; t[4 * g + 3] = a.w * scale;
+        t[4 * g] = a.x; t[4 * g + 1] = a.y; t[4 * g + 2] = a.z; t[4 * g + 3] = a.w;
     }
     return t;
 }
 // ... and with the features on the lanes (swapped-operand products)
-MPG_DEV f32x16 bias_lanes(const float* bias, int tile, int r, float scale) {
-    const float b = bias[32 * tile + r] * scale;
+MPG_DEV f32x16 bias_lanes(const float* bias, int tile, int r) {
+    const float b = bias[32 * tile + r];
     f32x16 t;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t[i] = b;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
     mab_fill(sO, p.Wo, 2 * nfE * 1024);
     mab_fill(sF, p.Wf, 2 * nfE * 1024);
     for (int i = threadIdx.x; i < 160 * NT; i += blockDim.x)
-        sBin[i] = i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT]);
+        sBin[i] = (i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT])) * zs;   // (as the accumulators carry them)
     __syncthreads();
     const WImg rIn = sIn, rO = sO, rF = sF;
     const int nw = blockDim.x >> 6;
@@ -217,9 +217,9 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
     V oh[KS], ol[KS];                     // attention output as B fragments of the out-projection
     static_for<0, NT>([&](auto tc) {
         MPG_CI(t, tc);
-        const f32x16 Qn = proj_n<KS>(rIn, nfIn, t, xh, xl, bias_regs(sBin, t, h, zs), lane16);
-        const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(sBin, NT + t, h, zs), lane16);
-        const f32x16 Vt = proj_t<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_lanes(sBin, 2 * NT + t, r, zs), lane16);
+        const f32x16 Qn = proj_n<KS>(rIn, nfIn, t, xh, xl, bias_regs(sBin, t, h), lane16);
+        const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(sBin, NT + t, h), lane16);
+        const f32x16 Vt = proj_t<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_lanes(sBin, 2 * NT + t, r), lane16);
         V vh[2], vl[2];
         tile_frag(Vt, 0, inv_zs * sa, vh[0], vl[0]);
         tile_frag(Vt, 1, inv_zs * sa, vh[1], vl[1]);
@@ -230,14 +230,14 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
             tile_frag(Qn, a, inv_zs * sa * 0.25f, qh, ql);   // 1/sqrt(d), d = 16
             tile_frag(Kn, a, inv_zs * sa, kh, kl);
             f32x16 s = mfma3(kh, kl, qh, ql, zero16());      // keys in registers, queries on lanes
-            const float inv_sa2 = 1.f / (sa * sa);
+            const float sc2 = 1.44269504088896341f / (sa * sa);   // scores in the base-2 domain: v_exp_f32 is 2^x
             float mx = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { s[i] = s[i] * inv_sa2 + kneg[i]; mx = fmaxf(mx, s[i]); }
+            for (int i = 0; i < 16; ++i) { s[i] = s[i] * sc2 + kneg[i]; mx = fmaxf(mx, s[i]); }
             mx = fmaxf(mx, other_half(mx));
             float den = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { s[i] = __expf(s[i] - mx); den += s[i]; }
+            for (int i = 0; i < 16; ++i) { s[i] = __builtin_amdgcn_exp2f(s[i] - mx); den += s[i]; }
             den += other_half(den);
             const float pn = MAB_SP / den;
             V ph[2], pl[2];
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
     V zh[KS], zl[KS];
     static_for<0, NT>([&](auto tc) {
         MPG_CI(t, tc);
-        const f32x16 acc = proj_n<KS>(rO, nfE, t, oh, ol, bias_regs(sBo, t, h, zs), lane16);
+        const f32x16 acc = proj_n<KS>(rO, nfE, t, oh, ol, bias_regs(sBo, t, h), lane16);
 #pragma unroll
         for (int i = 0; i < 16; ++i) z[t][i] = acc[i] * inv_zs + xt[t][i];
         drop_tile(z[t], seed_lo, seed_hi, p.tag + 0, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
     // out = dropout(z + dropout_ff(LeakyReLU(z Wf' + bf)))
     static_for<0, NT>([&](auto tc) {
         MPG_CI(t, tc);
-        f32x16 u = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(sBf, t, h, zs), lane16);
+        f32x16 u = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(sBf, t, h), lane16);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float v = u[i] * inv_zs;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
     uint32_t seed_lo = 0, seed_hi = 0;
     if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
     const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
-    const float zs = sa * ws, inv_zs = 1.f / zs, inv_sa2 = 1.f / (sa * sa);
+    const float zs = sa * ws, inv_zs = 1.f / zs, sc2 = 1.44269504088896341f / (sa * sa);   // (scores in the base-2 domain)
     constexpr int nfIn = 3 * NT * KS, nfE = NT * KS, nfInT = NT * 3 * KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sIn = smem;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
     mab_fill(sFT, p.WfT, 2 * nfE * 1024);
     float* const sBin = reinterpret_cast<float*>(sFT + 2 * nfE * 1024);  // biases: in_proj [3E] | ff [E]
     float* const sBf = sBin + 96 * NT;
-    for (int i = threadIdx.x; i < 128 * NT; i += blockDim.x) sBin[i] = i < 96 * NT ? p.bin[i] : p.bf[i - 96 * NT];
+    for (int i = threadIdx.x; i < 128 * NT; i += blockDim.x) sBin[i] = (i < 96 * NT ? p.bin[i] : p.bf[i - 96 * NT]) * zs;
     __syncthreads();
     const WImg rIn = sIn, rF = sF, rInT = sInT, rOT = sOT, rFT = sFT;
     const int nw = blockDim.x >> 6;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) dzf[t][i] *= xlive;
             drop_tile(dzf[t], seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
-            const f32x16 u = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(sBf, t, h, zs), lane16);
+            const f32x16 u = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(sBf, t, h), lane16);
             f32x16 du;
 #pragma unroll
             for (int i = 0; i < 16; ++i) du[i] = dzf[t][i] * ((p.ff_act && !(u[i] > 0.f)) ? p.alpha : 1.f);
@@ -404,11 +404,11 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
         // gradient of the attention output of this tile's two heads, both orientations
         const f32x16 dOn = proj_n<KS>(rOT, nfE, t, dzah, dzal, zero16(), lane16);
         const f32x16 dOp = proj_t<KS>(rOT, nfE, t, dzah, dzal, zero16(), lane16);
-        const f32x16 Qn = proj_n<KS>(rIn, nfIn, t, xh, xl, bias_regs(sBin, t, h, zs), lane16);
-        const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(sBin, NT + t, h, zs), lane16);
-        const f32x16 Vn = proj_n<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_regs(sBin, 2 * NT + t, h, zs), lane16);
-        const f32x16 Qp = proj_t<KS>(rIn, nfIn, t, xh, xl, bias_lanes(sBin, t, r, zs), lane16);
-        const f32x16 Kp = proj_t<KS>(rIn, nfIn, NT + t, yh, yl, bias_lanes(sBin, NT + t, r, zs), lane16);
+        const f32x16 Qn = proj_n<KS>(rIn, nfIn, t, xh, xl, bias_regs(sBin, t, h), lane16);
+        const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(sBin, NT + t, h), lane16);
+        const f32x16 Vn = proj_n<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_regs(sBin, 2 * NT + t, h), lane16);
+        const f32x16 Qp = proj_t<KS>(rIn, nfIn, t, xh, xl, bias_lanes(sBin, t, r), lane16);
+        const f32x16 Kp = proj_t<KS>(rIn, nfIn, NT + t, yh, yl, bias_lanes(sBin, NT + t, r), lane16);
         VB kph[2], kpl[2], qph[2], qpl[2], doph[2], dopl[2];
         static_for<0, 2>([&](auto sc) {
             MPG_CI(s, sc);
@@ -429,13 +429,13 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
             f32x16 s = mfma3(kh, kl, qh, ql, zero16());
             float mx = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { s[i] = s[i] * inv_sa2 + kneg[i]; mx = fmaxf(mx, s[i]); }
+            for (int i = 0; i < 16; ++i) { s[i] = s[i] * sc2 + kneg[i]; mx = fmaxf(mx, s[i]); }
             mx = fmaxf(mx, other_half(mx));
             float den = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { s[i] = __expf(s[i] - mx); den += s[i]; }
+            for (int i = 0; i < 16; ++i) { s[i] = __builtin_amdgcn_exp2f(s[i] - mx); den += s[i]; }
             den += other_half(den);
-            const float inv_den = 1.f / den, cq = mx + __logf(den);
+            const float inv_den = 1.f / den, cq = mx + __builtin_amdgcn_logf(den);   // log2
             const f32x16 dP = mfma3(vbh, vbl, dobh, dobl, zero16());
             float D = 0.f;
 #pragma unroll
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * g + e, qi = 8 * g + 4 * h + e;   // the query this register belongs to
                     const float c_q = __shfl(cq, qi), D_q = __shfl(D, qi);
-                    const float pr = key_off ? 0.f : __expf(sT[i] * inv_sa2 - c_q);
+                    const float pr = key_off ? 0.f : __builtin_amdgcn_exp2f(sT[i] * sc2 - c_q);
                     pT[i] = pr;
                     dST[i] = pr * (dPT[i] - D_q) * 0.25f;
                 }
