@@ -166,8 +166,13 @@ def _attn_mask(mask: Tensor) -> Optional[Tensor]:
     take ([B*N], 1 = ignore) rides along as an attribute, so that the blocks of a network do not each convert it."""
     if mask is None:
         return None
-    inv = 1 - mask
-    am = inv.bool()
+    return _ignore_mask(1 - mask)
+
+
+def _ignore_mask(inv: Tensor) -> Tensor:
+    """[B, N, 1] floats, 1 = ignore, as the attention mask the blocks pass around.  On the GPU the float tensor itself
+    travels (the kernels read it through ``_mpg_ignore``; a bool copy would be one more launch per forward)."""
+    am = inv if inv.is_cuda else inv.bool()
     am._mpg_ignore = inv.reshape(-1).contiguous()
     return am
 
@@ -257,11 +262,11 @@ class GAPT_D(nn.Module):
 
     def features(self, x: Tensor, labels: Tensor = None):
         """Everything up to the pooled seed: ([B, 1, E], None)."""
-        mask = None
+        am = None
         if self.use_mask:
-            mask = x[..., -1:] + 0.5
+            # mask = x[..., -1:] + 0.5 (:336); what the blocks need is 1 - mask = 0.5 - x[..., -1:]: one launch
+            am = _ignore_mask(0.5 - x.detach()[..., -1:])   # (no gradient flows through the mask column: :336-338, bool mask)
             x = x[..., :-1]
-        am = _attn_mask(mask)
         x = self.input_embedding(x.contiguous())
         for sab in self.sabs:
             x = sab(x, am)
