@@ -62,8 +62,12 @@ class LinearNet(nn.Module):
 
 
 class MPLayer(nn.Module):
-    """One message-passing iteration, executed by ``ops.FusedMPLayerFn`` (one fused edge kernel +
-    the node network)."""
+    """One message-passing iteration.  The reference's default configuration -- edge network [96, 160, 192] on
+    [x_i ; x_j], two hidden node layers, fully connected or k-NN graph -- runs on ``ops.FusedMPLayerFn`` (fused edge
+    kernels + chained node network).  Every other option of the reference's constructor (edge features ``pos_diffs`` /
+    ``delta_r`` / ``delta_coords``, conditioning columns ``clabels`` / ``mask_fne_np``, other layer widths) takes the
+    un-fused route of ``_forward_edges``: the edge matrix is materialised as the reference builds it and the two
+    networks run layer by layer on the HIP GEMM -- same results, none of the fused kernels' speed."""
 
     def __init__(self, input_node_size: int, fe_layers: list, fn_layers: list, output_node_size: int,
                  pos_diffs: bool = False, all_ef: bool = True, coords: str = "polarrel", delta_coords: bool = False,
@@ -71,26 +75,94 @@ class MPLayer(nn.Module):
                  fully_connected: bool = True, num_knn: int = 20, self_loops: bool = True, sum: bool = True,
                  **linear_args):
         super().__init__()
-        # clabels / mask_fne_np: the reference appends them with ``labels.repeat(num_nodes * num_knn, 1)`` (:249, :253,
-        # :272, :276), which tiles the [B, C] block: edge row r receives the labels of jet r mod B, not of its own jet.
-        # Reproducing that needs a per-EDGE input of the edge network, not a per-jet one (out of scope).
-        _unsupported(pos_diffs=pos_diffs, int_diffs=int_diffs, clabels=clabels, mask_fne_np=mask_fne_np)
-        if list(fe_layers) != [ops.H1, ops.H2, ops.H3] or len(fn_layers) != 2:
-            raise NotImplementedError("mpgan_amd: the fused edge kernel is built for fe_layers=[96,160,192] and two "
-                                      f"hidden fn layers (got fe={list(fe_layers)}, fn={list(fn_layers)})")
+        # int_diffs reserves an input column of the edge network that the reference's forward never fills (:180, :284-317)
+        _unsupported(int_diffs=int_diffs)
         self.input_node_size, self.output_node_size = input_node_size, output_node_size
         self.fe_layers, self.fn_layers = list(fe_layers), list(fn_layers)
         self.sum = sum
+        self.pos_diffs, self.all_ef, self.coords = bool(pos_diffs), bool(all_ef), coords
+        self.delta_coords, self.delta_r = bool(delta_coords), bool(delta_r)
+        self.clabels, self.mask_fne_np = int(clabels), bool(mask_fne_np)
         # fully_connected=False: every receiver aggregates over its num_knn nearest senders only (reference _getA_knn);
-        # here the fused kernels still walk all N senders with the neighbour sets as a per-edge 0/1 factor
+        # the fused kernels still walk all N senders with the neighbour sets as a per-edge 0/1 factor
         self.fully_connected, self.num_knn, self.self_loops = fully_connected, int(num_knn), bool(self_loops)
-        self.fe = LinearNet(self.fe_layers, input_size=2 * input_node_size, final_linear=False, **linear_args)
-        self.fn = LinearNet(self.fn_layers, input_size=self.fe_layers[-1] + input_node_size,
+        num_ef = 0   # edge features appended to [x_i ; x_j] (:169-178)
+        if self.pos_diffs:
+            if self.delta_coords:
+                num_ef += 3 if coords == "cartesian" else 2
+            if self.delta_r or self.all_ef:
+                num_ef += 1
+        self.num_ef = num_ef
+        extra = self.clabels + int(self.mask_fne_np)
+        self.fused = (list(self.fe_layers) == [ops.H1, ops.H2, ops.H3] and len(self.fn_layers) == 2
+                      and num_ef == 0 and extra == 0)
+        self.fe = LinearNet(self.fe_layers, input_size=2 * input_node_size + num_ef + extra, final_linear=False, **linear_args)
+        self.fn = LinearNet(self.fn_layers, input_size=self.fe_layers[-1] + input_node_size + extra,
                             output_size=output_node_size, final_linear=True, **linear_args)
+
+    def _forward_edges(self, x: Tensor, use_mask: bool, mask: Tensor, labels: Tensor, num_jet_particles: Tensor) -> Tensor:
+        """The un-fused route: edge matrix built row by row as ``MPLayer.forward`` / ``_getA_*`` do (mpgan/model.py:
+        206-381), edge and node networks through ``LinearNet`` (one fused Linear launch per layer)."""
+        B, N, F = x.shape
+        nc = 3 if self.coords == "cartesian" else 2
+        if self.fully_connected:
+            k = N
+            xi, xj = x.unsqueeze(2).expand(B, N, N, F), x.unsqueeze(1).expand(B, N, N, F)   # edge (b, i, j) = [x_i ; x_j]
+            cols = [xi, xj]
+            if self.pos_diffs:
+                diffs = (xj - xi) if self.all_ef else (xj[..., :nc] - xi[..., :nc])
+                dists = torch.norm(diffs + 1e-12, dim=3, keepdim=True)
+                if self.delta_r and self.delta_coords:
+                    cols += [diffs, dists]
+                elif self.delta_r or self.all_ef:
+                    cols += [dists]
+                elif self.delta_coords:
+                    cols += [diffs]
+            edge_mask = mask.unsqueeze(1) if use_mask else None   # the sender's mask
+        else:
+            k = self.num_knn
+            if k + int(not self.self_loops) > N:
+                raise ValueError(f"num_knn = {k} neighbours (self_loops = {self.self_loops}) out of {N} nodes")
+            xs = (((1 - 1e4) * mask + 1e4) * x) if use_mask else x   # zero-masked senders are pushed out of reach
+            dd = xs.unsqueeze(1) - x.unsqueeze(2)
+            if self.pos_diffs and not self.all_ef:
+                dd = dd[..., :nc]
+            order = torch.sort(torch.norm(dd + 1e-12, dim=3), dim=2)
+            first = int(not self.self_loops)
+            idx = order.indices[:, :, first:first + k]
+
+            def neighbours(t):
+                return torch.gather(t.unsqueeze(1).expand(B, N, N, t.shape[-1]), 2,
+                                    idx.unsqueeze(3).expand(B, N, k, t.shape[-1]))
+            cols = [x.unsqueeze(2).expand(B, N, k, F), neighbours(x)]
+            if self.pos_diffs:
+                cols.append(order.values[:, :, first:first + k].unsqueeze(3))
+            edge_mask = neighbours(mask) if use_mask else None
+        A = torch.cat(cols, dim=3).reshape(B * N * k, -1)
+        # conditioning columns: ``t.repeat(rows / B, 1)`` tiles the [B, C] block, so ROW r gets the entry of jet r mod B
+        # (:249, :253, :272, :276) -- reproduced as the reference computes it
+        if self.clabels:
+            A = torch.cat((A, labels[:, :self.clabels].repeat(N * k, 1)), dim=1)
+        if self.mask_fne_np:
+            A = torch.cat((A, num_jet_particles.repeat(N * k, 1)), dim=1)
+        E = self.fe(A.contiguous()).reshape(B, N, k, self.fe_layers[-1])
+        if edge_mask is not None:
+            E = E * edge_mask
+        agg = E.sum(dim=2) if self.sum else E.mean(dim=2)
+        h = torch.cat((agg, x), dim=2).reshape(B * N, -1)
+        if self.clabels:
+            h = torch.cat((h, labels[:, :self.clabels].repeat(N, 1)), dim=1)
+        if self.mask_fne_np:
+            h = torch.cat((h, num_jet_particles.repeat(N, 1)), dim=1)
+        return self.fn(h.contiguous()).reshape(B, N, self.output_node_size)
 
     def forward(self, x: Tensor, use_mask: bool = False, mask: Tensor = None, labels: Tensor = None,
                 num_jet_particles: Tensor = None) -> Tensor:
         assert not (use_mask and mask is None), "need ``mask`` tensor if using ``use_mask`` option"
+        assert not (self.clabels and labels is None), "need ``labels`` tensor if using ``clabels`` option"
+        assert not (self.mask_fne_np and num_jet_particles is None), "need ``num_jet_particles`` tensor if using ``mask_fne_np`` option"
+        if not self.fused:
+            return self._forward_edges(x, use_mask, mask, labels, num_jet_particles)
         fe, fn = self.fe.net, self.fn.net
         nbr = None
         if not self.fully_connected:

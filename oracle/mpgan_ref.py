@@ -169,6 +169,93 @@ def mplayer_forward(
     return _node_net(sd, prefix, agg, x, n_fn, alpha, p, k, probe)
 
 
+def mplayer_forward_general(
+    sd: Dict[str, Tensor],
+    prefix: str,
+    x: Tensor,
+    mask: Optional[Tensor] = None,
+    labels: Optional[Tensor] = None,
+    num_jet_particles: Optional[Tensor] = None,
+    *,
+    pos_diffs: bool = False,
+    all_ef: bool = True,
+    coords: str = "polarrel",
+    delta_coords: bool = False,
+    delta_r: bool = True,
+    clabels: int = 0,
+    mask_fne_np: bool = False,
+    knn: Optional[tuple] = None,
+    sum_agg: bool = True,
+    alpha: float = 0.2,
+) -> Tensor:
+    """``MPLayer.forward`` with its non-default options (mpgan/model.py:206-282), any layer widths, no dropout: the edge
+    tensor is materialised row by row as the reference builds it.
+
+    * edge features (``_getA_fully_connected`` :297-313): diffs = x_j - x_i over all features (``all_ef``) or the first
+      2 / 3 coordinates; dists = || diffs + 1e-12 ||; appended as [diffs, dists] (delta_r and delta_coords), [dists]
+      (delta_r or all_ef) or [diffs] (delta_coords).  On the k-NN graph (:319-381) the appended column is the sorted
+      distance itself (computed with zero-masked senders pushed away by 1e4).
+    * ``clabels`` / ``mask_fne_np`` (:247-253, :270-276) are appended with ``t.repeat(rows / B, 1)``: ROW r of the edge
+      (node) matrix receives the entry of jet  r mod B  -- not of the jet the row belongs to.  Restated as is.
+    """
+    B, N, F = x.shape
+    nc = 3 if coords == "cartesian" else 2
+    if knn is None:
+        k = N
+        xi = x.unsqueeze(2).expand(B, N, N, F)   # edge (b, i, j): receiver i first (:294)
+        xj = x.unsqueeze(1).expand(B, N, N, F)
+        parts = [xi, xj]
+        if pos_diffs:
+            diffs = (xj - xi) if all_ef else (xj[..., :nc] - xi[..., :nc])
+            dists = torch.norm(diffs + 1e-12, dim=3, keepdim=True)
+            if delta_r and delta_coords:
+                parts += [diffs, dists]
+            elif delta_r or all_ef:
+                parts += [dists]
+            elif delta_coords:
+                parts += [diffs]
+        edge_mask = None if mask is None else mask.unsqueeze(1)   # senders only (:262)
+    else:
+        k, self_loops = knn
+        xs = x if mask is None else ((1 - 1e4) * mask + 1e4) * x
+        dd = xs.unsqueeze(1) - x.unsqueeze(2)
+        if not (all_ef or not pos_diffs):
+            dd = dd[..., :nc]
+        srt = torch.sort(torch.norm(dd + 1e-12, dim=3), dim=2)
+        first = 0 if self_loops else 1
+        idx = srt[1][:, :, first:first + k]
+        gather = lambda t: torch.gather(t.unsqueeze(1).expand(B, N, N, t.shape[-1]), 2,
+                                        idx.unsqueeze(3).expand(B, N, k, t.shape[-1]))
+        parts = [x.unsqueeze(2).expand(B, N, k, F), gather(x)]
+        if pos_diffs:
+            parts.append(srt[0][:, :, first:first + k].unsqueeze(3))
+        edge_mask = None if mask is None else gather(mask)
+    A = torch.cat(parts, dim=3).reshape(B * N * k, -1)
+    if clabels:
+        A = torch.cat((A, labels[:, :clabels].repeat(N * k, 1)), dim=1)
+    if mask_fne_np:
+        A = torch.cat((A, num_jet_particles.repeat(N * k, 1)), dim=1)
+    n_fe = sum(1 for key in sd if key.startswith(f"{prefix}.fe.net.") and key.endswith(".weight"))
+    n_fn = sum(1 for key in sd if key.startswith(f"{prefix}.fn.net.") and key.endswith(".weight"))
+    e = A
+    for l in range(n_fe):
+        e = leaky(e @ sd[f"{prefix}.fe.net.{l}.weight"].t() + sd[f"{prefix}.fe.net.{l}.bias"], alpha)
+    e = e.reshape(B, N, k, -1)
+    if edge_mask is not None:
+        e = e * edge_mask
+    agg = e.sum(dim=2) if sum_agg else e.mean(dim=2)
+    h = torch.cat((agg, x), dim=2).reshape(B * N, -1)
+    if clabels:
+        h = torch.cat((h, labels[:, :clabels].repeat(N, 1)), dim=1)
+    if mask_fne_np:
+        h = torch.cat((h, num_jet_particles.repeat(N, 1)), dim=1)
+    for l in range(n_fn):
+        h = h @ sd[f"{prefix}.fn.net.{l}.weight"].t() + sd[f"{prefix}.fn.net.{l}.bias"]
+        if l + 1 < n_fn:
+            h = leaky(h, alpha)
+    return h.reshape(B, N, -1)
+
+
 def _node_net(sd, prefix, agg, x, n_fn, alpha, p, k, probe):
     """fn on [agg ; x] (mpgan/model.py:268-279)."""
     h = torch.cat((agg, x), dim=2)

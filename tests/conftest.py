@@ -49,3 +49,34 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     den = np.abs(b).max()
     return float(np.abs(a - b).max() / (den if den > 0 else 1.0))
+
+
+def option_case_shapes(F, out, kw):
+    """State-dict shapes of an MPLayer built with the option keywords of ``gen_golden.OPTION_CASES`` (edge features,
+    conditioning columns and layer widths change the first Linear of fe / fn; mpgan/model.py:169-204)."""
+    nc = 3 if kw.get("coords", "polarrel") == "cartesian" else 2
+    num_ef = 0
+    if kw.get("pos_diffs"):
+        if kw.get("delta_coords"):
+            num_ef += nc
+        if kw.get("delta_r", True) or kw.get("all_ef", True):
+            num_ef += 1
+    extra = int(kw.get("clabels", 0)) + int(bool(kw.get("mask_fne_np")))
+    fe, fn = list(kw.get("fe", [96, 160, 192])), list(kw.get("fn", [256, 256]))
+    sh = {}
+    d = [2 * F + num_ef + extra] + fe
+    for k in range(len(fe)):
+        sh[f"fe.net.{k}.weight"], sh[f"fe.net.{k}.bias"] = (d[k + 1], d[k]), (d[k + 1],)
+    d = [fe[-1] + F + extra] + fn + [out]
+    for k in range(len(fn) + 1):
+        sh[f"fn.net.{k}.weight"], sh[f"fn.net.{k}.bias"] = (d[k + 1], d[k]), (d[k + 1],)
+    return sh
+
+
+def option_case_oracle_kwargs(kw):
+    """The keywords of ``oracle.mpgan_ref.mplayer_forward_general`` for one ``OPTION_CASES`` entry."""
+    o = {k: kw[k] for k in ("pos_diffs", "all_ef", "coords", "delta_coords", "delta_r", "clabels", "mask_fne_np") if k in kw}
+    if not kw.get("fully_connected", True):
+        o["knn"] = (kw["num_knn"], kw.get("self_loops", True))
+    o["sum_agg"] = kw.get("sum", True)
+    return o

@@ -51,6 +51,18 @@ def rand_mask(B, N, seed):
     return torch.from_numpy(m)
 
 
+# MPLayer configurations outside the fused kernels' shapes (name, B, N, F, out, constructor keywords); the tests import
+# this table so that the oracle and the product are built with the very same arguments
+OPTION_CASES = [
+    ("ef", 3, 9, 32, 32, dict(pos_diffs=True)),                                                   # delta_r over all features
+    ("efc", 3, 8, 3, 32, dict(pos_diffs=True, all_ef=False, delta_coords=True, delta_r=True)),   # [diffs(2), dists]
+    ("cl", 4, 7, 32, 32, dict(clabels=1, mask_fne_np=True)),                                      # rows tiled jet r mod B
+    ("knnef", 3, 12, 32, 32, dict(pos_diffs=True, fully_connected=False, num_knn=5, self_loops=True, sum=False)),
+    ("widths", 3, 9, 16, 8, dict(fe=[64, 48], fn=[40], use_mask=False)),                          # any layer widths
+]
+OPTION_SEEDS = {"ef": 60, "efc": 61, "cl": 62, "knnef": 63, "widths": 64}
+
+
 def main():
     if not os.path.isdir(REF):
         print(f"reference not found at {REF}; nothing generated")
@@ -118,6 +130,31 @@ def main():
             rec["grad__" + k] = summarize(k, p.grad)
         np.savez_compressed(os.path.join(OUT, f"mplayer_{name}_f64.npz"), **rec)
         print("mplayer", name, float(y.abs().max()))
+
+    # ------------------------------------------------------------------ 1c. MPLayer with its non-default options
+    for name, B, N, F, out, kw in OPTION_CASES:
+        dt = torch.float64
+        ci = OPTION_SEEDS[name]
+        layer = rmp.MPLayer(F, kw.get("fe", fe), kw.get("fn", fn), out,
+                            **{k: v for k, v in kw.items() if k not in ("fe", "fn", "use_mask")}).to(dt)
+        shapes = {k: tuple(v.shape) for k, v in layer.state_dict().items()}
+        layer.load_state_dict(init_state_dict(shapes, seed=ci, dtype=dt))
+        x = seeded((B, N, F), 100 + ci, 0.5).to(dt).requires_grad_(True)
+        use_mask = kw.get("use_mask", True)
+        mask = rand_mask(B, N, 200 + ci).to(dt) if use_mask else None
+        labels = seeded((B, 2), 400 + ci, 1.0).to(dt)
+        njp = mask.sum(1) / N if mask is not None else torch.ones(B, 1, dtype=dt)
+        g = seeded((B, N, out), 300 + ci).to(dt)
+        y = layer(x, use_mask, mask, labels, njp)
+        (y * g).sum().backward()
+        rec = dict(x=x.detach().numpy(), g=g.numpy(), y=y.detach().numpy(), dx=x.grad.numpy(), seed=ci,
+                   labels=labels.numpy(), njp=njp.numpy())
+        if mask is not None:
+            rec["mask"] = mask.numpy()
+        for k, p in layer.named_parameters():
+            rec["grad__" + k] = summarize(k, p.grad)
+        np.savez_compressed(os.path.join(OUT, f"mplayer_opt_{name}_f64.npz"), **rec)
+        print("mplayer option case", name, float(y.abs().max()))
 
     # ------------------------------------------------------------------ default args / manifests
     sys.argv = ["gen_golden"]

@@ -96,15 +96,20 @@ def test_product_has_no_cpu_path_and_says_so():
 def test_unsupported_options_raise():
     from mpgan_amd.mpgan import MPLayer, LinearNet
     from mpgan_amd.gapt import MAB
-    with pytest.raises(NotImplementedError):
-        MPLayer(32, [96, 160, 192], [256, 256], 32, pos_diffs=True)
-    assert MPLayer(32, [96, 160, 192], [256, 256], 32, fully_connected=False, num_knn=10).num_knn == 10   # k-NN graphs are on the path
-    with pytest.raises(NotImplementedError):
-        MPLayer(32, [64, 64], [256, 256], 32)
+    with pytest.raises(NotImplementedError):   # an input column the reference's own forward never fills
+        MPLayer(32, [96, 160, 192], [256, 256], 32, int_diffs=True)
     with pytest.raises(NotImplementedError):
         LinearNet([8, 8], batch_norm=True)
-    with pytest.raises(NotImplementedError):   # the reference tiles these over EDGES (labels of jet r mod B on edge row r)
-        MPLayer(32, [96, 160, 192], [256, 256], 32, clabels=1)
+    # the default configuration (and its k-NN form) is on the fused kernels ...
+    assert MPLayer(32, [96, 160, 192], [256, 256], 32).fused
+    assert MPLayer(32, [96, 160, 192], [256, 256], 32, fully_connected=False, num_knn=10).fused
+    # ... every other option builds the reference's layer shapes and takes the un-fused route
+    for kw, fe_in, fn_in in ((dict(pos_diffs=True), 65, 224), (dict(pos_diffs=True, all_ef=False, delta_coords=True), 67, 224),
+                             (dict(clabels=1, mask_fne_np=True), 66, 226)):
+        m = MPLayer(32, [96, 160, 192], [256, 256], 32, **kw)
+        assert not m.fused and m.fe.net[0].in_features == fe_in and m.fn.net[0].in_features == fn_in, kw
+    m = MPLayer(16, [64, 48], [40], 8)
+    assert not m.fused and [l.out_features for l in m.fe.net] == [64, 48] and [l.out_features for l in m.fn.net] == [40, 8]
     m = MAB(64, 4, layer_norm=True)            # LayerNorm is on the HIP path (ops.LayerNormFn)
     assert [k for k in m.state_dict() if "norm" in k] == ["norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"]
 

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import load_golden, rel_err, summarize
 
 pytestmark = pytest.mark.gpu
 
@@ -486,3 +486,31 @@ def test_mplayer_dropout_exact(p_drop):
     assert rel_err(x.grad.cpu().numpy(), xo.grad.numpy()) < TIGHT
     for k, p in layer.named_parameters():
         assert rel_err(p.grad.cpu().numpy(), sdo["L." + k].grad.numpy()) < TIGHT, k
+
+
+def _option_cases():
+    from gen_golden import OPTION_CASES
+    return OPTION_CASES
+
+
+@pytest.mark.parametrize("case", _option_cases(), ids=lambda c: c[0])
+def test_mplayer_options_vs_reference_golden(case):
+    """The un-fused route (edge features, conditioning columns tiled as the reference tiles them, k-NN with distances, other
+    layer widths): outputs and gradients against the reference's own, captured in tests/golden/mplayer_opt_*."""
+    from conftest import option_case_shapes
+    from oracle import train_ref as T
+    from mpgan_amd.mpgan import MPLayer
+    name, B, N, F, out, kw = case
+    g = load_golden(f"mplayer_opt_{name}_f64.npz")
+    ctor = {k: v for k, v in kw.items() if k not in ("fe", "fn", "use_mask")}
+    layer = MPLayer(F, kw.get("fe", [96, 160, 192]), kw.get("fn", [256, 256]), out, **ctor).cuda()
+    assert not layer.fused
+    layer.load_state_dict(T.init_state_dict(option_case_shapes(F, out, kw), seed=int(g["seed"]), dtype=torch.float32))
+    x = torch.from_numpy(g["x"]).float().cuda().requires_grad_(True)
+    mask = torch.from_numpy(g["mask"]).float().cuda() if "mask" in g else None
+    y = layer(x, mask is not None, mask, torch.from_numpy(g["labels"]).float().cuda(), torch.from_numpy(g["njp"]).float().cuda())
+    (y * torch.from_numpy(g["g"]).float().cuda()).sum().backward()
+    assert rel_err(y.detach().cpu().numpy(), g["y"]) < TIGHT, name
+    assert rel_err(x.grad.cpu().numpy(), g["dx"]) < TOL, name
+    for k, p in layer.named_parameters():
+        assert rel_err(summarize(k, p.grad), g["grad__" + k]) < TOL, (name, k)

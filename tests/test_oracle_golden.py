@@ -208,3 +208,29 @@ def test_mplayer_knn_f64(name, F):
     assert rel_err(x.grad.numpy(), g["dx"]) < 1e-11
     for k, v in sd.items():
         assert rel_err(summarize(k[2:], v.grad), g["grad__" + k[2:]]) < 1e-10, k
+
+
+def _option_cases():
+    from gen_golden import OPTION_CASES
+    return OPTION_CASES
+
+
+@pytest.mark.parametrize("case", _option_cases(), ids=lambda c: c[0])
+def test_mplayer_options_f64(case):
+    """MPLayer's non-default options (edge features, conditioning columns with the reference's row tiling, k-NN with
+    distances, other layer widths: mpgan/model.py:206-381) against outputs and gradients captured from the reference."""
+    from conftest import option_case_shapes, option_case_oracle_kwargs
+    from oracle.mpgan_ref import mplayer_forward_general
+    name, B, N, F, out, kw = case
+    g = load_golden(f"mplayer_opt_{name}_f64.npz")
+    sd = T.init_state_dict(option_case_shapes(F, out, kw), seed=int(g["seed"]), dtype=torch.float64)
+    sd = {"L." + k: v.requires_grad_(True) for k, v in sd.items()}
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    mask = torch.from_numpy(g["mask"]) if "mask" in g else None
+    y = mplayer_forward_general(sd, "L", x, mask, torch.from_numpy(g["labels"]), torch.from_numpy(g["njp"]),
+                                **option_case_oracle_kwargs(kw))
+    assert rel_err(y.detach().numpy(), g["y"]) < 1e-12
+    (y * torch.from_numpy(g["g"])).sum().backward()
+    assert rel_err(x.grad.numpy(), g["dx"]) < 1e-11
+    for k, v in sd.items():
+        assert rel_err(summarize(k[2:], v.grad), g["grad__" + k[2:]]) < 1e-10, k
