@@ -331,22 +331,24 @@ class MPDiscriminator(MPNet):
     def __init__(self, dea: bool = True, dea_sum: bool = True, fnd: list = [], mask_fnd_np: bool = False,
                  **mpnet_args):
         super().__init__(output_node_size=1 if not dea else 0, **mpnet_args)
-        _unsupported(mask_fnd_np=mask_fnd_np)
-        self.dea, self.dea_sum, self.mask_fnd_np = dea, dea_sum, mask_fnd_np
-        if dea:
-            self.fnd_layer = LinearNet(fnd, input_size=self.hidden_node_size, output_size=1, final_linear=True,
-                                       **self.linear_args)
+        self.dea, self.dea_sum, self.mask_fnd_np = dea, dea_sum, bool(mask_fnd_np)
+        if dea:   # (mask_fnd_np: the fraction of real particles is one more input of the final network, :803)
+            self.fnd_layer = LinearNet(fnd, input_size=self.hidden_node_size + int(self.mask_fnd_np), output_size=1,
+                                       final_linear=True, **self.linear_args)
 
     def _get_mask(self, x, labels, mask_manual=False, mask_learn=False, mask_learn_sep=False, mask_c=True,
                   mask_fne_np=False, mask_fnd_np=False, **mask_args):
-        if not (mask_manual or mask_learn or mask_c or mask_learn_sep):
-            return x, False, None, None
-        return x[:, :, :-1], True, x[:, :, -1:] + 0.5, None
+        use_mask = bool(mask_manual or mask_learn or mask_c or mask_learn_sep)
+        mask = x[:, :, -1:] + 0.5 if (use_mask or mask_fnd_np) else None   # (:881-883)
+        if use_mask:
+            x = x[:, :, :-1]
+        njp = torch.mean(mask, dim=1) if mask_fne_np else None           # fraction of real particles, [B, 1] (:888)
+        return x, use_mask, mask, njp
 
     def fused_head(self):
         """(weight [1, F], bias, mean-pooling?, sigmoid?, dropout p) when pooling + ``fnd_layer`` + final activation are
         the single-launch head of ``ops.DiscHeadFn`` (``dea`` with an empty ``fnd`` list: the reference default), else None."""
-        if not self.dea or len(self.fnd_layer.net) != 1 or self.final_activation not in ("", "sigmoid"):
+        if not self.dea or self.mask_fnd_np or len(self.fnd_layer.net) != 1 or self.final_activation not in ("", "sigmoid"):
             return None
         lin = self.fnd_layer.net[0]
         return lin.weight, lin.bias, not self.dea_sum, self.final_activation == "sigmoid", self.fnd_layer.dropout_p
@@ -375,7 +377,11 @@ class MPDiscriminator(MPNet):
                 x = x / (mask.sum(1) + 1e-12)
         else:
             x = x.mean(1) if mean else x.sum(1)
-        return self.fnd_layer(x) if self.dea else x
+        if not self.dea:
+            return x
+        if self.mask_fnd_np:
+            x = torch.cat((num_jet_particles, x), dim=1)   # (:826-827: the reference needs mask_fne_np on as well)
+        return self.fnd_layer(x.contiguous())
 
     def __repr__(self):
         dea_str = f",\nFND = {self.fnd_layer}" if self.dea else ""

@@ -61,6 +61,17 @@ OPTION_CASES = [
     ("widths", 3, 9, 16, 8, dict(fe=[64, 48], fn=[40], use_mask=False)),                          # any layer widths
 ]
 OPTION_SEEDS = {"ef": 60, "efc": 61, "cl": 62, "knnef": 63, "widths": 64}
+# a whole discriminator with the conditioning options on (keywords as setup_training.setup_mpgan passes them, :1206-1293)
+D_OPT = dict(
+    num_particles=8, hidden_node_size=32, fe_layers=[96, 160, 192], fn_layers=[256, 256], fn1_layers=None, mp_iters=2,
+    fe1_layers=None, final_activation="sigmoid", input_node_size=3, dea=True, dea_sum=True, fnd=[], mask_fnd_np=True,
+    mp_args=dict(pos_diffs=True, all_ef=False, coords="polarrel", delta_coords=False, delta_r=True, int_diffs=False, clabels=1,
+                 mask_fne_np=True, fully_connected=True, num_knn=20, self_loops=True, sum=True),
+    mp_args_first_layer=dict(clabels=1, all_ef=False),
+    linear_args=dict(leaky_relu_alpha=0.2, dropout_p=0.0, batch_norm=False, spectral_norm=False),
+    mask_args=dict(mask_feat=False, mask_feat_bin=False, mask_weights=False, mask_manual=False, mask_exp=False,
+                   mask_real_only=False, mask_learn=False, mask_learn_bin=True, mask_learn_sep=False, fmg=[64],
+                   mask_disc_sep=False, mask_fnd_np=True, mask_c=True, mask_fne_np=True))
 
 
 def main():
@@ -155,6 +166,26 @@ def main():
             rec["grad__" + k] = summarize(k, p.grad)
         np.savez_compressed(os.path.join(OUT, f"mplayer_opt_{name}_f64.npz"), **rec)
         print("mplayer option case", name, float(y.abs().max()))
+
+    # ------------------------------------------------------------------ 1d. a discriminator with the conditioning options
+    dt = torch.float64
+    Dopt = rmp.MPDiscriminator(**D_OPT).to(dt)
+    shapes = {k: tuple(v.shape) for k, v in Dopt.state_dict().items()}
+    Dopt.load_state_dict(init_state_dict(shapes, seed=70, dtype=dt))
+    Dopt.eval()
+    B, N = 5, D_OPT["num_particles"]
+    mk = rand_mask(B, N, 270).to(dt)
+    xin = torch.cat((seeded((B, N, 3), 170, 0.5).to(dt) * mk, mk - 0.5), dim=2).requires_grad_(True)
+    lab = seeded((B, 2), 470, 1.0).to(dt)
+    yD = Dopt(xin, lab)
+    gD = seeded(tuple(yD.shape), 370).to(dt)
+    (yD * gD).sum().backward()
+    rec = dict(x=xin.detach().numpy(), labels=lab.numpy(), g=gD.numpy(), y=yD.detach().numpy(), dx=xin.grad.numpy(), seed=70,
+               keys=np.array(list(shapes.keys())), shapes=np.array([str(v) for v in shapes.values()]))
+    for k, p in Dopt.named_parameters():
+        rec["grad__" + k] = summarize(k, p.grad)
+    np.savez_compressed(os.path.join(OUT, "mpdisc_opt_f64.npz"), **rec)
+    print("mpdisc options", float(yD.abs().max()))
 
     # ------------------------------------------------------------------ default args / manifests
     sys.argv = ["gen_golden"]

@@ -114,6 +114,20 @@ def test_unsupported_options_raise():
     assert [k for k in m.state_dict() if "norm" in k] == ["norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"]
 
 
+def test_discriminator_with_conditioning_options_has_the_reference_manifest():
+    """MPDiscriminator built with the keywords setup_training.setup_mpgan passes when the conditioning options are on:
+    same state-dict keys and shapes as the reference module had when the golden was made."""
+    import numpy as np
+    from conftest import load_golden
+    from gen_golden import D_OPT
+    from mpgan_amd.mpgan import MPDiscriminator
+    g = load_golden("mpdisc_opt_f64.npz")
+    D = MPDiscriminator(**D_OPT)
+    assert [k for k in D.state_dict()] == list(g["keys"])
+    assert [str(tuple(v.shape)) for v in D.state_dict().values()] == list(g["shapes"])
+    assert not any(l.fused for l in D.mp_layers) and D.fused_head() is None
+
+
 def test_product_does_not_import_the_oracle():
     import sys
     import importlib

@@ -321,3 +321,24 @@ def test_generation_path_no_grad_vs_reference_golden():
     full = mgen.generate_jets(G, 1000, 30, labels=torch.full((1000, 1), 20 / 30.0), batch_size=512)
     assert full.shape == (1000, 30, 3) and bool(torch.isfinite(full).all())
     assert int((full.abs().sum(-1) > 0).sum(1).max()) <= 20
+
+
+def test_discriminator_with_conditioning_options_vs_reference_golden():
+    """A whole MPDiscriminator with clabels, mask_fne_np, mask_fnd_np and delta-r edge features on (the un-fused route of
+    every layer and of the head): output and gradients against the reference's own."""
+    import numpy as np
+    from conftest import load_golden, summarize, rel_err
+    from gen_golden import D_OPT
+    from oracle import train_ref as T
+    from mpgan_amd.mpgan import MPDiscriminator
+    g = load_golden("mpdisc_opt_f64.npz")
+    D = MPDiscriminator(**D_OPT).cuda().eval()
+    shapes = {k: tuple(v.shape) for k, v in D.state_dict().items()}
+    D.load_state_dict(T.init_state_dict(shapes, seed=int(g["seed"]), dtype=torch.float32))
+    x = torch.from_numpy(g["x"]).float().cuda().requires_grad_(True)
+    y = D(x, torch.from_numpy(g["labels"]).float().cuda())
+    (y * torch.from_numpy(g["g"]).float().cuda()).sum().backward()
+    assert rel_err(y.detach().cpu().numpy(), g["y"]) < 1e-4
+    assert rel_err(x.grad.cpu().numpy(), g["dx"]) < 1e-3   # (the mask column included: it feeds the masked sums and njp)
+    for k, p in D.named_parameters():
+        assert rel_err(summarize(k, p.grad), g["grad__" + k]) < 1e-3, k
