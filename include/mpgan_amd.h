@@ -318,6 +318,18 @@ int mpg_layernorm_fwd(const float* x, int ldx, const float* w, const float* b, f
 int mpg_layernorm_bwd(const float* g, int ldg, const float* x, int ldx, const float* w, const float* stats, float* dx,
                       int lddx, float* part, int nwaves, float* dw, float* db, int accumulate, int M, int E, void* stream);
 
+/* mpg_batchnorm_*: nn.BatchNorm1d(F) over the rows of x [M, F] -- LinearNet's optional normalisation behind each
+ * LeakyReLU (mpgan/model.py:58-60, :80-81).  stats writes the batch mean and BIASED variance (two passes; `part` is scratch
+ * of nchunk * F floats); apply normalises with whatever mean / var it is given (batch statistics in training, running
+ * statistics in eval) and the affine w, b (NULL = 1, 0); bwd (training statistics) writes dx and dw = sum g xhat,
+ * db = sum g (added to when accumulate) with `part` of 2 * nchunk * F and `sums` of 2 * F floats as scratch. */
+int mpg_batchnorm_stats(const float* x, int ldx, int M, int F, float* part, int nchunk, float* mean, float* var, void* stream);
+int mpg_batchnorm_apply(const float* x, int ldx, const float* mean, const float* var, const float* w, const float* b, float eps,
+                        float* y, int ldy, int M, int F, void* stream);
+int mpg_batchnorm_bwd(const float* g, int ldg, const float* x, int ldx, const float* mean, const float* var, const float* w, float eps,
+                      float* part, int nchunk, float* sums, float* dx, int lddx, float* dw, float* db, int accumulate, int M, int F,
+                      void* stream);
+
 /* ---- optimisers --------------------------------------------------------------------------------
  * One launch over one flat buffer of n parameters; `gscale` multiplies the gradient first (1/world after a
  * summing all-reduce).  They replace torch.optim.*.step() as the reference builds them (setup_training.py:1511-1523):

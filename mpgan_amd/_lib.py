@@ -186,6 +186,10 @@ SIGNATURES = {
     "mpg_layernorm_fwd": (C.c_int, [_fp, C.c_int, _fp, _fp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "mpg_layernorm_bwd": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int,
                                     C.c_int, C.c_int, C.c_void_p]),
+    "mpg_batchnorm_stats": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, C.c_void_p]),
+    "mpg_batchnorm_apply": (C.c_int, [_fp, C.c_int, _fp, _fp, _fp, _fp, C.c_float, _fp, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mpg_batchnorm_bwd": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, C.c_float, _fp, C.c_int, _fp, _fp, C.c_int, _fp, _fp,
+                                    C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mpg_rmsprop": (C.c_int, [_fp, _fp, _fp, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "mpg_adam": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                            C.c_float, C.c_void_p]),

@@ -90,7 +90,7 @@ class MAB(nn.Module):
 
     # -- the whole block as one launch (ops.mab_forward; csrc/mab.hip) ------------------------------------------
     def _fused_ok(self, x: Tensor, L: int, S: int) -> bool:
-        return (MAB.fused and x.is_cuda and not self.layer_norm and len(self.ff.net) == 1
+        return (MAB.fused and x.is_cuda and not self.layer_norm and len(self.ff.net) == 1 and self.ff.plain
                 and ops.mab_fusable(self.embed_dim, self.num_heads, L, S))
 
     def _packed(self) -> "ops.PackedMAB":
@@ -255,7 +255,7 @@ class GAPT_D(nn.Module):
     def fused_head(self):
         """(weight [1, E], bias, mean?, sigmoid?, dropout p) of ``final_fc`` + sigmoid as ``ops.DiscHeadFn`` (with
         N = 1 "particles": the pooled seed), when ``final_fc`` is a single Linear; else None."""
-        if len(self.final_fc.net) != 1:
+        if len(self.final_fc.net) != 1 or not self.final_fc.plain:
             return None
         lin = self.final_fc.net[0]
         return lin.weight, lin.bias, False, True, self.final_fc.dropout_p

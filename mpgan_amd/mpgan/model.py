@@ -29,20 +29,81 @@ def _unsupported(**flags):
             "mpgan_amd: option(s) %s are outside the fused MI355X path (see DESIGN.md, scope)" % ", ".join(bad))
 
 
+class SpectralNorm(nn.Module):
+    """Spectral normalisation of a Linear layer as the reference wraps it (mpgan/spectral_normalization.py:11-61): the
+    wrapped module keeps ``weight_bar`` (trained), ``weight_u`` / ``weight_v`` (power-iteration vectors, no gradient) and
+    ``bias`` -- same state-dict keys (``module.weight_bar`` ...).  ``weight()`` runs one power iteration in place and
+    returns  W_bar / (u' W_bar v + 1e-12)  with the gradient flowing through W_bar only, which the caller feeds to the
+    fused Linear launch."""
+
+    def __init__(self, module: nn.Linear, power_iterations: int = 1):
+        super().__init__()
+        self.module, self.power_iterations = module, power_iterations
+        w = module.weight
+        u = nn.Parameter(torch.nn.functional.normalize(torch.randn(w.shape[0]), dim=0, eps=1e-12), requires_grad=False)
+        v = nn.Parameter(torch.nn.functional.normalize(torch.randn(w.shape[1]), dim=0, eps=1e-12), requires_grad=False)
+        del module._parameters["weight"]
+        module.register_parameter("weight_u", u)
+        module.register_parameter("weight_v", v)
+        module.register_parameter("weight_bar", nn.Parameter(w.data))
+
+    @property
+    def bias(self):
+        return self.module.bias
+
+    def weight(self) -> Tensor:
+        mod = self.module
+        u, v, w = mod.weight_u, mod.weight_v, mod.weight_bar
+        with torch.no_grad():
+            for _ in range(self.power_iterations):
+                t = torch.mv(w.t(), u)
+                v.copy_(t / (t.norm() + 1e-12))
+                t = torch.mv(w, v)
+                u.copy_(t / (t.norm() + 1e-12))
+        sigma = u.dot(w.mv(v))
+        return w / (sigma + 1e-12)
+
+
 class LinearNet(nn.Module):
-    """Stack of ``Linear -> LeakyReLU -> Dropout`` (last layer ``Linear -> Dropout`` when
-    ``final_linear``); parameters live in ``self.net`` so keys read ``net.{i}.weight|bias``."""
+    """Stack of ``Linear -> LeakyReLU -> [BatchNorm1d] -> Dropout`` (last layer ``Linear -> Dropout`` when
+    ``final_linear``); parameters live in ``self.net`` so keys read ``net.{i}.weight|bias`` (``bn.{i}.*`` with batch
+    norm, ``net.{i}.module.weight_bar|weight_u|weight_v|bias`` with spectral norm: mpgan/model.py:55-68)."""
 
     def __init__(self, layers: list, input_size: int = 0, output_size: int = 0, final_linear: bool = False,
                  leaky_relu_alpha: float = 0.2, dropout_p: float = 0, batch_norm: bool = False,
                  spectral_norm: bool = False):
         super().__init__()
-        _unsupported(batch_norm=batch_norm, spectral_norm=spectral_norm)
         widths = ([input_size] if input_size else []) + list(layers) + ([output_size] if output_size else [])
         self.final_linear = final_linear
         self.leaky_relu_alpha = leaky_relu_alpha
         self.dropout_p = float(dropout_p)
+        self.batch_norm, self.spectral_norm = bool(batch_norm), bool(spectral_norm)
         self.net = nn.ModuleList(nn.Linear(i, o) for i, o in zip(widths[:-1], widths[1:]))
+        if self.batch_norm:   # (one per layer, the last one unused when final_linear: as the reference registers them)
+            self.bn = nn.ModuleList(nn.BatchNorm1d(o) for o in widths[1:])
+        if self.spectral_norm:
+            for i in range(len(self.net)):
+                if i != len(self.net) - 1 or not final_linear:
+                    self.net[i] = SpectralNorm(self.net[i])
+
+    @property
+    def plain(self) -> bool:
+        """Neither normalisation: the form the fused kernels (and the grouped weight-gradient launches) take."""
+        return not (self.batch_norm or self.spectral_norm)
+
+    def _bn(self, i: int, x: Tensor) -> Tensor:
+        bn = self.bn[i]
+        if not (self.training or not bn.track_running_stats):
+            return ops.batchnorm_eval(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        y, mean, var = ops.BatchNormFn.apply(x, bn.weight, bn.bias, bn.eps)
+        if bn.track_running_stats:   # running statistics as nn.BatchNorm1d keeps them (unbiased variance, momentum 0.1)
+            with torch.no_grad():
+                M = x.shape[0]
+                bn.num_batches_tracked += 1
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(var, alpha=mom * M / max(M - 1, 1))
+        return y
 
     def forward(self, x: Tensor, resid: Tensor = None) -> Tensor:
         """``resid`` (not in the reference signature): added to the output, inside the last layer's launch when that
@@ -51,8 +112,13 @@ class LinearNet(nn.Module):
         for k, lin in enumerate(self.net):
             act = not (self.final_linear and k == last)
             fuse = resid if (k == last and not act) else None
-            x = ops.FusedLinearFn.apply(x, lin.weight, lin.bias, act, self.leaky_relu_alpha, self.dropout_p,
-                                        self.training, fuse)
+            W = lin.weight() if isinstance(lin, SpectralNorm) else lin.weight
+            if self.batch_norm and act:   # the norm sits between the activation and the dropout (:78-83)
+                x = ops.FusedLinearFn.apply(x, W, lin.bias, True, self.leaky_relu_alpha, 0.0, self.training, None)
+                x = self._bn(k, x.reshape(-1, x.shape[-1])).reshape(x.shape)
+                x = ops.FusedDropoutFn.apply(x, self.dropout_p, self.training)
+            else:
+                x = ops.FusedLinearFn.apply(x, W, lin.bias, act, self.leaky_relu_alpha, self.dropout_p, self.training, fuse)
             if k == last and resid is not None and fuse is None:
                 x = x + resid
         return x
@@ -95,7 +161,8 @@ class MPLayer(nn.Module):
         self.num_ef = num_ef
         extra = self.clabels + int(self.mask_fne_np)
         self.fused = (list(self.fe_layers) == [ops.H1, ops.H2, ops.H3] and len(self.fn_layers) == 2
-                      and num_ef == 0 and extra == 0)
+                      and num_ef == 0 and extra == 0
+                      and not (linear_args.get("batch_norm") or linear_args.get("spectral_norm")))
         self.fe = LinearNet(self.fe_layers, input_size=2 * input_node_size + num_ef + extra, final_linear=False, **linear_args)
         self.fn = LinearNet(self.fn_layers, input_size=self.fe_layers[-1] + input_node_size + extra,
                             output_size=output_node_size, final_linear=True, **linear_args)
@@ -348,7 +415,8 @@ class MPDiscriminator(MPNet):
     def fused_head(self):
         """(weight [1, F], bias, mean-pooling?, sigmoid?, dropout p) when pooling + ``fnd_layer`` + final activation are
         the single-launch head of ``ops.DiscHeadFn`` (``dea`` with an empty ``fnd`` list: the reference default), else None."""
-        if not self.dea or self.mask_fnd_np or len(self.fnd_layer.net) != 1 or self.final_activation not in ("", "sigmoid"):
+        if (not self.dea or self.mask_fnd_np or len(self.fnd_layer.net) != 1 or not self.fnd_layer.plain
+                or self.final_activation not in ("", "sigmoid")):
             return None
         lin = self.fnd_layer.net[0]
         return lin.weight, lin.bias, not self.dea_sum, self.final_activation == "sigmoid", self.fnd_layer.dropout_p

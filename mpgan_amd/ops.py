@@ -1115,6 +1115,61 @@ def disc_head_loss(y, mask, w, b, *, mean, sigmoid, p_drop, training, loss, n_re
     return out, dy
 
 
+class BatchNormFn(torch.autograd.Function):
+    """nn.BatchNorm1d in training mode over the rows of x [M, F] (LinearNet's optional normalisation, mpgan/model.py:58-60,
+    :80-81) on ``mpg_batchnorm_*``; returns (y, batch mean, biased batch variance) -- the caller keeps the running
+    statistics (``LinearNet._bn``)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        _chk(x, "x")
+        x2 = x.contiguous()
+        M, F = x2.shape
+        nchunk = max(1, min(256, M // 64))
+        part = torch.empty((nchunk, F), device=x.device, dtype=torch.float32)
+        mean, var = (torch.empty(F, device=x.device, dtype=torch.float32) for _ in range(2))
+        check(_lib.lib().mpg_batchnorm_stats(_p(x2), x2.stride(0), M, F, _p(part), nchunk, _p(mean), _p(var), _stream()),
+              "mpg_batchnorm_stats")
+        y = torch.empty_like(x2)
+        check(_lib.lib().mpg_batchnorm_apply(_p(x2), x2.stride(0), _p(mean), _p(var), _p(w), _p(b), eps, _p(y), y.stride(0), M, F,
+                                             _stream()), "mpg_batchnorm_apply")
+        ctx.save_for_backward(x2, w, mean, var)
+        ctx.eps, ctx.params = eps, (w, b)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, _gm, _gv):
+        x2, w, mean, var = ctx.saved_tensors
+        M, F = x2.shape
+        g2 = g.contiguous()
+        nchunk = max(1, min(256, M // 64))
+        part = torch.empty((2 * nchunk, F), device=g.device, dtype=torch.float32)
+        sums = torch.empty(2 * F, device=g.device, dtype=torch.float32)
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        wp, bp = ctx.params
+        st = dev_state(g.device)
+        gw = _grad_target(wp) if st.grad_into_param else None
+        gb = _grad_target(bp) if st.grad_into_param else None
+        direct = gw is not None and gb is not None
+        dw = gw if direct else torch.empty(F, device=g.device, dtype=torch.float32)
+        db = gb if direct else torch.empty(F, device=g.device, dtype=torch.float32)
+        check(_lib.lib().mpg_batchnorm_bwd(_p(g2), g2.stride(0), _p(x2), x2.stride(0), _p(mean), _p(var), _p(w), ctx.eps, _p(part), nchunk,
+                                           _p(sums), _p(dx), F, _p(dw), _p(db), int(direct), M, F, _stream()), "mpg_batchnorm_bwd")
+        return dx, (None if direct else dw), (None if direct else db), None
+
+
+def batchnorm_eval(x, w, b, mean, var, eps):
+    """BatchNorm1d with given (running) statistics: one elementwise launch, no gradient bookkeeping of its own."""
+    x2 = x.contiguous()
+    M, F = x2.shape
+    y = torch.empty_like(x2)
+    check(_lib.lib().mpg_batchnorm_apply(_p(x2), x2.stride(0), _p(mean), _p(var), _p(w), _p(b), eps, _p(y), y.stride(0), M, F, _stream()),
+          "mpg_batchnorm_apply")
+    return y
+
+
 class LayerNormFn(torch.autograd.Function):
     """nn.LayerNorm over the last dimension (GAPT's MAB.norm1 / norm2, gapt/model.py:118-120, :131-136): one launch
     forward, one launch + a fixed-order reduction of the weight / bias gradients backward."""

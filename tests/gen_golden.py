@@ -187,6 +187,35 @@ def main():
     np.savez_compressed(os.path.join(OUT, "mpdisc_opt_f64.npz"), **rec)
     print("mpdisc options", float(yD.abs().max()))
 
+    # ------------------------------------------------------------------ 1e. LinearNet with batch norm and spectral norm
+    dt = torch.float64
+    ln = rmp.LinearNet([24, 16], input_size=12, output_size=5, final_linear=True, batch_norm=True, spectral_norm=True,
+                       dropout_p=0.0).to(dt)
+    lshapes = {k: tuple(v.shape) for k, v in ln.state_dict().items() if "running" not in k and "num_batches" not in k}
+    sd_ln = ln.state_dict()
+    sd_ln.update(init_state_dict(lshapes, seed=75, dtype=dt))   # running statistics keep their defaults (0, 1, 0)
+    ln.load_state_dict(sd_ln)
+    ln.train()
+    x1, x2 = seeded((40, 12), 175).to(dt), seeded((40, 12), 176).to(dt).requires_grad_(True)
+    g1, g2 = seeded((40, 5), 375).to(dt), seeded((40, 5), 376).to(dt)
+    y1 = ln(x1)
+    (y1 * g1).sum().backward()
+    ln.zero_grad()
+    y2 = ln(x2)
+    (y2 * g2).sum().backward()
+    rec = dict(x1=x1.numpy(), x2=x2.detach().numpy(), g1=g1.numpy(), g2=g2.numpy(), y1=y1.detach().numpy(), y2=y2.detach().numpy(),
+               dx2=x2.grad.numpy(), seed=75)
+    for k, p in ln.named_parameters():
+        if p.grad is not None:
+            rec["grad__" + k] = p.grad.numpy()
+    ln.eval()
+    rec["y3"] = ln(x2.detach()).detach().numpy()
+    for k, v in ln.state_dict().items():
+        if "running" in k or "num_batches" in k or k.endswith(("weight_u", "weight_v")):
+            rec["state__" + k] = v.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "linearnet_bn_sn_f64.npz"), **rec)
+    print("linearnet bn+sn", float(y2.abs().max()))
+
     # ------------------------------------------------------------------ default args / manifests
     sys.argv = ["gen_golden"]
     args = st.process_args(st.parse_args())

@@ -98,8 +98,9 @@ def test_unsupported_options_raise():
     from mpgan_amd.gapt import MAB
     with pytest.raises(NotImplementedError):   # an input column the reference's own forward never fills
         MPLayer(32, [96, 160, 192], [256, 256], 32, int_diffs=True)
-    with pytest.raises(NotImplementedError):
-        LinearNet([8, 8], batch_norm=True)
+    bn_sn = LinearNet([8, 8], input_size=4, batch_norm=True, spectral_norm=True)   # both normalisations exist (un-fused)
+    assert not bn_sn.plain and "bn.0.running_mean" in bn_sn.state_dict() and "net.0.module.weight_bar" in bn_sn.state_dict()
+    assert not MPLayer(32, [96, 160, 192], [256, 256], 32, batch_norm=True).fused
     # the default configuration (and its k-NN form) is on the fused kernels ...
     assert MPLayer(32, [96, 160, 192], [256, 256], 32).fused
     assert MPLayer(32, [96, 160, 192], [256, 256], 32, fully_connected=False, num_knn=10).fused

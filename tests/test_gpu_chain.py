@@ -183,3 +183,36 @@ def test_packed_images_follow_parameter_updates():
     layer.refresh_packed()                         # ... needs the explicit refresh
     fresh.load_state_dict(layer.state_dict())
     assert torch.equal(fresh(x), layer(x))
+
+
+def test_linearnet_batch_norm_spectral_norm_vs_reference_golden():
+    """LinearNet with both normalisations (mpgan/model.py:55-83, spectral_normalization.py): two training forwards (the power
+    iteration and the running statistics move), gradients of the second, then an eval forward -- against the reference's own."""
+    from conftest import load_golden
+    from oracle import train_ref as T
+    from mpgan_amd.mpgan import LinearNet
+    g = load_golden("linearnet_bn_sn_f64.npz")
+    net = LinearNet([24, 16], input_size=12, output_size=5, final_linear=True, batch_norm=True, spectral_norm=True, dropout_p=0.0).cuda()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items() if "running" not in k and "num_batches" not in k}
+    sd = net.state_dict()
+    sd.update({k: v.cuda() for k, v in T.init_state_dict(shapes, seed=int(g["seed"]), dtype=torch.float32).items()})
+    net.load_state_dict(sd)
+    net.train()
+    dev = lambda a: torch.from_numpy(a).float().cuda()
+    y1 = net(dev(g["x1"]))
+    (y1 * dev(g["g1"])).sum().backward()
+    net.zero_grad()
+    x2 = dev(g["x2"]).requires_grad_(True)
+    y2 = net(x2)
+    (y2 * dev(g["g2"])).sum().backward()
+    assert rel_err(y1.detach().cpu().numpy(), g["y1"]) < TIGHT
+    assert rel_err(y2.detach().cpu().numpy(), g["y2"]) < TIGHT
+    assert rel_err(x2.grad.cpu().numpy(), g["dx2"]) < TIGHT
+    for k, p in net.named_parameters():
+        if "grad__" + k in g:
+            assert rel_err(p.grad.cpu().numpy(), g["grad__" + k]) < TIGHT, k
+    net.eval()
+    assert rel_err(net(x2.detach()).detach().cpu().numpy(), g["y3"]) < TIGHT
+    for k, v in net.state_dict().items():
+        if "state__" + k in g:
+            assert rel_err(v.double().cpu().numpy(), g["state__" + k]) < TIGHT, k
