@@ -261,7 +261,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                     print(" ".join(job[1]))
                 subprocess.run(job[1], check=True, env=env)
                 return job[0]
-            with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            with ThreadPoolExecutor(max_workers=max(1, min(os.cpu_count() or 4, 8, len(jobs)))) as ex:
                 objs = list(ex.map(run, jobs))
             tmplib = os.path.join(tmpdir, "libmpgan_amd.so")
             subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmplib] + objs, check=True, env=env)
