@@ -1,572 +1,9 @@
-// Backward of the fused edge network, data-gradient path (see edge.hip for the forward and the chain layout).
-//
-//   dZ3 = m_j * dagg_i * keep3 * phi'(Z3)      phi'(Z3) from the forward's saved sign words
-//   dE2 = W3'^T dZ3 ;  dZ2 = dE2 * keep2 * phi'(Z2)     (Z2 recomputed: one 90-MFMA layer)
-//   dE1 = W2'^T dZ2 ;  dZ1 = dE1 * keep1 * phi'(Z1) ;  da_i = sum_j dZ1 ;  dc_j = sum_i dZ1
-//
-// A workgroup owns one (jet, 32 receivers, sender chunk); its four waves split the chunk's UNMASKED senders and are
-// independent of each other between the prologue and the final reduction of da.  What bounds this kernel is operand
-// delivery, not the matrix pipe: every MFMA needs a 1 KiB weight fragment, and a CU moves 64 B/clk from L1/L2 and
-// 128 B/clk from LDS.  So a wave walks its senders in PAIRS: each weight fragment (W3^T from LDS, W2 and W2^T
-// streamed from L2) feeds the MFMAs of two senders, halving the fragment traffic per edge, and the pair's operands
-// are built just in time:
-//   phase A  Z2 = W2 E1 + b2     tile by tile (5 tiles x 6 k-steps); the epilogue of a tile (LeakyReLU, dropout,
-//                                sign bits for the later gate, E2 staged for the weight-gradient kernel) sits behind the
-//                                MFMAs of the next one
-//   phase B  dE2 = W3'^T dZ3     k-outer (12 k-steps x 5 tiles): the dZ3 fragment of k-step k+1 is built behind the
-//                                MFMAs of k-step k, so dZ3 never exists as a whole (96 registers per sender saved)
-//   phase C  dE1 = W2'^T dZ2     k-outer (10 k-steps x 3 tiles): dZ2 = gate * dE2 built (and staged) the same way
-//                                from phase B's accumulators
-// Arithmetic and accumulation order per output element are those of the forward's mfma3 (lo*hi, hi*lo, hi*hi per
-// k-step, k ascending).
-#include "edge_common.h"
+// mpg_edge_bwd: the entry point and the fp16-recompute variants of the data-gradient kernel (edge_bwd2_impl.h holds the
+// kernel; the bf16-recompute variants -- OPTIONS["fwd_f16"] = False -- are edge_bwd2_bf16.hip, so that the two halves of
+// this slow-to-compile template build side by side).
+#include "edge_bwd2_impl.h"
 
-#ifndef MPG_B2EXP
-#define MPG_B2EXP 0  // experiment bits (tools/ubench/bwd2_bench.hip): 1 streamed fragments all from k-step 0 (L1 hits), 2 no staging stores
-#endif
-
-#ifdef MPG_B2STAMP  // diagnostic build: s_memtime at the phase boundaries of the first pair of every wave of the first 64 workgroups
-__device__ unsigned long long g_b2_stamps[64 * 4 * 8];
-#define B2_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); b2_st[i] = pq == w ? t_ : b2_st[i]; } while (0)
-#else
-#define B2_STAMP(i) do {} while (0)
-#endif
-
-namespace {
-
-// LDS plan (all of the 160 KiB): W3^T hi|lo (bf16) | dagg tile of the 32 receivers | a tile | b2 | per-wave rows of
-// c for the two senders in flight | list of the chunk's unmasked senders.  W2 and W2^T stream from L2.
-constexpr int B2_W_BYTES = 2 * NF3T * 1024;      // 122,880
-constexpr int B2_DG_BYTES = T3 * 4 * 64 * 16;    //  24,576
-constexpr int B2_A_BYTES = T1 * 4 * 64 * 16;     //  12,288
-constexpr int B2_B2_BYTES = H2 * 4;              //     640
-constexpr int B2_C_BYTES = 4 * 2 * H1 * 4;       //   3,072
-constexpr int B2_LIST_MAX = 188;                 // senders per chunk (uint16 entries + count: 384 B)
-constexpr int B2_LDS_BYTES = B2_W_BYTES + B2_DG_BYTES + B2_A_BYTES + B2_B2_BYTES + B2_C_BYTES + 384;
-static_assert(B2_LDS_BYTES <= 163840, "LDS plan exceeds 160 KiB");
-
-typedef unsigned int b2_u32x4 __attribute__((ext_vector_type(4)));
-
-// hi/lo split of a PAIR of floats into word `wi` (elements 2 wi, 2 wi + 1) of two bf16x8 fragments, cut in two
-// halves so that they can sit in different issue slots.
-struct PairBf {
-    uint32_t hp;
-    float r0;
-    MPG_DEV void first(float v0, float v1) {
-        hp = cvt_pk_bf16(v0, v1);
-        r0 = v0 - __builtin_bit_cast(float, hp << 16);
-    }
-    MPG_DEV void second(float v1, b2_u32x4& hi, b2_u32x4& lo, int wi) {
-        const float r1 = v1 - __builtin_bit_cast(float, hp & 0xffff0000u);
-        hi[wi] = hp;
-        lo[wi] = cvt_pk_bf16(r0, r1);
-    }
-};
-
-// if_set / if_clear chosen by bit BIT of `word`: v_bfe_i32 + v_bfi_b32 (left to itself the compiler builds a compare,
-// two wait states for VCC and a v_cndmask per element)
-template <int BIT>
-MPG_DEV float sel_by_bit(uint32_t word, float if_set, float if_clear) {
-    int m;
-    float r;
-    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(word), "n"(BIT));
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(if_set), "v"(if_clear));
-    return r;
-}
-
-// units u of [0, NU) that fall into slot SL of NS
-template <int NU, int NS, int SL, typename F>
-MPG_DEV void run_slot(F&& unit) {
-    constexpr int u0 = (SL * NU) / NS, u1 = ((SL + 1) * NU) / NS;
-    static_for<u0, u1>(unit);
-}
-
-template <bool F16, typename V>
-MPG_DEV f32x16 mma(const V a, const V b, const f32x16 c) {
-    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-template <int DROP, bool F16, bool NEEDW>  // DROP: 0 off, 1 byte mode, 2 bit mode (see common.h)
-__global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
-    typedef typename FragT<F16>::type V;  // forward-recomputation operands; gradient operands are bf16
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int RB = (p.N + 31) / 32;
-    int bid = blockIdx.x;
-    const int sc = bid % p.SC; bid /= p.SC;
-    const int rb = bid % RB;
-    const int b = bid / RB;
-    const int i = rb * 32 + r;
-    const int JC = (p.N + p.SC - 1) / p.SC;
-    const int jbeg = sc * JC, jend = min(p.N, jbeg + JC);
-    const int ldac = p.ld_ac ? p.ld_ac : H1;
-
-    const __amdgpu_buffer_rsrc_t r2 = img_rsrc(p.W2img, 2 * NF2);     // W2 hi | lo (forward image)
-    const __amdgpu_buffer_rsrc_t r2t = img_rsrc(p.W2Timg, 2 * NF2T);  // W2^T hi | lo (bf16)
-    const int lane16 = lane * 16;
-    const bf16x8* t3g = reinterpret_cast<const bf16x8*>(p.W3Timg);
-    bf16x8* l3t = reinterpret_cast<bf16x8*>(smem);
-    float4* ldg = reinterpret_cast<float4*>(smem + B2_W_BYTES);                // [(m*4+g)][lane]
-    float4* la = reinterpret_cast<float4*>(smem + B2_W_BYTES + B2_DG_BYTES);   // [(q*2+s)*2+u][lane]
-    float* lb2 = reinterpret_cast<float*>(smem + B2_W_BYTES + B2_DG_BYTES + B2_A_BYTES);
-    float* lcw = lb2 + H2 + w * (2 * H1);                                      // this wave's two rows of c
-    unsigned short* lst = reinterpret_cast<unsigned short*>(smem + B2_W_BYTES + B2_DG_BYTES + B2_A_BYTES + B2_B2_BYTES + B2_C_BYTES);
-    int* lnv = reinterpret_cast<int*>(lst + B2_LIST_MAX);
-
-    // ---- prologue (whole workgroup): weights and the per-receiver tiles into LDS, the list of unmasked senders
-    copy_to_lds(l3t, t3g, 2 * NF3T * 64, tid);
-    for (int t = tid; t < H2; t += 256) lb2[t] = p.b2[t] * SC_E2;  // (the recomputed layer 2 runs in the forward's operand scales)
-    // upstream gradient dagg (scaled) and the layer-1 receiver term a, both in the register order the chain layout
-    // wants (zeros for padding lanes: they carry exact zeros all the way down)
-    for (int t = tid; t < T3 * 4 * 64; t += 256) {
-        const int ln = t & 63, mg = t >> 6, rr = ln & 31, hh = ln >> 5, ii = rb * 32 + rr;
-        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ii < p.N) {
-            const float* di = p.dagg + (size_t)(b * p.N + ii) * p.ld_dagg + 32 * (mg >> 2) + 8 * (mg & 3) + 4 * hh;
-            v4 = make_float4(di[0] * p.agg_scale, di[1] * p.agg_scale, di[2] * p.agg_scale, di[3] * p.agg_scale);
-        }
-        ldg[t] = v4;
-    }
-    for (int t = tid; t < T1 * 4 * 64; t += 256) {
-        const int ln = t & 63, qsu = t >> 6, rr = ln & 31, hh = ln >> 5, ii = rb * 32 + rr;
-        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ii < p.N) v4 = ld4(p.a + (size_t)(b * p.N + ii) * ldac + 8 * qsu + 4 * hh);
-        la[t] = make_float4(v4.x * SC_A, v4.y * SC_A, v4.z * SC_A, v4.w * SC_A);
-    }
-    if (w == 0) {  // unmasked senders of the chunk, in order (the chunk holds at most B2_LIST_MAX senders)
-        int cnt = 0;
-        for (int j0 = jbeg; j0 < jend; j0 += 64) {
-            const int j = j0 + lane;
-            const bool ok = j < jend && (p.mask == nullptr || p.mask[b * p.N + j] != 0.f);
-            const unsigned long long bits = __ballot(ok);
-            if (ok) lst[cnt + __popcll(bits & ((1ull << lane) - 1ull))] = (unsigned short)j;
-            cnt += __popcll(bits);
-        }
-        if (lane == 0) *lnv = cnt;
-    }
-    // masked senders: every gradient through their edges is exactly zero (mpg_edge_dw skips those blocks too)
-    if (p.mask != nullptr)
-        for (int t = tid; t < (jend - jbeg) * (H1 / 4); t += 256) {
-            const int j = jbeg + t / (H1 / 4);
-            if (p.mask[b * p.N + j] == 0.f)
-                reinterpret_cast<float4*>(p.dc + ((size_t)rb * p.B * p.N + (size_t)(b * p.N + j)) * H1)[t % (H1 / 4)] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    __syncthreads();
-    const int nvalid = __builtin_amdgcn_readfirstlane(*lnv);
-
-    uint32_t seed_lo = 0, seed_hi = 0;
-    if (DROP) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
-
-    const uint32_t lb3t = lds_base(smem, lane16);                 // W3^T hi fragments; lo at + NF3T KiB
-    const uint32_t lbdg = lds_base(smem, B2_W_BYTES + lane16);    // dagg tile
-    const uint32_t lbla = lds_base(smem, B2_W_BYTES + B2_DG_BYTES + lane16);  // a tile
-    const uint32_t lbc = lds_base(smem, B2_W_BYTES + B2_DG_BYTES + B2_A_BYTES + B2_B2_BYTES + w * (2 * H1 * 4) + 16 * h);  // this wave's rows of c
-    // staging: block blk = (b*RB + rb)*N + j ; plane part (0 hi, 1 lo) ; the 10 B-operand fragments (tile, k-step) of
-    // the 160-feature tensor exactly as the lanes hold them: one coalesced 16-byte store per lane and fragment.
-    // Buffer stores: a block offset beyond the buffer (the idle second half of an odd pair) is dropped by the hardware.
-    const int nblk = p.B * RB * p.N;
-    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(p.stageE2, 0, NEEDW ? nblk * (2 * NFR2 * 1024) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(p.stageZ2, 0, NEEDW ? nblk * (2 * NFR2 * 1024) : 0, 0x00020000);
-
-    uint32_t opaque_zero;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
-    float valpha = p.alpha, vone = 1.f;   // the two slopes in vector registers (operands of v_bfi)
-    asm volatile("" : "+v"(valpha), "+v"(vone));
-    float dacc[T1][16];
-#pragma unroll
-    for (int q = 0; q < T1; ++q)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) dacc[q][k] = 0.f;
-
-#ifdef MPG_B2STAMP
-    unsigned long long b2_st[7] = {0, 0, 0, 0, 0, 0, 0};
-#endif
-    for (int pq = w; 2 * pq < nvalid; pq += 4) {
-        const bool has2 = 2 * pq + 1 < nvalid;
-        B2_STAMP(0);
-        int jj[2];
-        jj[0] = __builtin_amdgcn_readfirstlane((int)lst[2 * pq]);
-        jj[1] = has2 ? __builtin_amdgcn_readfirstlane((int)lst[2 * pq + 1]) : jj[0];
-        float cpos[2], cneg[2];     // slope of layer 3 times m_j * dscale: one select between two uniform constants
-        // erow2 == erow, in a form the optimiser cannot prove equal: every dropout word is needed twice per pair, phases
-        // apart (forward recomputation, then the gate of the matching gradient), and with one visible value it keeps
-        // all the one-instruction keep-masks of the first use alive for the second (hundreds of registers, spilled)
-        uint32_t erow[2], erow2[2];
-        int stoff[2];               // byte offset of the sender's staging block (out of range for an idle half)
-        uint32_t sw[2][T3 / 2];     // this lane's 96 sign bits of Z3 per sender
-#pragma unroll
-        for (int sd = 0; sd < 2; ++sd) {
-            const float mj = p.mask ? p.mask[b * p.N + jj[sd]] : 1.f;
-            const float mjs = (sd == 0 || has2) ? mj * p.dscale : 0.f;
-            float in_set = 1.f;
-            if (p.nbr != nullptr) {  // k-nearest-neighbour graph: the edge (i, j) exists only if j's bit is set in i's row
-                const unsigned int wb = p.nbr[(size_t)(b * p.N + (i < p.N ? i : 0)) * ((p.N + 31) >> 5) + (jj[sd] >> 5)];
-                in_set = ((wb >> (jj[sd] & 31)) & 1u) ? 1.f : 0.f;
-            }
-            cpos[sd] = mjs * in_set; cneg[sd] = mjs * p.alpha * in_set;
-            erow[sd] = (uint32_t)((b * p.N + i) * p.N + jj[sd]);
-            erow2[sd] = erow[sd] + opaque_zero;
-            const int blk = (b * RB + rb) * p.N + jj[sd];
-            stoff[sd] = (sd == 0 || has2) ? blk * (2 * NFR2 * 1024) + lane16 : (int)0x7ffffff0;
-#pragma unroll
-            for (int q = 0; q < T3 / 2; ++q) sw[sd][q] = p.sign3[(size_t)blk * (T3 * 32) + q * 64 + lane];
-            // the sender's row of c into this wave's LDS slot (96 floats: lanes 0..63, then lanes 0..31)
-            const float* cj = p.c + (size_t)(b * p.N + jj[sd]) * ldac;
-            lcw[sd * H1 + lane] = cj[lane] * SC_A;
-            if (lane < H1 - 64) lcw[sd * H1 + 64 + lane] = cj[64 + lane] * SC_A;
-        }
-
-        // ---- phase A: Z2 = W2' E1 + b2, k-outer (6 k-steps x 5 tiles).  The fragment of e1 = drop(lrelu(a_i + c_j))
-        //      for k-step k+1 is built behind the MFMAs of k-step k (the signs of a_i + c_j are kept for dZ1's gate);
-        //      W2 hi+lo stream from L2 one k-step ahead.  E2 itself is only needed by the weight-gradient kernel
-        //      (staged) and, as signs, by dZ2's gate.
-        uint32_t neg1[2][2] = {{0u, 0u}, {0u, 0u}};            // sign bits of Z1: tiles 0,1 | 2 (16 bits)
-        uint32_t neg2[2][3] = {{0u, 0u, 0u}, {0u, 0u, 0u}};   // sign bits of Z2: tiles 0,1 | 2,3 | 4 (16 bits)
-        uint32_t wd2[2][T2];                                   // bit-mode dropout words of the five tiles
-        {
-            constexpr int KS = T1 * 2;
-            f32x16 acc[T2][2];       // [tile][sender]
-            V eh[2][2], el[2][2];    // [buffer][sender] e1 fragment (hi, lo) of a k-step
-            V wh[2][T2], wl[2][T2];  // [buffer][tile] W2 fragments of a k-step
-            float v1[2][8];
-            PairSplit<V> ps1[2][4];
-            f32x4 a4[2], c4[2][2];   // receiver terms (shared by the two senders) and sender terms of the k-step being built
-            auto load_w = [&](auto kc) {
-                MPG_CI(k, kc);
-#pragma unroll
-                for (int m = 0; m < T2; ++m) {
-                    wh[k & 1][m] = img_frag<V>(r2, lane16, m * KS + ((MPG_B2EXP & 1) ? 0 : k));
-                    wl[k & 1][m] = img_frag<V>(r2, lane16, NF2 + m * KS + ((MPG_B2EXP & 1) ? 0 : k));
-                }
-            };
-            // build units of the e1 fragment of k-step k = (q, s): per sender 8 element units + 4 pairs x 2 halves = 16;
-            // unit 32 of the pair: the receiver terms a (shared by the two senders) are read first
-            auto load_a = [&](auto kc) {
-                MPG_CI(k, kc);
-                a4[0] = lds_frag<f32x4>(lbla, (k * 2 + 0) * 1024);
-                a4[1] = lds_frag<f32x4>(lbla, (k * 2 + 1) * 1024);
-#pragma unroll
-                for (int sd = 0; sd < 2; ++sd)
-#pragma unroll
-                    for (int uh = 0; uh < 2; ++uh) c4[sd][uh] = lds_frag<f32x4>(lbc, (sd * H1 + 16 * k + 8 * uh) * 4);
-            };
-            auto buildA = [&](auto kc, auto uc) {
-                MPG_CI(k, kc); MPG_CI(uu, uc);
-                constexpr int sd = uu / 16, u = uu % 16;
-                constexpr int q = k >> 1, s = k & 1;
-                if constexpr (u < 8) {
-                    constexpr int uh = u >> 2, t = u & 3;  // element 4 uh + t  <->  feature 32q + 16s + 8uh + 4h + t
-                    const float cc = c4[sd][uh][t] + a4[uh][t];
-                    neg1[sd][q >> 1] = __builtin_amdgcn_alignbit(neg1[sd][q >> 1], __builtin_bit_cast(uint32_t, cc), 31);
-                    const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow[sd], q, 4 * s + 2 * uh + h, h);
-                    v1[sd][u] = drop_apply<DROP>(lrelu(cc, p.alpha), wd, 16 * s + 8 * uh + t, t, p.thr);
-                } else {
-                    constexpr int pr = (u - 8) >> 1;
-                    if constexpr (((u - 8) & 1) == 0) ps1[sd][pr].first(v1[sd][2 * pr], v1[sd][2 * pr + 1]);
-                    else ps1[sd][pr].second(v1[sd][2 * pr + 1], eh[k & 1][sd], el[k & 1][sd], 2 * pr);
-                }
-            };
-            load_w(std::integral_constant<int, 0>{});
-            load_a(std::integral_constant<int, 0>{});
-            static_for<0, 32>([&](auto uc) { buildA(std::integral_constant<int, 0>{}, uc); });
-            B2_STAMP(1);
-            // accumulators start as the bias column
-#pragma unroll
-            for (int m = 0; m < T2; ++m)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 b4 = ld4(lb2 + 32 * m + 8 * g + 4 * h);
-#pragma unroll
-                    for (int sd = 0; sd < 2; ++sd) {
-                        acc[m][sd][4 * g + 0] = b4.x; acc[m][sd][4 * g + 1] = b4.y;
-                        acc[m][sd][4 * g + 2] = b4.z; acc[m][sd][4 * g + 3] = b4.w;
-                    }
-                }
-            static_for<0, KS>([&](auto kc) {
-                MPG_CI(k, kc);
-                if constexpr (k + 1 < KS) {
-                    load_w(std::integral_constant<int, k + 1>{});
-                    load_a(std::integral_constant<int, k + 1>{});
-                }
-                const V bh0 = eh[k & 1][0], bl0 = el[k & 1][0], bh1 = eh[k & 1][1], bl1 = el[k & 1][1];
-                static_for<0, T2>([&](auto mc) {
-                    MPG_CI(m, mc);
-                    auto slot = [&](auto slc) {
-                        MPG_CI(SL, slc);
-                        if constexpr (k + 1 < KS && SL >= 2) run_slot<32, 28, SL - 2>([&](auto uc) { buildA(std::integral_constant<int, k + 1>{}, uc); });
-                        __builtin_amdgcn_sched_barrier(0);
-                    };
-                    const V a_h = wh[k & 1][m], a_l = wl[k & 1][m];
-                    acc[m][0] = mma<F16>(a_l, bh0, acc[m][0]); slot(std::integral_constant<int, 6 * m + 0>{});
-                    acc[m][1] = mma<F16>(a_l, bh1, acc[m][1]); slot(std::integral_constant<int, 6 * m + 1>{});
-                    acc[m][0] = mma<F16>(a_h, bl0, acc[m][0]); slot(std::integral_constant<int, 6 * m + 2>{});
-                    acc[m][1] = mma<F16>(a_h, bl1, acc[m][1]); slot(std::integral_constant<int, 6 * m + 3>{});
-                    acc[m][0] = mma<F16>(a_h, bh0, acc[m][0]); slot(std::integral_constant<int, 6 * m + 4>{});
-                    acc[m][1] = mma<F16>(a_h, bh1, acc[m][1]); slot(std::integral_constant<int, 6 * m + 5>{});
-                });
-            });
-            B2_STAMP(2);
-            // epilogue: LeakyReLU, dropout, the sign bits for dZ2's gate; E2 staged as fragments (hi, lo)
-            static_for<0, T2>([&](auto mc) {
-                MPG_CI(mm, mc);
-#pragma unroll
-                for (int sd = 0; sd < 2; ++sd) {
-                    float x2[16];
-                    if constexpr (DROP == 2) wd2[sd][mm] = drop_tile_word<2>(seed_lo, seed_hi, p.tag_base + TAG_E1, erow[sd], mm, 0, h);
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int g = u >> 2, t = u & 3;
-                        const float z = acc[mm][sd][u];
-                        neg2[sd][mm >> 1] = __builtin_amdgcn_alignbit(neg2[sd][mm >> 1], __builtin_bit_cast(uint32_t, z), 31);
-                        uint32_t wd;
-                        if constexpr (DROP == 2) wd = wd2[sd][mm];
-                        else wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E1, erow[sd], mm, 2 * g + h, h);
-                        x2[u] = drop_apply<DROP>(lrelu(z, p.alpha), wd, 8 * g + t, t, p.thr);
-                    }
-                    if constexpr (NEEDW && !(MPG_B2EXP & 2)) {
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            V e2h, e2l;
-                            split8(x2 + 8 * s, e2h, e2l);
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, e2h), rsE, stoff[sd], (mm * 2 + s) * 1024, 0);
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, e2l), rsE, stoff[sd], (NFR2 + mm * 2 + s) * 1024, 0);
-                        }
-                    }
-                }
-            });
-        }
-
-        B2_STAMP(3);
-        // ---- phase B: dE2 = W3'^T dZ3, k-outer.  dZ3 = dagg * slope(sign word) * keep3 is built one k-step ahead.
-        f32x16 accB[T2][2];
-        {
-            constexpr int KS = T3 * 2;  // 12 k-steps of 16 features of layer 3
-            b2_u32x4 zh[2][2], zl[2][2];  // [buffer][sender] dZ3 fragment (hi, lo) of a k-step
-            float v3[2][8];
-            PairBf pb[2][4];
-            f32x4 dg[2];                  // dagg of the k-step being built (shared by the two senders)
-            uint32_t wd3[2] = {0u, 0u};
-            bf16x8 ah[2][T2], al[2][T2];  // [buffer][tile] W3^T fragments of a k-step
-            auto load_w = [&](auto kc) {
-                MPG_CI(k, kc);
-#pragma unroll
-                for (int m = 0; m < T2; ++m) {
-                    ah[k & 1][m] = lds_frag<bf16x8>(lb3t, (m * KS + k) * 1024);
-                    al[k & 1][m] = lds_frag<bf16x8>(lb3t, (NF3T + m * KS + k) * 1024);
-                }
-            };
-            auto load_dg = [&](auto kc) {
-                MPG_CI(k, kc);
-                constexpr int m3 = k >> 1, s = k & 1;
-                dg[0] = lds_frag<f32x4>(lbdg, ((m3 * 4 + 2 * s) * 64) * 16);
-                dg[1] = lds_frag<f32x4>(lbdg, ((m3 * 4 + 2 * s + 1) * 64) * 16);
-            };
-            // build units of the dZ3 fragment of k-step k: per sender 8 element units + 4 pairs x 2 halves = 16
-            auto buildB = [&](auto kc, auto uc) {
-                MPG_CI(k, kc); MPG_CI(uu, uc);
-                constexpr int sd = uu / 16, u = uu % 16;
-                constexpr int m3 = k >> 1, s = k & 1;
-                if constexpr (u < 8) {
-                    constexpr int r16 = 8 * s + u, g = r16 >> 2, t = r16 & 3;
-                    if constexpr (DROP == 2) { if constexpr (u == 0 && s == 0) wd3[sd] = drop_tile_word<2>(seed_lo, seed_hi, p.tag_base + TAG_E2, erow[sd], m3, 0, h); }
-                    uint32_t wd = wd3[sd];
-                    if constexpr (DROP == 1) wd = drop_tile_word<1>(seed_lo, seed_hi, p.tag_base + TAG_E2, erow[sd], m3, 2 * g + h, h);
-                    const float dd = dg[u >> 2][t];
-                    // sign bit of this lane's Z3 register (tile m3, r16): see the forward's epi3
-                    const float sel = dd * sel_by_bit<31 - (16 * (m3 & 1) + r16)>(sw[sd][m3 >> 1], cneg[sd], cpos[sd]);
-                    v3[sd][u] = drop_apply<DROP>(sel, wd, 8 * g + t, t, p.thr);
-                } else {
-                    constexpr int pr = (u - 8) >> 1;
-                    if constexpr (((u - 8) & 1) == 0) pb[sd][pr].first(v3[sd][2 * pr], v3[sd][2 * pr + 1]);
-                    else pb[sd][pr].second(v3[sd][2 * pr + 1], zh[k & 1][sd], zl[k & 1][sd], pr);
-                }
-            };
-            load_w(std::integral_constant<int, 0>{});
-            load_dg(std::integral_constant<int, 0>{});
-            static_for<0, 32>([&](auto uc) { buildB(std::integral_constant<int, 0>{}, uc); });
-            static_for<0, KS>([&](auto kc) {
-                MPG_CI(k, kc);
-                if constexpr (k + 1 < KS) {
-                    load_dg(std::integral_constant<int, k + 1>{});  // (first: the build units behind the next MFMAs wait for it)
-                    load_w(std::integral_constant<int, k + 1>{});
-                }
-                const bf16x8 bh0 = __builtin_bit_cast(bf16x8, zh[k & 1][0]), bl0 = __builtin_bit_cast(bf16x8, zl[k & 1][0]);
-                const bf16x8 bh1 = __builtin_bit_cast(bf16x8, zh[k & 1][1]), bl1 = __builtin_bit_cast(bf16x8, zl[k & 1][1]);
-                static_for<0, T2>([&](auto mc) {
-                    MPG_CI(m, mc);
-                    auto slot = [&](auto slc) {
-                        MPG_CI(SL, slc);
-                        // the first slots leave the LDS reads of the next k-step time to land
-                        if constexpr (k + 1 < KS && SL >= 2) run_slot<32, 28, SL - 2>([&](auto uc) { buildB(std::integral_constant<int, k + 1>{}, uc); });
-                        __builtin_amdgcn_sched_barrier(0);
-                    };
-                    const bf16x8 a_h = ah[k & 1][m], a_l = al[k & 1][m];
-                    if constexpr (k == 0) {
-                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        accB[m][0] = mma<false>(a_l, bh0, z); slot(std::integral_constant<int, 6 * m + 0>{});
-                        accB[m][1] = mma<false>(a_l, bh1, z); slot(std::integral_constant<int, 6 * m + 1>{});
-                    } else {
-                        accB[m][0] = mma<false>(a_l, bh0, accB[m][0]); slot(std::integral_constant<int, 6 * m + 0>{});
-                        accB[m][1] = mma<false>(a_l, bh1, accB[m][1]); slot(std::integral_constant<int, 6 * m + 1>{});
-                    }
-                    accB[m][0] = mma<false>(a_h, bl0, accB[m][0]); slot(std::integral_constant<int, 6 * m + 2>{});
-                    accB[m][1] = mma<false>(a_h, bl1, accB[m][1]); slot(std::integral_constant<int, 6 * m + 3>{});
-                    accB[m][0] = mma<false>(a_h, bh0, accB[m][0]); slot(std::integral_constant<int, 6 * m + 4>{});
-                    accB[m][1] = mma<false>(a_h, bh1, accB[m][1]); slot(std::integral_constant<int, 6 * m + 5>{});
-                });
-            });
-        }
-
-        B2_STAMP(4);
-        // ---- phase C: dE1 = W2'^T dZ2, k-outer; dZ2 = dE2 * keep2 * phi'(Z2) is built (and staged) one k-step
-        //      ahead from phase B's accumulators.  W2^T streams from L2 two k-steps ahead.
-        f32x16 accC[T1][2];
-        {
-            constexpr int KS = T2 * 2;  // 10 k-steps of 16 features of layer 2
-            b2_u32x4 zh[2][2], zl[2][2];
-            float v2[2][8];
-            PairBf pb[2][4];
-            bf16x8 ah[3][T1], al[3][T1];  // ring of three k-steps of W2^T fragments (L2 is more than one k-step away)
-            uint32_t wd2c[2] = {0u, 0u};  // bit-mode dropout word of the layer-2 tile being gated (hashed again: see erow2)
-            auto load_w = [&](auto kc) {
-                MPG_CI(k, kc);
-#pragma unroll
-                for (int m = 0; m < T1; ++m) {
-                    ah[k % 3][m] = img_frag<bf16x8>(r2t, lane16, m * KS + ((MPG_B2EXP & 1) ? 0 : k));
-                    al[k % 3][m] = img_frag<bf16x8>(r2t, lane16, NF2T + m * KS + ((MPG_B2EXP & 1) ? 0 : k));
-                }
-            };
-            // build units of the dZ2 fragment of k-step k: per sender 8 element units + 4 pairs x 2 halves + 1 store = 17
-            auto buildC = [&](auto kc, auto uc) {
-                MPG_CI(k, kc); MPG_CI(uu, uc);
-                constexpr int sd = uu / 17, u = uu % 17;
-                constexpr int m2 = k >> 1, s = k & 1;
-                if constexpr (u < 8) {
-                    constexpr int r16 = 8 * s + u, g = r16 >> 2, t = r16 & 3;
-                    // sign of Z2 (register r16 of tile m2): pushed in (tile, register) order into word m2 >> 1, which
-                    // holds 32 bits (tiles 0..3) or 16 (tile 4)
-                    constexpr int nb = m2 < 4 ? 32 : 16;
-                    float gt = sel_by_bit<nb - 1 - (16 * (m2 & 1) + r16)>(neg2[sd][m2 >> 1], valpha, vone);
-                    if constexpr (DROP != 0) {
-                        uint32_t wd;
-                        if constexpr (DROP == 2) {
-                            if constexpr (u == 0 && s == 0) wd2c[sd] = drop_tile_word<2>(seed_lo, seed_hi, p.tag_base + TAG_E1, erow2[sd], m2, 0, h);
-                            wd = wd2c[sd];
-                        } else wd = drop_tile_word<1>(seed_lo, seed_hi, p.tag_base + TAG_E1, erow2[sd], m2, 2 * g + h, h);
-                        gt = drop_apply<DROP>(gt, wd, 8 * g + t, t, p.thr);
-                    }
-                    v2[sd][u] = accB[m2][sd][r16] * gt;
-                } else if constexpr (u < 16) {
-                    constexpr int pr = (u - 8) >> 1;
-                    if constexpr (((u - 8) & 1) == 0) pb[sd][pr].first(v2[sd][2 * pr], v2[sd][2 * pr + 1]);
-                    else pb[sd][pr].second(v2[sd][2 * pr + 1], zh[k & 1][sd], zl[k & 1][sd], pr);
-                } else {
-                    if constexpr (NEEDW && !(MPG_B2EXP & 2)) {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zh[k & 1][sd]), rsZ, stoff[sd], k * 1024, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zl[k & 1][sd]), rsZ, stoff[sd], (NFR2 + k) * 1024, 0);
-                    }
-                }
-            };
-            load_w(std::integral_constant<int, 0>{});
-            load_w(std::integral_constant<int, 1>{});
-            static_for<0, 34>([&](auto uc) { buildC(std::integral_constant<int, 0>{}, uc); });
-            static_for<0, KS>([&](auto kc) {
-                MPG_CI(k, kc);
-                if constexpr (k + 2 < KS) load_w(std::integral_constant<int, k + 2>{});
-                const bf16x8 bh0 = __builtin_bit_cast(bf16x8, zh[k & 1][0]), bl0 = __builtin_bit_cast(bf16x8, zl[k & 1][0]);
-                const bf16x8 bh1 = __builtin_bit_cast(bf16x8, zh[k & 1][1]), bl1 = __builtin_bit_cast(bf16x8, zl[k & 1][1]);
-                static_for<0, T1>([&](auto mc) {
-                    MPG_CI(m, mc);
-                    auto slot = [&](auto slc) {
-                        MPG_CI(SL, slc);
-                        if constexpr (k + 1 < KS) run_slot<34, 18, SL>([&](auto uc) { buildC(std::integral_constant<int, k + 1>{}, uc); });
-                        __builtin_amdgcn_sched_barrier(0);
-                    };
-                    const bf16x8 a_h = ah[k % 3][m], a_l = al[k % 3][m];
-                    if constexpr (k == 0) {
-                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        accC[m][0] = mma<false>(a_l, bh0, z); slot(std::integral_constant<int, 6 * m + 0>{});
-                        accC[m][1] = mma<false>(a_l, bh1, z); slot(std::integral_constant<int, 6 * m + 1>{});
-                    } else {
-                        accC[m][0] = mma<false>(a_l, bh0, accC[m][0]); slot(std::integral_constant<int, 6 * m + 0>{});
-                        accC[m][1] = mma<false>(a_l, bh1, accC[m][1]); slot(std::integral_constant<int, 6 * m + 1>{});
-                    }
-                    accC[m][0] = mma<false>(a_h, bl0, accC[m][0]); slot(std::integral_constant<int, 6 * m + 2>{});
-                    accC[m][1] = mma<false>(a_h, bl1, accC[m][1]); slot(std::integral_constant<int, 6 * m + 3>{});
-                    accC[m][0] = mma<false>(a_h, bh0, accC[m][0]); slot(std::integral_constant<int, 6 * m + 4>{});
-                    accC[m][1] = mma<false>(a_h, bh1, accC[m][1]); slot(std::integral_constant<int, 6 * m + 5>{});
-                });
-            });
-        }
-
-        B2_STAMP(5);
-        // ---- dZ1 = dE1 * keep1 * phi'(Z1) ; da_i += dZ1 ; dc_j = sum_i dZ1
-        {
-            // dc_j = sum over the 32 receivers (lanes of one half) of dZ1: 16 values per tile and lane.  Halving
-            // reduction: at each step a lane keeps half of its values and hands the other half to its partner
-            // (DPP), so 16 values cost 15 exchanges instead of 80 and lane l ends with the total of value l & 15
-            // (= accumulator register 8s + 4u + t  <->  feature 32 mm + 16 s + 8 u + 4 h + t).
-            const bool lb0 = lane & 1, lb1 = lane & 2, lbb2 = lane & 4, lb3 = lane & 8;
-            static_for<0, 2>([&](auto sdc) {
-                MPG_CI(sd, sdc);
-                float* dcj = p.dc + ((size_t)rb * p.B * p.N + (size_t)(b * p.N + jj[sd])) * H1;
-                static_for<0, T1>([&](auto mmc) {
-                    MPG_CI(mm, mmc);
-                    float ured[4];
-                    static_for<0, 4>([&](auto suc) {
-                        MPG_CI(su, suc);
-                        constexpr int s = su >> 1, u = su & 1;
-                        const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow2[sd], mm, 4 * s + 2 * u + h, h);
-                        float dz[4];
-                        static_for<0, 4>([&](auto tc) {
-                            MPG_CI(t, tc);
-                            // sign of a_i + c_j: pushed in (tile, element) order into word mm >> 1 (32 bits for tiles 0,1; 16 for tile 2)
-                            constexpr int nb = mm < 2 ? 32 : 16;
-                            float gt = sel_by_bit<nb - 1 - (16 * (mm & 1) + 8 * s + 4 * u + t)>(neg1[sd][mm >> 1], valpha, vone);
-                            gt = drop_apply<DROP>(gt, wd, 16 * s + 8 * u + t, t, p.thr);
-                            dz[t] = accC[mm][sd][8 * s + 4 * u + t] * gt;
-                            dacc[mm][8 * s + 4 * u + t] += dz[t];
-                        });
-                        const float w0 = halve_add<0xB1>(lb0, dz[0], dz[1]), w1 = halve_add<0xB1>(lb0, dz[2], dz[3]);
-                        ured[su] = halve_add<0x4E>(lb1, w0, w1);
-                    });
-                    const float x0 = halve_add<0x124>(lbb2, ured[0], ured[1]), x1 = halve_add<0x124>(lbb2, ured[2], ured[3]);
-                    float y = halve_add<0x128>(lb3, x0, x1);
-                    y += __shfl_xor(y, 16, 64);
-                    const int e = lane & 15;
-                    if (!(lane & 16) && (sd == 0 || has2)) dcj[32 * mm + 16 * (e >> 3) + 8 * ((e >> 2) & 1) + 4 * h + (e & 3)] = y;
-                });
-            });
-        }
-        B2_STAMP(6);
-    }
-
-#ifdef MPG_B2STAMP
-    if (blockIdx.x < 64 && lane == 0)
-        for (int q = 0; q < 7; ++q) g_b2_stamps[(blockIdx.x * 4 + w) * 8 + q] = b2_st[q];
-#endif
-    // ---- da: reduce over the four waves (disjoint sender subsets)
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int q = 0; q < T1; ++q)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) red[((w * T1 + q) * 16 + k) * 64 + lane] = dacc[q][k];
-    __syncthreads();
-    float* out = p.da + ((size_t)sc * p.B + b) * p.N * H1;
-    for (int e = tid; e < T1 * 16 * 64; e += 256) {
-        const int ln = e & 63, k = (e >> 6) & 15, q = e >> 10;
-        const float sum = red[e] + red[e + T1 * 1024] + red[e + 2 * T1 * 1024] + red[e + 3 * T1 * 1024];
-        const int ii = rb * 32 + (ln & 31);
-        const int f = 32 * q + 16 * (k >> 3) + 8 * ((k >> 2) & 1) + 4 * (ln >> 5) + (k & 3);
-        if (ii < p.N) out[(size_t)ii * H1 + f] = sum;
-    }
-}
-
-}  // namespace
+int mpg_edge_bwd_bf16(const MpgEdgeBwd* p, hipStream_t st);   // edge_bwd2_bf16.hip
 
 extern "C" int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream) {
     if (p->B <= 0 || p->N <= 0 || p->SC <= 0) return -1;
@@ -575,28 +12,10 @@ extern "C" int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream) {
     if ((p->N + p->SC - 1) / p->SC > B2_LIST_MAX) return -6;  // senders per chunk (the list of unmasked ones lives in LDS)
     const int RB = (p->N + 31) / 32;
     if ((long long)p->B * RB * p->N * (2 * NFR2 * 1024) > 0x7fffffffLL) return -7;  // staging offsets are 32-bit
-    dim3 grid(p->B * RB * p->SC), block(256);
     hipStream_t st = (hipStream_t)stream;
-    const bool needw = p->stageE2 != nullptr && p->stageZ2 != nullptr;
-    const int dm = p->thr == 0 ? 0 : (p->thr == 128 ? 2 : 1);
-#define MPG_BWD_ONE(D, H, W)                                                                                      \
-    do {                                                                                                          \
-        MPG_ENSURE_LDS((edge_bwd_kernel<D, H, W>), B2_LDS_BYTES);                                                 \
-        hipLaunchKernelGGL((edge_bwd_kernel<D, H, W>), grid, block, B2_LDS_BYTES, st, *p);                        \
-    } while (0)
-#define MPG_BWD_W(D, H)                                                                                           \
-    do { if (needw) MPG_BWD_ONE(D, H, true); else MPG_BWD_ONE(D, H, false); } while (0)
-#define MPG_BWD_H(D)                                                                                              \
-    do { if (p->f16) MPG_BWD_W(D, true); else MPG_BWD_W(D, false); } while (0)
 #ifdef MPG_SINGLE_VARIANT
-    MPG_BWD_W(MPG_SINGLE_VARIANT, true);
+    return b2_launch<true>(p, st);
 #else
-    if (dm == 0) MPG_BWD_H(0);
-    else if (dm == 1) MPG_BWD_H(1);
-    else MPG_BWD_H(2);
+    return p->f16 ? b2_launch<true>(p, st) : mpg_edge_bwd_bf16(p, st);
 #endif
-#undef MPG_BWD_H
-#undef MPG_BWD_W
-#undef MPG_BWD_ONE
-    return (int)hipGetLastError();
 }

@@ -1,0 +1,4 @@
+// The bf16-recompute variants of the data-gradient kernel (see edge_bwd2.hip).
+#include "edge_bwd2_impl.h"
+
+int mpg_edge_bwd_bf16(const MpgEdgeBwd* p, hipStream_t st) { return b2_launch<false>(p, st); }
