@@ -22,6 +22,13 @@
 #include "../../include/mpgan_amd.h"
 #include <stdlib.h>
 
+#ifdef MPG_MABSTAMP  // diagnostic build (tools/mab_stamps.py): s_memtime at the phase boundaries, the waves of workgroup 0
+__device__ unsigned long long g_mab_stamps[2 * 4 * 8];
+#define MAB_STAMP(i) do { mab_st[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MAB_STAMP(i) do {} while (0)
+#endif
+
 namespace {
 
 constexpr float MAB_SP = 256.f;   // attention probabilities are split as 256 P (an fp16 lo half stays normal down to P ~ 1e-3)
@@ -174,6 +181,10 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
     constexpr int KS = 2 * NT;            // k-steps of 16 over E = 32 NT features
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5, lane16 = lane * 16;
+#ifdef MPG_MABSTAMP
+    unsigned long long mab_st[8] = {};
+#endif
+    MAB_STAMP(0);
     uint32_t seed_lo = 0, seed_hi = 0;
     if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
     const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
@@ -186,6 +197,22 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
     float* const sBin = reinterpret_cast<float*>(sF + 2 * nfE * 1024);   // biases: in_proj [3E] | out_proj [E] | ff [E]
     float* const sBo = sBin + 96 * NT;
     float* const sBf = sBo + 32 * NT;
+    // the wave's first jet: its rows are requested BEFORE the weight fill (loads return in issue order; behind 80 KiB of
+    // weights per workgroup they would arrive ~3,000 clk later, and their conversion can run while the fill lands)
+    const int nw = blockDim.x >> 6;
+    const long jet0 = (long)blockIdx.x * nw + w;
+    f32x16 xt[NT], yt[CROSS ? NT : 1], kneg;
+    auto load_rows = [&](long jet) {
+        const long xr = jet * p.L + min(r, p.L - 1), yr = jet * p.S + min(r, p.S - 1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p.x, p.ldx, xr, t, h);
+        if constexpr (CROSS) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) yt[t] = rows_to_tile(p.y, p.ldy, yr, t, h);
+        }
+        kneg = key_mask_regs(p.ignore, jet, p.S, h);
+    };
+    load_rows(min(jet0, (long)p.B - 1));
     mab_fill(sIn, p.Win, 2 * nfIn * 1024);
     mab_fill(sO, p.Wo, 2 * nfE * 1024);
     mab_fill(sF, p.Wf, 2 * nfE * 1024);
@@ -193,27 +220,21 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
         sBin[i] = (i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT])) * zs;   // (as the accumulators carry them)
     __syncthreads();
     const WImg rIn = sIn, rO = sO, rF = sF;
-    const int nw = blockDim.x >> 6;
-    for (long jet = (long)blockIdx.x * nw + w; jet < p.B; jet += (long)gridDim.x * nw) {   // (no barrier inside)
+    MAB_STAMP(1);
+    for (long jet = jet0; jet < p.B; jet += (long)gridDim.x * nw) {   // (no barrier inside)
 
     // rows past the end of a set are read from its last row and never stored; as keys they are masked
-    const long xrow = jet * p.L + min(r, p.L - 1), yrow = jet * p.S + min(r, p.S - 1);
+    const long xrow = jet * p.L + min(r, p.L - 1);
     const bool xvalid = r < p.L;
-    // every global load of the jet is issued here, together: x (kept as tiles for the residual), y, the key mask
-    f32x16 xt[NT], yt[CROSS ? NT : 1];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p.x, p.ldx, xrow, t, h);
-    if constexpr (CROSS) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) yt[t] = rows_to_tile(p.y, p.ldy, yrow, t, h);
-    }
-    const f32x16 kneg = key_mask_regs(p.ignore, jet, p.S, h);
+    // every global load of a jet is issued together: x (kept as tiles for the residual), y, the key mask
+    if (jet != jet0) load_rows(jet);
     V xh[KS], xl[KS], yh_[CROSS ? KS : 1], yl_[CROSS ? KS : 1];
     tiles_to_frags<NT>(xt, sa, xh, xl);
     if constexpr (CROSS) tiles_to_frags<NT>(yt, sa, yh_, yl_);
     const V* yh = CROSS ? yh_ : xh;
     const V* yl = CROSS ? yl_ : xl;
 
+    MAB_STAMP(2);
     V oh[KS], ol[KS];                     // attention output as B fragments of the out-projection
     static_for<0, NT>([&](auto tc) {
         MPG_CI(t, tc);
@@ -254,6 +275,7 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
         tile_frag(Ot, 1, 1.f / MAB_SP, oh[2 * t + 1], ol[2 * t + 1]);
     });
 
+    MAB_STAMP(3);
     // za = x + o Wo' + bo ; z = dropout(za)
     f32x16 z[NT];
     V zh[KS], zl[KS];
@@ -267,6 +289,7 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
         tile_frag(z[t], 0, sa, zh[2 * t], zl[2 * t]);
         tile_frag(z[t], 1, sa, zh[2 * t + 1], zl[2 * t + 1]);
     });
+    MAB_STAMP(4);
     // out = dropout(z + dropout_ff(LeakyReLU(z Wf' + bf)))
     static_for<0, NT>([&](auto tc) {
         MPG_CI(t, tc);
@@ -282,7 +305,12 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
         drop_tile(u, seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
         if (xvalid) tile_to_rows(p.out, p.ldo, xrow, t, h, u, 1.f);
     });
+    MAB_STAMP(5);
     }  // jets of this wave
+#ifdef MPG_MABSTAMP
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) g_mab_stamps[w * 8 + i] = mab_st[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -508,6 +536,14 @@ int mab_check(const MpgMab* p) {
     return 0;
 }
 
+
+#ifdef MPG_MABSTAMP
+}  // namespace
+extern "C" int mpg_debug_mab_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mab_stamps), sizeof(unsigned long long) * 64);
+}
+namespace {
+#endif
 
 // waves (= jets in flight) per workgroup: as many workgroups as CUs first, then up to four waves each
 int mab_waves(int B) {

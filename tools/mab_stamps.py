@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Phase timing of mpg_mab_fwd from a diagnostic build (s_memtime stamps of workgroup 0):
+   MPG_HIPCC_FLAGS="-fno-slp-vectorize -DMPG_MABSTAMP" python -c "from mpgan_amd import _lib; _lib.build(force=True)"
+   python tools/mab_stamps.py            (then rebuild without the flag)"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mpgan_amd import _lib
+from mpgan_amd.gapt import SAB
+B = int(os.environ.get("MAB_B", "512"))
+blk = SAB(embed_dim=64, ff_layers=[], final_linear=False, num_heads=4, layer_norm=False, dropout_p=0.0,
+          linear_args={"leaky_relu_alpha": 0.2, "dropout_p": 0.0, "batch_norm": False, "spectral_norm": False}).cuda()
+x = torch.randn(B, 30, 64, device="cuda")
+with torch.no_grad():
+    for _ in range(3):
+        blk(x, None)
+torch.cuda.synchronize()
+lib = C.CDLL(_lib.LIBPATH)
+buf = (C.c_ulonglong * 64)()
+assert lib.mpg_debug_mab_stamps(buf) == 0
+names = ["start", "weights in LDS", "rows loaded", "attention done", "out-projection done", "stored"]
+for w in range(4):
+    st = [buf[w * 8 + i] for i in range(6)]
+    print("wave", w, " ".join(f"{names[i]}={st[i] - st[0]}" for i in range(1, 6) if st[i]))
