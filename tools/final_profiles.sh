@@ -33,6 +33,16 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_C
 for k in "edge_fwd_kernel<0" "edge_fwd_kernel<2" "edge_bwd_kernel<0, true, true" "edge_bwd_kernel<0, true, false" "edge_bwd_kernel<2, true, true" "edge_bwd_kernel<2, true, false" "edge_dw_kernel<0" "edge_dw_kernel<2"; do
   echo "== $k"; python3 $R/tools/pmc_summary.py $o "$k"
 done > $R/gpurun_out/final/pmc_sq_summary.txt 2>&1
+# the one-launch attention blocks of GAPT: SQ counters and HBM traffic from a short bench run (no timing legs)
+for c in SQ FETCH_SIZE WRITE_SIZE; do
+  o=$R/gpurun_out/final/pmc_gapt_$c
+  rm -rf $o
+  if [ $c = SQ ]; then ctrs="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE"; else ctrs=$c; fi
+  rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $o -o p -- python3 $R/bench.py --model gapt --steps 3 --warmup 2 --no-graphs --no-roofline --no-cpu-baseline > $o.log 2>&1 || { tail -5 $o.log; exit 1; }
+  for k in "mab_fwd_kernel<2, false" "mab_bwd_kernel<2, false" "mab_fwd_kernel<2, true" "mab_bwd_kernel<2, true"; do
+    echo "== $c $k"; python3 $R/tools/pmc_summary.py $o "$k"
+  done
+done > $R/gpurun_out/final/pmc_gapt_summary.txt 2>&1
 echo "sq done"
 cd $R
 (timeout -k 10 120 tools/ubench/mfma_model; timeout -k 10 120 tools/ubench/mfma_model2; timeout -k 10 120 tools/ubench/mfma_power) > gpurun_out/final/ubench.txt 2>&1

@@ -119,6 +119,16 @@ if os.path.isfile(sq_path):
                 f"{(v.get('SQ_INSTS_VALU', 0) / nm if nm else 0):16.1f}\n")
     open(os.path.join(P, f"{tag}_pmc_sq_counters.txt"), "w").write(txt + "#\n" + sq)
 
+gp = os.path.join(F, "pmc_gapt_summary.txt")
+if os.path.isfile(gp):
+    open(os.path.join(P, f"{tag}_pmc_gapt_mab_counters.txt"), "w").write(
+        "# One-launch attention blocks (csrc/mab.hip) under rocprofv3 --kernel-trace --pmc, one pass per counter set, workload\n"
+        "# bench.py --model gapt --steps 3 --warmup 2 --no-graphs (B = 512: launches of 512 and 1,024 jets), per dispatch.\n"
+        "# SQ_* units as in the edge-kernel table (quad-cycles summed over waves; MFMA_BUSY in cycles summed over SIMDs);\n"
+        "# HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB).  One wave per jet: MFMA busy / (4 x WAVE_CYCLES) is the share of a\n"
+        "# wave's lifetime the matrix pipe works -- these kernels are a latency chain of VALU work between small MFMA groups.\n#\n"
+        + open(gp).read())
+
 ub = open(os.path.join(F, "ubench.txt")).read()
 open(os.path.join(P, f"{tag}_ubench_mfma.txt"), "w").write(
     "# tools/ubench/mfma_model, mfma_model2, mfma_power on MI355X (the machine model the fused kernels are scheduled against).\n"
