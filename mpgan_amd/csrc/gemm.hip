@@ -83,9 +83,15 @@ MPG_DEV void tile_store(const float (&v)[8], V (*hi)[2][64], V (*lo)[2][64], int
 }
 
 template <bool AK, bool BK, bool F16>
-MPG_DEV void gemm_body(const MpgGemm& g, const int bx, const int by, const int bz, const int nz) {
+MPG_DEV void gemm_body(const MpgGemm& g_, const int bx, const int by, const int bz, const int nz, const bool fold_ones = false) {
     typedef typename FragT<F16>::type V;
     __shared__ V As_hi[2][2][64], As_lo[2][2][64], Bs_hi[2][2][64], Bs_lo[2][2][64];
+    // fold_ones (the grouped weight-gradient launch, when the ones column would be alone in a 64-wide tile column of its
+    // own -- K a multiple of 64): the products run on the N - 1 real columns and the workgroups of tile column 0 add up
+    // the rows of their A tiles, which they have in registers anyway, into column N - 1 (the bias gradient)
+    MpgGemm g = g_;
+    if (fold_ones) { g.N -= 1; g.ones_col = 0; }
+    float rsum = 0.f;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
     const int m0 = by * 64, n0 = bx * 64;
@@ -108,6 +114,7 @@ MPG_DEV void gemm_body(const MpgGemm& g, const int bx, const int by, const int b
         tile_load<BK>(vb, g.B, g.ldb, nullptr, 0, 0, n0, g.N, kbeg, kend_z, tid, b_vec, b_ones);
     }
     for (int kt = kbeg; kt < kend_z; kt += 32) {
+        if (fold_ones && bx == 0) rsum += ((va[0] + va[1]) + (va[2] + va[3])) + ((va[4] + va[5]) + (va[6] + va[7]));
         tile_store<AK>(va, As_hi, As_lo, tid);
         tile_store<BK>(vb, Bs_hi, Bs_lo, tid);
         __syncthreads();
@@ -121,6 +128,17 @@ MPG_DEV void gemm_body(const MpgGemm& g, const int bx, const int by, const int b
         __syncthreads();
     }
 
+    if constexpr (!AK) {
+        if (fold_ones && bx == 0) {   // thread (row = tid & 63, k group = tid >> 6) holds its row's sum over its 8 k of every tile
+            float* red = reinterpret_cast<float*>(&As_hi[0][0][0]);   // (the loop ended with a barrier: the buffers are free)
+            red[tid] = rsum;
+            __syncthreads();
+            const int m = m0 + tid;
+            if (tid < 64 && m < g.M)
+                (g.C + (size_t)bz * g.split_stride)[(size_t)m * g.ldc + g.N] =
+                    ((red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192])) * g.out_scale;
+        }
+    }
     // ---------------- epilogue (D layout: reg 4g+t -> row 8g+4h+t, lane&31 -> col)
     const int c = lane & 31, h = lane >> 5;
     const int n = n0 + 32 * wc + c;
@@ -161,6 +179,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const MpgGemm g) {
 // Several independent weight-gradient GEMMs (dW = dY^T X, split-K) in ONE launch: each of these is a few hundred
 // short workgroups that cannot fill the chip or hide their own latencies; side by side they do.
 // (only the fields the weight-gradient form uses travel as kernel arguments: 16 whole MpgGemm would not fit the 4 KiB)
+// the ones column would be the only column of the last 64-wide tile column
+__host__ __device__ inline bool wgrad_fold_ones(int N, int ones_col) { return ones_col && N > 1 && (N - 1) % 64 == 0; }
 struct GemmSlim { const float* A; const float* B; float* C; long long split_stride; int lda, ldb, ldc, M, N, K; float out_scale; int ones_col; };
 struct GemmGroup { GemmSlim g[MPG_GROUP_MAX]; int splitk[MPG_GROUP_MAX]; int wg0[MPG_GROUP_MAX + 1]; int n; };
 template <bool F16>
@@ -173,8 +193,9 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup G) {
     g.lda = e.lda; g.ldb = e.ldb; g.ldc = e.ldc; g.M = e.M; g.N = e.N; g.K = e.K;
     g.out_scale = e.out_scale; g.ones_col = e.ones_col; g.alpha = 0.2f; g.f16 = F16;
     const int local = blockIdx.x - G.wg0[q];
-    const int tx = (g.N + 63) / 64, ty = (g.M + 63) / 64;
-    gemm_body<false, false, F16>(g, local % tx, (local / tx) % ty, local / (tx * ty), G.splitk[q]);
+    const bool fold = wgrad_fold_ones(g.N, g.ones_col);
+    const int tx = (g.N - (fold ? 1 : 0) + 63) / 64, ty = (g.M + 63) / 64;
+    gemm_body<false, false, F16>(g, local % tx, (local / tx) % ty, local / (tx * ty), G.splitk[q], fold);
 }
 
 struct ReduceGroup { MpgReduceJob j[MPG_GROUP_MAX]; int blk0[MPG_GROUP_MAX + 1]; int n; };
@@ -269,7 +290,8 @@ extern "C" int mpg_gemm_wgrad_group(const MpgGemm* g, const int* splitk, int n, 
         e.lda = g[q].lda; e.ldb = g[q].ldb; e.ldc = g[q].ldc; e.M = g[q].M; e.N = g[q].N; e.K = g[q].K;
         e.out_scale = g[q].out_scale; e.ones_col = g[q].ones_col;
         G.splitk[q] = splitk[q];
-        G.wg0[q + 1] = G.wg0[q] + ((g[q].N + 63) / 64) * ((g[q].M + 63) / 64) * splitk[q];
+        const int ncol = g[q].N - (wgrad_fold_ones(g[q].N, g[q].ones_col) ? 1 : 0);
+        G.wg0[q + 1] = G.wg0[q] + ((ncol + 63) / 64) * ((g[q].M + 63) / 64) * splitk[q];
     }
     if (g[0].f16) hipLaunchKernelGGL((gemm_group_kernel<true>), dim3(G.wg0[n]), dim3(256), 0, (hipStream_t)stream, G);
     else hipLaunchKernelGGL((gemm_group_kernel<false>), dim3(G.wg0[n]), dim3(256), 0, (hipStream_t)stream, G);

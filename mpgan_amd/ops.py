@@ -237,7 +237,10 @@ class WgradBatch:
         M, N = dy.shape
         K = x.shape[1]
         hb = int(bias_out is not None)
-        tiles = ((N + 63) // 64) * ((K + hb + 63) // 64)
+        # (a ones column that would sit alone in a tile column of its own -- K a multiple of 64 -- is folded into the
+        # workgroups of tile column 0 by the kernel: csrc/gemm.hip)
+        kcols = K if (hb and K % 64 == 0) else K + hb
+        tiles = ((N + 63) // 64) * ((kcols + 63) // 64)
         splitk = max(1, min((M + 255) // 256, (WGRAD_TARGET_WGS + tiles - 1) // tiles))
         part = torch.empty((splitk, N, K + hb), device=dy.device, dtype=torch.float32)
         self.jobs.append((dy, x, out, out_col0, out_scale, bias_out, splitk, part, accumulate))
