@@ -783,8 +783,16 @@ __global__ __launch_bounds__(256) void edge_dw_reduce(const float* __restrict__ 
     const int ix = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int idx = blockIdx.x * 32 + ix;
     float s = 0.f;
-    if (idx < PER)
-        for (int g = sl; g < nwg; g += 8) s += part[(size_t)g * PER + idx];
+    if (idx < PER) {   // (four independent partial sums: a thread's loads are in flight together; fixed summation order)
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int g = sl;
+        for (; g + 24 < nwg; g += 32) {
+            s0 += part[(size_t)g * PER + idx]; s1 += part[(size_t)(g + 8) * PER + idx];
+            s2 += part[(size_t)(g + 16) * PER + idx]; s3 += part[(size_t)(g + 24) * PER + idx];
+        }
+        for (; g < nwg; g += 8) s0 += part[(size_t)g * PER + idx];
+        s = (s0 + s1) + (s2 + s3);
+    }
     red[sl][ix] = s;
     __syncthreads();
     if (sl != 0 || idx >= PER) return;

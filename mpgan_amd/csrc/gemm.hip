@@ -207,8 +207,16 @@ __global__ void splitk_reduce_group_kernel(const ReduceGroup R) {
     const int ldp = J.K + J.has_bias;
     if (idx >= J.N * ldp) return;
     const int n = idx / ldp, k = idx % ldp;
-    float s = 0.f;
-    for (int z = 0; z < J.S; ++z) s += J.part[(size_t)z * J.N * ldp + idx];
+    // (four independent partial sums: the loads of a thread are then in flight together; the summation order is fixed)
+    const size_t zs = (size_t)J.N * ldp;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 4 <= J.S; z += 4) {
+        s0 += J.part[(size_t)z * zs + idx]; s1 += J.part[(size_t)(z + 1) * zs + idx];
+        s2 += J.part[(size_t)(z + 2) * zs + idx]; s3 += J.part[(size_t)(z + 3) * zs + idx];
+    }
+    for (; z < J.S; ++z) s0 += J.part[(size_t)z * zs + idx];
+    const float s = (s0 + s1) + (s2 + s3);
     if (k < J.K) { float* d = J.out + (size_t)n * J.ldo + k; *d = s + (J.accumulate ? *d : 0.f); }
     else if (J.bias != nullptr) J.bias[n] = s + (J.accumulate ? J.bias[n] : 0.f);
 }
