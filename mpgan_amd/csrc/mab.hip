@@ -23,7 +23,7 @@
 #include <stdlib.h>
 
 #ifdef MPG_MABSTAMP  // diagnostic build (tools/mab_stamps.py): s_memtime at the phase boundaries, the waves of workgroup 0
-__device__ unsigned long long g_mab_stamps[2 * 4 * 8];
+__device__ unsigned long long g_mab_stamps[2 * 4 * 8];   // [forward | backward][wave][stamp]
 #define MAB_STAMP(i) do { mab_st[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define MAB_STAMP(i) do {} while (0)
@@ -343,6 +343,10 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
     constexpr int KS = 2 * NT;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5, lane16 = lane * 16;
+#ifdef MPG_MABSTAMP
+    unsigned long long mab_st[8] = {};
+#endif
+    MAB_STAMP(0);
     uint32_t seed_lo = 0, seed_hi = 0;
     if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
     const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
@@ -354,6 +358,19 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
     char* const sInT = sF + 2 * nfE * 1024;
     char* const sOT = sInT + 2 * nfInT * 1024;
     char* const sFT = sOT + 2 * nfE * 1024;
+    // ONE jet per wave (the launcher sizes the grid for it).  Its dout and z rows -- all the feed-forward half needs --
+    // are requested BEFORE the 144 KiB weight fill (loads return in issue order: behind the fill they arrived ~8,000 clk
+    // late); x and y follow the fill and land while that half runs.
+    const int nw = blockDim.x >> 6;
+    const long jet_raw = (long)blockIdx.x * nw + w;
+    const long jet = min(jet_raw, (long)p.B - 1);
+    const long xrow = jet * p.L + min(r, p.L - 1), yrow = jet * p.S + min(r, p.S - 1);
+    f32x16 dzf[NT], zt[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        dzf[t] = rows_to_tile(p.dout, p.lddout, xrow, t, h);
+        zt[t] = rows_to_tile(p.save_z, p.E, xrow, t, h);
+    }
     mab_fill(sIn, p.Win, 2 * nfIn * 1024);
     mab_fill(sF, p.Wf, 2 * nfE * 1024);
     mab_fill(sInT, p.WinT, 2 * nfInT * 1024);
@@ -364,22 +381,17 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
     for (int i = threadIdx.x; i < 128 * NT; i += blockDim.x) sBin[i] = (i < 96 * NT ? p.bin[i] : p.bf[i - 96 * NT]) * zs;
     __syncthreads();
     const WImg rIn = sIn, rF = sF, rInT = sInT, rOT = sOT, rFT = sFT;
-    const int nw = blockDim.x >> 6;
-    for (long jet = (long)blockIdx.x * nw + w; jet < p.B; jet += (long)gridDim.x * nw) {   // (no barrier inside)
-
-    const long xrow = jet * p.L + min(r, p.L - 1), yrow = jet * p.S + min(r, p.S - 1);
+    MAB_STAMP(1);
+    if (jet_raw >= p.B) return;           // (a wave without a jet: it has helped with the fill)
+    {
     const bool xvalid = r < p.L, yvalid = r < p.S;
     const float xlive = xvalid ? 1.f : 0.f;
     const f32x16 kneg = key_mask_regs(p.ignore, jet, p.S, h);
     bool key_off = !yvalid;               // this lane as a KEY (transposed tiles)
     if (p.ignore != nullptr) key_off = key_off || p.ignore[jet * p.S + min(r, p.S - 1)] != 0.f;
-
-    // every global load of the jet is issued here, together: dout, z, x, y (the key mask above)
-    f32x16 dzf[NT], zt[NT], xt[NT], yt[CROSS ? NT : 1];
+    f32x16 xt[NT], yt[CROSS ? NT : 1];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        dzf[t] = rows_to_tile(p.dout, p.lddout, xrow, t, h);
-        zt[t] = rows_to_tile(p.save_z, p.E, xrow, t, h);
         xt[t] = rows_to_tile(p.x, p.ldx, xrow, t, h);
         if constexpr (CROSS) yt[t] = rows_to_tile(p.y, p.ldy, yrow, t, h);
     }
@@ -389,6 +401,7 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
     const VF* yh = CROSS ? yh_ : xh;
     const VF* yl = CROSS ? yl_ : xl;
 
+    MAB_STAMP(2);
     // ---- feed-forward half: dzf = dropout'(dout) ; du = dzf drop_ff' act'(u) ; dz = dzf + du Wf ; dza = dropout'(dz)
     VB dzah[KS], dzal[KS];
     f32x16 dxa[NT];                       // gradient with respect to x: starts as the residual path
@@ -420,6 +433,7 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
             dxa[t] = dz;
         });
     }
+    MAB_STAMP(3);
     f32x16 dya[CROSS ? NT : 1];
     if constexpr (CROSS) {
 #pragma unroll
@@ -518,6 +532,7 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
         tile_frag(dVt, 0, 1.f, fh[0], fl[0]); tile_frag(dVt, 1, 1.f, fh[1], fl[1]);
         acc_wt<NT>(rInT, nfInT, 3 * KS, 2 * (2 * NT + t), fh, fl, dkv_acc, lane16);
     });
+    MAB_STAMP(4);
     static_for<0, NT>([&](auto tc) {
         MPG_CI(t, tc);
         if (p.dx != nullptr && xvalid) tile_to_rows(p.dx, p.lddx, xrow, t, h, dxa[t], 1.f);
@@ -525,7 +540,12 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
             if (p.dy != nullptr && yvalid) tile_to_rows(p.dy, p.lddy, yrow, t, h, dya[t], 1.f);
         }
     });
-    }  // jets of this wave
+    MAB_STAMP(5);
+    }  // (the wave's jet)
+#ifdef MPG_MABSTAMP
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) g_mab_stamps[32 + w * 8 + i] = mab_st[i];
+#endif
 }
 
 int mab_check(const MpgMab* p) {
@@ -553,9 +573,9 @@ int mab_waves(int B) {
 }
 
 template <typename K>
-int mab_launch(K kernel, const MpgMab* p, int lds_bytes, hipStream_t st) {
+int mab_launch(K kernel, const MpgMab* p, int lds_bytes, hipStream_t st, bool one_jet_per_wave = false) {
     const int nw = mab_waves(p->B);
-    const int grid = (p->B + nw - 1) / nw < 1024 ? (p->B + nw - 1) / nw : 1024;
+    const int grid = ((p->B + nw - 1) / nw < 1024 || one_jet_per_wave) ? (p->B + nw - 1) / nw : 1024;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * nw), lds_bytes, st, *p);
     return (int)hipGetLastError();
 }
@@ -572,12 +592,12 @@ extern "C" int mpg_mab_bwd(const MpgMab* p, void* stream) {
     const int NT = p->E / 32;
     const int lds = 2 * 1024 * (2 * 3 * NT * 2 * NT + 3 * NT * 2 * NT) + 4 * 128 * NT;   // Win, WinT (3E x E) + Wf, WoT, WfT (E x E) + biases
     if (p->E == 64) {
-        if (cross) { MPG_ENSURE_LDS((mab_bwd_kernel<2, true>), lds); return mab_launch(mab_bwd_kernel<2, true>, p, lds, st); }
+        if (cross) { MPG_ENSURE_LDS((mab_bwd_kernel<2, true>), lds); return mab_launch(mab_bwd_kernel<2, true>, p, lds, st, true); }
         MPG_ENSURE_LDS((mab_bwd_kernel<2, false>), lds);
-        return mab_launch(mab_bwd_kernel<2, false>, p, lds, st);
+        return mab_launch(mab_bwd_kernel<2, false>, p, lds, st, true);
     }
-    if (cross) return mab_launch(mab_bwd_kernel<1, true>, p, lds, st);
-    return mab_launch(mab_bwd_kernel<1, false>, p, lds, st);
+    if (cross) return mab_launch(mab_bwd_kernel<1, true>, p, lds, st, true);
+    return mab_launch(mab_bwd_kernel<1, false>, p, lds, st, true);
 }
 
 extern "C" int mpg_mab_fwd(const MpgMab* p, void* stream) {

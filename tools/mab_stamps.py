@@ -14,6 +14,9 @@ x = torch.randn(B, 30, 64, device="cuda")
 with torch.no_grad():
     for _ in range(3):
         blk(x, None)
+xg = x.clone().requires_grad_(True)
+for _ in range(3):
+    blk(xg, None).sum().backward()
 torch.cuda.synchronize()
 lib = C.CDLL(_lib.LIBPATH)
 buf = (C.c_ulonglong * 64)()
@@ -21,4 +24,8 @@ assert lib.mpg_debug_mab_stamps(buf) == 0
 names = ["start", "weights in LDS", "rows loaded", "attention done", "out-projection done", "stored"]
 for w in range(4):
     st = [buf[w * 8 + i] for i in range(6)]
-    print("wave", w, " ".join(f"{names[i]}={st[i] - st[0]}" for i in range(1, 6) if st[i]))
+    print("forward  wave", w, " ".join(f"{names[i]}={st[i] - st[0]}" for i in range(1, 6) if st[i]))
+bnames = ["start", "weights in LDS", "rows loaded", "feed-forward half done", "attention + input gradients done", "stored"]
+for w in range(4):
+    st = [buf[32 + w * 8 + i] for i in range(6)]
+    print("backward wave", w, " ".join(f"{bnames[i]}={st[i] - st[0]}" for i in range(1, 6) if st[i]))
