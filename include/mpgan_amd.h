@@ -170,11 +170,15 @@ int mpg_knn_sets(const float* x, int ldx, const float* mask, int B, int N, int F
 /* mpg_edge_bwd: autograd backward of the same span, data path.  Given dagg = dL/dagg and the
  * forward's sign words it produces
  *   da [SC, B*N, 96]  (partial over sender chunks),  dc [RB, B*N, 96]  (partial over receiver blocks of 32)
- * and, when stageE2/stageZ2 are non-NULL (weight gradients wanted), parks E2 = fe.net.1's output and
- * dZ2 = dL/d(its pre-activation) as 16-bit hi/lo fragments [B*RB*N blocks][2][10][64 lanes][8] (fp16 / bf16 resp.
- * bf16 / bf16 when f16 = 0) for mpg_edge_dw.  W2img is the forward image (mpg_pack_weights, f16 as the
- * flag says); W3Timg / W2Timg are bf16 images of the transposed weights.  A sender chunk (ceil(N / SC) senders)
- * may hold at most 188 senders (error -6: raise SC), and the staging buffers must stay below 2 GiB (error -7). */
+ * and, when stageE2/stageZ2 are non-NULL (weight gradients wanted), parks E2 = fe.net.1's output (in the forward's
+ * operand scale) and dZ2 = dL/d(its pre-activation) as fp16 fragments [B*RB*N blocks][10][64 lanes][8] for
+ * mpg_edge_dw.  dZ2 is parked in units of 2^-e of its (jet, receiver block) -- gradients have any magnitude, fp16 has
+ * 30 binades -- and gexp[b*RB + rb] = e says which (e is chosen from max |dagg| of the block's receivers).
+ * All images are fp16 (f16 must be 1, error -8): W2img the forward image, W3Timg / W2Timg the images of the transposed
+ * weights packed with the forward's scales (dscale * 64, dscale * 16).  The recomputed layer 2 repeats the forward
+ * bit for bit (three fp16 terms); the two gradient products run as two fp16 terms (image hi + lo times the gradient
+ * rounded to fp16).  A sender chunk (ceil(N / SC) senders) may hold at most 180 senders (error -6: raise SC), and
+ * the staging buffers must stay below 2 GiB (error -7). */
 typedef struct MpgEdgeBwd {
     const float* a; const float* c; int ld_ac; const float* mask;
     const float* dagg; int ld_dagg;
@@ -188,12 +192,15 @@ typedef struct MpgEdgeBwd {
     const uint64_t* seed; uint32_t tag_base, thr; float dscale;
     int f16;
     const unsigned int* nbr;              /* as MpgEdgeFwd.nbr */
+    int* gexp;                            /* [B*RB] gradient-unit exponents of the parked dZ2 (required with stageE2/stageZ2) */
 } MpgEdgeBwd;
 int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream);
 
 /* mpg_edge_dw: weight gradients of fe.net.1 / fe.net.2 (and their biases) from the fragments parked by
  * mpg_edge_bwd:  dW3 = dscale * sum_e dZ3 E2^T [192,160], dW2 = dscale * sum_e dZ2 E1^T [160,96],
  * db3 = sum_e dZ3 [192], db2 = sum_e dZ2 [160]; E1 and dZ3 are rebuilt from a, c, dagg and the sign words.
+ * Two fp16 terms per product: the rebuilt operand as hi + lo, the parked one as the fp16 value it was parked as,
+ * everything in ONE gradient unit 2^-min(gexp) for the launch (the parked dZ2 is rescaled exactly).
  * `part` is scratch of nwg * 46,432 floats (per-workgroup partial sums); nwg workgroups share the B*RB*N blocks
  * evenly and each may take at most 64 of them (error -5 otherwise). */
 typedef struct MpgEdgeDw {
@@ -207,8 +214,9 @@ typedef struct MpgEdgeDw {
     int B, N;
     float alpha, agg_scale;
     const uint64_t* seed; uint32_t tag_base, thr; float dscale;
-    int f16;
+    int f16;                              /* must be 1 */
     const unsigned int* nbr;              /* as MpgEdgeFwd.nbr */
+    const int* gexp;                      /* [B*RB] from mpg_edge_bwd */
 } MpgEdgeDw;
 int mpg_edge_dw(const MpgEdgeDw* p, void* stream);
 

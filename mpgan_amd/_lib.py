@@ -63,7 +63,7 @@ class MpgEdgeBwd(C.Structure):
         ("B", C.c_int), ("N", C.c_int), ("SC", C.c_int),
         ("alpha", C.c_float), ("agg_scale", C.c_float),
         ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
-        ("f16", C.c_int), ("nbr", _fp),
+        ("f16", C.c_int), ("nbr", _fp), ("gexp", _fp),
     ]
 
 
@@ -77,7 +77,7 @@ class MpgEdgeDw(C.Structure):
         ("B", C.c_int), ("N", C.c_int),
         ("alpha", C.c_float), ("agg_scale", C.c_float),
         ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
-        ("f16", C.c_int), ("nbr", _fp),
+        ("f16", C.c_int), ("nbr", _fp), ("gexp", _fp),
     ]
 
 

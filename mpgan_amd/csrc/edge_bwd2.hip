@@ -1,21 +1,25 @@
-// mpg_edge_bwd: the entry point and the fp16-recompute variants of the data-gradient kernel (edge_bwd2_impl.h holds the
-// kernel; the bf16-recompute variants -- OPTIONS["fwd_f16"] = False -- are edge_bwd2_bf16.hip, so that the two halves of
-// this slow-to-compile template build side by side).
+// mpg_edge_bwd: the entry point and the no-dropout variants of the data-gradient kernel (edge_bwd2_impl.h holds the
+// kernel; the variants with dropout are edge_bwd2_d1.hip / edge_bwd2_d2.hip, so that the three parts of this
+// slow-to-compile template build side by side).
 #include "edge_bwd2_impl.h"
 
-int mpg_edge_bwd_bf16(const MpgEdgeBwd* p, hipStream_t st);   // edge_bwd2_bf16.hip
+int mpg_edge_bwd_d1(const MpgEdgeBwd* p, hipStream_t st);   // edge_bwd2_d1.hip: byte-threshold dropout
+int mpg_edge_bwd_d2(const MpgEdgeBwd* p, hipStream_t st);   // edge_bwd2_d2.hip: one-bit dropout (p = 1/2)
 
 extern "C" int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream) {
     if (p->B <= 0 || p->N <= 0 || p->SC <= 0) return -1;
     if (p->sign3 == nullptr) return -3;
     if (!(p->alpha >= 0.f && p->alpha <= 1.f)) return -4;
+    if (!p->f16) return -8;   // the recomputed layer and both gradient products take fp16 images
     if ((p->N + p->SC - 1) / p->SC > B2_LIST_MAX) return -6;  // senders per chunk (the list of unmasked ones lives in LDS)
     const int RB = (p->N + 31) / 32;
-    if ((long long)p->B * RB * p->N * (2 * NFR2 * 1024) > 0x7fffffffLL) return -7;  // staging offsets are 32-bit
+    if ((long long)p->B * RB * p->N * (NFR2 * 1024) > 0x7fffffffLL) return -7;  // staging offsets are 32-bit
+    if ((p->stageE2 != nullptr && p->stageZ2 != nullptr) && p->gexp == nullptr) return -9;
     hipStream_t st = (hipStream_t)stream;
 #ifdef MPG_SINGLE_VARIANT
-    return b2_launch<true>(p, st);
+    return b2_launch<MPG_SINGLE_VARIANT>(p, st);
 #else
-    return p->f16 ? b2_launch<true>(p, st) : mpg_edge_bwd_bf16(p, st);
+    const int dm = p->thr == 0 ? 0 : (p->thr == 128 ? 2 : 1);
+    return dm == 0 ? b2_launch<0>(p, st) : (dm == 1 ? mpg_edge_bwd_d1(p, st) : mpg_edge_bwd_d2(p, st));
 #endif
 }

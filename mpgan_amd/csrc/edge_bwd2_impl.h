@@ -17,8 +17,20 @@
 //                                MFMAs of k-step k, so dZ3 never exists as a whole (96 registers per sender saved)
 //   phase C  dE1 = W2'^T dZ2     k-outer (10 k-steps x 3 tiles): dZ2 = gate * dE2 built (and staged) the same way
 //                                from phase B's accumulators
-// Arithmetic and accumulation order per output element are those of the forward's mfma3 (lo*hi, hi*lo, hi*hi per
-// k-step, k ascending).
+// Arithmetic.  Phase A repeats the forward bit for bit (fp16 hi/lo operands, lo*hi, hi*lo, hi*hi per k-step, k
+// ascending): its signs gate dZ2.  The two gradient products have no kink behind their rounding and run as TWO fp16
+// terms: the weight image keeps hi and lo, the operand built on the fly (dZ3, dZ2) is rounded to ONE fp16 value
+// (2^-12 relative per element).  Left alone that rounding would be the same for every sender of a receiver -- dZ3_ij is
+// dagg_i times one of two constants, dZ2_ij nearly so -- i.e. coherent along the very axis da sums over (measured:
+// 2.8e-4 on dx at any batch size).  So every sender works in ITS OWN unit: the pair's gradients are multiplied by a
+// dither factor c in [1, 2) hashed from the block index (free: it rides in the slope constants of layer 3), which puts
+// the roundings of different senders at unrelated places of the mantissa, and 1/c is folded into the gate constants of
+// layer 1 (and into mpg_edge_dw's rescaling of the parked dZ2).  The roundings then average out like independent noise in
+// every sum over edges (tests/test_gpu_mplayer.py, tests/probe_precision.py).
+// fp16 has 30 binades, gradients have any magnitude, so the workgroup works in units of 2^-e of its own receivers'
+// upstream gradient: e is chosen in the prologue such that max |dZ3| * 2^e lies in [2^8, 2^9), the factor rides for free
+// in constants that already multiply every element (the slope constants of layer 3; the gates of layers 2 and 1 undo
+// the images' operand scales and 2^e), and gexp[(b, rb)] = e tells mpg_edge_dw the unit of the staged dZ2.
 #pragma once
 #include "edge_common.h"
 
@@ -35,34 +47,24 @@ __device__ unsigned long long g_b2_stamps[64 * 4 * 8];
 
 namespace {
 
-// LDS plan (all of the 160 KiB): W3^T hi|lo (bf16) | dagg tile of the 32 receivers | a tile | b2 | per-wave rows of
+// LDS plan (all of the 160 KiB): W3^T hi|lo (fp16) | dagg tile of the 32 receivers | a tile | b2 | per-wave rows of
 // c for the two senders in flight | list of the chunk's unmasked senders.  W2 and W2^T stream from L2.
 constexpr int B2_W_BYTES = 2 * NF3T * 1024;      // 122,880
 constexpr int B2_DG_BYTES = T3 * 4 * 64 * 16;    //  24,576
 constexpr int B2_A_BYTES = T1 * 4 * 64 * 16;     //  12,288
 constexpr int B2_B2_BYTES = H2 * 4;              //     640
 constexpr int B2_C_BYTES = 4 * 2 * H1 * 4;       //   3,072
-constexpr int B2_LIST_MAX = 188;                 // senders per chunk (uint16 entries + count: 384 B)
+constexpr int B2_LIST_MAX = 180;                 // senders per chunk (uint16 entries + count + 4 wave maxima of the prologue: 384 B)
 constexpr int B2_LDS_BYTES = B2_W_BYTES + B2_DG_BYTES + B2_A_BYTES + B2_B2_BYTES + B2_C_BYTES + 384;
 static_assert(B2_LDS_BYTES <= 163840, "LDS plan exceeds 160 KiB");
 
 typedef unsigned int b2_u32x4 __attribute__((ext_vector_type(4)));
 
-// hi/lo split of a PAIR of floats into word `wi` (elements 2 wi, 2 wi + 1) of two bf16x8 fragments, cut in two
-// halves so that they can sit in different issue slots.
-struct PairBf {
-    uint32_t hp;
-    float r0;
-    MPG_DEV void first(float v0, float v1) {
-        hp = cvt_pk_bf16(v0, v1);
-        r0 = v0 - __builtin_bit_cast(float, hp << 16);
-    }
-    MPG_DEV void second(float v1, b2_u32x4& hi, b2_u32x4& lo, int wi) {
-        const float r1 = v1 - __builtin_bit_cast(float, hp & 0xffff0000u);
-        hi[wi] = hp;
-        lo[wi] = cvt_pk_bf16(r0, r1);
-    }
-};
+// two floats -> one word of an fp16x8 fragment (v_cvt_pk_f16_f32, round to nearest even)
+MPG_DEV uint32_t cvt_pk_f16(float v0, float v1) {
+    const f16x2 hp = {(_Float16)v0, (_Float16)v1};
+    return __builtin_bit_cast(uint32_t, hp);
+}
 
 // if_set / if_clear chosen by bit BIT of `word`: v_bfe_i32 + v_bfi_b32 (left to itself the compiler builds a compare,
 // two wait states for VCC and a v_cndmask per element)
@@ -82,15 +84,23 @@ MPG_DEV void run_slot(F&& unit) {
     static_for<u0, u1>(unit);
 }
 
-template <bool F16, typename V>
-MPG_DEV f32x16 mma(const V a, const V b, const f32x16 c) {
-    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+// e with m * 2^e in [2^8, 2^9) for a positive normal m, clamped to +-100 so that 2^e, 2^-e / SC_W2 stay normal floats
+// (gradients below 2^-92 are flushed by the fp16 rounding, as RMSprop's eps would do anyway).  fp16 is normal from 2^-14
+// to 2^16: with the largest |dZ3| (times its dither factor < 2) below 2^10, elements down to 2^-23 of the largest keep
+// their 11 bits, and dZ2 = W3^T dZ3 -- typically 1 .. 10 times the largest |dZ3| -- stays two binades and more below the
+// overflow.  m = 0 (no gradient at all: nothing to scale) gives the largest exponent, so that it never decides the
+// minimum mpg_edge_dw takes over a launch.
+MPG_DEV int grad_unit_exp(float m) {
+    const int ex = (int)((__builtin_bit_cast(uint32_t, m) >> 23) & 0xffu);
+    if (ex == 0) return 100;
+    return max(-100, min(100, 8 - (ex - 127)));
 }
 
-template <int DROP, bool F16, bool NEEDW>  // DROP: 0 off, 1 byte mode, 2 bit mode (see common.h)
+MPG_DEV f32x16 mma(const f16x8 a, const f16x8 b, const f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+template <int DROP, bool NEEDW>  // DROP: 0 off, 1 byte mode, 2 bit mode (see common.h)
 __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
-    typedef typename FragT<F16>::type V;  // forward-recomputation operands; gradient operands are bf16
+    typedef f16x8 V;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -106,22 +116,24 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     const int ldac = p.ld_ac ? p.ld_ac : H1;
 
     const __amdgpu_buffer_rsrc_t r2 = img_rsrc(p.W2img, 2 * NF2);     // W2 hi | lo (forward image)
-    const __amdgpu_buffer_rsrc_t r2t = img_rsrc(p.W2Timg, 2 * NF2T);  // W2^T hi | lo (bf16)
+    const __amdgpu_buffer_rsrc_t r2t = img_rsrc(p.W2Timg, 2 * NF2T);  // W2^T hi | lo (fp16, operand scale SC_W2)
     const int lane16 = lane * 16;
-    const bf16x8* t3g = reinterpret_cast<const bf16x8*>(p.W3Timg);
-    bf16x8* l3t = reinterpret_cast<bf16x8*>(smem);
+    const f16x8* t3g = reinterpret_cast<const f16x8*>(p.W3Timg);
+    f16x8* l3t = reinterpret_cast<f16x8*>(smem);
     float4* ldg = reinterpret_cast<float4*>(smem + B2_W_BYTES);                // [(m*4+g)][lane]
     float4* la = reinterpret_cast<float4*>(smem + B2_W_BYTES + B2_DG_BYTES);   // [(q*2+s)*2+u][lane]
     float* lb2 = reinterpret_cast<float*>(smem + B2_W_BYTES + B2_DG_BYTES + B2_A_BYTES);
     float* lcw = lb2 + H2 + w * (2 * H1);                                      // this wave's two rows of c
     unsigned short* lst = reinterpret_cast<unsigned short*>(smem + B2_W_BYTES + B2_DG_BYTES + B2_A_BYTES + B2_B2_BYTES + B2_C_BYTES);
     int* lnv = reinterpret_cast<int*>(lst + B2_LIST_MAX);
+    float* lmx = reinterpret_cast<float*>(smem + B2_LDS_BYTES - 16);                // wave maxima of |dagg|
 
     // ---- prologue (whole workgroup): weights and the per-receiver tiles into LDS, the list of unmasked senders
     copy_to_lds(l3t, t3g, 2 * NF3T * 64, tid);
     for (int t = tid; t < H2; t += 256) lb2[t] = p.b2[t] * SC_E2;  // (the recomputed layer 2 runs in the forward's operand scales)
     // upstream gradient dagg (scaled) and the layer-1 receiver term a, both in the register order the chain layout
     // wants (zeros for padding lanes: they carry exact zeros all the way down)
+    float amax = 0.f;
     for (int t = tid; t < T3 * 4 * 64; t += 256) {
         const int ln = t & 63, mg = t >> 6, rr = ln & 31, hh = ln >> 5, ii = rb * 32 + rr;
         float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -130,7 +142,11 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             v4 = make_float4(di[0] * p.agg_scale, di[1] * p.agg_scale, di[2] * p.agg_scale, di[3] * p.agg_scale);
         }
         ldg[t] = v4;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v4.x), fabsf(v4.y))), fmaxf(fabsf(v4.z), fabsf(v4.w)));
     }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0) lmx[w] = amax;
     for (int t = tid; t < T1 * 4 * 64; t += 256) {
         const int ln = t & 63, qsu = t >> 6, rr = ln & 31, hh = ln >> 5, ii = rb * 32 + rr;
         float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -157,6 +173,10 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
         }
     __syncthreads();
     const int nvalid = __builtin_amdgcn_readfirstlane(*lnv);
+    // the workgroup's gradient unit 2^-e (see the head of this file): max |dZ3| <= max |dagg * agg_scale| * dscale (mask <= 1)
+    const int gexp = __builtin_amdgcn_readfirstlane(grad_unit_exp(fmaxf(fmaxf(lmx[0], lmx[1]), fmaxf(lmx[2], lmx[3])) * p.dscale));
+    const float gunit = __builtin_bit_cast(float, (uint32_t)(gexp + 127) << 23);            // 2^e
+    if (NEEDW && tid == 0) p.gexp[b * RB + rb] = gexp;   // (the sender chunks of a receiver block all write the same value)
 
     uint32_t seed_lo = 0, seed_hi = 0;
     if (DROP) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
@@ -165,17 +185,25 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     const uint32_t lbdg = lds_base(smem, B2_W_BYTES + lane16);    // dagg tile
     const uint32_t lbla = lds_base(smem, B2_W_BYTES + B2_DG_BYTES + lane16);  // a tile
     const uint32_t lbc = lds_base(smem, B2_W_BYTES + B2_DG_BYTES + B2_A_BYTES + B2_B2_BYTES + w * (2 * H1 * 4) + 16 * h);  // this wave's rows of c
-    // staging: block blk = (b*RB + rb)*N + j ; plane part (0 hi, 1 lo) ; the 10 B-operand fragments (tile, k-step) of
-    // the 160-feature tensor exactly as the lanes hold them: one coalesced 16-byte store per lane and fragment.
+    // staging: block blk = (b*RB + rb)*N + j ; the 10 B-operand fragments (tile, k-step) of the 160-feature tensor,
+    // rounded to fp16, exactly as the lanes hold them: one coalesced 16-byte store per lane and fragment.
     // Buffer stores: a block offset beyond the buffer (the idle second half of an odd pair) is dropped by the hardware.
     const int nblk = p.B * RB * p.N;
-    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(p.stageE2, 0, NEEDW ? nblk * (2 * NFR2 * 1024) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(p.stageZ2, 0, NEEDW ? nblk * (2 * NFR2 * 1024) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(p.stageE2, 0, NEEDW ? nblk * (NFR2 * 1024) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(p.stageZ2, 0, NEEDW ? nblk * (NFR2 * 1024) : 0, 0x00020000);
 
     uint32_t opaque_zero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
-    float valpha = p.alpha, vone = 1.f;   // the two slopes in vector registers (operands of v_bfi)
-    asm volatile("" : "+v"(valpha), "+v"(vone));
+    // the two slopes in vector registers (operands of v_bfi), times what the gate has to undo: layer 2's gate takes
+    // phase B's accumulators (W3^T image: SC_W3) to dZ2 in gradient units, layer 1's gate takes phase C's
+    // (W2^T image: SC_W2, gradient unit 2^e) to plain dZ1
+    // (wave-uniform values; each phase moves its pair into vector registers for its own duration only)
+    // (times 1 / c_j of the sender, there).  gfx950 has no scalar float ALU: computed once on the vector side, kept in scalar registers
+    auto uniform = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };
+    const float salpha2 = uniform(p.alpha * (1.f / SC_W3)), sone2 = 1.f / SC_W3;
+    const float sone1 = __builtin_bit_cast(float, (uint32_t)(127 - gexp - 4) << 23);   // 2^-e / SC_W2 (SC_W2 = 2^4)
+    static_assert(SC_W2 == 16.f, "sone1 assumes SC_W2 = 2^4");
+    const float salpha1 = uniform(p.alpha * sone1);
     float dacc[T1][16];
 #pragma unroll
     for (int q = 0; q < T1; ++q)
@@ -191,7 +219,8 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
         int jj[2];
         jj[0] = __builtin_amdgcn_readfirstlane((int)lst[2 * pq]);
         jj[1] = has2 ? __builtin_amdgcn_readfirstlane((int)lst[2 * pq + 1]) : jj[0];
-        float cpos[2], cneg[2];     // slope of layer 3 times m_j * dscale: one select between two uniform constants
+        float cpos[2], cneg[2];     // slope of layer 3 times m_j * dscale * 2^e * c_j: one select between two uniform constants
+        float rcj[2];               // 1 / c_j
         // erow2 == erow, in a form the optimiser cannot prove equal: every dropout word is needed twice per pair, phases
         // apart (forward recomputation, then the gate of the matching gradient), and with one visible value it keeps
         // all the one-instruction keep-masks of the first use alive for the second (hundreds of registers, spilled)
@@ -201,17 +230,19 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
 #pragma unroll
         for (int sd = 0; sd < 2; ++sd) {
             const float mj = p.mask ? p.mask[b * p.N + jj[sd]] : 1.f;
-            const float mjs = (sd == 0 || has2) ? mj * p.dscale : 0.f;
+            const float mjs = (sd == 0 || has2) ? mj * p.dscale * gunit : 0.f;
             float in_set = 1.f;
             if (p.nbr != nullptr) {  // k-nearest-neighbour graph: the edge (i, j) exists only if j's bit is set in i's row
                 const unsigned int wb = p.nbr[(size_t)(b * p.N + (i < p.N ? i : 0)) * ((p.N + 31) >> 5) + (jj[sd] >> 5)];
                 in_set = ((wb >> (jj[sd] & 31)) & 1u) ? 1.f : 0.f;
             }
-            cpos[sd] = mjs * in_set; cneg[sd] = mjs * p.alpha * in_set;
+            const int blk = (b * RB + rb) * p.N + jj[sd];
+            const float dth = dither_of((uint32_t)blk);  // this sender's unit within the workgroup's (see the head of this file)
+            rcj[sd] = __builtin_amdgcn_rcpf(dth);
+            cpos[sd] = mjs * in_set * dth; cneg[sd] = mjs * p.alpha * in_set * dth;
             erow[sd] = (uint32_t)((b * p.N + i) * p.N + jj[sd]);
             erow2[sd] = erow[sd] + opaque_zero;
-            const int blk = (b * RB + rb) * p.N + jj[sd];
-            stoff[sd] = (sd == 0 || has2) ? blk * (2 * NFR2 * 1024) + lane16 : (int)0x7ffffff0;
+            stoff[sd] = (sd == 0 || has2) ? blk * (NFR2 * 1024) + lane16 : (int)0x7ffffff0;
 #pragma unroll
             for (int q = 0; q < T3 / 2; ++q) sw[sd][q] = p.sign3[(size_t)blk * (T3 * 32) + q * 64 + lane];
             // the sender's row of c into this wave's LDS slot (96 floats: lanes 0..63, then lanes 0..31)
@@ -301,16 +332,16 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                         __builtin_amdgcn_sched_barrier(0);
                     };
                     const V a_h = wh[k & 1][m], a_l = wl[k & 1][m];
-                    acc[m][0] = mma<F16>(a_l, bh0, acc[m][0]); slot(std::integral_constant<int, 6 * m + 0>{});
-                    acc[m][1] = mma<F16>(a_l, bh1, acc[m][1]); slot(std::integral_constant<int, 6 * m + 1>{});
-                    acc[m][0] = mma<F16>(a_h, bl0, acc[m][0]); slot(std::integral_constant<int, 6 * m + 2>{});
-                    acc[m][1] = mma<F16>(a_h, bl1, acc[m][1]); slot(std::integral_constant<int, 6 * m + 3>{});
-                    acc[m][0] = mma<F16>(a_h, bh0, acc[m][0]); slot(std::integral_constant<int, 6 * m + 4>{});
-                    acc[m][1] = mma<F16>(a_h, bh1, acc[m][1]); slot(std::integral_constant<int, 6 * m + 5>{});
+                    acc[m][0] = mma(a_l, bh0, acc[m][0]); slot(std::integral_constant<int, 6 * m + 0>{});
+                    acc[m][1] = mma(a_l, bh1, acc[m][1]); slot(std::integral_constant<int, 6 * m + 1>{});
+                    acc[m][0] = mma(a_h, bl0, acc[m][0]); slot(std::integral_constant<int, 6 * m + 2>{});
+                    acc[m][1] = mma(a_h, bl1, acc[m][1]); slot(std::integral_constant<int, 6 * m + 3>{});
+                    acc[m][0] = mma(a_h, bh0, acc[m][0]); slot(std::integral_constant<int, 6 * m + 4>{});
+                    acc[m][1] = mma(a_h, bh1, acc[m][1]); slot(std::integral_constant<int, 6 * m + 5>{});
                 });
             });
             B2_STAMP(2);
-            // epilogue: LeakyReLU, dropout, the sign bits for dZ2's gate; E2 staged as fragments (hi, lo)
+            // epilogue: the sign bits for dZ2's gate; LeakyReLU, dropout and E2 staged as fp16 fragments
             static_for<0, T2>([&](auto mc) {
                 MPG_CI(mm, mc);
 #pragma unroll
@@ -330,10 +361,10 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                     if constexpr (NEEDW && !(MPG_B2EXP & 2)) {
 #pragma unroll
                         for (int s = 0; s < 2; ++s) {
-                            V e2h, e2l;
-                            split8(x2 + 8 * s, e2h, e2l);
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, e2h), rsE, stoff[sd], (mm * 2 + s) * 1024, 0);
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, e2l), rsE, stoff[sd], (NFR2 + mm * 2 + s) * 1024, 0);
+                            b2_u32x4 e2;
+#pragma unroll
+                            for (int pr = 0; pr < 4; ++pr) e2[pr] = cvt_pk_f16(x2[8 * s + 2 * pr], x2[8 * s + 2 * pr + 1]);
+                            __builtin_amdgcn_raw_buffer_store_b128(e2, rsE, stoff[sd], (mm * 2 + s) * 1024, 0);
                         }
                     }
                 }
@@ -341,22 +372,22 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
         }
 
         B2_STAMP(3);
-        // ---- phase B: dE2 = W3'^T dZ3, k-outer.  dZ3 = dagg * slope(sign word) * keep3 is built one k-step ahead.
+        // ---- phase B: dE2 = W3'^T dZ3, k-outer, two fp16 terms (W3^T lo, hi x dZ3 rounded to fp16).  dZ3 = dagg * slope(sign
+        //      word) * keep3 in the sender's gradient unit is built one k-step ahead.
         f32x16 accB[T2][2];
         {
             constexpr int KS = T3 * 2;  // 12 k-steps of 16 features of layer 3
-            b2_u32x4 zh[2][2], zl[2][2];  // [buffer][sender] dZ3 fragment (hi, lo) of a k-step
+            b2_u32x4 zz[2][2];            // [buffer][sender] dZ3 fragment of a k-step
             float v3[2][8];
-            PairBf pb[2][4];
             f32x4 dg[2];                  // dagg of the k-step being built (shared by the two senders)
             uint32_t wd3[2] = {0u, 0u};
-            bf16x8 ah[2][T2], al[2][T2];  // [buffer][tile] W3^T fragments of a k-step
+            V ah[2][T2], al[2][T2];       // [buffer][tile] W3^T fragments of a k-step
             auto load_w = [&](auto kc) {
                 MPG_CI(k, kc);
 #pragma unroll
                 for (int m = 0; m < T2; ++m) {
-                    ah[k & 1][m] = lds_frag<bf16x8>(lb3t, (m * KS + k) * 1024);
-                    al[k & 1][m] = lds_frag<bf16x8>(lb3t, (NF3T + m * KS + k) * 1024);
+                    ah[k & 1][m] = lds_frag<V>(lb3t, (m * KS + k) * 1024);
+                    al[k & 1][m] = lds_frag<V>(lb3t, (NF3T + m * KS + k) * 1024);
                 }
             };
             auto load_dg = [&](auto kc) {
@@ -365,10 +396,10 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                 dg[0] = lds_frag<f32x4>(lbdg, ((m3 * 4 + 2 * s) * 64) * 16);
                 dg[1] = lds_frag<f32x4>(lbdg, ((m3 * 4 + 2 * s + 1) * 64) * 16);
             };
-            // build units of the dZ3 fragment of k-step k: per sender 8 element units + 4 pairs x 2 halves = 16
+            // build units of the dZ3 fragment of k-step k: per sender 8 element units + 4 pair conversions = 12
             auto buildB = [&](auto kc, auto uc) {
                 MPG_CI(k, kc); MPG_CI(uu, uc);
-                constexpr int sd = uu / 16, u = uu % 16;
+                constexpr int sd = uu / 12, u = uu % 12;
                 constexpr int m3 = k >> 1, s = k & 1;
                 if constexpr (u < 8) {
                     constexpr int r16 = 8 * s + u, g = r16 >> 2, t = r16 & 3;
@@ -380,77 +411,74 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                     const float sel = dd * sel_by_bit<31 - (16 * (m3 & 1) + r16)>(sw[sd][m3 >> 1], cneg[sd], cpos[sd]);
                     v3[sd][u] = drop_apply<DROP>(sel, wd, 8 * g + t, t, p.thr);
                 } else {
-                    constexpr int pr = (u - 8) >> 1;
-                    if constexpr (((u - 8) & 1) == 0) pb[sd][pr].first(v3[sd][2 * pr], v3[sd][2 * pr + 1]);
-                    else pb[sd][pr].second(v3[sd][2 * pr + 1], zh[k & 1][sd], zl[k & 1][sd], pr);
+                    constexpr int pr = u - 8;
+                    zz[k & 1][sd][pr] = cvt_pk_f16(v3[sd][2 * pr], v3[sd][2 * pr + 1]);
                 }
             };
             load_w(std::integral_constant<int, 0>{});
             load_dg(std::integral_constant<int, 0>{});
-            static_for<0, 32>([&](auto uc) { buildB(std::integral_constant<int, 0>{}, uc); });
+            static_for<0, 24>([&](auto uc) { buildB(std::integral_constant<int, 0>{}, uc); });
             static_for<0, KS>([&](auto kc) {
                 MPG_CI(k, kc);
                 if constexpr (k + 1 < KS) {
                     load_dg(std::integral_constant<int, k + 1>{});  // (first: the build units behind the next MFMAs wait for it)
                     load_w(std::integral_constant<int, k + 1>{});
                 }
-                const bf16x8 bh0 = __builtin_bit_cast(bf16x8, zh[k & 1][0]), bl0 = __builtin_bit_cast(bf16x8, zl[k & 1][0]);
-                const bf16x8 bh1 = __builtin_bit_cast(bf16x8, zh[k & 1][1]), bl1 = __builtin_bit_cast(bf16x8, zl[k & 1][1]);
+                const V b0 = __builtin_bit_cast(V, zz[k & 1][0]), b1 = __builtin_bit_cast(V, zz[k & 1][1]);
                 static_for<0, T2>([&](auto mc) {
                     MPG_CI(m, mc);
                     auto slot = [&](auto slc) {
                         MPG_CI(SL, slc);
                         // the first slots leave the LDS reads of the next k-step time to land
-                        if constexpr (k + 1 < KS && SL >= 2) run_slot<32, 28, SL - 2>([&](auto uc) { buildB(std::integral_constant<int, k + 1>{}, uc); });
+                        if constexpr (k + 1 < KS && SL >= 2) run_slot<24, 18, SL - 2>([&](auto uc) { buildB(std::integral_constant<int, k + 1>{}, uc); });
                         __builtin_amdgcn_sched_barrier(0);
                     };
-                    const bf16x8 a_h = ah[k & 1][m], a_l = al[k & 1][m];
+                    const V a_h = ah[k & 1][m], a_l = al[k & 1][m];
                     if constexpr (k == 0) {
                         const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        accB[m][0] = mma<false>(a_l, bh0, z); slot(std::integral_constant<int, 6 * m + 0>{});
-                        accB[m][1] = mma<false>(a_l, bh1, z); slot(std::integral_constant<int, 6 * m + 1>{});
+                        accB[m][0] = mma(a_l, b0, z); slot(std::integral_constant<int, 4 * m + 0>{});
+                        accB[m][1] = mma(a_l, b1, z); slot(std::integral_constant<int, 4 * m + 1>{});
                     } else {
-                        accB[m][0] = mma<false>(a_l, bh0, accB[m][0]); slot(std::integral_constant<int, 6 * m + 0>{});
-                        accB[m][1] = mma<false>(a_l, bh1, accB[m][1]); slot(std::integral_constant<int, 6 * m + 1>{});
+                        accB[m][0] = mma(a_l, b0, accB[m][0]); slot(std::integral_constant<int, 4 * m + 0>{});
+                        accB[m][1] = mma(a_l, b1, accB[m][1]); slot(std::integral_constant<int, 4 * m + 1>{});
                     }
-                    accB[m][0] = mma<false>(a_h, bl0, accB[m][0]); slot(std::integral_constant<int, 6 * m + 2>{});
-                    accB[m][1] = mma<false>(a_h, bl1, accB[m][1]); slot(std::integral_constant<int, 6 * m + 3>{});
-                    accB[m][0] = mma<false>(a_h, bh0, accB[m][0]); slot(std::integral_constant<int, 6 * m + 4>{});
-                    accB[m][1] = mma<false>(a_h, bh1, accB[m][1]); slot(std::integral_constant<int, 6 * m + 5>{});
+                    accB[m][0] = mma(a_h, b0, accB[m][0]); slot(std::integral_constant<int, 4 * m + 2>{});
+                    accB[m][1] = mma(a_h, b1, accB[m][1]); slot(std::integral_constant<int, 4 * m + 3>{});
                 });
             });
         }
 
         B2_STAMP(4);
-        // ---- phase C: dE1 = W2'^T dZ2, k-outer; dZ2 = dE2 * keep2 * phi'(Z2) is built (and staged) one k-step
-        //      ahead from phase B's accumulators.  W2^T streams from L2 two k-steps ahead.
+        // ---- phase C: dE1 = W2'^T dZ2, k-outer, two fp16 terms; dZ2 = dE2 * keep2 * phi'(Z2) (still in the sender's unit) is
+        //      built -- and staged -- one k-step ahead from phase B's accumulators.  W2^T streams from L2 two k-steps ahead.
         f32x16 accC[T1][2];
         {
             constexpr int KS = T2 * 2;  // 10 k-steps of 16 features of layer 2
-            b2_u32x4 zh[2][2], zl[2][2];
+            float valpha2 = salpha2, vone2 = sone2;
+            asm volatile("" : "+v"(valpha2), "+v"(vone2));
+            b2_u32x4 zz[2][2];
             float v2[2][8];
-            PairBf pb[2][4];
-            bf16x8 ah[3][T1], al[3][T1];  // ring of three k-steps of W2^T fragments (L2 is more than one k-step away)
+            V ah[3][T1], al[3][T1];       // ring of three k-steps of W2^T fragments (L2 is more than one k-step away)
             uint32_t wd2c[2] = {0u, 0u};  // bit-mode dropout word of the layer-2 tile being gated (hashed again: see erow2)
             auto load_w = [&](auto kc) {
                 MPG_CI(k, kc);
 #pragma unroll
                 for (int m = 0; m < T1; ++m) {
-                    ah[k % 3][m] = img_frag<bf16x8>(r2t, lane16, m * KS + ((MPG_B2EXP & 1) ? 0 : k));
-                    al[k % 3][m] = img_frag<bf16x8>(r2t, lane16, NF2T + m * KS + ((MPG_B2EXP & 1) ? 0 : k));
+                    ah[k % 3][m] = img_frag<V>(r2t, lane16, m * KS + ((MPG_B2EXP & 1) ? 0 : k));
+                    al[k % 3][m] = img_frag<V>(r2t, lane16, NF2T + m * KS + ((MPG_B2EXP & 1) ? 0 : k));
                 }
             };
-            // build units of the dZ2 fragment of k-step k: per sender 8 element units + 4 pairs x 2 halves + 1 store = 17
+            // build units of the dZ2 fragment of k-step k: per sender 8 element units + 4 pair conversions + 1 store = 13
             auto buildC = [&](auto kc, auto uc) {
                 MPG_CI(k, kc); MPG_CI(uu, uc);
-                constexpr int sd = uu / 17, u = uu % 17;
+                constexpr int sd = uu / 13, u = uu % 13;
                 constexpr int m2 = k >> 1, s = k & 1;
                 if constexpr (u < 8) {
                     constexpr int r16 = 8 * s + u, g = r16 >> 2, t = r16 & 3;
                     // sign of Z2 (register r16 of tile m2): pushed in (tile, register) order into word m2 >> 1, which
                     // holds 32 bits (tiles 0..3) or 16 (tile 4)
                     constexpr int nb = m2 < 4 ? 32 : 16;
-                    float gt = sel_by_bit<nb - 1 - (16 * (m2 & 1) + r16)>(neg2[sd][m2 >> 1], valpha, vone);
+                    float gt = sel_by_bit<nb - 1 - (16 * (m2 & 1) + r16)>(neg2[sd][m2 >> 1], valpha2, vone2);
                     if constexpr (DROP != 0) {
                         uint32_t wd;
                         if constexpr (DROP == 2) {
@@ -460,57 +488,59 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                         gt = drop_apply<DROP>(gt, wd, 8 * g + t, t, p.thr);
                     }
                     v2[sd][u] = accB[m2][sd][r16] * gt;
-                } else if constexpr (u < 16) {
-                    constexpr int pr = (u - 8) >> 1;
-                    if constexpr (((u - 8) & 1) == 0) pb[sd][pr].first(v2[sd][2 * pr], v2[sd][2 * pr + 1]);
-                    else pb[sd][pr].second(v2[sd][2 * pr + 1], zh[k & 1][sd], zl[k & 1][sd], pr);
+                } else if constexpr (u < 12) {
+                    constexpr int pr = u - 8;
+                    zz[k & 1][sd][pr] = cvt_pk_f16(v2[sd][2 * pr], v2[sd][2 * pr + 1]);
                 } else {
-                    if constexpr (NEEDW && !(MPG_B2EXP & 2)) {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zh[k & 1][sd]), rsZ, stoff[sd], k * 1024, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zl[k & 1][sd]), rsZ, stoff[sd], (NFR2 + k) * 1024, 0);
-                    }
+                    if constexpr (NEEDW && !(MPG_B2EXP & 2))
+                        __builtin_amdgcn_raw_buffer_store_b128(zz[k & 1][sd], rsZ, stoff[sd], k * 1024, 0);
                 }
             };
             load_w(std::integral_constant<int, 0>{});
             load_w(std::integral_constant<int, 1>{});
-            static_for<0, 34>([&](auto uc) { buildC(std::integral_constant<int, 0>{}, uc); });
+            static_for<0, 26>([&](auto uc) { buildC(std::integral_constant<int, 0>{}, uc); });
             static_for<0, KS>([&](auto kc) {
                 MPG_CI(k, kc);
                 if constexpr (k + 2 < KS) load_w(std::integral_constant<int, k + 2>{});
-                const bf16x8 bh0 = __builtin_bit_cast(bf16x8, zh[k & 1][0]), bl0 = __builtin_bit_cast(bf16x8, zl[k & 1][0]);
-                const bf16x8 bh1 = __builtin_bit_cast(bf16x8, zh[k & 1][1]), bl1 = __builtin_bit_cast(bf16x8, zl[k & 1][1]);
+                const V b0 = __builtin_bit_cast(V, zz[k & 1][0]), b1 = __builtin_bit_cast(V, zz[k & 1][1]);
                 static_for<0, T1>([&](auto mc) {
                     MPG_CI(m, mc);
                     auto slot = [&](auto slc) {
                         MPG_CI(SL, slc);
-                        if constexpr (k + 1 < KS) run_slot<34, 18, SL>([&](auto uc) { buildC(std::integral_constant<int, k + 1>{}, uc); });
+                        if constexpr (k + 1 < KS) run_slot<26, 12, SL>([&](auto uc) { buildC(std::integral_constant<int, k + 1>{}, uc); });
                         __builtin_amdgcn_sched_barrier(0);
                     };
-                    const bf16x8 a_h = ah[k % 3][m], a_l = al[k % 3][m];
+                    const V a_h = ah[k % 3][m], a_l = al[k % 3][m];
                     if constexpr (k == 0) {
                         const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        accC[m][0] = mma<false>(a_l, bh0, z); slot(std::integral_constant<int, 6 * m + 0>{});
-                        accC[m][1] = mma<false>(a_l, bh1, z); slot(std::integral_constant<int, 6 * m + 1>{});
+                        accC[m][0] = mma(a_l, b0, z); slot(std::integral_constant<int, 4 * m + 0>{});
+                        accC[m][1] = mma(a_l, b1, z); slot(std::integral_constant<int, 4 * m + 1>{});
                     } else {
-                        accC[m][0] = mma<false>(a_l, bh0, accC[m][0]); slot(std::integral_constant<int, 6 * m + 0>{});
-                        accC[m][1] = mma<false>(a_l, bh1, accC[m][1]); slot(std::integral_constant<int, 6 * m + 1>{});
+                        accC[m][0] = mma(a_l, b0, accC[m][0]); slot(std::integral_constant<int, 4 * m + 0>{});
+                        accC[m][1] = mma(a_l, b1, accC[m][1]); slot(std::integral_constant<int, 4 * m + 1>{});
                     }
-                    accC[m][0] = mma<false>(a_h, bl0, accC[m][0]); slot(std::integral_constant<int, 6 * m + 2>{});
-                    accC[m][1] = mma<false>(a_h, bl1, accC[m][1]); slot(std::integral_constant<int, 6 * m + 3>{});
-                    accC[m][0] = mma<false>(a_h, bh0, accC[m][0]); slot(std::integral_constant<int, 6 * m + 4>{});
-                    accC[m][1] = mma<false>(a_h, bh1, accC[m][1]); slot(std::integral_constant<int, 6 * m + 5>{});
+                    accC[m][0] = mma(a_h, b0, accC[m][0]); slot(std::integral_constant<int, 4 * m + 2>{});
+                    accC[m][1] = mma(a_h, b1, accC[m][1]); slot(std::integral_constant<int, 4 * m + 3>{});
                 });
             });
         }
 
         B2_STAMP(5);
-        // ---- dZ1 = dE1 * keep1 * phi'(Z1) ; da_i += dZ1 ; dc_j = sum_i dZ1
+        // ---- dZ1 = dE1 * keep1 * phi'(Z1) (back in plain units: the gate constants carry 2^-e / SC_W2) ; da_i += dZ1 ; dc_j = sum_i dZ1
         {
             // dc_j = sum over the 32 receivers (lanes of one half) of dZ1: 16 values per tile and lane.  Halving
             // reduction: at each step a lane keeps half of its values and hands the other half to its partner
             // (DPP), so 16 values cost 15 exchanges instead of 80 and lane l ends with the total of value l & 15
             // (= accumulator register 8s + 4u + t  <->  feature 32 mm + 16 s + 8 u + 4 h + t).
             const bool lb0 = lane & 1, lb1 = lane & 2, lbb2 = lane & 4, lb3 = lane & 8;
+            float valpha1[2] = {salpha1 * rcj[0], salpha1 * rcj[1]}, vone1[2] = {sone1 * rcj[0], sone1 * rcj[1]};
+            asm volatile("" : "+v"(valpha1[0]), "+v"(vone1[0]), "+v"(valpha1[1]), "+v"(vone1[1]));
+            // (the lane's slot in a row of dc, from an opaque copy of the lane id: hoisted out of the sender loop these few
+            // loop-invariant values are what the register allocator spills -- and every scratch reload drains vmcnt)
+            int oln = lane;
+            asm volatile("" : "+v"(oln));
+            const int dcslot = 16 * ((oln >> 3) & 1) + 8 * ((oln >> 2) & 1) + 4 * (oln >> 5) + (oln & 3);
+            const bool dcown = !(oln & 16);
             static_for<0, 2>([&](auto sdc) {
                 MPG_CI(sd, sdc);
                 float* dcj = p.dc + ((size_t)rb * p.B * p.N + (size_t)(b * p.N + jj[sd])) * H1;
@@ -526,7 +556,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                             MPG_CI(t, tc);
                             // sign of a_i + c_j: pushed in (tile, element) order into word mm >> 1 (32 bits for tiles 0,1; 16 for tile 2)
                             constexpr int nb = mm < 2 ? 32 : 16;
-                            float gt = sel_by_bit<nb - 1 - (16 * (mm & 1) + 8 * s + 4 * u + t)>(neg1[sd][mm >> 1], valpha, vone);
+                            float gt = sel_by_bit<nb - 1 - (16 * (mm & 1) + 8 * s + 4 * u + t)>(neg1[sd][mm >> 1], valpha1[sd], vone1[sd]);
                             gt = drop_apply<DROP>(gt, wd, 16 * s + 8 * u + t, t, p.thr);
                             dz[t] = accC[mm][sd][8 * s + 4 * u + t] * gt;
                             dacc[mm][8 * s + 4 * u + t] += dz[t];
@@ -537,8 +567,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                     const float x0 = halve_add<0x124>(lbb2, ured[0], ured[1]), x1 = halve_add<0x124>(lbb2, ured[2], ured[3]);
                     float y = halve_add<0x128>(lb3, x0, x1);
                     y += __shfl_xor(y, 16, 64);
-                    const int e = lane & 15;
-                    if (!(lane & 16) && (sd == 0 || has2)) dcj[32 * mm + 16 * (e >> 3) + 8 * ((e >> 2) & 1) + 4 * h + (e & 3)] = y;
+                    if (dcown && (sd == 0 || has2)) dcj[32 * mm + dcslot] = y;
                 });
             });
         }
@@ -567,29 +596,20 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     }
 }
 
-// the variants of one operand type (the two types compile as separate translation units: edge_bwd2.hip, edge_bwd2_bf16.hip)
-template <bool F16>
+// the NEEDW pair of one dropout mode (the three modes compile as separate translation units: edge_bwd2.hip, edge_bwd2_d1.hip,
+// edge_bwd2_d2.hip -- this template is slow to compile)
+template <int D>
 int b2_launch(const MpgEdgeBwd* p, hipStream_t st) {
     const int RB = (p->N + 31) / 32;
     dim3 grid(p->B * RB * p->SC), block(256);
     const bool needw = p->stageE2 != nullptr && p->stageZ2 != nullptr;
-    const int dm = p->thr == 0 ? 0 : (p->thr == 128 ? 2 : 1);
-#define MPG_BWD_ONE(D, W)                                                                                         \
-    do {                                                                                                          \
-        MPG_ENSURE_LDS((edge_bwd_kernel<D, F16, W>), B2_LDS_BYTES);                                               \
-        hipLaunchKernelGGL((edge_bwd_kernel<D, F16, W>), grid, block, B2_LDS_BYTES, st, *p);                      \
-    } while (0)
-#define MPG_BWD_W(D)                                                                                              \
-    do { if (needw) MPG_BWD_ONE(D, true); else MPG_BWD_ONE(D, false); } while (0)
-#ifdef MPG_SINGLE_VARIANT
-    MPG_BWD_W(MPG_SINGLE_VARIANT);
-#else
-    if (dm == 0) MPG_BWD_W(0);
-    else if (dm == 1) MPG_BWD_W(1);
-    else MPG_BWD_W(2);
-#endif
-#undef MPG_BWD_W
-#undef MPG_BWD_ONE
+    if (needw) {
+        MPG_ENSURE_LDS((edge_bwd_kernel<D, true>), B2_LDS_BYTES);
+        hipLaunchKernelGGL((edge_bwd_kernel<D, true>), grid, block, B2_LDS_BYTES, st, *p);
+    } else {
+        MPG_ENSURE_LDS((edge_bwd_kernel<D, false>), B2_LDS_BYTES);
+        hipLaunchKernelGGL((edge_bwd_kernel<D, false>), grid, block, B2_LDS_BYTES, st, *p);
+    }
     return (int)hipGetLastError();
 }
 

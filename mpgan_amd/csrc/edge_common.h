@@ -101,6 +101,15 @@ MPG_DEV void tile_chain(f32x16& acc, const V (*bhi)[2], const V (*blo)[2], LH lo
 // SC_E2*SC_W3 (= SC_E3), which the aggregation folds into m_j * dscale.  (fp16 range: e1 < 16k, e2 < 1k, weights < 1k.)
 constexpr float SC_A = 4.f, SC_W2 = 16.f, SC_W3 = 64.f, SC_E2 = SC_A * SC_W2, SC_E3 = SC_E2 * SC_W3;
 
+// Dither factor of a block (jet, receiver block, sender) of the edge backward: c in [1, 2), a hash of the block index.
+// mpg_edge_bwd works on the block's gradients times c, mpg_edge_dw divides the parked dZ2 by it (edge_bwd2_impl.h).
+MPG_DEV float dither_of(uint32_t blk) {
+    uint32_t x = blk * 0x9E3779B1u + 0x7F4A7C15u;
+    x ^= x >> 15; x *= 0x85EBCA77u;
+    x ^= x >> 13;
+    return __builtin_bit_cast(float, 0x3F800000u | (x >> 9));
+}
+
 constexpr int NF3T = T2 * T3 * 2;  // W3^T image: 5 row tiles x 6 k-tiles x 2 = 60 fragments
 constexpr int NF2T = T1 * T2 * 2;  // W2^T image: 3 x 5 x 2 = 30
 constexpr int NFR2 = T2 * 2;       // B-operand fragments of a 160-feature tensor

@@ -1,0 +1,531 @@
+// Weight gradients of the fused edge network (see edge.hip for the forward, edge_bwd2_impl.h for the data-gradient kernel):
+//
+//   dW3 = s * sum_e dZ3 E2^T ;  dW2 = s * sum_e dZ2 E1^T ;  db3 = sum_e dZ3 ;  db2 = sum_e dZ2
+//
+// mpg_edge_bwd parks E2 and dZ2 in memory as the fp16 B fragments its lanes hold (one coalesced 16-byte store per lane
+// and fragment; dZ2 in units of 2^-gexp of its (jet, receiver block)).  edge_dw_kernel streams those fragments into
+// [receiver][feature] LDS images, rebuilds the cheap operands (E1 from a_i + c_j, dZ3 from dagg and the sign words),
+// fetches MFMA operands with transposing LDS reads and accumulates dW3/dW2/db3/db2 in registers over its share of the
+// edges; the per-workgroup partials are summed by a last small kernel that also undoes the fragment-order permutation of
+// the feature indices and the launch's gradient unit.
+//
+// Arithmetic: two fp16 terms per product.  The rebuilt operand (dZ3, E1) is split hi + lo, the parked one (E2, dZ2) is
+// the single fp16 value it was parked as: its rounding (2^-12 relative, independent from edge to edge) averages out over
+// the ~10^5 edges a weight gradient sums.  The contraction runs over receivers, senders AND jets, so everything is
+// brought to ONE gradient unit 2^-eG, eG = min over the launch of gexp: dZ3 is built in it; a parked dZ2 piece stays as
+// it is and its partner E1 is multiplied by 2^(eG - gexp) / c, c the block's dither factor (a jet whose gradients are
+// 2^-24 of the largest jet's drops out of the fp16 range, and of any fp32 sum with that jet too).
+#include "edge_common.h"
+
+#ifndef MPG_DW_EXP
+#define MPG_DW_EXP 0  // experiment bits (tools/ubench/dw_bench.hip): 1 consumers idle, 2 builders idle, 4 no staged loads, 8 no LDS writes
+#endif
+
+namespace {
+
+// The contraction runs over edges = (receiver, sender): per block (32 receivers of one jet, one sender) the
+// four operand tensors are needed as [feature][receiver], but the backward (and any rebuild) naturally
+// produces [receiver][8 features] pieces.  So the block's operands are laid down in LDS as plain
+// [receiver][feature] fp16 images and the MFMA fragments are fetched with gfx950's transposing LDS read
+// (ds_read_b64_tr_b16: a 16-lane group reads 4 receivers x 16 features and each lane receives one feature's
+// 4 receivers).  Row strides are odd multiples of 64 B, which makes those reads bank-conflict free.
+//
+// A workgroup is 8 waves on 4 SIMDs: waves 0-3 are CONSUMERS (each owns 10-12 of the 45 output tiles in
+// registers and only issues LDS reads + MFMAs), waves 4-7 are BUILDERS (VALU only: copy the parked E2, rescale the
+// parked dZ2, rebuild dZ3 from dagg and the sign words and E1 from a_i + c_j, sum the biases).  The images are double
+// buffered (2 x 60 KiB): builders fill block n+1 while consumers multiply block n, one barrier per block.  Every
+// builder thread owns fixed (receiver, feature chunk) pieces, keeps what it needs of dagg / a in registers and reloads
+// each parked piece for the block after next right after using it, so no builder ever waits on another.
+constexpr int DW_RS3 = 448, DW_RS2 = 320, DW_RS1 = 192;  // image row strides (bytes)
+constexpr int DW_Z3H = 0, DW_Z3L = DW_Z3H + 32 * DW_RS3, DW_E2H = DW_Z3L + 32 * DW_RS3, DW_Z2H = DW_E2H + 32 * DW_RS2,
+              DW_E1H = DW_Z2H + 32 * DW_RS2, DW_E1L = DW_E1H + 32 * DW_RS1, DW_BUF = DW_E1L + 32 * DW_RS1;
+constexpr int DW_LDS_BYTES = 2 * DW_BUF;  // 122,880
+static_assert(DW_LDS_BYTES <= 163840, "dW images must fit the LDS twice");
+
+struct DwTile { int prod, m, n; };  // prod 0: dW3 (A = Z3 tile m, B = E2 tile n); 1: dW2 (A = Z2, B = E1)
+// consumer wave w owns tiles [0,12) [12,23) [23,34) [34,45)
+__device__ constexpr DwTile DW_TILES[45] = {
+    {0,0,0},{0,0,1},{0,0,2},{0,0,3},{0,0,4},{0,1,0},{0,1,1},{0,1,2},{0,1,3},{0,1,4},{1,0,0},{1,0,1},
+    {0,2,0},{0,2,1},{0,2,2},{0,2,3},{0,2,4},{0,3,0},{0,3,1},{0,3,2},{0,3,3},{0,3,4},{1,0,2},
+    {0,4,0},{0,4,1},{0,4,2},{0,4,3},{0,4,4},{0,5,0},{0,5,1},{0,5,2},{0,5,3},{0,5,4},{1,1,0},
+    {1,1,1},{1,1,2},{1,2,0},{1,2,1},{1,2,2},{1,3,0},{1,3,1},{1,3,2},{1,4,0},{1,4,1},{1,4,2}};
+
+constexpr bool dw_same_rows(int t, int u) { return DW_TILES[t].prod == DW_TILES[u].prod && DW_TILES[t].m == DW_TILES[u].m; }
+constexpr bool dw_leader(int t, int begin) { return t == begin || !dw_same_rows(t, t - 1); }
+constexpr int dw_group_end(int t, int end) {
+    int e = t + 1;
+    while (e < end && dw_same_rows(t, e)) ++e;
+    return e;
+}
+
+MPG_DEV int feat_of_fi(int fi) {  // fragment-order index -> feature
+    const int ms = fi >> 4, hh = (fi >> 3) & 1, jj = fi & 7;
+    return 32 * (ms >> 1) + 16 * (ms & 1) + 8 * (jj >> 2) + 4 * hh + (jj & 3);
+}
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+// fragment (32 features starting at byte column `col`, receivers 16s .. 16s+15) of an image: two transposed reads
+MPG_DEV f16x8 dw_frag(uint32_t lane_addr, int off, int rs) {
+    typedef __attribute__((address_space(3))) s16x4* P;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((P)(uintptr_t)(lane_addr + (uint32_t)off));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((P)(uintptr_t)(lane_addr + (uint32_t)(off + 4 * rs)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(f16x8, v);
+}
+
+template <int BEGIN, int END>
+MPG_DEV void dw_consume(f32x16* acc, uint32_t buf, int lane) {
+    // lane 4q+p of 16-lane group g supplies row (8 (g>>1) + q), feature columns 16 (g&1) + 4p .. +3 of the block
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int row = 8 * (g >> 1) + q, col = (16 * (g & 1) + 4 * pp) * 2;
+    // one opaque base per image family, everything else is an immediate offset
+    uint32_t bz3 = buf + DW_Z3H + row * DW_RS3 + col, be2 = buf + DW_E2H + row * DW_RS2 + col;
+    uint32_t bz2 = buf + DW_Z2H + row * DW_RS2 + col, be1 = buf + DW_E1H + row * DW_RS1 + col;
+    asm volatile("" : "+v"(bz3), "+v"(be2), "+v"(bz2), "+v"(be1));
+    // tiles sharing their A rows (same product and m) form a group: per k-step the A fragments are read once
+    // and only the B fragments change -- a few fragment registers live beside the 160-192 accumulators.
+    // dW3: A = dZ3 (hi, lo), B = E2 ; dW2: A = dZ2, B = E1 (hi, lo)
+    static_for<BEGIN, END>([&](auto tc) {
+        MPG_CI(t, tc);
+        if constexpr (dw_leader(t, BEGIN)) {
+            constexpr DwTile d = DW_TILES[t];
+            constexpr int ge = dw_group_end(t, END);
+            constexpr int rsa = d.prod == 0 ? DW_RS3 : DW_RS2, rsb = d.prod == 0 ? DW_RS2 : DW_RS1;
+            constexpr int alo = DW_Z3L - DW_Z3H, blo = DW_E1L - DW_E1H;
+            uint32_t ba = d.prod == 0 ? bz3 : bz2, bb = d.prod == 0 ? be2 : be1;
+            // a fresh (opaque) base per group: otherwise the B fragments of a whole product (80 registers) are kept
+            // for the next group and the accumulators spill
+            asm volatile("" : "+v"(ba), "+v"(bb));
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f16x8 ah = dw_frag(ba, 16 * s * rsa + 64 * d.m, rsa);
+                f16x8 al = ah;
+                if constexpr (d.prod == 0) al = dw_frag(ba, alo + 16 * s * rsa + 64 * d.m, rsa);
+                static_for<t, ge>([&](auto uc) {
+                    MPG_CI(u, uc);
+                    constexpr int n = DW_TILES[u].n;
+                    const f16x8 bh = dw_frag(bb, 16 * s * rsb + 64 * n, rsb);
+                    if constexpr (d.prod == 0) {
+                        acc[u - BEGIN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[u - BEGIN], 0, 0, 0);
+                    } else {
+                        const f16x8 bl = dw_frag(bb, blo + 16 * s * rsb + 64 * n, rsb);
+                        acc[u - BEGIN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[u - BEGIN], 0, 0, 0);
+                    }
+                    acc[u - BEGIN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[u - BEGIN], 0, 0, 0);
+                });
+            }
+        }
+    });
+}
+
+template <int BEGIN, int END>
+MPG_DEV void dw_store(const f32x16* acc, float* part3, float* part2, int lane) {
+    const int cc = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int t = BEGIN; t < END; ++t) {
+        const DwTile d = DW_TILES[t];
+        float* dst = d.prod == 0 ? part3 : part2;
+        const int ncol = d.prod == 0 ? H2 : H1;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int row = 32 * d.m + 8 * (k >> 2) + 4 * hh + (k & 3);
+            dst[(size_t)row * ncol + 32 * d.n + cc] = acc[t - BEGIN][k];
+        }
+    }
+}
+
+// A workgroup walks at most 64 blocks (the launcher sizes the grid for that); their valid-sender bits are one
+// ballot taken at kernel start, so stepping to the next unmasked block is pure scalar arithmetic -- no memory
+// access and no loop inside the pipelined loops (either would make the compiler drain vmcnt there).
+// The blocks of a workgroup are STRIDED over the launch (slot t of workgroup g is block g + t * gridDim.x): a contiguous
+// range would be one jet's senders, and a launch would last as long as its fullest jet (masks sorted to the end of a
+// jet left whole workgroups idle at N = 150); strided, every workgroup samples all jets.
+MPG_DEV int dw_block(int t) { return (int)blockIdx.x + t * (int)gridDim.x; }
+MPG_DEV unsigned long long dw_valid_bits(const MpgEdgeDw& p, int blk0, int blk1) {   // over the slots [blk0, blk1)
+    const int RB = (p.N + 31) / 32, t = blk0 + (int)(threadIdx.x & 63), x = dw_block(t);
+    bool ok = t < blk1;
+    if (ok && p.mask != nullptr) ok = p.mask[((x / p.N) / RB) * p.N + x % p.N] != 0.f;
+    return __ballot(ok);
+}
+MPG_DEV int dw_next_valid(unsigned long long bits, int blk0, int blk, int blk1) {
+    const int d = blk - blk0;
+    const unsigned long long rem = d < 64 ? bits >> d : 0ull;
+    return rem ? blk + __builtin_ctzll(rem) : blk1;
+}
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL load
+// (vmcnt(0)), which would expose the latency of the staged pieces requested a block ahead.
+MPG_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The per-workgroup loop of one consumer wave (its output tiles BEGIN..END of DW_TILES).  Instantiated per
+// role: a run-time branch around the MFMA section would make the accumulators merge at every join.
+template <int BEGIN, int END>
+MPG_DEV void dw_consumer(const MpgEdgeDw& p, int blk0, int blk1, unsigned long long vbits) {
+    const int lane = threadIdx.x & 63;
+    f32x16 acc[END - BEGIN];
+#pragma unroll
+    for (int t = 0; t < END - BEGIN; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    int cur = dw_next_valid(vbits, blk0, blk0, blk1), it = 0;
+    lds_barrier();  // block `cur` is in buffer 0
+    while (cur < blk1) {
+        if (!(MPG_DW_EXP & 1)) dw_consume<BEGIN, END>(acc, lds0 + (it & 1) * DW_BUF, lane);
+        lds_barrier();
+        cur = dw_next_valid(vbits, blk0, cur + 1, blk1);
+        ++it;
+    }
+    float* part = p.part + (size_t)blockIdx.x * (H3 * H2 + H2 * H1 + H3 + H2);
+    dw_store<BEGIN, END>(acc, part, part + H3 * H2, lane);
+}
+
+// keep bits (bit k = element k) of one 8-feature chunk: features 32 tile + f0 + {0..3, 8..11} of edge row `erow`
+template <int DM>
+MPG_DEV uint32_t dw_chunk_keep(uint32_t seed_lo, uint32_t seed_hi, uint32_t tag, uint32_t erow, int tile, int f0, uint32_t thr) {
+    if constexpr (DM == 2) {
+        const uint32_t w = drop_word(seed_lo, seed_hi, tag, erow, DROP_BIT_GRP + (uint32_t)tile) >> f0;
+        return (w & 0xfu) | ((w >> 4) & 0xf0u);  // bits f0..f0+3 and f0+8..f0+11
+    } else if constexpr (DM == 1) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t w = drop_word(seed_lo, seed_hi, tag, erow, (uint32_t)(8 * tile + (f0 >> 2) + 2 * u));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) m |= (drop_keep(w, t, thr) ? 1u : 0u) << (4 * u + t);
+        }
+        return m;
+    } else {
+        return 0xffu;
+    }
+}
+
+// min over the launch of the gradient-unit exponents: the launch's unit (every wave that needs it computes it itself)
+MPG_DEV int dw_launch_exp(const MpgEdgeDw& p) {
+    const int n = p.B * ((p.N + 31) / 32);
+    int e = 0x7fffffff;
+    for (int t = (int)(threadIdx.x & 63); t < n; t += 64) e = min(e, p.gexp[t]);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) e = min(e, __shfl_xor(e, o, 64));
+    return __builtin_amdgcn_readfirstlane(e);
+}
+
+template <int DROP>
+MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsigned long long vbits) {
+    const int bt = threadIdx.x - 256;     // builder thread 0..255
+    const int r = bt & 31, cg = bt >> 5;  // receiver row of the images, chunk group: chunks cg, cg + 8, cg + 16
+    const int RB = (p.N + 31) / 32;
+    // chunk c = 2 frag + h holds fragment-order features 8c .. 8c+7 = registers 8s .. 8s+7 of tile (c >> 2) of
+    // lane (r, h):  s = (c >> 1) & 1 and h = c & 1 are the same for all chunks of this thread
+    const int cs = (cg >> 1) & 1, ch = cg & 1;
+    const int f0 = 16 * cs + 4 * ch;  // features of chunk c: 32 (c >> 2) + f0 + {0..3, 8..11}
+
+    uint32_t seed_lo = 0, seed_hi = 0;
+    if (DROP) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+
+    float dreg[3][8], areg[2][8];   // dagg / a of this thread's Z3 / E1 chunks, current jet (raw)
+    float db3[3][8], db2[3][8];
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { db3[n][k] = 0.f; db2[n][k] = 0.f; }
+    uint32_t sw[3];                 // sign words of the Z3 chunks' lanes
+    float4 cv[2][2];                // c_j of the E1 chunks
+    f16x8 eh[3];                    // parked E2 pieces
+    f16x8 zh[3];                    // parked dZ2 pieces (in their block's gradient unit)
+    // gradient units: the launch's exponent and, in lane t, the exponent of slot t's (jet, receiver block)
+    const int eG = dw_launch_exp(p);
+    const float unitG = __builtin_bit_cast(float, (uint32_t)(eG + 127) << 23);   // 2^eG (|eG| <= 100)
+    int eslot = eG;
+    {
+        const int t = blk0 + (int)(threadIdx.x & 63);
+        if (t < blk1) eslot = p.gexp[dw_block(t) / p.N];
+    }
+
+    const bool third = cg < 4;  // chunk groups 0..3 own a third 160-feature piece and a second E1 chunk
+    auto e1tile = [&](int n) { return n == 0 || third ? 2 * n + (cg >> 2) : (cg >> 2); };  // 0..2
+    // Threads of chunk groups 4..7 have no third piece of the 160-feature tensors (and no second E1 chunk): they
+    // redo their previous piece instead (same data to the same place), which keeps the whole build free of
+    // branches -- inside a branch the compiler waits for ALL outstanding loads, i.e. for the prefetches too.
+    auto chunk160 = [&](int n) { return n < 2 || third ? cg + 8 * n : cg + 8; };
+
+    // Every global read is a raw buffer load: resource in SGPRs, block-dependent part as scalar offset, one
+    // thread-constant VGPR offset per stream (plain pointers cost two VGPRs of address per load in flight).
+    const int nblk = p.B * RB * p.N;
+    const __amdgpu_buffer_rsrc_t rE = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.stageE2), 0, nblk * (NFR2 * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.stageZ2), 0, nblk * (NFR2 * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int*>(p.sign3), 0, nblk * (T3 * 32 * 4), 0x00020000);
+    const int ldac = p.ld_ac ? p.ld_ac : H1;
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.c), 0, p.B * p.N * ldac * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.B * p.N * ldac * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dagg), 0, p.B * p.N * p.ld_dagg * 4, 0x00020000);
+    int vo160[3];  // byte offset of this thread's piece n inside a 10 KiB block
+#pragma unroll
+    for (int n = 0; n < 3; ++n) vo160[n] = (chunk160(n) * 32 + r) * 16;
+    const int voS = (32 * ch + r) * 4;
+    int voE1[2];   // byte offset of E1 chunk n's first feature inside a 96-float row of a / c
+#pragma unroll
+    for (int n = 0; n < 2; ++n) voE1[n] = (32 * e1tile(n) + f0) * 4;
+    auto ldb4 = [&](__amdgpu_buffer_rsrc_t rs, int vo, int so) {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
+    };
+
+    // dagg / a of the (jet, receiver block) of block `blk`, RAW: nothing may be computed from a prefetched value
+    // before the block that needs it (a use right behind the load would make every iteration wait for its
+    // youngest load, i.e. drain the whole prefetch queue).  Padding receivers read row 0 and get scale 0.
+    float dscl = 0.f;  // agg_scale * dscale * 2^eG, or 0 for a padding receiver -- belongs to the jet in dreg
+    auto load_jet = [&](int blk) {
+        const int brb = blk / p.N, rb = brb % RB, b = brb / RB, ii = rb * 32 + r;
+        const bool ok = ii < p.N;
+        dscl = ok ? p.agg_scale * p.dscale * unitG : 0.f;
+        const int rowD = (ok ? ii : 0) * p.ld_dagg * 4 + (32 * (cg >> 2) + f0) * 4, soD = b * p.N * p.ld_dagg * 4;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const float4 u = ldb4(rD, rowD + 256 * n, soD), v = ldb4(rD, rowD + 256 * n + 32, soD);
+            dreg[n][0] = u.x; dreg[n][1] = u.y; dreg[n][2] = u.z; dreg[n][3] = u.w;
+            dreg[n][4] = v.x; dreg[n][5] = v.y; dreg[n][6] = v.z; dreg[n][7] = v.w;
+        }
+        const int rowA = (ok ? ii : 0) * ldac * 4, soA = b * p.N * ldac * 4;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const float4 u = ldb4(rA, rowA + voE1[n], soA), v = ldb4(rA, rowA + voE1[n] + 32, soA);
+            areg[n][0] = u.x; areg[n][1] = u.y; areg[n][2] = u.z; areg[n][3] = u.w;
+            areg[n][4] = v.x; areg[n][5] = v.y; areg[n][6] = v.z; areg[n][7] = v.w;
+        }
+    };
+    unsigned int nbw = 0xffffffffu;  // this receiver's neighbour word holding the block's sender (k-NN graphs)
+    const __amdgpu_buffer_rsrc_t rN = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int*>(p.nbr), 0, p.nbr ? p.B * p.N * ((p.N + 31) >> 5) * 4 : 0, 0x00020000);
+    auto load_nb = [&](int blk) {  // (with no graph the resource is empty: the load returns 0 and is ignored below)
+        const int j = blk % p.N, brb = blk / p.N, rb = brb % RB, b = brb / RB, ii = rb * 32 + r;
+        nbw = __builtin_amdgcn_raw_buffer_load_b32(rN, ((b * p.N + (ii < p.N ? ii : 0)) * ((p.N + 31) >> 5) + (j >> 5)) * 4, 0, 0);
+    };
+    auto load_sw = [&](int blk) {  // word (tile >> 1) = n of lane (r, h)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) sw[n] = __builtin_amdgcn_raw_buffer_load_b32(rS, voS, blk * (T3 * 32 * 4) + n * 256, 0);
+    };
+    auto load_c = [&](int blk) {
+        const int j = blk % p.N, b = (blk / p.N) / RB, so = (b * p.N + j) * ldac * 4;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) { cv[n][0] = ldb4(rC, voE1[n], so); cv[n][1] = ldb4(rC, voE1[n] + 32, so); }
+    };
+    // parked pieces: chunk c of receiver r is element c * 32 + r of a block of 640 16-byte pieces
+    auto load_e2 = [&](int blk, int n) {
+        eh[n] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rE, vo160[n], blk * (NFR2 * 1024), 0));
+    };
+    auto load_z2 = [&](int blk, int n) {
+        zh[n] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rZ, vo160[n], blk * (NFR2 * 1024), 0));
+    };
+
+    // build the block of slot `slot` into buffer `buf`; right after a parked piece is used, request the one of slot `pre_slot`
+    auto build = [&](int slot, char* buf, int pre_slot) {
+        const bool exp_noload = (MPG_DW_EXP & 4) && p.N != 12345, exp_nowrite = (MPG_DW_EXP & 8) && p.N != 12345;
+        const int blk = dw_block(slot), pre = dw_block((MPG_DW_EXP & 16) ? blk0 : pre_slot);
+        const int j = blk % p.N, brb = blk / p.N, rb = brb % RB, b = brb / RB, ii = rb * 32 + r;
+        const uint32_t erow = (uint32_t)((b * p.N + ii) * p.N + j);
+        // dZ2 goes into the image AS PARKED, in its block's unit 2^-e / c (c: the block's dither factor): rounded once, by
+        // mpg_edge_bwd.  What takes it to the launch's unit, funit = 2^(eG - e) / c <= 1, multiplies the OTHER operand of its
+        // product instead -- E1 below, built in fp32 anyway -- and the bias sums, which are fp32
+        const int de = eG - __builtin_amdgcn_readlane(eslot, slot - blk0);
+        const float funit = __builtin_bit_cast(float, (uint32_t)max(de + 127, 0) << 23) * __builtin_amdgcn_rcpf(dither_of((uint32_t)blk));
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const int c = chunk160(n);
+            if (!exp_nowrite) *reinterpret_cast<f16x8*>(buf + DW_Z2H + r * DW_RS2 + c * 16) = zh[n];
+            const float take = n < 2 || third ? funit : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) db2[n][k] += take * (float)zh[n][k];
+            if (!exp_noload) load_z2(pre, n);
+        }
+        // E2: as parked
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const int c = chunk160(n);
+            if (!exp_nowrite) *reinterpret_cast<f16x8*>(buf + DW_E2H + r * DW_RS2 + c * 16) = eh[n];
+            else if (eh[n][0] == (_Float16)123.f) db2[0][0] += (float)eh[n][1];
+            if (!exp_noload) load_e2(pre, n);
+        }
+        // dZ3 = dagg * slope(sign bit) * keep3, in the launch's gradient unit, hi + lo
+        const float in_set = (p.nbr == nullptr || ((nbw >> (j & 31)) & 1u)) ? 1.f : 0.f;
+        const float dscl_1 = dscl * in_set, dscl_a = dscl * p.alpha * in_set;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const int m = 2 * n + (cg >> 2), c = cg + 8 * n;
+            float v[8];
+            const uint32_t keep = dw_chunk_keep<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, m, f0, p.thr);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t neg = (sw[n] >> (31 - (16 * (m & 1) + 8 * cs + k))) & 1u;
+                float x = dreg[n][k] * (neg ? dscl_a : dscl_1);
+                if (DROP && !((keep >> k) & 1u)) x = 0.f;
+                v[k] = x;
+                db3[n][k] += x;
+            }
+            f16x8 hh, ll;
+            split8(v, hh, ll);
+            if (!exp_nowrite) {
+                *reinterpret_cast<f16x8*>(buf + DW_Z3H + r * DW_RS3 + c * 16) = hh;
+                *reinterpret_cast<f16x8*>(buf + DW_Z3L + r * DW_RS3 + c * 16) = ll;
+            } else if (hh[0] == (_Float16)123.f) db2[0][0] += (float)ll[1];
+        }
+        if (!exp_noload) { load_sw(pre); load_nb(pre); }
+        // E1 = keep1 * lrelu(a_i + c_j), times funit (see dZ2)   (chunk groups 4..7: the second chunk repeats the first)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int q = e1tile(n), c = 4 * q + (cg & 3);
+            const float cc[8] = {cv[n][0].x, cv[n][0].y, cv[n][0].z, cv[n][0].w, cv[n][1].x, cv[n][1].y, cv[n][1].z, cv[n][1].w};
+            float v[8];
+            const uint32_t keep = dw_chunk_keep<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, q, f0, p.thr);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float x = lrelu(areg[n][k] + cc[k], p.alpha) * funit;
+                if (DROP && !((keep >> k) & 1u)) x = 0.f;
+                v[k] = x;
+            }
+            f16x8 hh, ll;
+            split8(v, hh, ll);
+            if (!exp_nowrite) {
+                *reinterpret_cast<f16x8*>(buf + DW_E1H + r * DW_RS1 + c * 16) = hh;
+                *reinterpret_cast<f16x8*>(buf + DW_E1L + r * DW_RS1 + c * 16) = ll;
+            } else if (hh[0] == (_Float16)123.f) db2[0][0] += (float)ll[1];
+        }
+        if (!exp_noload) { load_c(pre); load_jet(pre); }
+    };
+
+    int cur = dw_next_valid(vbits, blk0, blk0, blk1), it = 0;
+    int nxt = dw_next_valid(vbits, blk0, cur + 1, blk1);
+    // `pre` is clamped to the last block of the range: past the end the prefetches fetch that block again, unused
+    if (cur < blk1) {
+        const int b0 = dw_block(cur);
+        load_jet(b0); load_sw(b0); load_nb(b0); load_c(b0);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) { load_e2(b0, n); load_z2(b0, n); }
+        build(cur, smem, min(nxt, blk1 - 1));
+    }
+    lds_barrier();
+    while (cur < blk1) {
+        const int nxt2 = dw_next_valid(vbits, blk0, nxt + 1, blk1);
+        if (nxt < blk1 && !(MPG_DW_EXP & 2)) build(nxt, smem + ((it + 1) & 1) * DW_BUF, min(nxt2, blk1 - 1));
+        lds_barrier();
+        cur = nxt;
+        nxt = nxt2;
+        ++it;
+    }
+
+    // bias sums: add the 32 receivers (one half-wave per chunk group), fragment-order index fi = 8 c + k
+    float* part = p.part + (size_t)blockIdx.x * (H3 * H2 + H2 * H1 + H3 + H2);
+    float* pb3 = part + H3 * H2 + H2 * H1, *pb2 = pb3 + H3;
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float x = db3[n][k], y = db2[n][k];
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) { x += __shfl_xor(x, o, 64); y += __shfl_xor(y, o, 64); }
+            const int c = cg + 8 * n;
+            if (r == 0) {
+                pb3[8 * c + k] = x;
+                if (c < 2 * NFR2) pb2[8 * c + k] = y;  // (the repeated third piece added zeros)
+            }
+        }
+}
+
+template <int DROP>
+__global__ __launch_bounds__(512, 1) void edge_dw_kernel(const MpgEdgeDw p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int RB = (p.N + 31) / 32;
+    const int nblk = p.B * RB * p.N;
+    const int blk0 = 0, blk1 = (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // slots of this workgroup
+    const unsigned long long vbits = dw_valid_bits(p, blk0, blk1);
+    if (w == 0) dw_consumer<0, 12>(p, blk0, blk1, vbits);
+    else if (w == 1) dw_consumer<12, 23>(p, blk0, blk1, vbits);
+    else if (w == 2) dw_consumer<23, 34>(p, blk0, blk1, vbits);
+    else if (w == 3) dw_consumer<34, 45>(p, blk0, blk1, vbits);
+    else dw_builder<DROP>(p, smem, blk0, blk1, vbits);
+}
+
+// out = scale * 2^-eG * sum over workgroup partials, feature indices mapped back from fragment order.
+// 32 outputs x 8 partial-slices per block: the 256 partials of an output are read by 8 threads.
+__global__ __launch_bounds__(256) void edge_dw_reduce(const float* __restrict__ part, int nwg, float scale3, float scale, int accumulate,
+                                                      const int* __restrict__ gexp, int ngexp,
+                                                      float* __restrict__ dW3, float* __restrict__ dW2,
+                                                      float* __restrict__ db3, float* __restrict__ db2) {
+    __shared__ float red[8][32];
+    __shared__ int emin[4];
+    {   // the launch's gradient unit (as dw_launch_exp)
+        int e = 0x7fffffff;
+        for (int t = threadIdx.x; t < ngexp; t += 256) e = min(e, gexp[t]);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) e = min(e, __shfl_xor(e, o, 64));
+        if ((threadIdx.x & 63) == 0) emin[threadIdx.x >> 6] = e;
+    }
+    constexpr int PER = H3 * H2 + H2 * H1 + H3 + H2;
+    const int ix = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + ix;
+    float s = 0.f;
+    if (idx < PER) {   // (four independent partial sums: a thread's loads are in flight together; fixed summation order)
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int g = sl;
+        for (; g + 24 < nwg; g += 32) {
+            s0 += part[(size_t)g * PER + idx]; s1 += part[(size_t)(g + 8) * PER + idx];
+            s2 += part[(size_t)(g + 16) * PER + idx]; s3 += part[(size_t)(g + 24) * PER + idx];
+        }
+        for (; g < nwg; g += 8) s0 += part[(size_t)g * PER + idx];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[sl][ix] = s;
+    __syncthreads();
+    if (sl != 0 || idx >= PER) return;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += red[k][ix];
+    s *= __builtin_bit_cast(float, (uint32_t)(127 - min(min(emin[0], emin[1]), min(emin[2], emin[3]))) << 23);
+    if (idx < H3 * H2) {
+        const int r3 = idx / H2, c2 = idx % H2;
+        float* d = dW3 + feat_of_fi(r3) * H2 + feat_of_fi(c2);
+        *d = s * scale3 + (accumulate ? *d : 0.f);
+    } else if (idx < H3 * H2 + H2 * H1) {
+        const int k = idx - H3 * H2, r2 = k / H1, c1 = k % H1;
+        float* d = dW2 + feat_of_fi(r2) * H1 + feat_of_fi(c1);
+        *d = s * scale + (accumulate ? *d : 0.f);
+    } else if (idx < H3 * H2 + H2 * H1 + H3) {
+        float* d = db3 + feat_of_fi(idx - H3 * H2 - H2 * H1);
+        *d = s + (accumulate ? *d : 0.f);
+    } else {
+        float* d = db2 + feat_of_fi(idx - H3 * H2 - H2 * H1 - H3);
+        *d = s + (accumulate ? *d : 0.f);
+    }
+}
+
+}  // namespace
+
+extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
+    if (p->B <= 0 || p->N <= 0 || p->nwg <= 0) return -1;
+    if (!p->f16) return -8;
+    if (p->gexp == nullptr) return -9;
+    {
+        const int nblk = p->B * ((p->N + 31) / 32) * p->N;
+        if ((nblk + p->nwg - 1) / p->nwg > 64) return -5;  // a workgroup walks at most 64 blocks (one ballot of valid bits)
+    }
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(p->nwg), block(512);
+    const int dm = p->thr == 0 ? 0 : (p->thr == 128 ? 2 : 1);
+#define MPG_DW_ONE(D)                                                                                             \
+    do {                                                                                                          \
+        MPG_ENSURE_LDS((edge_dw_kernel<D>), DW_LDS_BYTES);                                                        \
+        hipLaunchKernelGGL((edge_dw_kernel<D>), grid, block, DW_LDS_BYTES, st, *p);                               \
+    } while (0)
+#ifdef MPG_SINGLE_VARIANT  // tools/ubench/dw_bench.hip: one instantiation
+    MPG_DW_ONE(MPG_SINGLE_VARIANT);
+#else
+    if (dm == 0) MPG_DW_ONE(0);
+    else if (dm == 1) MPG_DW_ONE(1);
+    else MPG_DW_ONE(2);
+#endif
+#undef MPG_DW_ONE
+    constexpr int PER = H3 * H2 + H2 * H1 + H3 + H2;
+    // (the parked E2 carries the forward's operand scale SC_E2; db3 / db2 only the gradient unit)
+    hipLaunchKernelGGL(edge_dw_reduce, dim3((PER + 31) / 32), dim3(256), 0, st, p->part, p->nwg, p->dscale / SC_E2, p->dscale, p->accumulate,
+                       p->gexp, p->B * ((p->N + 31) / 32), p->dW3, p->dW2, p->db3, p->db2);
+    return (int)hipGetLastError();
+}

@@ -247,7 +247,7 @@ class MPLayer(nn.Module):
         """Persistent weight images of this layer for the current mode (dropout scale) -- rebuilt when a
         parameter changes (``PackedMPLayer.ensure``) or on ``refresh_packed()``."""
         dscale = ops.drop_params(self.fe.dropout_p)[1] if self.training else 1.0
-        key = (dscale, ops.OPTIONS["fwd_f16"])
+        key = (dscale, ops.FWD_F16)
         cache = self.__dict__.setdefault("_pack_cache", {})
         params = tuple(l.weight for l in (*self.fe.net, *self.fn.net))
         pk = cache.get(key)

@@ -28,10 +28,11 @@ TAG_E0, TAG_E1, TAG_E2, TAG_N0, TAG_N1, TAG_N2, TAG_GENERIC = 1, 2, 3, 4, 5, 6, 
 # Read-only configuration of the arithmetic (set before building models; not step state).
 OPTIONS = {
     "skip_masked": True,      # edge forward: skip zero-masked senders (they contribute exactly 0)
-    # forward products (they decide LeakyReLU signs) split as fp16 hi/lo (~2^-21 per product);
-    # False = bf16 hi/lo (~2^-17, unlimited range).  Gradient products are always bf16 hi/lo.
-    "fwd_f16": True,
 }
+# Forward products (they decide LeakyReLU signs) are split as fp16 hi/lo with the operand scales below (~2^-21 per
+# product); the fused edge backward works in fp16 as well (csrc/edge_bwd2_impl.h).  Range: |e2| < 1023, node activations
+# < 8188, |W * dscale| < 1023 -- see INTEGRATION.md.
+FWD_F16 = True
 
 
 class DeviceState:
@@ -183,7 +184,7 @@ def linear_fwd(x, W, bias=None, *, act=False, alpha=0.2, drop=None, x2=None, w_c
     y = torch.empty((M, N), device=x.device, dtype=torch.float32)
     gemm(x, x.stride(0), W, W.stride(0), y, N, M, N, K, ak=True, bk=True, b_off=w_col0,
          A2=x2, lda2=0 if x2 is None else x2.stride(0), K1=K1, bias=bias, act=act, alpha=alpha, drop=drop,
-         resid=resid, ldr=0 if resid is None else resid.stride(0), f16=OPTIONS["fwd_f16"])
+         resid=resid, ldr=0 if resid is None else resid.stride(0), f16=FWD_F16)
     return y
 
 
@@ -335,7 +336,7 @@ class PackedMPLayer:
         # name: (W, packed rows, packed cols, transpose, scale, f16, row_split, split_cols)
         spec = {
             "W2": (W2, H2, H1, 0, dscale * SC_W2, f16, 0, 0), "W3": (W3, H3, H2, 0, dscale * SC_W3, f16, 0, 0),
-            "W3T": (W3, H2, H3, 1, dscale, False, 0, 0), "W2T": (W2, H1, H2, 1, dscale, False, 0, 0),
+            "W3T": (W3, H2, H3, 1, dscale * SC_W3, True, 0, 0), "W2T": (W2, H1, H2, 1, dscale * SC_W2, True, 0, 0),
             "V1": (V1, V1.shape[0], KN, 0, SC_WN, f16, 0, 0), "V2": (V2, V2.shape[0], V2.shape[1], 0, SC_WN, f16, 0, 0),
             "V3": (V3, out, V3.shape[1], 0, SC_WN, f16, 0, 0),
             "V3T": (V3, V3.shape[1], out, 1, 1.0, False, 0, 0), "V2T": (V2, V2.shape[1], V2.shape[0], 1, 1.0, False, 0, 0),
@@ -399,7 +400,7 @@ def chain(M, layers, *, A, lda, K1, A2=None, lda2=0, a_slabs=1, a_slab_stride=0,
     check(_lib.lib().mpg_chain(C.byref(c), _stream()), "mpg_chain")
 
 
-MAX_CHUNK_SENDERS = 188   # mpg_edge_bwd keeps the list of a chunk's unmasked senders in LDS (csrc/edge_bwd2.hip)
+MAX_CHUNK_SENDERS = 180   # mpg_edge_bwd keeps the list of a chunk's unmasked senders in LDS (csrc/edge_bwd2.hip)
 
 
 def _sender_chunks(B, N):
@@ -443,7 +444,7 @@ class FusedMPLayerFn(torch.autograd.Function):
         if x2.stride(1) != 1:
             x2 = x2.contiguous()      # ... every consumer below takes the row stride, only unit column stride matters
         m1 = None if mask is None else mask.reshape(V).contiguous()
-        f16 = OPTIONS["fwd_f16"]
+        f16 = FWD_F16
         out_f = V3.shape[0]
         if packed is None or packed.dscale != dscale or packed.f16 != f16:  # direct callers: pack for this call
             packed = PackedMPLayer((W1, W2, W3, V1, V2, V3), F, out_f, dscale, f16)
@@ -543,8 +544,9 @@ class FusedMPLayerFn(torch.autograd.Function):
         dcp = torch.empty((RB, V, H1), device=dev, dtype=torch.float32)
         stE2 = stZ2 = None
         if need_w:
-            stE2 = torch.empty((nblk, 2, H2, 32), device=dev, dtype=torch.int16)
-            stZ2 = torch.empty((nblk, 2, H2, 32), device=dev, dtype=torch.int16)
+            stE2 = torch.empty((nblk, H2, 32), device=dev, dtype=torch.float16)   # fp16 fragments as the lanes hold them
+            stZ2 = torch.empty((nblk, H2, 32), device=dev, dtype=torch.float16)
+            gexp = torch.empty((B * RB,), device=dev, dtype=torch.int32)           # gradient-unit exponent per (jet, receiver block)
         e = MpgEdgeBwd()
         e.a, e.c, e.ld_ac, e.mask = _p(ac), _p(ac, H1), 2 * H1, _p(m1)
         e.dagg, e.ld_dagg = _p(dh0), dh0.stride(0)
@@ -555,6 +557,7 @@ class FusedMPLayerFn(torch.autograd.Function):
         e.da, e.dc = _p(dap), _p(dcp)
         e.stageE2 = None if stE2 is None else C.c_void_p(stE2.data_ptr())
         e.stageZ2 = None if stZ2 is None else C.c_void_p(stZ2.data_ptr())
+        e.gexp = None if stZ2 is None else C.c_void_p(gexp.data_ptr())
         e.B, e.N, e.SC = B, N, SC
         e.alpha, e.agg_scale, e.nbr = alpha, agg_scale, nbr_p
         e.seed, e.tag_base, e.thr, e.dscale = _p(seed_t), tag, thr, dscale
@@ -576,6 +579,7 @@ class FusedMPLayerFn(torch.autograd.Function):
             d.dagg, d.ld_dagg = _p(dh0), dh0.stride(0)
             d.sign3 = C.c_void_p(sign3.data_ptr())
             d.stageE2, d.stageZ2 = C.c_void_p(stE2.data_ptr()), C.c_void_p(stZ2.data_ptr())
+            d.gexp = C.c_void_p(gexp.data_ptr())
             d.part, d.nwg = _p(part), nwg
             d.dW3, d.dW2, d.db3, d.db2, d.accumulate = _p(dW3), _p(dW2), _p(db3), _p(db2), int(direct)
             d.B, d.N = B, N

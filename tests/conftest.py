@@ -51,6 +51,41 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (den if den > 0 else 1.0))
 
 
+def summary_err(name, t, golden):
+    """Error of a tensor against a golden SUMMARY (sum, l2, 64 sampled entries; tests/gen_golden.py) as a fraction of
+    each entry's natural scale: the l2 norm and the sampled entries over max|golden[1:]| (the tensor's own magnitude),
+    the sum over the l1 norm of the tensor -- a sum of n entries that each carry a relative error eps is only known
+    to eps * sum|x_i|; against |sum x_i|, which cancellation makes arbitrarily smaller, the same eps looks like a
+    multiple of itself (a weight gradient whose entries cancel to 1.5 % of their l1 turned 3e-5 into 2e-3)."""
+    s = summarize(name, t)
+    g = np.asarray(golden, dtype=np.float64)
+    scale = np.abs(g[1:]).max()
+    scale = scale if scale > 0 else 1.0
+    l1 = float(t.detach().double().abs().sum().item())
+    return float(max(np.abs(s[1:] - g[1:]).max() / scale, abs(s[0] - g[0]) / (l1 if l1 > 0 else 1.0)))
+
+
+def assert_grads(got, ref, tol, control=None, what=""):
+    """Per-parameter gradient check against the fp64 oracle: max|got - ref| <= tol * max|ref|; a parameter whose true
+    gradient vanishes by symmetry is held to tol * 1e-3 of the network's largest gradient instead of to its own
+    rounding noise.  ``control`` = the SAME oracle evaluated in plain fp32 (the reference's arithmetic): a parameter
+    beyond ``tol`` still passes within 3x of fp32's own error against fp64 on this input -- LeakyReLU' jumps at 0,
+    so a pre-activation within rounding of zero takes the other slope in any finite arithmetic, fp32 included, and
+    in a short sum (few jets) one such edge is visible at ~1e-2."""
+    scale = max(float(np.abs(np.asarray(v)).max()) for v in ref.values())
+    bad = {}
+    for k, r in ref.items():
+        r = np.asarray(r, dtype=np.float64)
+        den = max(np.abs(r).max(), 1e-3 * scale)
+        err = float(np.abs(np.asarray(got[k], dtype=np.float64) - r).max() / den)
+        bar = tol
+        if control is not None:
+            bar = max(tol, 3.0 * float(np.abs(np.asarray(control[k], dtype=np.float64) - r).max() / den))
+        if not err <= bar:
+            bad[k] = (err, bar)
+    assert not bad, (what, bad)
+
+
 def option_case_shapes(F, out, kw):
     """State-dict shapes of an MPLayer built with the option keywords of ``gen_golden.OPTION_CASES`` (edge features,
     conditioning columns and layer widths change the first Linear of fe / fn; mpgan/model.py:169-204)."""

@@ -116,10 +116,12 @@ def test_pack_many_equals_pack_weights():
     rs = np.random.RandomState(8)
     W, pk = _holder(rs, 32, 32, dscale=2.0)
     singles = {
-        # forward images carry the power-of-two operand scales on top of the dropout scale; gradient images do not
+        # the edge network's images (forward and transposed) carry the power-of-two operand scales on top of the
+        # dropout scale and are fp16; the node network's gradient images are plain bf16
         "W2": ops.pack_weights(W["W2"], 160, 96, scale=2.0 * ops.SC_W2, f16=True),
         "W3": ops.pack_weights(W["W3"], 192, 160, scale=2.0 * ops.SC_W3, f16=True),
-        "W3T": ops.pack_weights(W["W3"], 192, 160, transpose=True, scale=2.0), "W2T": ops.pack_weights(W["W2"], 160, 96, transpose=True, scale=2.0),
+        "W3T": ops.pack_weights(W["W3"], 192, 160, transpose=True, scale=2.0 * ops.SC_W3, f16=True),
+        "W2T": ops.pack_weights(W["W2"], 160, 96, transpose=True, scale=2.0 * ops.SC_W2, f16=True),
         "V2": ops.pack_weights(W["V2"], 256, 256, scale=ops.SC_WN, f16=True), "V1T": ops.pack_weights(W["V1"], 256, 224, transpose=True),
     }
     for k, img in singles.items():

@@ -12,7 +12,18 @@ from conftest import load_golden, rel_err, summarize
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-3       # BASELINE.json north_star: "within 1e-3 rel fp32"
-TIGHT = 1e-4     # what the split-bf16 path actually delivers (margin asserted)
+TIGHT = 1e-4     # what the three-term split-16-bit products deliver (forward: measured ~1e-6; margin asserted)
+
+
+def _assert_smooth_bars(errs, what=""):
+    """Bars of a case without kinks (slope 1, or margins asserted from the oracle).  The forward and everything the
+    three-term products alone produce (the node network's parameter gradients) sit at TIGHT.  The gradients that pass
+    through the fused edge backward -- dx and the fe.* parameter gradients -- carry its two-term fp16 products (one
+    operand rounded to 11 bits: 2^-12 = 2.4e-4 relative per element, made independent from sender to sender by the
+    dither factors): the north-star bar TOL for graphs of a few edges, where nothing averages (measured up to 4e-4 on
+    9 edges); <= 9e-5 measured at B = 4 .. 256 (test_mplayer_full_size_smooth pins 2e-4; tests/probe_precision.py)."""
+    bad = {k: v for k, v in errs.items() if not v < (TOL if (k == "dx" or k.startswith("fe.")) else TIGHT)}
+    assert not bad, (what, bad, errs)
 
 
 def _dev():
@@ -224,8 +235,8 @@ def test_mplayer_slope1_strict(case):
     """LeakyReLU slope 1 makes the layer smooth: every GEMM orientation, reduction and layout of
     the forward AND backward path must then agree with the fp64 oracle to bf16x3 accuracy."""
     errs, _, _ = _run_case(*case, seed=CASES.index(case), alpha=1.0)
-    bad = {k: v for k, v in errs.items() if not v < TIGHT}
-    assert not bad, (bad, errs)
+    print("errs", errs)
+    _assert_smooth_bars(errs)
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -262,7 +273,7 @@ def test_mplayer_plain_relu_strict_when_away_from_the_kink():
             if margin < 5e-5:
                 continue
             found += 1
-            assert max(errs.values()) < TIGHT, (case, seed, margin, errs)
+            _assert_smooth_bars(errs, (case, seed, margin))
     assert found >= 5, found
 
 
@@ -276,13 +287,13 @@ def test_mplayer_small_strict_gradients():
             if margin < 5e-5:
                 continue
             found += 1
-            assert max(errs.values()) < TIGHT, (case, seed, margin, errs)
+            _assert_smooth_bars(errs, (case, seed, margin))
     assert found >= 5, found
 
 
 def test_mplayer_noskip():
     errs, _, _ = _run_case(4, 30, 32, 32, True, True, seed=42, skip=False, alpha=1.0)
-    assert max(errs.values()) < TIGHT, errs
+    _assert_smooth_bars(errs)
 
 
 @pytest.mark.parametrize("name,F,out,ci", [("g0", 32, 32, 0), ("d0", 3, 32, 1)])
@@ -352,23 +363,34 @@ def test_mplayer_knn_vs_reference_golden(name, F):
         xx = x64.float().to(_dev()).requires_grad_(True)
         y = layer(xx, mask is not None, mask)
         (y * torch.from_numpy(g["g"]).float().to(_dev())).sum().backward()
-        if strict:  # slope 1: smooth, against the oracle's kNN branch, everything at 1e-4
+        if strict:  # slope 1: smooth, against the oracle's kNN branch (bars: _assert_smooth_bars)
             import oracle
             sdo = {"L." + kk: v.clone().requires_grad_(True) for kk, v in sd64.items()}
             xo = x64.clone().requires_grad_(True)
             yo = oracle.mplayer_forward(sdo, "L", xo, mask64, sum_agg=sm, alpha=1.0, knn=(k, loops))
             (yo * torch.from_numpy(g["g"])).sum().backward()
-            assert rel_err(y.detach().cpu().numpy(), yo.detach().numpy()) < TIGHT
-            assert rel_err(xx.grad.cpu().numpy(), xo.grad.numpy()) < TIGHT
-            for kk, p in layer.named_parameters():
-                assert rel_err(p.grad.cpu().numpy(), sdo["L." + kk].grad.numpy()) < TIGHT, kk
-        else:       # default slope: the reference's own fp64 outputs (kink flips allowed on a few % of dx)
+            errs = {"y": rel_err(y.detach().cpu().numpy(), yo.detach().numpy()), "dx": rel_err(xx.grad.cpu().numpy(), xo.grad.numpy())}
+            errs.update({kk: rel_err(p.grad.cpu().numpy(), sdo["L." + kk].grad.numpy()) for kk, p in layer.named_parameters()})
+            _assert_smooth_bars(errs, name)
+        else:       # default slope: forward against the reference's own fp64 output; gradients against the fp64 oracle
+            # (pinned to that golden at 1e-10, test_oracle_golden.py) with the fp32 oracle as the control for kink flips
+            import oracle
             assert rel_err(y.detach().cpu().numpy(), g["y"]) < TIGHT
-            dx, rdx = xx.grad.cpu().numpy().astype(np.float64), g["dx"]
-            assert np.abs(dx - rdx).max() < 2e-2 * np.abs(rdx).max()
-            assert float((np.abs(dx - rdx) > 1e-3 * np.abs(rdx).max()).mean()) < 0.05
-            for kk, p in layer.named_parameters():
-                assert rel_err(summarize(kk, p.grad), g["grad__" + kk]) < 2e-2, kk
+            runs = {}
+            for dt in (torch.float64, torch.float32):
+                sdo = {"L." + kk: v.detach().clone().to(dt).requires_grad_(True) for kk, v in sd64.items()}
+                xo = x64.detach().clone().to(dt).requires_grad_(True)
+                yo = oracle.mplayer_forward(sdo, "L", xo, None if mask64 is None else mask64.to(dt), sum_agg=sm, alpha=alpha, knn=(k, loops))
+                (yo * torch.from_numpy(g["g"]).to(dt)).sum().backward()
+                runs[dt] = {"dx": xo.grad.double().numpy(), **{kk[2:]: v.grad.double().numpy() for kk, v in sdo.items()}}
+            ref, c32 = runs[torch.float64], runs[torch.float32]
+            assert rel_err(ref["dx"], g["dx"]) < 1e-9   # the oracle's kNN branch IS the reference's here
+            got = {"dx": xx.grad.double().cpu().numpy(), **{kk: p.grad.double().cpu().numpy() for kk, p in layer.named_parameters()}}
+            off = lambda a, b: float((np.abs(a - b) > 1e-3 * np.abs(b).max()).mean())
+            errs = {kk: rel_err(got[kk], ref[kk]) for kk in ref}
+            frac = {kk: off(got[kk], ref[kk]) for kk in ref}
+            control = {kk: (rel_err(c32[kk], ref[kk]), off(c32[kk], ref[kk])) for kk in ref}
+            _assert_gradients_up_to_kink_flips(errs, frac, control, None)
 
 
 def test_mplayer_knn_n150_and_dropout():
@@ -402,8 +424,11 @@ def test_mplayer_full_size_smooth():
     """BASELINE config 2 (B = 256, N = 30, F = 32) with slope 1 (no kink): every product, reduction and layout of
     forward and backward at full size, strict."""
     errs, _, _ = _run_case(256, 30, 32, 32, True, True, seed=7, alpha=1.0)
-    bad = {k: v for k, v in errs.items() if not v < TIGHT}
-    assert not bad, (bad, errs)
+    print("full-size smooth errors", errs)
+    _assert_smooth_bars(errs)
+    # over the ~1.4e5 edges of this batch the independent roundings of the two-term products average out: weight
+    # gradients of the edge network well inside the bar
+    assert max(v for k, v in errs.items() if k == "dx" or k.startswith("fe.")) < 2e-4, errs
 
 
 def test_mplayer_full_size():
@@ -482,10 +507,10 @@ def test_mplayer_dropout_exact(p_drop):
     xo = x64.clone().requires_grad_(True)
     yo = oracle.mplayer_forward(sdo, "L", xo, mask64, alpha=1.0, p=thr / 256.0, keeps=keeps)
     (yo * g64).sum().backward()
-    assert rel_err(y.detach().cpu().numpy(), yo.detach().numpy()) < TIGHT
-    assert rel_err(x.grad.cpu().numpy(), xo.grad.numpy()) < TIGHT
-    for k, p in layer.named_parameters():
-        assert rel_err(p.grad.cpu().numpy(), sdo["L." + k].grad.numpy()) < TIGHT, k
+    errs = {"y": rel_err(y.detach().cpu().numpy(), yo.detach().numpy()), "dx": rel_err(x.grad.cpu().numpy(), xo.grad.numpy())}
+    errs.update({k: rel_err(p.grad.cpu().numpy(), sdo["L." + k].grad.numpy()) for k, p in layer.named_parameters()})
+    print("errs", errs)
+    _assert_smooth_bars(errs, p_drop)
 
 
 def _option_cases():

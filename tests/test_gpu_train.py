@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, summarize, rel_err
+from conftest import load_golden, summarize, rel_err, summary_err, assert_grads
 
 pytestmark = pytest.mark.gpu
 
@@ -55,11 +55,11 @@ def test_train_step_vs_reference_golden():
         ts._seg_D()
         if it == 0:
             for k, p in D.named_parameters():
-                assert rel_err(summarize(k, p.grad), g["gradD__" + k]) < 1e-3, k
+                assert summary_err(k, p.grad, g["gradD__" + k]) < 1e-3, k
         ts._seg_G()
         if it == 0:
             for k, p in G.named_parameters():
-                assert rel_err(summarize(k, p.grad), g["gradG__" + k]) < 1e-3, k
+                assert summary_err(k, p.grad, g["gradG__" + k]) < 1e-3, k
         ts._seg_end()
         assert abs(float(ts.D_loss) - float(g[f"D_loss{it}"])) < 1e-4 * abs(float(g[f"D_loss{it}"]))
         assert abs(float(ts.G_loss) - float(g[f"G_loss{it}"])) < 1e-4 * abs(float(g[f"G_loss{it}"]))
@@ -69,17 +69,23 @@ def test_train_step_vs_reference_golden():
             assert rel_err(summarize(k, p.data), g[f"post{net}__" + k]) < 1e-4, (net, k)
     # ... and the UPDATES themselves (post - initial on the sum and the 64 samples; the l2 entry is not linear):
     # a value check at 1e-4 of max|w| would let a 10 % error of a ~1e-4 step through
-    _assert_updates_match(init, {"D": D, "G": G}, g)
+    # yardstick for the updates: the oracle's own two iterations in plain fp32 (the reference's arithmetic)
+    from oracle import train_ref as T
+    sdD = T.init_state_dict(T.mpgan_param_shapes(False), 42, torch.float32)
+    sdG = T.init_state_dict(T.mpgan_param_shapes(True), 41, torch.float32)
+    stD, stG = {}, {}
+    f32 = lambda a: torch.from_numpy(np.asarray(a)).float()
+    for it in range(2):
+        T.train_iteration("mpgan", sdD, sdG, stD, stG, f32(g["data"]), f32(g["labels"]), f32(g["noise_D"]), f32(g["noise_G"]),
+                          float(g["lr_d"]), float(g["lr_g"]))
+    _assert_updates_match(init, {"D": dict(D.named_parameters()), "G": dict(G.named_parameters())}, g, control={"D": sdD, "G": sdG})
 
 
-def _assert_updates_match(init, nets, g, tol=2e-2, outliers=0.02):
-    """RMSprop's first steps are ~ +-lr / sqrt(1 - alpha) whatever the gradient's size, so an update is off by more
-    than `tol` of the largest one only where a gradient entry is within rounding of zero (its sign decides the
-    step): allow `outliers` of the sampled entries for that, nothing else."""
+def _count_update_outliers(init, nets, g, tol):
     lin = np.r_[0, 2:66]
     n_bad = n_all = 0
-    for net, mod in nets.items():
-        for k, p in mod.named_parameters():
+    for net, params in nets.items():
+        for k, p in params.items():
             d_ours = (summarize(k, p.data) - summarize(k, init[(net, k)]))[lin]
             d_ref = (g[f"post{net}__" + k] - summarize(k, init[(net, k)]))[lin]
             # (the golden's initial values are the same tensors: init_state_dict is a function of name and seed;
@@ -87,7 +93,20 @@ def _assert_updates_match(init, nets, g, tol=2e-2, outliers=0.02):
             scale = np.abs(d_ref[1:]).max()
             bad = np.abs(d_ours[1:] - d_ref[1:]) > tol * scale
             n_bad += int(bad.sum()); n_all += bad.size
-    assert n_bad <= outliers * n_all, (n_bad, n_all)
+    return n_bad, n_all
+
+
+def _assert_updates_match(init, nets, g, control, tol=1e-3):
+    """Parameter UPDATES of two iterations against the reference's (fp64 golden), sampled entries, at the north-star
+    1e-3 of the largest update of each tensor.  RMSprop's first steps are ~ +-lr / sqrt(1 - alpha) whatever the
+    gradient's size, so where a gradient entry is within rounding of zero its SIGN decides a full-size step -- in any
+    finite arithmetic.  The yardstick is therefore the oracle's own iteration in plain fp32 (``control``: its
+    parameters after the same two iterations): entries off by more than ``tol`` may not be more than 3x as many as
+    fp32 itself shows against the golden (+ 0.2 % of the sample for Poisson noise)."""
+    n_bad, n_all = _count_update_outliers(init, nets, g, tol)
+    c_bad, _ = _count_update_outliers(init, {n: {k: v for k, v in control[n].items() if k in nets[n]} for n in nets}, g, tol)
+    print("update entries beyond", tol, ": HIP", n_bad, "fp32 oracle", c_bad, "of", n_all)
+    assert n_bad <= 3 * c_bad + 0.002 * n_all, (n_bad, c_bad, n_all)
 
 
 def test_graph_replay_equals_eager():
@@ -204,28 +223,28 @@ def test_train_step_n150_vs_oracle():
     ts._seg_D()
     # (labels: float32(n) * float32(1/N) times N truncates to n in fp32 -- the reference's arithmetic -- but for some n
     # falls a hair below n in fp64; the oracle gets the fp32 meaning)
+    # control: the same oracle iteration in plain fp32 (the reference's arithmetic) from the same parameters
+    c32 = lambda sd: {k: v.float() for k, v in sd.items()}
+    _, _, cD, cG = T.train_iteration("mpgan", c32(sdD), c32(sdG), {}, {}, data.float(), labels.float(), nD.float(), nG.float(),
+                                     0.0, train.LR["g"][1], return_grads=True)
     dl, gl, gD, gG = T.train_iteration("mpgan", sdD, sdG, {}, {}, data.double(), labels.double() + 1e-7, nD.double(),
                                        nG.double(), 0.0, train.LR["g"][1], return_grads=True)
     # B = 2: every LeakyReLU sign that fp32-level rounding decides differently from fp64 shows at ~1e-2 in these
-    # short sums (the fp32 reference has them too: test_mplayer_full_size counts them); arithmetic at N = 150 is pinned
-    # at 1e-4 by the smooth MPLayer cases, this test pins the iteration's wiring (chunks, receiver blocks, both nets)
-    _assert_grads(D, gD, 5e-2)
+    # short sums -- for the fp32 control as for the kernels, hence the bar max(1e-3, 3x fp32's own error) per parameter
+    _assert_grads(D, gD, 1e-3, control=cD)
     ts._seg_G()
-    _assert_grads(G, gG, 5e-2)
+    _assert_grads(G, gG, 1e-3, control=cG)
     ts._seg_end()
     assert abs(float(ts.D_loss) - dl) < 1e-4 * abs(dl) and abs(float(ts.G_loss) - gl) < 1e-4 * abs(gl)
 
 
-def _assert_grads(module, ref, tol):
-    """max|got - ref| <= tol * max|ref| per parameter; a parameter whose true gradient vanishes by symmetry (e.g. the
-    last node-layer bias of D under the w / hinge losses: real and generated jets have the same multiplicities and
-    opposite loss gradients) is held to tol * 1e-3 of the largest gradient in the network instead of to its own
-    rounding noise."""
-    scale = max(float(v.abs().max()) for v in ref.values())
-    for k, p in module.named_parameters():
-        r = ref[k].numpy()
-        err = np.abs(p.grad.double().cpu().numpy() - r).max()
-        assert err <= tol * max(np.abs(r).max(), 1e-3 * scale), (k, err, np.abs(r).max(), scale)
+def _assert_grads(module, ref, tol, control=None):
+    """conftest.assert_grads on a module's .grad buffers (e.g. the last node-layer bias of D under the w / hinge
+    losses has a gradient that vanishes by symmetry: real and generated jets have the same multiplicities and opposite
+    loss gradients)."""
+    assert_grads({k: p.grad.double().cpu().numpy() for k, p in module.named_parameters()},
+                 {k: v.detach().numpy() for k, v in ref.items()}, tol,
+                 control=None if control is None else {k: v.detach().double().numpy() for k, v in control.items()})
 
 
 @pytest.mark.parametrize("loss", ["og", "w", "hinge"])
@@ -250,11 +269,14 @@ def test_train_step_other_losses_vs_oracle(loss):
     ts.fixed_noise = (nD.cuda(), nG.cuda())
     cfg = {"D": {"sigmoid": loss not in ("w", "hinge")}}
     ts._seg_D()
+    c32 = lambda sd: {k: v.float() for k, v in sd.items()}
+    _, _, cD, cG = T.train_iteration("mpgan", c32(sdD), c32(sdG), {}, {}, data.float(), labels.float(), nD.float(), nG.float(),
+                                     0.0, train.LR["g"][1], return_grads=True, loss=loss, cfg=cfg)
     dl, gl, gD, gG = T.train_iteration("mpgan", sdD, sdG, {}, {}, data.double(), labels.double(), nD.double(),
                                        nG.double(), 0.0, train.LR["g"][1], return_grads=True, loss=loss, cfg=cfg)
-    _assert_grads(D, gD, 2e-3)
+    _assert_grads(D, gD, 1e-3, control=cD)   # (1e-3, or 3x what the fp32 oracle itself shows against fp64 here)
     ts._seg_G()
-    _assert_grads(G, gG, 2e-3)
+    _assert_grads(G, gG, 1e-3, control=cG)
     ts._seg_end()
     assert abs(float(ts.D_loss) - dl) < 1e-4 * max(abs(dl), 1e-3) and abs(float(ts.G_loss) - gl) < 1e-4 * max(abs(gl), 1e-3)
 
@@ -327,7 +349,6 @@ def test_discriminator_with_conditioning_options_vs_reference_golden():
     """A whole MPDiscriminator with clabels, mask_fne_np, mask_fnd_np and delta-r edge features on (the un-fused route of
     every layer and of the head): output and gradients against the reference's own."""
     import numpy as np
-    from conftest import load_golden, summarize, rel_err
     from gen_golden import D_OPT
     from oracle import train_ref as T
     from mpgan_amd.mpgan import MPDiscriminator
@@ -341,4 +362,4 @@ def test_discriminator_with_conditioning_options_vs_reference_golden():
     assert rel_err(y.detach().cpu().numpy(), g["y"]) < 1e-4
     assert rel_err(x.grad.cpu().numpy(), g["dx"]) < 1e-3   # (the mask column included: it feeds the masked sums and njp)
     for k, p in D.named_parameters():
-        assert rel_err(summarize(k, p.grad), g["grad__" + k]) < 1e-3, k
+        assert summary_err(k, p.grad, g["grad__" + k]) < 1e-3, k

@@ -13,8 +13,8 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTI
   o=$OUT/pass$i
   rm -rf $o
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $o -o p -- $BIN $ARGS > $o.log 2>&1; rc=$?
-  if [ $rc -ne 0 ] && [ $rc -ne 2 ]; then tail -5 $o.log; exit 1; fi   # (2 = the harness saw bitwise differences)
-  for k in edge_bwd_v1_kernel "edge_bwd_kernel"; do
+  if [ $rc -ne 0 ]; then tail -5 $o.log; exit 1; fi
+  for k in "edge_bwd_kernel"; do
     echo "== pass $i $k"; python3 $R/tools/pmc_summary.py $o "$k"
   done
   i=$((i+1))
