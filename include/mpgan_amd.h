@@ -201,8 +201,9 @@ int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream);
  * db3 = sum_e dZ3 [192], db2 = sum_e dZ2 [160]; E1 and dZ3 are rebuilt from a, c, dagg and the sign words.
  * Two fp16 terms per product: the rebuilt operand as hi + lo, the parked one as the fp16 value it was parked as,
  * everything in ONE gradient unit 2^-min(gexp) for the launch (the parked dZ2 is rescaled exactly).
- * `part` is scratch of nwg * 46,432 floats (per-workgroup partial sums); nwg workgroups share the B*RB*N blocks
- * evenly and each may take at most 64 of them (error -5 otherwise). */
+ * `part` is scratch of nwg * 46,432 floats (per-workgroup partial sums); the nwg workgroups share the B*RB*N blocks
+ * in runs of R consecutive senders (R = the largest divisor of N up to 6), and each may take at most 64 blocks, i.e.
+ * R * ceil(B*RB*N / R / nwg) <= 64 (error -5 otherwise). */
 typedef struct MpgEdgeDw {
     const float* a; const float* c; int ld_ac; const float* mask;
     const float* dagg; int ld_dagg;

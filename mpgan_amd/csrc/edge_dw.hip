@@ -9,9 +9,12 @@
 // edges; the per-workgroup partials are summed by a last small kernel that also undoes the fragment-order permutation of
 // the feature indices and the launch's gradient unit.
 //
-// Arithmetic: two fp16 terms per product.  The rebuilt operand (dZ3, E1) is split hi + lo, the parked one (E2, dZ2) is
-// the single fp16 value it was parked as: its rounding (2^-12 relative, independent from edge to edge) averages out over
-// the ~10^5 edges a weight gradient sums.  The contraction runs over receivers, senders AND jets, so everything is
+// Arithmetic: ONE fp16 term per product -- every operand is a single fp16 value (2^-12 relative rounding), and every one
+// of these roundings is independent from block to block: E2 and E1 differ from edge to edge by themselves, the parked
+// dZ2 carries its block's dither factor (edge_bwd2_impl.h), and dZ3 -- for one receiver the same number for all senders
+// up to one of two constants -- is built times that factor c while its partner E2 is divided by it.  Independent
+// roundings average out over the edges a weight gradient sums (measured: tests/probe_precision.py).
+// The contraction runs over receivers, senders AND jets, so everything is
 // brought to ONE gradient unit 2^-eG, eG = min over the launch of gexp: dZ3 is built in it; a parked dZ2 piece stays as
 // it is and its partner E1 is multiplied by 2^(eG - gexp) / c, c the block's dither factor (a jet whose gradients are
 // 2^-24 of the largest jet's drops out of the fp16 range, and of any fp32 sum with that jet too).
@@ -31,15 +34,15 @@ namespace {
 // 4 receivers).  Row strides are odd multiples of 64 B, which makes those reads bank-conflict free.
 //
 // A workgroup is 8 waves on 4 SIMDs: waves 0-3 are CONSUMERS (each owns 10-12 of the 45 output tiles in
-// registers and only issues LDS reads + MFMAs), waves 4-7 are BUILDERS (VALU only: copy the parked E2, rescale the
-// parked dZ2, rebuild dZ3 from dagg and the sign words and E1 from a_i + c_j, sum the biases).  The images are double
-// buffered (2 x 60 KiB): builders fill block n+1 while consumers multiply block n, one barrier per block.  Every
-// builder thread owns fixed (receiver, feature chunk) pieces, keeps what it needs of dagg / a in registers and reloads
-// each parked piece for the block after next right after using it, so no builder ever waits on another.
+// registers and only issues LDS reads + MFMAs), waves 4-7 are BUILDERS (VALU only: copy the parked dZ2, divide the
+// parked E2 by the dither factor, rebuild dZ3 from dagg and the sign words and E1 from a_i + c_j, sum the biases).  The
+// images are double buffered (2 x 40 KiB): builders fill block n+1 while consumers multiply block n, one barrier per block.  Every
+// builder thread owns fixed (receiver, feature chunk) pieces and fetches everything it needs of a block two blocks ahead,
+// into one of two register sets, right after the piece it replaces was used: no builder ever waits on another.
 constexpr int DW_RS3 = 448, DW_RS2 = 320, DW_RS1 = 192;  // image row strides (bytes)
-constexpr int DW_Z3H = 0, DW_Z3L = DW_Z3H + 32 * DW_RS3, DW_E2H = DW_Z3L + 32 * DW_RS3, DW_Z2H = DW_E2H + 32 * DW_RS2,
-              DW_E1H = DW_Z2H + 32 * DW_RS2, DW_E1L = DW_E1H + 32 * DW_RS1, DW_BUF = DW_E1L + 32 * DW_RS1;
-constexpr int DW_LDS_BYTES = 2 * DW_BUF;  // 122,880
+constexpr int DW_Z3H = 0, DW_E2H = DW_Z3H + 32 * DW_RS3, DW_Z2H = DW_E2H + 32 * DW_RS2, DW_E1H = DW_Z2H + 32 * DW_RS2,
+              DW_BUF = DW_E1H + 32 * DW_RS1;
+constexpr int DW_LDS_BYTES = 2 * DW_BUF;  // 81,920
 static_assert(DW_LDS_BYTES <= 163840, "dW images must fit the LDS twice");
 
 struct DwTile { int prod, m, n; };  // prod 0: dW3 (A = Z3 tile m, B = E2 tile n); 1: dW2 (A = Z2, B = E1)
@@ -74,49 +77,54 @@ MPG_DEV f16x8 dw_frag(uint32_t lane_addr, int off, int rs) {
     return __builtin_bit_cast(f16x8, v);
 }
 
+constexpr bool dw_has_prod(int prod, int begin, int end) {
+    for (int t = begin; t < end; ++t) if (DW_TILES[t].prod == prod) return true;
+    return false;
+}
+constexpr bool dw_uses_n(int prod, int n, int begin, int end) {
+    for (int t = begin; t < end; ++t) if (DW_TILES[t].prod == prod && DW_TILES[t].n == n) return true;
+    return false;
+}
+
+// One block into the wave's accumulators: per k-step (16 receivers) the B fragments the wave's tiles of a product need
+// are read ONCE (E2: all five, E1: up to three), then every row group (same product and m) reads its A fragment and
+// issues its MFMAs.  The transposing reads are what bounds this kernel (LDS bandwidth), so no fragment is read twice.
 template <int BEGIN, int END>
 MPG_DEV void dw_consume(f32x16* acc, uint32_t buf, int lane) {
     // lane 4q+p of 16-lane group g supplies row (8 (g>>1) + q), feature columns 16 (g&1) + 4p .. +3 of the block
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     const int row = 8 * (g >> 1) + q, col = (16 * (g & 1) + 4 * pp) * 2;
-    // one opaque base per image family, everything else is an immediate offset
-    uint32_t bz3 = buf + DW_Z3H + row * DW_RS3 + col, be2 = buf + DW_E2H + row * DW_RS2 + col;
-    uint32_t bz2 = buf + DW_Z2H + row * DW_RS2 + col, be1 = buf + DW_E1H + row * DW_RS1 + col;
-    asm volatile("" : "+v"(bz3), "+v"(be2), "+v"(bz2), "+v"(be1));
-    // tiles sharing their A rows (same product and m) form a group: per k-step the A fragments are read once
-    // and only the B fragments change -- a few fragment registers live beside the 160-192 accumulators.
-    // dW3: A = dZ3 (hi, lo), B = E2 ; dW2: A = dZ2, B = E1 (hi, lo)
-    static_for<BEGIN, END>([&](auto tc) {
-        MPG_CI(t, tc);
-        if constexpr (dw_leader(t, BEGIN)) {
-            constexpr DwTile d = DW_TILES[t];
-            constexpr int ge = dw_group_end(t, END);
-            constexpr int rsa = d.prod == 0 ? DW_RS3 : DW_RS2, rsb = d.prod == 0 ? DW_RS2 : DW_RS1;
-            constexpr int alo = DW_Z3L - DW_Z3H, blo = DW_E1L - DW_E1H;
-            uint32_t ba = d.prod == 0 ? bz3 : bz2, bb = d.prod == 0 ? be2 : be1;
-            // a fresh (opaque) base per group: otherwise the B fragments of a whole product (80 registers) are kept
-            // for the next group and the accumulators spill
-            asm volatile("" : "+v"(ba), "+v"(bb));
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const f16x8 ah = dw_frag(ba, 16 * s * rsa + 64 * d.m, rsa);
-                f16x8 al = ah;
-                if constexpr (d.prod == 0) al = dw_frag(ba, alo + 16 * s * rsa + 64 * d.m, rsa);
-                static_for<t, ge>([&](auto uc) {
-                    MPG_CI(u, uc);
-                    constexpr int n = DW_TILES[u].n;
-                    const f16x8 bh = dw_frag(bb, 16 * s * rsb + 64 * n, rsb);
-                    if constexpr (d.prod == 0) {
-                        acc[u - BEGIN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[u - BEGIN], 0, 0, 0);
-                    } else {
-                        const f16x8 bl = dw_frag(bb, blo + 16 * s * rsb + 64 * n, rsb);
-                        acc[u - BEGIN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[u - BEGIN], 0, 0, 0);
+    for (int s = 0; s < 2; ++s) {
+        // fresh (opaque) bases per k-step: everything else is an immediate offset, and no fragment of this k-step can be
+        // kept for the next (the accumulators would spill)
+        uint32_t bz3 = buf + DW_Z3H + row * DW_RS3 + col, be2 = buf + DW_E2H + row * DW_RS2 + col;
+        uint32_t bz2 = buf + DW_Z2H + row * DW_RS2 + col, be1 = buf + DW_E1H + row * DW_RS1 + col;
+        asm volatile("" : "+v"(bz3), "+v"(be2), "+v"(bz2), "+v"(be1));
+        static_for<0, 2>([&](auto pc) {
+            MPG_CI(prod, pc);
+            if constexpr (dw_has_prod(prod, BEGIN, END)) {
+                constexpr int rsa = prod == 0 ? DW_RS3 : DW_RS2, rsb = prod == 0 ? DW_RS2 : DW_RS1, nb = prod == 0 ? T2 : T1;
+                const uint32_t ba = prod == 0 ? bz3 : bz2, bb = prod == 0 ? be2 : be1;
+                f16x8 bfr[nb];
+                static_for<0, nb>([&](auto nc) {
+                    MPG_CI(n, nc);
+                    if constexpr (dw_uses_n(prod, n, BEGIN, END)) bfr[n] = dw_frag(bb, 16 * s * rsb + 64 * n, rsb);
+                });
+                static_for<BEGIN, END>([&](auto tc) {
+                    MPG_CI(t, tc);
+                    if constexpr (DW_TILES[t].prod == prod && dw_leader(t, BEGIN)) {
+                        constexpr int ge = dw_group_end(t, END);
+                        const f16x8 a = dw_frag(ba, 16 * s * rsa + 64 * DW_TILES[t].m, rsa);
+                        static_for<t, ge>([&](auto uc) {
+                            MPG_CI(u, uc);
+                            acc[u - BEGIN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfr[DW_TILES[u].n], acc[u - BEGIN], 0, 0, 0);
+                        });
                     }
-                    acc[u - BEGIN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[u - BEGIN], 0, 0, 0);
                 });
             }
-        }
-    });
+        });
+    }
 }
 
 template <int BEGIN, int END>
@@ -138,12 +146,16 @@ MPG_DEV void dw_store(const f32x16* acc, float* part3, float* part2, int lane) {
 // A workgroup walks at most 64 blocks (the launcher sizes the grid for that); their valid-sender bits are one
 // ballot taken at kernel start, so stepping to the next unmasked block is pure scalar arithmetic -- no memory
 // access and no loop inside the pipelined loops (either would make the compiler drain vmcnt there).
-// The blocks of a workgroup are STRIDED over the launch (slot t of workgroup g is block g + t * gridDim.x): a contiguous
+// The blocks of a workgroup are RUNS of R consecutive senders of one (jet, receiver block), the runs strided over the
+// launch: run q of workgroup g is run g + q * gridDim.x, i.e. blocks (g + q * gridDim.x) * R .. + R - 1.  A contiguous
 // range would be one jet's senders, and a launch would last as long as its fullest jet (masks sorted to the end of a
-// jet left whole workgroups idle at N = 150); strided, every workgroup samples all jets.
-MPG_DEV int dw_block(int t) { return (int)blockIdx.x + t * (int)gridDim.x; }
-MPG_DEV unsigned long long dw_valid_bits(const MpgEdgeDw& p, int blk0, int blk1) {   // over the slots [blk0, blk1)
-    const int RB = (p.N + 31) / 32, t = blk0 + (int)(threadIdx.x & 63), x = dw_block(t);
+// jet left whole workgroups idle at N = 150); strided run by run, every workgroup samples several jets at all positions
+// of the sender axis.  Within a run the receivers' rows of dagg and a stay in registers: fetched per block they were
+// 36 KB of the 60 KB a block pulls through the CU's 64 B/clk texture path -- more than the parked pieces themselves.
+// R divides N (the launcher picks it), so a run never straddles two receiver blocks.
+MPG_DEV int dw_block(int t, int R) { return ((int)blockIdx.x + (t / R) * (int)gridDim.x) * R + t % R; }
+MPG_DEV unsigned long long dw_valid_bits(const MpgEdgeDw& p, int R, int blk0, int blk1) {   // over the slots [blk0, blk1)
+    const int RB = (p.N + 31) / 32, t = blk0 + (int)(threadIdx.x & 63), x = dw_block(t, R);
     bool ok = t < blk1;
     if (ok && p.mask != nullptr) ok = p.mask[((x / p.N) / RB) * p.N + x % p.N] != 0.f;
     return __ballot(ok);
@@ -179,6 +191,7 @@ MPG_DEV void dw_consumer(const MpgEdgeDw& p, int blk0, int blk1, unsigned long l
     }
     float* part = p.part + (size_t)blockIdx.x * (H3 * H2 + H2 * H1 + H3 + H2);
     dw_store<BEGIN, END>(acc, part, part + H3 * H2, lane);
+    lds_barrier();   // (the builders exchange their bias sums through LDS behind this one)
 }
 
 // keep bits (bit k = element k) of one 8-feature chunk: features 32 tile + f0 + {0..3, 8..11} of edge row `erow`
@@ -212,9 +225,13 @@ MPG_DEV int dw_launch_exp(const MpgEdgeDw& p) {
 }
 
 template <int DROP>
-MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsigned long long vbits) {
+MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk1, unsigned long long vbits) {
     const int bt = threadIdx.x - 256;     // builder thread 0..255
-    const int r = bt & 31, cg = bt >> 5;  // receiver row of the images, chunk group: chunks cg, cg + 8, cg + 16
+    // receiver row r of the images and chunk group cg (chunks cg, cg + 8, cg + 16).  Four ADJACENT lanes hold the four chunk
+    // groups of one receiver that make up a whole 32-feature tile: their two 16-byte reads of a dagg / a row cover one
+    // contiguous 128-byte line, so a wave's load touches 16 rows x 1 line.  (With the receiver in the low lane bits every
+    // lane read its own row -- 64 lines per load instruction, and the texture path, not HBM, was what the builders waited for.)
+    const int r = (bt >> 2) & 31, cg = ((bt >> 7) << 2) | (bt & 3);
     const int RB = (p.N + 31) / 32;
     // chunk c = 2 frag + h holds fragment-order features 8c .. 8c+7 = registers 8s .. 8s+7 of tile (c >> 2) of
     // lane (r, h):  s = (c >> 1) & 1 and h = c & 1 are the same for all chunks of this thread
@@ -224,24 +241,42 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsi
     uint32_t seed_lo = 0, seed_hi = 0;
     if (DROP) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
 
-    float dreg[3][8], areg[2][8];   // dagg / a of this thread's Z3 / E1 chunks, current jet (raw)
     float db3[3][8], db2[3][8];
 #pragma unroll
     for (int n = 0; n < 3; ++n)
 #pragma unroll
         for (int k = 0; k < 8; ++k) { db3[n][k] = 0.f; db2[n][k] = 0.f; }
-    uint32_t sw[3];                 // sign words of the Z3 chunks' lanes
-    float4 cv[2][2];                // c_j of the E1 chunks
-    f16x8 eh[3];                    // parked E2 pieces
-    f16x8 zh[3];                    // parked dZ2 pieces (in their block's gradient unit)
+    // Everything of a block is fetched ahead, RAW: nothing may be computed from a prefetched value before the block that
+    // needs it (a use right behind the load would make every iteration wait for its youngest load, i.e. drain the whole
+    // prefetch queue).  The parked pieces come from HBM -- a round trip under load is longer than one block's build -- and
+    // are requested TWO blocks ahead, into two register sets (block k lives in set k & 1); the rest is L2-resident and
+    // requested one block ahead.  Vector memory operations complete in issue order, so within a build the one-ahead
+    // requests are issued before the two-ahead ones: the next build waits for nothing younger than what it needs.
+    struct Small {
+        float dreg[3][8], areg[2][8];   // dagg / a of this thread's Z3 / E1 chunks (raw)
+        float dscl;                     // agg_scale * dscale * 2^eG, or 0 for a padding receiver
+        uint32_t sw[3];                 // sign words of the Z3 chunks' lanes
+        unsigned int nbw;               // this receiver's neighbour word holding the block's sender (k-NN graphs)
+        float4 cv[2][2];                // c_j of the E1 chunks
+    };
+    struct Big {
+        f16x8 eh[3];                    // parked E2 pieces
+        f16x8 zh[3];                    // parked dZ2 pieces (in their block's gradient unit)
+    };
+    Small S;
+    Big B0, B1;
     // gradient units: the launch's exponent and, in lane t, the exponent of slot t's (jet, receiver block)
     const int eG = dw_launch_exp(p);
     const float unitG = __builtin_bit_cast(float, (uint32_t)(eG + 127) << 23);   // 2^eG (|eG| <= 100)
     int eslot = eG;
     {
         const int t = blk0 + (int)(threadIdx.x & 63);
-        if (t < blk1) eslot = p.gexp[dw_block(t) / p.N];
+        if (t < blk1) eslot = p.gexp[dw_block(t, R) / p.N];
     }
+    // (a value defined HERE, not by a load: the pipelined loop below reads it with v_readlane, and for a load result the
+    // compiler would wait there with vmcnt(0) -- it cannot tell how old a load is across the loop's back edge -- and
+    // drain every prefetch of every block)
+    asm volatile("" : "+v"(eslot));
 
     const bool third = cg < 4;  // chunk groups 0..3 own a third 160-feature piece and a second E1 chunk
     auto e1tile = [&](int n) { return n == 0 || third ? 2 * n + (cg >> 2) : (cg >> 2); };  // 0..2
@@ -271,83 +306,76 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsi
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
     };
 
-    // dagg / a of the (jet, receiver block) of block `blk`, RAW: nothing may be computed from a prefetched value
-    // before the block that needs it (a use right behind the load would make every iteration wait for its
-    // youngest load, i.e. drain the whole prefetch queue).  Padding receivers read row 0 and get scale 0.
-    float dscl = 0.f;  // agg_scale * dscale * 2^eG, or 0 for a padding receiver -- belongs to the jet in dreg
-    auto load_jet = [&](int blk) {
+    // dagg / a of the (jet, receiver block) of block `blk`.  Padding receivers read row 0 and get scale 0.
+    auto load_d = [&](Small& P, int blk) {
         const int brb = blk / p.N, rb = brb % RB, b = brb / RB, ii = rb * 32 + r;
         const bool ok = ii < p.N;
-        dscl = ok ? p.agg_scale * p.dscale * unitG : 0.f;
+        P.dscl = ok ? p.agg_scale * p.dscale * unitG : 0.f;
         const int rowD = (ok ? ii : 0) * p.ld_dagg * 4 + (32 * (cg >> 2) + f0) * 4, soD = b * p.N * p.ld_dagg * 4;
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
             const float4 u = ldb4(rD, rowD + 256 * n, soD), v = ldb4(rD, rowD + 256 * n + 32, soD);
-            dreg[n][0] = u.x; dreg[n][1] = u.y; dreg[n][2] = u.z; dreg[n][3] = u.w;
-            dreg[n][4] = v.x; dreg[n][5] = v.y; dreg[n][6] = v.z; dreg[n][7] = v.w;
+            P.dreg[n][0] = u.x; P.dreg[n][1] = u.y; P.dreg[n][2] = u.z; P.dreg[n][3] = u.w;
+            P.dreg[n][4] = v.x; P.dreg[n][5] = v.y; P.dreg[n][6] = v.z; P.dreg[n][7] = v.w;
         }
+    };
+    auto load_a = [&](Small& P, int blk) {
+        const int brb = blk / p.N, rb = brb % RB, b = brb / RB, ii = rb * 32 + r;
+        const bool ok = ii < p.N;
         const int rowA = (ok ? ii : 0) * ldac * 4, soA = b * p.N * ldac * 4;
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const float4 u = ldb4(rA, rowA + voE1[n], soA), v = ldb4(rA, rowA + voE1[n] + 32, soA);
-            areg[n][0] = u.x; areg[n][1] = u.y; areg[n][2] = u.z; areg[n][3] = u.w;
-            areg[n][4] = v.x; areg[n][5] = v.y; areg[n][6] = v.z; areg[n][7] = v.w;
+            P.areg[n][0] = u.x; P.areg[n][1] = u.y; P.areg[n][2] = u.z; P.areg[n][3] = u.w;
+            P.areg[n][4] = v.x; P.areg[n][5] = v.y; P.areg[n][6] = v.z; P.areg[n][7] = v.w;
         }
     };
-    unsigned int nbw = 0xffffffffu;  // this receiver's neighbour word holding the block's sender (k-NN graphs)
     const __amdgpu_buffer_rsrc_t rN = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int*>(p.nbr), 0, p.nbr ? p.B * p.N * ((p.N + 31) >> 5) * 4 : 0, 0x00020000);
-    auto load_nb = [&](int blk) {  // (with no graph the resource is empty: the load returns 0 and is ignored below)
+    auto load_nb = [&](Small& P, int blk) {  // (with no graph the resource is empty: the load returns 0 and is ignored below)
         const int j = blk % p.N, brb = blk / p.N, rb = brb % RB, b = brb / RB, ii = rb * 32 + r;
-        nbw = __builtin_amdgcn_raw_buffer_load_b32(rN, ((b * p.N + (ii < p.N ? ii : 0)) * ((p.N + 31) >> 5) + (j >> 5)) * 4, 0, 0);
+        P.nbw = __builtin_amdgcn_raw_buffer_load_b32(rN, ((b * p.N + (ii < p.N ? ii : 0)) * ((p.N + 31) >> 5) + (j >> 5)) * 4, 0, 0);
     };
-    auto load_sw = [&](int blk) {  // word (tile >> 1) = n of lane (r, h)
+    auto load_sw = [&](Small& P, int blk) {  // word (tile >> 1) = n of lane (r, h)
 #pragma unroll
-        for (int n = 0; n < 3; ++n) sw[n] = __builtin_amdgcn_raw_buffer_load_b32(rS, voS, blk * (T3 * 32 * 4) + n * 256, 0);
+        for (int n = 0; n < 3; ++n) P.sw[n] = __builtin_amdgcn_raw_buffer_load_b32(rS, voS, blk * (T3 * 32 * 4) + n * 256, 0);
     };
-    auto load_c = [&](int blk) {
+    auto load_c = [&](Small& P, int blk) {
         const int j = blk % p.N, b = (blk / p.N) / RB, so = (b * p.N + j) * ldac * 4;
 #pragma unroll
-        for (int n = 0; n < 2; ++n) { cv[n][0] = ldb4(rC, voE1[n], so); cv[n][1] = ldb4(rC, voE1[n] + 32, so); }
+        for (int n = 0; n < 2; ++n) { P.cv[n][0] = ldb4(rC, voE1[n], so); P.cv[n][1] = ldb4(rC, voE1[n] + 32, so); }
     };
     // parked pieces: chunk c of receiver r is element c * 32 + r of a block of 640 16-byte pieces
-    auto load_e2 = [&](int blk, int n) {
-        eh[n] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rE, vo160[n], blk * (NFR2 * 1024), 0));
+    auto load_e2 = [&](Big& P, int blk, int n) {
+        P.eh[n] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rE, vo160[n], blk * (NFR2 * 1024), 0));
     };
-    auto load_z2 = [&](int blk, int n) {
-        zh[n] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rZ, vo160[n], blk * (NFR2 * 1024), 0));
+    auto load_z2 = [&](Big& P, int blk, int n) {
+        P.zh[n] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rZ, vo160[n], blk * (NFR2 * 1024), 0));
     };
 
-    // build the block of slot `slot` into buffer `buf`; right after a parked piece is used, request the one of slot `pre_slot`
-    auto build = [&](int slot, char* buf, int pre_slot) {
+    auto load_small = [&](Small& P, int blk) { load_d(P, blk); load_sw(P, blk); load_nb(P, blk); load_c(P, blk); load_a(P, blk); };
+    auto load_big = [&](Big& Q, int blk) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n) { load_z2(Q, blk, n); load_e2(Q, blk, n); }
+    };
+
+    // build the block of slot `slot` (small things in S, parked pieces in Q) into buffer `buf`.  Right after a piece is used
+    // its successor is requested: the small things of slot `pre1` first, the parked pieces of slot `pre2` behind them
+    auto build = [&](int slot, char* buf, int pre1_slot, int pre2_slot, Big& Q) {
         const bool exp_noload = (MPG_DW_EXP & 4) && p.N != 12345, exp_nowrite = (MPG_DW_EXP & 8) && p.N != 12345;
-        const int blk = dw_block(slot), pre = dw_block((MPG_DW_EXP & 16) ? blk0 : pre_slot);
+        const int blk = dw_block(slot, R), pre1 = dw_block((MPG_DW_EXP & 16) ? blk0 : pre1_slot, R), pre2 = dw_block((MPG_DW_EXP & 16) ? blk0 : pre2_slot, R);
+        const bool newrun = pre1_slot / R != slot / R;   // the next block belongs to other receivers: fetch their rows
         const int j = blk % p.N, brb = blk / p.N, rb = brb % RB, b = brb / RB, ii = rb * 32 + r;
         const uint32_t erow = (uint32_t)((b * p.N + ii) * p.N + j);
-        // dZ2 goes into the image AS PARKED, in its block's unit 2^-e / c (c: the block's dither factor): rounded once, by
-        // mpg_edge_bwd.  What takes it to the launch's unit, funit = 2^(eG - e) / c <= 1, multiplies the OTHER operand of its
-        // product instead -- E1 below, built in fp32 anyway -- and the bias sums, which are fp32
+        // the block's units: its gradient unit is 2^-e / c (c: the block's dither factor), the launch's 2^-eG
         const int de = eG - __builtin_amdgcn_readlane(eslot, slot - blk0);
-        const float funit = __builtin_bit_cast(float, (uint32_t)max(de + 127, 0) << 23) * __builtin_amdgcn_rcpf(dither_of((uint32_t)blk));
-#pragma unroll
-        for (int n = 0; n < 3; ++n) {
-            const int c = chunk160(n);
-            if (!exp_nowrite) *reinterpret_cast<f16x8*>(buf + DW_Z2H + r * DW_RS2 + c * 16) = zh[n];
-            const float take = n < 2 || third ? funit : 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) db2[n][k] += take * (float)zh[n][k];
-            if (!exp_noload) load_z2(pre, n);
-        }
-        // E2: as parked
-#pragma unroll
-        for (int n = 0; n < 3; ++n) {
-            const int c = chunk160(n);
-            if (!exp_nowrite) *reinterpret_cast<f16x8*>(buf + DW_E2H + r * DW_RS2 + c * 16) = eh[n];
-            else if (eh[n][0] == (_Float16)123.f) db2[0][0] += (float)eh[n][1];
-            if (!exp_noload) load_e2(pre, n);
-        }
-        // dZ3 = dagg * slope(sign bit) * keep3, in the launch's gradient unit, hi + lo
-        const float in_set = (p.nbr == nullptr || ((nbw >> (j & 31)) & 1u)) ? 1.f : 0.f;
-        const float dscl_1 = dscl * in_set, dscl_a = dscl * p.alpha * in_set;
+        const float dth = dither_of((uint32_t)blk), rdth = __builtin_amdgcn_rcpf(dth);
+        const float funit = __builtin_bit_cast(float, (uint32_t)max(de + 127, 0) << 23) * rdth;
+        const _Float16 rch = (_Float16)rdth;
+        // dZ3 = dagg * slope(sign bit) * keep3, in the launch's gradient unit times the block's dither factor (dZ3 of a
+        // receiver is the same number for all its senders up to one of two constants: see edge_bwd2_impl.h); the bias
+        // sums take it without the factor
+        const float in_set = (p.nbr == nullptr || ((S.nbw >> (j & 31)) & 1u)) ? 1.f : 0.f;
+        const float dscl_1 = S.dscl * in_set, dscl_a = S.dscl * p.alpha * in_set;
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
             const int m = 2 * n + (cg >> 2), c = cg + 8 * n;
@@ -355,94 +383,132 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, char* smem, int blk0, int blk1, unsi
             const uint32_t keep = dw_chunk_keep<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, m, f0, p.thr);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const uint32_t neg = (sw[n] >> (31 - (16 * (m & 1) + 8 * cs + k))) & 1u;
-                float x = dreg[n][k] * (neg ? dscl_a : dscl_1);
+                const uint32_t neg = (S.sw[n] >> (31 - (16 * (m & 1) + 8 * cs + k))) & 1u;
+                float x = S.dreg[n][k] * (neg ? dscl_a : dscl_1);
                 if (DROP && !((keep >> k) & 1u)) x = 0.f;
-                v[k] = x;
+                v[k] = x * dth;
                 db3[n][k] += x;
             }
-            f16x8 hh, ll;
-            split8(v, hh, ll);
-            if (!exp_nowrite) {
-                *reinterpret_cast<f16x8*>(buf + DW_Z3H + r * DW_RS3 + c * 16) = hh;
-                *reinterpret_cast<f16x8*>(buf + DW_Z3L + r * DW_RS3 + c * 16) = ll;
-            } else if (hh[0] == (_Float16)123.f) db2[0][0] += (float)ll[1];
+            const f16x8 hh = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3], (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
+            if (!exp_nowrite) *reinterpret_cast<f16x8*>(buf + DW_Z3H + r * DW_RS3 + c * 16) = hh;
+            else if (hh[0] == (_Float16)123.f) db2[0][0] += (float)hh[1];
         }
-        if (!exp_noload) { load_sw(pre); load_nb(pre); }
-        // E1 = keep1 * lrelu(a_i + c_j), times funit (see dZ2)   (chunk groups 4..7: the second chunk repeats the first)
+        if (!exp_noload) { load_sw(S, pre1); load_nb(S, pre1); if (newrun) load_d(S, pre1); }
+        // E1 = keep1 * lrelu(a_i + c_j), times funit: what takes the parked dZ2 -- which goes into its image AS PARKED,
+        // rounded once, by mpg_edge_bwd -- to the launch's unit multiplies the OTHER operand of its product, built in
+        // fp32 anyway (chunk groups 4..7: the second chunk repeats the first)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int q = e1tile(n), c = 4 * q + (cg & 3);
-            const float cc[8] = {cv[n][0].x, cv[n][0].y, cv[n][0].z, cv[n][0].w, cv[n][1].x, cv[n][1].y, cv[n][1].z, cv[n][1].w};
+            const float cc[8] = {S.cv[n][0].x, S.cv[n][0].y, S.cv[n][0].z, S.cv[n][0].w, S.cv[n][1].x, S.cv[n][1].y, S.cv[n][1].z, S.cv[n][1].w};
             float v[8];
             const uint32_t keep = dw_chunk_keep<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, q, f0, p.thr);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                float x = lrelu(areg[n][k] + cc[k], p.alpha) * funit;
+                float x = lrelu(S.areg[n][k] + cc[k], p.alpha) * funit;
                 if (DROP && !((keep >> k) & 1u)) x = 0.f;
                 v[k] = x;
             }
-            f16x8 hh, ll;
-            split8(v, hh, ll);
-            if (!exp_nowrite) {
-                *reinterpret_cast<f16x8*>(buf + DW_E1H + r * DW_RS1 + c * 16) = hh;
-                *reinterpret_cast<f16x8*>(buf + DW_E1L + r * DW_RS1 + c * 16) = ll;
-            } else if (hh[0] == (_Float16)123.f) db2[0][0] += (float)ll[1];
+            const f16x8 hh = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3], (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
+            if (!exp_nowrite) *reinterpret_cast<f16x8*>(buf + DW_E1H + r * DW_RS1 + c * 16) = hh;
+            else if (hh[0] == (_Float16)123.f) db2[0][0] += (float)hh[1];
         }
-        if (!exp_noload) { load_c(pre); load_jet(pre); }
+        if (!exp_noload) { load_c(S, pre1); if (newrun) load_a(S, pre1); }
+        // dZ2: as parked; the bias sums (fp32) in the launch's unit
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const int c = chunk160(n);
+            if (!exp_nowrite) *reinterpret_cast<f16x8*>(buf + DW_Z2H + r * DW_RS2 + c * 16) = Q.zh[n];
+            const float take = n < 2 || third ? funit : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) db2[n][k] += take * (float)Q.zh[n][k];
+            if (!exp_noload) load_z2(Q, pre2, n);
+        }
+        // E2: as parked, divided by the block's dither factor (its partner dZ3 was built times that factor)
+        const f16x8 rc8 = {rch, rch, rch, rch, rch, rch, rch, rch};
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const int c = chunk160(n);
+            const f16x8 e = Q.eh[n] * rc8;
+            if (!exp_nowrite) *reinterpret_cast<f16x8*>(buf + DW_E2H + r * DW_RS2 + c * 16) = e;
+            else if (e[0] == (_Float16)123.f) db2[0][0] += (float)e[1];
+            if (!exp_noload) load_e2(Q, pre2, n);
+        }
     };
 
+    // valid slots v0, v1, v2, ...: block v_k takes its parked pieces from set k & 1, which is then refilled with those of
+    // v_{k+2}, and refills the small things with those of v_{k+1}.  Past the end the prefetches are clamped to the
+    // range's last slot: they fetch that block again, unused.
     int cur = dw_next_valid(vbits, blk0, blk0, blk1), it = 0;
-    int nxt = dw_next_valid(vbits, blk0, cur + 1, blk1);
-    // `pre` is clamped to the last block of the range: past the end the prefetches fetch that block again, unused
+    int n1 = dw_next_valid(vbits, blk0, cur + 1, blk1), n2 = dw_next_valid(vbits, blk0, n1 + 1, blk1);
     if (cur < blk1) {
-        const int b0 = dw_block(cur);
-        load_jet(b0); load_sw(b0); load_nb(b0); load_c(b0);
-#pragma unroll
-        for (int n = 0; n < 3; ++n) { load_e2(b0, n); load_z2(b0, n); }
-        build(cur, smem, min(nxt, blk1 - 1));
+        load_small(S, dw_block(cur, R));
+        load_big(B0, dw_block(cur, R));
+        load_big(B1, dw_block(min(n1, blk1 - 1), R));
+        build(cur, smem, min(n1, blk1 - 1), min(n2, blk1 - 1), B0);
     }
     lds_barrier();
     while (cur < blk1) {
-        const int nxt2 = dw_next_valid(vbits, blk0, nxt + 1, blk1);
-        if (nxt < blk1 && !(MPG_DW_EXP & 2)) build(nxt, smem + ((it + 1) & 1) * DW_BUF, min(nxt2, blk1 - 1));
-        lds_barrier();
-        cur = nxt;
-        nxt = nxt2;
-        ++it;
+        {   // odd blocks: set 1
+            const int n3 = dw_next_valid(vbits, blk0, n2 + 1, blk1);
+            if (n1 < blk1 && !(MPG_DW_EXP & 2)) build(n1, smem + ((it + 1) & 1) * DW_BUF, min(n2, blk1 - 1), min(n3, blk1 - 1), B1);
+            lds_barrier();
+            cur = n1; n1 = n2; n2 = n3; ++it;
+        }
+        if (!(cur < blk1)) break;
+        {   // even blocks: set 0
+            const int n3 = dw_next_valid(vbits, blk0, n2 + 1, blk1);
+            if (n1 < blk1 && !(MPG_DW_EXP & 2)) build(n1, smem + ((it + 1) & 1) * DW_BUF, min(n2, blk1 - 1), min(n3, blk1 - 1), B0);
+            lds_barrier();
+            cur = n1; n1 = n2; n2 = n3; ++it;
+        }
     }
 
-    // bias sums: add the 32 receivers (one half-wave per chunk group), fragment-order index fi = 8 c + k
-    float* part = p.part + (size_t)blockIdx.x * (H3 * H2 + H2 * H1 + H3 + H2);
-    float* pb3 = part + H3 * H2 + H2 * H1, *pb2 = pb3 + H3;
+    // bias sums: add the 32 receivers of a chunk group -- 16 in this wave (lane bits 2..5), 16 in its neighbour wave
+    // (through LDS: the images are dead after the loop's last barrier); fragment-order index fi = 8 c + k
+    float* red = reinterpret_cast<float*>(smem);   // [wave 0..3][lane & 3][n][k][db3 | db2]
+    const int bw = bt >> 6, bl = bt & 3;
 #pragma unroll
     for (int n = 0; n < 3; ++n)
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float x = db3[n][k], y = db2[n][k];
 #pragma unroll
-            for (int o = 1; o < 32; o <<= 1) { x += __shfl_xor(x, o, 64); y += __shfl_xor(y, o, 64); }
-            const int c = cg + 8 * n;
-            if (r == 0) {
-                pb3[8 * c + k] = x;
-                if (c < 2 * NFR2) pb2[8 * c + k] = y;  // (the repeated third piece added zeros)
+            for (int o = 4; o < 64; o <<= 1) { x += __shfl_xor(x, o, 64); y += __shfl_xor(y, o, 64); }
+            if ((bt & 63) < 4) {
+                red[(((bw * 4 + bl) * 3 + n) * 8 + k) * 2 + 0] = x;
+                red[(((bw * 4 + bl) * 3 + n) * 8 + k) * 2 + 1] = y;
             }
         }
+    lds_barrier();   // (the consumers take part in it, see dw_consumer)
+    float* part = p.part + (size_t)blockIdx.x * (H3 * H2 + H2 * H1 + H3 + H2);
+    float* pb3 = part + H3 * H2 + H2 * H1, *pb2 = pb3 + H3;
+    if (r == 0) {   // lanes 0..3 of waves 0 and 2: their own 16 receivers + those of waves 1 and 3
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i0 = (((bw * 4 + bl) * 3 + n) * 8 + k) * 2, i1 = ((((bw + 1) * 4 + bl) * 3 + n) * 8 + k) * 2;
+                const int c = cg + 8 * n;
+                pb3[8 * c + k] = red[i0] + red[i1];
+                if (c < 2 * NFR2) pb2[8 * c + k] = red[i0 + 1] + red[i1 + 1];  // (the repeated third piece added zeros)
+            }
+    }
 }
 
 template <int DROP>
-__global__ __launch_bounds__(512, 1) void edge_dw_kernel(const MpgEdgeDw p) {
+__global__ __launch_bounds__(512, 1) void edge_dw_kernel(const MpgEdgeDw p, const int R) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int RB = (p.N + 31) / 32;
-    const int nblk = p.B * RB * p.N;
-    const int blk0 = 0, blk1 = (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // slots of this workgroup
-    const unsigned long long vbits = dw_valid_bits(p, blk0, blk1);
+    const int nruns = p.B * RB * p.N / R;
+    const int blk0 = 0, blk1 = R * ((nruns - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);   // slots of this workgroup
+    const unsigned long long vbits = dw_valid_bits(p, R, blk0, blk1);
     if (w == 0) dw_consumer<0, 12>(p, blk0, blk1, vbits);
     else if (w == 1) dw_consumer<12, 23>(p, blk0, blk1, vbits);
     else if (w == 2) dw_consumer<23, 34>(p, blk0, blk1, vbits);
     else if (w == 3) dw_consumer<34, 45>(p, blk0, blk1, vbits);
-    else dw_builder<DROP>(p, smem, blk0, blk1, vbits);
+    else dw_builder<DROP>(p, R, smem, blk0, blk1, vbits);
 }
 
 // out = scale * 2^-eG * sum over workgroup partials, feature indices mapped back from fragment order.
@@ -503,9 +569,11 @@ extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
     if (p->B <= 0 || p->N <= 0 || p->nwg <= 0) return -1;
     if (!p->f16) return -8;
     if (p->gexp == nullptr) return -9;
+    int R = 1;   // run length: the largest divisor of N up to 6 (see dw_block)
+    for (int d = 2; d <= 6; ++d) if (p->N % d == 0) R = d;
     {
-        const int nblk = p->B * ((p->N + 31) / 32) * p->N;
-        if ((nblk + p->nwg - 1) / p->nwg > 64) return -5;  // a workgroup walks at most 64 blocks (one ballot of valid bits)
+        const int nruns = p->B * ((p->N + 31) / 32) * p->N / R;
+        if (R * ((nruns + p->nwg - 1) / p->nwg) > 64) return -5;  // a workgroup walks at most 64 blocks (one ballot of valid bits)
     }
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(p->nwg), block(512);
@@ -513,7 +581,7 @@ extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
 #define MPG_DW_ONE(D)                                                                                             \
     do {                                                                                                          \
         MPG_ENSURE_LDS((edge_dw_kernel<D>), DW_LDS_BYTES);                                                        \
-        hipLaunchKernelGGL((edge_dw_kernel<D>), grid, block, DW_LDS_BYTES, st, *p);                               \
+        hipLaunchKernelGGL((edge_dw_kernel<D>), grid, block, DW_LDS_BYTES, st, *p, R);                            \
     } while (0)
 #ifdef MPG_SINGLE_VARIANT  // tools/ubench/dw_bench.hip: one instantiation
     MPG_DW_ONE(MPG_SINGLE_VARIANT);

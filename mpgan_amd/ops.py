@@ -424,6 +424,14 @@ def _sender_chunks(B, N):
     return best
 
 
+def dw_workgroups(nblk, N):
+    """Workgroups of an ``mpg_edge_dw`` launch: one per CU, more when a workgroup would get over 64 blocks.  The blocks are
+    dealt in runs of R consecutive senders (csrc/edge_dw.hip), so the bound is R * ceil(nblk / R / nwg) <= 64."""
+    R = max(d for d in range(1, 7) if N % d == 0)
+    nruns = nblk // R
+    return min(nruns, max(256, -(-nruns // (64 // R))))
+
+
 class FusedMPLayerFn(torch.autograd.Function):
     """MPLayer.forward (mpgan/model.py:206-282), default configuration: fully connected, no edge
     features, no conditioning labels; fe = 3 layers [96,160,192], fn = 2 hidden layers + linear."""
@@ -567,7 +575,7 @@ class FusedMPLayerFn(torch.autograd.Function):
         dc = dcp[0] if RB == 1 else dcp.sum(0)
         dW1 = db1 = dW2 = db2 = dW3 = db3 = None
         if need_w:
-            nwg = min(nblk, max(256, -(-nblk // 64)))  # one workgroup per CU; at most 64 blocks each
+            nwg = dw_workgroups(nblk, N)
             part = torch.empty((nwg, H3 * H2 + H2 * H1 + H3 + H2), device=dev, dtype=torch.float32)
             if direct:
                 dW3, dW2, db3, db2 = gW3, gW2, gb3, gb2
