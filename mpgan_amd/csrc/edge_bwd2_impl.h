@@ -198,12 +198,11 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     // phase B's accumulators (W3^T image: SC_W3) to dZ2 in gradient units, layer 1's gate takes phase C's
     // (W2^T image: SC_W2, gradient unit 2^e) to plain dZ1
     // (wave-uniform values; each phase moves its pair into vector registers for its own duration only)
-    // (times 1 / c_j of the sender, there).  gfx950 has no scalar float ALU: computed once on the vector side, kept in scalar registers
-    auto uniform = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };
-    const float salpha2 = uniform(p.alpha * (1.f / SC_W3)), sone2 = 1.f / SC_W3;
-    const float sone1 = __builtin_bit_cast(float, (uint32_t)(127 - gexp - 4) << 23);   // 2^-e / SC_W2 (SC_W2 = 2^4)
+    // (times 1 / c_j of the sender, there).  gfx950 has no scalar float ALU: what is not integer arithmetic is recomputed where it is
+    // used -- kept across the pair loop such a value is the first thing the register allocator spills
+    const float sone2 = 1.f / SC_W3;
+    const float sone1 = __builtin_bit_cast(float, (uint32_t)(127 - gexp - 4) << 23);   // 2^-e / SC_W2 (SC_W2 = 2^4): integer arithmetic, a scalar register
     static_assert(SC_W2 == 16.f, "sone1 assumes SC_W2 = 2^4");
-    const float salpha1 = uniform(p.alpha * sone1);
     float dacc[T1][16];
 #pragma unroll
     for (int q = 0; q < T1; ++q)
@@ -213,6 +212,25 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
 #ifdef MPG_B2STAMP
     unsigned long long b2_st[7] = {0, 0, 0, 0, 0, 0, 0};
 #endif
+    // What a pair needs from memory -- its senders' sign words and rows of c -- is requested one pair ahead, at the top of
+    // the previous pair: vector memory operations complete in order, and requested at its own top a pair's loads queue up
+    // behind all the staging stores of the pair before (measured: ~1.2k clk of every pair).  Past the end the indices are
+    // clamped (the last pair is fetched again, unused).
+    uint32_t psw[2][T3 / 2];
+    float pc0[2], pc1[2];
+    auto prefetch = [&](int pq2) {
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd) {
+            const int jn = __builtin_amdgcn_readfirstlane((int)lst[max(0, min(2 * pq2 + sd, nvalid - 1))]);
+            const int blk = (b * RB + rb) * p.N + jn;
+#pragma unroll
+            for (int q = 0; q < T3 / 2; ++q) psw[sd][q] = p.sign3[(size_t)blk * (T3 * 32) + q * 64 + lane];
+            const float* cj = p.c + (size_t)(b * p.N + jn) * ldac;
+            pc0[sd] = cj[lane];
+            pc1[sd] = cj[64 + (lane & 31)];
+        }
+    };
+    prefetch(w);
     for (int pq = w; 2 * pq < nvalid; pq += 4) {
         const bool has2 = 2 * pq + 1 < nvalid;
         B2_STAMP(0);
@@ -220,7 +238,6 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
         jj[0] = __builtin_amdgcn_readfirstlane((int)lst[2 * pq]);
         jj[1] = has2 ? __builtin_amdgcn_readfirstlane((int)lst[2 * pq + 1]) : jj[0];
         float cpos[2], cneg[2];     // slope of layer 3 times m_j * dscale * 2^e * c_j: one select between two uniform constants
-        float rcj[2];               // 1 / c_j
         // erow2 == erow, in a form the optimiser cannot prove equal: every dropout word is needed twice per pair, phases
         // apart (forward recomputation, then the gate of the matching gradient), and with one visible value it keeps
         // all the one-instruction keep-masks of the first use alive for the second (hundreds of registers, spilled)
@@ -238,18 +255,17 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             }
             const int blk = (b * RB + rb) * p.N + jj[sd];
             const float dth = dither_of((uint32_t)blk);  // this sender's unit within the workgroup's (see the head of this file)
-            rcj[sd] = __builtin_amdgcn_rcpf(dth);
             cpos[sd] = mjs * in_set * dth; cneg[sd] = mjs * p.alpha * in_set * dth;
             erow[sd] = (uint32_t)((b * p.N + i) * p.N + jj[sd]);
             erow2[sd] = erow[sd] + opaque_zero;
             stoff[sd] = (sd == 0 || has2) ? blk * (NFR2 * 1024) + lane16 : (int)0x7ffffff0;
 #pragma unroll
-            for (int q = 0; q < T3 / 2; ++q) sw[sd][q] = p.sign3[(size_t)blk * (T3 * 32) + q * 64 + lane];
+            for (int q = 0; q < T3 / 2; ++q) sw[sd][q] = psw[sd][q];
             // the sender's row of c into this wave's LDS slot (96 floats: lanes 0..63, then lanes 0..31)
-            const float* cj = p.c + (size_t)(b * p.N + jj[sd]) * ldac;
-            lcw[sd * H1 + lane] = cj[lane] * SC_A;
-            if (lane < H1 - 64) lcw[sd * H1 + 64 + lane] = cj[64 + lane] * SC_A;
+            lcw[sd * H1 + lane] = pc0[sd] * SC_A;
+            if (lane < H1 - 64) lcw[sd * H1 + 64 + lane] = pc1[sd] * SC_A;
         }
+        prefetch(pq + 4);
 
         // ---- phase A: Z2 = W2' E1 + b2, k-outer (6 k-steps x 5 tiles).  The fragment of e1 = drop(lrelu(a_i + c_j))
         //      for k-step k+1 is built behind the MFMAs of k-step k (the signs of a_i + c_j are kept for dZ1's gate);
@@ -454,8 +470,9 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
         f32x16 accC[T1][2];
         {
             constexpr int KS = T2 * 2;  // 10 k-steps of 16 features of layer 2
-            float valpha2 = salpha2, vone2 = sone2;
-            asm volatile("" : "+v"(valpha2), "+v"(vone2));
+            float valpha2 = p.alpha, vone2 = sone2;
+            asm volatile("" : "+v"(valpha2), "+v"(vone2));   // (opaque copies made HERE: the product below cannot be hoisted out of the pair loop)
+            valpha2 *= vone2;
             b2_u32x4 zz[2][2];
             float v2[2][8];
             V ah[3][T1], al[3][T1];       // ring of three k-steps of W2^T fragments (L2 is more than one k-step away)
@@ -533,8 +550,11 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             // (DPP), so 16 values cost 15 exchanges instead of 80 and lane l ends with the total of value l & 15
             // (= accumulator register 8s + 4u + t  <->  feature 32 mm + 16 s + 8 u + 4 h + t).
             const bool lb0 = lane & 1, lb1 = lane & 2, lbb2 = lane & 4, lb3 = lane & 8;
-            float valpha1[2] = {salpha1 * rcj[0], salpha1 * rcj[1]}, vone1[2] = {sone1 * rcj[0], sone1 * rcj[1]};
-            asm volatile("" : "+v"(valpha1[0]), "+v"(vone1[0]), "+v"(valpha1[1]), "+v"(vone1[1]));
+            // (1 / c_j recomputed from the block index: two registers less across the pair)
+            float vone1[2] = {sone1 * __builtin_amdgcn_rcpf(dither_of((uint32_t)((b * RB + rb) * p.N + jj[0]))),
+                              sone1 * __builtin_amdgcn_rcpf(dither_of((uint32_t)((b * RB + rb) * p.N + jj[1])))};
+            asm volatile("" : "+v"(vone1[0]), "+v"(vone1[1]));
+            float valpha1[2] = {p.alpha * vone1[0], p.alpha * vone1[1]};
             // (the lane's slot in a row of dc, from an opaque copy of the lane id: hoisted out of the sender loop these few
             // loop-invariant values are what the register allocator spills -- and every scratch reload drains vmcnt)
             int oln = lane;
