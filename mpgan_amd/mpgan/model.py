@@ -32,7 +32,7 @@ def _unsupported(**flags):
 class SpectralNorm(nn.Module):
     """Spectral normalisation of a Linear layer as the reference wraps it (mpgan/spectral_normalization.py:11-61): the
     wrapped module keeps ``weight_bar`` (trained), ``weight_u`` / ``weight_v`` (power-iteration vectors, no gradient) and
-    ``bias`` -- same state-dict keys (``module.weight_bar`` ...).  ``weight()`` runs one power iteration in place and
+    ``bias`` -- same state-dict keys (``module.weight_bar`` ...).  ``weight()`` runs one power iteration and
     returns  W_bar / (u' W_bar v + 1e-12)  with the gradient flowing through W_bar only, which the caller feeds to the
     fused Linear launch."""
 
@@ -54,13 +54,18 @@ class SpectralNorm(nn.Module):
     def weight(self) -> Tensor:
         mod = self.module
         u, v, w = mod.weight_u, mod.weight_v, mod.weight_bar
+        # The power iteration runs out of place and the new vectors are stored through ``.data`` (as the reference does,
+        # spectral_normalization.py:31-36): an in-place ``copy_`` would bump the version of tensors autograd saved for
+        # the sigma graph of an EARLIER forward -- train_D runs D(real) and D(fake) before one backward.
         with torch.no_grad():
+            un, vn = u.data, v.data
             for _ in range(self.power_iterations):
-                t = torch.mv(w.t(), u)
-                v.copy_(t / (t.norm() + 1e-12))
-                t = torch.mv(w, v)
-                u.copy_(t / (t.norm() + 1e-12))
-        sigma = u.dot(w.mv(v))
+                t = torch.mv(w.t(), un)
+                vn = t / (t.norm() + 1e-12)
+                t = torch.mv(w, vn)
+                un = t / (t.norm() + 1e-12)
+        u.data, v.data = un, vn
+        sigma = un.dot(w.mv(vn))
         return w / (sigma + 1e-12)
 
 

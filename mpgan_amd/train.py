@@ -97,7 +97,16 @@ class FlatParams:
     def __init__(self, module: nn.Module, optimizer: str = "rmsprop", betas=(0.9, 0.999), weight_decay: float = 5e-4):
         if optimizer not in OPTIMIZERS:
             raise ValueError(f"optimizer must be one of {OPTIMIZERS}, got {optimizer!r}")
-        ps = [p for p in module.parameters()]
+        # Only what is TRAINED goes into the flat buffers: frozen parameters (spectral norm's power-iteration vectors,
+        # requires_grad = False) are never stepped by the reference's optimizers either -- filtered out by requires_grad
+        # or left with grad None (setup_training.py:1500-1523) -- and Adam's weight decay would otherwise move them.
+        all_ps = list(module.parameters())
+        self._trained_idx = [i for i, p in enumerate(all_ps) if p.requires_grad]   # positions in module.parameters()
+        self._n_all = len(all_ps)
+        ps = [all_ps[i] for i in self._trained_idx]
+        if not ps:
+            raise ValueError("FlatParams: the module has no trainable parameter")
+        self.params = ps
         self.module = module
         self.optimizer, self.betas, self.weight_decay = optimizer, tuple(betas), float(weight_decay)
         n = sum(p.numel() for p in ps)
@@ -169,32 +178,51 @@ class FlatParams:
             return torch.optim.Adam(stand_ins, lr=lr, weight_decay=self.weight_decay, betas=self.betas)
         return torch.optim.Adadelta(stand_ins, lr=lr)
 
-    def state_dict(self, lr: float = None) -> dict:
-        """What ``torch.optim.<Optimizer>(module.parameters(), ...).state_dict()`` would hold after the same steps."""
+    def state_dict(self, lr: float = None, filtered: bool = True) -> dict:
+        """What a ``torch.optim.<Optimizer>`` would hold after the same steps.  ``filtered`` (default): built over the
+        trainable parameters only, as ``setup_training.optimizers`` does under ``--spectral-norm-gen``
+        (``filter(lambda p: p.requires_grad, ...)``, setup_training.py:1500-1509) -- and identical to the unfiltered form for
+        a module without frozen parameters.  ``filtered=False``: built over ALL of ``module.parameters()``, frozen ones
+        included without state (what the reference's other branch gives a spectral-norm discriminator)."""
         lr = self.lr if lr is None else lr
         sd = self._torch_optimizer(1e-2 if lr is None else lr).state_dict()
         k_sq, k_aux = self._STATE_KEYS[self.optimizer]
         steps = torch.tensor(self.steps, dtype=torch.float32)
+        if not filtered:
+            sd["param_groups"][0]["params"] = list(range(self._n_all))
         if float(steps) > 0:
             for i, (off, k, shape) in enumerate(self._spans):
                 ent = {"step": steps.clone(), k_sq: self.sq[off:off + k].view(shape).clone()}
                 if k_aux is not None:
                     ent[k_aux] = self.aux[off:off + k].view(shape).clone()
-                sd["state"][i] = ent
+                sd["state"][i if filtered else self._trained_idx[i]] = ent
         return sd
 
     def load_state_dict(self, sd: dict):
-        """Take over the per-parameter state of a ``torch.optim`` state dict of the matching optimizer class
-        (parameters in ``module.parameters()`` order).  Returns the learning rate recorded in it."""
+        """Take over the per-parameter state of a ``torch.optim`` state dict of the matching optimizer class.  Its indices
+        are positions either in the list of trainable parameters or in all of ``module.parameters()`` (see
+        ``state_dict``): told apart by the length of its parameter group; entries may be missing (parameters that were
+        never stepped).  Returns the learning rate recorded in it."""
         k_sq, k_aux = self._STATE_KEYS[self.optimizer]
         state = sd["state"]
-        if state and len(state) != len(self._spans):
-            raise ValueError(f"optimizer state holds {len(state)} parameters, the module has {len(self._spans)}")
+        groups = sd.get("param_groups") or [{}]
+        n_listed = sum(len(g.get("params", ())) for g in groups)
+        if n_listed == len(self._spans) or (n_listed == 0 and len(state) <= len(self._spans)):
+            index = list(range(len(self._spans)))
+        elif n_listed == self._n_all:
+            index = self._trained_idx
+        else:
+            raise ValueError(f"optimizer state lists {n_listed} parameters; the module has {len(self._spans)} trainable "
+                             f"of {self._n_all}")
+        known = set(index)
+        stray = [k for k in state if int(k) not in known]
+        if stray:
+            raise ValueError(f"optimizer state has entries for parameters {stray} that are not trained here")
         self.sq.zero_()
         if self.aux is not None:
             self.aux.zero_()
         steps = 0.0
-        for i, (off, k, shape) in enumerate(self._spans):
+        for (off, k, shape), i in zip(self._spans, index):
             ent = state.get(i, state.get(str(i)))
             if ent is None:
                 continue
@@ -208,13 +236,17 @@ class FlatParams:
             steps = max(steps, float(ent.get("step", 0.0)))
         self.step_count.fill_(steps)
         self._host_steps = int(steps)
-        groups = sd.get("param_groups") or [{}]
         self.lr = groups[0].get("lr", self.lr)
         return self.lr
 
+    def versions(self) -> int:
+        """Sum of the autograd version counters of the parameters: changes when anything but the fused optimiser (which
+        works on the flat buffer, behind autograd's back) writes them -- ``load_state_dict``, an in-place edit."""
+        return sum(p._version for p in self.params)
 
-def _set_requires_grad(module: nn.Module, flag: bool):
-    for p in module.parameters():
+
+def _set_requires_grad(flat: "FlatParams", flag: bool):
+    for p in flat.params:    # (the trained ones: frozen parameters stay frozen)
         p.requires_grad_(flag)
 
 
@@ -296,6 +328,7 @@ class TrainStep:
         self.use_graphs = use_graphs and dev.type == "cuda"
         self._graphs = None
         self.fixed_noise = None  # tests: (noise_D, noise_G) used instead of fresh samples
+        self._seen_versions = (self.fD.versions(), self.fG.versions())
 
     # -- the three segments between collectives ------------------------------------------------
     def _noise(self, which: int = 0):
@@ -325,7 +358,7 @@ class TrainStep:
         ops.bump_seed(self.dev)
         self.D.train(); self.G.eval()
         self.fD.zero_grad()
-        _set_requires_grad(self.D, True)
+        _set_requires_grad(self.fD, True)
         if self._fused_ends():
             # real jets sit in the first half of the static batch; the generator writes the second half itself
             with torch.no_grad():
@@ -372,7 +405,7 @@ class TrainStep:
         self._refresh_packed(self.D)
         self.G.train()
         self.fG.zero_grad()
-        _set_requires_grad(self.D, False)
+        _set_requires_grad(self.fD, False)
         fake = self.G(self._noise(1), self.labels)
         if self._fused_ends():
             y, mask = self.D.features(fake, self.labels)
@@ -383,7 +416,7 @@ class TrainStep:
             loss = g_loss(self.loss, out)
             self._backward(loss)
             self.G_loss.copy_(loss.detach())
-        _set_requires_grad(self.D, True)
+        _set_requires_grad(self.fD, True)
 
     def _seg_end(self):  # G_optimizer.step() (train.py:521)
         self.fG.step(self.lr_gen, gscale=1.0 / self.world)
@@ -398,13 +431,33 @@ class TrainStep:
         self._seg_G(); self._allreduce(self.fG)
         self._seg_end()
 
+    def _training_state(self):
+        """Everything an iteration changes: parameters, optimiser moments and step counters, the dropout seed, the losses."""
+        ts = [self.D_loss, self.G_loss, ops.seed_tensor(self.dev)]
+        for f in (self.fD, self.fG):
+            ts += [f.flat, f.sq, f.step_count] + ([f.aux] if f.aux is not None else [])
+        return ts
+
     def capture(self, warmup: int = 3):
-        """Warm up eagerly on a side stream, then capture the three segments into hipGraphs."""
+        """Warm up eagerly on a side stream, then capture the three segments into hipGraphs.  The warm-up iterations are
+        real ones (kernels get loaded, their LDS limits set, the allocator's pools filled -- none of which may happen
+        during a capture): the training state is saved before and put back after them, so capturing -- which ``step``
+        does on its first call -- leaves parameters, optimiser state, step counters and the dropout seed where they
+        were.  (A run resumed from a checkpoint continues from exactly the state it loaded.)"""
         s = torch.cuda.Stream(device=self.dev)
         s.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(s):
+            if warmup:
+                saved = [t.clone() for t in self._training_state()]
+                host = (self.fD._host_steps, self.fG._host_steps)
             for _ in range(warmup):
                 self._eager()
+            if warmup:
+                for t, v in zip(self._training_state(), saved):
+                    t.copy_(v)
+                self.fD._host_steps, self.fG._host_steps = host
+                self._refresh_packed(self.D)
+                self._refresh_packed(self.G)
         torch.cuda.current_stream(self.dev).wait_stream(s)
         torch.cuda.synchronize(self.dev)
         graphs = []
@@ -428,7 +481,20 @@ class TrainStep:
         self._labels2[:self.B].copy_(self.labels)
         self._labels2[self.B:].copy_(self.labels)
 
+    def sync_external_writes(self):
+        """Parameters written from outside since the last step -- ``load_state_dict`` of a checkpoint (resume,
+        setup_training.py:1406-1416), an in-place edit -- went into the flat buffer (the parameters are views of it), but
+        the layers' packed weight images are only rebuilt behind an optimiser step, inside the captured segments: rebuild
+        them now, eagerly.  Called by ``step``; cheap when nothing changed (one pass over the version counters)."""
+        seen = (self.fD.versions(), self.fG.versions())
+        if seen != self._seen_versions:
+            if self.dev.type == "cuda":
+                self._refresh_packed(self.D)
+                self._refresh_packed(self.G)
+            self._seen_versions = seen
+
     def step(self):
+        self.sync_external_writes()
         if self.use_graphs and self._graphs is None:
             self.capture()
         if not self.use_graphs:

@@ -363,3 +363,58 @@ def test_discriminator_with_conditioning_options_vs_reference_golden():
     assert rel_err(x.grad.cpu().numpy(), g["dx"]) < 1e-3   # (the mask column included: it feeds the masked sums and njp)
     for k, p in D.named_parameters():
         assert summary_err(k, p.grad, g["grad__" + k]) < 1e-3, k
+
+
+def _run_steps(opt, n_steps, tmp, save_at=None, resume_from=None, precaptured=False):
+    """TrainStep with hipGraphs on fixed noise (dropout off).  ``save_at``: write the reference's checkpoint files after
+    that many steps.  ``resume_from``: start from FRESH modules + a fresh TrainStep and load that epoch's files before
+    stepping (``precaptured``: the TrainStep has already captured its graphs -- and run a step on other weights -- when
+    the checkpoint is loaded into it)."""
+    from mpgan_amd import train, checkpoint as ck
+    from oracle.train_ref import synthetic_batch
+    B, N = 16, 30
+    data, labels = synthetic_batch(B, N, seed=21)
+    if resume_from is None:
+        G, D = _setup(B, N)
+    else:
+        G, D = _setup(B, N, seedG=77, seedD=78)          # other weights: everything must come from the files
+    ts = train.TrainStep(G, D, B, N, use_graphs=True, optimizer=opt, betas=(0.5, 0.9))
+    ts.set_batch(data.cuda(), labels.cuda())
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    ts.fixed_noise = (torch.randn(B, N, 32, device="cuda", generator=gen) * 0.2,
+                      torch.randn(B, N, 32, device="cuda", generator=gen) * 0.2)
+    if resume_from is not None:
+        if precaptured:
+            ts.capture(warmup=0)
+            ts.step()
+        ck.load_models(D, G, tmp, resume_from)
+        ck.load_optimizers(ts.fD, ts.fG, tmp, resume_from)
+    for it in range(n_steps):
+        ts.step()
+        if save_at is not None and it + 1 == save_at:
+            torch.cuda.synchronize()
+            ck.save_models(D, G, ts.fD, ts.fG, tmp, save_at)
+    torch.cuda.synchronize()
+    return ts.fD.flat.clone(), ts.fG.flat.clone(), ts.fD.sq.clone(), ts.fG.sq.clone(), ts.fD.steps, float(ts.D_loss), float(ts.G_loss)
+
+
+@pytest.mark.parametrize("opt", ["rmsprop", "adam"])
+def test_resume_from_checkpoint_equals_uninterrupted_run(opt, tmp_path):
+    """setup_training.py:1134-1179, :1406-1416, :1525-1535 + train.py:526-537: four iterations in one go against two
+    iterations, ``save_models``, fresh modules and a fresh TrainStep (hipGraphs on), ``load_models`` +
+    ``load_optimizers``, two more -- bit-identical parameters, optimiser moments, step counters and losses.  Adam's step
+    counter lives in device memory and the captured graphs hold buffer addresses: also with the checkpoint loaded into
+    a TrainStep that has ALREADY captured its graphs."""
+    tmp = str(tmp_path / "models")
+    whole = _run_steps(opt, 4, tmp, save_at=2)
+    import os
+    assert sorted(os.listdir(tmp)) == ["D_2.pt", "D_optim_2.pt", "G_2.pt", "G_optim_2.pt"]
+    sd = torch.load(os.path.join(tmp, "D_optim_2.pt"), weights_only=False)
+    cls = {"rmsprop": torch.optim.RMSprop, "adam": torch.optim.Adam}[opt]
+    probe = cls([torch.zeros(tuple(v.shape)) for v in torch.load(os.path.join(tmp, "D_2.pt")).values()], lr=1.0)
+    probe.load_state_dict(sd)                            # the reference's own optimizer class reads the file
+    for variant in (False, True):
+        again = _run_steps(opt, 2, tmp, resume_from=2, precaptured=variant)
+        for a, b in zip(whole[:4], again[:4]):
+            assert torch.equal(a, b), (opt, variant)
+        assert whole[4:] == again[4:], (opt, variant, whole[4:], again[4:])

@@ -129,3 +129,96 @@ def test_fused_backwards_decline_double_backward():
     for fn in (ops.FusedMPLayerFn, ops.FusedLinearFn, ops.FusedDropoutFn, ops.FusedPackedAttnFn, ops.FusedAttnFn):
         src = inspect.getsource(fn)
         assert "@once_differentiable\n    def backward" in src, fn
+
+
+def test_jetnet_file_reader(tmp_path):
+    """JetNet's on-disk layout (particle_features [n, N, 4], jet_features [n, 4] = pt, eta, mass, num_particles) read
+    from a file the test writes itself, normalised as train.py:41-67 configures JetNet: x / max + shift per particle
+    feature, num_particles * (1 / num_hits) as the label, 70 / 30 train / valid split."""
+    from mpgan_amd.data import JetArrayDataset, read_jetnet_file, FEATURE_MAXES, FEATURE_SHIFTS
+    rs = np.random.RandomState(1)
+    n, N = 40, 30
+    mult = rs.randint(1, N + 1, size=n)
+    pf = rs.uniform(-1, 1, size=(n, N, 4)).astype(np.float32)
+    pf[..., 3] = np.arange(N)[None] < mult[:, None]
+    pf[..., :3] *= pf[..., 3:]
+    jf = np.stack([rs.uniform(800, 1600, n), rs.normal(0, 1, n), rs.uniform(0, 200, n), mult], axis=1).astype(np.float32)
+    np.savez(tmp_path / "g.npz", particle_features=pf, jet_features=jf)
+    a, b = read_jetnet_file(str(tmp_path / "g.npz"))
+    assert np.array_equal(a, pf) and np.array_equal(b, jf)
+    tr = JetArrayDataset.from_jetnet_file(str(tmp_path), "g", 30, split="train")
+    va = JetArrayDataset.from_jetnet_file(str(tmp_path), "g", 30, split="valid")
+    assert len(tr) == 28 and len(va) == 12
+    x, lab = va[2]
+    want = pf[30] / np.array(FEATURE_MAXES["g"], dtype=np.float32) + np.array(FEATURE_SHIFTS, dtype=np.float32)
+    assert np.allclose(x.numpy(), want, atol=1e-7) and x.dtype == torch.float32
+    assert float(lab) == float(np.float32(mult[30]) * np.float32(1.0 / 30))     # the product with the reciprocal
+    assert int(float(lab) * 30) == mult[30]
+    # a shorter particle axis takes the first (pT-ordered) particles and counts the multiplicity again
+    cut = JetArrayDataset.from_jetnet_file(str(tmp_path), "g", 10, split="all")
+    assert cut.particle_data.shape == (n, 10, 4)
+    assert np.allclose(cut.jet_features[:, 0].numpy() * 10, np.minimum(mult, 10))
+    # the 150-particle file name, a missing file, a malformed array
+    np.savez(tmp_path / "t150.npz", particle_features=np.zeros((3, 150, 4), np.float32))
+    assert JetArrayDataset.from_jetnet_file(str(tmp_path), "t", 150, split="all").particle_data.shape == (3, 150, 4)
+    with pytest.raises(FileNotFoundError):
+        JetArrayDataset.from_jetnet_file(str(tmp_path), "q", 30)
+    np.savez(tmp_path / "q.npz", particle_features=np.zeros((3, 30, 3), np.float32))
+    with pytest.raises(ValueError):
+        JetArrayDataset.from_jetnet_file(str(tmp_path), "q", 30)
+
+
+def test_flat_params_leave_frozen_parameters_alone():
+    """Spectral norm's power-iteration vectors (requires_grad = False) are not part of the flat buffers, never stepped,
+    and optimiser state dicts come and go in both index conventions of the reference's optimizers
+    (setup_training.py:1500-1523: filtered by requires_grad, or all of module.parameters())."""
+    from mpgan_amd.mpgan import LinearNet
+    from mpgan_amd.train import FlatParams
+    net = LinearNet([8, 6], input_size=5, output_size=2, final_linear=True, spectral_norm=True)
+    names = [k for k, _ in net.named_parameters()]
+    frozen = [i for i, (k, p) in enumerate(net.named_parameters()) if not p.requires_grad]
+    assert frozen and all(("weight_u" in names[i]) or ("weight_v" in names[i]) for i in frozen)
+    u_before = [p.detach().clone() for p in net.parameters() if not p.requires_grad]
+    fp = FlatParams(net, "adam", betas=(0.5, 0.9))
+    assert fp.n == sum(p.numel() for p in net.parameters() if p.requires_grad)
+    assert all(p.grad is None for p in net.parameters() if not p.requires_grad)
+    assert all(torch.equal(a, b) for a, b in zip(u_before, [p for p in net.parameters() if not p.requires_grad]))
+    trained = [p for p in net.parameters() if p.requires_grad]
+    for ref in (torch.optim.Adam(trained, lr=1e-3, weight_decay=5e-4, betas=(0.5, 0.9)),
+                torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=5e-4, betas=(0.5, 0.9))):
+        for p in trained:
+            p.grad.fill_(0.25)
+        ref.step()
+        sd = ref.state_dict()
+        fp.load_state_dict(sd)                                           # the reference's file, either convention
+        assert fp.steps == 1.0
+        filtered = len(sd["param_groups"][0]["params"]) == len(trained)
+        ours = fp.state_dict(1e-3, filtered=filtered)
+        assert list(ours["state"].keys()) == list(sd["state"].keys())
+        for i in sd["state"]:
+            assert torch.equal(ours["state"][i]["exp_avg_sq"].cpu(), sd["state"][i]["exp_avg_sq"])
+        ref.load_state_dict(ours)                                        # ... and torch.optim reads ours
+    with pytest.raises(ValueError):
+        fp.load_state_dict({"state": {}, "param_groups": [{"params": list(range(fp._n_all + 3))}]})
+
+
+def test_spectral_norm_two_forwards_before_one_backward():
+    """train_D runs D(real) and D(fake) and backpropagates once (train.py:432-460): the power iteration of the second
+    forward must not invalidate what autograd saved for the first."""
+    from mpgan_amd.mpgan.model import SpectralNorm
+    torch.manual_seed(0)
+    sn = SpectralNorm(torch.nn.Linear(6, 4))
+    u0 = sn.module.weight_u.detach().clone()
+    w1 = sn.weight()
+    w2 = sn.weight()
+    (w1.sum() + (w2 * w2).sum()).backward()
+    assert sn.module.weight_bar.grad is not None and bool(torch.isfinite(sn.module.weight_bar.grad).all())
+    assert not torch.equal(sn.module.weight_u, u0) and not sn.module.weight_u.requires_grad
+    # one power iteration as the reference does it (spectral_normalization.py:29-39)
+    ref = torch.nn.Linear(6, 4)
+    torch.manual_seed(0)
+    sn2 = SpectralNorm(torch.nn.Linear(6, 4))
+    w, u = sn2.module.weight_bar.detach(), sn2.module.weight_u.detach().clone()
+    v = torch.mv(w.t(), u); v = v / (v.norm() + 1e-12)
+    u = torch.mv(w, v); u = u / (u.norm() + 1e-12)
+    assert torch.allclose(sn2.weight(), w / (u.dot(w.mv(v)) + 1e-12), atol=1e-7)
