@@ -110,9 +110,31 @@ class LinearNet(nn.Module):
                 bn.running_var.mul_(1 - mom).add_(var, alpha=mom * M / max(M - 1, 1))
         return y
 
+    def _forward_dd(self, x: Tensor, resid: Tensor = None) -> Tensor:
+        """The twice-differentiable form (``ops.double_backward_route``): Linear as ``ops.MatMulFn`` + bias, LeakyReLU and
+        dropout as ATen's own (their derivative formulas are differentiable; dropout draws from torch's generator, as
+        the reference's does).  Batch norm has a first-order kernel only."""
+        if self.batch_norm:
+            raise NotImplementedError("LinearNet: batch norm has no double-backward route (the gradient penalty needs one)")
+        last = len(self.net) - 1
+        shp = x.shape
+        x = x.reshape(-1, shp[-1])
+        for k, lin in enumerate(self.net):
+            W = lin.weight() if isinstance(lin, SpectralNorm) else lin.weight
+            x = ops.MatMulFn.apply(x, W, "nt")
+            if lin.bias is not None:
+                x = x + lin.bias
+            if not (self.final_linear and k == last):
+                x = torch.nn.functional.leaky_relu(x, self.leaky_relu_alpha)
+            x = torch.nn.functional.dropout(x, self.dropout_p, self.training)
+        x = x.reshape(*shp[:-1], x.shape[-1])
+        return x if resid is None else x + resid
+
     def forward(self, x: Tensor, resid: Tensor = None) -> Tensor:
         """``resid`` (not in the reference signature): added to the output, inside the last layer's launch when that
         layer has no activation -- MAB's ``x + ff(x)``."""
+        if x.is_cuda and ops.double_backward_on(x.device):
+            return self._forward_dd(x, resid)
         last = len(self.net) - 1
         for k, lin in enumerate(self.net):
             act = not (self.final_linear and k == last)
@@ -233,7 +255,7 @@ class MPLayer(nn.Module):
         assert not (use_mask and mask is None), "need ``mask`` tensor if using ``use_mask`` option"
         assert not (self.clabels and labels is None), "need ``labels`` tensor if using ``clabels`` option"
         assert not (self.mask_fne_np and num_jet_particles is None), "need ``num_jet_particles`` tensor if using ``mask_fne_np`` option"
-        if not self.fused:
+        if not self.fused or (x.is_cuda and ops.double_backward_on(x.device)):
             return self._forward_edges(x, use_mask, mask, labels, num_jet_particles)
         fe, fn = self.fe.net, self.fn.net
         nbr = None
@@ -435,7 +457,7 @@ class MPDiscriminator(MPNet):
         return x, (mask if use_mask else None)
 
     def forward(self, x: Tensor, labels: Tensor = None) -> Tensor:
-        head = self.fused_head() if x.is_cuda else None
+        head = self.fused_head() if (x.is_cuda and not ops.double_backward_on(x.device)) else None
         if head is None:
             return super().forward(x, labels)
         y, mask = self.features(x, labels)

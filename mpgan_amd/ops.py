@@ -47,6 +47,8 @@ class DeviceState:
                     ``torch.autograd.grad``, hooks or anything else needs the gradients as autograd values)
     deferred_wgrad  a ``WgradBatch`` that collects the stand-alone Linear layers' weight gradients of the
                     backward in flight (``TrainStep`` flushes it as grouped launches), or None
+    double_backward modules built while it is set (``double_backward_route``) take the route whose backward is itself
+                    differentiable: the gradient penalty's ``torch.autograd.grad(..., create_graph=True)`` (train.py:304-311)
     """
 
     def __init__(self, index: int):
@@ -56,6 +58,7 @@ class DeviceState:
         self.last_tag = 0
         self.grad_into_param = False
         self.deferred_wgrad = None
+        self.double_backward = False
 
 
     @property
@@ -175,8 +178,9 @@ def gemm(A, lda, B, ldb, Cout, ldc, M, N, K, *, ak=True, bk=True, a_off=0, b_off
     check(_lib.lib().mpg_gemm(C.byref(g), int(ak), int(bk), splitk, _stream()), "mpg_gemm")
 
 
-def linear_fwd(x, W, bias=None, *, act=False, alpha=0.2, drop=None, x2=None, w_col0=0, w_cols=None, resid=None):
-    """y = drop(act([x | x2] @ W[:, w_col0:w_col0+K]^T + bias)) (+ resid).  x [M,K1], W [N,ldw]."""
+def linear_fwd(x, W, bias=None, *, act=False, alpha=0.2, drop=None, x2=None, w_col0=0, w_cols=None, resid=None, f16=None):
+    """y = drop(act([x | x2] @ W[:, w_col0:w_col0+K]^T + bias)) (+ resid).  x [M,K1], W [N,ldw].  ``f16``: fp16 hi/lo
+    operands (the forward's default: ~2^-21 per product, magnitudes below 65504) or bf16 hi/lo (~2^-17, any magnitude)."""
     M, K1 = x.shape
     K2 = 0 if x2 is None else x2.shape[1]
     K = K1 + K2 if w_cols is None else w_cols
@@ -184,7 +188,7 @@ def linear_fwd(x, W, bias=None, *, act=False, alpha=0.2, drop=None, x2=None, w_c
     y = torch.empty((M, N), device=x.device, dtype=torch.float32)
     gemm(x, x.stride(0), W, W.stride(0), y, N, M, N, K, ak=True, bk=True, b_off=w_col0,
          A2=x2, lda2=0 if x2 is None else x2.stride(0), K1=K1, bias=bias, act=act, alpha=alpha, drop=drop,
-         resid=resid, ldr=0 if resid is None else resid.stride(0), f16=FWD_F16)
+         resid=resid, ldr=0 if resid is None else resid.stride(0), f16=FWD_F16 if f16 is None else f16)
     return y
 
 
@@ -681,6 +685,62 @@ class FusedLinearFn(torch.autograd.Function):
             db = g2.sum(0)
         dx = linear_bwd_data(g2, W).reshape(shp) if ctx.needs_input_grad[0] else None
         return dx, dW, db, None, None, None, None, (gy if ctx.has_resid else None)
+
+
+class MatMulFn(torch.autograd.Function):
+    """C = A B^T ("nt"), A B ("nn") or A^T B ("tn") on ``mpg_gemm`` -- with a backward that is written in terms of
+    ``MatMulFn`` itself, so that it can be differentiated again, to any order.  The three forms are closed under
+    differentiation:  nt: dA = G B (nn), dB = G^T A (tn);  nn: dA = G B^T (nt), dB = A^T G (tn);  tn: dA = B G^T (nt),
+    dB = A G (nn).  This is the product the double-backward route is made of (``LinearNet._forward_dd``): the gradient
+    penalty (train.py:286-324) differentiates D's input gradient once more, which the fused kernels
+    (``once_differentiable``) decline."""
+
+    @staticmethod
+    def forward(ctx, A, B, form):
+        _chk(A, "A"); _chk(B, "B")
+        A, B = A.contiguous(), B.contiguous()
+        ctx.form = form
+        ctx.save_for_backward(A, B)
+        if form == "nt":   # (bf16 hi/lo like the other two forms: gradients of any magnitude pass through all three)
+            return linear_fwd(A, B, None, f16=False)
+        if form == "nn":
+            return linear_bwd_data(A, B)
+        if form == "tn":
+            return linear_bwd_weight(A, B)
+        raise ValueError(f"MatMulFn: form must be nt / nn / tn, got {form!r}")
+
+    @staticmethod
+    def backward(ctx, G):
+        A, B = ctx.saved_tensors
+        nA, nB = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        mm = MatMulFn.apply
+        if ctx.form == "nt":
+            return (mm(G, B, "nn") if nA else None), (mm(G, A, "tn") if nB else None), None
+        if ctx.form == "nn":
+            return (mm(G, B, "nt") if nA else None), (mm(A, G, "tn") if nB else None), None
+        return (mm(B, G, "nt") if nA else None), (mm(A, G, "nn") if nB else None), None
+
+
+class double_backward_route:
+    """``with ops.double_backward_route(device):`` -- modules called inside take the route that can be differentiated
+    twice: every product a ``MatMulFn``, everything elementwise plain ATen (whose backward formulas are differentiable
+    themselves), the edge matrix materialised as the reference builds it.  First-order-only pieces (the fused
+    message-passing and attention kernels, batch norm) are not used there; a configuration that needs one raises."""
+
+    def __init__(self, device="cuda"):
+        self.state = dev_state(device)
+
+    def __enter__(self):
+        self.prev, self.state.double_backward = self.state.double_backward, True
+        return self
+
+    def __exit__(self, *exc):
+        self.state.double_backward = self.prev
+        return False
+
+
+def double_backward_on(device) -> bool:
+    return dev_state(device).double_backward
 
 
 class FusedDropoutFn(torch.autograd.Function):

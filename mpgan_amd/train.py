@@ -5,8 +5,10 @@ Mirrors the reference's ``train_D`` / ``train_G`` (train.py:398-523): losses ``l
 (default), Adam, Adadelta as ``setup_training.optimizers`` builds them (setup_training.py:1511-1523),
 ``num_critic = num_gen = 1``, generator noise ~ N(0, sd=0.2) sampled on the device every step
 (train.py:100-141), D in train mode (dropout on) in both sub-steps, G in eval mode in the D step.
-The gradient penalty (train.py:286-324) needs a second derivative through D; the fused ops are first-order only
-(``once_differentiable``), so ``gp_lambda != 0`` is refused at construction.
+The gradient penalty (train.py:286-324, ``--gp``) needs a second derivative through D.  The fused ops are first-order
+only (``once_differentiable``), so the penalty's own pass D(interpolated) takes the double-backward route
+(``ops.double_backward_route``: every product an ``ops.MatMulFn`` on the HIP GEMM, the rest ATen) while D(real) and
+D(generated) stay on the fused kernels; available for the message-passing discriminator.
 
 Two pieces of work the reference does and throws away are not done (results-neutral, SURVEY.md
 section 3.1): the D step does not back-propagate into G (its gradients are zeroed before use,
@@ -294,13 +296,15 @@ class TrainStep:
                  optimizer: str = "rmsprop", betas=(0.9, 0.999), gp_lambda: float = 0.0):
         if loss not in LOSSES:
             raise ValueError(f"loss must be one of {LOSSES}, got {loss!r}")
-        if gp_lambda:
+        if gp_lambda and not isinstance(D, MPDiscriminator):
             # train.py:286-324: torch.autograd.grad(D(interpolated), interpolated, create_graph=True) and a backward
-            # through that gradient.  The fused MPLayer / attention backward kernels are not themselves
-            # differentiable (ops: once_differentiable) -- declined here, loudly, rather than training on a
-            # penalty whose second-order terms are silently missing.
-            raise RuntimeError("mpgan_amd: the gradient penalty (--gp) needs double backward through the discriminator, "
-                               "which the fused MI355X ops do not provide; use gp_lambda = 0")
+            # through that gradient.  The attention blocks have first-order kernels only and no double-backward route
+            # yet -- declined here, loudly, rather than training on a penalty whose second-order terms are missing.
+            raise NotImplementedError("mpgan_amd: the gradient penalty (--gp) needs double backward through the "
+                                      "discriminator; that route exists for MPDiscriminator only")
+        self.gp_lambda = float(gp_lambda)
+        self.GP = torch.zeros((), device=next(G.parameters()).device)   # last penalty value (the reference's losses["gp"])
+        self.fixed_alpha = None   # tests: the interpolation weights [B, 1, 1] instead of fresh uniform samples
         self.G, self.D = G, D
         self.loss = loss
         # train_D evaluates D on the real and on the generated batch (train.py:432-447).  D has no cross-sample
@@ -342,7 +346,8 @@ class TrainStep:
         configurations.  Then an iteration has no autograd node and no elementwise ATen kernel between the last
         message-passing / attention block and the loss, in either direction."""
         return (self.dev.type == "cuda" and hasattr(self.G, "generate_into") and hasattr(self.D, "features")
-                and getattr(self.D, "fused_head", lambda: None)() is not None and self.batch_real_fake)
+                and getattr(self.D, "fused_head", lambda: None)() is not None and self.batch_real_fake
+                and not self.gp_lambda)
 
     def _head_loss(self, y, mask, gen_step: bool, n_jets: int, loss_out, wgrad: bool):
         w, b, mean, sigmoid, p = self.D.fused_head()
@@ -374,8 +379,26 @@ class TrainStep:
         else:
             out = torch.cat([self.D(self.data.clone(), self.labels).reshape(-1), self.D(fake, self.labels).reshape(-1)])
         loss = d_loss(self.loss, out, self.B, self._real)
+        self.D_loss.copy_(loss.detach())   # (D_real_loss + D_fake_loss: the reference's losses["D"] leaves the penalty out)
+        if self.gp_lambda:
+            gp = self.gradient_penalty(self.data, fake)
+            self.GP.copy_(gp.detach())
+            loss = loss + gp
         self._backward(loss)
-        self.D_loss.copy_(loss.detach())
+
+    def gradient_penalty(self, real: torch.Tensor, fake: torch.Tensor) -> torch.Tensor:
+        """``gradient_penalty`` of train.py:286-324:  gp_lambda * mean_b (|| dD(x_b)/dx_b ||_2 - 1)^2  at
+        x = a real + (1 - a) generated, a ~ U[0, 1) per jet; D is called without labels, the norm runs over all
+        particles and features of a jet (mask column included) with 1e-12 under the root.  D(x) runs on the
+        double-backward route, so that the penalty can be back-propagated into D's parameters."""
+        B = real.shape[0]
+        alpha = self.fixed_alpha if self.fixed_alpha is not None else torch.rand(B, 1, 1, device=real.device)
+        x = (alpha * real + (1 - alpha) * fake.detach()).requires_grad_(True)
+        with ops.double_backward_route(self.dev):
+            prob = self.D(x)
+            grads = torch.autograd.grad(prob, x, torch.ones_like(prob), create_graph=True, retain_graph=True)[0]
+        norm = torch.sqrt((grads.reshape(B, -1) ** 2).sum(1) + 1e-12)
+        return self.gp_lambda * ((norm - 1) ** 2).mean()
 
     def _backward(self, root, grad=None):
         """root.backward(grad) with the stand-alone Linear layers' weight gradients collected and issued as grouped

@@ -408,6 +408,53 @@ def main():
             rec["postG__" + k] = summarize(k, p.data)
         np.savez_compressed(os.path.join(OUT, f"train_step_{model}.npz"), **rec)
         print("train step", model, rec["D_loss0"], rec["G_loss0"], rec["D_loss1"], rec["G_loss1"])
+
+    # ------------------------------------------------------------------ 6. gradient penalty (--gp): double backward through D
+    # train.py cannot be imported (jetnet), but its ``gradient_penalty`` and ``calc_D_loss`` (train.py:286-395) are
+    # self-contained: their definitions are taken out of the reference's source with ``ast`` and EXECUTED here as they
+    # are, on the reference's own discriminator.  The interpolation weights they draw (torch.rand(B, 1, 1), the first
+    # draw after the seed) are recorded by repeating the draw.
+    import ast
+    with open(os.path.join(REF, "train.py")) as f:
+        tree = ast.parse(f.read())
+    wanted = [n for n in tree.body
+              if (isinstance(n, ast.FunctionDef) and n.name in ("gradient_penalty", "calc_D_loss"))
+              or (isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") in ("bce", "mse"))]
+    assert len(wanted) == 4, [getattr(n, "name", None) for n in wanted]
+    from torch.autograd import Variable, grad as torch_grad
+    ns = {"torch": torch, "Variable": Variable, "torch_grad": torch_grad}
+    exec(compile(ast.Module(body=wanted, type_ignores=[]), os.path.join(REF, "train.py"), "exec"), ns)
+    for loss in ("w", "ls"):
+        dt = torch.float64
+        B, N = 8, 30
+        sys.argv = ["gen_golden", "--model", "mpgan", "--disc-dropout", "0", "--loss", loss, "--gp", "10"]
+        a = st.process_args(st.parse_args())
+        Gm, Dm = st.setup_mpgan(a, gen=True).to(dt), st.setup_mpgan(a, gen=False).to(dt)
+        Gm.load_state_dict(init_state_dict(mpgan_param_shapes(True), seed=41, dtype=dt))
+        Dm.load_state_dict(init_state_dict(mpgan_param_shapes(False), seed=42, dtype=dt))
+        data, labels = synthetic_batch(B, N, seed=9, dist="uniform", dtype=dt)
+        nD = seeded((B, N, 32), 45, 0.2).to(dt)
+        Dm.train(); Gm.eval()
+        out_r = Dm(data.clone(), labels)
+        fake = Gm(nD, labels)
+        out_f = Dm(fake, labels)
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(dt)   # (the reference draws alpha and its ones in the default dtype)
+        try:
+            torch.manual_seed(1234)
+            alpha = torch.rand(B, 1, 1)
+            torch.manual_seed(1234)
+            D_loss, items = ns["calc_D_loss"](loss, Dm, data, fake, out_r, out_f, B, model="mpgan", gp_lambda=a.gp)
+        finally:
+            torch.set_default_dtype(prev)
+        Dm.zero_grad()
+        D_loss.backward()
+        rec = dict(data=data.numpy(), labels=labels.numpy(), noise_D=nD.numpy(), alpha=alpha.numpy(), gp_lambda=a.gp,
+                   D_loss=D_loss.item(), Dr=items["Dr"], Df=items["Df"], gp=items["gp"], fake=fake.detach().numpy())
+        for k, p in Dm.named_parameters():
+            rec["gradD__" + k] = summarize(k, p.grad)
+        np.savez_compressed(os.path.join(OUT, f"gp_step_mpgan_{loss}.npz"), **rec)
+        print("gp step", loss, rec["D_loss"], rec["gp"])
     return 0
 
 

@@ -418,3 +418,97 @@ def test_resume_from_checkpoint_equals_uninterrupted_run(opt, tmp_path):
         for a, b in zip(whole[:4], again[:4]):
             assert torch.equal(a, b), (opt, variant)
         assert whole[4:] == again[4:], (opt, variant, whole[4:], again[4:])
+
+
+def test_matmul_fn_is_twice_differentiable():
+    """ops.MatMulFn (the product of the double-backward route): values, first and second derivatives of a scalar built
+    from all three forms against torch's own matmul in fp64."""
+    from mpgan_amd import ops
+    torch.manual_seed(3)
+    A = torch.randn(37, 20, device="cuda", requires_grad=True)
+    Bm = torch.randn(11, 20, device="cuda", requires_grad=True)
+    Cm = torch.randn(11, 5, device="cuda", requires_grad=True)
+
+    def f(mm, a, b, c):
+        y = mm(a, b, "nt")                 # [37, 11]
+        z = mm(torch.tanh(y), c, "nn")     # [37, 5]
+        w = mm(z, torch.sin(a), "tn")      # [5, 20]
+        return (w ** 2).sum()
+
+    ref_mm = lambda x, y, form: x @ y.t() if form == "nt" else (x @ y if form == "nn" else x.t() @ y)
+    a64, b64, c64 = (t.detach().double().cpu().requires_grad_(True) for t in (A, Bm, Cm))
+    v, r = f(ops.MatMulFn.apply, A, Bm, Cm), f(ref_mm, a64, b64, c64)
+    assert abs(float(v) - float(r)) < 1e-4 * abs(float(r))
+    g = torch.autograd.grad(v, (A, Bm, Cm), create_graph=True)
+    g64 = torch.autograd.grad(r, (a64, b64, c64), create_graph=True)
+    for x, y in zip(g, g64):
+        assert rel_err(x.detach().cpu().numpy(), y.detach().numpy()) < 1e-4
+    s, s64 = sum((x ** 2).sum() for x in g), sum((y ** 2).sum() for y in g64)
+    h = torch.autograd.grad(s, (A, Bm, Cm))
+    h64 = torch.autograd.grad(s64, (a64, b64, c64))
+    for x, y in zip(h, h64):
+        assert rel_err(x.cpu().numpy(), y.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("loss", ["w", "ls"])
+def test_gradient_penalty_step_vs_reference_golden(loss):
+    """--gp (train.py:286-324, calc_D_loss :331-395): the D step's loss, penalty and gradients -- with the penalty's
+    second-order terms, back-propagated through the double-backward route of the discriminator -- against what the
+    reference's own functions produced (tests/gen_golden.py executes them from its source).  The fused route still
+    declines a second derivative."""
+    from oracle import train_ref as T
+    from mpgan_amd import train, ops
+    g = load_golden(f"gp_step_mpgan_{loss}.npz")
+    B, N = g["data"].shape[:2]
+    G, D = train.default_mpgan(N, disc_dropout=0.0, loss=loss)
+    G.load_state_dict(T.init_state_dict(T.mpgan_param_shapes(True), 41, torch.float32))
+    D.load_state_dict(T.init_state_dict(T.mpgan_param_shapes(False), 42, torch.float32))
+    ts = train.TrainStep(G, D, B, N, use_graphs=False, loss=loss, gp_lambda=float(g["gp_lambda"]), lr_disc=0.0)
+    ts.set_batch(torch.from_numpy(g["data"]).float().cuda(), torch.from_numpy(g["labels"]).float().cuda())
+    nD = torch.from_numpy(g["noise_D"]).float().cuda()
+    ts.fixed_noise = (nD, nD)
+    ts.fixed_alpha = torch.from_numpy(g["alpha"]).float().cuda()
+    ts._seg_D()
+    torch.cuda.synchronize()
+    assert abs(float(ts.GP) - float(g["gp"])) < 1e-3 * abs(float(g["gp"]))
+    assert abs(float(ts.D_loss) - (float(g["Dr"]) + float(g["Df"]))) < 1e-4 * max(abs(float(g["Dr"]) + float(g["Df"])), 1e-3)
+    assert abs(float(ts.D_loss) + float(ts.GP) - float(g["D_loss"])) < 1e-3 * abs(float(g["D_loss"]))
+    for k, p in D.named_parameters():
+        assert summary_err(k, p.grad, g["gradD__" + k]) < 1e-3, k
+    # the fused kernels are first order: asking them for a second derivative fails loudly
+    x = torch.from_numpy(g["data"]).float().cuda().requires_grad_(True)
+    out = D(x)
+    (gx,) = torch.autograd.grad(out.sum(), x, create_graph=True)
+    with pytest.raises(RuntimeError):
+        (gx ** 2).sum().backward()
+    # the attention discriminator has no double-backward route: declined at construction
+    Gg, Dg = train.default_gapt(N, disc_dropout=0.0)
+    with pytest.raises(NotImplementedError):
+        train.TrainStep(Gg, Dg, B, N, gp_lambda=10.0)
+
+
+def test_gradient_penalty_under_graphs_equals_eager():
+    """The --gp iteration (double-backward route inside train_D) captured into hipGraphs replays bit-identically to eager
+    execution (dropout off, fixed noise and interpolation weights)."""
+    from oracle.train_ref import synthetic_batch
+    from mpgan_amd import train
+    B, N = 8, 30
+    data, labels = synthetic_batch(B, N, seed=13)
+    res = []
+    for use_graphs in (False, True):
+        G, D = train.default_mpgan(N, disc_dropout=0.0, loss="w")
+        from oracle import train_ref as T
+        G.load_state_dict(T.init_state_dict(T.mpgan_param_shapes(True), 41, torch.float32))
+        D.load_state_dict(T.init_state_dict(T.mpgan_param_shapes(False), 42, torch.float32))
+        ts = train.TrainStep(G, D, B, N, use_graphs=use_graphs, loss="w", gp_lambda=10.0)
+        ts.set_batch(data.cuda(), labels.cuda())
+        gen = torch.Generator(device="cuda").manual_seed(2)
+        ts.fixed_noise = (torch.randn(B, N, 32, device="cuda", generator=gen) * 0.2,
+                          torch.randn(B, N, 32, device="cuda", generator=gen) * 0.2)
+        ts.fixed_alpha = torch.rand(B, 1, 1, device="cuda", generator=gen)
+        for _ in range(2):
+            ts.step()
+        torch.cuda.synchronize()
+        res.append((ts.fD.flat.clone(), ts.fG.flat.clone(), float(ts.D_loss), float(ts.GP), float(ts.G_loss)))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and res[0][2:] == res[1][2:]
+    assert res[0][3] > 0

@@ -171,6 +171,30 @@ def test_train_step(model):
         assert rel_err(summarize(k, v), g["postG__" + k]) < 1e-10, k
 
 
+@pytest.mark.parametrize("loss", ["w", "ls"])
+def test_gradient_penalty_step(loss):
+    """The D step with --gp (train.py:286-324 + calc_D_loss :331-395, both EXECUTED from the reference's source by
+    tests/gen_golden.py): loss, penalty and D's gradients -- the penalty's second-order terms included."""
+    g = load_golden(f"gp_step_mpgan_{loss}.npz")
+    dt = torch.float64
+    sdG = T.init_state_dict(T.mpgan_param_shapes(True), 41, dt)
+    sdD = {k: v.requires_grad_(True) for k, v in T.init_state_dict(T.mpgan_param_shapes(False), 42, dt).items()}
+    data, labels, nD, alpha = (torch.from_numpy(g[k]) for k in ("data", "labels", "noise_D", "alpha"))
+    cfg = {"D": {"sigmoid": loss not in ("w", "hinge")}}
+    with torch.no_grad():
+        fake = T._fwd_G("mpgan", sdG, nD, labels, data.shape[1], cfg)
+    assert rel_err(fake.numpy(), g["fake"]) < 1e-12
+    out_r = T._fwd_D("mpgan", sdD, data, labels, 0.0, None, cfg)
+    out_f = T._fwd_D("mpgan", sdD, fake, labels, 0.0, None, cfg)
+    base = T.d_loss_ref(loss, out_r, out_f)
+    gp = T.gradient_penalty_ref(float(g["gp_lambda"]), sdD, data, fake, alpha, cfg)
+    assert abs(float(gp) - float(g["gp"])) < 1e-10 * abs(float(g["gp"]))
+    assert abs(float(base + gp) - float(g["D_loss"])) < 1e-10 * abs(float(g["D_loss"]))
+    grads = torch.autograd.grad(base + gp, list(sdD.values()))
+    for (k, _), v in zip(sdD.items(), grads):
+        assert rel_err(summarize(k, v), g["gradD__" + k]) < 1e-8, k
+
+
 def ln_sab_shapes(E=64):
     sh = dict(T._mab_shapes("mab", E))
     for n in ("norm1", "norm2"):
