@@ -111,8 +111,9 @@ def parse_args():
 
 
 def self_launch(args):
-    """--gpus N > 1 outside torchrun: become the launcher.  Nothing in this process has touched a GPU yet (torch is
-    not even imported), so starting children is safe; the library is built first because ranks must not compile."""
+    """--gpus N > 1 outside torchrun: become the launcher.  No HIP call has been made in this process (importing the
+    package imports torch, which initialises nothing on the device), so starting children is safe; the library is
+    built first because ranks must not compile."""
     from mpgan_amd import _lib
     _lib.build()
     with socket.socket() as s:
@@ -121,6 +122,10 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     log("launching", " ".join(cmd))
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: the hosts this runs on only support dmabuf IPC; RCCL's intra-node transport shares
+    # device buffers between the ranks' processes, and with the legacy mode hipIpcGetMemHandle fails ("invalid
+    # argument").  The image exports it already -- this keeps it when the caller's environment was scrubbed, and
+    # never overrides a value the caller set.
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.call(cmd, env=env)
 

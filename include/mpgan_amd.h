@@ -159,8 +159,8 @@ typedef struct MpgEdgeFwd {
 int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream);
 
 /* mpg_knn_sets: the neighbour sets of MPLayer._getA_knn (mpgan/model.py:319-381) as bit masks for the fused edge kernels.
- * Per jet: d(i, j) = || s_j x_j - x_i + 1e-12 || over the F node features, s_j = 1 for a real sender and 1e4 for a
- * zero-masked one (:333-335); the senders of receiver i are those of rank [first, first + k) in ascending distance
+ * Per jet: d(i, j) = || s_j x_j - x_i + 1e-12 || over the F node features, s_j = (1 - 1e4) mask_j + 1e4 (:333-335: 1 for
+ * a real sender, 1e4 for a zero-masked one); the senders of receiver i are those of rank [first, first + k) in ascending distance
  * (first = 0 with self loops, 1 without; equal distances in index order).  nbr is [B*N][ceil(N/32)] words.  Running
  * the fully-connected kernels over all N senders with these bits as a per-edge factor gives the reference's
  * gather / fe / sum over the k gathered neighbours (mean: agg_scale = 1/k); N <= 192. */

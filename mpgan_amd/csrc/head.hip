@@ -187,7 +187,9 @@ __global__ __launch_bounds__(256) void knn_sets_kernel(const float* __restrict__
     const float* xb = x + (size_t)b * N * ldx;
     for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
         const int i = e / N, j = e % N;
-        const float sj = (mask != nullptr && mask[(size_t)b * N + j] == 0.f) ? 1e4f : 1.f;   // ((1 - mul) mask + mul), mul = 1e4
+        // ((1 - mul) mask + mul), mul = 1e4 (mpgan/model.py:333-335), as the reference evaluates it: continuous in the mask
+        // (1 for a real sender, 1e4 for a zero-masked one, in between for the soft masks of mask_exp / learnt masks)
+        const float sj = mask != nullptr ? (1.f - 1e4f) * mask[(size_t)b * N + j] + 1e4f : 1.f;
         float acc = 0.f;
         for (int f = 0; f < F; ++f) {
             const float d = sj * xb[(size_t)j * ldx + f] - xb[(size_t)i * ldx + f] + 1e-12f;

@@ -187,8 +187,10 @@ class MPLayer(nn.Module):
                 num_ef += 1
         self.num_ef = num_ef
         extra = self.clabels + int(self.mask_fne_np)
+        # (pos_diffs without any edge feature would still change which coordinates the k-NN distance is measured on,
+        # mpgan/model.py:340-345; the fused route measures it on all node features)
         self.fused = (list(self.fe_layers) == [ops.H1, ops.H2, ops.H3] and len(self.fn_layers) == 2
-                      and num_ef == 0 and extra == 0
+                      and num_ef == 0 and extra == 0 and not self.pos_diffs
                       and not (linear_args.get("batch_norm") or linear_args.get("spectral_norm")))
         self.fe = LinearNet(self.fe_layers, input_size=2 * input_node_size + num_ef + extra, final_linear=False, **linear_args)
         self.fn = LinearNet(self.fn_layers, input_size=self.fe_layers[-1] + input_node_size + extra,
@@ -274,13 +276,16 @@ class MPLayer(nn.Module):
         """Persistent weight images of this layer for the current mode (dropout scale) -- rebuilt when a
         parameter changes (``PackedMPLayer.ensure``) or on ``refresh_packed()``."""
         dscale = ops.drop_params(self.fe.dropout_p)[1] if self.training else 1.0
-        key = (dscale, ops.FWD_F16)
-        cache = self.__dict__.setdefault("_pack_cache", {})
         params = tuple(l.weight for l in (*self.fe.net, *self.fn.net))
+        # keyed by the DEVICE of the weights as well: ``nn.DataParallel`` (the reference's multi-GPU mode,
+        # setup_training.py:1418-1421) replicates a module by shallow-copying its __dict__, so all replicas see this one
+        # dict, each from its own device's thread -- every replica gets (and replaces) only its own device's entry
+        key = (dscale, ops.FWD_F16, params[0].device.index if params[0].is_cuda else -1)
+        cache = self.__dict__.setdefault("_pack_cache", {})
         pk = cache.get(key)
         if pk is None or any(a is not b for a, b in zip(pk.params, params)):
             plist = tuple(q for l in (*self.fe.net, *self.fn.net) for q in (l.weight, l.bias))
-            pk = cache[key] = ops.PackedMPLayer(params, self.input_node_size, self.output_node_size, *key, plist=plist)
+            pk = cache[key] = ops.PackedMPLayer(params, self.input_node_size, self.output_node_size, key[0], key[1], plist=plist)
         return pk
 
     def packed_sets(self):

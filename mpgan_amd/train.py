@@ -293,7 +293,8 @@ class TrainStep:
     def __init__(self, G: nn.Module, D: nn.Module, batch_size: int, num_particles: int, latent: int = 32,
                  lr_disc: float = 3e-5, lr_gen: float = 1e-5, noise_std: float = 0.2, use_graphs: bool = True,
                  process_group=None, world_size: int = 1, batch_real_fake: bool = True, loss: str = "ls",
-                 optimizer: str = "rmsprop", betas=(0.9, 0.999), gp_lambda: float = 0.0):
+                 optimizer: str = "rmsprop", betas=(0.9, 0.999), gp_lambda: float = 0.0,
+                 graph_collectives: Optional[bool] = None):
         if loss not in LOSSES:
             raise ValueError(f"loss must be one of {LOSSES}, got {loss!r}")
         if gp_lambda and not isinstance(D, MPDiscriminator):
@@ -315,6 +316,12 @@ class TrainStep:
         self.B, self.N, self.latent = batch_size, num_particles, latent
         self.lr_disc, self.lr_gen, self.noise_std = lr_disc, lr_gen, noise_std
         self.pg, self.world = process_group, world_size
+        # RCCL collectives can be captured into a hipGraph like kernels: the two gradient all-reduces then sit INSIDE
+        # one graph and a multi-rank iteration is a single replay.  Opt-in (argument, or MPG_GRAPH_COLLECTIVES=1):
+        # the default keeps the all-reduces as ordinary calls between three graph segments.
+        if graph_collectives is None:
+            graph_collectives = os.environ.get("MPG_GRAPH_COLLECTIVES") == "1"
+        self.graph_collectives = bool(graph_collectives) and process_group is not None
         dev = next(G.parameters()).device
         self.dev = dev
         self.state = ops.dev_state(dev)
@@ -486,8 +493,16 @@ class TrainStep:
         graphs = []
         pool = None
         # one graph per segment between collectives; without a process group the whole iteration is one graph
-        split = self.world > 1 or self.pg is not None or os.environ.get("MPG_SPLIT_GRAPHS")
-        groups = [(self._seg_D,), (self._seg_G,), (self._seg_end,)] if split else [(self._seg_D, self._seg_G, self._seg_end)]
+        split = (self.world > 1 or self.pg is not None or os.environ.get("MPG_SPLIT_GRAPHS")) and not self.graph_collectives
+        if self.graph_collectives:
+            if torch.distributed.get_backend(self.pg) != "nccl":
+                raise RuntimeError("graph_collectives needs an nccl (RCCL) process group: only its collectives are stream operations")
+            rD, rG = (lambda: self._allreduce(self.fD)), (lambda: self._allreduce(self.fG))
+            groups = [(self._seg_D, rD, self._seg_G, rG, self._seg_end)]
+        elif split:
+            groups = [(self._seg_D,), (self._seg_G,), (self._seg_end,)]
+        else:
+            groups = [(self._seg_D, self._seg_G, self._seg_end)]
         for segs in groups:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool):

@@ -27,9 +27,15 @@ def test_world1_nccl_group_three_segments_equal_eager():
     try:
         b = _three_steps(16, 30, use_graphs=True, pg=dist.group.WORLD)   # graphs + collective
         c = _three_steps(16, 30, use_graphs=False, pg=dist.group.WORLD)  # eager + collective
+        # the two all-reduces captured INSIDE the graph: the multi-rank iteration as one replay
+        os.environ["MPG_GRAPH_COLLECTIVES"] = "1"
+        try:
+            d = _three_steps(16, 30, use_graphs=True, pg=dist.group.WORLD, n_graphs=1)
+        finally:
+            os.environ.pop("MPG_GRAPH_COLLECTIVES", None)
     finally:
         dist.destroy_process_group()
-    for r in (b, c):
+    for r in (b, c, d):
         assert torch.equal(a[0], r[0]) and torch.equal(a[1], r[1]) and a[2:] == r[2:]
 
 

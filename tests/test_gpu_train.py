@@ -145,7 +145,7 @@ def test_graph_replay_equals_eager():
     assert len(set(losses)) == 4  # fresh noise and fresh dropout masks on every replay
 
 
-def _three_steps(B, N, use_graphs, split=False, pg=None, model="mpgan", disc_dropout=0.0, steps=3, seed=3):
+def _three_steps(B, N, use_graphs, split=False, pg=None, model="mpgan", disc_dropout=0.0, steps=3, seed=3, n_graphs=None):
     """Parameters after `steps` iterations from fixed weights / data / noise."""
     import os
     from mpgan_amd import train
@@ -171,7 +171,7 @@ def _three_steps(B, N, use_graphs, split=False, pg=None, model="mpgan", disc_dro
                           torch.randn(B, N, latent, device="cuda", generator=gen) * 0.2)
         if use_graphs:
             ts.capture(warmup=0)
-            assert len(ts._graphs) == (3 if (split or pg is not None) else 1)
+            assert len(ts._graphs) == (n_graphs if n_graphs is not None else (3 if (split or pg is not None) else 1))
         for _ in range(steps):
             ts.step()
         torch.cuda.synchronize()
