@@ -52,8 +52,8 @@ for l in pm.splitlines():
 def kb(c, k): return vals.get((c, k), 0.0)
 def tot(k): return (2 * kb("FETCH_SIZE", k) + kb("WRITE_SIZE", k)) * 1024
 rows = [("edge_fwd_kernel<0", "forward, no dropout"), ("edge_fwd_kernel<2", "forward, p = 1/2"),
-        ("edge_bwd_kernel<0, true, true", "backward + staging"), ("edge_bwd_kernel<0, true, false", "backward, data path only"),
-        ("edge_bwd_kernel<2, true, true", "backward + staging, p = 1/2"), ("edge_bwd_kernel<2, true, false", "backward, data path, p = 1/2"),
+        ("edge_bwd_kernel<0, true", "backward + staging"), ("edge_bwd_kernel<0, false", "backward, data path only"),
+        ("edge_bwd_kernel<2, true", "backward + staging, p = 1/2"), ("edge_bwd_kernel<2, false", "backward, data path, p = 1/2"),
         ("edge_dw_kernel<0", "weight gradients"), ("edge_dw_kernel<2", "weight gradients, p = 1/2"),
         ("chain2_kernel", "chained node layers (all uses)"), ("gemm_group_kernel", "grouped dense weight gradients")]
 txt = ("# HBM traffic of the fused kernels: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (one counter per pass, as\n"
@@ -74,13 +74,13 @@ def rate(sub, key):
     return tot(key) / d[0] / 1e12 if d else float("nan")
 txt += ("#\n# Achieved HBM rate at B=256 (bytes above / rocprof average duration in " + f"{tag}_bench_kernel_stats.csv" + "; HBM3E peak 8 TB/s):\n"
         f"#   edge_fwd_kernel<0, true, true>   {rate('edge_fwd_kernel<0, true, true>', 'edge_fwd_kernel<0'):5.2f} TB/s  (compute bound: see the SQ counters)\n"
-        f"#   edge_bwd_kernel<0, true, true>   {rate('edge_bwd_kernel<0, true, true>', 'edge_bwd_kernel<0, true, true'):5.2f} TB/s\n"
-        f"#   edge_dw_kernel<0, true>          {rate('edge_dw_kernel<0, true>', 'edge_dw_kernel<0'):5.2f} TB/s\n")
-txt += ("#\n# forward: a|c in, agg + sign words out (algorithmic 17.7 MB).  backward + staging: 2 x 20 KiB of E2 / dZ2 fragments per\n"
+        f"#   edge_bwd_kernel<0, true>   {rate('edge_bwd_kernel<0, true>', 'edge_bwd_kernel<0, true'):5.2f} TB/s\n"
+        f"#   edge_dw_kernel<0>          {rate('edge_dw_kernel<0>', 'edge_dw_kernel<0'):5.2f} TB/s\n")
+txt += ("#\n# forward: a|c in, agg + sign words out (algorithmic 17.7 MB).  backward + staging: 2 x 10 KiB of fp16 E2 / dZ2 fragments per\n"
         "# unmasked (jet, sender) block for mpg_edge_dw, which reads them back and writes 256 per-workgroup partial sums.\n#\n" + pm)
 open(os.path.join(P, f"{tag}_pmc_hbm_traffic.txt"), "w").write(txt)
-w, wo = tot("edge_bwd_kernel<2, true, true"), tot("edge_bwd_kernel<2, true, false")
-w0 = tot("edge_bwd_kernel<0, true, true")
+w, wo = tot("edge_bwd_kernel<2, true"), tot("edge_bwd_kernel<2, false")
+w0 = tot("edge_bwd_kernel<0, true")
 traffic = {
     "note": f"bytes per launch from profiles/{tag}_pmc_hbm_traffic.txt (2 x FETCH_SIZE + WRITE_SIZE), B=256, N=30. edge_bwd_kernel: "
             "launch-weighted mean over the 6 launches of one default bench step (2 at 2B = 512 jets with staging [D, p = 1/2], "

@@ -1,5 +1,5 @@
 // Stand-alone timing of edge_fwd_kernel<DROP, f16, sign> at B=256, N=30 on random data (no torch):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -DMPG_SINGLE_VARIANT=0 [-DMPG_EXP=n] tools/ubench/fwd_bench.hip -o fwd_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -fno-slp-vectorize -DMPG_SINGLE_VARIANT=<0|2> [-DMPG_EXP=n] tools/ubench/fwd_bench.hip -o fwd_bench
 #include "../../mpgan_amd/csrc/edge.hip"
 #include <stdio.h>
 #include <stdlib.h>
