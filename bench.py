@@ -32,7 +32,7 @@ PEAK_MFMA_16BIT = 2.5e15  # dense bf16/f16 MFMA, MI355X (MI355X_MICROARCH.md, ch
 PEAK_HBM = 8.0e12         # HBM3E bytes/s, same guide
 
 H1, H2, H3 = 96, 160, 192
-SPLIT = 3                 # MFMA MACs issued per algorithmic MAC (hi/lo operand split, csrc/common.h)
+SPLIT = 3                 # MFMA MACs issued per algorithmic MAC by a three-term product (hi/lo operand split, csrc/common.h)
 
 
 # --------------------------------------------------------------------------- work models
@@ -53,31 +53,33 @@ def iteration_flops_per_jet(N):
 
 def executed_flops_per_jet(N, valid_frac):
     """MFMA FLOPs the fused path actually ISSUES per jet and G+D iteration: the logical MACs of every launch in the
-    step (x2) times the 3 MFMAs of the hi/lo split.  Differences to the algorithmic figure: layer 1 of fe is the
-    factorised a_i + c_j (two node-level products instead of one per edge); masked senders are skipped (``valid_frac``
-    = mean multiplicity / N of the batch); the backward recomputes fe layer 2; train_D does not back-propagate
-    into G and train_G forms no weight gradients of D (both results-neutral, train.py:420, :495).  Tile padding
-    (30 receivers on 32 lanes, K rounded up to 32) is not counted."""
+    step (x2) times the number of 16-bit terms the product runs in -- 3 (hi/lo x hi/lo without lo*lo) for every forward
+    product, the backward's recomputation of fe layer 2 and the node network; 2 for the edge backward's data-gradient
+    products (weight hi + lo times the gradient rounded to fp16); 1 for the edge weight gradients.  Differences to the
+    algorithmic figure: layer 1 of fe is the factorised a_i + c_j (two node-level products instead of one per edge);
+    masked senders are skipped (``valid_frac`` = mean multiplicity / N of the batch); the backward recomputes fe
+    layer 2; train_D does not back-propagate into G and train_G forms no weight gradients of D (both results-neutral,
+    train.py:420, :495).  Tile padding (30 receivers on 32 lanes, K rounded up to 32) is not counted."""
     E = N * N * valid_frac                      # edges that are computed per jet-layer
 
     def layer(F, out, fwd, bwd_x, bwd_w, first):
         f = 0.0
         node_fwd = 2 * ((H3 + F) * 256 + 256 * 256 + 256 * out) * N
         ac = 2 * F * 2 * H1 * N
-        f += fwd * (ac + E * 2 * (H1 * H2 + H2 * H3) + node_fwd)
+        f += fwd * 3 * (ac + E * 2 * (H1 * H2 + H2 * H3) + node_fwd)
         if bwd_x or bwd_w:
-            f += node_fwd                                                       # fn input-gradient chain
-            f += E * 2 * (H1 * H2 + H2 * H3 + H2 * H1)                          # recompute L2, dE2, dE1
+            f += 3 * node_fwd                                                   # fn input-gradient chain
+            f += E * 2 * (3 * H1 * H2 + 2 * (H2 * H3 + H2 * H1))                # recompute L2 (3 terms); dE2, dE1 (2 terms)
             if bwd_w:
-                f += E * 2 * (H3 * H2 + H2 * H1) + node_fwd + ac                # dW3, dW2; fn dW; dW1
+                f += E * 2 * (H3 * H2 + H2 * H1) + 3 * (node_fwd + ac)          # dW3, dW2 (1 term); fn dW; dW1
             if not first:
-                f += ac                                                         # dx through [W1a ; W1c]
+                f += 3 * ac                                                     # dx through [W1a ; W1c]
         return f
     G = lambda fwd, bx, bw: layer(32, 32, fwd, bx, bw, True) + layer(32, 3, fwd, bx, bw, False)
     D = lambda fwd, bx, bw: layer(3, 32, fwd, bx, bw, True) + layer(32, 32, fwd, bx, bw, False)
     step_D = G(1, 0, 0) + 2 * D(1, 1, 1)        # G forward only; D forward + full backward on real + generated
     step_G = G(1, 1, 1) + D(1, 1, 0)            # D: data gradient only
-    return SPLIT * (step_D + step_G)
+    return step_D + step_G
 
 
 def log(*a):
@@ -97,8 +99,8 @@ def host_threads():
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)     # >= 100 timed, >= 20 warm-up iterations
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--model", default="mpgan", choices=["mpgan", "gapt"],
                     help="mpgan = the headline config; gapt = BASELINE config 4 (not the bench line)")
     ap.add_argument("--batch", type=int, default=0, help="jets per GPU (weak scaling); default 256 (mpgan) / 512 (gapt)")
@@ -204,7 +206,10 @@ def main():
                   else f"jets/sec (G+D step) {args.model} N={N} bs={B}",
         "value": jets_per_s, "unit": "jets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16x3 (forward) / bf16x3 (gradients) split-16-bit MFMA, fp32 accumulate, fp32 in/out",
+        "dtype": "split-16-bit MFMA, fp32 accumulate, fp32 in/out: f16 hi/lo x3 terms (forward, recomputation), f16 x2 / x1 "
+                 "terms in per-sender dithered units (edge backward: data / weight gradients), bf16 hi/lo x3 (node network "
+                 "gradients)" if args.model == "mpgan" else
+                 "split-16-bit MFMA, fp32 accumulate, fp32 in/out: f16 hi/lo x3 terms (forward), bf16 hi/lo x3 (gradients)",
         "data": "synthetic",
         "config": {"workload": f"{args.model.upper()} gluon-like jets, N={N} particles, B={B} per GPU, one "
                                "train_D+train_G iteration (LSGAN, RMSprop, D dropout 0.5)",
@@ -245,7 +250,7 @@ def _work(name, a):
         edges = o.B * o.N * o.N
         # the two dense layers the kernel fuses per edge: forward e2 = W2 e1, e3 = W3 e2; backward dE2 = W3^T dZ3,
         # dE1 = W2^T dZ2; weight gradients dW3 = dZ3 E2^T, dW2 = dZ2 E1^T -- (96*160 + 160*192) MAC = 92,160 FLOP per
-        # edge each.  The backward's recomputation of layer 2 and the 3x of the hi/lo split are execution cost.
+        # edge each.  The backward's recomputation of layer 2 and the number of 16-bit terms per product are execution cost.
         io = {"mpg_edge_fwd": 2 * H1 + H3, "mpg_edge_bwd": 2 * H1 + H3 + 2 * H1, "mpg_edge_dw": 2 * H1 + H3}[name]
         return edges * 2 * (H1 * H2 + H2 * H3), o.B * o.N * io * 4
     if name in ("mpg_attn_fwd", "mpg_attn_bwd"):
@@ -332,9 +337,10 @@ def roofline(torch, ts, model, dev, measured_traffic=True):
                 "frac": ach * 1e12 / PEAK_MFMA_16BIT, "traffic": traffic,
                 "flop_per_launch": flop_sum / nl, "avg_launch_ms": ms_sum / nl,
                 "note": "algorithmic FLOPs of the two fused dense layers (one MAC = 2 FLOP, all B*N*N edges) over the "
-                        "HIP-event time of all launches of the kernel in a step; the kernel issues 3 MFMA MACs per "
-                        "algorithmic MAC (hi/lo split), so 1/3 is the ceiling of frac, and tools/ubench/mfma_power.hip "
-                        "measures 1.45 PFLOP/s (not 2.5) as the dense f16 MFMA rate this chip sustains on random operands"}
+                        "HIP-event time of all launches of the kernel in a step; the forward issues 3 MFMA MACs per "
+                        "algorithmic MAC (hi/lo split: 1/3 is the ceiling of its frac), the data-gradient kernel 2 per MAC plus "
+                        "the 3-term recomputation of layer 2 (ceiling 0.34), and tools/ubench/mfma_power.hip measures 1.45 "
+                        "PFLOP/s (not 2.5) as the dense f16 MFMA rate this chip sustains on random operands"}
     else:
         ach = byte_sum / (ms_sum * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": PEAK_HBM / 1e9, "unit": "GB/s",

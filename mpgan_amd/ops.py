@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import itertools
+import os
 import threading
 from typing import Optional
 
@@ -415,6 +416,9 @@ def _sender_chunks(B, N):
     doubling up to 320 workgroups would run two rounds at 62 % occupancy)."""
     RB = (N + 31) // 32
     wg = B * RB
+    forced = os.environ.get("MPG_FORCE_SC")   # experiments only (DESIGN.md section 7: load balance of one-round launches)
+    if forced:
+        return max(int(forced), -(-N // MAX_CHUNK_SENDERS))
     best, best_cost = 1, None
     for sc in range(1, max(1, N // 8) + 1):
         per = -(-N // sc)
