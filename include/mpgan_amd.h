@@ -155,6 +155,8 @@ typedef struct MpgEdgeFwd {
     unsigned int* sign3;                  /* optional [B*RB*N][3][64] per-lane sign words of Z3 for the backward (NULL = off) */
     const unsigned int* nbr;              /* optional k-nearest-neighbour graph: [B*N][ceil(N/32)] words, bit j of row (b, i) set
                                              <=> sender j is a neighbour of receiver i (mpg_knn_sets); NULL = fully connected */
+    void* stageE2;                        /* with sign3: E2 = fe.net.1's output (in the forward's operand scale) parked as fp16
+                                             fragments [B*RB*N blocks][10][64 lanes][8] for mpg_edge_bwd / mpg_edge_dw */
 } MpgEdgeFwd;
 int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream);
 
@@ -170,14 +172,14 @@ int mpg_knn_sets(const float* x, int ldx, const float* mask, int B, int N, int F
 /* mpg_edge_bwd: autograd backward of the same span, data path.  Given dagg = dL/dagg and the
  * forward's sign words it produces
  *   da [SC, B*N, 96]  (partial over sender chunks),  dc [RB, B*N, 96]  (partial over receiver blocks of 32)
- * and, when stageE2/stageZ2 are non-NULL (weight gradients wanted), parks E2 = fe.net.1's output (in the forward's
- * operand scale) and dZ2 = dL/d(its pre-activation) as fp16 fragments [B*RB*N blocks][10][64 lanes][8] for
- * mpg_edge_dw.  dZ2 is parked in units of 2^-e of its (jet, receiver block) -- gradients have any magnitude, fp16 has
- * 30 binades -- and gexp[b*RB + rb] = e says which (e is chosen from max |dagg| of the block's receivers).
- * All images are fp16 (f16 must be 1, error -8): W2img the forward image, W3Timg / W2Timg the images of the transposed
- * weights packed with the forward's scales (dscale * 64, dscale * 16).  The recomputed layer 2 repeats the forward
- * bit for bit (three fp16 terms); the two gradient products run as two fp16 terms (image hi + lo times the gradient
- * rounded to fp16).  A sender chunk (ceil(N / SC) senders) may hold at most 180 senders (error -6: raise SC), and
+ * from stageE2 -- E2 = fe.net.1's output as mpg_edge_fwd parked it (required: its signs are phi'(Z2); nothing of the
+ * forward is recomputed) -- and, when stageZ2 is non-NULL (weight gradients wanted), parks dZ2 = dL/d(fe.net.1's
+ * pre-activation) as fp16 fragments [B*RB*N blocks][10][64 lanes][8] for mpg_edge_dw.  dZ2 is parked in units of
+ * 2^-e of its (jet, receiver block) -- gradients have any magnitude, fp16 has 30 binades -- and gexp[b*RB + rb] = e
+ * says which (e is chosen from max |dagg| of the block's receivers).
+ * All images are fp16 (f16 must be 1, error -8): W3Timg / W2Timg the images of the transposed weights packed with the
+ * forward's scales (dscale * 64, dscale * 16); W2img and b2 are not read.  The two gradient products run as two fp16
+ * terms (image hi + lo times the gradient rounded to fp16 in a per-sender unit).  A sender chunk (ceil(N / SC) senders) may hold at most 180 senders (error -6: raise SC), and
  * the staging buffers must stay below 2 GiB (error -7). */
 typedef struct MpgEdgeBwd {
     const float* a; const float* c; int ld_ac; const float* mask;
@@ -186,7 +188,8 @@ typedef struct MpgEdgeBwd {
     const void* W2img; const void* W3Timg; const void* W2Timg;
     const float* b2;
     float* da; float* dc;
-    void* stageE2; void* stageZ2;
+    const void* stageE2;                  /* from mpg_edge_fwd (required)                        */
+    void* stageZ2;                        /* optional output for mpg_edge_dw                     */
     int B, N, SC;
     float alpha, agg_scale;
     const uint64_t* seed; uint32_t tag_base, thr; float dscale;

@@ -47,7 +47,7 @@ class MpgEdgeFwd(C.Structure):
         ("alpha", C.c_float), ("agg_scale", C.c_float),
         ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
         ("skip_masked", C.c_int), ("f16", C.c_int),
-        ("sign3", _fp), ("nbr", _fp),
+        ("sign3", _fp), ("nbr", _fp), ("stageE2", _fp),
     ]
 
 

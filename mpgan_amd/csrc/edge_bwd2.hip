@@ -8,13 +8,13 @@ int mpg_edge_bwd_d2(const MpgEdgeBwd* p, hipStream_t st);   // edge_bwd2_d2.hip:
 
 extern "C" int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream) {
     if (p->B <= 0 || p->N <= 0 || p->SC <= 0) return -1;
-    if (p->sign3 == nullptr) return -3;
+    if (p->sign3 == nullptr || p->stageE2 == nullptr) return -3;   // the forward's by-products: sign words of Z3, parked E2
     if (!(p->alpha >= 0.f && p->alpha <= 1.f)) return -4;
     if (!p->f16) return -8;   // the recomputed layer and both gradient products take fp16 images
     if ((p->N + p->SC - 1) / p->SC > B2_LIST_MAX) return -6;  // senders per chunk (the list of unmasked ones lives in LDS)
     const int RB = (p->N + 31) / 32;
     if ((long long)p->B * RB * p->N * (NFR2 * 1024) > 0x7fffffffLL) return -7;  // staging offsets are 32-bit
-    if ((p->stageE2 != nullptr && p->stageZ2 != nullptr) && p->gexp == nullptr) return -9;
+    if (p->stageZ2 != nullptr && p->gexp == nullptr) return -9;
     hipStream_t st = (hipStream_t)stream;
 #ifdef MPG_SINGLE_VARIANT
     return b2_launch<MPG_SINGLE_VARIANT>(p, st);

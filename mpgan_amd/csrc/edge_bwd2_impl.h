@@ -1,24 +1,24 @@
-// Backward of the fused edge network, data-gradient path (see edge.hip for the forward and the chain layout).
+// Backward of the fused edge network, data-gradient path (see edge_fwd2_impl.h for the forward and the chain layout).
 //
 //   dZ3 = m_j * dagg_i * keep3 * phi'(Z3)      phi'(Z3) from the forward's saved sign words
-//   dE2 = W3'^T dZ3 ;  dZ2 = dE2 * keep2 * phi'(Z2)     (Z2 recomputed: one 90-MFMA layer)
-//   dE1 = W2'^T dZ2 ;  dZ1 = dE1 * keep1 * phi'(Z1) ;  da_i = sum_j dZ1 ;  dc_j = sum_i dZ1
+//   dE2 = W3'^T dZ3 ;  dZ2 = dE2 * keep2 * phi'(Z2)     phi'(Z2) from the SIGN of the E2 fragments the forward parked
+//   dE1 = W2'^T dZ2 ;  dZ1 = dE1 * keep1 * phi'(Z1) ;  da_i = sum_j dZ1 ;  dc_j = sum_i dZ1     (Z1 = a_i + c_j, one add)
+//
+// Nothing of the forward is recomputed: E2 = fe.net.1's output is parked by the forward anyway (fp16 fragments, for the
+// weight-gradient kernel), and all this kernel needs of layer 2 is its sign pattern -- which LeakyReLU preserves.  (The
+// recomputation -- 180 MFMAs and 2,600 VALU instructions per pair of senders, a third of this kernel -- bought 59 MB
+// less HBM traffic per launch in a kernel that is bound by VALU issue.)
 //
 // A workgroup owns one (jet, 32 receivers, sender chunk); its four waves split the chunk's UNMASKED senders and are
-// independent of each other between the prologue and the final reduction of da.  What bounds this kernel is operand
-// delivery, not the matrix pipe: every MFMA needs a 1 KiB weight fragment, and a CU moves 64 B/clk from L1/L2 and
-// 128 B/clk from LDS.  So a wave walks its senders in PAIRS: each weight fragment (W3^T from LDS, W2 and W2^T
-// streamed from L2) feeds the MFMAs of two senders, halving the fragment traffic per edge, and the pair's operands
-// are built just in time:
-//   phase A  Z2 = W2 E1 + b2     tile by tile (5 tiles x 6 k-steps); the epilogue of a tile (LeakyReLU, dropout,
-//                                sign bits for the later gate, E2 staged for the weight-gradient kernel) sits behind the
-//                                MFMAs of the next one
+// independent of each other between the prologue and the final reduction of da.  Every MFMA needs a 1 KiB weight
+// fragment, and a CU moves 64 B/clk from L1/L2 and 128 B/clk from LDS.  So a wave walks its senders in PAIRS: each
+// weight fragment (W3^T from LDS, W2^T streamed from L2) feeds the MFMAs of two senders, and the pair's operands are
+// built just in time:
 //   phase B  dE2 = W3'^T dZ3     k-outer (12 k-steps x 5 tiles): the dZ3 fragment of k-step k+1 is built behind the
-//                                MFMAs of k-step k, so dZ3 never exists as a whole (96 registers per sender saved)
-//   phase C  dE1 = W2'^T dZ2     k-outer (10 k-steps x 3 tiles): dZ2 = gate * dE2 built (and staged) the same way
-//                                from phase B's accumulators
-// Arithmetic.  Phase A repeats the forward bit for bit (fp16 hi/lo operands, lo*hi, hi*lo, hi*hi per k-step, k
-// ascending): its signs gate dZ2.  The two gradient products have no kink behind their rounding and run as TWO fp16
+//                                MFMAs of k-step k, so dZ3 never exists as a whole
+//   phase C  dE1 = W2'^T dZ2     k-outer (10 k-steps x 3 tiles): dZ2 = gate * dE2 built (and parked for the
+//                                weight-gradient kernel) the same way from phase B's accumulators
+// Arithmetic.  The two gradient products have no kink behind their rounding and run as TWO fp16
 // terms: the weight image keeps hi and lo, the operand built on the fly (dZ3, dZ2) is rounded to ONE fp16 value
 // (2^-12 relative per element).  Left alone that rounding would be the same for every sender of a receiver -- dZ3_ij is
 // dagg_i times one of two constants, dZ2_ij nearly so -- i.e. coherent along the very axis da sums over (measured:
@@ -35,7 +35,7 @@
 #include "edge_common.h"
 
 #ifndef MPG_B2EXP
-#define MPG_B2EXP 0  // experiment bits (tools/ubench/bwd2_bench.hip): 1 streamed fragments all from k-step 0 (L1 hits), 2 no staging stores
+#define MPG_B2EXP 0  // experiment bits (tools/ubench/bwd2_bench.hip): 1 streamed fragments all from k-step 0 (L1 hits), 2 no parking stores
 #endif
 
 #ifdef MPG_B2STAMP  // diagnostic build: s_memtime at the phase boundaries of the first pair of every wave of the first 64 workgroups
@@ -47,7 +47,7 @@ __device__ unsigned long long g_b2_stamps[64 * 4 * 8];
 
 namespace {
 
-// LDS plan (all of the 160 KiB): W3^T hi|lo (fp16) | dagg tile of the 32 receivers | a tile | b2 | per-wave rows of
+// LDS plan (all of the 160 KiB): W3^T hi|lo (fp16) | dagg tile of the 32 receivers | a tile | (640 B unused) | per-wave rows of
 // c for the two senders in flight | list of the chunk's unmasked senders.  W2 and W2^T stream from L2.
 constexpr int B2_W_BYTES = 2 * NF3T * 1024;      // 122,880
 constexpr int B2_DG_BYTES = T3 * 4 * 64 * 16;    //  24,576
@@ -115,7 +115,6 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     const int jbeg = sc * JC, jend = min(p.N, jbeg + JC);
     const int ldac = p.ld_ac ? p.ld_ac : H1;
 
-    const __amdgpu_buffer_rsrc_t r2 = img_rsrc(p.W2img, 2 * NF2);     // W2 hi | lo (forward image)
     const __amdgpu_buffer_rsrc_t r2t = img_rsrc(p.W2Timg, 2 * NF2T);  // W2^T hi | lo (fp16, operand scale SC_W2)
     const int lane16 = lane * 16;
     const f16x8* t3g = reinterpret_cast<const f16x8*>(p.W3Timg);
@@ -130,7 +129,6 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
 
     // ---- prologue (whole workgroup): weights and the per-receiver tiles into LDS, the list of unmasked senders
     copy_to_lds(l3t, t3g, 2 * NF3T * 64, tid);
-    for (int t = tid; t < H2; t += 256) lb2[t] = p.b2[t] * SC_E2;  // (the recomputed layer 2 runs in the forward's operand scales)
     // upstream gradient dagg (scaled) and the layer-1 receiver term a, both in the register order the chain layout
     // wants (zeros for padding lanes: they carry exact zeros all the way down)
     float amax = 0.f;
@@ -189,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     // rounded to fp16, exactly as the lanes hold them: one coalesced 16-byte store per lane and fragment.
     // Buffer stores: a block offset beyond the buffer (the idle second half of an odd pair) is dropped by the hardware.
     const int nblk = p.B * RB * p.N;
-    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(p.stageE2, 0, NEEDW ? nblk * (NFR2 * 1024) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.stageE2), 0, nblk * (NFR2 * 1024), 0x00020000);   // (read)
     const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(p.stageZ2, 0, NEEDW ? nblk * (NFR2 * 1024) : 0, 0x00020000);
 
     uint32_t opaque_zero;
@@ -237,12 +235,18 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
         int jj[2];
         jj[0] = __builtin_amdgcn_readfirstlane((int)lst[2 * pq]);
         jj[1] = has2 ? __builtin_amdgcn_readfirstlane((int)lst[2 * pq + 1]) : jj[0];
+        // (the lane's first edge row, from an opaque copy of the lane id: a loop-invariant per-lane value kept across the
+        // pair loop is what the register allocator spills first, and every scratch reload drains vmcnt)
+        int oln0 = lane;
+        asm volatile("" : "+v"(oln0));
+        const uint32_t ebase = (uint32_t)((b * p.N + rb * 32 + (oln0 & 31)) * p.N);
         float cpos[2], cneg[2];     // slope of layer 3 times m_j * dscale * 2^e * c_j: one select between two uniform constants
         // erow2 == erow, in a form the optimiser cannot prove equal: every dropout word is needed twice per pair, phases
         // apart (forward recomputation, then the gate of the matching gradient), and with one visible value it keeps
         // all the one-instruction keep-masks of the first use alive for the second (hundreds of registers, spilled)
         uint32_t erow[2], erow2[2];
         int stoff[2];               // byte offset of the sender's staging block (out of range for an idle half)
+        int stsc[2];                // the block's offset as a scalar (reads of the parked E2)
         uint32_t sw[2][T3 / 2];     // this lane's 96 sign bits of Z3 per sender
 #pragma unroll
         for (int sd = 0; sd < 2; ++sd) {
@@ -256,9 +260,10 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             const int blk = (b * RB + rb) * p.N + jj[sd];
             const float dth = dither_of((uint32_t)blk);  // this sender's unit within the workgroup's (see the head of this file)
             cpos[sd] = mjs * in_set * dth; cneg[sd] = mjs * p.alpha * in_set * dth;
-            erow[sd] = (uint32_t)((b * p.N + i) * p.N + jj[sd]);
+            erow[sd] = ebase + (uint32_t)jj[sd];
             erow2[sd] = erow[sd] + opaque_zero;
             stoff[sd] = (sd == 0 || has2) ? blk * (NFR2 * 1024) + lane16 : (int)0x7ffffff0;
+            stsc[sd] = blk * (NFR2 * 1024);
 #pragma unroll
             for (int q = 0; q < T3 / 2; ++q) sw[sd][q] = psw[sd][q];
             // the sender's row of c into this wave's LDS slot (96 floats: lanes 0..63, then lanes 0..31)
@@ -267,127 +272,9 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
         }
         prefetch(pq + 4);
 
-        // ---- phase A: Z2 = W2' E1 + b2, k-outer (6 k-steps x 5 tiles).  The fragment of e1 = drop(lrelu(a_i + c_j))
-        //      for k-step k+1 is built behind the MFMAs of k-step k (the signs of a_i + c_j are kept for dZ1's gate);
-        //      W2 hi+lo stream from L2 one k-step ahead.  E2 itself is only needed by the weight-gradient kernel
-        //      (staged) and, as signs, by dZ2's gate.
-        uint32_t neg1[2][2] = {{0u, 0u}, {0u, 0u}};            // sign bits of Z1: tiles 0,1 | 2 (16 bits)
-        uint32_t neg2[2][3] = {{0u, 0u, 0u}, {0u, 0u, 0u}};   // sign bits of Z2: tiles 0,1 | 2,3 | 4 (16 bits)
-        uint32_t wd2[2][T2];                                   // bit-mode dropout words of the five tiles
-        {
-            constexpr int KS = T1 * 2;
-            f32x16 acc[T2][2];       // [tile][sender]
-            V eh[2][2], el[2][2];    // [buffer][sender] e1 fragment (hi, lo) of a k-step
-            V wh[2][T2], wl[2][T2];  // [buffer][tile] W2 fragments of a k-step
-            float v1[2][8];
-            PairSplit<V> ps1[2][4];
-            f32x4 a4[2], c4[2][2];   // receiver terms (shared by the two senders) and sender terms of the k-step being built
-            auto load_w = [&](auto kc) {
-                MPG_CI(k, kc);
-#pragma unroll
-                for (int m = 0; m < T2; ++m) {
-                    wh[k & 1][m] = img_frag<V>(r2, lane16, m * KS + ((MPG_B2EXP & 1) ? 0 : k));
-                    wl[k & 1][m] = img_frag<V>(r2, lane16, NF2 + m * KS + ((MPG_B2EXP & 1) ? 0 : k));
-                }
-            };
-            // build units of the e1 fragment of k-step k = (q, s): per sender 8 element units + 4 pairs x 2 halves = 16;
-            // unit 32 of the pair: the receiver terms a (shared by the two senders) are read first
-            auto load_a = [&](auto kc) {
-                MPG_CI(k, kc);
-                a4[0] = lds_frag<f32x4>(lbla, (k * 2 + 0) * 1024);
-                a4[1] = lds_frag<f32x4>(lbla, (k * 2 + 1) * 1024);
-#pragma unroll
-                for (int sd = 0; sd < 2; ++sd)
-#pragma unroll
-                    for (int uh = 0; uh < 2; ++uh) c4[sd][uh] = lds_frag<f32x4>(lbc, (sd * H1 + 16 * k + 8 * uh) * 4);
-            };
-            auto buildA = [&](auto kc, auto uc) {
-                MPG_CI(k, kc); MPG_CI(uu, uc);
-                constexpr int sd = uu / 16, u = uu % 16;
-                constexpr int q = k >> 1, s = k & 1;
-                if constexpr (u < 8) {
-                    constexpr int uh = u >> 2, t = u & 3;  // element 4 uh + t  <->  feature 32q + 16s + 8uh + 4h + t
-                    const float cc = c4[sd][uh][t] + a4[uh][t];
-                    neg1[sd][q >> 1] = __builtin_amdgcn_alignbit(neg1[sd][q >> 1], __builtin_bit_cast(uint32_t, cc), 31);
-                    const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow[sd], q, 4 * s + 2 * uh + h, h);
-                    v1[sd][u] = drop_apply<DROP>(lrelu(cc, p.alpha), wd, 16 * s + 8 * uh + t, t, p.thr);
-                } else {
-                    constexpr int pr = (u - 8) >> 1;
-                    if constexpr (((u - 8) & 1) == 0) ps1[sd][pr].first(v1[sd][2 * pr], v1[sd][2 * pr + 1]);
-                    else ps1[sd][pr].second(v1[sd][2 * pr + 1], eh[k & 1][sd], el[k & 1][sd], 2 * pr);
-                }
-            };
-            load_w(std::integral_constant<int, 0>{});
-            load_a(std::integral_constant<int, 0>{});
-            static_for<0, 32>([&](auto uc) { buildA(std::integral_constant<int, 0>{}, uc); });
-            B2_STAMP(1);
-            // accumulators start as the bias column
-#pragma unroll
-            for (int m = 0; m < T2; ++m)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 b4 = ld4(lb2 + 32 * m + 8 * g + 4 * h);
-#pragma unroll
-                    for (int sd = 0; sd < 2; ++sd) {
-                        acc[m][sd][4 * g + 0] = b4.x; acc[m][sd][4 * g + 1] = b4.y;
-                        acc[m][sd][4 * g + 2] = b4.z; acc[m][sd][4 * g + 3] = b4.w;
-                    }
-                }
-            static_for<0, KS>([&](auto kc) {
-                MPG_CI(k, kc);
-                if constexpr (k + 1 < KS) {
-                    load_w(std::integral_constant<int, k + 1>{});
-                    load_a(std::integral_constant<int, k + 1>{});
-                }
-                const V bh0 = eh[k & 1][0], bl0 = el[k & 1][0], bh1 = eh[k & 1][1], bl1 = el[k & 1][1];
-                static_for<0, T2>([&](auto mc) {
-                    MPG_CI(m, mc);
-                    auto slot = [&](auto slc) {
-                        MPG_CI(SL, slc);
-                        if constexpr (k + 1 < KS && SL >= 2) run_slot<32, 28, SL - 2>([&](auto uc) { buildA(std::integral_constant<int, k + 1>{}, uc); });
-                        __builtin_amdgcn_sched_barrier(0);
-                    };
-                    const V a_h = wh[k & 1][m], a_l = wl[k & 1][m];
-                    acc[m][0] = mma(a_l, bh0, acc[m][0]); slot(std::integral_constant<int, 6 * m + 0>{});
-                    acc[m][1] = mma(a_l, bh1, acc[m][1]); slot(std::integral_constant<int, 6 * m + 1>{});
-                    acc[m][0] = mma(a_h, bl0, acc[m][0]); slot(std::integral_constant<int, 6 * m + 2>{});
-                    acc[m][1] = mma(a_h, bl1, acc[m][1]); slot(std::integral_constant<int, 6 * m + 3>{});
-                    acc[m][0] = mma(a_h, bh0, acc[m][0]); slot(std::integral_constant<int, 6 * m + 4>{});
-                    acc[m][1] = mma(a_h, bh1, acc[m][1]); slot(std::integral_constant<int, 6 * m + 5>{});
-                });
-            });
-            B2_STAMP(2);
-            // epilogue: the sign bits for dZ2's gate; LeakyReLU, dropout and E2 staged as fp16 fragments
-            static_for<0, T2>([&](auto mc) {
-                MPG_CI(mm, mc);
-#pragma unroll
-                for (int sd = 0; sd < 2; ++sd) {
-                    float x2[16];
-                    if constexpr (DROP == 2) wd2[sd][mm] = drop_tile_word<2>(seed_lo, seed_hi, p.tag_base + TAG_E1, erow[sd], mm, 0, h);
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int g = u >> 2, t = u & 3;
-                        const float z = acc[mm][sd][u];
-                        neg2[sd][mm >> 1] = __builtin_amdgcn_alignbit(neg2[sd][mm >> 1], __builtin_bit_cast(uint32_t, z), 31);
-                        uint32_t wd;
-                        if constexpr (DROP == 2) wd = wd2[sd][mm];
-                        else wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E1, erow[sd], mm, 2 * g + h, h);
-                        x2[u] = drop_apply<DROP>(lrelu(z, p.alpha), wd, 8 * g + t, t, p.thr);
-                    }
-                    if constexpr (NEEDW && !(MPG_B2EXP & 2)) {
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            b2_u32x4 e2;
-#pragma unroll
-                            for (int pr = 0; pr < 4; ++pr) e2[pr] = cvt_pk_f16(x2[8 * s + 2 * pr], x2[8 * s + 2 * pr + 1]);
-                            __builtin_amdgcn_raw_buffer_store_b128(e2, rsE, stoff[sd], (mm * 2 + s) * 1024, 0);
-                        }
-                    }
-                }
-            });
-        }
-
-        B2_STAMP(3);
+        // (no recomputation of layer 2: E2 = fe.net.1's output comes back from memory, parked by the forward as the fp16
+        //  fragments the lanes hold -- requested above, first used by phase C's gate)
+        B2_STAMP(1); B2_STAMP(2); B2_STAMP(3);
         // ---- phase B: dE2 = W3'^T dZ3, k-outer, two fp16 terms (W3^T lo, hi x dZ3 rounded to fp16).  dZ3 = dagg * slope(sign
         //      word) * keep3 in the sender's gradient unit is built one k-step ahead.
         f32x16 accB[T2][2];
@@ -476,6 +363,9 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             b2_u32x4 zz[2][2];
             float v2[2][8];
             V ah[3][T1], al[3][T1];       // ring of three k-steps of W2^T fragments (L2 is more than one k-step away)
+            // ... and of the parked E2 fragments (10 x 16 B per lane and sender, one per k-step): their SIGN is phi'(Z2) for
+            // dZ2's gate (LeakyReLU keeps the sign; a dropped element is +0 and is zeroed by the regenerated keep mask)
+            b2_u32x4 e2g[3][2];
             uint32_t wd2c[2] = {0u, 0u};  // bit-mode dropout word of the layer-2 tile being gated (hashed again: see erow2)
             auto load_w = [&](auto kc) {
                 MPG_CI(k, kc);
@@ -485,6 +375,11 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                     al[k % 3][m] = img_frag<V>(r2t, lane16, NF2T + m * KS + ((MPG_B2EXP & 1) ? 0 : k));
                 }
             };
+            auto load_e2 = [&](auto kc) {   // (requested one k-step before the build that reads it, two before its MFMAs)
+                MPG_CI(k, kc);
+#pragma unroll
+                for (int sd = 0; sd < 2; ++sd) e2g[k % 3][sd] = __builtin_amdgcn_raw_buffer_load_b128(rsE, lane16, stsc[sd] + k * 1024, 0);
+            };
             // build units of the dZ2 fragment of k-step k: per sender 8 element units + 4 pair conversions + 1 store = 13
             auto buildC = [&](auto kc, auto uc) {
                 MPG_CI(k, kc); MPG_CI(uu, uc);
@@ -492,10 +387,8 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                 constexpr int m2 = k >> 1, s = k & 1;
                 if constexpr (u < 8) {
                     constexpr int r16 = 8 * s + u, g = r16 >> 2, t = r16 & 3;
-                    // sign of Z2 (register r16 of tile m2): pushed in (tile, register) order into word m2 >> 1, which
-                    // holds 32 bits (tiles 0..3) or 16 (tile 4)
-                    constexpr int nb = m2 < 4 ? 32 : 16;
-                    float gt = sel_by_bit<nb - 1 - (16 * (m2 & 1) + r16)>(neg2[sd][m2 >> 1], valpha2, vone2);
+                    // sign of Z2 (register r16 of tile m2) = sign of element u of the parked E2 fragment 2 m2 + s
+                    float gt = sel_by_bit<16 * (u & 1) + 15>(e2g[k % 3][sd][u >> 1], valpha2, vone2);
                     if constexpr (DROP != 0) {
                         uint32_t wd;
                         if constexpr (DROP == 2) {
@@ -513,12 +406,14 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                         __builtin_amdgcn_raw_buffer_store_b128(zz[k & 1][sd], rsZ, stoff[sd], k * 1024, 0);
                 }
             };
+            load_e2(std::integral_constant<int, 0>{});
+            load_e2(std::integral_constant<int, 1>{});
             load_w(std::integral_constant<int, 0>{});
             load_w(std::integral_constant<int, 1>{});
             static_for<0, 26>([&](auto uc) { buildC(std::integral_constant<int, 0>{}, uc); });
             static_for<0, KS>([&](auto kc) {
                 MPG_CI(k, kc);
-                if constexpr (k + 2 < KS) load_w(std::integral_constant<int, k + 2>{});
+                if constexpr (k + 2 < KS) { load_e2(std::integral_constant<int, k + 2>{}); load_w(std::integral_constant<int, k + 2>{}); }
                 const V b0 = __builtin_bit_cast(V, zz[k & 1][0]), b1 = __builtin_bit_cast(V, zz[k & 1][1]);
                 static_for<0, T1>([&](auto mc) {
                     MPG_CI(m, mc);
@@ -571,12 +466,14 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                         MPG_CI(su, suc);
                         constexpr int s = su >> 1, u = su & 1;
                         const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow2[sd], mm, 4 * s + 2 * u + h, h);
+                        // Z1 = a_i + c_j of the four features 32 mm + 16 s + 8 u + 4 h + t, as the forward adds them
+                        const f32x4 a4 = lds_frag<f32x4>(lbla, ((mm * 2 + s) * 2 + u) * 1024);
+                        const f32x4 c4 = lds_frag<f32x4>(lbc, (sd * H1 + 32 * mm + 16 * s + 8 * u) * 4);
                         float dz[4];
                         static_for<0, 4>([&](auto tc) {
                             MPG_CI(t, tc);
-                            // sign of a_i + c_j: pushed in (tile, element) order into word mm >> 1 (32 bits for tiles 0,1; 16 for tile 2)
-                            constexpr int nb = mm < 2 ? 32 : 16;
-                            float gt = sel_by_bit<nb - 1 - (16 * (mm & 1) + 8 * s + 4 * u + t)>(neg1[sd][mm >> 1], valpha1[sd], vone1[sd]);
+                            const float z1 = c4[t] + a4[t];
+                            float gt = sel_by_bit<31>(__builtin_bit_cast(uint32_t, z1), valpha1[sd], vone1[sd]);
                             gt = drop_apply<DROP>(gt, wd, 16 * s + 8 * u + t, t, p.thr);
                             dz[t] = accC[mm][sd][8 * s + 4 * u + t] * gt;
                             dacc[mm][8 * s + 4 * u + t] += dz[t];
@@ -622,7 +519,7 @@ template <int D>
 int b2_launch(const MpgEdgeBwd* p, hipStream_t st) {
     const int RB = (p->N + 31) / 32;
     dim3 grid(p->B * RB * p->SC), block(256);
-    const bool needw = p->stageE2 != nullptr && p->stageZ2 != nullptr;
+    const bool needw = p->stageZ2 != nullptr;
     if (needw) {
         MPG_ENSURE_LDS((edge_bwd_kernel<D, true>), B2_LDS_BYTES);
         hipLaunchKernelGGL((edge_bwd_kernel<D, true>), grid, block, B2_LDS_BYTES, st, *p);

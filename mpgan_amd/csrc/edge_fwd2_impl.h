@@ -122,6 +122,9 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
     const uint32_t lbc = lds_base(smem, F2_W_BYTES + F2_A_BYTES + F2_B_BYTES + w * (2 * H1 * 4) + 16 * h);
 
     const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(p.sign3, 0, SIGN ? p.B * RB * p.N * (T3 * 32 * 4) : 0, 0x00020000);
+    // E2 parked for the backward (mpg_edge_bwd takes phi'(Z2) from its signs, mpg_edge_dw multiplies with it): the hi halves
+    // of the fragments built below, as they are -- one 16-byte store per lane and fragment, no arithmetic
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(p.stageE2, 0, (SIGN && p.stageE2 != nullptr) ? p.B * RB * p.N * (NFR2 * 1024) : 0, 0x00020000);
 
     f32x16 agg[T3];
 #pragma unroll
@@ -247,6 +250,12 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
 
         // ---- E2 = drop(lrelu(Z2)) as B fragments (hi, lo): tile mm, k-step half s -> fragment 2 mm + s
         f2_u32x4 e2h[2][T2 * 2], e2l[2][T2 * 2];
+        int stv[2], sts[2];   // the senders' parking blocks: per-lane offset (out of range for the idle half of an odd pair), block offset
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd) {
+            stv[sd] = (sd == 0 || has2) ? lane16 : (int)0x7ffffff0;
+            sts[sd] = ((b * RB + rb) * p.N + jj[sd]) * (NFR2 * 1024);
+        }
         static_for<0, T2>([&](auto mc) {
             MPG_CI(mm, mc);
 #pragma unroll
@@ -267,6 +276,7 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
                     split8(x2 + 8 * s, hi, lo);
                     e2h[sd][2 * mm + s] = __builtin_bit_cast(f2_u32x4, hi);
                     e2l[sd][2 * mm + s] = __builtin_bit_cast(f2_u32x4, lo);
+                    if constexpr (SIGN) __builtin_amdgcn_raw_buffer_store_b128(e2h[sd][2 * mm + s], rsE, stv[sd], sts[sd] + (2 * mm + s) * 1024, 0);
                 }
             }
         });

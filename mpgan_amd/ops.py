@@ -490,6 +490,10 @@ class FusedMPLayerFn(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)
         sign3 = torch.empty((B * RB * N * 192,), device=dev, dtype=torch.int32) if need_grad else None
         e.sign3 = None if sign3 is None else C.c_void_p(sign3.data_ptr())
+        # E2 (the second edge layer's output) parked as fp16 fragments for the backward, which takes LeakyReLU' from its
+        # signs instead of recomputing the layer, and for the weight-gradient kernel
+        stE2 = torch.empty((B * RB * N, H2, 32), device=dev, dtype=torch.float16) if need_grad else None
+        e.stageE2 = None if stE2 is None else C.c_void_p(stE2.data_ptr())
         check(_lib.lib().mpg_edge_fwd(C.byref(e), _stream()), "mpg_edge_fwd")
         agg = aggp[0] if SC == 1 else aggp.sum(0)
 
@@ -504,14 +508,14 @@ class FusedMPLayerFn(torch.autograd.Function):
               A=agg, lda=H3, K1=H3, A2=x2, lda2=x2.stride(0), alpha=alpha, seed_t=seed_t, f16=f16, ascale=SC_ACT)
         ctx.packed = pk
 
-        ctx.save_for_backward(x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3, nbr)
+        ctx.save_for_backward(x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3, nbr, stE2)
         ctx.cfg = (B, N, F, agg_scale, alpha, thr, dscale, tag, SC, f16)
         return y.reshape(B, N, V3.shape[0])
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3, nbr = ctx.saved_tensors
+        x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3, nbr, stE2 = ctx.saved_tensors
         pk = ctx.packed
         B, N, F, agg_scale, alpha, thr, dscale, tag, SC, f16 = ctx.cfg
         nbr_p = None if nbr is None else C.c_void_p(nbr.data_ptr())
@@ -558,10 +562,9 @@ class FusedMPLayerFn(torch.autograd.Function):
         nblk = B * RB * N
         dap = torch.empty((SC, V, H1), device=dev, dtype=torch.float32)
         dcp = torch.empty((RB, V, H1), device=dev, dtype=torch.float32)
-        stE2 = stZ2 = None
+        stZ2 = None
         if need_w:
-            stE2 = torch.empty((nblk, H2, 32), device=dev, dtype=torch.float16)   # fp16 fragments as the lanes hold them
-            stZ2 = torch.empty((nblk, H2, 32), device=dev, dtype=torch.float16)
+            stZ2 = torch.empty((nblk, H2, 32), device=dev, dtype=torch.float16)   # fp16 fragments as the lanes hold them
             gexp = torch.empty((B * RB,), device=dev, dtype=torch.int32)           # gradient-unit exponent per (jet, receiver block)
         e = MpgEdgeBwd()
         e.a, e.c, e.ld_ac, e.mask = _p(ac), _p(ac, H1), 2 * H1, _p(m1)
@@ -571,7 +574,7 @@ class FusedMPLayerFn(torch.autograd.Function):
         e.W3Timg, e.W2Timg = pk.ptr("W3T"), pk.ptr("W2T")
         e.b2 = _p(b2)
         e.da, e.dc = _p(dap), _p(dcp)
-        e.stageE2 = None if stE2 is None else C.c_void_p(stE2.data_ptr())
+        e.stageE2 = C.c_void_p(stE2.data_ptr())
         e.stageZ2 = None if stZ2 is None else C.c_void_p(stZ2.data_ptr())
         e.gexp = None if stZ2 is None else C.c_void_p(gexp.data_ptr())
         e.B, e.N, e.SC = B, N, SC
@@ -603,7 +606,7 @@ class FusedMPLayerFn(torch.autograd.Function):
             d.seed, d.tag_base, d.thr, d.dscale = _p(seed_t), tag, thr, dscale
             d.f16 = int(f16)
             check(_lib.lib().mpg_edge_dw(C.byref(d), _stream()), "mpg_edge_dw")
-            del stE2, stZ2
+            del stZ2
             # layer 1 (fe.net.0): a = W1[:, :F] x + b1, c = W1[:, F:] x
             if direct:
                 dW1, db1 = gW1, gb1
