@@ -274,6 +274,16 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
 
         // (no recomputation of layer 2: E2 = fe.net.1's output comes back from memory, parked by the forward as the fp16
         //  fragments the lanes hold -- requested above, first used by phase C's gate)
+        // the parked E2 fragments (10 x 16 B per lane and sender, one per k-step of phase C) come from HBM: a ring of
+        // E2D + 1, the first E2D requested here -- a whole phase B ahead -- and one more per k-step of phase C
+        constexpr int E2D = 4;
+        b2_u32x4 e2g[E2D + 1][2];
+        auto load_e2 = [&](auto kc) {
+            MPG_CI(k, kc);
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd) e2g[k % (E2D + 1)][sd] = __builtin_amdgcn_raw_buffer_load_b128(rsE, lane16, stsc[sd] + k * 1024, 0);
+        };
+        static_for<0, E2D>([&](auto kc) { load_e2(kc); });
         B2_STAMP(1); B2_STAMP(2); B2_STAMP(3);
         // ---- phase B: dE2 = W3'^T dZ3, k-outer, two fp16 terms (W3^T lo, hi x dZ3 rounded to fp16).  dZ3 = dagg * slope(sign
         //      word) * keep3 in the sender's gradient unit is built one k-step ahead.
@@ -365,7 +375,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             V ah[3][T1], al[3][T1];       // ring of three k-steps of W2^T fragments (L2 is more than one k-step away)
             // ... and of the parked E2 fragments (10 x 16 B per lane and sender, one per k-step): their SIGN is phi'(Z2) for
             // dZ2's gate (LeakyReLU keeps the sign; a dropped element is +0 and is zeroed by the regenerated keep mask)
-            b2_u32x4 e2g[3][2];
+            // (declared and first requested before phase B: e2g, E2D)
             uint32_t wd2c[2] = {0u, 0u};  // bit-mode dropout word of the layer-2 tile being gated (hashed again: see erow2)
             auto load_w = [&](auto kc) {
                 MPG_CI(k, kc);
@@ -375,11 +385,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                     al[k % 3][m] = img_frag<V>(r2t, lane16, NF2T + m * KS + ((MPG_B2EXP & 1) ? 0 : k));
                 }
             };
-            auto load_e2 = [&](auto kc) {   // (requested one k-step before the build that reads it, two before its MFMAs)
-                MPG_CI(k, kc);
-#pragma unroll
-                for (int sd = 0; sd < 2; ++sd) e2g[k % 3][sd] = __builtin_amdgcn_raw_buffer_load_b128(rsE, lane16, stsc[sd] + k * 1024, 0);
-            };
+
             // build units of the dZ2 fragment of k-step k: per sender 8 element units + 4 pair conversions + 1 store = 13
             auto buildC = [&](auto kc, auto uc) {
                 MPG_CI(k, kc); MPG_CI(uu, uc);
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                 if constexpr (u < 8) {
                     constexpr int r16 = 8 * s + u, g = r16 >> 2, t = r16 & 3;
                     // sign of Z2 (register r16 of tile m2) = sign of element u of the parked E2 fragment 2 m2 + s
-                    float gt = sel_by_bit<16 * (u & 1) + 15>(e2g[k % 3][sd][u >> 1], valpha2, vone2);
+                    float gt = sel_by_bit<16 * (u & 1) + 15>(e2g[k % (E2D + 1)][sd][u >> 1], valpha2, vone2);
                     if constexpr (DROP != 0) {
                         uint32_t wd;
                         if constexpr (DROP == 2) {
@@ -406,14 +412,14 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                         __builtin_amdgcn_raw_buffer_store_b128(zz[k & 1][sd], rsZ, stoff[sd], k * 1024, 0);
                 }
             };
-            load_e2(std::integral_constant<int, 0>{});
-            load_e2(std::integral_constant<int, 1>{});
             load_w(std::integral_constant<int, 0>{});
             load_w(std::integral_constant<int, 1>{});
             static_for<0, 26>([&](auto uc) { buildC(std::integral_constant<int, 0>{}, uc); });
             static_for<0, KS>([&](auto kc) {
                 MPG_CI(k, kc);
-                if constexpr (k + 2 < KS) { load_e2(std::integral_constant<int, k + 2>{}); load_w(std::integral_constant<int, k + 2>{}); }
+                // (fragment k + 1 is read by the build units in this k-step's slots: slot (k + E2D) % (E2D + 1) is free)
+                if constexpr (k + E2D < KS) load_e2(std::integral_constant<int, k + E2D>{});
+                if constexpr (k + 2 < KS) load_w(std::integral_constant<int, k + 2>{});
                 const V b0 = __builtin_bit_cast(V, zz[k & 1][0]), b1 = __builtin_bit_cast(V, zz[k & 1][1]);
                 static_for<0, T1>([&](auto mc) {
                     MPG_CI(m, mc);

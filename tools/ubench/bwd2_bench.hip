@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
     hipMalloc(&a, ha.size() * 4); hipMalloc(&c, hc.size() * 4); hipMalloc(&m, hm.size() * 4); hipMalloc(&d, hd.size() * 4);
     hipMalloc(&b2, 160 * 4); hipMalloc(&w2, hw2.size() * 4); hipMalloc(&w3, hw3.size() * 4);
     hipMalloc(&da, dab); hipMalloc(&dc, dcb); hipMalloc(&sE, stb); hipMalloc(&sZ, stb); hipMalloc(&gexp, B * RB * 4);
-    { std::vector<uint16_t> he(stb / 2); for (auto& x : he) x = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15)); hipMemcpy(sE, he.data(), stb, hipMemcpyHostToDevice); }  // the forward's parked E2: fp16 values of either sign
+    { std::vector<uint16_t> he(stb / 2); unsigned int st = 777u; for (auto& x : he) { st = st * 1664525u + 1013904223u; x = (uint16_t)(0x3000 + ((st >> 8) & 0xfff) + (((st >> 24) & 1) << 15)); } hipMemcpy(sE, he.data(), stb, hipMemcpyHostToDevice); }  // the forward's parked E2: fp16 values of either sign
     hipMemset(sZ, 0, stb); hipMemset(da, 0xff, dab); hipMemset(dc, 0xff, dcb);
     hipMalloc(&i2, 2 * 30 * 1024); hipMalloc(&i3t, 2 * 60 * 1024); hipMalloc(&i2t, 2 * 30 * 1024);
     hipMalloc(&sg, (size_t)nblk * 192 * 4); hipMalloc(&seed, 8);
@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
     hipMemcpy(m, hm.data(), hm.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d, hd.data(), hd.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(b2, hb.data(), 160 * 4, hipMemcpyHostToDevice);
     hipMemcpy(w2, hw2.data(), hw2.size() * 4, hipMemcpyHostToDevice); hipMemcpy(w3, hw3.data(), hw3.size() * 4, hipMemcpyHostToDevice);
-    { std::vector<unsigned int> hs((size_t)nblk * 192); for (auto& x : hs) x = (unsigned int)rand() * 2654435761u; hipMemcpy(sg, hs.data(), hs.size() * 4, hipMemcpyHostToDevice); }
+    { std::vector<unsigned int> hs((size_t)nblk * 192); unsigned int st = 12345u; for (auto& x : hs) { st = st * 1664525u + 1013904223u; x = st ^ (st >> 15); }   /* (own generator: rand() is shared with the HIP runtime's threads once it is up, and its sequence then differs from process to process) */ hipMemcpy(sg, hs.data(), hs.size() * 4, hipMemcpyHostToDevice); }
     hipMemset(seed, 1, 8);
     const float dscale = MPG_SINGLE_VARIANT == 2 ? 2.f : (MPG_SINGLE_VARIANT == 1 ? 256.f / 179.f : 1.f);
     mpg_pack_weights(w2, 96, 160, 96, 0, 16.f * dscale, 1, i2, nullptr);
@@ -56,6 +56,19 @@ int main(int argc, char** argv) {
     for (int i = 0; i < R; ++i) mpg_edge_bwd(&p, nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
+    {   // run-to-run determinism: two more launches, outputs compared word for word
+        auto grab = [&](void* dev, size_t n) { std::vector<unsigned int> h(n / 4); hipMemcpy(h.data(), dev, n, hipMemcpyDeviceToHost); return h; };
+        mpg_edge_bwd(&p, nullptr); hipDeviceSynchronize();
+        auto a0 = grab(da, dab), c0 = grab(dc, dcb), z0 = grab(sZ, needw ? stb : 4);
+        mpg_edge_bwd(&p, nullptr); hipDeviceSynchronize();
+        auto a1 = grab(da, dab), c1 = grab(dc, dcb), z1 = grab(sZ, needw ? stb : 4);
+        size_t na = 0, nc = 0, nz = 0, fa = (size_t)-1, fc = (size_t)-1, fz = (size_t)-1;
+        for (size_t i = 0; i < a0.size(); ++i) if (a0[i] != a1[i]) { if (!na) fa = i; ++na; }
+        for (size_t i = 0; i < c0.size(); ++i) if (c0[i] != c1[i]) { if (!nc) fc = i; ++nc; }
+        for (size_t i = 0; i < z0.size(); ++i) if (z0[i] != z1[i]) { if (!nz) fz = i; ++nz; }
+        printf("  determinism: da %zu of %zu words differ (first %zu = jet %zu row %zu feat %zu), dc %zu (first %zu), dZ2 %zu (first word %zu = block %zu frag %zu lane %zu)\n",
+               na, a0.size(), fa, fa / (N * 96), (fa / 96) % N, fa % 96, nc, fc, nz, fz, fz / 2560, (fz % 2560) / 256, (fz % 256) / 4);
+    }
     auto checksum = [](void* dev, size_t n) {
         std::vector<unsigned int> h(n / 4); hipMemcpy(h.data(), dev, n, hipMemcpyDeviceToHost);
         unsigned long long s = 0; for (size_t i = 0; i < h.size(); ++i) s = s * 1099511628211ull + h[i];
@@ -71,6 +84,8 @@ int main(int argc, char** argv) {
                n, (avg[1] + avg[2] + avg[3]) / n, avg[4] / n, avg[5] / n, avg[6] / n);
     }
 #endif
+    printf("  inputs: a %016llx c %016llx dagg %016llx mask %016llx sign %016llx W3T %016llx W2T %016llx\n", checksum(a, ha.size() * 4), checksum(c, hc.size() * 4),
+           checksum(d, hd.size() * 4), checksum(m, hm.size() * 4), checksum(sg, (size_t)nblk * 192 * 4), checksum(i3t, 2 * 60 * 1024), checksum(i2t, 2 * 30 * 1024));
     printf("DROP=%d B=%d N=%d SC=%d %s ragged=%d: %.1f us   checksums da %016llx dc %016llx E2 %016llx dZ2 %016llx\n",
            MPG_SINGLE_VARIANT, B, N, SC, needw ? "dW" : "data", ragged, ms * 1e3f / R, checksum(da, dab), checksum(dc, dcb),
            checksum(sE, stb), needw ? checksum(sZ, stb) : 0ull);
