@@ -73,11 +73,13 @@ def rate(sub, key):
     d = [v for k, v in dur.items() if sub in k]
     return tot(key) / d[0] / 1e12 if d else float("nan")
 txt += ("#\n# Achieved HBM rate at B=256 (bytes above / rocprof average duration in " + f"{tag}_bench_kernel_stats.csv" + "; HBM3E peak 8 TB/s):\n"
-        f"#   edge_fwd_kernel<0, true, true>   {rate('edge_fwd_kernel<0, true, true>', 'edge_fwd_kernel<0'):5.2f} TB/s  (compute bound: see the SQ counters)\n"
+        f"#   edge_fwd_kernel<0, true>   {rate('edge_fwd_kernel<0, true>', 'edge_fwd_kernel<0'):5.2f} TB/s  (compute bound: see the SQ counters)\n"
         f"#   edge_bwd_kernel<0, true>   {rate('edge_bwd_kernel<0, true>', 'edge_bwd_kernel<0, true'):5.2f} TB/s\n"
         f"#   edge_dw_kernel<0>          {rate('edge_dw_kernel<0>', 'edge_dw_kernel<0'):5.2f} TB/s\n")
-txt += ("#\n# forward: a|c in, agg + sign words out (algorithmic 17.7 MB).  backward + staging: 2 x 10 KiB of fp16 E2 / dZ2 fragments per\n"
-        "# unmasked (jet, sender) block for mpg_edge_dw, which reads them back and writes 256 per-workgroup partial sums.\n#\n" + pm)
+txt += ("#\n# forward: a|c in, agg + sign words out (algorithmic 17.7 MB) + 10 KiB of fp16 E2 fragments per unmasked (jet, sender) block,\n"
+        "# parked for the backward (which reads them for the LeakyReLU gate instead of recomputing the layer) and for mpg_edge_dw;\n"
+        "# backward + staging: 10 KiB of fp16 dZ2 fragments per block; mpg_edge_dw reads both back and writes 256 per-workgroup\n"
+        "# partial sums.\n#\n" + pm)
 open(os.path.join(P, f"{tag}_pmc_hbm_traffic.txt"), "w").write(txt)
 w, wo = tot("edge_bwd_kernel<2, true"), tot("edge_bwd_kernel<2, false")
 w0 = tot("edge_bwd_kernel<0, true")
@@ -85,8 +87,10 @@ traffic = {
     "note": f"bytes per launch from profiles/{tag}_pmc_hbm_traffic.txt (2 x FETCH_SIZE + WRITE_SIZE), B=256, N=30. edge_bwd_kernel: "
             "launch-weighted mean over the 6 launches of one default bench step (2 at 2B = 512 jets with staging [D, p = 1/2], "
             "2 at B = 256 data path only [D in the G step], 2 at B = 256 with staging [G, no dropout]); edge_fwd_kernel: mean over "
-            "its 8 launches (2 at 512 jets)",
-    "edge_fwd_kernel": {"bytes_per_launch": int(tot("edge_fwd_kernel<2") * 10 / 8)},
+            "its 8 launches (2 at B without by-products, 2 at 512 jets and 4 at B with sign words + parked E2)",
+    # forward: 2 launches at B without by-products for a backward (the generator in the D step: a|c in, agg out = 13.3 MB
+    # algorithmic, not in the PMC workload), 2 at 2B and 4 at B with sign words and parked E2
+    "edge_fwd_kernel": {"bytes_per_launch": int((2 * 13.3e6 + 2 * 2 * tot("edge_fwd_kernel<2") + 4 * tot("edge_fwd_kernel<0")) / 8)},
     "edge_bwd_kernel": {"bytes_per_launch": int((2 * 2 * w + 2 * wo + 2 * w0) / 6)},
     "edge_dw_kernel": {"bytes_per_launch": int(tot("edge_dw_kernel<2"))},
 }
