@@ -54,11 +54,10 @@ def iteration_flops_per_jet(N):
 def executed_flops_per_jet(N, valid_frac):
     """MFMA FLOPs the fused path actually ISSUES per jet and G+D iteration: the logical MACs of every launch in the
     step (x2) times the number of 16-bit terms the product runs in -- 3 (hi/lo x hi/lo without lo*lo) for every forward
-    product, the backward's recomputation of fe layer 2 and the node network; 2 for the edge backward's data-gradient
+    product and the node network; 2 for the edge backward's data-gradient
     products (weight hi + lo times the gradient rounded to fp16); 1 for the edge weight gradients.  Differences to the
     algorithmic figure: layer 1 of fe is the factorised a_i + c_j (two node-level products instead of one per edge);
-    masked senders are skipped (``valid_frac`` = mean multiplicity / N of the batch); the backward recomputes fe
-    layer 2; train_D does not back-propagate into G and train_G forms no weight gradients of D (both results-neutral,
+    masked senders are skipped (``valid_frac`` = mean multiplicity / N of the batch); train_D does not back-propagate into G and train_G forms no weight gradients of D (both results-neutral,
     train.py:420, :495).  Tile padding (30 receivers on 32 lanes, K rounded up to 32) is not counted."""
     E = N * N * valid_frac                      # edges that are computed per jet-layer
 
@@ -69,7 +68,7 @@ def executed_flops_per_jet(N, valid_frac):
         f += fwd * 3 * (ac + E * 2 * (H1 * H2 + H2 * H3) + node_fwd)
         if bwd_x or bwd_w:
             f += 3 * node_fwd                                                   # fn input-gradient chain
-            f += E * 2 * (3 * H1 * H2 + 2 * (H2 * H3 + H2 * H1))                # recompute L2 (3 terms); dE2, dE1 (2 terms)
+            f += E * 2 * 2 * (H2 * H3 + H2 * H1)                                # dE2, dE1 (2 terms; nothing is recomputed)
             if bwd_w:
                 f += E * 2 * (H3 * H2 + H2 * H1) + 3 * (node_fwd + ac)          # dW3, dW2 (1 term); fn dW; dW1
             if not first:
@@ -338,8 +337,8 @@ def roofline(torch, ts, model, dev, measured_traffic=True):
                 "flop_per_launch": flop_sum / nl, "avg_launch_ms": ms_sum / nl,
                 "note": "algorithmic FLOPs of the two fused dense layers (one MAC = 2 FLOP, all B*N*N edges) over the "
                         "HIP-event time of all launches of the kernel in a step; the forward issues 3 MFMA MACs per "
-                        "algorithmic MAC (hi/lo split: 1/3 is the ceiling of its frac), the data-gradient kernel 2 per MAC plus "
-                        "the 3-term recomputation of layer 2 (ceiling 0.34), and tools/ubench/mfma_power.hip measures 1.45 "
+                        "algorithmic MAC (hi/lo split: 1/3 is the ceiling of its frac), the data-gradient kernel 2 per MAC "
+                        "(ceiling 1/2), and tools/ubench/mfma_power.hip measures 1.45 "
                         "PFLOP/s (not 2.5) as the dense f16 MFMA rate this chip sustains on random operands"}
     else:
         ach = byte_sum / (ms_sum * 1e-3) / 1e9
