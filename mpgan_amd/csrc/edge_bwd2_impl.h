@@ -66,17 +66,6 @@ MPG_DEV uint32_t cvt_pk_f16(float v0, float v1) {
     return __builtin_bit_cast(uint32_t, hp);
 }
 
-// if_set / if_clear chosen by bit BIT of `word`: v_bfe_i32 + v_bfi_b32 (left to itself the compiler builds a compare,
-// two wait states for VCC and a v_cndmask per element)
-template <int BIT>
-MPG_DEV float sel_by_bit(uint32_t word, float if_set, float if_clear) {
-    int m;
-    float r;
-    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(word), "n"(BIT));
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(if_set), "v"(if_clear));
-    return r;
-}
-
 // units u of [0, NU) that fall into slot SL of NS
 template <int NU, int NS, int SL, typename F>
 MPG_DEV void run_slot(F&& unit) {

@@ -101,6 +101,17 @@ MPG_DEV void tile_chain(f32x16& acc, const V (*bhi)[2], const V (*blo)[2], LH lo
 // SC_E2*SC_W3 (= SC_E3), which the aggregation folds into m_j * dscale.  (fp16 range: e1 < 16k, e2 < 1k, weights < 1k.)
 constexpr float SC_A = 4.f, SC_W2 = 16.f, SC_W3 = 64.f, SC_E2 = SC_A * SC_W2, SC_E3 = SC_E2 * SC_W3;
 
+// if_set / if_clear chosen by bit BIT of `word`: v_bfe_i32 + v_bfi_b32 (left to itself the compiler builds a compare,
+// two wait states for VCC and a v_cndmask per element)
+template <int BIT>
+MPG_DEV float sel_by_bit(uint32_t word, float if_set, float if_clear) {
+    int m;
+    float r;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(word), "n"(BIT));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(if_set), "v"(if_clear));
+    return r;
+}
+
 // Dither factor of a block (jet, receiver block, sender) of the edge backward: c in [1, 2), a hash of the block index.
 // mpg_edge_bwd works on the block's gradients times c, mpg_edge_dw divides the parked dZ2 by it (edge_bwd2_impl.h).
 MPG_DEV float dither_of(uint32_t blk) {

@@ -375,20 +375,22 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
         // receiver is the same number for all its senders up to one of two constants: see edge_bwd2_impl.h); the bias
         // sums take it without the factor
         const float in_set = (p.nbr == nullptr || ((S.nbw >> (j & 31)) & 1u)) ? 1.f : 0.f;
-        const float dscl_1 = S.dscl * in_set, dscl_a = S.dscl * p.alpha * in_set;
+        const float dscl_1 = S.dscl * in_set * dth, dscl_a = dscl_1 * p.alpha;   // (the dither factor rides in the slope constants)
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
             const int m = 2 * n + (cg >> 2), c = cg + 8 * n;
             float v[8];
             const uint32_t keep = dw_chunk_keep<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, m, f0, p.thr);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t neg = (S.sw[n] >> (31 - (16 * (m & 1) + 8 * cs + k))) & 1u;
-                float x = S.dreg[n][k] * (neg ? dscl_a : dscl_1);
+            // sign bit of element k: bit 31 - (16 (m & 1) + 8 cs + k) of the lane's word -- shifted once so that the bit index
+            // is a compile-time constant (v_bfe + v_bfi instead of shift, and, compare, select)
+            const uint32_t swn = S.sw[n] << (16 * (m & 1) + 8 * cs);
+            static_for<0, 8>([&](auto kc) {
+                MPG_CI(k, kc);
+                float x = S.dreg[n][k] * sel_by_bit<31 - k>(swn, dscl_a, dscl_1);
                 if (DROP && !((keep >> k) & 1u)) x = 0.f;
-                v[k] = x * dth;
-                db3[n][k] += x;
-            }
+                v[k] = x;
+                db3[n][k] = fmaf(x, rdth, db3[n][k]);
+            });
             const f16x8 hh = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3], (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
             if (!exp_nowrite) *reinterpret_cast<f16x8*>(buf + DW_Z3H + r * DW_RS3 + c * 16) = hh;
             else if (hh[0] == (_Float16)123.f) db2[0][0] += (float)hh[1];
