@@ -44,7 +44,10 @@ typedef struct MpgGemm {
     const float* resid;  /* C += resid[m*ldr+n]                                                     */
     int ldr;
     int accumulate;      /* C += result instead of C = result                                       */
-    int f16;             /* 1: split operands as fp16 hi/lo (forward products); 0: bf16 hi/lo (gradients) */
+    int f16;             /* 1: split operands as fp16 hi/lo (forward products); 0: bf16 hi/lo (gradients);
+                          * 2 (mpg_gemm_wgrad_group only, every job of the call): one-term fp16 products on 128 x 128 tiles with a
+                          * power-of-two unit per 128 rows of A -- needs 16-byte aligned B, ldb % 4 == 0 and rows of B at least
+                          * as long as their width rounded up to 4 (-3 otherwise)                                     */
     int ones_col;        /* 1: column N-1 of B is the constant 1 (N counts it): C[:, N-1] = row sums of A  */
 } MpgGemm;
 
