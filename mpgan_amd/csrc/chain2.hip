@@ -84,13 +84,25 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
 #endif
     C2_STAMP(0);
 
+    // biases into LDS: requested behind the input rows and the first weight tile (which the first k loop waits for anyway),
+    // laid down after the rows are staged -- at the top of the kernel their latency was 1.3k clk in front of everything
     float* const sbias = reinterpret_cast<float*>(smem + 2 * C2_FB);
-    static_for<0, NL>([&](auto lc) {   // (a run-time index into p.L would move the whole argument block to scratch)
-        MPG_CI(l, lc);
-        const int nb = p.L[l].bias != nullptr ? (p.L[l].nbias ? p.L[l].nbias : p.L[l].N) : 0;
-        const float so = p.L[l].drop_thr ? p.L[l].drop_scale : 1.f;   // the layer's dropout scale rides on bias and product
-        sbias[256 * l + tid] = tid < nb ? p.L[l].bias[min(tid, max(nb - 1, 0))] * so : 0.f;
-    });
+    float bv[NL];
+    auto bias_request = [&]() {
+        static_for<0, NL>([&](auto lc) {   // (a run-time index into p.L would move the whole argument block to scratch)
+            MPG_CI(l, lc);
+            const int nb = p.L[l].bias != nullptr ? (p.L[l].nbias ? p.L[l].nbias : p.L[l].N) : 0;
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.L[l].bias), 0, nb * 4, 0x00020000);
+            bv[l] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, tid * 4, 0, 0));   // (past nb: zero)
+        });
+    };
+    auto bias_store = [&]() {
+        static_for<0, NL>([&](auto lc) {
+            MPG_CI(l, lc);
+            const float so = p.L[l].drop_thr ? p.L[l].drop_scale : 1.f;   // the layer's dropout scale rides on bias and product
+            sbias[256 * l + tid] = bv[l] * so;
+        });
+    };
 
     C2_STAMP(18);
     V wb[2][16][2];   // [slot A | slot B][k-step][hi | lo]: whole tiles
@@ -127,9 +139,12 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
             constexpr int NI = (KS0 * 64 + 255) / 256;
             float4 x[NI][2];
             const float* a2 = p.A2 != nullptr ? p.A2 : p.A;
+            // unit u = (row rr, k-step ks, half hh), row-major: the 2 KS0 units of a row sit on adjacent lanes, so a wave
+            // instruction takes whole 128-byte lines of two or three rows (lane = row made every lane its own line: 64 line
+            // requests per instruction, 2k clk of the texture path per workgroup before the first weight tile could be asked for)
             static_for<0, NI>([&](auto ic) {
                 MPG_CI(i, ic);
-                const int u = min(tid + 256 * i, KS0 * 64 - 1), ks = u >> 6, ln = u & 63, rr = ln & 31, hh = ln >> 5;
+                const int u = min(tid + 256 * i, KS0 * 64 - 1), rr = u / (2 * KS0), rem = u - rr * (2 * KS0), ks = rem >> 1, hh = rem & 1;
                 const size_t row = (size_t)min(m0 + rr, p.M - 1);
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
@@ -140,6 +155,7 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
             });
             C2_STAMP(19);
             first_tile(I0{});     // (its 28+ KiB per wave arrive while the rows are converted)
+            bias_request();
             C2_STAMP(20);
             const uint32_t in_thr = p.in_thr;
             const bool in_on = in_thr != 0u;
@@ -148,7 +164,8 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
                 p.in_out, 0, p.in_out != nullptr ? (int)((size_t)p.M * p.ld_in_out * 4) : 0, 0x00020000);
             static_for<0, NI>([&](auto ic) {
                 MPG_CI(i, ic);
-                const int u = tid + 256 * i, uc = min(u, KS0 * 64 - 1), ks = uc >> 6, ln = uc & 63, rr = ln & 31, hh = ln >> 5;
+                const int u = tid + 256 * i, uc = min(u, KS0 * 64 - 1), rr = uc / (2 * KS0), rem = uc - rr * (2 * KS0), ks = rem >> 1, hh = rem & 1;
+                const int ln = rr + 32 * hh;
                 const int mm = m0 + rr;
                 const bool live = mm < p.M;
                 float v[8];
@@ -183,7 +200,10 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
                 }
             });
             first_tile(I1{});
+            bias_store();
         } else {
+            bias_request();
+            bias_store();
             for (int u = tid; u < KS0 * 64; u += 256) {
                 const int ks = u >> 6, ln = u & 63, rr = ln & 31, hh = ln >> 5;
                 const int mm = m0 + rr;
