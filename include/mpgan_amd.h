@@ -160,7 +160,15 @@ typedef struct MpgEdgeFwd {
                                              <=> sender j is a neighbour of receiver i (mpg_knn_sets); NULL = fully connected */
     void* stageE2;                        /* with sign3: E2 = fe.net.1's output (in the forward's operand scale) parked as fp16
                                              fragments [B*RB*N blocks][10][64 lanes][8] for mpg_edge_bwd / mpg_edge_dw */
+    /* Edge features and row-tiled conditioning columns of MPLayer (mpgan/model.py:247-253, :297-313: delta_r, clabels,
+     * mask_fne_np) -- MPG_EDGE_SCALARS scalars per edge, each times its own column of fe.net.0.weight:
+     *   Z1(i, j) = a_i + c_j + sum_q es[b][j][q][i] * wq[q][:]
+     * es is [B][N senders][MPG_EDGE_SCALARS][N receivers], wq [MPG_EDGE_SCALARS][96] (unused scalars: zero columns); NULL = none.
+     * The scalars themselves (4 bytes per edge and scalar, not the 2F+ features per edge of the reference's edge matrix) are
+     * the caller's: a norm of a coordinate difference, a gather from a [B] table. */
+    const float* es; const float* wq;
 } MpgEdgeFwd;
+#define MPG_EDGE_SCALARS 2
 int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream);
 
 /* mpg_knn_sets: the neighbour sets of MPLayer._getA_knn (mpgan/model.py:319-381) as bit masks for the fused edge kernels.
@@ -199,6 +207,11 @@ typedef struct MpgEdgeBwd {
     int f16;
     const unsigned int* nbr;              /* as MpgEdgeFwd.nbr */
     int* gexp;                            /* [B*RB] gradient-unit exponents of the parked dZ2 (required with stageE2/stageZ2) */
+    const float* es; const float* wq;     /* as MpgEdgeFwd (NULL = none) */
+    float* des;                           /* with es: dL/des, same layout (rows of skipped -- zero-masked -- senders are not written:
+                                             clear it first) */
+    float* daq;                           /* with es: [SC][B*N][MPG_EDGE_SCALARS][96] = sum_j es(i, j) * dZ1(i, j) per receiver;
+                                             summed over its rows it is the gradient of wq */
 } MpgEdgeBwd;
 int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream);
 
@@ -224,6 +237,7 @@ typedef struct MpgEdgeDw {
     int f16;                              /* must be 1 */
     const unsigned int* nbr;              /* as MpgEdgeFwd.nbr */
     const int* gexp;                      /* [B*RB] from mpg_edge_bwd */
+    const float* es; const float* wq;     /* as MpgEdgeFwd (NULL = none): E1 is rebuilt with them */
 } MpgEdgeDw;
 int mpg_edge_dw(const MpgEdgeDw* p, void* stream);
 

@@ -48,6 +48,7 @@ class MpgEdgeFwd(C.Structure):
         ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
         ("skip_masked", C.c_int), ("f16", C.c_int),
         ("sign3", _fp), ("nbr", _fp), ("stageE2", _fp),
+        ("es", _fp), ("wq", _fp),
     ]
 
 
@@ -64,6 +65,7 @@ class MpgEdgeBwd(C.Structure):
         ("alpha", C.c_float), ("agg_scale", C.c_float),
         ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
         ("f16", C.c_int), ("nbr", _fp), ("gexp", _fp),
+        ("es", _fp), ("wq", _fp), ("des", _fp), ("daq", _fp),
     ]
 
 
@@ -78,6 +80,7 @@ class MpgEdgeDw(C.Structure):
         ("alpha", C.c_float), ("agg_scale", C.c_float),
         ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
         ("f16", C.c_int), ("nbr", _fp), ("gexp", _fp),
+        ("es", _fp), ("wq", _fp),
     ]
 
 

@@ -4,6 +4,9 @@
 #include "edge_fwd2_impl.h"
 
 int mpg_edge_fwd_d1(const MpgEdgeFwd* p, hipStream_t st);   // edge_fwd_d1.hip: byte-threshold dropout
+int mpg_edge_fwd_q0(const MpgEdgeFwd* p, hipStream_t st);   // edge_fwd_q{0,1,2}.hip: with edge scalars, by dropout mode
+int mpg_edge_fwd_q1(const MpgEdgeFwd* p, hipStream_t st);
+int mpg_edge_fwd_q2(const MpgEdgeFwd* p, hipStream_t st);
 int mpg_edge_fwd_d2(const MpgEdgeFwd* p, hipStream_t st);   // edge_fwd_d2.hip: one-bit dropout (p = 1/2)
 
 namespace {
@@ -60,6 +63,10 @@ extern "C" int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream) {
     return f2_launch<MPG_SINGLE_VARIANT>(p, st);
 #else
     const int dm = p->thr == 0 ? 0 : (p->thr == 128 ? 2 : 1);
+    if (p->es != nullptr) {
+        if (p->wq == nullptr) return -3;
+        return dm == 0 ? mpg_edge_fwd_q0(p, st) : (dm == 1 ? mpg_edge_fwd_q1(p, st) : mpg_edge_fwd_q2(p, st));
+    }
     return dm == 0 ? f2_launch<0>(p, st) : (dm == 1 ? mpg_edge_fwd_d1(p, st) : mpg_edge_fwd_d2(p, st));
 #endif
 }

@@ -5,6 +5,9 @@
 
 int mpg_edge_bwd_d1(const MpgEdgeBwd* p, hipStream_t st);   // edge_bwd2_d1.hip: byte-threshold dropout
 int mpg_edge_bwd_d2(const MpgEdgeBwd* p, hipStream_t st);   // edge_bwd2_d2.hip: one-bit dropout (p = 1/2)
+int mpg_edge_bwd_q0(const MpgEdgeBwd* p, hipStream_t st);   // edge_bwd2_q{0,1,2}.hip: with edge scalars, by dropout mode
+int mpg_edge_bwd_q1(const MpgEdgeBwd* p, hipStream_t st);
+int mpg_edge_bwd_q2(const MpgEdgeBwd* p, hipStream_t st);
 
 extern "C" int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream) {
     if (p->B <= 0 || p->N <= 0 || p->SC <= 0) return -1;
@@ -20,6 +23,11 @@ extern "C" int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream) {
     return b2_launch<MPG_SINGLE_VARIANT>(p, st);
 #else
     const int dm = p->thr == 0 ? 0 : (p->thr == 128 ? 2 : 1);
+    if (p->es != nullptr) {
+        if (p->wq == nullptr || p->des == nullptr || p->daq == nullptr) return -3;
+        if ((p->N + p->SC - 1) / p->SC > B2_LIST_MAX_Q) return -6;
+        return dm == 0 ? mpg_edge_bwd_q0(p, st) : (dm == 1 ? mpg_edge_bwd_q1(p, st) : mpg_edge_bwd_q2(p, st));
+    }
     return dm == 0 ? b2_launch<0>(p, st) : (dm == 1 ? mpg_edge_bwd_d1(p, st) : mpg_edge_bwd_d2(p, st));
 #endif
 }

@@ -57,6 +57,12 @@ constexpr int B2_C_BYTES = 4 * 2 * H1 * 4;       //   3,072
 constexpr int B2_LIST_MAX = 180;                 // senders per chunk (uint16 entries + count + 4 wave maxima of the prologue: 384 B)
 constexpr int B2_LDS_BYTES = B2_W_BYTES + B2_DG_BYTES + B2_A_BYTES + B2_B2_BYTES + B2_C_BYTES + 384;
 static_assert(B2_LDS_BYTES <= 163840, "LDS plan exceeds 160 KiB");
+// with edge scalars (NQ > 0) the columns wq [2][96] take the 640 bytes left over from b2 (nothing is recomputed any more)
+// and the first 128 bytes of the list area: a chunk then holds at most 116 senders
+constexpr int B2_Q_OFF = B2_W_BYTES + B2_DG_BYTES + B2_A_BYTES;
+constexpr int B2_LIST_MAX_Q = 116;
+constexpr int B2_Q_BYTES = MPG_EDGE_SCALARS * H1 * 4;   // 768: the rows of c and the list move up by 128 bytes
+static_assert(2 * B2_LIST_MAX_Q + 4 + 16 <= 384 - (B2_Q_BYTES - B2_B2_BYTES), "list area with edge scalars");
 
 typedef unsigned int b2_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -87,8 +93,11 @@ MPG_DEV int grad_unit_exp(float m) {
 
 MPG_DEV f32x16 mma(const f16x8 a, const f16x8 b, const f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-template <int DROP, bool NEEDW>  // DROP: 0 off, 1 byte mode, 2 bit mode (see common.h)
+// DROP: 0 off, 1 byte mode, 2 bit mode (see common.h); NQ: edge scalars (0 or MPG_EDGE_SCALARS): Z1 = a_i + c_j + sum_q es wq[q],
+// and the kernel also returns des = dZ1 . wq[q] per edge and daq = sum_j es dZ1 per receiver
+template <int DROP, bool NEEDW, int NQ>
 __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
+    constexpr int QB = NQ > 0 ? B2_Q_BYTES : B2_B2_BYTES;   // bytes between the a tile and the rows of c
     typedef f16x8 V;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -110,10 +119,10 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     f16x8* l3t = reinterpret_cast<f16x8*>(smem);
     float4* ldg = reinterpret_cast<float4*>(smem + B2_W_BYTES);                // [(m*4+g)][lane]
     float4* la = reinterpret_cast<float4*>(smem + B2_W_BYTES + B2_DG_BYTES);   // [(q*2+s)*2+u][lane]
-    float* lb2 = reinterpret_cast<float*>(smem + B2_W_BYTES + B2_DG_BYTES + B2_A_BYTES);
-    float* lcw = lb2 + H2 + w * (2 * H1);                                      // this wave's two rows of c
-    unsigned short* lst = reinterpret_cast<unsigned short*>(smem + B2_W_BYTES + B2_DG_BYTES + B2_A_BYTES + B2_B2_BYTES + B2_C_BYTES);
-    int* lnv = reinterpret_cast<int*>(lst + B2_LIST_MAX);
+    float* lwq = reinterpret_cast<float*>(smem + B2_Q_OFF);                    // wq [NQ][96] (times SC_A, like a and c)
+    float* lcw = reinterpret_cast<float*>(smem + B2_Q_OFF + QB) + w * (2 * H1); // this wave's two rows of c
+    unsigned short* lst = reinterpret_cast<unsigned short*>(smem + B2_Q_OFF + QB + B2_C_BYTES);
+    int* lnv = reinterpret_cast<int*>(lst + (NQ > 0 ? B2_LIST_MAX_Q : B2_LIST_MAX));
     float* lmx = reinterpret_cast<float*>(smem + B2_LDS_BYTES - 16);                // wave maxima of |dagg|
 
     // ---- prologue (whole workgroup): weights and the per-receiver tiles into LDS, the list of unmasked senders
@@ -140,6 +149,8 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
         if (ii < p.N) v4 = ld4(p.a + (size_t)(b * p.N + ii) * ldac + 8 * qsu + 4 * hh);
         la[t] = make_float4(v4.x * SC_A, v4.y * SC_A, v4.z * SC_A, v4.w * SC_A);
     }
+    if constexpr (NQ > 0)
+        for (int t = tid; t < NQ * H1; t += 256) lwq[t] = p.wq[t] * SC_A;
     if (w == 0) {  // unmasked senders of the chunk, in order (the chunk holds at most B2_LIST_MAX senders)
         int cnt = 0;
         for (int j0 = jbeg; j0 < jend; j0 += 64) {
@@ -171,7 +182,8 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     const uint32_t lb3t = lds_base(smem, lane16);                 // W3^T hi fragments; lo at + NF3T KiB
     const uint32_t lbdg = lds_base(smem, B2_W_BYTES + lane16);    // dagg tile
     const uint32_t lbla = lds_base(smem, B2_W_BYTES + B2_DG_BYTES + lane16);  // a tile
-    const uint32_t lbc = lds_base(smem, B2_W_BYTES + B2_DG_BYTES + B2_A_BYTES + B2_B2_BYTES + w * (2 * H1 * 4) + 16 * h);  // this wave's rows of c
+    const uint32_t lbc = lds_base(smem, B2_Q_OFF + QB + w * (2 * H1 * 4) + 16 * h);  // this wave's rows of c
+    const uint32_t lbq = lds_base(smem, B2_Q_OFF + 16 * h);
     // staging: block blk = (b*RB + rb)*N + j ; the 10 B-operand fragments (tile, k-step) of the 160-feature tensor,
     // rounded to fp16, exactly as the lanes hold them: one coalesced 16-byte store per lane and fragment.
     // Buffer stores: a block offset beyond the buffer (the idle second half of an odd pair) is dropped by the hardware.
@@ -205,6 +217,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     // clamped (the last pair is fetched again, unused).
     uint32_t psw[2][T3 / 2];
     float pc0[2], pc1[2];
+    float pes[2][NQ > 0 ? NQ : 1];
     auto prefetch = [&](int pq2) {
 #pragma unroll
         for (int sd = 0; sd < 2; ++sd) {
@@ -215,8 +228,23 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             const float* cj = p.c + (size_t)(b * p.N + jn) * ldac;
             pc0[sd] = cj[lane];
             pc1[sd] = cj[64 + (lane & 31)];
+            if constexpr (NQ > 0) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) pes[sd][q] = p.es[((size_t)(b * p.N + jn) * NQ + q) * p.N + (i < p.N ? i : 0)];
+            }
         }
     };
+    // (with edge scalars) per receiver: sum over this wave's senders of es(i, j, q) * dZ1(i, j) -- the gradient of wq's column
+    // once summed over receivers
+    float dqacc[NQ > 0 ? NQ : 1][T1][16];
+    if constexpr (NQ > 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int m = 0; m < T1; ++m)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) dqacc[q][m][k] = 0.f;
+    }
     prefetch(w);
     for (int pq = w; 2 * pq < nvalid; pq += 4) {
         const bool has2 = 2 * pq + 1 < nvalid;
@@ -258,6 +286,13 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             // the sender's row of c into this wave's LDS slot (96 floats: lanes 0..63, then lanes 0..31)
             lcw[sd * H1 + lane] = pc0[sd] * SC_A;
             if (lane < H1 - 64) lcw[sd * H1 + 64 + lane] = pc1[sd] * SC_A;
+        }
+        float esv[2][NQ > 0 ? NQ : 1];
+        if constexpr (NQ > 0) {
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) esv[sd][q] = (sd == 0 || has2) ? pes[sd][q] : 0.f;
         }
         prefetch(pq + 4);
 
@@ -454,6 +489,9 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
             static_for<0, 2>([&](auto sdc) {
                 MPG_CI(sd, sdc);
                 float* dcj = p.dc + ((size_t)rb * p.B * p.N + (size_t)(b * p.N + jj[sd])) * H1;
+                float dsq[NQ > 0 ? NQ : 1];   // des(i, j, q) = dZ1(i, j) . wq[q]: this lane's half of the 96 features
+#pragma unroll
+                for (int q = 0; q < (NQ > 0 ? NQ : 1); ++q) dsq[q] = 0.f;
                 static_for<0, T1>([&](auto mmc) {
                     MPG_CI(mm, mmc);
                     float ured[4];
@@ -464,14 +502,30 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                         // Z1 = a_i + c_j of the four features 32 mm + 16 s + 8 u + 4 h + t, as the forward adds them
                         const f32x4 a4 = lds_frag<f32x4>(lbla, ((mm * 2 + s) * 2 + u) * 1024);
                         const f32x4 c4 = lds_frag<f32x4>(lbc, (sd * H1 + 32 * mm + 16 * s + 8 * u) * 4);
+                        f32x4 q4[NQ > 0 ? NQ : 1];
+                        if constexpr (NQ > 0) {
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) q4[q] = lds_frag<f32x4>(lbq, (q * H1 + 32 * mm + 16 * s + 8 * u) * 4);
+                        }
                         float dz[4];
                         static_for<0, 4>([&](auto tc) {
                             MPG_CI(t, tc);
-                            const float z1 = c4[t] + a4[t];
+                            float z1 = c4[t] + a4[t];
+                            if constexpr (NQ > 0) {   // (the forward's order of additions: the sign must be the forward's)
+#pragma unroll
+                                for (int q = 0; q < NQ; ++q) z1 = fmaf(esv[sd][q], q4[q][t], z1);
+                            }
                             float gt = sel_by_bit<31>(__builtin_bit_cast(uint32_t, z1), valpha1[sd], vone1[sd]);
                             gt = drop_apply<DROP>(gt, wd, 16 * s + 8 * u + t, t, p.thr);
                             dz[t] = accC[mm][sd][8 * s + 4 * u + t] * gt;
                             dacc[mm][8 * s + 4 * u + t] += dz[t];
+                            if constexpr (NQ > 0) {
+#pragma unroll
+                                for (int q = 0; q < NQ; ++q) {
+                                    dsq[q] = fmaf(dz[t], q4[q][t], dsq[q]);
+                                    dqacc[q][mm][8 * s + 4 * u + t] = fmaf(esv[sd][q], dz[t], dqacc[q][mm][8 * s + 4 * u + t]);
+                                }
+                            }
                         });
                         const float w0 = halve_add<0xB1>(lb0, dz[0], dz[1]), w1 = halve_add<0xB1>(lb0, dz[2], dz[3]);
                         ured[su] = halve_add<0x4E>(lb1, w0, w1);
@@ -481,6 +535,14 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                     y += __shfl_xor(y, 16, 64);
                     if (dcown && (sd == 0 || has2)) dcj[32 * mm + dcslot] = y;
                 });
+                if constexpr (NQ > 0) {   // (wq sits in LDS times SC_A: undone here)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const float tot = (dsq[q] + __shfl_xor(dsq[q], 32, 64)) * (1.f / SC_A);
+                        if (oln < 32 && rb * 32 + oln < p.N && (sd == 0 || has2))
+                            p.des[((size_t)(b * p.N + jj[sd]) * NQ + q) * p.N + rb * 32 + oln] = tot;
+                    }
+                }
             });
         }
         B2_STAMP(6);
@@ -506,21 +568,40 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
         const int f = 32 * q + 16 * (k >> 3) + 8 * ((k >> 2) & 1) + 4 * (ln >> 5) + (k & 3);
         if (ii < p.N) out[(size_t)ii * H1 + f] = sum;
     }
+    if constexpr (NQ > 0) {   // daq [SC][B*N][NQ][96], the same reduction per scalar
+        static_for<0, NQ>([&](auto qc) {
+            MPG_CI(qq, qc);
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < T1; ++q)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) red[((w * T1 + q) * 16 + k) * 64 + lane] = dqacc[qq][q][k];
+            __syncthreads();
+            float* outq = p.daq + (((size_t)sc * p.B + b) * p.N * NQ + qq) * H1;
+            for (int e = tid; e < T1 * 16 * 64; e += 256) {
+                const int ln = e & 63, k = (e >> 6) & 15, q = e >> 10;
+                const float sum = red[e] + red[e + T1 * 1024] + red[e + 2 * T1 * 1024] + red[e + 3 * T1 * 1024];
+                const int ii = rb * 32 + (ln & 31);
+                const int f = 32 * q + 16 * (k >> 3) + 8 * ((k >> 2) & 1) + 4 * (ln >> 5) + (k & 3);
+                if (ii < p.N) outq[(size_t)ii * NQ * H1 + f] = sum;
+            }
+        });
+    }
 }
 
 // the NEEDW pair of one dropout mode (the three modes compile as separate translation units: edge_bwd2.hip, edge_bwd2_d1.hip,
 // edge_bwd2_d2.hip -- this template is slow to compile)
-template <int D>
+template <int D, int NQ = 0>
 int b2_launch(const MpgEdgeBwd* p, hipStream_t st) {
     const int RB = (p->N + 31) / 32;
     dim3 grid(p->B * RB * p->SC), block(256);
     const bool needw = p->stageZ2 != nullptr;
     if (needw) {
-        MPG_ENSURE_LDS((edge_bwd_kernel<D, true>), B2_LDS_BYTES);
-        hipLaunchKernelGGL((edge_bwd_kernel<D, true>), grid, block, B2_LDS_BYTES, st, *p);
+        MPG_ENSURE_LDS((edge_bwd_kernel<D, true, NQ>), B2_LDS_BYTES);
+        hipLaunchKernelGGL((edge_bwd_kernel<D, true, NQ>), grid, block, B2_LDS_BYTES, st, *p);
     } else {
-        MPG_ENSURE_LDS((edge_bwd_kernel<D, false>), B2_LDS_BYTES);
-        hipLaunchKernelGGL((edge_bwd_kernel<D, false>), grid, block, B2_LDS_BYTES, st, *p);
+        MPG_ENSURE_LDS((edge_bwd_kernel<D, false, NQ>), B2_LDS_BYTES);
+        hipLaunchKernelGGL((edge_bwd_kernel<D, false, NQ>), grid, block, B2_LDS_BYTES, st, *p);
     }
     return (int)hipGetLastError();
 }

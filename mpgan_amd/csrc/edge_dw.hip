@@ -171,9 +171,10 @@ MPG_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::
 
 // The per-workgroup loop of one consumer wave (its output tiles BEGIN..END of DW_TILES).  Instantiated per
 // role: a run-time branch around the MFMA section would make the accumulators merge at every join.
-template <int BEGIN, int END>
+template <int BEGIN, int END, int NQ>
 MPG_DEV void dw_consumer(const MpgEdgeDw& p, int blk0, int blk1, unsigned long long vbits) {
     const int lane = threadIdx.x & 63;
+    if constexpr (NQ > 0) lds_barrier();   // (the builders lay down the edge-scalar columns behind this one)
     f32x16 acc[END - BEGIN];
 #pragma unroll
     for (int t = 0; t < END - BEGIN; ++t)
@@ -224,9 +225,15 @@ MPG_DEV int dw_launch_exp(const MpgEdgeDw& p) {
     return __builtin_amdgcn_readfirstlane(e);
 }
 
-template <int DROP>
+// NQ: edge scalars (0 or MPG_EDGE_SCALARS): E1 = lrelu(a_i + c_j + sum_q es(i, j, q) wq[q]), as the forward adds it up
+template <int DROP, int NQ>
 MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk1, unsigned long long vbits) {
     const int bt = threadIdx.x - 256;     // builder thread 0..255
+    if constexpr (NQ > 0) {
+        float* lwq = reinterpret_cast<float*>(smem + DW_LDS_BYTES);
+        if (bt < NQ * H1) lwq[bt] = p.wq[bt];
+        lds_barrier();
+    }
     // receiver row r of the images and chunk group cg (chunks cg, cg + 8, cg + 16).  Four ADJACENT lanes hold the four chunk
     // groups of one receiver that make up a whole 32-feature tile: their two 16-byte reads of a dagg / a row cover one
     // contiguous 128-byte line, so a wave's load touches 16 rows x 1 line.  (With the receiver in the low lane bits every
@@ -258,6 +265,7 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
         uint32_t sw[3];                 // sign words of the Z3 chunks' lanes
         unsigned int nbw;               // this receiver's neighbour word holding the block's sender (k-NN graphs)
         float4 cv[2][2];                // c_j of the E1 chunks
+        float esq[NQ > 0 ? NQ : 1];     // edge scalars of (this receiver, the block's sender)
     };
     struct Big {
         f16x8 eh[3];                    // parked E2 pieces
@@ -339,10 +347,17 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
 #pragma unroll
         for (int n = 0; n < 3; ++n) P.sw[n] = __builtin_amdgcn_raw_buffer_load_b32(rS, voS, blk * (T3 * 32 * 4) + n * 256, 0);
     };
+    const __amdgpu_buffer_rsrc_t rES = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.es), 0, NQ > 0 ? p.B * p.N * NQ * p.N * 4 : 0, 0x00020000);
     auto load_c = [&](Small& P, int blk) {
         const int j = blk % p.N, b = (blk / p.N) / RB, so = (b * p.N + j) * ldac * 4;
 #pragma unroll
         for (int n = 0; n < 2; ++n) { P.cv[n][0] = ldb4(rC, voE1[n], so); P.cv[n][1] = ldb4(rC, voE1[n] + 32, so); }
+        if constexpr (NQ > 0) {
+            const int rb = (blk / p.N) % RB, ii = rb * 32 + r;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                P.esq[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rES, (ii < p.N ? ii : 0) * 4, ((b * p.N + j) * NQ + q) * p.N * 4, 0));
+        }
     };
     // parked pieces: chunk c of receiver r is element c * 32 + r of a block of 640 16-byte pieces
     auto load_e2 = [&](Big& P, int blk, int n) {
@@ -405,9 +420,24 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
             const float cc[8] = {S.cv[n][0].x, S.cv[n][0].y, S.cv[n][0].z, S.cv[n][0].w, S.cv[n][1].x, S.cv[n][1].y, S.cv[n][1].z, S.cv[n][1].w};
             float v[8];
             const uint32_t keep = dw_chunk_keep<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, q, f0, p.thr);
+            float wqv[NQ > 0 ? NQ : 1][8];
+            if constexpr (NQ > 0) {
+#pragma unroll
+                for (int qq = 0; qq < NQ; ++qq) {
+                    const float4* lw = reinterpret_cast<const float4*>(smem + DW_LDS_BYTES + (qq * H1 + 32 * q + f0) * 4);
+                    const float4 u0 = lw[0], u1 = lw[2];
+                    wqv[qq][0] = u0.x; wqv[qq][1] = u0.y; wqv[qq][2] = u0.z; wqv[qq][3] = u0.w;
+                    wqv[qq][4] = u1.x; wqv[qq][5] = u1.y; wqv[qq][6] = u1.z; wqv[qq][7] = u1.w;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                float x = lrelu(S.areg[n][k] + cc[k], p.alpha) * funit;
+                float z1 = S.areg[n][k] + cc[k];
+                if constexpr (NQ > 0) {
+#pragma unroll
+                    for (int qq = 0; qq < NQ; ++qq) z1 = fmaf(S.esq[qq], wqv[qq][k], z1);
+                }
+                float x = lrelu(z1, p.alpha) * funit;
                 if (DROP && !((keep >> k) & 1u)) x = 0.f;
                 v[k] = x;
             }
@@ -498,7 +528,7 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
     }
 }
 
-template <int DROP>
+template <int DROP, int NQ>
 __global__ __launch_bounds__(512, 1) void edge_dw_kernel(const MpgEdgeDw p, const int R) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -506,11 +536,11 @@ __global__ __launch_bounds__(512, 1) void edge_dw_kernel(const MpgEdgeDw p, cons
     const int nruns = p.B * RB * p.N / R;
     const int blk0 = 0, blk1 = R * ((nruns - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);   // slots of this workgroup
     const unsigned long long vbits = dw_valid_bits(p, R, blk0, blk1);
-    if (w == 0) dw_consumer<0, 12>(p, blk0, blk1, vbits);
-    else if (w == 1) dw_consumer<12, 23>(p, blk0, blk1, vbits);
-    else if (w == 2) dw_consumer<23, 34>(p, blk0, blk1, vbits);
-    else if (w == 3) dw_consumer<34, 45>(p, blk0, blk1, vbits);
-    else dw_builder<DROP>(p, R, smem, blk0, blk1, vbits);
+    if (w == 0) dw_consumer<0, 12, NQ>(p, blk0, blk1, vbits);
+    else if (w == 1) dw_consumer<12, 23, NQ>(p, blk0, blk1, vbits);
+    else if (w == 2) dw_consumer<23, 34, NQ>(p, blk0, blk1, vbits);
+    else if (w == 3) dw_consumer<34, 45, NQ>(p, blk0, blk1, vbits);
+    else dw_builder<DROP, NQ>(p, R, smem, blk0, blk1, vbits);
 }
 
 // out = scale * 2^-eG * sum over workgroup partials, feature indices mapped back from fragment order.
@@ -567,6 +597,25 @@ __global__ __launch_bounds__(256) void edge_dw_reduce(const float* __restrict__ 
 
 }  // namespace
 
+#ifdef MPG_DW_Q_UNIT   // edge_dw_q.hip: the variants with edge scalars, compiled beside this unit
+int mpg_edge_dw_q(const MpgEdgeDw* p, int R, hipStream_t st) {
+    dim3 grid(p->nwg), block(512);
+    const int dm = p->thr == 0 ? 0 : (p->thr == 128 ? 2 : 1);
+    constexpr int LDSQ = DW_LDS_BYTES + MPG_EDGE_SCALARS * H1 * 4;
+#define MPG_DW_Q(D)                                                                                               \
+    do {                                                                                                          \
+        MPG_ENSURE_LDS((edge_dw_kernel<D, MPG_EDGE_SCALARS>), LDSQ);                                              \
+        hipLaunchKernelGGL((edge_dw_kernel<D, MPG_EDGE_SCALARS>), grid, block, LDSQ, st, *p, R);                  \
+    } while (0)
+    if (dm == 0) MPG_DW_Q(0);
+    else if (dm == 1) MPG_DW_Q(1);
+    else MPG_DW_Q(2);
+#undef MPG_DW_Q
+    return (int)hipGetLastError();
+}
+#else
+int mpg_edge_dw_q(const MpgEdgeDw* p, int R, hipStream_t st);
+
 extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
     if (p->B <= 0 || p->N <= 0 || p->nwg <= 0) return -1;
     if (!p->f16) return -8;
@@ -582,13 +631,16 @@ extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
     const int dm = p->thr == 0 ? 0 : (p->thr == 128 ? 2 : 1);
 #define MPG_DW_ONE(D)                                                                                             \
     do {                                                                                                          \
-        MPG_ENSURE_LDS((edge_dw_kernel<D>), DW_LDS_BYTES);                                                        \
-        hipLaunchKernelGGL((edge_dw_kernel<D>), grid, block, DW_LDS_BYTES, st, *p, R);                            \
+        MPG_ENSURE_LDS((edge_dw_kernel<D, 0>), DW_LDS_BYTES);                                                     \
+        hipLaunchKernelGGL((edge_dw_kernel<D, 0>), grid, block, DW_LDS_BYTES, st, *p, R);                         \
     } while (0)
 #ifdef MPG_SINGLE_VARIANT  // tools/ubench/dw_bench.hip: one instantiation
     MPG_DW_ONE(MPG_SINGLE_VARIANT);
 #else
-    if (dm == 0) MPG_DW_ONE(0);
+    if (p->es != nullptr) {
+        if (p->wq == nullptr) return -3;
+        if (int e = mpg_edge_dw_q(p, R, st)) return e;
+    } else if (dm == 0) MPG_DW_ONE(0);
     else if (dm == 1) MPG_DW_ONE(1);
     else MPG_DW_ONE(2);
 #endif
@@ -599,3 +651,4 @@ extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
                        p->gexp, p->B * ((p->N + 31) / 32), p->dW3, p->dW2, p->db3, p->db2);
     return (int)hipGetLastError();
 }
+#endif

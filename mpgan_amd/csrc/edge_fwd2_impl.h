@@ -42,7 +42,8 @@ constexpr int F2_A_BYTES = T1 * 4 * 64 * 16;     //  12,288
 constexpr int F2_B_BYTES = (H2 + H3) * 4;        //   1,408
 constexpr int F2_C_BYTES = 4 * 2 * H1 * 4;       //   3,072
 constexpr int F2_LIST_MAX = 180;                 // senders per chunk (uint16 entries + count: 384 B)
-constexpr int F2_LDS_BYTES = F2_W_BYTES + F2_A_BYTES + F2_B_BYTES + F2_C_BYTES + 384;
+constexpr int F2_Q_OFF = F2_W_BYTES + F2_A_BYTES + F2_B_BYTES + F2_C_BYTES + 384;   // edge-scalar columns wq [3][96] (NQ > 0)
+constexpr int F2_LDS_BYTES = F2_Q_OFF + MPG_EDGE_SCALARS * H1 * 4;
 static_assert(F2_LDS_BYTES <= 163840, "LDS plan exceeds 160 KiB");
 static_assert(4 * T3 * 16 * 64 * 4 <= F2_W_BYTES, "the final reduction reuses the weight area");
 
@@ -60,7 +61,8 @@ MPG_DEV f32x16 f2_mma(const f16x8 a, const f16x8 b, const f32x16 c) { return __b
 
 // DROP: 0 off, 1 byte-threshold dropout, 2 one-bit (p = 1/2) dropout.  SIGN: also write the per-lane sign words of Z3 the
 // backward needs (a run-time test here would put a branch after every accumulator register).
-template <int DROP, bool SIGN>
+// NQ: edge scalars per edge (0, or MPG_EDGE_SCALARS: Z1 = a_i + c_j + sum_q es(i, j, q) wq[q])
+template <int DROP, bool SIGN, int NQ>
 __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
     typedef f16x8 V;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -93,6 +95,8 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
     //      the list of the chunk's senders (the unmasked ones: a zero-masked sender adds exactly 0)
     copy_to_lds(l3, g3, 2 * NF3 * 64, tid);
     for (int t = tid; t < H2 + H3; t += 256) lb2[t] = t < H2 ? p.b2[t] * SC_E2 : p.b3[t - H2] * SC_E3;
+    if constexpr (NQ > 0)
+        for (int t = tid; t < NQ * H1; t += 256) reinterpret_cast<float*>(smem + F2_Q_OFF)[t] = p.wq[t] * SC_A;
     for (int t = tid; t < T1 * 4 * 64; t += 256) {
         const int ln = t & 63, qsu = t >> 6, rr = ln & 31, hh = ln >> 5, ii = rb * 32 + rr;
         float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -120,6 +124,7 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
     const uint32_t lb3hi = lds_base(smem, lane16), lb3lo = lds_base(smem, NF3 * 1024 + lane16);
     const uint32_t lbla = lds_base(smem, F2_W_BYTES + lane16);
     const uint32_t lbc = lds_base(smem, F2_W_BYTES + F2_A_BYTES + F2_B_BYTES + w * (2 * H1 * 4) + 16 * h);
+    const uint32_t lbq = lds_base(smem, F2_Q_OFF + 16 * h);
 
     const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(p.sign3, 0, SIGN ? p.B * RB * p.N * (T3 * 32 * 4) : 0, 0x00020000);
     // E2 parked for the backward (mpg_edge_bwd takes phi'(Z2) from its signs, mpg_edge_dw multiplies with it): the hi halves
@@ -135,6 +140,7 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
     // the rows of c of a pair are requested one pair ahead (vector memory operations complete in order: requested at its own
     // top a pair's loads would queue behind the sign-word stores of the pair before)
     float pc0[2], pc1[2];
+    float pes[2][NQ > 0 ? NQ : 1];   // the lane's receiver's edge scalars with the pair's senders
     auto prefetch = [&](int pq2) {
 #pragma unroll
         for (int sd = 0; sd < 2; ++sd) {
@@ -142,6 +148,10 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
             const float* cj = p.c + (size_t)(b * p.N + jn) * ldac;
             pc0[sd] = cj[lane];
             pc1[sd] = cj[64 + (lane & 31)];
+            if constexpr (NQ > 0) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) pes[sd][q] = p.es[((size_t)(b * p.N + jn) * NQ + q) * p.N + (vi ? i : 0)];
+            }
         }
     };
     prefetch(w);
@@ -164,6 +174,13 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
             lcw[sd * H1 + lane] = pc0[sd] * SC_A;
             if (lane < H1 - 64) lcw[sd * H1 + 64 + lane] = pc1[sd] * SC_A;
         }
+        float esv[2][NQ > 0 ? NQ : 1];
+        if constexpr (NQ > 0) {
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) esv[sd][q] = pes[sd][q];
+        }
         prefetch(pq + 4);
 
         // ---- layer 2: Z2 = W2' E1 + b2, k-outer; e1 = drop(lrelu(a_i + c_j)) built one k-step ahead
@@ -175,6 +192,7 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
             float v1[2][8];
             PairSplit<V> ps1[2][4];
             f32x4 a4[2], c4[2][2];
+            f32x4 q4[NQ > 0 ? NQ : 1][2];
             auto load_w = [&](auto kc) {
                 MPG_CI(k, kc);
 #pragma unroll
@@ -191,6 +209,12 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
                 for (int sd = 0; sd < 2; ++sd)
 #pragma unroll
                     for (int uh = 0; uh < 2; ++uh) c4[sd][uh] = lds_frag<f32x4>(lbc, (sd * H1 + 16 * k + 8 * uh) * 4);
+                if constexpr (NQ > 0) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int uh = 0; uh < 2; ++uh) q4[q][uh] = lds_frag<f32x4>(lbq, (q * H1 + 16 * k + 8 * uh) * 4);
+                }
             };
             // build units of the e1 fragment of k-step k = (q, s): per sender 8 element units + 4 pairs x 2 halves = 16
             auto buildA = [&](auto kc, auto uc) {
@@ -199,7 +223,11 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
                 constexpr int q = k >> 1, s = k & 1;
                 if constexpr (u < 8) {
                     constexpr int uh = u >> 2, t = u & 3;  // element 4 uh + t  <->  feature 32q + 16s + 8uh + 4h + t
-                    const float cc = c4[sd][uh][t] + a4[uh][t];
+                    float cc = c4[sd][uh][t] + a4[uh][t];
+                    if constexpr (NQ > 0) {
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) cc = fmaf(esv[sd][q], q4[q][uh][t], cc);
+                    }
                     const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow[sd], q, 4 * s + 2 * uh + h, h);
                     v1[sd][u] = drop_apply<DROP>(lrelu(cc, p.alpha), wd, 16 * s + 8 * uh + t, t, p.thr);
                 } else {
@@ -376,18 +404,18 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
     }
 }
 
-// the SIGN pair of one dropout mode (the three modes compile as separate translation units: edge.hip, edge_fwd_d1.hip,
-// edge_fwd_d2.hip)
-template <int D>
+// the SIGN pair of one dropout mode and edge-scalar count (the combinations compile as separate translation units: edge.hip,
+// edge_fwd_d1.hip, edge_fwd_d2.hip; edge_fwd_q{0,1,2}.hip with the edge scalars)
+template <int D, int NQ = 0>
 int f2_launch(const MpgEdgeFwd* p, hipStream_t st) {
     const int RB = (p->N + 31) / 32;
     dim3 grid(p->B * RB * p->SC), block(256);
     if (p->sign3 != nullptr) {
-        MPG_ENSURE_LDS((edge_fwd_kernel<D, true>), F2_LDS_BYTES);
-        hipLaunchKernelGGL((edge_fwd_kernel<D, true>), grid, block, F2_LDS_BYTES, st, *p);
+        MPG_ENSURE_LDS((edge_fwd_kernel<D, true, NQ>), F2_LDS_BYTES);
+        hipLaunchKernelGGL((edge_fwd_kernel<D, true, NQ>), grid, block, F2_LDS_BYTES, st, *p);
     } else {
-        MPG_ENSURE_LDS((edge_fwd_kernel<D, false>), F2_LDS_BYTES);
-        hipLaunchKernelGGL((edge_fwd_kernel<D, false>), grid, block, F2_LDS_BYTES, st, *p);
+        MPG_ENSURE_LDS((edge_fwd_kernel<D, false, NQ>), F2_LDS_BYTES);
+        hipLaunchKernelGGL((edge_fwd_kernel<D, false, NQ>), grid, block, F2_LDS_BYTES, st, *p);
     }
     return (int)hipGetLastError();
 }

@@ -187,10 +187,22 @@ class MPLayer(nn.Module):
                 num_ef += 1
         self.num_ef = num_ef
         extra = self.clabels + int(self.mask_fne_np)
-        # (pos_diffs without any edge feature would still change which coordinates the k-NN distance is measured on,
-        # mpgan/model.py:340-345; the fused route measures it on all node features)
+        # What the fused kernels take besides [x_i ; x_j]: up to ops.EDGE_SCALARS scalars per edge, each times its own column
+        # of fe.net.0.weight -- the distance column (delta_r / all_ef) and the conditioning columns, which the reference
+        # tiles over ROWS and so are per-edge gathers (_edge_scalars) -- and coordinate differences, which are linear in
+        # x_i, x_j and fold into the a | c projection (_folded_w1).  Not fused: differences over ALL features with their own
+        # columns (all_ef + delta_coords: the reference sizes fe for 2-3 of them and fails itself), edge features on the
+        # k-NN graph (its distance column is measured to the mask-scaled senders, mpgan/model.py:333-345), more scalars
+        # than EDGE_SCALARS, other layer widths.
+        nc = 3 if coords == "cartesian" else 2
+        # the columns MPLayer.forward appends (:303-308): [diffs, dists] | [dists] | [diffs], diffs over nc coordinates or all features
+        has_diffs = self.pos_diffs and self.delta_coords and (self.delta_r or not self.all_ef)
+        self._dist_col = self.pos_diffs and (self.delta_r or self.all_ef)
+        self._diff_cols = nc if (has_diffs and not self.all_ef) else 0
+        self.n_es = int(self._dist_col) + extra
+        consistent = num_ef == self._diff_cols + int(self._dist_col) and not (has_diffs and self.all_ef)
         self.fused = (list(self.fe_layers) == [ops.H1, ops.H2, ops.H3] and len(self.fn_layers) == 2
-                      and num_ef == 0 and extra == 0 and not self.pos_diffs
+                      and consistent and self.n_es <= ops.EDGE_SCALARS and (self.fully_connected or not self.pos_diffs)
                       and not (linear_args.get("batch_norm") or linear_args.get("spectral_norm")))
         self.fe = LinearNet(self.fe_layers, input_size=2 * input_node_size + num_ef + extra, final_linear=False, **linear_args)
         self.fn = LinearNet(self.fn_layers, input_size=self.fe_layers[-1] + input_node_size + extra,
@@ -266,11 +278,53 @@ class MPLayer(nn.Module):
                 raise ValueError(f"num_knn = {self.num_knn} neighbours (self_loops = {self.self_loops}) out of {x.shape[1]} nodes")
             with torch.no_grad():
                 nbr = ops.knn_sets(x, mask if use_mask else None, self.num_knn, self.self_loops)
+        es, xfn = self._edge_scalars(x, labels, num_jet_particles)
+        W1, packed = fe[0].weight, None
+        if self._diff_cols:
+            W1 = self._folded_w1(W1)   # (not a parameter: its images are packed for this call)
+        else:
+            packed = self._packed()
         return ops.FusedMPLayerFn.apply(
             x, mask if use_mask else None,
-            fe[0].weight, fe[0].bias, fe[1].weight, fe[1].bias, fe[2].weight, fe[2].bias,
+            W1, fe[0].bias, fe[1].weight, fe[1].bias, fe[2].weight, fe[2].bias,
             fn[0].weight, fn[0].bias, fn[1].weight, fn[1].bias, fn[2].weight, fn[2].bias,
-            self.sum, self.fe.leaky_relu_alpha, self.fe.dropout_p, self.training, self._packed(), nbr, self.num_knn)
+            self.sum, self.fe.leaky_relu_alpha, self.fe.dropout_p, self.training, packed, nbr, self.num_knn,
+            es, self.n_es, xfn)
+
+    def _folded_w1(self, W1: Tensor) -> Tensor:
+        """fe.net.0.weight with the coordinate-difference columns folded into the node columns: the reference appends
+        x_j[:nc] - x_i[:nc] to [x_i ; x_j] (mpgan/model.py:297-313), and W_d (x_j - x_i) is -W_d x_i + W_d x_j.  Built with
+        torch operations, so the columns' gradients come out of autograd."""
+        F, nc = self.input_node_size, self._diff_cols
+        Wd = torch.nn.functional.pad(W1[:, 2 * F:2 * F + nc], (0, F - nc))
+        return torch.cat((W1[:, :F] - Wd, W1[:, F:2 * F] + Wd, W1[:, 2 * F + nc:]), dim=1)
+
+    def _edge_scalars(self, x: Tensor, labels: Tensor, num_jet_particles: Tensor):
+        """``(es [B, N senders, EDGE_SCALARS, N receivers] or None, xfn [B, N, F + E] or None)``: the scalars the fused edge
+        kernels multiply with their own columns of fe.net.0.weight -- the distance ||x_j - x_i + 1e-12|| (mpgan/model.py:
+        299-302; 4 bytes per edge instead of the edge matrix) and the conditioning columns AS THE REFERENCE TILES THEM:
+        ``t.repeat(rows / B, 1)`` gives ROW r the entry of jet r mod B (:249, :253), a per-edge gather for the edge network
+        and a per-node one for the node network (:272, :276)."""
+        if self.n_es == 0:
+            return None, None
+        B, N, F = x.shape
+        cols = []
+        if self._dist_col:
+            d = x.unsqueeze(1) - x.unsqueeze(2)                 # [B, i, j, F] = x_j - x_i
+            if not self.all_ef:
+                d = d[..., :(3 if self.coords == "cartesian" else 2)]
+            cols.append(torch.norm(d + 1e-12, dim=3).transpose(1, 2))   # [B, j, i]
+        xfn = None
+        if self.clabels or self.mask_fne_np:
+            erow = (torch.arange(B * N * N, device=x.device) % B).reshape(B, N, N).transpose(1, 2)   # [B, j, i]: jet of edge row (b, i, j)
+            nrow = torch.arange(B * N, device=x.device) % B
+            extra = []
+            for t in ([labels[:, q] for q in range(self.clabels)] + ([num_jet_particles[:, 0]] if self.mask_fne_np else [])):
+                cols.append(t.to(x.dtype)[erow])
+                extra.append(t.to(x.dtype)[nrow].reshape(B, N, 1))
+            xfn = torch.cat([x] + extra, dim=2)
+        cols += [torch.zeros_like(cols[0])] * (ops.EDGE_SCALARS - len(cols))
+        return torch.stack(cols, dim=2), xfn
 
     def _packed(self) -> "ops.PackedMPLayer":
         """Persistent weight images of this layer for the current mode (dropout scale) -- rebuilt when a

@@ -368,7 +368,7 @@ class PackedMPLayer:
         self.plist = plist  # the twelve Parameters (W1, b1, ..., V3, c3) when built by MPLayer: .grad targets
         self.params, self.F, self.out, self.dscale, self.f16 = params, F, out, float(dscale), bool(f16)
         dev = W1.device
-        KN = H3 + F
+        KN = V1.shape[1]   # H3 + F (+ the conditioning columns appended to the node network's input)
         # name: (W, packed rows, packed cols, transpose, scale, f16, row_split, split_cols)
         spec = {
             "W2": (W2, H2, H1, 0, dscale * SC_W2, f16, 0, 0), "W3": (W3, H3, H2, 0, dscale * SC_W3, f16, 0, 0),
@@ -436,10 +436,12 @@ def chain(M, layers, *, A, lda, K1, A2=None, lda2=0, a_slabs=1, a_slab_stride=0,
     check(_lib.lib().mpg_chain(C.byref(c), _stream()), "mpg_chain")
 
 
+EDGE_SCALARS = 2          # MPG_EDGE_SCALARS of include/mpgan_amd.h
+MAX_CHUNK_SENDERS_ES = 116   # ... with edge scalars (their columns take part of the list's LDS)
 MAX_CHUNK_SENDERS = 180   # mpg_edge_bwd keeps the list of a chunk's unmasked senders in LDS (csrc/edge_bwd2.hip)
 
 
-def _sender_chunks(B, N):
+def _sender_chunks(B, N, max_chunk=None):
     """Sender chunks per (jet, receiver block).  A workgroup costs a 150 KiB LDS fill (about five senders' worth of
     time) plus its chunk's senders, and the 256 CUs take the workgroups of a launch in rounds: the chunk count that
     minimises  rounds * (fill + senders per chunk), with chunks of at least 8 and at most MAX_CHUNK_SENDERS senders
@@ -447,19 +449,20 @@ def _sender_chunks(B, N):
     doubling up to 320 workgroups would run two rounds at 62 % occupancy)."""
     RB = (N + 31) // 32
     wg = B * RB
+    max_chunk = max_chunk or MAX_CHUNK_SENDERS
     forced = os.environ.get("MPG_FORCE_SC")   # experiments only (DESIGN.md section 7: load balance of one-round launches)
     if forced:
-        return max(int(forced), -(-N // MAX_CHUNK_SENDERS))
+        return max(int(forced), -(-N // max_chunk))
     best, best_cost = 1, None
     for sc in range(1, max(1, N // 8) + 1):
         per = -(-N // sc)
-        if per > MAX_CHUNK_SENDERS:
+        if per > max_chunk:
             continue
         cost = -(-wg * sc // 256) * (5 + per)
         if best_cost is None or cost < best_cost:
             best, best_cost = sc, cost
     if best_cost is None:   # (N > 8 * MAX_CHUNK_SENDERS cannot happen below the kernels' own limits; be safe)
-        best = -(-N // MAX_CHUNK_SENDERS)
+        best = -(-N // max_chunk)
     return best
 
 
@@ -477,9 +480,14 @@ class FusedMPLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mask, W1, b1, W2, b2, W3, b3, V1, c1, V2, c2, V3, c3, sum_agg, alpha, p_drop, training,
-                packed=None, nbr=None, num_knn=0):
+                packed=None, nbr=None, num_knn=0, es=None, nq=0, xfn=None):
         """``nbr`` (from ``knn_sets``) restricts receiver i's senders to its ``num_knn`` nearest neighbours
-        (``fully_connected=False``, mpgan/model.py:319-381); the mean then divides by ``num_knn`` (:267)."""
+        (``fully_connected=False``, mpgan/model.py:319-381); the mean then divides by ``num_knn`` (:267).
+
+        ``es`` [B, N senders, EDGE_SCALARS, N receivers] with ``nq`` live scalars: the edge features / row-tiled conditioning
+        columns of the reference (mpgan/model.py:247-253, :297-313), one scalar per edge each; they multiply the columns
+        ``W1[:, 2F : 2F + nq]`` (``Z1 = a_i + c_j + sum_q es_q w_q``) and get a gradient.  ``xfn`` [B, N, F + E]: the node
+        network's view of the nodes when conditioning columns are appended to it (:270-276); ``V1`` then has E more columns."""
         _chk(x, "x")
         B, N, F = x.shape
         V = B * N
@@ -504,7 +512,7 @@ class FusedMPLayerFn(torch.autograd.Function):
         ac = torch.empty((V, 2 * H1), device=dev, dtype=torch.float32)
         chain(V, [dict(img=pk.ptr("W1S"), K=F, N=2 * H1, bias=b1, nbias=H1, out=ac, wscale=SC_WN)], A=x2, lda=x2.stride(0), K1=F,
               alpha=alpha, f16=f16, ascale=SC_ACT)
-        SC = _sender_chunks(B, N)
+        SC = _sender_chunks(B, N, MAX_CHUNK_SENDERS_ES if es is not None else None)
         aggp = torch.empty((SC, V, H3), device=dev, dtype=torch.float32)
         e = MpgEdgeFwd()
         e.a, e.c, e.ld_ac, e.mask = _p(ac), _p(ac, H1), 2 * H1, _p(m1)
@@ -517,6 +525,13 @@ class FusedMPLayerFn(torch.autograd.Function):
         e.seed, e.tag_base, e.thr, e.dscale = _p(seed_t), tag, thr, dscale
         e.skip_masked = int(OPTIONS["skip_masked"])
         e.f16 = int(f16)
+        wq = None
+        if es is not None:
+            assert 0 < nq <= EDGE_SCALARS and tuple(es.shape) == (B, N, EDGE_SCALARS, N) and W1.shape[1] == 2 * F + nq
+            es = es.detach().float().contiguous()
+            wq = torch.zeros((EDGE_SCALARS, H1), device=dev, dtype=torch.float32)
+            wq[:nq] = W1.detach()[:, 2 * F:2 * F + nq].t()
+            e.es, e.wq = _p(es), _p(wq)
         RB = (N + 31) // 32
         need_grad = any(ctx.needs_input_grad)
         sign3 = torch.empty((B * RB * N * 192,), device=dev, dtype=torch.int32) if need_grad else None
@@ -529,26 +544,32 @@ class FusedMPLayerFn(torch.autograd.Function):
         agg = aggp[0] if SC == 1 else aggp.sum(0)
 
         # node network fn: three chained layers, one launch
+        xf2 = x2
+        if xfn is not None:
+            xf2 = xfn.detach().reshape(V, -1)
+            if xf2.stride(1) != 1:
+                xf2 = xf2.contiguous()
+        assert V1.shape[1] == H3 + xf2.shape[1]
         n1, n2 = V1.shape[0], V2.shape[0]
         h1 = torch.empty((V, n1), device=dev, dtype=torch.float32)
         h2 = torch.empty((V, n2), device=dev, dtype=torch.float32)
         y = torch.empty((V, out_f), device=dev, dtype=torch.float32)
-        chain(V, [dict(img=pk.ptr("V1"), K=H3 + F, N=n1, bias=c1, act=True, drop=dr(TAG_N0), out=h1, wscale=SC_WN),
+        chain(V, [dict(img=pk.ptr("V1"), K=V1.shape[1], N=n1, bias=c1, act=True, drop=dr(TAG_N0), out=h1, wscale=SC_WN),
                   dict(img=pk.ptr("V2"), K=n1, N=n2, bias=c2, act=True, drop=dr(TAG_N1), out=h2, wscale=SC_WN),
                   dict(img=pk.ptr("V3"), K=n2, N=out_f, bias=c3, act=False, drop=dr(TAG_N2), out=y, wscale=SC_WN)],
-              A=agg, lda=H3, K1=H3, A2=x2, lda2=x2.stride(0), alpha=alpha, seed_t=seed_t, f16=f16, ascale=SC_ACT)
+              A=agg, lda=H3, K1=H3, A2=xf2, lda2=xf2.stride(0), alpha=alpha, seed_t=seed_t, f16=f16, ascale=SC_ACT)
         ctx.packed = pk
 
-        ctx.save_for_backward(x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3, nbr, stE2)
-        ctx.cfg = (B, N, F, agg_scale, alpha, thr, dscale, tag, SC, f16)
+        ctx.save_for_backward(x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3, nbr, stE2, es, wq, xf2)
+        ctx.cfg = (B, N, F, agg_scale, alpha, thr, dscale, tag, SC, f16, nq)
         return y.reshape(B, N, V3.shape[0])
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3, nbr, stE2 = ctx.saved_tensors
+        x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3, nbr, stE2, es, wq, xf2 = ctx.saved_tensors
         pk = ctx.packed
-        B, N, F, agg_scale, alpha, thr, dscale, tag, SC, f16 = ctx.cfg
+        B, N, F, agg_scale, alpha, thr, dscale, tag, SC, f16, nq = ctx.cfg
         nbr_p = None if nbr is None else C.c_void_p(nbr.data_ptr())
         V = B * N
         dev = x2.device
@@ -566,10 +587,10 @@ class FusedMPLayerFn(torch.autograd.Function):
         dz3 = torch.empty_like(gy2) if thr else gy2
         dz2 = torch.empty((V, n2), device=dev, dtype=torch.float32)
         dz1 = torch.empty((V, n1), device=dev, dtype=torch.float32)
-        dh0 = torch.empty((V, H3 + F), device=dev, dtype=torch.float32)  # [dagg | dx(node path)]
+        dh0 = torch.empty((V, V1.shape[1]), device=dev, dtype=torch.float32)  # [dagg | dx(node path) | (conditioning columns)]
         chain(V, [dict(img=pk.ptr("V3T"), K=out_f, N=n2, gate=(h2, True, tag + TAG_N1, thr, dscale), out=dz2),
                   dict(img=pk.ptr("V2T"), K=n2, N=n1, gate=(h1, True, tag + TAG_N0, thr, dscale), out=dz1),
-                  dict(img=pk.ptr("V1T"), K=n1, N=H3 + F, out=dh0)],
+                  dict(img=pk.ptr("V1T"), K=n1, N=V1.shape[1], out=dh0)],
               A=gy2, lda=gy2.stride(0), K1=out_f, in_gate=(tag + TAG_N2, thr, dscale), in_out=dz3 if thr else None,
               alpha=alpha, seed_t=seed_t, f16=False)
         dV1 = dV2 = dV3 = dc1 = dc2 = dc3 = None
@@ -586,7 +607,7 @@ class FusedMPLayerFn(torch.autograd.Function):
             wb.add(dz3, h2, out=dV3, bias_out=dc3, accumulate=direct)
             wb.add(dz2, h1, out=dV2, bias_out=dc2, accumulate=direct)
             wb.add(dz1, agg, out=dV1, out_col0=0, bias_out=dc1, accumulate=direct)
-            wb.add(dz1, x2, out=dV1, out_col0=H3, accumulate=direct)
+            wb.add(dz1, xf2, out=dV1, out_col0=H3, accumulate=direct)
 
         # ---- edge network backward: data path, then (if wanted) the weight-gradient pass
         RB = (N + 31) // 32
@@ -612,6 +633,11 @@ class FusedMPLayerFn(torch.autograd.Function):
         e.alpha, e.agg_scale, e.nbr = alpha, agg_scale, nbr_p
         e.seed, e.tag_base, e.thr, e.dscale = _p(seed_t), tag, thr, dscale
         e.f16 = int(f16)
+        des = daq = None
+        if es is not None:
+            des = torch.zeros_like(es)   # (zero-masked senders' rows are not written)
+            daq = torch.empty((SC, V, EDGE_SCALARS, H1), device=dev, dtype=torch.float32)
+            e.es, e.wq, e.des, e.daq = _p(es), _p(wq), _p(des), _p(daq)
         check(_lib.lib().mpg_edge_bwd(C.byref(e), _stream()), "mpg_edge_bwd")
         da = dap[0] if SC == 1 else dap.sum(0)
         dc = dcp[0] if RB == 1 else dcp.sum(0)
@@ -636,6 +662,8 @@ class FusedMPLayerFn(torch.autograd.Function):
             d.alpha, d.agg_scale, d.nbr = alpha, agg_scale, nbr_p
             d.seed, d.tag_base, d.thr, d.dscale = _p(seed_t), tag, thr, dscale
             d.f16 = int(f16)
+            if es is not None:
+                d.es, d.wq = _p(es), _p(wq)
             check(_lib.lib().mpg_edge_dw(C.byref(d), _stream()), "mpg_edge_dw")
             del stZ2
             # layer 1 (fe.net.0): a = W1[:, :F] x + b1, c = W1[:, F:] x
@@ -647,17 +675,23 @@ class FusedMPLayerFn(torch.autograd.Function):
             wb.add(da, x2, out=dW1, out_col0=0, bias_out=db1, accumulate=direct)
             wb.add(dc, x2, out=dW1, out_col0=F, accumulate=direct)
             wb.flush()
+            if es is not None:   # the columns of the edge scalars: sum over receivers of daq
+                dWq = daq.sum((0, 1))[:nq].t()
+                if direct:
+                    dW1[:, 2 * F:2 * F + nq] += dWq
+                else:
+                    dW1[:, 2 * F:2 * F + nq] = dWq
             if direct:  # already in .grad: autograd gets nothing to accumulate
                 dW1 = db1 = dW2 = db2 = dW3 = db3 = dV1 = dc1 = dV2 = dc2 = dV3 = dc3 = None
         dx = None
         if need_x:
             # dx = dx(node path) + [da | dc] [W1a ; W1c]: one chained layer over the stacked transposed view
             dx = torch.empty((V, F), device=dev, dtype=torch.float32)
-            chain(V, [dict(img=pk.ptr("W1ST"), K=2 * H1, N=F, resid=dh0[:, H3:], out=dx)],
+            chain(V, [dict(img=pk.ptr("W1ST"), K=2 * H1, N=F, resid=dh0[:, H3:H3 + F], out=dx)],
                   A=dap, lda=H1, K1=H1, a_slabs=SC, a_slab_stride=V * H1, A2=dc, lda2=dc.stride(0), alpha=alpha, f16=False)
             dx = dx.reshape(B, N, F)
         return (dx, None, dW1, db1, dW2, db2, dW3, db3, dV1, dc1, dV2, dc2, dV3, dc3,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, des, None, None)
 
 
 def _grad_target(t):

@@ -104,11 +104,15 @@ def test_unsupported_options_raise():
     # the default configuration (and its k-NN form) is on the fused kernels ...
     assert MPLayer(32, [96, 160, 192], [256, 256], 32).fused
     assert MPLayer(32, [96, 160, 192], [256, 256], 32, fully_connected=False, num_knn=10).fused
-    # ... every other option builds the reference's layer shapes and takes the un-fused route
-    for kw, fe_in, fn_in in ((dict(pos_diffs=True), 65, 224), (dict(pos_diffs=True, all_ef=False, delta_coords=True), 67, 224),
-                             (dict(clabels=1, mask_fne_np=True), 66, 226)):
+    # ... and so are the edge-feature / conditioning options that are a scalar per edge each (at most ops.EDGE_SCALARS) or
+    # fold into the node terms; every other combination builds the reference's layer shapes and takes the un-fused route
+    for kw, fe_in, fn_in, fused in ((dict(pos_diffs=True), 65, 224, True),
+                                    (dict(pos_diffs=True, all_ef=False, delta_coords=True), 67, 224, True),
+                                    (dict(clabels=1, mask_fne_np=True), 66, 226, True),
+                                    (dict(pos_diffs=True, clabels=1, mask_fne_np=True), 67, 226, False),        # three scalars
+                                    (dict(pos_diffs=True, fully_connected=False, num_knn=5), 65, 224, False)):  # k-NN distances
         m = MPLayer(32, [96, 160, 192], [256, 256], 32, **kw)
-        assert not m.fused and m.fe.net[0].in_features == fe_in and m.fn.net[0].in_features == fn_in, kw
+        assert m.fused == fused and m.fe.net[0].in_features == fe_in and m.fn.net[0].in_features == fn_in, kw
     m = MPLayer(16, [64, 48], [40], 8)
     assert not m.fused and [l.out_features for l in m.fe.net] == [64, 48] and [l.out_features for l in m.fn.net] == [40, 8]
     m = MAB(64, 4, layer_norm=True)            # LayerNorm is on the HIP path (ops.LayerNormFn)

@@ -518,10 +518,17 @@ def _option_cases():
     return OPTION_CASES
 
 
+FUSED_OPTION_CASES = ("ef", "efc", "cl")   # distance column; folded coordinate differences + distance; two row-tiled conditioning columns
+
+
+@pytest.mark.parametrize("route", ["fused", "edges"])
 @pytest.mark.parametrize("case", _option_cases(), ids=lambda c: c[0])
-def test_mplayer_options_vs_reference_golden(case):
-    """The un-fused route (edge features, conditioning columns tiled as the reference tiles them, k-NN with distances, other
-    layer widths): outputs and gradients against the reference's own, captured in tests/golden/mplayer_opt_*."""
+def test_mplayer_options_vs_reference_golden(case, route):
+    """MPLayer's non-default options -- edge features, conditioning columns tiled as the reference tiles them, k-NN with
+    distances, other layer widths -- against the reference's own outputs and gradients (tests/golden/mplayer_opt_*), on both
+    routes: the fused kernels (one scalar per edge and option, each with its column of fe.net.0.weight; coordinate
+    differences folded into the node terms) where they cover the case, and the un-fused route (edge matrix built as the
+    reference builds it), which every case can take."""
     from conftest import option_case_shapes
     from oracle import train_ref as T
     from mpgan_amd.mpgan import MPLayer
@@ -529,7 +536,11 @@ def test_mplayer_options_vs_reference_golden(case):
     g = load_golden(f"mplayer_opt_{name}_f64.npz")
     ctor = {k: v for k, v in kw.items() if k not in ("fe", "fn", "use_mask")}
     layer = MPLayer(F, kw.get("fe", [96, 160, 192]), kw.get("fn", [256, 256]), out, **ctor).cuda()
-    assert not layer.fused
+    assert layer.fused == (name in FUSED_OPTION_CASES)
+    if route == "fused" and not layer.fused:
+        pytest.skip("outside the fused kernels (k-NN distances / other widths)")
+    if route == "edges":
+        layer.fused = False
     layer.load_state_dict(T.init_state_dict(option_case_shapes(F, out, kw), seed=int(g["seed"]), dtype=torch.float32))
     x = torch.from_numpy(g["x"]).float().cuda().requires_grad_(True)
     mask = torch.from_numpy(g["mask"]).float().cuda() if "mask" in g else None
@@ -539,3 +550,63 @@ def test_mplayer_options_vs_reference_golden(case):
     assert rel_err(x.grad.cpu().numpy(), g["dx"]) < TOL, name
     for k, p in layer.named_parameters():
         assert rel_err(summarize(k, p.grad), g["grad__" + k]) < TOL, (name, k)
+
+
+@pytest.mark.parametrize("alpha", [1.0, 0.2])
+@pytest.mark.parametrize("p_drop,use_mask,N", [(0.0, True, 30), (0.5, True, 30), (0.3, False, 30), (0.5, True, 40)])
+def test_edge_scalars_separable_case_equals_node_features(p_drop, use_mask, N, alpha):
+    """The edge-scalar kernels in every dropout mode, against the plain kernels: an edge scalar of the form u_i + v_j times a
+    column w is  a_i + c_j + (u_i + v_j) w = (a_i + u_i w) + (c_j + v_j w), i.e. the default layer on nodes with two more
+    features [x, u, v] and fe.net.0.weight = [W1a | w | 0 | W1c | 0 | w] (zero columns for them in fn.net.0).  Same seed and
+    tag, so both runs draw the same dropout masks.  Outputs, dx, d(es) (against du_i = sum_j, dv_j = sum_i of it) and every
+    parameter gradient must agree: forward at TIGHT, gradients at the fused backward's bar (both runs round differently).
+    Slope 1 is the strict form; at slope 0.2 the two runs add Z1 up in different orders, so a pre-activation within 1e-7 of
+    zero may fall on either side (measured: one of 700k elements moved the fe.net.1 gradients by 3e-3 of their maximum) --
+    there at most 1 % of a tensor's elements may differ by more than the bar, none by more than 2e-2."""
+    import itertools
+    from mpgan_amd import ops
+    rs = np.random.RandomState(17 + N)
+    dev = _dev()
+    B, F, out = 3, 30, 32
+    t = lambda *s, sc=1.0: torch.from_numpy(rs.normal(size=s) * sc).float().to(dev)
+    x, u, v = t(B, N, F, sc=0.5), t(B, N, sc=0.5), t(B, N, sc=0.5)
+    mask = None
+    if use_mask:
+        mask = (torch.from_numpy(rs.uniform(size=(B, N, 1))) < 0.8).float().to(dev)
+        mask[:, 0] = 1
+    W1a, W1c, w = t(96, F, sc=0.2), t(96, F, sc=0.2), t(96, 1, sc=0.2)
+    b1, W2, b2, W3, b3 = t(96, sc=0.1), t(160, 96, sc=0.1), t(160, sc=0.1), t(192, 160, sc=0.1), t(192, sc=0.1)
+    V1a, V1x, c1, V2, c2, V3, c3 = t(256, 192, sc=0.1), t(256, F, sc=0.1), t(256, sc=0.1), t(256, 256, sc=0.1), t(256, sc=0.1), t(out, 256, sc=0.1), t(out, sc=0.1)
+    up = t(B, N, out)
+    z1, z2 = torch.zeros(96, 1, device=dev), torch.zeros(256, 2, device=dev)
+
+    def run(with_es):
+        st = ops.dev_state(dev)
+        st.tags = itertools.count(77)      # the same dropout sites for both runs
+        ops.set_seed(1234, dev)
+        leaves = [q.clone().requires_grad_(True) for q in (x, u, v, W1a, W1c, w, b1, W2, b2, W3, b3, V1a, V1x, c1, V2, c2, V3, c3)]
+        X, U, Vv, A, Cc, Ww, B1, w2, bb2, w3, bb3, v1a, v1x, cc1, v2, cc2, v3, cc3 = leaves
+        if with_es:
+            es = torch.stack((U.unsqueeze(1) + Vv.unsqueeze(2), torch.zeros(B, N, N, device=dev)), dim=2)   # [b, j, q, i] = u_i + v_j
+            es.retain_grad()
+            y = ops.FusedMPLayerFn.apply(X, mask, torch.cat((A, Cc, Ww), 1), B1, w2, bb2, w3, bb3, torch.cat((v1a, v1x), 1), cc1, v2, cc2,
+                                         v3, cc3, True, alpha, p_drop, True, None, None, 0, es, 1, None)
+        else:
+            X2 = torch.cat((X, U.unsqueeze(2), Vv.unsqueeze(2)), 2)
+            W1 = torch.cat((A, Ww, z1, Cc, z1, Ww), 1)
+            y = ops.FusedMPLayerFn.apply(X2, mask, W1, B1, w2, bb2, w3, bb3, torch.cat((v1a, v1x, z2), 1), cc1, v2, cc2, v3, cc3,
+                                         True, alpha, p_drop, True, None, None, 0)
+        (y * up).sum().backward()
+        return y.detach(), [q.grad for q in leaves]
+
+    y_es, g_es = run(True)
+    y_nf, g_nf = run(False)
+    assert rel_err(y_es.cpu().numpy(), y_nf.cpu().numpy()) < TIGHT
+    names = "x u v W1a W1c w b1 W2 b2 W3 b3 V1a V1x c1 V2 c2 V3 c3".split()
+    errs = {n: rel_err(a.cpu().numpy(), b.cpu().numpy()) for n, a, b in zip(names, g_es, g_nf)}
+    print("errs", errs)
+    if alpha == 1.0:
+        assert max(errs.values()) < TOL, errs
+    else:
+        off = {n: float(((a - b).abs() > TOL * b.abs().max()).float().mean()) for n, a, b in zip(names, g_es, g_nf)}
+        assert max(errs.values()) < 2e-2 and max(off.values()) < 0.01, (errs, off)
