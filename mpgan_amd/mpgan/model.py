@@ -190,10 +190,10 @@ class MPLayer(nn.Module):
         # What the fused kernels take besides [x_i ; x_j]: up to ops.EDGE_SCALARS scalars per edge, each times its own column
         # of fe.net.0.weight -- the distance column (delta_r / all_ef) and the conditioning columns, which the reference
         # tiles over ROWS and so are per-edge gathers (_edge_scalars) -- and coordinate differences, which are linear in
-        # x_i, x_j and fold into the a | c projection (_folded_w1).  Not fused: differences over ALL features with their own
-        # columns (all_ef + delta_coords: the reference sizes fe for 2-3 of them and fails itself), edge features on the
-        # k-NN graph (its distance column is measured to the mask-scaled senders, mpgan/model.py:333-345), more scalars
-        # than EDGE_SCALARS, other layer widths.
+        # x_i, x_j and fold into the a | c projection (_folded_w1).  On the k-NN graph the one edge feature is the distance the
+        # neighbours were ranked by (to the mask-scaled senders, mpgan/model.py:333-345, :372): the same scalar.  Not fused:
+        # differences over ALL features with their own columns (all_ef + delta_coords: the reference sizes fe for 2-3 of
+        # them and fails itself), more scalars than EDGE_SCALARS, other layer widths.
         nc = 3 if coords == "cartesian" else 2
         # the columns MPLayer.forward appends (:303-308): [diffs, dists] | [dists] | [diffs], diffs over nc coordinates or all features
         has_diffs = self.pos_diffs and self.delta_coords and (self.delta_r or not self.all_ef)
@@ -202,7 +202,8 @@ class MPLayer(nn.Module):
         self.n_es = int(self._dist_col) + extra
         consistent = num_ef == self._diff_cols + int(self._dist_col) and not (has_diffs and self.all_ef)
         self.fused = (list(self.fe_layers) == [ops.H1, ops.H2, ops.H3] and len(self.fn_layers) == 2
-                      and consistent and self.n_es <= ops.EDGE_SCALARS and (self.fully_connected or not self.pos_diffs)
+                      and consistent and self.n_es <= ops.EDGE_SCALARS
+                      and (self.fully_connected or (not self._diff_cols and extra == 0))
                       and not (linear_args.get("batch_norm") or linear_args.get("spectral_norm")))
         self.fe = LinearNet(self.fe_layers, input_size=2 * input_node_size + num_ef + extra, final_linear=False, **linear_args)
         self.fn = LinearNet(self.fn_layers, input_size=self.fe_layers[-1] + input_node_size + extra,
@@ -276,9 +277,10 @@ class MPLayer(nn.Module):
         if not self.fully_connected:
             if self.num_knn + int(not self.self_loops) > x.shape[1]:
                 raise ValueError(f"num_knn = {self.num_knn} neighbours (self_loops = {self.self_loops}) out of {x.shape[1]} nodes")
-            with torch.no_grad():
-                nbr = ops.knn_sets(x, mask if use_mask else None, self.num_knn, self.self_loops)
-        es, xfn = self._edge_scalars(x, labels, num_jet_particles)
+            with torch.no_grad():   # (with pos_diffs and not all_ef the reference ranks by the coordinates alone, :340-345)
+                xr = x[..., :(3 if self.coords == "cartesian" else 2)] if (self.pos_diffs and not self.all_ef) else x
+                nbr = ops.knn_sets(xr, mask if use_mask else None, self.num_knn, self.self_loops)
+        es, xfn = self._edge_scalars(x, labels, num_jet_particles, mask if (use_mask and not self.fully_connected) else None)
         W1, packed = fe[0].weight, None
         if self._diff_cols:
             W1 = self._folded_w1(W1)   # (not a parameter: its images are packed for this call)
@@ -299,18 +301,21 @@ class MPLayer(nn.Module):
         Wd = torch.nn.functional.pad(W1[:, 2 * F:2 * F + nc], (0, F - nc))
         return torch.cat((W1[:, :F] - Wd, W1[:, F:2 * F] + Wd, W1[:, 2 * F + nc:]), dim=1)
 
-    def _edge_scalars(self, x: Tensor, labels: Tensor, num_jet_particles: Tensor):
+    def _edge_scalars(self, x: Tensor, labels: Tensor, num_jet_particles: Tensor, knn_mask: Tensor = None):
         """``(es [B, N senders, EDGE_SCALARS, N receivers] or None, xfn [B, N, F + E] or None)``: the scalars the fused edge
         kernels multiply with their own columns of fe.net.0.weight -- the distance ||x_j - x_i + 1e-12|| (mpgan/model.py:
         299-302; 4 bytes per edge instead of the edge matrix) and the conditioning columns AS THE REFERENCE TILES THEM:
         ``t.repeat(rows / B, 1)`` gives ROW r the entry of jet r mod B (:249, :253), a per-edge gather for the edge network
-        and a per-node one for the node network (:272, :276)."""
+        and a per-node one for the node network (:272, :276).  (On the k-NN graph the reference's edge rows are (b, i, rank);
+        the conditioning columns are then tiled over THOSE rows, which the fused kernels -- walking all senders -- do not
+        have: clabels / mask_fne_np with fully_connected=False stay on the un-fused route.)"""
         if self.n_es == 0:
             return None, None
         B, N, F = x.shape
         cols = []
         if self._dist_col:
-            d = x.unsqueeze(1) - x.unsqueeze(2)                 # [B, i, j, F] = x_j - x_i
+            xs = x if knn_mask is None else ((1 - 1e4) * knn_mask + 1e4) * x   # k-NN: zero-masked senders pushed away (:333-335)
+            d = xs.unsqueeze(1) - x.unsqueeze(2)                # [B, i, j, F] = x_j - x_i
             if not self.all_ef:
                 d = d[..., :(3 if self.coords == "cartesian" else 2)]
             cols.append(torch.norm(d + 1e-12, dim=3).transpose(1, 2))   # [B, j, i]

@@ -110,7 +110,8 @@ def test_unsupported_options_raise():
                                     (dict(pos_diffs=True, all_ef=False, delta_coords=True), 67, 224, True),
                                     (dict(clabels=1, mask_fne_np=True), 66, 226, True),
                                     (dict(pos_diffs=True, clabels=1, mask_fne_np=True), 67, 226, False),        # three scalars
-                                    (dict(pos_diffs=True, fully_connected=False, num_knn=5), 65, 224, False)):  # k-NN distances
+                                    (dict(pos_diffs=True, fully_connected=False, num_knn=5), 65, 224, True),    # k-NN distances
+                                    (dict(clabels=1, fully_connected=False, num_knn=5), 65, 225, False)):       # tiled over rank rows
         m = MPLayer(32, [96, 160, 192], [256, 256], 32, **kw)
         assert m.fused == fused and m.fe.net[0].in_features == fe_in and m.fn.net[0].in_features == fn_in, kw
     m = MPLayer(16, [64, 48], [40], 8)

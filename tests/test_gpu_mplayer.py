@@ -518,7 +518,8 @@ def _option_cases():
     return OPTION_CASES
 
 
-FUSED_OPTION_CASES = ("ef", "efc", "cl")   # distance column; folded coordinate differences + distance; two row-tiled conditioning columns
+# distance column; folded coordinate differences + distance; two row-tiled conditioning columns; k-NN graph with its distances
+FUSED_OPTION_CASES = ("ef", "efc", "cl", "knnef")
 
 
 @pytest.mark.parametrize("route", ["fused", "edges"])
@@ -538,7 +539,7 @@ def test_mplayer_options_vs_reference_golden(case, route):
     layer = MPLayer(F, kw.get("fe", [96, 160, 192]), kw.get("fn", [256, 256]), out, **ctor).cuda()
     assert layer.fused == (name in FUSED_OPTION_CASES)
     if route == "fused" and not layer.fused:
-        pytest.skip("outside the fused kernels (k-NN distances / other widths)")
+        pytest.skip("outside the fused kernels (other widths)")
     if route == "edges":
         layer.fused = False
     layer.load_state_dict(T.init_state_dict(option_case_shapes(F, out, kw), seed=int(g["seed"]), dtype=torch.float32))
@@ -548,8 +549,9 @@ def test_mplayer_options_vs_reference_golden(case, route):
     (y * torch.from_numpy(g["g"]).float().cuda()).sum().backward()
     assert rel_err(y.detach().cpu().numpy(), g["y"]) < TIGHT, name
     assert rel_err(x.grad.cpu().numpy(), g["dx"]) < TOL, name
-    for k, p in layer.named_parameters():
-        assert rel_err(summarize(k, p.grad), g["grad__" + k]) < TOL, (name, k)
+    from conftest import summary_err
+    for k, p in layer.named_parameters():   # (the summaries' sum entry against the tensor's l1: conftest.summary_err)
+        assert summary_err(k, p.grad, g["grad__" + k]) < TOL, (name, k)
 
 
 @pytest.mark.parametrize("alpha", [1.0, 0.2])
