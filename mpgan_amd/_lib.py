@@ -48,7 +48,7 @@ class MpgEdgeFwd(C.Structure):
         ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
         ("skip_masked", C.c_int), ("f16", C.c_int),
         ("sign3", _fp), ("nbr", _fp), ("stageE2", _fp),
-        ("es", _fp), ("wq", _fp),
+        ("es", _fp), ("wq", _fp), ("order", _fp),
     ]
 
 
@@ -65,7 +65,7 @@ class MpgEdgeBwd(C.Structure):
         ("alpha", C.c_float), ("agg_scale", C.c_float),
         ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
         ("f16", C.c_int), ("nbr", _fp), ("gexp", _fp),
-        ("es", _fp), ("wq", _fp), ("des", _fp), ("daq", _fp),
+        ("es", _fp), ("wq", _fp), ("des", _fp), ("daq", _fp), ("order", _fp),
     ]
 
 
@@ -182,6 +182,7 @@ SIGNATURES = {
     "mpg_mab_bwd": (C.c_int, [C.POINTER(MpgMab), C.c_void_p]),
     "mpg_knn_sets": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_void_p]),
     "mpg_rank_mask": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, C.c_void_p]),
+    "mpg_jet_order": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_void_p]),
     "mpg_gen_tail_fwd": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mpg_gen_tail_bwd": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mpg_disc_head_fwd": (C.c_int, [C.POINTER(MpgDiscHead), C.c_void_p]),

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     int bid = blockIdx.x;
     const int sc = bid % p.SC; bid /= p.SC;
     const int rb = bid % RB;
-    const int b = bid / RB;
+    const int b = p.order != nullptr ? p.order[bid / RB] : bid / RB;   // (heaviest jets first: mpg_jet_order)
     const int i = rb * 32 + r;
     const int JC = (p.N + p.SC - 1) / p.SC;
     const int jbeg = sc * JC, jend = min(p.N, jbeg + JC);

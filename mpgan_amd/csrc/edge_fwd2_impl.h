@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
     int bid = blockIdx.x;
     const int sc = bid % p.SC; bid /= p.SC;
     const int rb = bid % RB;
-    const int b = bid / RB;
+    const int b = p.order != nullptr ? p.order[bid / RB] : bid / RB;   // (heaviest jets first: mpg_jet_order)
     const int i = rb * 32 + r;
     const bool vi = i < p.N;
     const int JC = (p.N + p.SC - 1) / p.SC;

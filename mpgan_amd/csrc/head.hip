@@ -34,6 +34,31 @@ __global__ __launch_bounds__(256) void rank_mask_kernel(const float* __restrict_
     }
 }
 
+// Jets in order of decreasing multiplicity (ties by index): counting sort in one workgroup.  keys[] and the histogram live in LDS.
+__global__ __launch_bounds__(1024) void jet_order_kernel(const float* __restrict__ mask, int B, int N, int* __restrict__ order) {
+    extern __shared__ int jo[];
+    int* keys = jo;            // [B]: N - (number of unmasked particles)  (0 = fullest)
+    int* hist = jo + B;        // [N + 2]
+    for (int t = threadIdx.x; t < N + 2; t += blockDim.x) hist[t] = 0;
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        int cnt = 0;
+        for (int j = 0; j < N; ++j) cnt += mask[(size_t)b * N + j] != 0.f;
+        keys[b] = N - cnt;
+        atomicAdd(&hist[N - cnt + 1], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 1; k < N + 2; ++k) hist[k] += hist[k - 1];   // hist[k] = jets with a smaller key
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const int k = keys[b];
+        int before = 0;
+        for (int c = 0; c < b; ++c) before += keys[c] == k;
+        order[hist[k] + before] = b;
+    }
+}
+
 __global__ __launch_bounds__(256) void gen_tail_fwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ mask,
                                                            float* __restrict__ out, int ldo, int V, int F, int act) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -320,6 +345,14 @@ extern "C" int mpg_rank_mask(const float* x, int ld_jet, int ld_part, const floa
     if (B <= 0 || N <= 0 || N > 8192) return -1;
     hipLaunchKernelGGL(rank_mask_kernel, dim3(B), dim3(N <= 64 ? 64 : 256), N * sizeof(float), (hipStream_t)stream, x, ld_jet, ld_part,
                        labels, ld_lab, N, mask);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mpg_jet_order(const float* mask, int B, int N, int* order, void* stream) {
+    if (B <= 0 || N <= 0 || mask == nullptr || order == nullptr) return -1;
+    const size_t lds = (size_t)(B + N + 2) * sizeof(int);
+    if (lds > 64 * 1024) return -2;
+    hipLaunchKernelGGL(jet_order_kernel, dim3(1), dim3(B <= 256 ? 256 : 1024), lds, (hipStream_t)stream, mask, B, N, order);
     return (int)hipGetLastError();
 }
 

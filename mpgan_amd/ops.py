@@ -35,7 +35,11 @@ OPTIONS = {
     # hi/lo.  Measured: the launch alone 24 against 35 us, the training step no faster, the node
     # networks' weight gradients 3e-5 .. 3e-4 instead of 1e-5 -- so it stays off
     "wgrad_f16": False,
+    # launches with more workgroups than CUs (the discriminator's real + generated batch) hand their jets out heaviest first
+    # (mpg_jet_order): no effect on results, 136 -> 113 us on the 2B launches of the headline configuration
+    "lpt_order": True,
 }
+NUM_CUS = 256
 # Forward products (they decide LeakyReLU signs) are split as fp16 hi/lo with the operand scales below (~2^-21 per
 # product); the fused edge backward works in fp16 as well (csrc/edge_bwd2_impl.h).  Range: |e2| < 1023, node activations
 # < 8188, |W * dscale| < 1023 -- see INTEGRATION.md.
@@ -441,6 +445,22 @@ MAX_CHUNK_SENDERS_ES = 116   # ... with edge scalars (their columns take part of
 MAX_CHUNK_SENDERS = 180   # mpg_edge_bwd keeps the list of a chunk's unmasked senders in LDS (csrc/edge_bwd2.hip)
 
 
+def jet_order(mask2d: torch.Tensor) -> torch.Tensor:
+    """int32 [B]: the jets by decreasing number of unmasked particles (``mpg_jet_order``).  The last result per device is kept
+    and handed out again for a mask with the same storage, shape and version -- the layers of one network pass share their
+    mask.  (A stale order would only change in which order workgroups start, never a result: any permutation is valid.)"""
+    st = dev_state(mask2d.device)
+    key = (mask2d.data_ptr(), tuple(mask2d.shape), mask2d._version)
+    hit = getattr(st, "order_cache", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    B, N = mask2d.shape
+    order = torch.empty((B,), device=mask2d.device, dtype=torch.int32)
+    check(_lib.lib().mpg_jet_order(_p(mask2d), B, N, C.c_void_p(order.data_ptr()), _stream()), "mpg_jet_order")
+    st.order_cache = (key, order)
+    return order
+
+
 def _sender_chunks(B, N, max_chunk=None):
     """Sender chunks per (jet, receiver block).  A workgroup costs a 150 KiB LDS fill (about five senders' worth of
     time) plus its chunk's senders, and the 256 CUs take the workgroups of a launch in rounds: the chunk count that
@@ -533,6 +553,10 @@ class FusedMPLayerFn(torch.autograd.Function):
             wq[:nq] = W1.detach()[:, 2 * F:2 * F + nq].t()
             e.es, e.wq = _p(es), _p(wq)
         RB = (N + 31) // 32
+        order = None
+        if m1 is not None and OPTIONS["lpt_order"] and B * RB * SC > NUM_CUS and B + N + 2 <= 16384:
+            order = jet_order(m1.view(B, N))
+            e.order = C.c_void_p(order.data_ptr())
         need_grad = any(ctx.needs_input_grad)
         sign3 = torch.empty((B * RB * N * 192,), device=dev, dtype=torch.int32) if need_grad else None
         e.sign3 = None if sign3 is None else C.c_void_p(sign3.data_ptr())
@@ -560,14 +584,14 @@ class FusedMPLayerFn(torch.autograd.Function):
               A=agg, lda=H3, K1=H3, A2=xf2, lda2=xf2.stride(0), alpha=alpha, seed_t=seed_t, f16=f16, ascale=SC_ACT)
         ctx.packed = pk
 
-        ctx.save_for_backward(x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3, nbr, stE2, es, wq, xf2)
+        ctx.save_for_backward(x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3, nbr, stE2, es, wq, xf2, order)
         ctx.cfg = (B, N, F, agg_scale, alpha, thr, dscale, tag, SC, f16, nq)
         return y.reshape(B, N, V3.shape[0])
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3, nbr, stE2, es, wq, xf2 = ctx.saved_tensors
+        x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3, nbr, stE2, es, wq, xf2, order = ctx.saved_tensors
         pk = ctx.packed
         B, N, F, agg_scale, alpha, thr, dscale, tag, SC, f16, nq = ctx.cfg
         nbr_p = None if nbr is None else C.c_void_p(nbr.data_ptr())
@@ -633,6 +657,8 @@ class FusedMPLayerFn(torch.autograd.Function):
         e.alpha, e.agg_scale, e.nbr = alpha, agg_scale, nbr_p
         e.seed, e.tag_base, e.thr, e.dscale = _p(seed_t), tag, thr, dscale
         e.f16 = int(f16)
+        if order is not None:
+            e.order = C.c_void_p(order.data_ptr())
         des = daq = None
         if es is not None:
             des = torch.zeros_like(es)   # (zero-masked senders' rows are not written)

@@ -612,3 +612,49 @@ def test_edge_scalars_separable_case_equals_node_features(p_drop, use_mask, N, a
     else:
         off = {n: float(((a - b).abs() > TOL * b.abs().max()).float().mean()) for n, a, b in zip(names, g_es, g_nf)}
         assert max(errs.values()) < 2e-2 and max(off.values()) < 0.01, (errs, off)
+
+
+def test_jet_order_and_heaviest_first_launches_change_no_result():
+    """mpg_jet_order: a permutation, multiplicities non-increasing, ties in index order.  A layer call with more workgroups
+    than CUs hands its jets out in that order (ops.OPTIONS['lpt_order']): outputs and every gradient are BIT-identical to the
+    index-order launch -- a jet's workgroup computes the same thing whenever it starts."""
+    from mpgan_amd import ops
+    from mpgan_amd.mpgan import MPLayer
+    dev = _dev()
+    rs = np.random.RandomState(5)
+    for B, N in ((300, 30), (7, 150), (1, 1), (2048, 30)):
+        n = rs.randint(0, N + 1, size=B)
+        m = (np.arange(N)[None, :] < n[:, None]).astype(np.float32)
+        rs.shuffle(m.T)   # (unmasked particles anywhere in the jet)
+        order = torch.empty(B, dtype=torch.int32, device=dev)
+        mt = torch.from_numpy(np.ascontiguousarray(m)).to(dev)
+        ops.check(ops._lib.lib().mpg_jet_order(ops._p(mt), B, N, ops.C.c_void_p(order.data_ptr()), ops._stream()), "mpg_jet_order")
+        o = order.cpu().numpy()
+        cnt = m.sum(1)
+        assert sorted(o.tolist()) == list(range(B))
+        assert np.array_equal(o, np.lexsort((np.arange(B), -cnt)))
+    B, N = 300, 30
+    torch.manual_seed(3)
+    layer = MPLayer(32, [96, 160, 192], [256, 256], 32, dropout_p=0.5).to(dev)
+    x0 = torch.randn(B, N, 32, device=dev) * 0.5
+    nn_ = torch.from_numpy(rs.randint(1, N + 1, size=B))
+    mask = (torch.arange(N)[None, :] < nn_[:, None]).float().unsqueeze(2).to(dev)
+    up = torch.randn(B, N, 32, device=dev)
+    res = {}
+    for lpt in (True, False):
+        ops.OPTIONS["lpt_order"] = lpt
+        try:
+            import itertools
+            ops.dev_state(dev).tags = itertools.count(500)
+            ops.dev_state(dev).order_cache = None
+            ops.set_seed(99, dev)
+            x = x0.clone().requires_grad_(True)
+            layer.zero_grad(set_to_none=True)
+            y = layer(x, True, mask)
+            (y * up).sum().backward()
+            res[lpt] = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+            assert (ops.dev_state(dev).order_cache is not None) == lpt
+        finally:
+            ops.OPTIONS["lpt_order"] = True
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
