@@ -151,11 +151,15 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
     }
     if constexpr (NQ > 0)
         for (int t = tid; t < NQ * H1; t += 256) lwq[t] = p.wq[t] * SC_A;
-    if (w == 0) {  // unmasked senders of the chunk, in order (the chunk holds at most B2_LIST_MAX senders)
+    // unmasked senders, in order: of the whole jet when they all fit the list -- which is then cut into SC equal parts (chunks
+    // by sender index are as uneven as the mask; see edge_fwd2_impl.h) --, else of the chunk's index range
+    const bool whole = p.N <= (NQ > 0 ? B2_LIST_MAX_Q : B2_LIST_MAX);
+    const int lbeg = whole ? 0 : jbeg, lend = whole ? p.N : jend;
+    if (w == 0) {
         int cnt = 0;
-        for (int j0 = jbeg; j0 < jend; j0 += 64) {
+        for (int j0 = lbeg; j0 < lend; j0 += 64) {
             const int j = j0 + lane;
-            const bool ok = j < jend && (p.mask == nullptr || p.mask[b * p.N + j] != 0.f);
+            const bool ok = j < lend && (p.mask == nullptr || p.mask[b * p.N + j] != 0.f);
             const unsigned long long bits = __ballot(ok);
             if (ok) lst[cnt + __popcll(bits & ((1ull << lane) - 1ull))] = (unsigned short)j;
             cnt += __popcll(bits);
@@ -170,7 +174,12 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) {
                 reinterpret_cast<float4*>(p.dc + ((size_t)rb * p.B * p.N + (size_t)(b * p.N + j)) * H1)[t % (H1 / 4)] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     __syncthreads();
-    const int nvalid = __builtin_amdgcn_readfirstlane(*lnv);
+    int nvalid = __builtin_amdgcn_readfirstlane(*lnv);
+    if (whole) {
+        const int per = (nvalid + p.SC - 1) / p.SC, l0 = min(nvalid, sc * per);
+        lst += l0;
+        nvalid = min(per, nvalid - l0);
+    }
     // the workgroup's gradient unit 2^-e (see the head of this file): max |dZ3| <= max |dagg * agg_scale| * dscale (mask <= 1)
     const int gexp = __builtin_amdgcn_readfirstlane(grad_unit_exp(fmaxf(fmaxf(lmx[0], lmx[1]), fmaxf(lmx[2], lmx[3])) * p.dscale));
     const float gunit = __builtin_bit_cast(float, (uint32_t)(gexp + 127) << 23);            // 2^e

@@ -103,11 +103,17 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
         if (ii < p.N) v4 = ld4(p.a + (size_t)(b * p.N + ii) * ldac + 8 * qsu + 4 * hh);
         la[t] = make_float4(v4.x * SC_A, v4.y * SC_A, v4.z * SC_A, v4.w * SC_A);
     }
+    // A jet whose senders all fit the list (N <= F2_LIST_MAX) is listed WHOLE and the list cut into SC equal parts: chunks by
+    // sender index are as uneven as the mask (150 particles, 117 unmasked, 3 chunks: 50 / 50 / 17 senders -- the launch lasts
+    // as long as the fullest).  Which chunk a sender lands in is this kernel's business alone: the by-products it leaves
+    // (sign words, parked E2) are indexed by sender, and the backward partitions its own list.
+    const bool whole = p.N <= F2_LIST_MAX;
+    const int lbeg = whole ? 0 : jbeg, lend = whole ? p.N : jend;
     if (w == 0) {
         int cnt = 0;
-        for (int j0 = jbeg; j0 < jend; j0 += 64) {
+        for (int j0 = lbeg; j0 < lend; j0 += 64) {
             const int j = j0 + lane;
-            const bool ok = j < jend && (!(p.skip_masked & 1) || p.mask == nullptr || p.mask[b * p.N + j] != 0.f);
+            const bool ok = j < lend && (!(p.skip_masked & 1) || p.mask == nullptr || p.mask[b * p.N + j] != 0.f);
             const unsigned long long bits = __ballot(ok);
             if (ok) lst[cnt + __popcll(bits & ((1ull << lane) - 1ull))] = (unsigned short)j;
             cnt += __popcll(bits);
@@ -116,7 +122,12 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
     }
     // (the sign words of skipped senders are never written, and never read: the backward skips the same blocks)
     __syncthreads();
-    const int nvalid = __builtin_amdgcn_readfirstlane(*lnv);
+    int nvalid = __builtin_amdgcn_readfirstlane(*lnv);
+    if (whole) {
+        const int per = (nvalid + p.SC - 1) / p.SC, l0 = min(nvalid, sc * per);
+        lst += l0;
+        nvalid = min(per, nvalid - l0);
+    }
 
     uint32_t seed_lo = 0, seed_hi = 0;
     if (DROP) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
