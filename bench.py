@@ -205,7 +205,7 @@ def main():
                   else f"jets/sec (G+D step) {args.model} N={N} bs={B}",
         "value": jets_per_s, "unit": "jets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "split-16-bit MFMA, fp32 accumulate, fp32 in/out: f16 hi/lo x3 terms (forward, recomputation), f16 x2 / x1 "
+        "dtype": "split-16-bit MFMA, fp32 accumulate, fp32 in/out: f16 hi/lo x3 terms (forward), f16 x2 / x1 "
                  "terms in per-sender dithered units (edge backward: data / weight gradients), bf16 hi/lo x3 (node network "
                  "gradients)" if args.model == "mpgan" else
                  "split-16-bit MFMA, fp32 accumulate, fp32 in/out: f16 hi/lo x3 terms (forward), bf16 hi/lo x3 (gradients)",

@@ -73,9 +73,9 @@ def rate(sub, key):
     d = [v for k, v in dur.items() if sub in k]
     return tot(key) / d[0] / 1e12 if d else float("nan")
 txt += ("#\n# Achieved HBM rate at B=256 (bytes above / rocprof average duration in " + f"{tag}_bench_kernel_stats.csv" + "; HBM3E peak 8 TB/s):\n"
-        f"#   edge_fwd_kernel<0, true>   {rate('edge_fwd_kernel<0, true>', 'edge_fwd_kernel<0'):5.2f} TB/s  (compute bound: see the SQ counters)\n"
-        f"#   edge_bwd_kernel<0, true>   {rate('edge_bwd_kernel<0, true>', 'edge_bwd_kernel<0, true'):5.2f} TB/s\n"
-        f"#   edge_dw_kernel<0>          {rate('edge_dw_kernel<0>', 'edge_dw_kernel<0'):5.2f} TB/s\n")
+        f"#   edge_fwd_kernel<0, true>   {rate('edge_fwd_kernel<0, true', 'edge_fwd_kernel<0'):5.2f} TB/s  (compute bound: see the SQ counters)\n"
+        f"#   edge_bwd_kernel<0, true>   {rate('edge_bwd_kernel<0, true', 'edge_bwd_kernel<0, true'):5.2f} TB/s\n"
+        f"#   edge_dw_kernel<0>          {rate('edge_dw_kernel<0', 'edge_dw_kernel<0'):5.2f} TB/s\n")
 txt += ("#\n# forward: a|c in, agg + sign words out (algorithmic 17.7 MB) + 10 KiB of fp16 E2 fragments per unmasked (jet, sender) block,\n"
         "# parked for the backward (which reads them for the LeakyReLU gate instead of recomputing the layer) and for mpg_edge_dw;\n"
         "# backward + staging: 10 KiB of fp16 dZ2 fragments per block; mpg_edge_dw reads both back and writes 256 per-workgroup\n"
