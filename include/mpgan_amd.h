@@ -96,6 +96,8 @@ int mpg_pack_weights(const float* W, int ldw, int rows, int cols, int transpose,
 typedef struct MpgPackJob {
     const float* W; int ldw, rows, cols, transpose; float scale; int f16; void* img;
     int row_split, split_cols;
+    int* status;   /* optional device word, OR-ed into: 1 = an element of an fp16 image is beyond fp16's range after scaling
+                      (|W * scale| > 65504: the image holds inf and every product with it is lost), 2 = a weight is not finite */
 } MpgPackJob;
 int mpg_pack_many(const MpgPackJob* jobs, int njobs, void* stream);
 

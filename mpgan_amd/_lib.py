@@ -95,6 +95,7 @@ class MpgPackJob(C.Structure):
     _fields_ = [
         ("W", _fp), ("ldw", C.c_int), ("rows", C.c_int), ("cols", C.c_int), ("transpose", C.c_int),
         ("scale", C.c_float), ("f16", C.c_int), ("img", _fp), ("row_split", C.c_int), ("split_cols", C.c_int),
+        ("status", _fp),
     ]
 
 

@@ -360,6 +360,15 @@ __global__ void pack_many_kernel(const PackJobs jobs) {
         }
         v[j] = x;
     }
+    if (J.status != nullptr) {   // range guard: fp16 images hold inf beyond 65504, and nothing downstream would notice before the loss
+        int bad = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = fabsf(v[j]);
+            bad |= !(a <= 3.0e38f) ? 2 : ((J.f16 && a > 65504.f) ? 1 : 0);
+        }
+        if (bad) atomicOr(J.status, bad);
+    }
     if (J.f16) {
         f16x8 hi, lo;
         split8(v, hi, lo);

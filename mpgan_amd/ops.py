@@ -70,7 +70,16 @@ class DeviceState:
         self.grad_into_param = False
         self.deferred_wgrad = None
         self.double_backward = False
+        self._status = None
 
+    @property
+    def status(self) -> torch.Tensor:
+        """Range guard of the packed weight images: a device word ``mpg_pack_many`` ORs into (1: an fp16 image element beyond
+        65504 after scaling, 2: a non-finite weight).  ``range_status`` reads it."""
+        if self._status is None:
+            dev = torch.device("cuda", self.index) if self.index >= 0 else torch.device("cpu")
+            self._status = torch.zeros((1,), dtype=torch.int32, device=dev)
+        return self._status
 
     @property
     def seed(self) -> torch.Tensor:
@@ -112,6 +121,17 @@ def seed_tensor(device) -> torch.Tensor:
     """Per-device 64-bit dropout seed living in device memory.  ``bump_seed`` advances it; call once per
     training iteration."""
     return dev_state(device).seed
+
+
+def range_status(device="cuda", clear: bool = False) -> int:
+    """What the range guard has seen on ``device`` since it was last cleared (0 = nothing; synchronises): bit 0 = a weight times
+    its operand scale left fp16's range while the images were packed (the fused forward then multiplies with inf), bit 1 =
+    a weight was not finite."""
+    st = dev_state(device).status
+    v = int(st.item())
+    if clear:
+        st.zero_()
+    return v
 
 
 def set_seed(value: int, device="cuda"):
@@ -350,9 +370,11 @@ def refresh_many(packs):
     for i0 in range(0, len(todo), PACK_MAX):
         chunk = todo[i0:i0 + PACK_MAX]
         jobs = (MpgPackJob * len(chunk))()
+        status = C.c_void_p(dev_state(chunk[0][0].device).status.data_ptr())
         for j, (W, rows, cols, tr, scale, f16, rs, sc, img) in zip(jobs, chunk):
             j.W, j.ldw, j.rows, j.cols, j.transpose = _p(W), W.stride(0), rows, cols, tr
             j.scale, j.f16, j.img, j.row_split, j.split_cols = scale, int(f16), C.c_void_p(img.data_ptr()), rs, sc
+            j.status = status
         check(_lib.lib().mpg_pack_many(jobs, len(chunk), _stream()), "mpg_pack_many")
     for pk in packs:
         pk._key = pk._current_key()

@@ -531,6 +531,18 @@ class TrainStep:
                 self._refresh_packed(self.G)
             self._seen_versions = seen
 
+    def check_range(self):
+        """Raise ``FloatingPointError`` if the run has left the numeric range of the fused path (fp16 operands
+        with power-of-two scales): a weight image overflowed or a weight / loss is no longer finite.  Synchronises -- call it
+        once per epoch, next to the reference's loss logging (train.py:526-540), not per iteration."""
+        import math
+        st = ops.range_status(self.dev)
+        losses = (float(self.D_loss), float(self.G_loss))
+        if st or not all(math.isfinite(v) for v in losses):
+            raise FloatingPointError(
+                f"mpgan_amd: outside the fused path's numeric range (guard word {st}: 1 = |weight x operand scale| > 65504 in an "
+                f"fp16 image, 2 = non-finite weight; losses D {losses[0]}, G {losses[1]})")
+
     def step(self):
         self.sync_external_writes()
         if self.use_graphs and self._graphs is None:

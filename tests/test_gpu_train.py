@@ -546,3 +546,30 @@ def test_saturated_generator_vs_oracle():
           f"{rel_err(out.cpu().numpy(), ref.numpy()):.1e}")
     assert bool(torch.isfinite(out).all())
     assert rel_err(out.cpu().numpy(), ref.numpy()) < 1e-4
+
+
+def test_range_guard_reports_overflowing_weight_images():
+    """The packed weight images are fp16 with power-of-two operand scales: a weight beyond 65504 / scale turns into inf there
+    and every product with it is lost.  mpg_pack_many notes that in a device word; TrainStep.check_range raises."""
+    from mpgan_amd import ops, train
+    dev = torch.device("cuda:0")
+    ops.range_status(dev, clear=True)
+    G, D = train.default_mpgan(30, device=dev)
+    ts = train.TrainStep(G, D, 4, 30, use_graphs=False)
+    from mpgan_amd.data import synthetic_jets
+    data, labels = synthetic_jets(4, 30)
+    ts.set_batch(data.to(dev), labels.to(dev))
+    ts.step()
+    ts.check_range()                      # a healthy step: nothing to report
+    assert ops.range_status(dev) == 0
+    with torch.no_grad():
+        D.mp_layers[0].fe.net[1].weight[3, 5] = 2.0e4      # times the operand scale 16 x dropout scale 2: beyond fp16
+    ts.step()
+    assert ops.range_status(dev) & 1
+    with pytest.raises(FloatingPointError):
+        ts.check_range()
+    with torch.no_grad():
+        D.mp_layers[0].fe.net[1].weight[3, 5] = float("nan")
+    ops.range_status(dev, clear=True)
+    ts.step()
+    assert ops.range_status(dev, clear=True) & 2

@@ -23,6 +23,7 @@ for model, B, steps in (("mpgan", 256, 400), ("gapt", 512, 1000)):
             assert d == d and g == g and abs(d) < 10 and abs(g) < 10, (model, it, d, g)
             lo, hi = [min(lo[0], d), min(lo[1], g)], [max(hi[0], d), max(hi[1], g)]
     torch.cuda.synchronize()
+    ts.check_range()
     for net in (G, D):
         for k, p in net.named_parameters():
             assert torch.isfinite(p).all(), (model, k)
