@@ -275,7 +275,7 @@ int mpg_rank_mask(const float* x, int ld_jet, int ld_part, const float* labels, 
  * MpgEdgeFwd.order / MpgEdgeBwd.order.  The edge kernels take a workgroup per jet and as long as the jet has senders; when a
  * launch has more workgroups than the chip has CUs (the discriminator's real + generated batch), handing them out heaviest
  * first is the classic longest-processing-time rule: 136 -> 113 us for 512 gluon-like jets.  No effect on any result.
- * B + N + 2 <= 16384. */
+ * B + N + 2 + ceil(B / 64) * (N + 1) <= 16384 (error -2). */
 int mpg_jet_order(const float* mask, int B, int N, int* order, void* stream);
 
 /* mpg_gen_tail_fwd / _bwd: MPNet._final_activation (:533-538) + MPGenerator._final_mask (:741-757) on V = B*N rows:

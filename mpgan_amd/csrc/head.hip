@@ -35,27 +35,45 @@ __global__ __launch_bounds__(256) void rank_mask_kernel(const float* __restrict_
 }
 
 // Jets in order of decreasing multiplicity (ties by index): counting sort in one workgroup.  keys[] and the histogram live in LDS.
+// The mask is read coalesced (thread = element), the ranks among equal keys wave by wave from ballots: a jet's position is
+// (jets with a smaller key) + (jets with its key in earlier waves) + (lanes below it in its wave with its key).
 __global__ __launch_bounds__(1024) void jet_order_kernel(const float* __restrict__ mask, int B, int N, int* __restrict__ order) {
     extern __shared__ int jo[];
-    int* keys = jo;            // [B]: N - (number of unmasked particles)  (0 = fullest)
-    int* hist = jo + B;        // [N + 2]
+    int* keys = jo;                  // [B]: first the number of unmasked particles, then N - that (0 = fullest)
+    int* hist = jo + B;              // [N + 2]: hist[k + 1] = jets with key k, then its prefix sums
+    int* wcnt = jo + B + N + 2;      // [waves][N + 1]: jets with key k in wave w, then in the waves before w
+    const int nw = (B + 63) / 64, lane = threadIdx.x & 63;
+    for (int t = threadIdx.x; t < B; t += blockDim.x) keys[t] = 0;
     for (int t = threadIdx.x; t < N + 2; t += blockDim.x) hist[t] = 0;
+    for (int t = threadIdx.x; t < nw * (N + 1); t += blockDim.x) wcnt[t] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < B * N; e += blockDim.x)
+        if (mask[e] != 0.f) atomicAdd(&keys[e / N], 1);
     __syncthreads();
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        int cnt = 0;
-        for (int j = 0; j < N; ++j) cnt += mask[(size_t)b * N + j] != 0.f;
-        keys[b] = N - cnt;
-        atomicAdd(&hist[N - cnt + 1], 1);
+        const int k = N - keys[b];
+        keys[b] = k;
+        atomicAdd(&hist[k + 1], 1);
+        atomicAdd(&wcnt[(b >> 6) * (N + 1) + k], 1);
     }
     __syncthreads();
     if (threadIdx.x == 0)
         for (int k = 1; k < N + 2; ++k) hist[k] += hist[k - 1];   // hist[k] = jets with a smaller key
+    for (int k = threadIdx.x; k <= N; k += blockDim.x) {           // exclusive scan over the waves, per key
+        int run = 0;
+        for (int w = 0; w < nw; ++w) { const int c = wcnt[w * (N + 1) + k]; wcnt[w * (N + 1) + k] = run; run += c; }
+    }
     __syncthreads();
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        const int k = keys[b];
-        int before = 0;
-        for (int c = 0; c < b; ++c) before += keys[c] == k;
-        order[hist[k] + before] = b;
+    for (int b0 = (threadIdx.x >> 6) * 64; b0 < B; b0 += blockDim.x) {   // whole waves: ballots need every lane
+        const int b = b0 + lane;
+        const int k = b < B ? keys[b] : -1;
+        // lanes below this one with the same key: compare against every lane's key through the wave
+        int below = 0;
+        for (int l = 0; l < 64; ++l) {
+            const int kl = __shfl(k, l, 64);
+            below += (l < lane && kl == k);
+        }
+        if (b < B) order[hist[k] + wcnt[(b >> 6) * (N + 1) + k] + below] = b;
     }
 }
 
@@ -350,7 +368,7 @@ extern "C" int mpg_rank_mask(const float* x, int ld_jet, int ld_part, const floa
 
 extern "C" int mpg_jet_order(const float* mask, int B, int N, int* order, void* stream) {
     if (B <= 0 || N <= 0 || mask == nullptr || order == nullptr) return -1;
-    const size_t lds = (size_t)(B + N + 2) * sizeof(int);
+    const size_t lds = ((size_t)B + N + 2 + (size_t)((B + 63) / 64) * (N + 1)) * sizeof(int);
     if (lds > 64 * 1024) return -2;
     hipLaunchKernelGGL(jet_order_kernel, dim3(1), dim3(B <= 256 ? 256 : 1024), lds, (hipStream_t)stream, mask, B, N, order);
     return (int)hipGetLastError();

@@ -576,7 +576,7 @@ class FusedMPLayerFn(torch.autograd.Function):
             e.es, e.wq = _p(es), _p(wq)
         RB = (N + 31) // 32
         order = None
-        if m1 is not None and OPTIONS["lpt_order"] and B * RB * SC > NUM_CUS and B + N + 2 <= 16384:
+        if m1 is not None and OPTIONS["lpt_order"] and B * RB * SC > NUM_CUS and B + N + 2 + (B + 63) // 64 * (N + 1) <= 16384:
             order = jet_order(m1.view(B, N))
             e.order = C.c_void_p(order.data_ptr())
         need_grad = any(ctx.needs_input_grad)
