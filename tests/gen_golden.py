@@ -72,6 +72,12 @@ D_OPT = dict(
     mask_args=dict(mask_feat=False, mask_feat_bin=False, mask_weights=False, mask_manual=False, mask_exp=False,
                    mask_real_only=False, mask_learn=False, mask_learn_bin=True, mask_learn_sep=False, fmg=[64],
                    mask_disc_sep=False, mask_fnd_np=True, mask_c=True, mask_fne_np=True))
+# the same discriminator with TWO scalars per edge (distance + one conditioning column; no particle-count columns): what the
+# fused edge kernels take (mpgan_amd.ops.EDGE_SCALARS)
+D_OPT2 = dict(D_OPT, mask_fnd_np=False,
+              mp_args=dict(D_OPT["mp_args"], mask_fne_np=False),
+              mp_args_first_layer=dict(clabels=1, all_ef=False),   # (its own dict: the reference's constructor fills it in place)
+              mask_args=dict(D_OPT["mask_args"], mask_fnd_np=False, mask_fne_np=False))
 
 
 def main():
@@ -186,6 +192,27 @@ def main():
         rec["grad__" + k] = summarize(k, p.grad)
     np.savez_compressed(os.path.join(OUT, "mpdisc_opt_f64.npz"), **rec)
     print("mpdisc options", float(yD.abs().max()))
+
+    # ------------------------------------------------------------------ 1d'. the same with two scalars per edge (distance + one
+    # conditioning column): the combination the fused edge kernels take -- every layer of this discriminator is fused here
+    dt = torch.float64
+    Dopt2 = rmp.MPDiscriminator(**D_OPT2).to(dt)
+    shapes = {k: tuple(v.shape) for k, v in Dopt2.state_dict().items()}
+    Dopt2.load_state_dict(init_state_dict(shapes, seed=71, dtype=dt))
+    Dopt2.eval()
+    B, N = 6, D_OPT2["num_particles"]
+    mk = rand_mask(B, N, 271).to(dt)
+    xin = torch.cat((seeded((B, N, 3), 171, 0.5).to(dt) * mk, mk - 0.5), dim=2).requires_grad_(True)
+    lab = seeded((B, 2), 471, 1.0).to(dt)
+    yD = Dopt2(xin, lab)
+    gD = seeded(tuple(yD.shape), 371).to(dt)
+    (yD * gD).sum().backward()
+    rec = dict(x=xin.detach().numpy(), labels=lab.numpy(), g=gD.numpy(), y=yD.detach().numpy(), dx=xin.grad.numpy(), seed=71,
+               keys=np.array(list(shapes.keys())), shapes=np.array([str(v) for v in shapes.values()]))
+    for k, p in Dopt2.named_parameters():
+        rec["grad__" + k] = summarize(k, p.grad)
+    np.savez_compressed(os.path.join(OUT, "mpdisc_opt2_f64.npz"), **rec)
+    print("mpdisc options, two scalars", float(yD.abs().max()))
 
     # ------------------------------------------------------------------ 1e. LinearNet with batch norm and spectral norm
     dt = torch.float64

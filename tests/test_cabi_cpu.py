@@ -132,6 +132,13 @@ def test_discriminator_with_conditioning_options_has_the_reference_manifest():
     assert [k for k in D.state_dict()] == list(g["keys"])
     assert [str(tuple(v.shape)) for v in D.state_dict().values()] == list(g["shapes"])
     assert not any(l.fused for l in D.mp_layers) and D.fused_head() is None
+    # the same with two scalars per edge (distance + clabels): every layer on the fused kernels
+    from gen_golden import D_OPT2
+    g2 = load_golden("mpdisc_opt2_f64.npz")
+    D2 = MPDiscriminator(**D_OPT2)
+    assert [k for k in D2.state_dict()] == list(g2["keys"])
+    assert [str(tuple(v.shape)) for v in D2.state_dict().values()] == list(g2["shapes"])
+    assert all(l.fused and l.n_es == 2 for l in D2.mp_layers)
 
 
 def test_product_does_not_import_the_oracle():

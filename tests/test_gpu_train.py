@@ -347,22 +347,32 @@ def test_generation_path_no_grad_vs_reference_golden():
     assert int((full.abs().sum(-1) > 0).sum(1).max()) <= 20
 
 
-def test_discriminator_with_conditioning_options_vs_reference_golden():
-    """A whole MPDiscriminator with clabels, mask_fne_np, mask_fnd_np and delta-r edge features on (the un-fused route of
-    every layer and of the head): output and gradients against the reference's own."""
+@pytest.mark.parametrize("which", ["three scalars per edge: un-fused", "two scalars per edge: fused"])
+def test_discriminator_with_conditioning_options_vs_reference_golden(which):
+    """A whole MPDiscriminator with the conditioning options on, output and gradients against the reference's own: with
+    clabels, mask_fne_np, mask_fnd_np and delta-r edge features (three scalars per edge: the un-fused route of every layer and
+    of the head), and with delta-r + clabels (two: every layer on the fused edge kernels)."""
     import numpy as np
-    from gen_golden import D_OPT
+    import gen_golden
     from oracle import train_ref as T
     from mpgan_amd.mpgan import MPDiscriminator
-    g = load_golden("mpdisc_opt_f64.npz")
+    fused = which.endswith("fused") and not which.endswith("un-fused")
+    D_OPT = gen_golden.D_OPT2 if fused else gen_golden.D_OPT
+    g = load_golden("mpdisc_opt2_f64.npz" if fused else "mpdisc_opt_f64.npz")
     D = MPDiscriminator(**D_OPT).cuda().eval()
+    assert all(l.fused for l in D.mp_layers) == fused and any(l.fused for l in D.mp_layers) == fused
     shapes = {k: tuple(v.shape) for k, v in D.state_dict().items()}
     D.load_state_dict(T.init_state_dict(shapes, seed=int(g["seed"]), dtype=torch.float32))
     x = torch.from_numpy(g["x"]).float().cuda().requires_grad_(True)
     y = D(x, torch.from_numpy(g["labels"]).float().cuda())
     (y * torch.from_numpy(g["g"]).float().cuda()).sum().backward()
     assert rel_err(y.detach().cpu().numpy(), g["y"]) < 1e-4
-    assert rel_err(x.grad.cpu().numpy(), g["dx"]) < 1e-3   # (the mask column included: it feeds the masked sums and njp)
+    if fused:   # the fused layers take the mask as data (nothing upstream of it is ever trained: the generator's mask column
+        # comes out of a ranking): no gradient for the mask column, the particle features' against the reference's
+        assert rel_err(x.grad[..., :3].cpu().numpy(), g["dx"][..., :3]) < 1e-3
+        assert float(x.grad[..., 3].abs().max()) == 0.0
+    else:
+        assert rel_err(x.grad.cpu().numpy(), g["dx"]) < 1e-3   # (the mask column included: it feeds the masked sums and njp)
     for k, p in D.named_parameters():
         assert summary_err(k, p.grad, g["grad__" + k]) < 1e-3, k
 
