@@ -393,8 +393,14 @@ class TrainStep:
         """train_G's ``gen_data = gen(...)`` (train.py:500-511) on the side stream, in training mode."""
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.dev)
-        self._side.wait_stream(torch.cuda.current_stream(self.dev))
+        # G's weight images are shared by this forward and the D step's own generator call: built (on first use, or behind an
+        # outside write) on THIS stream, before the fork -- built inside the forward they would be written on the side stream
+        # while the other call reads them
         self.G.train()
+        for m in self.G.modules():
+            if hasattr(m, "_packed") and getattr(m, "fused", False):
+                m._packed().ensure()
+        self._side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self._side):
             self._fake_ahead = self.G(self._noise(1), self.labels)
         self._fake_ahead.record_stream(torch.cuda.current_stream(self.dev))   # (its consumer, the G step, runs on this stream)

@@ -583,3 +583,20 @@ def test_range_guard_reports_overflowing_weight_images():
     ops.range_status(dev, clear=True)
     ts.step()
     assert ops.range_status(dev, clear=True) & 2
+
+
+@pytest.mark.parametrize("use_graphs,split", [(True, False), (True, True), (False, False)])
+def test_generator_ahead_stream_changes_no_result(use_graphs, split):
+    """TrainStep launches the G step's generator forward beside the D step on a second stream (it reads nothing the D step
+    writes).  Same weights, data and noise with and without it (MPG_GEN_AHEAD=0): parameters after three iterations are
+    bit-identical -- captured right after construction (the weight images the two generator calls share are built on the
+    first iteration), as one graph, as three segments and eagerly.  (Dropout off: its masks are a function of the order in
+    which the fused ops are issued, which is what changes.)"""
+    import os
+    with_it = _three_steps(64, 30, use_graphs, split=split)
+    os.environ["MPG_GEN_AHEAD"] = "0"
+    try:
+        without = _three_steps(64, 30, use_graphs, split=split)
+    finally:
+        os.environ.pop("MPG_GEN_AHEAD", None)
+    assert torch.equal(with_it[0], without[0]) and torch.equal(with_it[1], without[1]) and with_it[2:] == without[2:]
