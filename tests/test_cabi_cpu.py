@@ -46,6 +46,20 @@ def test_struct_layouts_match_header():
         assert int(sizes[s]) == ctypes.sizeof(getattr(_lib, s)), s
 
 
+def test_header_constants_match_their_python_mirrors():
+    """The limits the header defines and the kernels' LDS plans imply are the ones ops.py plans its launches with."""
+    from mpgan_amd import ops
+    txt = open(HEADER).read()
+    defs = {k: int(v) for k, v in re.findall(r"^#define\s+(MPG_\w+)\s+(\d+)\s*$", txt, flags=re.M)}
+    assert defs["MPG_GROUP_MAX"] == ops.GROUP_MAX and defs["MPG_PACK_MAX_JOBS"] == ops.PACK_MAX
+    assert defs["MPG_EDGE_SCALARS"] == ops.EDGE_SCALARS
+    csrc = os.path.join(ROOT, "mpgan_amd", "csrc")
+    bwd, fwd = open(os.path.join(csrc, "edge_bwd2_impl.h")).read(), open(os.path.join(csrc, "edge_fwd2_impl.h")).read()
+    lim = lambda src, name: int(re.search(r"constexpr int " + name + r" = (\d+);", src).group(1))
+    assert lim(bwd, "B2_LIST_MAX") == ops.MAX_CHUNK_SENDERS <= lim(fwd, "F2_LIST_MAX")
+    assert lim(bwd, "B2_LIST_MAX_Q") == ops.MAX_CHUNK_SENDERS_ES
+
+
 def test_host_helpers():
     from mpgan_amd import ops
     assert ops.drop_params(0.0) == (0, 1.0)
