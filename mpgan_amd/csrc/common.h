@@ -1,15 +1,15 @@
 // Common device helpers for the MPGAN/GAPT hot-path kernels (gfx950 / CDNA4 only).
 //
-// Arithmetic: every matrix product runs on the 16-bit matrix cores as a 3-term split:
-// x = hi + lo with hi = T(x), lo = T(x - hi);  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi,
-// accumulated in fp32 by v_mfma_f32_32x32x16_{f16,bf16}.
-//   T = _Float16 ("f16x3"): 11+11 significand bits, product error ~2^-21 -- used for every
-//       FORWARD product (and its recomputation in the backward), because those decide on which
-//       side of the LeakyReLU kink a pre-activation falls; operands must be < 65504 in
-//       magnitude (activations / weights of these networks are O(1); fp16 subnormals carry lo).
-//   T = __bf16   ("bf16x3"): 8+8 bits, product error ~2^-17, fp32 exponent range -- used for
-//       the products that carry GRADIENTS (arbitrarily small), where there is no kink.
-// Both sit well inside the 1e-3 parity bar of BASELINE.json (plain bf16 would be ~2e-3).
+// Arithmetic: every matrix product runs on the 16-bit matrix cores (v_mfma_f32_32x32x16_{f16,bf16}, fp32 accumulate) on
+// operands split as x = hi + lo, hi = T(x), lo = T(x - hi).  How many of the partial products are issued:
+//   3 terms  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  -- every FORWARD product (T = _Float16 with power-of-two operand scales,
+//            product error ~2^-21: they decide on which side of the LeakyReLU kink a pre-activation falls; operands must stay
+//            below 65504 after scaling) and the plain gradient GEMMs of the node network and of GAPT (T = __bf16: 8+8 bits,
+//            ~2^-17, fp32 exponent range -- gradients have any magnitude);
+//   2 terms  weight hi + lo times the gradient rounded to ONE fp16 value in a per-sender power-of-two unit -- the fused edge
+//            backward's dE2 = W3^T dZ3, dE1 = W2^T dZ2 (edge_bwd2_impl.h);
+//   1 term   fp16 x fp16 -- the fused edge weight gradients, sums over ~1e5 edges of independent roundings (edge_dw.hip).
+// All sit inside the 1e-3 parity bar of BASELINE.json (plain bf16 would be ~2e-3).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
