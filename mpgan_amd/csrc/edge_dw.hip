@@ -39,6 +39,12 @@ namespace {
 // images are double buffered (2 x 40 KiB): builders fill block n+1 while consumers multiply block n, one barrier per block.  Every
 // builder thread owns fixed (receiver, feature chunk) pieces and fetches everything it needs of a block two blocks ahead,
 // into one of two register sets, right after the piece it replaces was used: no builder ever waits on another.
+#ifdef MPG_DWSTAMP  // diagnostic build (tools/ubench/dw_bench.hip): clocks per section of a builder's block, summed over a workgroup's blocks
+__device__ unsigned long long g_dw_stamps[64 * 4 * 8];
+#define DW_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); dw_acc[i] += t_ - dw_t; dw_t = t_; } while (0)
+#else
+#define DW_STAMP(i) do {} while (0)
+#endif
 constexpr int DW_RS3 = 448, DW_RS2 = 320, DW_RS1 = 192;  // image row strides (bytes)
 constexpr int DW_Z3H = 0, DW_E2H = DW_Z3H + 32 * DW_RS3, DW_Z2H = DW_E2H + 32 * DW_RS2, DW_E1H = DW_Z2H + 32 * DW_RS2,
               DW_BUF = DW_E1H + 32 * DW_RS1;
@@ -285,6 +291,25 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
     // compiler would wait there with vmcnt(0) -- it cannot tell how old a load is across the loop's back edge -- and
     // drain every prefetch of every block)
     asm volatile("" : "+v"(eslot));
+    // The workgroup's slots (at most 64) -> block, sender, jet, receiver block, ONE slot per lane: a block's indices are then
+    // four v_readlane instead of the scalar divisions by N, RB and R they came from -- six division sequences per block for
+    // the block, the one-ahead and the two-ahead requests, a third of everything a builder wave issued.
+    int sblk, sj, sb, srb;
+    {
+        const int t = min(blk0 + (int)(threadIdx.x & 63), max(blk1 - 1, blk0));
+        sblk = dw_block(t, R);
+        const int brb = sblk / p.N;
+        sj = sblk - brb * p.N;
+        sb = brb / RB;
+        srb = brb - sb * RB;
+    }
+    asm volatile("" : "+v"(sblk), "+v"(sj), "+v"(sb), "+v"(srb));
+    struct Idx { int blk, j, b, rb; };
+    auto idx_of = [&](int slot) {
+        const int l = slot - blk0;
+        return Idx{__builtin_amdgcn_readlane(sblk, l), __builtin_amdgcn_readlane(sj, l), __builtin_amdgcn_readlane(sb, l),
+                   __builtin_amdgcn_readlane(srb, l)};
+    };
 
     const bool third = cg < 4;  // chunk groups 0..3 own a third 160-feature piece and a second E1 chunk
     auto e1tile = [&](int n) { return n == 0 || third ? 2 * n + (cg >> 2) : (cg >> 2); };  // 0..2
@@ -315,8 +340,8 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
     };
 
     // dagg / a of the (jet, receiver block) of block `blk`.  Padding receivers read row 0 and get scale 0.
-    auto load_d = [&](Small& P, int blk) {
-        const int brb = blk / p.N, rb = brb % RB, b = brb / RB, ii = rb * 32 + r;
+    auto load_d = [&](Small& P, const Idx& X) {
+        const int rb = X.rb, b = X.b, ii = rb * 32 + r;
         const bool ok = ii < p.N;
         P.dscl = ok ? p.agg_scale * p.dscale * unitG : 0.f;
         const int rowD = (ok ? ii : 0) * p.ld_dagg * 4 + (32 * (cg >> 2) + f0) * 4, soD = b * p.N * p.ld_dagg * 4;
@@ -327,8 +352,8 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
             P.dreg[n][4] = v.x; P.dreg[n][5] = v.y; P.dreg[n][6] = v.z; P.dreg[n][7] = v.w;
         }
     };
-    auto load_a = [&](Small& P, int blk) {
-        const int brb = blk / p.N, rb = brb % RB, b = brb / RB, ii = rb * 32 + r;
+    auto load_a = [&](Small& P, const Idx& X) {
+        const int rb = X.rb, b = X.b, ii = rb * 32 + r;
         const bool ok = ii < p.N;
         const int rowA = (ok ? ii : 0) * ldac * 4, soA = b * p.N * ldac * 4;
 #pragma unroll
@@ -339,21 +364,23 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
         }
     };
     const __amdgpu_buffer_rsrc_t rN = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int*>(p.nbr), 0, p.nbr ? p.B * p.N * ((p.N + 31) >> 5) * 4 : 0, 0x00020000);
-    auto load_nb = [&](Small& P, int blk) {  // (with no graph the resource is empty: the load returns 0 and is ignored below)
-        const int j = blk % p.N, brb = blk / p.N, rb = brb % RB, b = brb / RB, ii = rb * 32 + r;
+    auto load_nb = [&](Small& P, const Idx& X) {  // (with no graph the resource is empty: the load returns 0 and is ignored below)
+        const int j = X.j, rb = X.rb, b = X.b, ii = rb * 32 + r;
         P.nbw = __builtin_amdgcn_raw_buffer_load_b32(rN, ((b * p.N + (ii < p.N ? ii : 0)) * ((p.N + 31) >> 5) + (j >> 5)) * 4, 0, 0);
     };
-    auto load_sw = [&](Small& P, int blk) {  // word (tile >> 1) = n of lane (r, h)
+    // (requested ONE block ahead like the other small things, in front of the two-ahead pieces: asked for two blocks ahead,
+    // behind them, the top of a build waited for them across the loop's back edge with vmcnt(0) -- 60 -> 67 us)
+    auto load_sw = [&](Small& P, const Idx& X) {  // word (tile >> 1) = n of lane (r, h)
 #pragma unroll
-        for (int n = 0; n < 3; ++n) P.sw[n] = __builtin_amdgcn_raw_buffer_load_b32(rS, voS, blk * (T3 * 32 * 4) + n * 256, 0);
+        for (int n = 0; n < 3; ++n) P.sw[n] = __builtin_amdgcn_raw_buffer_load_b32(rS, voS, X.blk * (T3 * 32 * 4) + n * 256, 0);
     };
     const __amdgpu_buffer_rsrc_t rES = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.es), 0, NQ > 0 ? p.B * p.N * NQ * p.N * 4 : 0, 0x00020000);
-    auto load_c = [&](Small& P, int blk) {
-        const int j = blk % p.N, b = (blk / p.N) / RB, so = (b * p.N + j) * ldac * 4;
+    auto load_c = [&](Small& P, const Idx& X) {
+        const int j = X.j, b = X.b, so = (b * p.N + j) * ldac * 4;
 #pragma unroll
         for (int n = 0; n < 2; ++n) { P.cv[n][0] = ldb4(rC, voE1[n], so); P.cv[n][1] = ldb4(rC, voE1[n] + 32, so); }
         if constexpr (NQ > 0) {
-            const int rb = (blk / p.N) % RB, ii = rb * 32 + r;
+            const int rb = X.rb, ii = rb * 32 + r;
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
                 P.esq[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rES, (ii < p.N ? ii : 0) * 4, ((b * p.N + j) * NQ + q) * p.N * 4, 0));
@@ -367,19 +394,25 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
         P.zh[n] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rZ, vo160[n], blk * (NFR2 * 1024), 0));
     };
 
-    auto load_small = [&](Small& P, int blk) { load_d(P, blk); load_sw(P, blk); load_nb(P, blk); load_c(P, blk); load_a(P, blk); };
+    auto load_small = [&](Small& P, const Idx& X) { load_d(P, X); load_sw(P, X); load_nb(P, X); load_c(P, X); load_a(P, X); };
     auto load_big = [&](Big& Q, int blk) {
 #pragma unroll
         for (int n = 0; n < 3; ++n) { load_z2(Q, blk, n); load_e2(Q, blk, n); }
     };
 
+#ifdef MPG_DWSTAMP
+    unsigned long long dw_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dw_t = __builtin_amdgcn_s_memtime();
+#endif
     // build the block of slot `slot` (small things in S, parked pieces in Q) into buffer `buf`.  Right after a piece is used
     // its successor is requested: the small things of slot `pre1` first, the parked pieces of slot `pre2` behind them
     auto build = [&](int slot, char* buf, int pre1_slot, int pre2_slot, Big& Q) {
         const bool exp_noload = (MPG_DW_EXP & 4) && p.N != 12345, exp_nowrite = (MPG_DW_EXP & 8) && p.N != 12345;
-        const int blk = dw_block(slot, R), pre1 = dw_block((MPG_DW_EXP & 16) ? blk0 : pre1_slot, R), pre2 = dw_block((MPG_DW_EXP & 16) ? blk0 : pre2_slot, R);
-        const bool newrun = pre1_slot / R != slot / R;   // the next block belongs to other receivers: fetch their rows
-        const int j = blk % p.N, brb = blk / p.N, rb = brb % RB, b = brb / RB, ii = rb * 32 + r;
+        const Idx X = idx_of(slot), X1 = idx_of((MPG_DW_EXP & 16) ? blk0 : pre1_slot);
+        const int blk = X.blk, pre2 = __builtin_amdgcn_readlane(sblk, ((MPG_DW_EXP & 16) ? blk0 : pre2_slot) - blk0);
+        // the next block belongs to other receivers: fetch their rows (a run never straddles two receiver blocks; two runs of
+        // the same receivers would fetch the same rows)
+        const bool newrun = X1.b != X.b || X1.rb != X.rb;
+        const int j = X.j, rb = X.rb, b = X.b, ii = rb * 32 + r;
         const uint32_t erow = (uint32_t)((b * p.N + ii) * p.N + j);
         // the block's units: its gradient unit is 2^-e / c (c: the block's dither factor), the launch's 2^-eG
         const int de = eG - __builtin_amdgcn_readlane(eslot, slot - blk0);
@@ -391,6 +424,7 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
         // sums take it without the factor
         const float in_set = (p.nbr == nullptr || ((S.nbw >> (j & 31)) & 1u)) ? 1.f : 0.f;
         const float dscl_1 = S.dscl * in_set * dth, dscl_a = dscl_1 * p.alpha;   // (the dither factor rides in the slope constants)
+        DW_STAMP(0);   // block setup (index arithmetic, units) -- and whatever the barrier before it cost
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
             const int m = 2 * n + (cg >> 2), c = cg + 8 * n;
@@ -399,6 +433,8 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
             // sign bit of element k: bit 31 - (16 (m & 1) + 8 cs + k) of the lane's word -- shifted once so that the bit index
             // is a compile-time constant (v_bfe + v_bfi instead of shift, and, compare, select)
             const uint32_t swn = S.sw[n] << (16 * (m & 1) + 8 * cs);
+            // (packed fp32 arithmetic -- v_pk_mul_f32 / v_pk_fma_f32, two elements per instruction -- was measured here: no
+            // faster; a packed instruction takes the two issue turns of the scalar ones it replaces)
             static_for<0, 8>([&](auto kc) {
                 MPG_CI(k, kc);
                 float x = S.dreg[n][k] * sel_by_bit<31 - k>(swn, dscl_a, dscl_1);
@@ -410,7 +446,8 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
             if (!exp_nowrite) *reinterpret_cast<f16x8*>(buf + DW_Z3H + r * DW_RS3 + c * 16) = hh;
             else if (hh[0] == (_Float16)123.f) db2[0][0] += (float)hh[1];
         }
-        if (!exp_noload) { load_sw(S, pre1); load_nb(S, pre1); if (newrun) load_d(S, pre1); }
+        DW_STAMP(1);   // dZ3
+        if (!exp_noload) { load_sw(S, X1); load_nb(S, X1); if (newrun) load_d(S, X1); }
         // E1 = keep1 * lrelu(a_i + c_j), times funit: what takes the parked dZ2 -- which goes into its image AS PARKED,
         // rounded once, by mpg_edge_bwd -- to the launch's unit multiplies the OTHER operand of its product, built in
         // fp32 anyway (chunk groups 4..7: the second chunk repeats the first)
@@ -445,7 +482,8 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
             if (!exp_nowrite) *reinterpret_cast<f16x8*>(buf + DW_E1H + r * DW_RS1 + c * 16) = hh;
             else if (hh[0] == (_Float16)123.f) db2[0][0] += (float)hh[1];
         }
-        if (!exp_noload) { load_c(S, pre1); if (newrun) load_a(S, pre1); }
+        DW_STAMP(2);   // requests + E1
+        if (!exp_noload) { load_c(S, X1); if (newrun) load_a(S, X1); }
         // dZ2: as parked; the bias sums (fp32) in the launch's unit
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
@@ -456,6 +494,7 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
             for (int k = 0; k < 8; ++k) db2[n][k] += take * (float)Q.zh[n][k];
             if (!exp_noload) load_z2(Q, pre2, n);
         }
+        DW_STAMP(3);   // requests + dZ2
         // E2: as parked, divided by the block's dither factor (its partner dZ3 was built times that factor)
         const f16x8 rc8 = {rch, rch, rch, rch, rch, rch, rch, rch};
 #pragma unroll
@@ -466,6 +505,7 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
             else if (e[0] == (_Float16)123.f) db2[0][0] += (float)e[1];
             if (!exp_noload) load_e2(Q, pre2, n);
         }
+        DW_STAMP(4);   // E2
     };
 
     // valid slots v0, v1, v2, ...: block v_k takes its parked pieces from set k & 1, which is then refilled with those of
@@ -474,9 +514,9 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
     int cur = dw_next_valid(vbits, blk0, blk0, blk1), it = 0;
     int n1 = dw_next_valid(vbits, blk0, cur + 1, blk1), n2 = dw_next_valid(vbits, blk0, n1 + 1, blk1);
     if (cur < blk1) {
-        load_small(S, dw_block(cur, R));
-        load_big(B0, dw_block(cur, R));
-        load_big(B1, dw_block(min(n1, blk1 - 1), R));
+        load_small(S, idx_of(cur));
+        load_big(B0, idx_of(cur).blk);
+        load_big(B1, idx_of(min(n1, blk1 - 1)).blk);
         build(cur, smem, min(n1, blk1 - 1), min(n2, blk1 - 1), B0);
     }
     lds_barrier();
@@ -485,6 +525,7 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
             const int n3 = dw_next_valid(vbits, blk0, n2 + 1, blk1);
             if (n1 < blk1 && !(MPG_DW_EXP & 2)) build(n1, smem + ((it + 1) & 1) * DW_BUF, min(n2, blk1 - 1), min(n3, blk1 - 1), B1);
             lds_barrier();
+            DW_STAMP(5);   // waiting at the barrier (for the consumers)
             cur = n1; n1 = n2; n2 = n3; ++it;
         }
         if (!(cur < blk1)) break;
@@ -492,10 +533,18 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
             const int n3 = dw_next_valid(vbits, blk0, n2 + 1, blk1);
             if (n1 < blk1 && !(MPG_DW_EXP & 2)) build(n1, smem + ((it + 1) & 1) * DW_BUF, min(n2, blk1 - 1), min(n3, blk1 - 1), B0);
             lds_barrier();
+            DW_STAMP(5);
             cur = n1; n1 = n2; n2 = n3; ++it;
         }
     }
 
+#ifdef MPG_DWSTAMP
+    if (blockIdx.x < 64 && (threadIdx.x & 63) == 0) {
+        dw_acc[6] = (unsigned long long)it;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) g_dw_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6) - 4) * 8 + q] = dw_acc[q];
+    }
+#endif
     // bias sums: add the 32 receivers of a chunk group -- 16 in this wave (lane bits 2..5), 16 in its neighbour wave
     // (through LDS: the images are dead after the loop's last barrier); fragment-order index fi = 8 c + k
     float* red = reinterpret_cast<float*>(smem);   // [wave 0..3][lane & 3][n][k][db3 | db2]

@@ -39,6 +39,18 @@ int main(int argc, char** argv) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<float> h(4); hipMemcpy(h.data(), dW3, 16, hipMemcpyDeviceToHost);
+#ifdef MPG_DWSTAMP
+    {
+        std::vector<unsigned long long> st(64 * 4 * 8);
+        hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_dw_stamps), st.size() * 8);
+        const char* nm[6] = {"setup(+barrier before)", "dZ3", "requests+E1", "requests+dZ2", "E2", "barrier wait"};
+        double tot[8] = {0};
+        for (int w = 0; w < 64 * 4; ++w) for (int q = 0; q < 8; ++q) tot[q] += (double)st[w * 8 + q];
+        const double nb = tot[6] > 0 ? tot[6] : 1;
+        printf("builder clocks per block (s_memtime ticks = shader clocks, ~1.4 GHz in this kernel), mean over 256 builder waves, %.1f blocks each:\n", nb / 256);
+        for (int q = 0; q < 6; ++q) printf("  %-24s %8.1f\n", nm[q], tot[q] / nb);
+    }
+#endif
     printf("edge_dw<%d> (+reduce) B=%d N=%d%s nwg=%d: %.1f us/launch   dW3[0..3] = %g %g %g %g\n", MPG_SINGLE_VARIANT, B, N,
            argc > 2 ? " ragged" : "", nwg, ms * 1e3 / R, h[0], h[1], h[2], h[3]);
     return 0;
