@@ -14,7 +14,6 @@
 // conflict-free ds_read_b128).
 #include "common.h"
 #include "gemm.h"
-#include "wgrad2.h"
 
 namespace {
 
@@ -287,28 +286,6 @@ extern "C" int mpg_gemm(const MpgGemm* g, int ak, int bk, int splitk, void* stre
 
 extern "C" int mpg_gemm_wgrad_group(const MpgGemm* g, const int* splitk, int n, void* stream) {
     if (n < 1 || n > MPG_GROUP_MAX) return -1;
-    if (g[0].f16 == 2) {   // one-term fp16 products on 128 x 128 tiles (wgrad2.hip)
-        W2Group W;
-        W.n = n;
-        W.wg0[0] = 0;
-        for (int q = 0; q < n; ++q) {
-            const MpgGemm& e = g[q];
-            const int hb = e.ones_col ? 1 : 0, Kin = e.N - hb;
-            if (e.f16 != 2 || e.M <= 0 || Kin <= 0 || e.K <= 0 || splitk[q] < 1) return -1;
-            if (e.A2 != nullptr || e.bias != nullptr || e.act || e.gateH != nullptr || e.resid != nullptr || e.accumulate || e.drop_thr) return -2;
-            // float4 column groups: 16-byte aligned rows, and a group that straddles the width stays inside its row
-            // (A -- the gradient -- may also come in rows of any length: the kernel then fetches it element by element)
-            if (((uintptr_t)e.B & 15) || e.ldb % 4 || e.ldb < ((Kin + 3) & ~3) || e.lda < e.M) return -3;
-            const bool dy_vec = !((uintptr_t)e.A & 15) && e.lda % 4 == 0 && e.lda >= ((e.M + 3) & ~3);
-            if ((size_t)e.K * e.lda * 4 >= 0x7fffffffull || (size_t)e.K * e.ldb * 4 >= 0x7fffffffull || (size_t)e.M * e.ldc * 4 >= 0x7fffffffull) return -4;
-            W2Job& j = W.j[q];
-            j.dy = e.A; j.x = e.B; j.part = e.C; j.split_stride = e.split_stride;
-            j.ldy = e.lda; j.ldx = e.ldb; j.ldp = e.ldc; j.N = e.M; j.K = Kin; j.M = e.K; j.out_scale = e.out_scale; j.hb = hb; j.dy_vec = dy_vec;
-            W.splitk[q] = splitk[q];
-            W.wg0[q + 1] = W.wg0[q] + ((e.M + 127) / 128) * ((Kin + 127) / 128) * splitk[q];
-        }
-        return mpg_wgrad2_launch(&W, (hipStream_t)stream);
-    }
     GemmGroup G;
     G.n = n;
     G.wg0[0] = 0;

@@ -67,6 +67,8 @@ class MAB(nn.Module):
                 km = y_mask if y_mask.dim() == 2 else y_mask[:, 0, :]
                 ignore = km.reshape(B * S).float().contiguous()
         x2 = x.reshape(B * L, E)
+        if x.is_cuda and ops.double_backward_on(x.device):
+            return self._forward_dd(x, y, ignore)
         if self._fused_ok(x, L, S):
             return self._fused(x, y, ignore, B, L, S)
         if x is y:   # the packed projections go to the attention core as they are (no q/k/v slices in autograd)
@@ -87,6 +89,41 @@ class MAB(nn.Module):
         out = ops.FusedDropoutFn.apply(zf, self.dropout_p, self.training)
         return out.reshape(B, L, E)
 
+
+    def _forward_dd(self, x: Tensor, y: Tensor, ignore: Optional[Tensor]) -> Tensor:
+        """The twice-differentiable form of the block (``ops.double_backward_route``: the gradient penalty's
+        ``D(interpolated)``, train.py:301-311): the five projections as ``ops.MatMulFn`` (closed under differentiation),
+        the two attention contractions per (jet, head) as broadcast products + sums, softmax / LeakyReLU / dropout / LayerNorm
+        as ATen's own -- all of whose derivative formulas are differentiable again.  A query row whose keys are ALL ignored
+        gets zero attention weights, as torch's scaled_dot_product_attention gives it (an interpolated jet attends only
+        to particles that are real in both of its endpoints, gapt/model.py:194-202 -- possibly none)."""
+        B, L, E = x.shape
+        S, H = y.shape[1], self.num_heads
+        d = E // H
+        att = self.attention
+        W, b = att.in_proj_weight, att.in_proj_bias
+        mm = ops.MatMulFn.apply
+        x2, y2 = x.reshape(B * L, E), y.reshape(B * S, E)
+        q = (mm(x2, W[:E], "nt") + b[:E]).reshape(B, L, H, d).permute(0, 2, 1, 3)            # [B, H, L, d]
+        k = (mm(y2, W[E:2 * E], "nt") + b[E:2 * E]).reshape(B, S, H, d).permute(0, 2, 1, 3)
+        v = (mm(y2, W[2 * E:], "nt") + b[2 * E:]).reshape(B, S, H, d).permute(0, 2, 1, 3)
+        s = (q.unsqueeze(3) * k.unsqueeze(2)).sum(-1) * (1.0 / d ** 0.5)                     # [B, H, L, S]
+        if ignore is not None:
+            ig = ignore.reshape(B, 1, 1, S) != 0     # (1 - mask).bool(): everything but exactly 1 is "ignore" (:194-202)
+            dead = ig.all(dim=-1, keepdim=True)
+            s = s.masked_fill(ig & ~dead, float("-inf"))
+            pr = torch.softmax(s, dim=-1) * (~dead).to(s.dtype)
+        else:
+            pr = torch.softmax(s, dim=-1)
+        o = (pr.unsqueeze(-1) * v.unsqueeze(2)).sum(3).permute(0, 2, 1, 3).reshape(B * L, E)
+        za = x2 + mm(o, att.out_proj.weight, "nt") + att.out_proj.bias
+        if self.layer_norm:
+            za = torch.nn.functional.layer_norm(za, (E,), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        z = torch.nn.functional.dropout(za, self.dropout_p, self.training)
+        zf = self.ff(z, resid=z)                                                             # (LinearNet takes its own dd form)
+        if self.layer_norm:
+            zf = torch.nn.functional.layer_norm(zf, (E,), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return torch.nn.functional.dropout(zf, self.dropout_p, self.training).reshape(B, L, E)
 
     # -- the whole block as one launch (ops.mab_forward; csrc/mab.hip) ------------------------------------------
     def _fused_ok(self, x: Tensor, L: int, S: int) -> bool:
@@ -265,7 +302,12 @@ class GAPT_D(nn.Module):
         am = None
         if self.use_mask:
             # mask = x[..., -1:] + 0.5 (:336); what the blocks need is 1 - mask = 0.5 - x[..., -1:]: one launch
-            am = _ignore_mask(0.5 - x.detach()[..., -1:])   # (no gradient flows through the mask column: :336-338, bool mask)
+            if x.is_cuda and ops.double_backward_on(x.device):
+                # interpolated jets (gradient penalty) carry fractional mask values: the reference's own order of operations,
+                # so that "exactly 1" is decided on the same roundings
+                am = _ignore_mask(1 - (x.detach()[..., -1:] + 0.5))
+            else:
+                am = _ignore_mask(0.5 - x.detach()[..., -1:])   # (no gradient flows through the mask column: :336-338, bool mask)
             x = x[..., :-1]
         x = self.input_embedding(x.contiguous())
         for sab in self.sabs:
@@ -274,7 +316,7 @@ class GAPT_D(nn.Module):
 
     def forward(self, x: Tensor, labels: Tensor = None):
         pooled, _ = self.features(x, labels)
-        head = self.fused_head() if pooled.is_cuda else None
+        head = self.fused_head() if (pooled.is_cuda and not ops.double_backward_on(pooled.device)) else None
         if head is None:
             return torch.sigmoid(self.final_fc(pooled.squeeze()))  # .squeeze() as the reference (:344)
         w, b, mean, sigmoid, p = head

@@ -4,13 +4,16 @@ Same class names, constructor keywords, ``forward`` signatures and state-dict ke
 rkansal47/MPGAN ``mpgan/model.py`` (LinearNet :11-88, MPLayer :91-384, MPNet :387-569,
 MPGenerator :572-757, MPDiscriminator :760-894), so ``setup_training.setup_mpgan`` /
 ``train.py`` / ``gen.py`` and published checkpoints work unchanged.  The arithmetic runs in
-libmpgan_amd.so (HIP, gfx950); there is no composite/CPU fallback -- option combinations the
-fused path does not cover raise ``NotImplementedError`` at construction time.
+libmpgan_amd.so (HIP, gfx950); there is no CPU fallback.
 
-Covered (= the reference's default and every published ``mp_*`` configuration, plus the k-nearest-neighbour
-graph): fully connected or ``fully_connected=False`` with ``num_knn`` / ``self_loops``, no edge features,
-``clabels=0``, ``mask_fne_np=False``, no batch/spectral norm, ``fe=[96,160,192]``, two hidden ``fn`` layers,
-``mask_c`` masking, ``dea`` pooling.
+Fused (``ops.FusedMPLayerFn``: the reference's default and every published ``mp_*`` configuration): edge network
+[96, 160, 192], two hidden node layers, fully connected or ``fully_connected=False`` with ``num_knn`` / ``self_loops``,
+and up to ``ops.EDGE_SCALARS`` scalars per edge -- the distance column of ``pos_diffs``, ``clabels``, ``mask_fne_np`` --
+plus coordinate differences (``delta_coords``, folded into the layer-1 projection); ``mask_c`` masking, ``dea`` pooling.
+Every other constructor option of the reference (more edge scalars, conditioning columns on the k-NN graph, other layer
+widths, batch / spectral norm) runs un-fused, layer by layer on the HIP GEMM (``MPLayer._forward_edges``); the few options
+the reference itself cannot run (``int_diffs``, ``mask_learn*``, ``mask_feat_bin``) raise ``NotImplementedError`` at
+construction.  ``MPLayer.fused`` says which route a layer takes.
 """
 from __future__ import annotations
 

@@ -30,11 +30,6 @@ TAG_E0, TAG_E1, TAG_E2, TAG_N0, TAG_N1, TAG_N2, TAG_GENERIC = 1, 2, 3, 4, 5, 6, 
 # Read-only configuration of the arithmetic (set before building models; not step state).
 OPTIONS = {
     "skip_masked": True,      # edge forward: skip zero-masked senders (they contribute exactly 0)
-    # grouped weight gradients dW = dy^T x of the node networks / projections: True = one-term fp16 products on 128 x 128
-    # tiles with a power-of-two unit per 128 rows of dy (csrc/wgrad2.hip); False = the generic 64 x 64 split-K GEMM, bf16
-    # hi/lo.  Measured: the launch alone 24 against 35 us, the training step no faster, the node
-    # networks' weight gradients 3e-5 .. 3e-4 instead of 1e-5 -- so it stays off
-    "wgrad_f16": False,
     # launches with more workgroups than CUs (the discriminator's real + generated batch) hand their jets out heaviest first
     # (mpg_jet_order): no effect on results, 136 -> 113 us on the 2B launches of the headline configuration
     "lpt_order": True,
@@ -275,42 +270,18 @@ class WgradBatch:
         hb = int(bias_out is not None)
         # (a ones column that would sit alone in a tile column of its own -- K a multiple of 64 -- is folded into the
         # workgroups of tile column 0 by the kernel: csrc/gemm.hip)
-        fast = self.fast_form(dy, x)
-        if fast:
-            # slices of 16 stages (512 rows): about 4k clk of MFMAs per wave, and partials a few times the outputs
-            splitk = max(1, min(64, ((M + 31) // 32 + 15) // 16))
-        else:
-            kcols = K if (hb and K % 64 == 0) else K + hb
-            tiles = ((N + 63) // 64) * ((kcols + 63) // 64)
-            splitk = max(1, min((M + 255) // 256, (WGRAD_TARGET_WGS + tiles - 1) // tiles))
+        kcols = K if (hb and K % 64 == 0) else K + hb
+        tiles = ((N + 63) // 64) * ((kcols + 63) // 64)
+        splitk = max(1, min((M + 255) // 256, (WGRAD_TARGET_WGS + tiles - 1) // tiles))
         part = torch.empty((splitk, N, K + hb), device=dy.device, dtype=torch.float32)
-        self.jobs.append((dy, x, out, out_col0, out_scale, bias_out, splitk, part, accumulate, fast))
-
-    @staticmethod
-    def fast_form(dy, x):
-        """Whether csrc/wgrad2.hip takes this product: float4 column groups of 16-byte aligned rows."""
-        if not OPTIONS["wgrad_f16"]:
-            return False
-
-        def ok(t, groups):
-            return (t.stride(1) == 1 and t.stride(0) >= t.shape[1] and t.shape[0] * t.stride(0) * 4 < 0x7fffffff and
-                    (not groups or (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 and t.stride(0) >= (t.shape[1] + 3) // 4 * 4)))
-        fast = ok(dy, False) and ok(x, True)   # (a gradient with rows of any length is fetched element by element)
-        if not fast and os.environ.get("MPG_WGRAD_DEBUG"):
-            print("wgrad: generic kernel for dy %s %s %d, x %s %s %d" % (tuple(dy.shape), dy.stride(), dy.data_ptr() % 16,
-                                                                        tuple(x.shape), x.stride(), x.data_ptr() % 16), file=sys.stderr)
-        return fast
+        self.jobs.append((dy, x, out, out_col0, out_scale, bias_out, splitk, part, accumulate))
 
     def flush(self):
-        # (a launch is one form: the one-term fp16 jobs first, whatever is left -- rows that are not float4 groups -- after)
-        ordered = [j for j in self.jobs if j[9]] + [j for j in self.jobs if not j[9]]
-        nfast = sum(1 for j in self.jobs if j[9])
-        bounds = list(range(0, nfast, GROUP_MAX)) + list(range(nfast, len(ordered), GROUP_MAX))
-        for i0 in bounds:
-            jobs = ordered[i0:min(i0 + GROUP_MAX, nfast if i0 < nfast else len(ordered))]
+        for i0 in range(0, len(self.jobs), GROUP_MAX):
+            jobs = self.jobs[i0:i0 + GROUP_MAX]
             n = len(jobs)
             gs, sk, rj = (MpgGemm * n)(), (C.c_int * n)(), (MpgReduceJob * n)()
-            for i, (dy, x, out, col0, scale, bias_out, splitk, part, acc, fast) in enumerate(jobs):
+            for i, (dy, x, out, col0, scale, bias_out, splitk, part, acc) in enumerate(jobs):
                 M, N = dy.shape
                 K = x.shape[1]
                 hb = int(bias_out is not None)
@@ -319,7 +290,6 @@ class WgradBatch:
                 g.C, g.ldc = _p(part), K + hb
                 g.M, g.N, g.K = N, K + hb, M
                 g.split_stride, g.out_scale, g.alpha, g.ones_col = N * (K + hb), scale, 0.2, hb
-                g.f16 = 2 if fast else 0
                 sk[i] = splitk
                 r = rj[i]
                 r.part, r.S, r.N, r.K, r.has_bias = _p(part), splitk, N, K, hb

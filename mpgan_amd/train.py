@@ -8,7 +8,7 @@ Mirrors the reference's ``train_D`` / ``train_G`` (train.py:398-523): losses ``l
 The gradient penalty (train.py:286-324, ``--gp``) needs a second derivative through D.  The fused ops are first-order
 only (``once_differentiable``), so the penalty's own pass D(interpolated) takes the double-backward route
 (``ops.double_backward_route``: every product an ``ops.MatMulFn`` on the HIP GEMM, the rest ATen) while D(real) and
-D(generated) stay on the fused kernels; available for the message-passing discriminator.
+D(generated) stay on the fused kernels; both discriminators (``MPDiscriminator``, ``GAPT_D``) have that route.
 
 Two pieces of work the reference does and throws away are not done (results-neutral, SURVEY.md
 section 3.1): the D step does not back-propagate into G (its gradients are zeroed before use,
@@ -279,8 +279,8 @@ def g_loss(loss: str, out: torch.Tensor) -> torch.Tensor:
     out = out.reshape(-1)
     if loss == "ls":
         return ((out - 1.0) ** 2).mean()
-    if loss == "og":
-        return -torch.log(out).clamp(min=-100.0).mean()
+    if loss == "og":   # nn.BCELoss against ones: logarithm clamped at -100, its backward's denominator at 1e-12
+        return torch.nn.functional.binary_cross_entropy(out, torch.ones_like(out))
     if loss in ("w", "hinge"):
         return -out.mean()
     raise ValueError(f"loss must be one of {LOSSES}, got {loss!r}")
@@ -297,12 +297,6 @@ class TrainStep:
                  graph_collectives: Optional[bool] = None):
         if loss not in LOSSES:
             raise ValueError(f"loss must be one of {LOSSES}, got {loss!r}")
-        if gp_lambda and not isinstance(D, MPDiscriminator):
-            # train.py:286-324: torch.autograd.grad(D(interpolated), interpolated, create_graph=True) and a backward
-            # through that gradient.  The attention blocks have first-order kernels only and no double-backward route
-            # yet -- declined here, loudly, rather than training on a penalty whose second-order terms are missing.
-            raise NotImplementedError("mpgan_amd: the gradient penalty (--gp) needs double backward through the "
-                                      "discriminator; that route exists for MPDiscriminator only")
         self.gp_lambda = float(gp_lambda)
         self.GP = torch.zeros((), device=next(G.parameters()).device)   # last penalty value (the reference's losses["gp"])
         self.fixed_alpha = None   # tests: the interpolation weights [B, 1, 1] instead of fresh uniform samples
@@ -432,7 +426,8 @@ class TrainStep:
         """``gradient_penalty`` of train.py:286-324:  gp_lambda * mean_b (|| dD(x_b)/dx_b ||_2 - 1)^2  at
         x = a real + (1 - a) generated, a ~ U[0, 1) per jet; D is called without labels, the norm runs over all
         particles and features of a jet (mask column included) with 1e-12 under the root.  D(x) runs on the
-        double-backward route, so that the penalty can be back-propagated into D's parameters."""
+        double-backward route, so that the penalty can be back-propagated into D's parameters (a discriminator that is
+        plain torch is twice differentiable as it is; the fused kernels decline a second derivative loudly)."""
         B = real.shape[0]
         alpha = self.fixed_alpha if self.fixed_alpha is not None else torch.rand(B, 1, 1, device=real.device)
         x = (alpha * real + (1 - alpha) * fake.detach()).requires_grad_(True)

@@ -40,8 +40,16 @@ def _mha(sd, prefix, x: Tensor, y: Tensor, ignore: Optional[Tensor], num_heads: 
     v = v.reshape(B, S, num_heads, d).transpose(1, 2)
     s = (q @ k.transpose(-1, -2)) / math.sqrt(d)  # [B,H,L,S]
     if ignore is not None:
-        s = s.masked_fill(ignore.reshape(B, 1, 1, S), float("-inf"))
-    pr = torch.softmax(s, dim=-1)
+        ig = ignore.reshape(B, 1, 1, S)
+        # a query row whose keys are ALL ignored: torch's scaled_dot_product_attention (>= 2.5, `_safe_softmax`; pinned here
+        # by the 2.10 goldens) returns zero attention weights for it instead of softmax(-inf, ..., -inf) = NaN.  It happens
+        # in the gradient penalty, whose interpolated jets attend only to particles real in BOTH endpoints
+        # (gapt/model.py:194-202: every mask value other than exactly 1 is "ignore").
+        dead = ig.all(dim=-1, keepdim=True)
+        s = s.masked_fill(ig & ~dead, float("-inf"))
+        pr = torch.softmax(s, dim=-1) * (~dead).to(s.dtype)
+    else:
+        pr = torch.softmax(s, dim=-1)
     o = (pr @ v).transpose(1, 2).reshape(B, L, E)
     return o @ sd[f"{prefix}.out_proj.weight"].t() + sd[f"{prefix}.out_proj.bias"]
 

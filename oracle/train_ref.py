@@ -165,15 +165,15 @@ def d_loss_ref(loss: str, out_r: Tensor, out_f: Tensor) -> Tensor:
 
 
 def gradient_penalty_ref(gp_lambda: float, sdD: Dict[str, Tensor], real: Tensor, fake: Tensor, alpha: Tensor,
-                         cfg: Optional[dict] = None, p_disc: float = 0.0, keeps=None) -> Tensor:
-    """gradient_penalty (train.py:286-324) for the message-passing discriminator:
+                         cfg: Optional[dict] = None, p_disc: float = 0.0, keeps=None, model: str = "mpgan") -> Tensor:
+    """gradient_penalty (train.py:286-324) for either discriminator (``model`` = "mpgan" / "gapt"):
     x = alpha real + (1 - alpha) fake with alpha [B, 1, 1] (:288-294); D(x) WITHOUT labels (:301);
     g = d sum(D(x)) / dx with the graph kept (:304-311); per jet || g ||_2 over all particles and features -- the
     mask column included -- with 1e-12 under the root (:316-320); gp_lambda * mean (norm - 1)^2 (:323).
     Differentiable with respect to the entries of ``sdD`` (the D step adds it to the loss, :381-384)."""
     B = real.shape[0]
     x = (alpha * real + (1 - alpha) * fake.detach()).requires_grad_(True)
-    prob = _fwd_D("mpgan", sdD, x, None, p_disc, keeps, cfg or {})
+    prob = _fwd_D(model, sdD, x, None, p_disc, keeps, cfg or {})
     g = torch.autograd.grad(prob, x, torch.ones_like(prob), create_graph=True, retain_graph=True)[0]
     norm = torch.sqrt((g.reshape(B, -1) ** 2).sum(1) + 1e-12)
     return gp_lambda * ((norm - 1) ** 2).mean()

@@ -445,9 +445,9 @@ def main():
     with open(os.path.join(REF, "train.py")) as f:
         tree = ast.parse(f.read())
     wanted = [n for n in tree.body
-              if (isinstance(n, ast.FunctionDef) and n.name in ("gradient_penalty", "calc_D_loss"))
+              if (isinstance(n, ast.FunctionDef) and n.name in ("gradient_penalty", "calc_D_loss", "calc_G_loss"))
               or (isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") in ("bce", "mse"))]
-    assert len(wanted) == 4, [getattr(n, "name", None) for n in wanted]
+    assert len(wanted) == 5, [getattr(n, "name", None) for n in wanted]
     from torch.autograd import Variable, grad as torch_grad
     ns = {"torch": torch, "Variable": Variable, "torch_grad": torch_grad}
     exec(compile(ast.Module(body=wanted, type_ignores=[]), os.path.join(REF, "train.py"), "exec"), ns)
@@ -482,6 +482,77 @@ def main():
             rec["gradD__" + k] = summarize(k, p.grad)
         np.savez_compressed(os.path.join(OUT, f"gp_step_mpgan_{loss}.npz"), **rec)
         print("gp step", loss, rec["D_loss"], rec["gp"])
+
+    # the same for the attention discriminator: gradient_penalty calls D(interpolated) on whatever D is (train.py:301);
+    # GAPT_D ends in a sigmoid for every loss (gapt/model.py:344).  nn.MultiheadAttention(need_weights=False) goes through
+    # F.scaled_dot_product_attention, and torch 2.10's CPU flash kernel has no second derivative ("derivative for
+    # aten::_scaled_dot_product_flash_attention_for_cpu_backward is not implemented"): the reference's functions are run
+    # under torch's MATH backend of that very operator (same definition, differentiable to any order).
+    from torch.nn.attention import sdpa_kernel, SDPBackend
+    for loss in ("ls", "w"):
+        dt = torch.float64
+        B, N = 8, 30
+        sys.argv = ["gen_golden", "--model", "gapt", "--disc-dropout", "0", "--loss", loss, "--gp", "10"]
+        a = st.process_args(st.parse_args())
+        Gm, Dm = st.setup_gapt(a, gen=True).to(dt), st.setup_gapt(a, gen=False).to(dt)
+        Gm.load_state_dict(init_state_dict(gapt_param_shapes(True), seed=41, dtype=dt))
+        Dm.load_state_dict(init_state_dict(gapt_param_shapes(False), seed=42, dtype=dt))
+        data, labels = synthetic_batch(B, N, seed=9, dist="uniform", dtype=dt)
+        nD = seeded((B, N, 64), 45, 0.2).to(dt)
+        Dm.train(); Gm.eval()
+        out_r = Dm(data.clone(), labels)
+        fake = Gm(nD, labels)
+        out_f = Dm(fake, labels)
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(dt)
+        try:
+            torch.manual_seed(1234)
+            alpha = torch.rand(B, 1, 1)
+            torch.manual_seed(1234)
+            with sdpa_kernel(SDPBackend.MATH):
+                D_loss, items = ns["calc_D_loss"](loss, Dm, data, fake, out_r, out_f, B, model="gapt", gp_lambda=a.gp)
+                Dm.zero_grad()
+                D_loss.backward()
+        finally:
+            torch.set_default_dtype(prev)
+        rec = dict(data=data.numpy(), labels=labels.numpy(), noise_D=nD.numpy(), alpha=alpha.numpy(), gp_lambda=a.gp,
+                   D_loss=D_loss.item(), Dr=items["Dr"], Df=items["Df"], gp=items["gp"], fake=fake.detach().numpy())
+        for k, p in Dm.named_parameters():
+            rec["gradD__" + k] = summarize(k, p.grad)
+        np.savez_compressed(os.path.join(OUT, f"gp_step_gapt_{loss}.npz"), **rec)
+        print("gp step gapt", loss, rec["D_loss"], rec["gp"])
+
+    # ------------------------------------------------------------------ 7. the four loss branches, executed from the source
+    # calc_D_loss (train.py:331-395) and calc_G_loss (:465-476) on fixed discriminator outputs [B, 1]: values and the
+    # gradients with respect to the outputs.  Outputs in (0, 1) for og / ls (a sigmoid's range; two entries at the ends,
+    # where BCELoss clamps its logarithm at -100), any sign and beyond +-1 for w / hinge (some hinge terms inactive).
+    rs = np.random.RandomState(77)
+    B = 16
+    rec = {}
+    for loss in ("og", "ls", "w", "hinge"):
+        if loss in ("og", "ls"):
+            r, f = rs.uniform(0.02, 0.98, size=(B, 1)), rs.uniform(0.02, 0.98, size=(B, 1))
+            r[0, 0], f[0, 0] = 1.0, 0.0          # log(1 - 1), log(0) of the wrong-side terms never occur; these are the exact ends
+            r[1, 0], f[1, 0] = 1e-50, 1.0 - 1e-17  # (rounds to 1.0 in fp64: log(1 - f) = -inf -> clamped)
+        else:
+            r, f = rs.normal(0, 1.5, size=(B, 1)), rs.normal(0, 1.5, size=(B, 1))
+        out_r = torch.from_numpy(r).requires_grad_(True)
+        out_f = torch.from_numpy(f).requires_grad_(True)
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float64)
+        try:
+            D_loss, items = ns["calc_D_loss"](loss, None, out_r, None, out_r, out_f, B)
+            gr, gf = torch.autograd.grad(D_loss, (out_r, out_f))
+            out_g = torch.from_numpy(f).requires_grad_(True)
+            G_loss = ns["calc_G_loss"](loss, out_g)
+            (gg,) = torch.autograd.grad(G_loss, out_g)
+        finally:
+            torch.set_default_dtype(prev)
+        rec.update({f"{loss}_out_r": r, f"{loss}_out_f": f, f"{loss}_D_loss": D_loss.item(), f"{loss}_Dr": items["Dr"],
+                    f"{loss}_Df": items["Df"], f"{loss}_dD_dr": gr.numpy(), f"{loss}_dD_df": gf.numpy(),
+                    f"{loss}_G_loss": G_loss.item(), f"{loss}_dG_df": gg.numpy()})
+        print("loss", loss, D_loss.item(), G_loss.item())
+    np.savez_compressed(os.path.join(OUT, "losses.npz"), **rec)
     return 0
 
 

@@ -122,9 +122,68 @@ def test_losses_match_oracle_definitions():
         assert abs(float(train.g_loss(loss, out[B:])) - float(T.g_loss_ref(loss, out[B:]))) < 1e-12, loss
 
 
-def test_gradient_penalty_is_declined():
+class ToyD2(torch.nn.Module):
+    """A plain-torch discriminator whose labels are optional (gradient_penalty calls D(interpolated), train.py:301)."""
+
+    def __init__(self):
+        super().__init__()
+        self.net = torch.nn.Sequential(torch.nn.Linear(4 * N, 7), torch.nn.Tanh(), torch.nn.Linear(7, 1))
+
+    def forward(self, x, labels=None):
+        return torch.sigmoid(self.net(x.reshape(x.shape[0], -1)))
+
+
+def test_gradient_penalty_host_logic_on_a_plain_torch_discriminator():
+    """``TrainStep(gp_lambda=...)`` with a discriminator that is plain torch (twice differentiable as it is): the D step's
+    gradients are those of  D_loss + gp_lambda * mean_b (||dD/dx_b|| - 1)^2  (train.py:286-324) written out directly --
+    the host logic of the penalty (interpolation, detached generated jets, create_graph, what is added to the loss)."""
     sys.path.insert(0, ROOT)
-    import pytest
     from mpgan_amd import train
-    with pytest.raises(RuntimeError, match="double backward"):
-        train.TrainStep(ToyG(), ToyD(), 4, N, latent=LAT, use_graphs=False, gp_lambda=10.0)
+    train.FlatParams.step = _torch_rmsprop
+    torch.manual_seed(5)
+    G, D = ToyG(), ToyD2()
+    B = 6
+    data, labels, nD, nG = _inputs(B)
+    ts = train.TrainStep(G, D, B, N, latent=LAT, use_graphs=False, loss="w", gp_lambda=10.0, lr_disc=0.0)
+    ts.set_batch(data, labels)
+    ts.fixed_noise = (nD, nG)
+    ts.fixed_alpha = torch.rand(B, 1, 1, generator=torch.Generator().manual_seed(1))
+    ts._seg_D()
+    got = ts.fD.grad.clone()
+    with torch.no_grad():
+        fake = G(nD, labels)
+    x = (ts.fixed_alpha * data + (1 - ts.fixed_alpha) * fake).requires_grad_(True)
+    prob = D(x)
+    (gx,) = torch.autograd.grad(prob, x, torch.ones_like(prob), create_graph=True)
+    gp = 10.0 * ((torch.sqrt((gx.reshape(B, -1) ** 2).sum(1) + 1e-12) - 1) ** 2).mean()
+    base = -D(data, labels).mean() + D(fake, labels).mean()
+    ref = torch.autograd.grad(base + gp, list(D.parameters()))
+    ref = torch.cat([r.reshape(-1) for r in ref])
+    assert abs(float(ts.GP) - float(gp)) < 1e-6 * abs(float(gp))
+    assert abs(float(ts.D_loss) - float(base)) < 1e-6
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-7), float((got - ref).abs().max())
+
+
+def test_loss_functions_vs_reference_golden():
+    """``train.d_loss`` / ``train.g_loss`` against calc_D_loss / calc_G_loss EXECUTED from the reference's source
+    (tests/golden/losses.npz): value and gradient of all four branches."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from mpgan_amd import train
+    g = np.load(os.path.join(ROOT, "tests", "golden", "losses.npz"))
+    for loss in train.LOSSES:
+        r, f = torch.from_numpy(g[f"{loss}_out_r"]), torch.from_numpy(g[f"{loss}_out_f"])
+        B = r.shape[0]
+        out = torch.cat([r, f]).requires_grad_(True)
+        L = train.d_loss(loss, out, B)
+        (go,) = torch.autograd.grad(L, out)
+        ref = float(g[f"{loss}_D_loss"])
+        assert abs(float(L) - ref) < 1e-12 * max(1.0, abs(ref)), loss
+        want = np.concatenate([g[f"{loss}_dD_dr"], g[f"{loss}_dD_df"]])
+        assert np.abs(go.numpy() - want).max() < 1e-12 * max(1.0, np.abs(want).max()), loss
+        f2 = f.clone().requires_grad_(True)
+        Lg = train.g_loss(loss, f2)
+        (gg,) = torch.autograd.grad(Lg, f2)
+        ref = float(g[f"{loss}_G_loss"])
+        assert abs(float(Lg) - ref) < 1e-12 * max(1.0, abs(ref)), loss
+        assert np.abs(gg.numpy() - g[f"{loss}_dG_df"]).max() < 1e-12 * max(1.0, np.abs(g[f"{loss}_dG_df"]).max()), loss

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import rel_err, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -133,3 +133,25 @@ def test_disc_head_fused_loss(loss, gen_step):
     assert rel_err(dy.cpu().numpy(), yr.grad.cpu().numpy()) < 1e-5
     assert rel_err(dw.cpu().numpy(), wr.grad.cpu().numpy()) < 1e-5
     assert rel_err(db.cpu().numpy(), br.grad.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("loss", ["og", "ls", "w", "hinge"])
+def test_disc_head_fused_loss_vs_reference_golden(loss):
+    """The loss branches of ``mpg_disc_head_bwd`` against calc_D_loss / calc_G_loss EXECUTED from the reference's source
+    (tests/golden/losses.npz): a head with one particle, one feature, weight 1, no activation hands the golden's
+    discriminator outputs to the loss as they are -- BCELoss's clamps at the ends of (0, 1) and inactive hinge terms included."""
+    from mpgan_amd import ops
+    g = load_golden("losses.npz")
+    r, f = g[f"{loss}_out_r"], g[f"{loss}_out_f"]
+    B = r.shape[0]
+    w, b = torch.ones(1, 1, device="cuda"), torch.zeros(1, device="cuda")
+    for gen_step in (False, True):
+        outs = f if gen_step else np.concatenate([r, f])
+        y = torch.from_numpy(outs).float().cuda().reshape(-1, 1, 1)
+        loss_out = torch.zeros((), device="cuda")
+        out, dy = ops.disc_head_loss(y, None, w, b, mean=False, sigmoid=False, p_drop=0.0, training=True, loss=loss,
+                                     n_real=B, gen_step=gen_step, count=B, loss_out=loss_out)
+        want_L = float(g[f"{loss}_G_loss"] if gen_step else g[f"{loss}_D_loss"])
+        want_g = g[f"{loss}_dG_df"] if gen_step else np.concatenate([g[f"{loss}_dD_dr"], g[f"{loss}_dD_df"]])
+        assert abs(float(loss_out) - want_L) < 1e-5 * max(1.0, abs(want_L)), (loss, gen_step)
+        assert rel_err(dy.reshape(-1).cpu().numpy(), want_g.reshape(-1)) < 1e-5, (loss, gen_step)

@@ -493,13 +493,43 @@ def test_gradient_penalty_step_vs_reference_golden(loss):
     (gx,) = torch.autograd.grad(out.sum(), x, create_graph=True)
     with pytest.raises(RuntimeError):
         (gx ** 2).sum().backward()
-    # the attention discriminator has no double-backward route: declined at construction
-    Gg, Dg = train.default_gapt(N, disc_dropout=0.0)
-    with pytest.raises(NotImplementedError):
-        train.TrainStep(Gg, Dg, B, N, gp_lambda=10.0)
 
 
-def test_gradient_penalty_under_graphs_equals_eager():
+@pytest.mark.parametrize("loss", ["ls", "w"])
+def test_gradient_penalty_step_gapt_vs_reference_golden(loss):
+    """--gp with the attention discriminator (train.py:301 calls D(interpolated) on whatever D is): loss, penalty and
+    gradients against the reference's own gradient_penalty / calc_D_loss executed on its GAPT_D (tests/gen_golden.py).
+    One jet of the golden batch attends to nothing (its two endpoints share no real particle): zero attention weights,
+    as torch gives it.  Every MAB takes its double-backward form there; D(real) / D(generated) stay on the one-launch blocks."""
+    from oracle import train_ref as T
+    from mpgan_amd import train, ops
+    g = load_golden(f"gp_step_gapt_{loss}.npz")
+    B, N = g["data"].shape[:2]
+    G, D = train.default_gapt(N, disc_dropout=0.0)
+    G.load_state_dict(T.init_state_dict(T.gapt_param_shapes(True), 41, torch.float32))
+    D.load_state_dict(T.init_state_dict(T.gapt_param_shapes(False), 42, torch.float32))
+    ts = train.TrainStep(G, D, B, N, latent=64, use_graphs=False, loss=loss, gp_lambda=float(g["gp_lambda"]), lr_disc=0.0)
+    ts.set_batch(torch.from_numpy(g["data"]).float().cuda(), torch.from_numpy(g["labels"]).float().cuda())
+    nD = torch.from_numpy(g["noise_D"]).float().cuda()
+    ts.fixed_noise = (nD, nD)
+    ts.fixed_alpha = torch.from_numpy(g["alpha"]).float().cuda()
+    ts._seg_D()
+    torch.cuda.synchronize()
+    assert abs(float(ts.GP) - float(g["gp"])) < 1e-3 * abs(float(g["gp"]))
+    assert abs(float(ts.D_loss) - (float(g["Dr"]) + float(g["Df"]))) < 1e-4 * max(abs(float(g["Dr"]) + float(g["Df"])), 1e-3)
+    assert abs(float(ts.D_loss) + float(ts.GP) - float(g["D_loss"])) < 1e-3 * abs(float(g["D_loss"]))
+    for k, p in D.named_parameters():
+        assert bool(torch.isfinite(p.grad).all()), k
+        assert summary_err(k, p.grad, g["gradD__" + k]) < 1e-3, k
+    # the one-launch block is first order: a second derivative through it fails loudly
+    x = torch.from_numpy(g["data"]).float().cuda().requires_grad_(True)
+    (gx,) = torch.autograd.grad(D(x).sum(), x, create_graph=True)
+    with pytest.raises(RuntimeError):
+        (gx ** 2).sum().backward()
+
+
+@pytest.mark.parametrize("model", ["mpgan", "gapt"])
+def test_gradient_penalty_under_graphs_equals_eager(model):
     """The --gp iteration (double-backward route inside train_D) captured into hipGraphs replays bit-identically to eager
     execution (dropout off, fixed noise and interpolation weights)."""
     from oracle.train_ref import synthetic_batch
@@ -507,16 +537,22 @@ def test_gradient_penalty_under_graphs_equals_eager():
     B, N = 8, 30
     data, labels = synthetic_batch(B, N, seed=13)
     res = []
+    lat = 32 if model == "mpgan" else 64
     for use_graphs in (False, True):
-        G, D = train.default_mpgan(N, disc_dropout=0.0, loss="w")
         from oracle import train_ref as T
-        G.load_state_dict(T.init_state_dict(T.mpgan_param_shapes(True), 41, torch.float32))
-        D.load_state_dict(T.init_state_dict(T.mpgan_param_shapes(False), 42, torch.float32))
-        ts = train.TrainStep(G, D, B, N, use_graphs=use_graphs, loss="w", gp_lambda=10.0)
+        if model == "mpgan":
+            G, D = train.default_mpgan(N, disc_dropout=0.0, loss="w")
+            shapes = T.mpgan_param_shapes
+        else:
+            G, D = train.default_gapt(N, disc_dropout=0.0)
+            shapes = T.gapt_param_shapes
+        G.load_state_dict(T.init_state_dict(shapes(True), 41, torch.float32))
+        D.load_state_dict(T.init_state_dict(shapes(False), 42, torch.float32))
+        ts = train.TrainStep(G, D, B, N, latent=lat, use_graphs=use_graphs, loss="w", gp_lambda=10.0)
         ts.set_batch(data.cuda(), labels.cuda())
         gen = torch.Generator(device="cuda").manual_seed(2)
-        ts.fixed_noise = (torch.randn(B, N, 32, device="cuda", generator=gen) * 0.2,
-                          torch.randn(B, N, 32, device="cuda", generator=gen) * 0.2)
+        ts.fixed_noise = (torch.randn(B, N, lat, device="cuda", generator=gen) * 0.2,
+                          torch.randn(B, N, lat, device="cuda", generator=gen) * 0.2)
         ts.fixed_alpha = torch.rand(B, 1, 1, device="cuda", generator=gen)
         for _ in range(2):
             ts.step()

@@ -195,6 +195,49 @@ def test_gradient_penalty_step(loss):
         assert rel_err(summarize(k, v), g["gradD__" + k]) < 1e-8, k
 
 
+@pytest.mark.parametrize("loss", ["ls", "w"])
+def test_gradient_penalty_step_gapt(loss):
+    """--gp with the attention discriminator: the reference's gradient_penalty / calc_D_loss executed on its own GAPT_D
+    (tests/gen_golden.py; torch's MATH backend of scaled_dot_product_attention, the only one with a second derivative)."""
+    g = load_golden(f"gp_step_gapt_{loss}.npz")
+    dt = torch.float64
+    sdG = T.init_state_dict(T.gapt_param_shapes(True), 41, dt)
+    sdD = {k: v.requires_grad_(True) for k, v in T.init_state_dict(T.gapt_param_shapes(False), 42, dt).items()}
+    data, labels, nD, alpha = (torch.from_numpy(g[k]) for k in ("data", "labels", "noise_D", "alpha"))
+    with torch.no_grad():
+        fake = T._fwd_G("gapt", sdG, nD, labels, data.shape[1], {})
+    assert rel_err(fake.numpy(), g["fake"]) < 1e-12
+    out_r = T._fwd_D("gapt", sdD, data, labels, 0.0, None, {})
+    out_f = T._fwd_D("gapt", sdD, fake, labels, 0.0, None, {})
+    base = T.d_loss_ref(loss, out_r, out_f)
+    assert abs(float(base) - (float(g["Dr"]) + float(g["Df"]))) < 1e-11
+    gp = T.gradient_penalty_ref(float(g["gp_lambda"]), sdD, data, fake, alpha, {}, model="gapt")
+    assert abs(float(gp) - float(g["gp"])) < 1e-10 * abs(float(g["gp"]))
+    grads = torch.autograd.grad(base + gp, list(sdD.values()))
+    for (k, _), v in zip(sdD.items(), grads):
+        assert rel_err(summarize(k, v), g["gradD__" + k]) < 1e-8, k
+
+
+@pytest.mark.parametrize("loss", ["og", "ls", "w", "hinge"])
+def test_loss_branches_vs_reference(loss):
+    """calc_D_loss (train.py:331-395) and calc_G_loss (:465-476), EXECUTED from the reference's source on fixed
+    discriminator outputs (tests/gen_golden.py section 7): values and gradients of all four branches -- BCELoss's clamp at
+    the ends of (0, 1) and inactive hinge terms included."""
+    g = load_golden("losses.npz")
+    r = torch.from_numpy(g[f"{loss}_out_r"]).requires_grad_(True)
+    f = torch.from_numpy(g[f"{loss}_out_f"]).requires_grad_(True)
+    D_loss = T.d_loss_ref(loss, r, f)
+    assert abs(float(D_loss) - float(g[f"{loss}_D_loss"])) < 1e-12 * max(1.0, abs(float(g[f"{loss}_D_loss"])))
+    gr, gf = torch.autograd.grad(D_loss, (r, f))
+    assert np.abs(gr.numpy() - g[f"{loss}_dD_dr"]).max() < 1e-12 * max(1.0, np.abs(g[f"{loss}_dD_dr"]).max())
+    assert np.abs(gf.numpy() - g[f"{loss}_dD_df"]).max() < 1e-12 * max(1.0, np.abs(g[f"{loss}_dD_df"]).max())
+    f2 = torch.from_numpy(g[f"{loss}_out_f"]).requires_grad_(True)
+    G_loss = T.g_loss_ref(loss, f2)
+    assert abs(float(G_loss) - float(g[f"{loss}_G_loss"])) < 1e-12 * max(1.0, abs(float(g[f"{loss}_G_loss"])))
+    (gg,) = torch.autograd.grad(G_loss, f2)
+    assert np.abs(gg.numpy() - g[f"{loss}_dG_df"]).max() < 1e-12 * max(1.0, np.abs(g[f"{loss}_dG_df"]).max())
+
+
 def ln_sab_shapes(E=64):
     sh = dict(T._mab_shapes("mab", E))
     for n in ("norm1", "norm2"):

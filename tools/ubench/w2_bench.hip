@@ -1,7 +1,7 @@
 // Stand-alone timing of wgrad2_kernel on the job mix of one MPLayer backward (no torch):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I include [-DMPG_W2_EXP=n] tools/ubench/w2_bench.hip -o w2_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I include -I tools/ubench [-DMPG_W2_EXP=n] tools/ubench/w2_bench.hip -o w2_bench
 //   w2_bench [rows=7680] [splitk=15] [jobs mask=63]
-#include "../../mpgan_amd/csrc/wgrad2.hip"
+#include "wgrad2.hip"
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>

@@ -1,5 +1,5 @@
 #pragma once
-// Grouped one-term fp16 weight gradients (wgrad2.hip), launched by mpg_gemm_wgrad_group when its jobs carry f16 = 2.
+// Grouped one-term fp16 weight gradients (wgrad2.hip): an experiment outside the product library.
 #include <hip/hip_runtime.h>
 #include "../../include/mpgan_amd.h"
 

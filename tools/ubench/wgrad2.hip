@@ -1,4 +1,5 @@
-// Grouped weight gradients dW[n, k] = sum_m dy[m, n] x[m, k] (the form `mpg_gemm_wgrad_group` launches with f16 = 2):
+// NOT PART OF THE PRODUCT LIBRARY (kept as a measured experiment; harness: w2_bench.hip).
+// Grouped weight gradients dW[n, k] = sum_m dy[m, n] x[m, k]:
 // one-term fp16 products, fp32 accumulation, split over the rows m.
 //
 // Why not the generic 64x64x32 split-K GEMM of gemm.hip: there both operands are k-major, so every thread fetches them
@@ -16,8 +17,8 @@
 //   * the bias gradient (column sums of dy) is added up from the fp32 values the threads hold anyway.
 // Products are dy (11 bits) x x (11 bits): the contraction runs over thousands of rows with independent roundings
 // (measured errors: DESIGN.md section 2).  x is an activation (|x| < 65504 as everywhere on the fp16 forward path).
-#include "common.h"
-#include "gemm.h"
+#include "../../mpgan_amd/csrc/common.h"
+#include "../../mpgan_amd/csrc/gemm.h"
 #include "wgrad2.h"
 
 #ifndef MPG_W2_EXP   // experiments (tools/ubench/w2_bench.hip): 1 no MFMAs, 2 no LDS traffic, 4 no global loads, 8 no partial stores
