@@ -58,6 +58,9 @@ extern "C" int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream) {
     if (!(p->alpha >= 0.f && p->alpha <= 1.f)) return -4;  // lrelu() is max(v, alpha v)
     if (!p->f16) return -8;                                // fp16 hi/lo images and activations
     if ((p->N + p->SC - 1) / p->SC > F2_LIST_MAX) return -6;  // senders per chunk (their list lives in LDS)
+    // the parked E2 fragments (10,240 bytes per block) and the sign words are addressed with 32-bit offsets behind a buffer
+    // descriptor whose record count is an int: the same limit as mpg_edge_bwd's, refused here, before anything is written
+    if (p->stageE2 != nullptr && (long long)p->B * ((p->N + 31) / 32) * p->N * 10240LL > 0x7fffffffLL) return -7;
     hipStream_t st = (hipStream_t)stream;
 #ifdef MPG_SINGLE_VARIANT  // tools/ubench/fwd_bench.hip: one dropout mode, seconds to compile
     return f2_launch<MPG_SINGLE_VARIANT>(p, st);

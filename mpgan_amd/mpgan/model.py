@@ -57,17 +57,23 @@ class SpectralNorm(nn.Module):
     def weight(self) -> Tensor:
         mod = self.module
         u, v, w = mod.weight_u, mod.weight_v, mod.weight_bar
-        # The power iteration runs out of place and the new vectors are stored through ``.data`` (as the reference does,
-        # spectral_normalization.py:31-36): an in-place ``copy_`` would bump the version of tensors autograd saved for
-        # the sigma graph of an EARLIER forward -- train_D runs D(real) and D(fake) before one backward.
+        # The power iteration runs OUT OF PLACE and sigma is built from the fresh vectors, so autograd never saves u / v
+        # themselves (train_D runs D(real) and D(fake) before one backward: writing u in place must not touch what an
+        # earlier forward saved).  The new vectors are then stored IN PLACE, at the parameters' fixed addresses: a captured
+        # hipGraph replays this very copy, so the iteration keeps accumulating across replayed steps as it does across the
+        # reference's eager ones (spectral_normalization.py:29-39) -- rebinding ``.data`` would run once, at capture time.
         with torch.no_grad():
-            un, vn = u.data, v.data
+            un, vn = u, v
             for _ in range(self.power_iterations):
                 t = torch.mv(w.t(), un)
                 vn = t / (t.norm() + 1e-12)
                 t = torch.mv(w, vn)
                 un = t / (t.norm() + 1e-12)
-        u.data, v.data = un, vn
+            if self.power_iterations > 0:
+                u.copy_(un)
+                v.copy_(vn)
+            else:
+                un, vn = u.clone(), v.clone()
         sigma = un.dot(w.mv(vn))
         return w / (sigma + 1e-12)
 
@@ -504,6 +510,11 @@ class MPDiscriminator(MPNet):
         if use_mask:
             x = x[:, :, :-1]
         njp = torch.mean(mask, dim=1) if mask_fne_np else None           # fraction of real particles, [B, 1] (:888)
+        if njp is not None and all(l.fused for l in self.mp_layers):
+            # the fused layers take the mask as data (its factor on the senders has no gradient there; nothing upstream of a
+            # mask column is ever trained: the generator's comes out of a ranking) -- consistently so: the particle count
+            # derived from it carries none either, instead of the partial gradient its columns alone would give
+            njp = njp.detach()
         return x, use_mask, mask, njp
 
     def fused_head(self):

@@ -434,6 +434,7 @@ def chain(M, layers, *, A, lda, K1, A2=None, lda2=0, a_slabs=1, a_slab_stride=0,
 
 EDGE_SCALARS = 2          # MPG_EDGE_SCALARS of include/mpgan_amd.h
 MAX_CHUNK_SENDERS_ES = 116   # ... with edge scalars (their columns take part of the list's LDS)
+PARK_BYTES_PER_BLOCK = 10240   # E2 / dZ2 of one (jet, receiver block, sender) block as fp16 fragments: 160 x 32 x 2 bytes
 MAX_CHUNK_SENDERS = 180   # mpg_edge_bwd keeps the list of a chunk's unmasked senders in LDS (csrc/edge_bwd2.hip)
 
 
@@ -550,6 +551,11 @@ class FusedMPLayerFn(torch.autograd.Function):
             order = jet_order(m1.view(B, N))
             e.order = C.c_void_p(order.data_ptr())
         need_grad = any(ctx.needs_input_grad)
+        if need_grad and B * RB * N * PARK_BYTES_PER_BLOCK > 0x7fffffff:
+            # (mpg_edge_fwd / mpg_edge_bwd return -7: the parked fragments are addressed with 32-bit offsets)
+            raise RuntimeError(f"FusedMPLayerFn: {B} jets x {N} particles park {B * RB * N * PARK_BYTES_PER_BLOCK / 2**30:.1f} GiB of "
+                               f"edge activations for the backward, beyond the kernels' 2 GiB per launch; split the batch "
+                               f"(at most {0x7fffffff // (RB * N * PARK_BYTES_PER_BLOCK)} jets per call at this size)")
         sign3 = torch.empty((B * RB * N * 192,), device=dev, dtype=torch.int32) if need_grad else None
         e.sign3 = None if sign3 is None else C.c_void_p(sign3.data_ptr())
         # E2 (the second edge layer's output) parked as fp16 fragments for the backward, which takes LeakyReLU' from its
@@ -708,8 +714,13 @@ class FusedMPLayerFn(torch.autograd.Function):
             chain(V, [dict(img=pk.ptr("W1ST"), K=2 * H1, N=F, resid=dh0[:, H3:H3 + F], out=dx)],
                   A=dap, lda=H1, K1=H1, a_slabs=SC, a_slab_stride=V * H1, A2=dc, lda2=dc.stride(0), alpha=alpha, f16=False)
             dx = dx.reshape(B, N, F)
+        dxfn = None
+        if ctx.needs_input_grad[23] and dh0.shape[1] > H3 + F:
+            # the conditioning columns appended to the node network's input (mpgan/model.py:270-276): their gradient is the
+            # tail of dh0; the x columns of xfn are the same nodes as x, whose node-path gradient is already in dx above
+            dxfn = torch.cat((torch.zeros((V, F), device=dev, dtype=torch.float32), dh0[:, H3 + F:]), dim=1).reshape(B, N, -1)
         return (dx, None, dW1, db1, dW2, db2, dW3, db3, dV1, dc1, dV2, dc2, dV3, dc3,
-                None, None, None, None, None, None, None, des, None, None)
+                None, None, None, None, None, None, None, des, None, dxfn)
 
 
 def _grad_target(t):

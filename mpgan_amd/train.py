@@ -36,12 +36,14 @@ LR = {  # setup_training.py:848-872 (lr_disc, lr_gen) per jet type for model = m
 
 
 def default_mpgan(num_particles: int = 30, disc_dropout: float = 0.5, gen_dropout: float = 0.0, device="cuda",
-                  loss: str = "ls"):
+                  loss: str = "ls", spectral_norm_gen: bool = False, spectral_norm_disc: bool = False,
+                  batch_norm_gen: bool = False, batch_norm_disc: bool = False):
     """MPGenerator / MPDiscriminator exactly as ``setup_training.setup_mpgan`` builds them from the
     reference's default arguments (setup_training.py:1195-1293, defaults :415-548); ``loss`` picks D's final
-    activation as :1250 does (none for ``w`` / ``hinge``, sigmoid otherwise)."""
-    def lin(p):
-        return {"leaky_relu_alpha": 0.2, "dropout_p": p, "batch_norm": False, "spectral_norm": False}
+    activation as :1250 does (none for ``w`` / ``hinge``, sigmoid otherwise); the four normalisation switches are
+    ``--spectral-norm-gen/-disc`` and ``--batch-norm-gen/-disc`` (:254-262 -> linear_args, :1207-1223)."""
+    def lin(p, bn=False, sn=False):
+        return {"leaky_relu_alpha": 0.2, "dropout_p": p, "batch_norm": bn, "spectral_norm": sn}
     mp_args = {"pos_diffs": False, "all_ef": False, "coords": "polarrel", "delta_coords": False, "delta_r": False,
                "int_diffs": False, "clabels": 0, "mask_fne_np": False, "fully_connected": True, "num_knn": 10,
                "self_loops": True, "sum": True}
@@ -53,12 +55,13 @@ def default_mpgan(num_particles: int = 30, disc_dropout: float = 0.5, gen_dropou
                  "mask_c": True, "mask_fne_np": False}
     G = MPGenerator(mp_iters=2, fe1_layers=None, final_activation="tanh", output_node_size=3, input_node_size=32,
                     lfc=False, lfc_latent_size=128, **common, mp_args=dict(mp_args),
-                    mp_args_first_layer={"clabels": 0}, linear_args=lin(gen_dropout), mask_args=dict(mask_args))
+                    mp_args_first_layer={"clabels": 0}, linear_args=lin(gen_dropout, batch_norm_gen, spectral_norm_gen),
+                    mask_args=dict(mask_args))
     D = MPDiscriminator(mp_iters=2, fe1_layers=None, final_activation="" if loss in ("w", "hinge") else "sigmoid",
                         input_node_size=3, dea=True,
                         dea_sum=True, fnd=[], mask_fnd_np=False, **common, mp_args=dict(mp_args),
-                        mp_args_first_layer={"clabels": 0, "all_ef": False}, linear_args=lin(disc_dropout),
-                        mask_args=dict(mask_args))
+                        mp_args_first_layer={"clabels": 0, "all_ef": False},
+                        linear_args=lin(disc_dropout, batch_norm_disc, spectral_norm_disc), mask_args=dict(mask_args))
     return G.to(device), D.to(device)
 
 
@@ -252,6 +255,16 @@ def _set_requires_grad(flat: "FlatParams", flag: bool):
         p.requires_grad_(flag)
 
 
+def _forward_writes_no_state(module: nn.Module) -> bool:
+    """No batch norm (running_mean / running_var / num_batches_tracked) and no spectral norm (weight_u / weight_v) anywhere
+    in ``module``: its forward reads parameters and buffers only."""
+    from .mpgan.model import LinearNet, SpectralNorm
+    for m in module.modules():
+        if isinstance(m, (SpectralNorm, nn.modules.batchnorm._BatchNorm)) or (isinstance(m, LinearNet) and not m.plain):
+            return False
+    return True
+
+
 LOSSES = ("ls", "og", "w", "hinge")
 
 
@@ -306,7 +319,8 @@ class TrainStep:
         # coupling (no batch norm), so one pass over the concatenated 2B jets gives the same outputs and the same
         # summed gradients as the reference's two passes -- with half the launches and twice the workgroups per
         # launch (jets have different multiplicities; more workgroups than CUs evens that out).
-        self.batch_real_fake = batch_real_fake
+        # (with batch norm in D the two passes normalise over their own B jets each: kept as the reference's two passes)
+        self.batch_real_fake = batch_real_fake and not any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in D.modules())
         self.B, self.N, self.latent = batch_size, num_particles, latent
         self.lr_disc, self.lr_gen, self.noise_std = lr_disc, lr_gen, noise_std
         self.pg, self.world = process_group, world_size
@@ -338,7 +352,12 @@ class TrainStep:
         # from an independent stream starts on those CUs (measured on one box: 104.3k -> 105.9k jets/s).  Message-passing
         # generators only: the attention blocks are one-wave-per-jet latency chains with no idle CUs to fill, and a second
         # stream beside them cost 4.7 % (650.6k -> 619.8k).  MPG_GEN_AHEAD=0 switches it off.
-        self.gen_ahead = dev.type == "cuda" and isinstance(G, MPGenerator) and os.environ.get("MPG_GEN_AHEAD", "1") != "0"
+        # Only for a generator whose forward writes NO module state: with batch norm (running statistics) or spectral norm
+        # (power-iteration vectors) the forked train-mode forward would update what the D step's eval-mode call reads on
+        # the main stream at the same time -- a race, and the reference's order the other way round (train.py:432-447 before
+        # :500-511).
+        self.gen_ahead = (dev.type == "cuda" and isinstance(G, MPGenerator) and _forward_writes_no_state(G)
+                          and os.environ.get("MPG_GEN_AHEAD", "1") != "0")
         self._side = None
         self._fake_ahead = None
         self.fixed_noise = None  # tests: (noise_D, noise_G) used instead of fresh samples
@@ -494,10 +513,13 @@ class TrainStep:
         self._seg_end()
 
     def _training_state(self):
-        """Everything an iteration changes: parameters, optimiser moments and step counters, the dropout seed, the losses."""
-        ts = [self.D_loss, self.G_loss, ops.seed_tensor(self.dev)]
+        """Everything an iteration changes: parameters, optimiser moments and step counters, the dropout seed, the losses --
+        and what a FORWARD changes: the modules' buffers (batch norm's running statistics and batch counter) and frozen
+        parameters (spectral norm's power-iteration vectors, written in place by ``SpectralNorm.weight``)."""
+        ts = [self.D_loss, self.G_loss, self.GP, ops.seed_tensor(self.dev)]
         for f in (self.fD, self.fG):
             ts += [f.flat, f.sq, f.step_count] + ([f.aux] if f.aux is not None else [])
+            ts += list(f.module.buffers()) + [p for p in f.module.parameters() if not p.requires_grad]
         return ts
 
     def capture(self, warmup: int = 3):
@@ -512,12 +534,18 @@ class TrainStep:
             if warmup:
                 saved = [t.clone() for t in self._training_state()]
                 host = (self.fD._host_steps, self.fG._host_steps)
+                # torch's generator on this device (the noise, the gradient penalty's interpolation weights and the dropout
+                # of the double-backward route draw from it): the warm-up's draws are taken back as well
+                rng = torch.cuda.get_rng_state(self.dev) if self.dev.type == "cuda" else None
             for _ in range(warmup):
                 self._eager()
             if warmup:
                 for t, v in zip(self._training_state(), saved):
                     t.copy_(v)
                 self.fD._host_steps, self.fG._host_steps = host
+                if rng is not None:
+                    torch.cuda.synchronize(self.dev)
+                    torch.cuda.set_rng_state(rng, self.dev)
                 self._refresh_packed(self.D)
                 self._refresh_packed(self.G)
         torch.cuda.current_stream(self.dev).wait_stream(s)

@@ -466,6 +466,57 @@ def test_mplayer_full_size():
         assert med < TOL, (k, [e[k] for e in all_errs])
 
 
+def test_mplayer_gradient_units_across_binades_and_zero_jets():
+    """One launch whose jets' upstream gradients span 2^-20 .. 2^+20 and include jets with an upstream gradient of exactly
+    zero (hinge-inactive jets look like that), B = 64, slope 1 (no kink: what is measured is the gradient arithmetic).
+    The data-gradient kernel works in a unit per workgroup (2^-e of its own receivers' upstream gradient) and
+    ``mpg_edge_dw`` brings the parked dZ2 of all blocks to ONE unit per launch (the minimum exponent, ``gexp``):
+      * dx of EVERY jet within the bar relative to that jet's own largest entry -- a jet 2^-40 below the launch's largest
+        keeps its full precision -- and exactly zero, finite, for the zero jets;
+      * every parameter gradient within the bar of its maximum against the fp64 oracle: the small jets' contributions may
+        vanish in the launch-wide unit (they are below 2^-24 of the sum), the large ones' may not be disturbed."""
+    import oracle
+    from oracle import train_ref as T
+    from mpgan_amd.mpgan import MPLayer
+    B, N, F, out = 64, 30, 32, 32
+    rs = np.random.RandomState(4242)
+    sd64 = T.init_state_dict(_mplayer_shapes(F, out), seed=5, dtype=torch.float64)
+    layer = MPLayer(F, [96, 160, 192], [256, 256], out, sum=True, leaky_relu_alpha=1.0).to(_dev())
+    layer.load_state_dict({k: v.float() for k, v in sd64.items()})
+    x64 = torch.from_numpy(rs.normal(0, 0.5, size=(B, N, F)))
+    m = np.zeros((B, N, 1))
+    for b in range(B):
+        m[b, rs.permutation(N)[: rs.randint(4, N + 1)], 0] = 1
+    mask64 = torch.from_numpy(m)
+    expo = rs.randint(-20, 21, size=B)
+    expo[:4] = (20, -20, 19, -19)
+    scale = 2.0 ** expo
+    scale[4:10] = 0.0                     # six jets with no upstream gradient at all
+    g64 = torch.from_numpy(rs.normal(size=(B, N, out)) * scale[:, None, None])
+    sdo = {"L." + k: v.clone().requires_grad_(True) for k, v in sd64.items()}
+    xo = x64.clone().requires_grad_(True)
+    yo = oracle.mplayer_forward(sdo, "L", xo, mask64, sum_agg=True, alpha=1.0)
+    (yo * g64).sum().backward()
+    x = x64.float().to(_dev()).requires_grad_(True)
+    y = layer(x, True, mask64.float().to(_dev()))
+    (y * g64.float().to(_dev())).sum().backward()
+    torch.cuda.synchronize()
+    dx, dxo = x.grad.double().cpu().numpy(), xo.grad.numpy()
+    assert np.isfinite(dx).all()
+    worst = 0.0
+    for b in range(B):
+        if scale[b] == 0.0:
+            assert np.abs(dx[b]).max() == 0.0, b
+        else:
+            worst = max(worst, rel_err(dx[b], dxo[b]))
+            assert rel_err(dx[b], dxo[b]) < TOL, (b, int(expo[b]), rel_err(dx[b], dxo[b]))
+    errs = {k: rel_err(p.grad.double().cpu().numpy(), sdo["L." + k].grad.numpy()) for k, p in layer.named_parameters()}
+    print("gradient units across 2^-20 .. 2^20: worst per-jet dx error", worst, "parameter gradients", errs)
+    for k, p in layer.named_parameters():
+        assert bool(torch.isfinite(p.grad).all()), k
+    _assert_smooth_bars(dict(errs, dx=worst))
+
+
 @pytest.mark.parametrize("p_drop", [0.5, 0.3])
 def test_mplayer_dropout_exact(p_drop):
     """Dropout on (training mode): the kernels' counter-based keep masks are dumped with

@@ -81,34 +81,47 @@ def test_train_step_vs_reference_golden():
     _assert_updates_match(init, {"D": dict(D.named_parameters()), "G": dict(G.named_parameters())}, g, control={"D": sdD, "G": sdG})
 
 
-def _count_update_outliers(init, nets, g, tol):
-    lin = np.r_[0, 2:66]
-    n_bad = n_all = 0
+def _count_update_outliers(init, nets, g, tol, k_excl=30.0):
+    """(entries beyond ``tol``, entries compared, entries excluded) over the 64 sampled entries of every tensor.  An entry
+    is EXCLUDED when the reference's own first-iteration gradient there (the golden's ``grad{net}__*`` summary holds the
+    same sampled positions) is within ``k_excl * tol`` of zero relative to the tensor's largest sampled gradient."""
+    n_bad = n_all = n_excl = 0
+    worst = (0.0, None)
     for net, params in nets.items():
         for k, p in params.items():
-            d_ours = (summarize(k, p.data) - summarize(k, init[(net, k)]))[lin]
-            d_ref = (g[f"post{net}__" + k] - summarize(k, init[(net, k)]))[lin]
+            d_ours = (summarize(k, p.data) - summarize(k, init[(net, k)]))[2:66]
+            d_ref = (g[f"post{net}__" + k] - summarize(k, init[(net, k)]))[2:66]
             # (the golden's initial values are the same tensors: init_state_dict is a function of name and seed;
             # fp32 rounding of the initial weights enters both differences alike)
-            scale = np.abs(d_ref[1:]).max()
-            bad = np.abs(d_ours[1:] - d_ref[1:]) > tol * scale
-            n_bad += int(bad.sum()); n_all += bad.size
-    return n_bad, n_all
+            g1 = np.abs(g[f"grad{net}__" + k][2:66])
+            keep = g1 > k_excl * tol * g1.max()
+            scale = np.abs(d_ref).max()
+            err = np.abs(d_ours - d_ref) / scale
+            bad = (err > tol) & keep
+            n_bad += int(bad.sum()); n_all += int(keep.sum()); n_excl += int((~keep).sum())
+            if keep.any() and err[keep].max() > worst[0]:
+                worst = (float(err[keep].max()), (net, k))
+    return n_bad, n_all, n_excl, worst
 
 
 def _assert_updates_match(init, nets, g, control, tol=1e-3):
     """Parameter UPDATES of two iterations against the reference's (fp64 golden), sampled entries, at the north-star
-    1e-3 of the largest update of each tensor.  RMSprop's first steps are ~ +-lr / sqrt(1 - alpha) whatever the
-    gradient's size, so where a gradient entry is within rounding of zero its SIGN decides a full-size step -- in any
-    finite arithmetic.  The yardstick is therefore the oracle's own iteration in plain fp32 (``control``: its
-    parameters after the same two iterations): entries off by more than ``tol`` may not be more than 3x as many as
-    fp32 itself shows against the golden, + 0.5 % of the sample: the count is a handful of near-zero gradient entries and
-    moves with anything that reorders a sum (measured on the MPGAN golden: 20 with the senders chunked by index, 23 chunked
-    by list position -- the same products added up in another order; fp32: 5; of 3,200)."""
-    n_bad, n_all = _count_update_outliers(init, nets, g, tol)
-    c_bad, _ = _count_update_outliers(init, {n: {k: v for k, v in control[n].items() if k in nets[n]} for n in nets}, g, tol)
-    print("update entries beyond", tol, ": HIP", n_bad, "fp32 oracle", c_bad, "of", n_all)
-    assert n_bad <= 3 * c_bad + 0.005 * n_all, (n_bad, c_bad, n_all)
+    1e-3 of the largest update of each tensor.  Two RMSprop steps move an entry by
+        -10 lr [ sign(g1) + r / sqrt(0.99 + r^2) ],   r = g2 / |g1|
+    (first step: +-lr / sqrt(1 - alpha) whatever the gradient's size).  Where g1 is within rounding of zero its SIGN decides a
+    full-size step, and a relative error eps of g1 moves the second term by about 0.2 eps of the largest update -- in ANY
+    finite arithmetic: an absolute gradient error of 1e-4 of the tensor's maximum (what plain fp32 shows on this batch) is
+    eps = 1e-4 / (|g1| / max) and stays below the bar only for |g1| above 2e-2 of the maximum.  So the entries whose reference
+    gradient is within 30 * tol of zero relative to the tensor's largest are taken out EXPLICITLY, and NO outlier is allowed on
+    the rest -- for the HIP path and, as a check of the instrument itself, for the oracle's own two iterations in plain fp32
+    (``control``).  (At 10 * tol the fp32 control itself shows 2 entries beyond the bar, worst 1.8e-3.)"""
+    n_bad, n_all, n_excl, worst = _count_update_outliers(init, nets, g, tol)
+    c_bad, _, _, c_worst = _count_update_outliers(init, {n: {k: v for k, v in control[n].items() if k in nets[n]} for n in nets}, g, tol)
+    print("update entries beyond", tol, ": HIP", n_bad, "(worst %.2e at %s)" % worst, "fp32 oracle", c_bad,
+          "(worst %.2e at %s)" % c_worst, "of", n_all, "compared,", n_excl, "excluded (near-zero reference gradient)")
+    assert n_excl < 0.35 * (n_all + n_excl), (n_excl, n_all)   # the exclusion must stay the minority
+    assert c_bad == 0, (c_bad, c_worst)
+    assert n_bad == 0, (n_bad, worst)
 
 
 def test_graph_replay_equals_eager():
@@ -249,18 +262,28 @@ def _assert_grads(module, ref, tol, control=None):
                  control=None if control is None else {k: v.detach().double().numpy() for k, v in control.items()})
 
 
-@pytest.mark.parametrize("loss", ["og", "w", "hinge"])
-def test_train_step_other_losses_vs_oracle(loss):
-    """--loss og / w / hinge (train.py:331-395, :465-476): losses and first-iteration gradients vs the oracle."""
+@pytest.mark.parametrize("loss,B,head", [("og", 8, None), ("w", 8, None), ("hinge", 8, None), ("hinge", 64, (10.0, 0.28))],
+                         ids=["og", "w", "hinge", "hinge-B64-inactive-jets"])
+def test_train_step_other_losses_vs_oracle(loss, B, head):
+    """--loss og / w / hinge (train.py:331-395, :465-476): losses and first-iteration gradients vs the oracle.
+    ``head`` = (s, shift): D's last Linear scaled and shifted (out -> s * (out - shift)) so that its outputs straddle the
+    hinge margins -- at B = 64 with (10, 0.28) the oracle finds 14 real and 3 generated jets beyond them (asserted below,
+    with the smallest distance to a margin): whole jets whose upstream gradient is EXACTLY zero ride in the same launches
+    as active ones, through the fused head, the data-gradient kernels' per-workgroup gradient units and the
+    weight-gradient kernel's launch-wide unit."""
     from oracle import train_ref as T
     from oracle.train_ref import synthetic_batch
     from mpgan_amd import train
-    B, N = 8, 30
+    N = 30
     G, D = train.default_mpgan(N, disc_dropout=0.0, loss=loss)
-    G.load_state_dict(T.init_state_dict(T.mpgan_param_shapes(True), 41, torch.float32))
-    D.load_state_dict(T.init_state_dict(T.mpgan_param_shapes(False), 42, torch.float32))
     sdG = T.init_state_dict(T.mpgan_param_shapes(True), 41, torch.float64)
     sdD = T.init_state_dict(T.mpgan_param_shapes(False), 42, torch.float64)
+    if head is not None:
+        s_, shift = head
+        sdD["fnd_layer.net.0.bias"] = sdD["fnd_layer.net.0.bias"] * s_ - s_ * shift
+        sdD["fnd_layer.net.0.weight"] = sdD["fnd_layer.net.0.weight"] * s_
+    G.load_state_dict({k: v.float() for k, v in sdG.items()})
+    D.load_state_dict({k: v.float() for k, v in sdD.items()})
     data, labels = synthetic_batch(B, N, seed=12)
     gen = torch.Generator().manual_seed(7)
     nD, nG = torch.randn(B, N, 32, generator=gen) * 0.2, torch.randn(B, N, 32, generator=gen) * 0.2
@@ -270,6 +293,15 @@ def test_train_step_other_losses_vs_oracle(loss):
     ts.set_batch(data.cuda(), labels.cuda())
     ts.fixed_noise = (nD.cuda(), nG.cuda())
     cfg = {"D": {"sigmoid": loss not in ("w", "hinge")}}
+    if head is not None:
+        with torch.no_grad():
+            fake = T._fwd_G("mpgan", sdG, nD.double(), labels.double(), N, cfg)
+            o_r = T._fwd_D("mpgan", sdD, data.double(), labels.double(), 0.0, None, cfg)
+            o_f = T._fwd_D("mpgan", sdD, fake, labels.double(), 0.0, None, cfg)
+        n_r, n_f = int(((1 - o_r) <= 0).sum()), int(((1 + o_f) <= 0).sum())
+        margin = float(torch.minimum((1 - o_r).abs().min(), (1 + o_f).abs().min()))
+        print("hinge-inactive jets: real", n_r, "generated", n_f, "of", B, "each; closest to a margin", margin)
+        assert n_r >= 4 and n_f >= 2 and n_r < B and margin > 1e-2
     ts._seg_D()
     c32 = lambda sd: {k: v.float() for k, v in sd.items()}
     _, _, cD, cG = T.train_iteration("mpgan", c32(sdD), c32(sdG), {}, {}, data.float(), labels.float(), nD.float(), nG.float(),
@@ -619,6 +651,57 @@ def test_range_guard_reports_overflowing_weight_images():
     ops.range_status(dev, clear=True)
     ts.step()
     assert ops.range_status(dev, clear=True) & 2
+
+
+def _norm_run(use_graphs, steps, gen_ahead_env=None, **norms):
+    """Parameters, power-iteration vectors and running statistics after ``steps`` iterations of a TrainStep whose networks
+    carry spectral / batch norm (the un-fused route of every layer), from fixed weights, data and noise."""
+    import os
+    from mpgan_amd import train
+    from oracle.train_ref import synthetic_batch
+    B, N = 8, 30
+    torch.manual_seed(11)
+    G, D = train.default_mpgan(N, disc_dropout=0.0, **norms)
+    data, labels = synthetic_batch(B, N, seed=5)
+    if gen_ahead_env is not None:
+        os.environ["MPG_GEN_AHEAD"] = gen_ahead_env
+    try:
+        ts = train.TrainStep(G, D, B, N, use_graphs=use_graphs, lr_disc=1e-3, lr_gen=1e-3)
+    finally:
+        os.environ.pop("MPG_GEN_AHEAD", None)
+    ts.set_batch(data.cuda(), labels.cuda())
+    gen = torch.Generator(device="cuda").manual_seed(6)
+    ts.fixed_noise = (torch.randn(B, N, 32, device="cuda", generator=gen) * 0.2,
+                      torch.randn(B, N, 32, device="cuda", generator=gen) * 0.2)
+    for _ in range(steps):
+        ts.step()
+    torch.cuda.synchronize()
+    state = {"flatD": ts.fD.flat.clone(), "flatG": ts.fG.flat.clone()}
+    for name, net in (("G", G), ("D", D)):
+        for k, v in net.state_dict().items():
+            if k.endswith(("weight_u", "weight_v", "running_mean", "running_var", "num_batches_tracked")):
+                state[f"{name}.{k}"] = v.clone()
+    return state, ts
+
+
+@pytest.mark.parametrize("norms", [dict(spectral_norm_disc=True, spectral_norm_gen=True),
+                                   dict(batch_norm_gen=True, spectral_norm_disc=True)], ids=["sn-both", "bnG-snD"])
+def test_forward_time_state_under_graphs_equals_eager(norms):
+    """Spectral norm's power iteration and batch norm's running statistics are state a FORWARD writes.  Under hipGraph replay
+    they must keep accumulating at the modules' own addresses exactly as in eager execution (the reference's
+    spectral_normalization.py:29-39 carries u / v from step to step): parameters, u / v and the running statistics after
+    three captured-and-replayed iterations are bit-identical to three eager ones, capturing (with its warm-up iterations)
+    leaves them where they were, and the generator-ahead stream stays off for such a generator (its forked forward would
+    write that state beside the D step's own generator call)."""
+    eager, ts_e = _norm_run(False, 3, **norms)
+    graphs, ts_g = _norm_run(True, 3, **norms)
+    assert not ts_e.gen_ahead and not ts_g.gen_ahead
+    assert any(k.endswith("weight_u") for k in eager)
+    for k in eager:
+        assert torch.equal(eager[k], graphs[k]), k
+    one, _ = _norm_run(True, 1, **norms)
+    moved = [k for k in eager if k.endswith(("weight_u", "running_mean")) and not torch.equal(one[k], graphs[k])]
+    assert moved, "the forward-time state did not advance between replays"
 
 
 @pytest.mark.parametrize("use_graphs,split", [(True, False), (True, True), (False, False)])
