@@ -14,8 +14,11 @@ Prints ONE JSON line on rank 0 (contract in the task description) with two extra
                    taken in this process on the launch stream
   cpu_baseline  -- the CPU oracle (own port of the reference step) timed on this box's host cores
                    on a bounded sample (rank 0, N = 1 only)
-Other workloads (``--model gapt`` = BASELINE config 4, ``--particles 150 --batch 16`` = config 5's per-GPU shard)
-print the same line under their own metric name.
+  secondary     -- (default run, --gpus 1) the two other single-GPU workloads of BASELINE.json, 20 warm-up + 100 timed
+                   iterations each in the same process: GAPT B = 512 (config 4) and MPGAN N = 150, B = 16 (config 5's
+                   per-GPU shard), each with its own value / ms_per_step / roofline
+Other workloads (``--model gapt``, ``--particles 150 --batch 16``) can also be run as the line itself: same fields under
+their own metric name.
 """
 import argparse
 import json
@@ -108,6 +111,8 @@ def parse_args():
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the GAPT B=512 and MPGAN N=150 B=16 legs that follow the headline run at --gpus 1")
     return ap.parse_args()
 
 
@@ -138,8 +143,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from mpgan_amd import train, ops, dist as mdist
-    from mpgan_amd.data import synthetic_jets
+    from mpgan_amd import dist as mdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -159,69 +163,20 @@ def main():
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     B, N = args.batch or (256 if args.model == "mpgan" else 512), args.particles
-    torch.manual_seed(4 + rank)  # setup_training.py:184 (+ rank: every rank draws its own noise)
-    if args.model == "mpgan":
-        G, D = train.default_mpgan(N, disc_dropout=0.5, device=dev)
-        latent, (lr_d, lr_g) = 32, train.LR["g"]
-    else:
-        G, D = train.default_gapt(N, disc_dropout=0.5, device=dev)
-        latent, (lr_d, lr_g) = 64, train.LR_GAPT
-    if world > 1:  # one-time parameter broadcast from rank 0
-        mdist.broadcast_module(G, 0, pg)
-        mdist.broadcast_module(D, 0, pg)
-    ts = train.TrainStep(G, D, B, N, latent=latent, lr_disc=lr_d, lr_gen=lr_g, use_graphs=not args.no_graphs,
-                         process_group=pg, world_size=world)
-    data, labels = synthetic_jets(B, N, seed=4 + rank, dist=args.dist)
-    ts.set_batch(data.to(dev), labels.to(dev))
-    ops.set_seed(mdist.rank_seed(0x5EED, rank), dev)
-    valid_frac = float((data[..., 3] > 0).float().mean())
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    log(f"rank {rank}/{world}: models built, B={B} N={N}; warm-up ({args.warmup} steps, hipGraph capture)")
-    for _ in range(args.warmup):
-        ts.step()
-    barrier()
-    log("warm-up done; timing")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ts.step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-    jets_per_s = world * B * args.steps / dt
-    log(f"timed {args.steps} steps in {dt:.3f} s -> {jets_per_s:.0f} jets/s")
-    d_loss, g_loss = float(ts.D_loss), float(ts.G_loss)
-
+    out, ts = run_workload(torch, dist, args.model, B, N, args.steps, args.warmup, dev, rank, world, pg, args.dist,
+                           not args.no_graphs, share)
     headline = args.model == "mpgan" and N == 30 and B == 256
-    out = {
-        "metric": "jets/sec (G+D step) MPGAN gluon N=30 bs=256 @1/2/4/8 MI355X" if headline
-                  else f"jets/sec (G+D step) {args.model} N={N} bs={B}",
-        "value": jets_per_s, "unit": "jets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "split-16-bit MFMA, fp32 accumulate, fp32 in/out: f16 hi/lo x3 terms (forward), f16 x2 / x1 "
-                 "terms in per-sender dithered units (edge backward: data / weight gradients), bf16 hi/lo x3 (node network "
-                 "gradients)" if args.model == "mpgan" else
-                 "split-16-bit MFMA, fp32 accumulate, fp32 in/out: f16 hi/lo x3 terms (forward), bf16 hi/lo x3 (gradients)",
-        "data": "synthetic",
-        "config": {"workload": f"{args.model.upper()} gluon-like jets, N={N} particles, B={B} per GPU, one "
-                               "train_D+train_G iteration (LSGAN, RMSprop, D dropout 0.5)",
-                   "global_batch": world * B, "particles": N, "multiplicity": args.dist,
-                   "mean_multiplicity": valid_frac * N, "parallelism": f"dp{world}", "hip_graphs": not args.no_graphs,
-                   **({"rehearsal": "all ranks share cuda:0, gloo exchange (MPGAN_BENCH_SHARE_GPU)"} if share else {})},
-        "losses": {"D": d_loss, "G": g_loss},
-    }
-    if args.model == "mpgan":
-        out["algorithmic_gflop_per_jet"] = iteration_flops_per_jet(N) / 1e9
-        out["executed_gflop_per_jet"] = executed_flops_per_jet(N, valid_frac) / 1e9
-        out["whole_step_mfma_frac"] = jets_per_s / world * iteration_flops_per_jet(N) / PEAK_MFMA_16BIT
-        out["whole_step_executed_mfma_frac"] = jets_per_s / world * executed_flops_per_jet(N, valid_frac) / PEAK_MFMA_16BIT
+    if world > 1 or pg is not None:
+        # what the exchange really was: ranks in the RCCL communicator, its version, and whether the two all-reduces sat
+        # between three hipGraph segments (default) or inside one graph (MPG_GRAPH_COLLECTIVES=1)
+        out["config"]["rccl_ranks"] = dist.get_world_size() if dist.is_initialized() else 1
+        out["config"]["collective_backend"] = dist.get_backend(pg) if dist.is_initialized() else None
+        try:
+            out["config"]["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:   # noqa: BLE001 -- informational only
+            out["config"]["rccl_version"] = None
+    out["config"]["graph_collectives"] = bool(ts.graph_collectives)
+    out["config"]["graphs_per_step"] = len(ts._graphs) if ts._graphs else 0
 
     # ------------------------------------------------------------------ roofline of the dominant kernel
     # rank 0 only, after the timed region, with the collectives switched off (the other ranks are not taking part)
@@ -229,6 +184,23 @@ def main():
         ts.world, ts.pg = 1, None
         out["roofline"], out["kernels"] = roofline(torch, ts, args.model, dev, measured_traffic=headline)
         log("roofline leg done", out["roofline"]["kernel"], out["roofline"]["frac"])
+    del ts
+
+    # ------------------------------------------------------------------ the other single-GPU workloads of BASELINE.json
+    # (config 4: GAPT B = 512; config 5's per-GPU shard: MPGAN N = 150, B = 16), same process, after the headline legs:
+    # their own value / ms_per_step / roofline under one extra key -- metric, value and config above stay the headline's
+    if rank == 0 and world == 1 and headline and not args.no_secondary:
+        out["secondary"] = {}
+        for key, (model2, B2, N2) in {"gapt_n30_b512": ("gapt", 512, 30), "mpgan_n150_b16": ("mpgan", 16, 150)}.items():
+            torch.cuda.empty_cache()
+            o2, ts2 = run_workload(torch, dist, model2, B2, N2, 100, 20, dev, 0, 1, None, args.dist, not args.no_graphs, False)
+            sec = {"metric": o2["metric"], "value": o2["value"], "unit": o2["unit"], "ms_per_step": o2["ms_per_step"],
+                   "steps": 100, "warmup": 20, "config": o2["config"], "losses": o2["losses"]}
+            if not args.no_roofline:
+                sec["roofline"], sec["kernels"] = roofline(torch, ts2, model2, dev, measured_traffic=False)
+            out["secondary"][key] = sec
+            log("secondary", key, f"{o2['value']:.0f} jets/s")
+            del ts2
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -239,6 +211,77 @@ def main():
     if world > 1:
         dist.barrier()  # rank 0 arrives after its extra legs; nobody tears the group down under it
         dist.destroy_process_group()
+
+
+def run_workload(torch, dist, model, B, N, steps, warmup, dev, rank, world, pg, mult, graphs, share):
+    """``warmup`` untimed + ``steps`` timed G+D iterations of ``model`` at B jets per GPU, N particles; returns the JSON
+    line's fields for it (value = whole-job jets/s over the MAX time over ranks) and the TrainStep."""
+    from mpgan_amd import train, ops, dist as mdist
+    from mpgan_amd.data import synthetic_jets
+    torch.manual_seed(4 + rank)  # setup_training.py:184 (+ rank: every rank draws its own noise)
+    if model == "mpgan":
+        G, D = train.default_mpgan(N, disc_dropout=0.5, device=dev)
+        latent, (lr_d, lr_g) = 32, train.LR["g"]
+    else:
+        G, D = train.default_gapt(N, disc_dropout=0.5, device=dev)
+        latent, (lr_d, lr_g) = 64, train.LR_GAPT
+    if world > 1:  # one-time parameter broadcast from rank 0
+        mdist.broadcast_module(G, 0, pg)
+        mdist.broadcast_module(D, 0, pg)
+    ts = train.TrainStep(G, D, B, N, latent=latent, lr_disc=lr_d, lr_gen=lr_g, use_graphs=graphs,
+                         process_group=pg, world_size=world)
+    data, labels = synthetic_jets(B, N, seed=4 + rank, dist=mult)
+    ts.set_batch(data.to(dev), labels.to(dev))
+    ops.set_seed(mdist.rank_seed(0x5EED, rank), dev)
+    valid_frac = float((data[..., 3] > 0).float().mean())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    log(f"rank {rank}/{world}: {model} built, B={B} N={N}; warm-up ({warmup} steps, hipGraph capture)")
+    for _ in range(warmup):
+        ts.step()
+    barrier()
+    log("warm-up done; timing")
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ts.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    jets_per_s = world * B * steps / dt
+    log(f"timed {steps} steps in {dt:.3f} s -> {jets_per_s:.0f} jets/s")
+    d_loss, g_loss = float(ts.D_loss), float(ts.G_loss)
+
+    headline = model == "mpgan" and N == 30 and B == 256
+    out = {
+        "metric": "jets/sec (G+D step) MPGAN gluon N=30 bs=256 @1/2/4/8 MI355X" if headline
+                  else f"jets/sec (G+D step) {model} N={N} bs={B}",
+        "value": jets_per_s, "unit": "jets/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "split-16-bit MFMA, fp32 accumulate, fp32 in/out: f16 hi/lo x3 terms (forward), f16 x2 / x1 "
+                 "terms in per-sender dithered units (edge backward: data / weight gradients), bf16 hi/lo x3 (node network "
+                 "gradients)" if model == "mpgan" else
+                 "split-16-bit MFMA, fp32 accumulate, fp32 in/out: f16 hi/lo x3 terms (forward), bf16 hi/lo x3 (gradients)",
+        "data": "synthetic",
+        "config": {"workload": f"{model.upper()} gluon-like jets, N={N} particles, B={B} per GPU, one "
+                               "train_D+train_G iteration (LSGAN, RMSprop, D dropout 0.5)",
+                   "global_batch": world * B, "particles": N, "multiplicity": mult,
+                   "mean_multiplicity": valid_frac * N, "parallelism": f"dp{world}", "hip_graphs": graphs,
+                   **({"rehearsal": "all ranks share cuda:0, gloo exchange (MPGAN_BENCH_SHARE_GPU)"} if share else {})},
+        "losses": {"D": d_loss, "G": g_loss},
+    }
+    if model == "mpgan":
+        out["algorithmic_gflop_per_jet"] = iteration_flops_per_jet(N) / 1e9
+        out["executed_gflop_per_jet"] = executed_flops_per_jet(N, valid_frac) / 1e9
+        out["whole_step_mfma_frac"] = jets_per_s / world * iteration_flops_per_jet(N) / PEAK_MFMA_16BIT
+        out["whole_step_executed_mfma_frac"] = jets_per_s / world * executed_flops_per_jet(N, valid_frac) / PEAK_MFMA_16BIT
+    return out, ts
 
 
 # --------------------------------------------------------------------------- roofline leg

@@ -596,10 +596,28 @@ def test_mplayer_options_vs_reference_golden(case, route):
     layer.load_state_dict(T.init_state_dict(option_case_shapes(F, out, kw), seed=int(g["seed"]), dtype=torch.float32))
     x = torch.from_numpy(g["x"]).float().cuda().requires_grad_(True)
     mask = torch.from_numpy(g["mask"]).float().cuda() if "mask" in g else None
-    y = layer(x, mask is not None, mask, torch.from_numpy(g["labels"]).float().cuda(), torch.from_numpy(g["njp"]).float().cuda())
+    labels = torch.from_numpy(g["labels"]).float().cuda().requires_grad_(True)
+    njp = torch.from_numpy(g["njp"]).float().cuda().requires_grad_(True)
+    y = layer(x, mask is not None, mask, labels, njp)
     (y * torch.from_numpy(g["g"]).float().cuda()).sum().backward()
     assert rel_err(y.detach().cpu().numpy(), g["y"]) < TIGHT, name
     assert rel_err(x.grad.cpu().numpy(), g["dx"]) < TOL, name
+    if layer.clabels or layer.mask_fne_np:
+        # the conditioning inputs get their FULL gradient on either route: through their columns of the edge network (per-edge
+        # gathers) and through the columns appended to the node network's input (mpgan/model.py:247-253, :270-276) -- against
+        # the oracle (which the goldens pin on this very case)
+        from conftest import option_case_oracle_kwargs
+        from oracle.mpgan_ref import mplayer_forward_general
+        sd64 = {"L." + k: v for k, v in T.init_state_dict(option_case_shapes(F, out, kw), seed=int(g["seed"]), dtype=torch.float64).items()}
+        lab64 = torch.from_numpy(g["labels"]).requires_grad_(True)
+        njp64 = torch.from_numpy(g["njp"]).requires_grad_(True)
+        yo = mplayer_forward_general(sd64, "L", torch.from_numpy(g["x"]), None if mask is None else torch.from_numpy(g["mask"]),
+                                     lab64, njp64, **option_case_oracle_kwargs(kw))
+        (yo * torch.from_numpy(g["g"])).sum().backward()
+        if layer.clabels:
+            assert rel_err(labels.grad.cpu().numpy(), lab64.grad.numpy()) < TOL, name
+        if layer.mask_fne_np:
+            assert rel_err(njp.grad.cpu().numpy(), njp64.grad.numpy()) < TOL, name
     from conftest import summary_err
     for k, p in layer.named_parameters():   # (the summaries' sum entry against the tensor's l1: conftest.summary_err)
         assert summary_err(k, p.grad, g["grad__" + k]) < TOL, (name, k)
