@@ -53,6 +53,11 @@ class DeviceState:
                     ``torch.autograd.grad``, hooks or anything else needs the gradients as autograd values)
     deferred_wgrad  a ``WgradBatch`` that collects the stand-alone Linear layers' weight gradients of the
                     backward in flight (``TrainStep`` flushes it as grouped launches), or None
+    wgrad_stream    a second stream for the launches that only produce WEIGHT gradients (``mpg_edge_dw`` + its reduction, the
+                    grouped node-network weight gradients): nothing reads them before the optimizer, so ``FusedMPLayerFn.backward``
+                    forks them off behind ``mpg_edge_bwd`` and goes on with the data gradients; ``TrainStep`` sets it around a
+                    backward and joins before the optimizer step / all-reduce.  ``wgrad_keep`` holds every tensor those
+                    launches touch until the join (the allocator must not hand their memory to main-stream work meanwhile)
     double_backward modules built while it is set (``double_backward_route``) take the route whose backward is itself
                     differentiable: the gradient penalty's ``torch.autograd.grad(..., create_graph=True)`` (train.py:304-311)
     """
@@ -64,6 +69,8 @@ class DeviceState:
         self.last_tag = 0
         self.grad_into_param = False
         self.deferred_wgrad = None
+        self.wgrad_stream = None
+        self.wgrad_keep = []
         self.double_backward = False
         self._status = None
 
@@ -666,6 +673,12 @@ class FusedMPLayerFn(torch.autograd.Function):
         da = dap[0] if SC == 1 else dap.sum(0)
         dc = dcp[0] if RB == 1 else dcp.sum(0)
         dW1 = db1 = dW2 = db2 = dW3 = db3 = None
+        # The weight-gradient launches below feed nothing before the optimizer: with a side stream set (TrainStep) they are
+        # forked off here, behind the data-gradient kernel that produced their inputs, and this stream goes straight on
+        # to dx and the layers below.  Same launches, same order per parameter: results are bit-identical.
+        st_dev = dev_state(dev)
+        side = st_dev.wgrad_stream if (need_w and direct and es is None) else None
+        main = torch.cuda.current_stream(dev) if side is not None else None
         if need_w:
             nwg = dw_workgroups(nblk, N)
             part = torch.empty((nwg, H3 * H2 + H2 * H1 + H3 + H2), device=dev, dtype=torch.float32)
@@ -688,8 +701,6 @@ class FusedMPLayerFn(torch.autograd.Function):
             d.f16 = int(f16)
             if es is not None:
                 d.es, d.wq = _p(es), _p(wq)
-            check(_lib.lib().mpg_edge_dw(C.byref(d), _stream()), "mpg_edge_dw")
-            del stZ2
             # layer 1 (fe.net.0): a = W1[:, :F] x + b1, c = W1[:, F:] x
             if direct:
                 dW1, db1 = gW1, gb1
@@ -698,7 +709,18 @@ class FusedMPLayerFn(torch.autograd.Function):
                 db1 = torch.empty(H1, device=dev, dtype=torch.float32)
             wb.add(da, x2, out=dW1, out_col0=0, bias_out=db1, accumulate=direct)
             wb.add(dc, x2, out=dW1, out_col0=F, accumulate=direct)
-            wb.flush()
+            if side is not None:
+                # everything these launches read or write stays referenced until TrainStep joins the stream
+                st_dev.wgrad_keep.append((ac, m1, dh0, sign3, stE2, stZ2, gexp, part, da, dc, dap, dcp, x2, xf2, agg, h1, h2,
+                                          dz1, dz2, dz3, gy2, nbr, [j[7] for j in wb.jobs]))
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    check(_lib.lib().mpg_edge_dw(C.byref(d), _stream()), "mpg_edge_dw")
+                    wb.flush()
+            else:
+                check(_lib.lib().mpg_edge_dw(C.byref(d), _stream()), "mpg_edge_dw")
+                wb.flush()
+            del stZ2
             if es is not None:   # the columns of the edge scalars: sum over receivers of daq
                 dWq = daq.sum((0, 1))[:nq].t()
                 if direct:
@@ -715,12 +737,12 @@ class FusedMPLayerFn(torch.autograd.Function):
                   A=dap, lda=H1, K1=H1, a_slabs=SC, a_slab_stride=V * H1, A2=dc, lda2=dc.stride(0), alpha=alpha, f16=False)
             dx = dx.reshape(B, N, F)
         dxfn = None
-        if ctx.needs_input_grad[23] and dh0.shape[1] > H3 + F:
+        if len(ctx.needs_input_grad) > 23 and ctx.needs_input_grad[23] and dh0.shape[1] > H3 + F:
             # the conditioning columns appended to the node network's input (mpgan/model.py:270-276): their gradient is the
             # tail of dh0; the x columns of xfn are the same nodes as x, whose node-path gradient is already in dx above
             dxfn = torch.cat((torch.zeros((V, F), device=dev, dtype=torch.float32), dh0[:, H3 + F:]), dim=1).reshape(B, N, -1)
         return (dx, None, dW1, db1, dW2, db2, dW3, db3, dV1, dc1, dV2, dc2, dV3, dc3,
-                None, None, None, None, None, None, None, des, None, dxfn)
+                None, None, None, None, None, None, None, des, None, dxfn)[:len(ctx.needs_input_grad)]
 
 
 def _grad_target(t):

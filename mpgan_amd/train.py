@@ -360,6 +360,13 @@ class TrainStep:
                           and os.environ.get("MPG_GEN_AHEAD", "1") != "0")
         self._side = None
         self._fake_ahead = None
+        # The launches that only produce weight gradients (mpg_edge_dw + reduction, the grouped node-network weight
+        # gradients: about a quarter of the step) feed nothing before the optimizer: they run on a second side stream, forked
+        # per layer behind mpg_edge_bwd and joined at the end of the backward (before the all-reduce / optimizer step), so
+        # that they start on CUs the one-round data-gradient launches leave idle and their launch boundaries stop
+        # serialising with the data path.  MPG_WGRAD_SIDE=0 switches it off.
+        self.wgrad_side = dev.type == "cuda" and os.environ.get("MPG_WGRAD_SIDE", "1") != "0"
+        self._wside = None
         self.fixed_noise = None  # tests: (noise_D, noise_G) used instead of fresh samples
         self._seen_versions = (self.fD.versions(), self.fG.versions())
 
@@ -460,11 +467,20 @@ class TrainStep:
         """root.backward(grad) with the stand-alone Linear layers' weight gradients collected and issued as grouped
         launches that add straight into the flat gradient buffers."""
         self.state.deferred_wgrad = ops.WgradBatch()
+        if self.wgrad_side:
+            if self._wside is None:
+                self._wside = torch.cuda.Stream(device=self.dev)
+            self.state.wgrad_stream = self._wside
         try:
             torch.autograd.backward([root], None if grad is None else [grad])
             self.state.deferred_wgrad.flush()
         finally:
             self.state.deferred_wgrad = None
+            if self.wgrad_side:
+                # join: the weight gradients are complete before whatever follows the backward (all-reduce, optimizer step)
+                self.state.wgrad_stream = None
+                torch.cuda.current_stream(self.dev).wait_stream(self._wside)
+                self.state.wgrad_keep.clear()
 
     @staticmethod
     def _refresh_packed(module: nn.Module):
