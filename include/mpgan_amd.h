@@ -174,6 +174,19 @@ typedef struct MpgEdgeFwd {
 #define MPG_EDGE_SCALARS 2
 int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream);
 
+/* mpg_edge_fwd_fn: mpg_edge_fwd with the node network as the EPILOGUE of every workgroup -- one launch for
+ *   A = fe(cat(x_i, x_j)) ; A * mask ; sum / mean ; x = fn(cat((A, x)))       (mpgan/model.py:256-279)
+ * The workgroup that has aggregated a jet's 32 receivers runs the three layers of `fn` (the chain `c`, as mpg_chain takes
+ * it) on them straight from LDS; agg reaches memory only as a by-product (p->agg, for fn.net.0's weight gradient; NULL =
+ * not kept).  `c` is the chain mpg_chain would be given for the same call -- K1 = 192 columns of agg (c->A is not read:
+ * the rows come from the kernel) followed by the node columns c->A2 [B*N, K - 192], three layers, outputs and dropout
+ * sites as there -- and the results are bit-identical to mpg_edge_fwd followed by mpg_chain.
+ * Covered: SC = 1, no edge scalars, fp16 images, layer widths K <= 224 -> N0, N1 in (224, 256] -> any N2 <= 256, no
+ * gates / residuals / input dropout, one dropout mode for all sites.  Anything else returns MPG_FN_NA without
+ * launching: the caller then runs the two launches. */
+#define MPG_FN_NA (-100)
+int mpg_edge_fwd_fn(const MpgEdgeFwd* p, const MpgChain* c, void* stream);
+
 /* mpg_knn_sets: the neighbour sets of MPLayer._getA_knn (mpgan/model.py:319-381) as bit masks for the fused edge kernels.
  * Per jet: d(i, j) = || s_j x_j - x_i + 1e-12 || over the F node features, s_j = (1 - 1e4) mask_j + 1e4 (:333-335: 1 for
  * a real sender, 1e4 for a zero-masked one); the senders of receiver i are those of rank [first, first + k) in ascending distance

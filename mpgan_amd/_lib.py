@@ -162,6 +162,8 @@ class MpgMab(C.Structure):
     ]
 
 
+MPG_FN_NA = -100   # mpg_edge_fwd_fn: "not one of my shapes" (include/mpgan_amd.h)
+
 # name -> (restype, argtypes); kept in step with include/mpgan_amd.h (tests check the symbol list)
 SIGNATURES = {
     "mpg_gemm": (C.c_int, [C.POINTER(MpgGemm), C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -175,6 +177,7 @@ SIGNATURES = {
     "mpg_pack_many": (C.c_int, [C.POINTER(MpgPackJob), C.c_int, C.c_void_p]),
     "mpg_chain": (C.c_int, [C.POINTER(MpgChain), C.c_void_p]),
     "mpg_edge_fwd": (C.c_int, [C.POINTER(MpgEdgeFwd), C.c_void_p]),
+    "mpg_edge_fwd_fn": (C.c_int, [C.POINTER(MpgEdgeFwd), C.POINTER(MpgChain), C.c_void_p]),
     "mpg_edge_bwd": (C.c_int, [C.POINTER(MpgEdgeBwd), C.c_void_p]),
     "mpg_edge_dw": (C.c_int, [C.POINTER(MpgEdgeDw), C.c_void_p]),
     "mpg_attn_fwd": (C.c_int, [C.POINTER(MpgAttn), C.c_void_p]),

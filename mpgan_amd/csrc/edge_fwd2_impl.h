@@ -28,6 +28,7 @@
 // backward's recomputation of layer 2 repeats bit for bit.
 #pragma once
 #include "edge_common.h"
+#include "chain2_impl.h"
 
 #ifndef MPG_EXP
 #define MPG_EXP 0  // experiment bits (tools/ubench/fwd_bench.hip): 1 streamed fragments all from k-step 0 (L1 hits)
@@ -62,8 +63,16 @@ MPG_DEV f32x16 f2_mma(const f16x8 a, const f16x8 b, const f32x16 c) { return __b
 // DROP: 0 off, 1 byte-threshold dropout, 2 one-bit (p = 1/2) dropout.  SIGN: also write the per-lane sign words of Z3 the
 // backward needs (a run-time test here would put a branch after every accumulator register).
 // NQ: edge scalars per edge (0, or MPG_EDGE_SCALARS: Z1 = a_i + c_j + sum_q es(i, j, q) wq[q])
-template <int DROP, bool SIGN, int NQ>
-__global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
+// FN: 0 = agg goes to memory; 1 / 2 = the node network fn (mpgan/model.py:268-279: cat((agg, x)) -> three layers) runs as
+// this workgroup's EPILOGUE on the 32 receivers it has just aggregated -- their agg rows never leave the CU as operands
+// (agg itself is still written when a backward will need it) -- with chain2's schedule (chain2_impl.h; 2: the last layer's
+// rows are not whole 16-byte groups).  Needs the whole jet in one workgroup (SC = 1).
+constexpr int F2_RED_BYTES = 4 * T3 * 16 * 64 * 4;      // the four waves' partial sums: 98,304
+constexpr int F2_FN_FB0 = F2_RED_BYTES;                 // fn's input fragments are laid down beside them ...
+constexpr int F2_FN_BIAS = F2_FN_FB0 + C2_FB;           // ... its second fragment buffer over them, once they are dead
+
+template <int DROP, bool SIGN, int NQ, int FN>
+MPG_DEV void edge_fwd_body(const MpgEdgeFwd& p, const MpgChain* const cp) {
     typedef f16x8 V;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -405,14 +414,83 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) red[((w * T3 + m) * 16 + k) * 64 + lane] = agg[m][k];
     __syncthreads();
-    float* out = p.agg + ((size_t)sc * p.B + b) * p.N * H3;
-    for (int e = tid; e < T3 * 16 * 64; e += 256) {
-        const int ln = e & 63, k = (e >> 6) & 15, m = e >> 10;
-        const float sum = red[e] + red[e + T3 * 1024] + red[e + 2 * T3 * 1024] + red[e + 3 * T3 * 1024];
-        const int ii = rb * 32 + (ln & 31);
-        const int f = 32 * m + 8 * (k >> 2) + 4 * (ln >> 5) + (k & 3);
-        if (ii < p.N) out[(size_t)ii * H3 + f] = sum * p.agg_scale;
+    if constexpr (FN == 0) {
+        float* out = p.agg + ((size_t)sc * p.B + b) * p.N * H3;
+        for (int e = tid; e < T3 * 16 * 64; e += 256) {
+            const int ln = e & 63, k = (e >> 6) & 15, m = e >> 10;
+            const float sum = red[e] + red[e + T3 * 1024] + red[e + 2 * T3 * 1024] + red[e + 3 * T3 * 1024];
+            const int ii = rb * 32 + (ln & 31);
+            const int f = 32 * m + 8 * (k >> 2) + 4 * (ln >> 5) + (k & 3);
+            if (ii < p.N) out[(size_t)ii * H3 + f] = sum * p.agg_scale;
+        }
+    } else {
+        // ---- the node network on these 32 receivers.  Registers 8s .. 8s+7 of accumulator tile m ARE the B fragment of
+        //      k-step 2m + s of fn's first layer (same chain layout): wave w sums k-steps w, w + 4, w + 8 of the four waves'
+        //      partials in the order of the plain path, times agg_scale -- the very fp32 values that path writes and
+        //      chain2 reads back, so both routes give the same bits -- and lays them down as hi/lo fragments beside the
+        //      partials; the x columns (k-steps 12, 13) come from memory.
+        static_assert(F2_FN_BIAS + C2_BIAS * 4 <= F2_LDS_BYTES, "fn's buffers must fit the edge kernel's LDS");
+        const MpgChain& c = *cp;
+        const int m0 = b * p.N + rb * 32, nrows = min(32, p.N - rb * 32);
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        auto stage = [&](auto&& first_tile, auto&& bias_request, auto&& bias_store, const uint32_t, const uint32_t, const float ascale) {
+            first_tile(I0{});   // (every register of the sender loop is free: the first weight tile is on its way during the staging)
+            bias_request();
+            V* fb = reinterpret_cast<V*>(smem + F2_FN_FB0);
+            const __amdgpu_buffer_rsrc_t ragg = __builtin_amdgcn_make_buffer_rsrc(p.agg, 0, p.agg != nullptr ? p.B * p.N * (H3 * 4) : 0, 0x00020000);
+            const int rowoff = vi ? (b * p.N + i) * (H3 * 4) : -1;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int ks = w + 4 * q, mm = ks >> 1, s2 = ks & 1;
+                float av[8], v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = (mm * 16 + 8 * s2 + j) * 64 + lane;
+                    const float sum = red[e] + red[e + T3 * 1024] + red[e + 2 * T3 * 1024] + red[e + 3 * T3 * 1024];
+                    av[j] = sum * p.agg_scale;
+                    v[j] = av[j] * ascale;
+                }
+                // features 32 mm + 16 s2 + 4 h + {0..3} and + 8: two 16-byte stores of the receiver's agg row (kept for the
+                // backward: fn.net.0's weight gradient; a NULL agg has an empty descriptor and the stores are dropped)
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        f2_u32x4{__builtin_bit_cast(uint32_t, av[4 * half]), __builtin_bit_cast(uint32_t, av[4 * half + 1]),
+                                 __builtin_bit_cast(uint32_t, av[4 * half + 2]), __builtin_bit_cast(uint32_t, av[4 * half + 3])},
+                        ragg, vi ? rowoff + (32 * mm + 16 * s2 + 8 * half + 4 * h) * 4 : -1, 0, 0);
+                V hi, lo;
+                split8(v, hi, lo);
+                fb[(ks * 2 + 0) * 64 + lane] = hi;
+                fb[(ks * 2 + 1) * 64 + lane] = lo;
+            }
+            if (w < 2) {   // the x columns [192, K) of cat((agg, x)): k-steps 12 and 13
+                const int ks = 12 + w, KX = c.L[0].K - H3;
+                const float* xr = c.A2 + (size_t)(m0 + r) * c.lda2;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int f = 16 * w + 8 * (j >> 2) + 4 * h + (j & 3);
+                    v[j] = (vi && f < KX) ? xr[f] * ascale : 0.f;
+                }
+                V hi, lo;
+                split8(v, hi, lo);
+                fb[(ks * 2 + 0) * 64 + lane] = hi;
+                fb[(ks * 2 + 1) * 64 + lane] = lo;
+            }
+            first_tile(I1{});
+            bias_store();
+        };
+        c2_body<true, 14, 16, 16, DROP, 0, 0, FN == 2>(c, m0, nrows, smem + F2_FN_FB0, smem, reinterpret_cast<float*>(smem + F2_FN_BIAS), stage);
     }
+}
+
+template <int DROP, bool SIGN, int NQ>
+__global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) { edge_fwd_body<DROP, SIGN, NQ, 0>(p, nullptr); }
+
+template <int DROP, bool SIGN, bool SL>
+__global__ __launch_bounds__(256, 1) void edge_fwd_fn_kernel(const MpgEdgeFwd p, const MpgChain c) {
+    edge_fwd_body<DROP, SIGN, 0, SL ? 2 : 1>(p, &c);
 }
 
 // the SIGN pair of one dropout mode and edge-scalar count (the combinations compile as separate translation units: edge.hip,
@@ -427,6 +505,21 @@ int f2_launch(const MpgEdgeFwd* p, hipStream_t st) {
     } else {
         MPG_ENSURE_LDS((edge_fwd_kernel<D, false, NQ>), F2_LDS_BYTES);
         hipLaunchKernelGGL((edge_fwd_kernel<D, false, NQ>), grid, block, F2_LDS_BYTES, st, *p);
+    }
+    return (int)hipGetLastError();
+}
+
+// the fused forward + node network of one dropout mode / SIGN (edge_fwd_fn_*.hip: one translation unit each)
+template <int D, bool SIGN>
+int f2_launch_fn(const MpgEdgeFwd* p, const MpgChain* c, bool sl, hipStream_t st) {
+    const int RB = (p->N + 31) / 32;
+    dim3 grid(p->B * RB), block(256);
+    if (sl) {
+        MPG_ENSURE_LDS((edge_fwd_fn_kernel<D, SIGN, true>), F2_LDS_BYTES);
+        hipLaunchKernelGGL((edge_fwd_fn_kernel<D, SIGN, true>), grid, block, F2_LDS_BYTES, st, *p, *c);
+    } else {
+        MPG_ENSURE_LDS((edge_fwd_fn_kernel<D, SIGN, false>), F2_LDS_BYTES);
+        hipLaunchKernelGGL((edge_fwd_fn_kernel<D, SIGN, false>), grid, block, F2_LDS_BYTES, st, *p, *c);
     }
     return (int)hipGetLastError();
 }

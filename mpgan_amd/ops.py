@@ -33,6 +33,9 @@ OPTIONS = {
     # launches with more workgroups than CUs (the discriminator's real + generated batch) hand their jets out heaviest first
     # (mpg_jet_order): no effect on results, 136 -> 113 us on the 2B launches of the headline configuration
     "lpt_order": True,
+    # the node network fn as the epilogue of the fused edge forward (mpg_edge_fwd_fn: one launch instead of two, same bits);
+    # False = mpg_edge_fwd followed by mpg_chain
+    "fn_epilogue": os.environ.get("MPG_FN_EPILOGUE", "1") != "0",
 }
 NUM_CUS = 256
 # Forward products (they decide LeakyReLU signs) are split as fp16 hi/lo with the operand scales below (~2^-21 per
@@ -406,10 +409,16 @@ class PackedMPLayer:
         return C.c_void_p(self.img[name].data_ptr())
 
 
-def chain(M, layers, *, A, lda, K1, A2=None, lda2=0, a_slabs=1, a_slab_stride=0, in_gate=None, in_out=None,
-          alpha=0.2, seed_t=None, f16=False, ascale=1.0):
+def chain(M, layers, **kw):
     """mpg_chain front-end.  ``layers``: dicts with img, K, N and optionally bias, nbias, act, drop=(tag,thr,scale),
     gate=(H, act, tag, thr, scale), out (tensor [M, >=N]), wscale (the image holds wscale * W)."""
+    c = chain_struct(M, layers, **kw)
+    check(_lib.lib().mpg_chain(C.byref(c), _stream()), "mpg_chain")
+
+
+def chain_struct(M, layers, *, A, lda, K1, A2=None, lda2=0, a_slabs=1, a_slab_stride=0, in_gate=None, in_out=None,
+                 alpha=0.2, seed_t=None, f16=False, ascale=1.0):
+    """The ``MpgChain`` argument block of ``chain`` (also what ``mpg_edge_fwd_fn`` takes for its epilogue)."""
     c = MpgChain()
     c.A, c.lda, c.K1 = _p(A), lda, K1
     c.A2, c.lda2 = _p(A2), lda2
@@ -436,7 +445,7 @@ def chain(M, layers, *, A, lda, K1, A2=None, lda2=0, a_slabs=1, a_slab_stride=0,
             L.resid, L.ldr = _p(d["resid"]), d["resid"].stride(0)
         if d.get("out") is not None:
             L.out, L.ldo = _p(d["out"]), d["out"].stride(0)
-    check(_lib.lib().mpg_chain(C.byref(c), _stream()), "mpg_chain")
+    return c
 
 
 EDGE_SCALARS = 2          # MPG_EDGE_SCALARS of include/mpgan_amd.h
@@ -569,10 +578,8 @@ class FusedMPLayerFn(torch.autograd.Function):
         # signs instead of recomputing the layer, and for the weight-gradient kernel
         stE2 = torch.empty((B * RB * N, H2, 32), device=dev, dtype=torch.float16) if need_grad else None
         e.stageE2 = None if stE2 is None else C.c_void_p(stE2.data_ptr())
-        check(_lib.lib().mpg_edge_fwd(C.byref(e), _stream()), "mpg_edge_fwd")
-        agg = aggp[0] if SC == 1 else aggp.sum(0)
-
-        # node network fn: three chained layers, one launch
+        # node network fn: three chained layers -- as the epilogue of the edge launch where that form covers the call
+        # (mpg_edge_fwd_fn: a whole jet per workgroup, the default widths), else one more launch
         xf2 = x2
         if xfn is not None:
             xf2 = xfn.detach().reshape(V, -1)
@@ -580,13 +587,28 @@ class FusedMPLayerFn(torch.autograd.Function):
                 xf2 = xf2.contiguous()
         assert V1.shape[1] == H3 + xf2.shape[1]
         n1, n2 = V1.shape[0], V2.shape[0]
-        h1 = torch.empty((V, n1), device=dev, dtype=torch.float32)
-        h2 = torch.empty((V, n2), device=dev, dtype=torch.float32)
+        # (what only a backward reads -- agg for fn.net.0's weight gradient, the hidden activations -- is not written without one)
+        h1 = torch.empty((V, n1), device=dev, dtype=torch.float32) if need_grad else None
+        h2 = torch.empty((V, n2), device=dev, dtype=torch.float32) if need_grad else None
         y = torch.empty((V, out_f), device=dev, dtype=torch.float32)
-        chain(V, [dict(img=pk.ptr("V1"), K=V1.shape[1], N=n1, bias=c1, act=True, drop=dr(TAG_N0), out=h1, wscale=SC_WN),
-                  dict(img=pk.ptr("V2"), K=n1, N=n2, bias=c2, act=True, drop=dr(TAG_N1), out=h2, wscale=SC_WN),
-                  dict(img=pk.ptr("V3"), K=n2, N=out_f, bias=c3, act=False, drop=dr(TAG_N2), out=y, wscale=SC_WN)],
-              A=agg, lda=H3, K1=H3, A2=xf2, lda2=xf2.stride(0), alpha=alpha, seed_t=seed_t, f16=f16, ascale=SC_ACT)
+        fn_layers = [dict(img=pk.ptr("V1"), K=V1.shape[1], N=n1, bias=c1, act=True, drop=dr(TAG_N0), out=h1, wscale=SC_WN),
+                     dict(img=pk.ptr("V2"), K=n1, N=n2, bias=c2, act=True, drop=dr(TAG_N1), out=h2, wscale=SC_WN),
+                     dict(img=pk.ptr("V3"), K=n2, N=out_f, bias=c3, act=False, drop=dr(TAG_N2), out=y, wscale=SC_WN)]
+        fn_kw = dict(A2=xf2, lda2=xf2.stride(0), alpha=alpha, seed_t=seed_t, f16=f16, ascale=SC_ACT)
+        rc = _lib.MPG_FN_NA
+        if OPTIONS["fn_epilogue"] and SC == 1 and es is None:
+            if not need_grad:
+                e.agg = None
+            cs = chain_struct(V, fn_layers, A=aggp, lda=H3, K1=H3, **fn_kw)
+            rc = _lib.lib().mpg_edge_fwd_fn(C.byref(e), C.byref(cs), _stream())
+            if rc != _lib.MPG_FN_NA:
+                check(rc, "mpg_edge_fwd_fn")
+                agg = aggp[0] if need_grad else None
+        if rc == _lib.MPG_FN_NA:
+            e.agg = _p(aggp)
+            check(_lib.lib().mpg_edge_fwd(C.byref(e), _stream()), "mpg_edge_fwd")
+            agg = aggp[0] if SC == 1 else aggp.sum(0)
+            chain(V, fn_layers, A=agg, lda=H3, K1=H3, **fn_kw)
         ctx.packed = pk
 
         ctx.save_for_backward(x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3, nbr, stE2, es, wq, xf2, order)

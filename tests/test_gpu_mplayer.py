@@ -727,3 +727,114 @@ def test_jet_order_and_heaviest_first_launches_change_no_result():
             ops.OPTIONS["lpt_order"] = True
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,N,F,out,p_drop,use_mask,train", [
+    (5, 30, 32, 32, 0.0, True, True), (5, 30, 32, 32, 0.5, True, True), (5, 30, 32, 32, 0.3, True, True),
+    (4, 30, 3, 32, 0.5, True, True),      # D's first layer: x is a 3-column slice of [.., 4] rows
+    (4, 30, 32, 3, 0.0, True, True),      # G's last layer: rows of 3 floats (element stores)
+    (3, 33, 32, 32, 0.0, True, True),     # two receiver blocks, the second with one receiver
+    (6, 30, 32, 32, 0.0, False, False),   # no mask, no gradient (nothing kept for a backward)
+    (2, 150, 32, 32, 0.0, True, True),    # N = 150: several sender chunks -- outside the epilogue form, both calls take two launches
+])
+def test_node_network_as_edge_epilogue_is_bit_identical(B, N, F, out, p_drop, use_mask, train):
+    """``mpg_edge_fwd_fn`` (fn as the epilogue of the edge forward's workgroups, mpgan/model.py:256-279 in one launch) against
+    ``mpg_edge_fwd`` + ``mpg_chain``: the layer's output, the by-products kept for the backward (agg, both hidden activations)
+    and every gradient must be BIT-identical -- same sums in the same order, same dropout sites -- in all three dropout modes,
+    for both output widths, a strided x, two receiver blocks, and without gradients."""
+    import itertools
+    from mpgan_amd import ops
+    from mpgan_amd.mpgan import MPLayer
+    from oracle import train_ref as T
+    dev = _dev()
+    rs = np.random.RandomState(N + F + out)
+    layer = MPLayer(F, [96, 160, 192], [256, 256], out, dropout_p=p_drop).to(dev)
+    layer.load_state_dict({k: v.float() for k, v in T.init_state_dict(_mplayer_shapes(F, out), seed=9, dtype=torch.float64).items()})
+    layer.train(train)
+    xfull = torch.from_numpy(rs.normal(0, 0.5, size=(B, N, F + 1))).float().to(dev)
+    mask = None
+    if use_mask:
+        m = np.zeros((B, N, 1))
+        for b in range(B):
+            m[b, rs.permutation(N)[: rs.randint(1, N + 1)], 0] = 1
+        mask = torch.from_numpy(m).float().to(dev)
+    up = torch.from_numpy(rs.normal(size=(B, N, out))).float().to(dev)
+
+    def run(fused):
+        ops.OPTIONS["fn_epilogue"] = fused
+        st = ops.dev_state(dev)
+        st.tags = itertools.count(55)
+        ops.set_seed(4321, dev)
+        layer.zero_grad()
+        x = xfull[..., :F].detach().requires_grad_(train)     # (a column slice: row stride F + 1)
+        with torch.set_grad_enabled(train):
+            y = layer(x, use_mask, mask)
+        res = {"y": y.detach().clone()}
+        if train:
+            saved = _fused_node(y).saved_tensors
+            res.update(agg=saved[3].clone(), h1=saved[4].clone(), h2=saved[5].clone())
+            (y * up).sum().backward()
+            res["dx"] = x.grad.clone()
+            res.update({k: q.grad.clone() for k, q in layer.named_parameters()})
+        return res
+
+    import os
+    calls = _count_calls(ops)
+    if N <= 64:
+        os.environ["MPG_FORCE_SC"] = "1"     # (a handful of jets would be cut into sender chunks to fill the chip: the whole-jet form)
+    try:
+        a, b_ = run(True), run(False)
+    finally:
+        ops.OPTIONS["fn_epilogue"] = True
+        os.environ.pop("MPG_FORCE_SC", None)
+        calls.restore()
+    want = ["mpg_chain", "mpg_edge_fwd_fn"] if N <= 64 else ["mpg_chain", "mpg_edge_fwd", "mpg_chain"]
+    names = [k for k in calls.names if k != "mpg_pack_many"]   # (the first call builds the weight images)
+    assert names[:len(want)] == want, names[:4]
+    assert bool(torch.isfinite(a["y"]).all())
+    for k in a:
+        assert torch.equal(a[k], b_[k]), (k, float((a[k] - b_[k]).abs().max()))
+
+
+class _count_calls:
+    """Records the names of the C-ABI entry points called while it is installed."""
+
+    def __init__(self, ops):
+        from mpgan_amd import _lib
+        self._lib, self.names = _lib, []
+        real = _lib.lib()
+        outer = self
+
+        class Spy:
+            def __getattr__(self, k):
+                fn = getattr(real, k)
+                if not k.startswith("mpg_"):
+                    return fn
+
+                def f(*a):
+                    outer.names.append(k)
+                    return fn(*a)
+                return f
+        self.saved = _lib._lib
+        _lib._lib = Spy()
+
+    def restore(self):
+        self._lib._lib = self.saved
+
+
+def test_node_network_epilogue_takes_one_launch():
+    """The default layer at the headline batch really runs as ONE launch (mpg_edge_fwd_fn) + the a|c projection, not three."""
+    from mpgan_amd import ops
+    from mpgan_amd.mpgan import MPLayer
+    dev = _dev()
+    layer = MPLayer(32, [96, 160, 192], [256, 256], 32).to(dev)
+    x = torch.randn(256, 30, 32, device=dev)
+    mask = torch.ones(256, 30, 1, device=dev)
+    layer(x, True, mask)   # (weight images built)
+    calls = _count_calls(ops)
+    try:
+        with torch.no_grad():
+            layer(x, True, mask)
+    finally:
+        calls.restore()
+    assert calls.names == ["mpg_chain", "mpg_edge_fwd_fn"], calls.names
