@@ -293,6 +293,11 @@ def _work(name, a):
         edges, rows = o.B * o.N * o.N, o.B * o.N
         fn = sum(2 * rows * c.L[l].K * c.L[l].N for l in range(3))
         return edges * 2 * (H1 * H2 + H2 * H3) + fn, rows * (2 * H1 + (c.L[0].K - H3) + c.L[2].N) * 4
+    if name == "mpg_edge_bwd_fn":   # the data-gradient products + the node network's three transposed layers, one launch
+        c = a[1]._obj
+        edges, rows = o.B * o.N * o.N, o.B * o.N
+        fn = sum(2 * rows * c.L[l].K * c.L[l].N for l in range(3))
+        return edges * 2 * (H1 * H2 + H2 * H3) + fn, rows * (2 * H1 + c.L[0].K + c.L[2].N + 2 * H1) * 4
     if name in ("mpg_edge_fwd", "mpg_edge_bwd", "mpg_edge_dw"):
         edges = o.B * o.N * o.N
         # the two dense layers the kernel fuses per edge: forward e2 = W2 e1, e3 = W3 e2; backward dE2 = W3^T dZ3,

@@ -31,7 +31,6 @@ namespace {
 // go element by element
 template <bool F16, int KS0, int KS1, int KS2, int DROP, int GATES, int RESID, bool SL>
 __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
-    typedef typename FragT<F16>::type V;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int m0 = blockIdx.x * 32;
@@ -41,128 +40,9 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const MpgChain p) {
 #else
     unsigned long long* const c2_st = nullptr;
 #endif
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
     auto stage = [&](auto&& first_tile, auto&& bias_request, auto&& bias_store, const uint32_t seed_lo, const uint32_t seed_hi,
                      const float ascale) {
-    // ---- stage the input rows as B fragments: unit = (k-step, lane) = 8 features of one row
-    {
-        const int K = p.L[0].K;
-        V* fb = reinterpret_cast<V*>(smem);   // fragment buffer 0
-        const bool fast = (p.lda % 4 == 0) && (p.K1 % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0) &&
-                          p.a_slabs == 1 && (p.K1 == K || ((p.lda2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.A2) & 15) == 0))) &&
-                          (p.in_out == nullptr || ((p.ld_in_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in_out) & 15) == 0)));
-        if (fast) {
-            // every load of the thread's (up to four) units first, then the arithmetic
-            constexpr int NI = (KS0 * 64 + 255) / 256;
-            float4 x[NI][2];
-            const float* a2 = p.A2 != nullptr ? p.A2 : p.A;
-            // unit u = (row rr, k-step ks, half hh), row-major: the 2 KS0 units of a row sit on adjacent lanes, so a wave
-            // instruction takes whole 128-byte lines of two or three rows (lane = row made every lane its own line: 64 line
-            // requests per instruction, 2k clk of the texture path per workgroup before the first weight tile could be asked for)
-            static_for<0, NI>([&](auto ic) {
-                MPG_CI(i, ic);
-                const int u = min(tid + 256 * i, KS0 * 64 - 1), rr = u / (2 * KS0), rem = u - rr * (2 * KS0), ks = rem >> 1, hh = rem & 1;
-                const size_t row = (size_t)min(m0 + rr, p.M - 1);
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int f = 16 * ks + 8 * half + 4 * hh;
-                    const int fc = min(f, K - 4);
-                    x[i][half] = fc < p.K1 ? c2_ld4(p.A + row * p.lda + fc) : c2_ld4(a2 + row * p.lda2 + (fc - p.K1));
-                }
-            });
-            C2_STAMP(19);
-            first_tile(I0{});     // (its 28+ KiB per wave arrive while the rows are converted)
-            bias_request();
-            C2_STAMP(20);
-            const uint32_t in_thr = p.in_thr;
-            const bool in_on = in_thr != 0u;
-            const float in_s = in_on ? p.in_scale : 1.f;
-            const __amdgpu_buffer_rsrc_t rio = __builtin_amdgcn_make_buffer_rsrc(
-                p.in_out, 0, p.in_out != nullptr ? (int)((size_t)p.M * p.ld_in_out * 4) : 0, 0x00020000);
-            static_for<0, NI>([&](auto ic) {
-                MPG_CI(i, ic);
-                const int u = tid + 256 * i, uc = min(u, KS0 * 64 - 1), rr = uc / (2 * KS0), rem = uc - rr * (2 * KS0), ks = rem >> 1, hh = rem & 1;
-                const int ln = rr + 32 * hh;
-                const int mm = m0 + rr;
-                const bool live = mm < p.M;
-                float v[8];
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int f = 16 * ks + 8 * half + 4 * hh;
-                    float x4[4] = {x[i][half].x, x[i][half].y, x[i][half].z, x[i][half].w};
-                    uint32_t wd = 0;
-                    if constexpr (DROP == 2) wd = drop_word(seed_lo, seed_hi, p.in_tag, (uint32_t)mm, DROP_BIT_GRP + (uint32_t)(f >> 5)) >> (f & 31);
-                    if constexpr (DROP == 1) wd = drop_word(seed_lo, seed_hi, p.in_tag, (uint32_t)mm, (uint32_t)(f >> 2));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float xv = (live && f + e < K) ? x4[e] : 0.f;
-                        if constexpr (DROP != 0) {
-                            const bool keep = (DROP == 2 ? ((wd >> e) & 1u) != 0u : drop_keep(wd, e, in_thr)) || !in_on;
-                            xv = keep ? xv * in_s : 0.f;
-                        }
-                        x4[e] = xv;
-                        v[4 * half + e] = xv * ascale;
-                    }
-                    const bool st = live && f + 4 <= K && u < KS0 * 64;
-                    __builtin_amdgcn_raw_buffer_store_b128(
-                        c2_u32x4{__builtin_bit_cast(uint32_t, x4[0]), __builtin_bit_cast(uint32_t, x4[1]), __builtin_bit_cast(uint32_t, x4[2]),
-                                 __builtin_bit_cast(uint32_t, x4[3])},
-                        rio, st ? (int)(((size_t)mm * p.ld_in_out + f) * 4) : -1, 0, 0);
-                }
-                V hi, lo;
-                split8(v, hi, lo);
-                if (u < KS0 * 64) {
-                    fb[(ks * 2 + 0) * 64 + ln] = hi;
-                    fb[(ks * 2 + 1) * 64 + ln] = lo;
-                }
-            });
-            first_tile(I1{});
-            bias_store();
-        } else {
-            bias_request();
-            bias_store();
-            for (int u = tid; u < KS0 * 64; u += 256) {
-                const int ks = u >> 6, ln = u & 63, rr = ln & 31, hh = ln >> 5;
-                const int mm = m0 + rr;
-                float v[8];
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int f = 16 * ks + 8 * half + 4 * hh;
-                    float x4[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (mm < p.M) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int k = f + e;
-                            if (k < p.K1) {
-                                for (int sl = 0; sl < p.a_slabs; ++sl) x4[e] += p.A[sl * p.a_slab_stride + (size_t)mm * p.lda + k];
-                            } else if (k < K) {
-                                x4[e] = p.A2[(size_t)mm * p.lda2 + (k - p.K1)];
-                            }
-                        }
-                        if (p.in_thr) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                x4[e] = (f + e < K && drop_keep_f(seed_lo, seed_hi, p.in_tag, (uint32_t)mm, f + e, p.in_thr)) ? x4[e] * p.in_scale : 0.f;
-                        }
-                        if (p.in_out != nullptr) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (f + e < K) p.in_out[(size_t)mm * p.ld_in_out + f + e] = x4[e];
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * half + e] = x4[e] * ascale;
-                }
-                V hi, lo;
-                split8(v, hi, lo);
-                fb[(ks * 2 + 0) * 64 + ln] = hi;
-                fb[(ks * 2 + 1) * 64 + ln] = lo;
-            }
-            first_tile(I0{});
-            first_tile(I1{});
-        }
-    }
+        c2_stage_rows<F16, KS0, DROP>(p, m0, 32, smem, first_tile, bias_request, bias_store, seed_lo, seed_hi, ascale, c2_st);
     };
     c2_body<F16, KS0, KS1, KS2, DROP, GATES, RESID, SL>(p, m0, 32, smem, smem + C2_FB, reinterpret_cast<float*>(smem + 2 * C2_FB), stage, c2_st);
 #ifdef MPG_CHSTAMP

@@ -36,6 +36,8 @@ OPTIONS = {
     # the node network fn as the epilogue of the fused edge forward (mpg_edge_fwd_fn: one launch instead of two, same bits);
     # False = mpg_edge_fwd followed by mpg_chain
     "fn_epilogue": os.environ.get("MPG_FN_EPILOGUE", "1") != "0",
+    # ... and its input-gradient chain as the prologue of the data-gradient kernel (mpg_edge_bwd_fn); False = mpg_chain + mpg_edge_bwd
+    "fn_prologue": os.environ.get("MPG_FN_PROLOGUE", "1") != "0",
 }
 NUM_CUS = 256
 # Forward products (they decide LeakyReLU signs) are split as fp16 hi/lo with the operand scales below (~2^-21 per
@@ -639,11 +641,12 @@ class FusedMPLayerFn(torch.autograd.Function):
         dz2 = torch.empty((V, n2), device=dev, dtype=torch.float32)
         dz1 = torch.empty((V, n1), device=dev, dtype=torch.float32)
         dh0 = torch.empty((V, V1.shape[1]), device=dev, dtype=torch.float32)  # [dagg | dx(node path) | (conditioning columns)]
-        chain(V, [dict(img=pk.ptr("V3T"), K=out_f, N=n2, gate=(h2, True, tag + TAG_N1, thr, dscale), out=dz2),
-                  dict(img=pk.ptr("V2T"), K=n2, N=n1, gate=(h1, True, tag + TAG_N0, thr, dscale), out=dz1),
-                  dict(img=pk.ptr("V1T"), K=n1, N=V1.shape[1], out=dh0)],
-              A=gy2, lda=gy2.stride(0), K1=out_f, in_gate=(tag + TAG_N2, thr, dscale), in_out=dz3 if thr else None,
-              alpha=alpha, seed_t=seed_t, f16=False)
+        # (launched below: as the prologue of the data-gradient kernel where that form covers the call, mpg_edge_bwd_fn)
+        fnb = chain_struct(V, [dict(img=pk.ptr("V3T"), K=out_f, N=n2, gate=(h2, True, tag + TAG_N1, thr, dscale), out=dz2),
+                               dict(img=pk.ptr("V2T"), K=n2, N=n1, gate=(h1, True, tag + TAG_N0, thr, dscale), out=dz1),
+                               dict(img=pk.ptr("V1T"), K=n1, N=V1.shape[1], out=dh0)],
+                           A=gy2, lda=gy2.stride(0), K1=out_f, in_gate=(tag + TAG_N2, thr, dscale), in_out=dz3 if thr else None,
+                           alpha=alpha, seed_t=seed_t, f16=False)
         dV1 = dV2 = dV3 = dc1 = dc2 = dc3 = None
         wb = WgradBatch()  # all six weight gradients of the layer go out as one grouped launch (below)
         # DeviceState.grad_into_param: add into the parameters' .grad buffers directly and return None for them
@@ -691,7 +694,14 @@ class FusedMPLayerFn(torch.autograd.Function):
             des = torch.zeros_like(es)   # (zero-masked senders' rows are not written)
             daq = torch.empty((SC, V, EDGE_SCALARS, H1), device=dev, dtype=torch.float32)
             e.es, e.wq, e.des, e.daq = _p(es), _p(wq), _p(des), _p(daq)
-        check(_lib.lib().mpg_edge_bwd(C.byref(e), _stream()), "mpg_edge_bwd")
+        rc = _lib.MPG_FN_NA
+        if OPTIONS["fn_prologue"] and SC == 1 and es is None:
+            rc = _lib.lib().mpg_edge_bwd_fn(C.byref(e), C.byref(fnb), _stream())
+            if rc != _lib.MPG_FN_NA:
+                check(rc, "mpg_edge_bwd_fn")
+        if rc == _lib.MPG_FN_NA:
+            check(_lib.lib().mpg_chain(C.byref(fnb), _stream()), "mpg_chain")
+            check(_lib.lib().mpg_edge_bwd(C.byref(e), _stream()), "mpg_edge_bwd")
         da = dap[0] if SC == 1 else dap.sum(0)
         dc = dcp[0] if RB == 1 else dcp.sum(0)
         dW1 = db1 = dW2 = db2 = dW3 = db3 = None

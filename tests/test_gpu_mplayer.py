@@ -739,7 +739,8 @@ def test_jet_order_and_heaviest_first_launches_change_no_result():
 ])
 def test_node_network_as_edge_epilogue_is_bit_identical(B, N, F, out, p_drop, use_mask, train):
     """``mpg_edge_fwd_fn`` (fn as the epilogue of the edge forward's workgroups, mpgan/model.py:256-279 in one launch) against
-    ``mpg_edge_fwd`` + ``mpg_chain``: the layer's output, the by-products kept for the backward (agg, both hidden activations)
+    ``mpg_edge_fwd`` + ``mpg_chain``, and ``mpg_edge_bwd_fn`` (fn's input-gradient chain as the prologue of the data-gradient
+    kernel's workgroups) against ``mpg_chain`` + ``mpg_edge_bwd``: the layer's output, the by-products kept for the backward (agg, both hidden activations)
     and every gradient must be BIT-identical -- same sums in the same order, same dropout sites -- in all three dropout modes,
     for both output widths, a strided x, two receiver blocks, and without gradients."""
     import itertools
@@ -761,7 +762,7 @@ def test_node_network_as_edge_epilogue_is_bit_identical(B, N, F, out, p_drop, us
     up = torch.from_numpy(rs.normal(size=(B, N, out))).float().to(dev)
 
     def run(fused):
-        ops.OPTIONS["fn_epilogue"] = fused
+        ops.OPTIONS["fn_epilogue"] = ops.OPTIONS["fn_prologue"] = fused
         st = ops.dev_state(dev)
         st.tags = itertools.count(55)
         ops.set_seed(4321, dev)
@@ -785,12 +786,15 @@ def test_node_network_as_edge_epilogue_is_bit_identical(B, N, F, out, p_drop, us
     try:
         a, b_ = run(True), run(False)
     finally:
-        ops.OPTIONS["fn_epilogue"] = True
+        ops.OPTIONS["fn_epilogue"] = ops.OPTIONS["fn_prologue"] = True
         os.environ.pop("MPG_FORCE_SC", None)
         calls.restore()
     want = ["mpg_chain", "mpg_edge_fwd_fn"] if N <= 64 else ["mpg_chain", "mpg_edge_fwd", "mpg_chain"]
     names = [k for k in calls.names if k != "mpg_pack_many"]   # (the first call builds the weight images)
     assert names[:len(want)] == want, names[:4]
+    if train:   # ... and the backward: the input-gradient chain as the prologue of the data-gradient kernel (mpg_edge_bwd_fn)
+        nb = names[len(want):names.index("mpg_edge_dw")]
+        assert nb == (["mpg_edge_bwd_fn"] if N <= 64 else ["mpg_chain", "mpg_edge_bwd"]), nb
     assert bool(torch.isfinite(a["y"]).all())
     for k in a:
         assert torch.equal(a[k], b_[k]), (k, float((a[k] - b_[k]).abs().max()))
