@@ -183,9 +183,13 @@ int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream);
  * sites as there -- and the results are bit-identical to mpg_edge_fwd followed by mpg_chain.
  * Covered: SC = 1, no edge scalars, fp16 images, layer widths K <= 224 -> N0, N1 in (224, 256] -> any N2 <= 256, no
  * gates / residuals / input dropout, one dropout mode for all sites.  Anything else returns MPG_FN_NA without
- * launching: the caller then runs the two launches. */
+ * launching: the caller then runs the two launches.
+ * `c2` (or NULL): one more mpg_chain call that runs behind fn on the same rows, in the same launch -- the NEXT MPLayer's
+ * layer-1 node terms a | c = [W1a ; W1c] x + [b1 ; 0] of the rows fn has just produced (one layer, K = c's last N <= 32,
+ * input c2->A = c->L[2].out), so that the next layer starts with its edge launch (mpgan/model.py:511-512: the loop over
+ * mp_layers). */
 #define MPG_FN_NA (-100)
-int mpg_edge_fwd_fn(const MpgEdgeFwd* p, const MpgChain* c, void* stream);
+int mpg_edge_fwd_fn(const MpgEdgeFwd* p, const MpgChain* c, const MpgChain* c2, void* stream);
 
 /* mpg_knn_sets: the neighbour sets of MPLayer._getA_knn (mpgan/model.py:319-381) as bit masks for the fused edge kernels.
  * Per jet: d(i, j) = || s_j x_j - x_i + 1e-12 || over the F node features, s_j = (1 - 1e4) mask_j + 1e4 (:333-335: 1 for

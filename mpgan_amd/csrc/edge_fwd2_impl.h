@@ -71,8 +71,11 @@ constexpr int F2_RED_BYTES = 4 * T3 * 16 * 64 * 4;      // the four waves' parti
 constexpr int F2_FN_FB0 = F2_RED_BYTES;                 // fn's input fragments are laid down beside them ...
 constexpr int F2_FN_BIAS = F2_FN_FB0 + C2_FB;           // ... its second fragment buffer over them, once they are dead
 
+// ``cp2`` (FN only; nlayers = 0: none): one more chain on the rows fn has just written -- the NEXT MPLayer's layer-1 node terms
+// a | c = [W1a ; W1c] y + [b1 ; 0] (its mpg_chain call, with fn's output rows as input) -- so that the next layer starts with
+// its edge launch.
 template <int DROP, bool SIGN, int NQ, int FN>
-MPG_DEV void edge_fwd_body(const MpgEdgeFwd& p, const MpgChain* const cp) {
+MPG_DEV void edge_fwd_body(const MpgEdgeFwd& p, const MpgChain* const cp, const MpgChain* const cp2 = nullptr) {
     typedef f16x8 V;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -482,6 +485,18 @@ MPG_DEV void edge_fwd_body(const MpgEdgeFwd& p, const MpgChain* const cp) {
             bias_store();
         };
         c2_body<true, 14, 16, 16, DROP, 0, 0, FN == 2>(c, m0, nrows, smem + F2_FN_FB0, smem, reinterpret_cast<float*>(smem + F2_FN_BIAS), stage);
+        if (cp2->nlayers > 0) {
+            // the next layer's a | c on the rows just written (every buffer of fn is dead behind its last barrier; the rows
+            // are this workgroup's own stores: ordered within the workgroup)
+            const MpgChain& c2 = *cp2;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            auto stage2 = [&](auto&& first_tile, auto&& bias_request, auto&& bias_store, const uint32_t s_lo, const uint32_t s_hi, const float ascale) {
+                c2_stage_rows<true, 2, 0>(c2, m0, nrows, smem, first_tile, bias_request, bias_store, s_lo, s_hi, ascale);
+            };
+            c2_body<true, 2, 0, 0, 0, 0, 0, false>(c2, m0, nrows, smem, smem + C2_FB, reinterpret_cast<float*>(smem + 2 * C2_FB), stage2);
+        }
     }
 }
 
@@ -489,8 +504,8 @@ template <int DROP, bool SIGN, int NQ>
 __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(const MpgEdgeFwd p) { edge_fwd_body<DROP, SIGN, NQ, 0>(p, nullptr); }
 
 template <int DROP, bool SIGN, bool SL>
-__global__ __launch_bounds__(256, 1) void edge_fwd_fn_kernel(const MpgEdgeFwd p, const MpgChain c) {
-    edge_fwd_body<DROP, SIGN, 0, SL ? 2 : 1>(p, &c);
+__global__ __launch_bounds__(256, 1) void edge_fwd_fn_kernel(const MpgEdgeFwd p, const MpgChain c, const MpgChain c2) {
+    edge_fwd_body<DROP, SIGN, 0, SL ? 2 : 1>(p, &c, &c2);
 }
 
 // the SIGN pair of one dropout mode and edge-scalar count (the combinations compile as separate translation units: edge.hip,
@@ -511,15 +526,17 @@ int f2_launch(const MpgEdgeFwd* p, hipStream_t st) {
 
 // the fused forward + node network of one dropout mode / SIGN (edge_fwd_fn_*.hip: one translation unit each)
 template <int D, bool SIGN>
-int f2_launch_fn(const MpgEdgeFwd* p, const MpgChain* c, bool sl, hipStream_t st) {
+int f2_launch_fn(const MpgEdgeFwd* p, const MpgChain* c, const MpgChain* c2, bool sl, hipStream_t st) {
     const int RB = (p->N + 31) / 32;
     dim3 grid(p->B * RB), block(256);
+    MpgChain none = {};   // nlayers = 0: no second chain
+    if (c2 == nullptr) c2 = &none;
     if (sl) {
         MPG_ENSURE_LDS((edge_fwd_fn_kernel<D, SIGN, true>), F2_LDS_BYTES);
-        hipLaunchKernelGGL((edge_fwd_fn_kernel<D, SIGN, true>), grid, block, F2_LDS_BYTES, st, *p, *c);
+        hipLaunchKernelGGL((edge_fwd_fn_kernel<D, SIGN, true>), grid, block, F2_LDS_BYTES, st, *p, *c, *c2);
     } else {
         MPG_ENSURE_LDS((edge_fwd_fn_kernel<D, SIGN, false>), F2_LDS_BYTES);
-        hipLaunchKernelGGL((edge_fwd_fn_kernel<D, SIGN, false>), grid, block, F2_LDS_BYTES, st, *p, *c);
+        hipLaunchKernelGGL((edge_fwd_fn_kernel<D, SIGN, false>), grid, block, F2_LDS_BYTES, st, *p, *c, *c2);
     }
     return (int)hipGetLastError();
 }

@@ -6,11 +6,11 @@
 #include <stdint.h>
 #include "../../include/mpgan_amd.h"
 
-#define MPG_FN_DECL(D, S) int mpg_edge_fwd_fn_d##D##s##S(const MpgEdgeFwd* p, const MpgChain* c, bool sl, hipStream_t st)
+#define MPG_FN_DECL(D, S) int mpg_edge_fwd_fn_d##D##s##S(const MpgEdgeFwd* p, const MpgChain* c, const MpgChain* c2, bool sl, hipStream_t st)
 MPG_FN_DECL(0, 0); MPG_FN_DECL(0, 1); MPG_FN_DECL(1, 0); MPG_FN_DECL(1, 1); MPG_FN_DECL(2, 0); MPG_FN_DECL(2, 1);
 #undef MPG_FN_DECL
 
-extern "C" int mpg_edge_fwd_fn(const MpgEdgeFwd* p, const MpgChain* c, void* stream) {
+extern "C" int mpg_edge_fwd_fn(const MpgEdgeFwd* p, const MpgChain* c, const MpgChain* c2, void* stream) {
     if (p->B <= 0 || p->N <= 0) return -1;
     if (!(p->alpha >= 0.f && p->alpha <= 1.f) || c->alpha != p->alpha) return -4;
     if (!p->f16 || !c->f16) return -8;
@@ -35,14 +35,21 @@ extern "C" int mpg_edge_fwd_fn(const MpgEdgeFwd* p, const MpgChain* c, void* str
         }
     }
     if ((size_t)p->B * p->N * 192 * 4 >= 0x7fffffffull) return MPG_FN_NA;
+    if (c2 != nullptr) {   // the next layer's a | c projection on fn's output rows: its own mpg_chain call (one layer, K <= 32)
+        const MpgChainLayer& L = c2->L[0];
+        if (c2->nlayers != 1 || !c2->f16 || c2->M != c->M || c2->a_slabs != 1 || c2->in_thr != 0 || c2->in_out != nullptr) return -2;
+        if (c2->A != c->L[2].out || c2->lda != c->L[2].ldo || c2->K1 != L.K || L.K != c->L[2].N || L.K > 32) return -2;
+        if (L.N > 256 || L.N % 4 || L.out == nullptr || L.ldo % 4 || ((uintptr_t)L.out & 15) || (size_t)c2->M * L.ldo * 4 >= 0x7fffffffull) return -2;
+        if (L.gateH != nullptr || L.resid != nullptr || L.drop_thr != 0 || L.act || c2->alpha != c->alpha) return -2;
+    }
     hipStream_t st = (hipStream_t)stream;
     const bool sg = p->sign3 != nullptr;
     switch (dm * 2 + (sg ? 1 : 0)) {
-    case 0: return mpg_edge_fwd_fn_d0s0(p, c, sl, st);
-    case 1: return mpg_edge_fwd_fn_d0s1(p, c, sl, st);
-    case 2: return mpg_edge_fwd_fn_d1s0(p, c, sl, st);
-    case 3: return mpg_edge_fwd_fn_d1s1(p, c, sl, st);
-    case 4: return mpg_edge_fwd_fn_d2s0(p, c, sl, st);
-    default: return mpg_edge_fwd_fn_d2s1(p, c, sl, st);
+    case 0: return mpg_edge_fwd_fn_d0s0(p, c, c2, sl, st);
+    case 1: return mpg_edge_fwd_fn_d0s1(p, c, c2, sl, st);
+    case 2: return mpg_edge_fwd_fn_d1s0(p, c, c2, sl, st);
+    case 3: return mpg_edge_fwd_fn_d1s1(p, c, c2, sl, st);
+    case 4: return mpg_edge_fwd_fn_d2s0(p, c, c2, sl, st);
+    default: return mpg_edge_fwd_fn_d2s1(p, c, c2, sl, st);
     }
 }

@@ -295,12 +295,25 @@ class MPLayer(nn.Module):
             W1 = self._folded_w1(W1)   # (not a parameter: its images are packed for this call)
         else:
             packed = self._packed()
-        return ops.FusedMPLayerFn.apply(
+        # consecutive fused layers of a network hand each other the layer-1 node terms a | c (ops.LayerHandoff): the launch
+        # that produces a layer's output rows also projects them for the next layer
+        handoff = None
+        nxt = self.__dict__.get("_next_layer")
+        ac_in = getattr(x, "_mpg_ac", None)
+        if packed is not None and (ac_in is not None or nxt is not None):
+            nx = None
+            if nxt is not None and nxt.fused and not nxt._diff_cols and nxt.training == self.training and nxt.n_es == 0:
+                nx = (nxt._packed(), nxt.fe.net[0].bias)
+            handoff = ops.LayerHandoff(next=nx, ac_in=ac_in)
+        y = ops.FusedMPLayerFn.apply(
             x, mask if use_mask else None,
             W1, fe[0].bias, fe[1].weight, fe[1].bias, fe[2].weight, fe[2].bias,
             fn[0].weight, fn[0].bias, fn[1].weight, fn[1].bias, fn[2].weight, fn[2].bias,
             self.sum, self.fe.leaky_relu_alpha, self.fe.dropout_p, self.training, packed, nbr, self.num_knn,
-            es, self.n_es, xfn)
+            es, self.n_es, xfn, handoff)
+        if handoff is not None and handoff.ac_out is not None:
+            y._mpg_ac = handoff.ac_out
+        return y
 
     def _folded_w1(self, W1: Tensor) -> Tensor:
         """fe.net.0.weight with the coordinate-difference columns folded into the node columns: the reference appends
@@ -396,11 +409,19 @@ class MPNet(nn.Module):
             self.mp_layers.append(MPLayer(sizes[k], fe_k, fn_k, sizes[k + 1], **(first if k == 0 else mp_args),
                                           **linear_args))
 
+    def _run_layers(self, x, use_mask, mask, labels, njp):
+        """The loop over ``mp_layers`` (mpgan/model.py:511-512).  Each layer is told which layer takes its output (a transient
+        attribute, set per call: ``nn.DataParallel`` replicas then see their own device's layers)."""
+        n = len(self.mp_layers)
+        for k, layer in enumerate(self.mp_layers):
+            layer.__dict__["_next_layer"] = self.mp_layers[k + 1] if k + 1 < n else None
+            x = layer(x, use_mask, mask, labels, njp)
+        return x
+
     def forward(self, x: Tensor, labels: Tensor = None) -> Tensor:
         x = self._pre_mp(x, labels)
         x, use_mask, mask, njp = self._get_mask(x, labels, **self.mask_args)
-        for layer in self.mp_layers:
-            x = layer(x, use_mask, mask, labels, njp)
+        x = self._run_layers(x, use_mask, mask, labels, njp)
         x = self._post_mp(x, labels, use_mask, mask, njp)
         return self._finish(x, mask)
 
@@ -481,8 +502,7 @@ class MPGenerator(MPNet):
         assert not torch.is_grad_enabled() and x.is_cuda
         x = self._pre_mp(x, labels)
         x, use_mask, mask, njp = self._get_mask(x, labels, **self.mask_args)
-        for layer in self.mp_layers:
-            x = layer(x, use_mask, mask, labels, njp)
+        x = self._run_layers(x, use_mask, mask, labels, njp)
         return ops.gen_tail_into(x, mask, ops.ACT_CODES[self.final_activation], out)
 
     def _final_mask(self, x, mask, mask_feat_bin: bool = False, **mask_args):
@@ -530,8 +550,7 @@ class MPDiscriminator(MPNet):
         """The message-passing part of ``forward``: (last layer's node features [B, N, F], mask [B, N, 1] or None)."""
         x = self._pre_mp(x, labels)
         x, use_mask, mask, njp = self._get_mask(x, labels, **self.mask_args)
-        for layer in self.mp_layers:
-            x = layer(x, use_mask, mask, labels, njp)
+        x = self._run_layers(x, use_mask, mask, labels, njp)
         return x, (mask if use_mask else None)
 
     def forward(self, x: Tensor, labels: Tensor = None) -> Tensor:

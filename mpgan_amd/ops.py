@@ -507,15 +507,31 @@ def dw_workgroups(nblk, N):
     return min(nruns, max(256, -(-nruns // (64 // R))))
 
 
+class LayerHandoff:
+    """What consecutive fused MPLayers of one network pass to each other around ``FusedMPLayerFn`` (``MPNet`` wires it):
+    ``next`` = (PackedMPLayer, fe.net.0.bias) of the layer that will take this layer's output; ``ac_in`` / ``ac_out`` =
+    (a | c [B*N, 192], the PackedMPLayer whose W1 image produced it, data pointer of the rows it was computed from, that
+    set's parameter key)."""
+    __slots__ = ("next", "ac_in", "ac_out")
+
+    def __init__(self, next=None, ac_in=None):
+        self.next, self.ac_in, self.ac_out = next, ac_in, None
+
+
 class FusedMPLayerFn(torch.autograd.Function):
     """MPLayer.forward (mpgan/model.py:206-282), default configuration: fully connected, no edge
     features, no conditioning labels; fe = 3 layers [96,160,192], fn = 2 hidden layers + linear."""
 
     @staticmethod
     def forward(ctx, x, mask, W1, b1, W2, b2, W3, b3, V1, c1, V2, c2, V3, c3, sum_agg, alpha, p_drop, training,
-                packed=None, nbr=None, num_knn=0, es=None, nq=0, xfn=None):
+                packed=None, nbr=None, num_knn=0, es=None, nq=0, xfn=None, handoff=None):
         """``nbr`` (from ``knn_sets``) restricts receiver i's senders to its ``num_knn`` nearest neighbours
         (``fully_connected=False``, mpgan/model.py:319-381); the mean then divides by ``num_knn`` (:267).
+
+        ``handoff`` (a ``LayerHandoff`` or None) couples consecutive layers of a network: ``handoff.ac_in`` are this layer's
+        layer-1 node terms a | c already computed by the launch that produced ``x`` (then no projection launch here), and
+        ``handoff.next`` is the next layer's ``(PackedMPLayer, b1)``: where this call's edge launch runs the node network as
+        its epilogue it appends that layer's projection and leaves the result in ``handoff.ac_out``.
 
         ``es`` [B, N senders, EDGE_SCALARS, N receivers] with ``nq`` live scalars: the edge features / row-tiled conditioning
         columns of the reference (mpgan/model.py:247-253, :297-313), one scalar per edge each; they multiply the columns
@@ -541,10 +557,16 @@ class FusedMPLayerFn(torch.autograd.Function):
         def dr(site):
             return (tag + site, thr, dscale)
 
-        # layer-1 node terms a | c = x [W1a ; W1c]^T (+ b1 on the a half), one launch
-        ac = torch.empty((V, 2 * H1), device=dev, dtype=torch.float32)
-        chain(V, [dict(img=pk.ptr("W1S"), K=F, N=2 * H1, bias=b1, nbias=H1, out=ac, wscale=SC_WN)], A=x2, lda=x2.stride(0), K1=F,
-              alpha=alpha, f16=f16, ascale=SC_ACT)
+        # layer-1 node terms a | c = x [W1a ; W1c]^T (+ b1 on the a half): handed over by the launch that produced x, or one launch
+        ac = None
+        if handoff is not None and handoff.ac_in is not None:
+            ac_pre, pk_pre, x_ptr, key_pre = handoff.ac_in   # (valid for these very rows and the weight images as they are now)
+            if pk_pre is pk and key_pre == pk._key and x_ptr == x2.data_ptr() and tuple(ac_pre.shape) == (V, 2 * H1):
+                ac = ac_pre
+        if ac is None:
+            ac = torch.empty((V, 2 * H1), device=dev, dtype=torch.float32)
+            chain(V, [dict(img=pk.ptr("W1S"), K=F, N=2 * H1, bias=b1, nbias=H1, out=ac, wscale=SC_WN)], A=x2, lda=x2.stride(0), K1=F,
+                  alpha=alpha, f16=f16, ascale=SC_ACT)
         SC = _sender_chunks(B, N, MAX_CHUNK_SENDERS_ES if es is not None else None)
         aggp = torch.empty((SC, V, H3), device=dev, dtype=torch.float32)
         e = MpgEdgeFwd()
@@ -604,10 +626,21 @@ class FusedMPLayerFn(torch.autograd.Function):
             if not need_grad:
                 e.agg = None
             cs = chain_struct(V, fn_layers, A=aggp, lda=H3, K1=H3, **fn_kw)
-            rc = _lib.lib().mpg_edge_fwd_fn(C.byref(e), C.byref(cs), _stream())
+            cs2 = ac_next = None
+            if handoff is not None and handoff.next is not None and out_f % 4 == 0 and out_f <= 32:
+                # the next layer's a | c projection of the rows this launch produces, appended to the epilogue
+                pk_n, b1_n = handoff.next
+                if pk_n.F == out_f and pk_n.f16 == f16:
+                    pk_n.ensure()
+                    ac_next = torch.empty((V, 2 * H1), device=dev, dtype=torch.float32)
+                    cs2 = chain_struct(V, [dict(img=pk_n.ptr("W1S"), K=out_f, N=2 * H1, bias=b1_n, nbias=H1, out=ac_next, wscale=SC_WN)],
+                                       A=y, lda=out_f, K1=out_f, alpha=alpha, f16=f16, ascale=SC_ACT)
+            rc = _lib.lib().mpg_edge_fwd_fn(C.byref(e), C.byref(cs), None if cs2 is None else C.byref(cs2), _stream())
             if rc != _lib.MPG_FN_NA:
                 check(rc, "mpg_edge_fwd_fn")
                 agg = aggp[0] if need_grad else None
+                if cs2 is not None:
+                    handoff.ac_out = (ac_next, pk_n, y.data_ptr(), pk_n._key)
         if rc == _lib.MPG_FN_NA:
             e.agg = _p(aggp)
             check(_lib.lib().mpg_edge_fwd(C.byref(e), _stream()), "mpg_edge_fwd")
@@ -776,7 +809,7 @@ class FusedMPLayerFn(torch.autograd.Function):
             # tail of dh0; the x columns of xfn are the same nodes as x, whose node-path gradient is already in dx above
             dxfn = torch.cat((torch.zeros((V, F), device=dev, dtype=torch.float32), dh0[:, H3 + F:]), dim=1).reshape(B, N, -1)
         return (dx, None, dW1, db1, dW2, db2, dW3, db3, dV1, dc1, dV2, dc2, dV3, dc3,
-                None, None, None, None, None, None, None, des, None, dxfn)[:len(ctx.needs_input_grad)]
+                None, None, None, None, None, None, None, des, None, dxfn, None)[:len(ctx.needs_input_grad)]
 
 
 def _grad_target(t):

@@ -783,10 +783,11 @@ def test_node_network_as_edge_epilogue_is_bit_identical(B, N, F, out, p_drop, us
     calls = _count_calls(ops)
     if N <= 64:
         os.environ["MPG_FORCE_SC"] = "1"     # (a handful of jets would be cut into sender chunks to fill the chip: the whole-jet form)
+    saved_opts = (ops.OPTIONS["fn_epilogue"], ops.OPTIONS["fn_prologue"])
     try:
         a, b_ = run(True), run(False)
     finally:
-        ops.OPTIONS["fn_epilogue"] = ops.OPTIONS["fn_prologue"] = True
+        ops.OPTIONS["fn_epilogue"], ops.OPTIONS["fn_prologue"] = saved_opts
         os.environ.pop("MPG_FORCE_SC", None)
         calls.restore()
     want = ["mpg_chain", "mpg_edge_fwd_fn"] if N <= 64 else ["mpg_chain", "mpg_edge_fwd", "mpg_chain"]
@@ -842,3 +843,58 @@ def test_node_network_epilogue_takes_one_launch():
     finally:
         calls.restore()
     assert calls.names == ["mpg_chain", "mpg_edge_fwd_fn"], calls.names
+
+
+@pytest.mark.parametrize("which,train", [("G", True), ("D", True), ("G", False)])
+def test_layers_hand_over_their_node_terms(which, train):
+    """A whole network at the headline batch: every layer's edge launch runs the node network as its epilogue AND, for all
+    layers but the last, the next layer's a | c projection behind it (``ops.LayerHandoff``) -- one ``mpg_chain`` launch per
+    network forward (the first layer's projection) instead of four, outputs and gradients bit-identical to the launches
+    taken one by one, dropout on in D."""
+    import itertools
+    from mpgan_amd import ops, train as mtrain
+    dev = _dev()
+    B, N = 256, 30
+    torch.manual_seed(3)
+    G, D = mtrain.default_mpgan(N, disc_dropout=0.5)
+    net = G if which == "G" else D
+    net.train(train)
+    rs = np.random.RandomState(5)
+    labels = torch.from_numpy(rs.randint(10, N + 1, size=(B, 1)) / N).float().to(dev)
+    if which == "G":
+        xin = torch.from_numpy(rs.normal(0, 0.2, size=(B, N, 32))).float().to(dev)
+    else:
+        from oracle.train_ref import synthetic_batch
+        xin = synthetic_batch(B, N, seed=3)[0].to(dev)
+
+    def run(fused):
+        ops.OPTIONS["fn_epilogue"] = fused
+        st = ops.dev_state(dev)
+        st.tags = itertools.count(91)
+        ops.set_seed(99, dev)
+        net.zero_grad()
+        x = xin.clone().requires_grad_(train)
+        calls = _count_calls(ops)
+        try:
+            with torch.set_grad_enabled(train):
+                y = net(x, labels)
+        finally:
+            calls.restore()
+        names = [k for k in calls.names if k in ("mpg_chain", "mpg_edge_fwd", "mpg_edge_fwd_fn")]
+        res = {"y": y.detach().clone()}
+        if train:
+            y.sum().backward()
+            res["dx"] = x.grad.clone()
+            res.update({k: q.grad.clone() for k, q in net.named_parameters() if q.grad is not None})
+        return res, names
+
+    saved = ops.OPTIONS["fn_epilogue"]
+    try:
+        net(xin, labels)   # (weight images built)
+        (a, na), (b_, nb) = run(True), run(False)
+    finally:
+        ops.OPTIONS["fn_epilogue"] = saved
+    assert na == ["mpg_chain", "mpg_edge_fwd_fn", "mpg_edge_fwd_fn"], na
+    assert nb == ["mpg_chain", "mpg_edge_fwd", "mpg_chain"] * 2, nb
+    for k in a:
+        assert torch.equal(a[k], b_[k]), (k, float((a[k] - b_[k]).abs().max()))
