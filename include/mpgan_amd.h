@@ -340,6 +340,11 @@ typedef struct MpgDiscHead {
 } MpgDiscHead;
 int mpg_disc_head_fwd(const MpgDiscHead* p, void* stream);
 int mpg_disc_head_bwd(const MpgDiscHead* p, void* stream);
+/* mpg_disc_head_loss: forward, the named loss and the whole backward of the head in one pass -- p->loss >= 0 with its
+ * fields set as for mpg_disc_head_bwd: a jet's loss gradient needs nothing but its own output, so the wave that has pooled
+ * a jet goes straight on to dy (one launch + the small reduction for the loss value and dw / db, instead of mpg_disc_head_fwd
+ * + mpg_disc_head_bwd).  Same results as the two calls. */
+int mpg_disc_head_loss(const MpgDiscHead* p, void* stream);
 
 /* mpg_mab_fwd / mpg_mab_bwd: one launch per MAB.forward (gapt/model.py:124-139) and one for its backward, for sets of at
  * most 32 tokens, E in {32, 64}, heads of 16 features, no layer norm (csrc/mab.hip; anything else runs block by block
@@ -403,13 +408,21 @@ int mpg_batchnorm_bwd(const float* g, int ldg, const float* x, int ldx, const fl
  * mpg_rmsprop  (--optimizer rmsprop, the default): v = alpha v + (1-alpha) g^2; p -= lr g / (sqrt(v) + eps)
  * mpg_adam     (--optimizer adam; weight_decay 5e-4 there): torch.optim.Adam with L2 weight decay; `step` is a
  *              device float holding the number of steps taken so far (advanced by the call)
- * mpg_adadelta (--optimizer adadelta): torch.optim.Adadelta (rho 0.9, eps 1e-6 by default). */
-int mpg_rmsprop(float* p, const float* g, float* v, uint64_t n, float lr, float alpha, float eps, float gscale,
+ * mpg_adadelta (--optimizer adadelta): torch.optim.Adadelta (rho 0.9, eps 1e-6 by default).
+ * zero_grad != 0: g is cleared behind its last use -- optimizer.zero_grad() of the NEXT train_D / train_G (train.py:419,
+ * :494) without a launch of its own. */
+int mpg_rmsprop(float* p, float* g, float* v, uint64_t n, float lr, float alpha, float eps, float gscale, int zero_grad,
                 void* stream);
-int mpg_adam(float* p, const float* g, float* m, float* v, float* step, uint64_t n, float lr, float beta1,
-             float beta2, float eps, float weight_decay, float gscale, void* stream);
-int mpg_adadelta(float* p, const float* g, float* v, float* u, uint64_t n, float lr, float rho, float eps,
-                 float gscale, void* stream);
+int mpg_adam(float* p, float* g, float* m, float* v, float* step, uint64_t n, float lr, float beta1,
+             float beta2, float eps, float weight_decay, float gscale, int zero_grad, void* stream);
+int mpg_adadelta(float* p, float* g, float* v, float* u, uint64_t n, float lr, float rho, float eps,
+                 float gscale, int zero_grad, void* stream);
+
+/* mpg_normal: out[i] = mean + std * z_i with z ~ N(0, 1) -- the generator's input noise (get_gen_noise, train.py:100-141:
+ * torch.randn * sd) from a counter-based stream keyed by the device-resident 64-bit `seed` (the dropout seed, advanced
+ * once per iteration) and a site `tag`: a captured hipGraph draws fresh values on every replay, and torch's generator
+ * (whose graph-safe state costs two fill launches in front of every replay) is not involved. */
+int mpg_normal(float* out, uint64_t n, const uint64_t* seed, uint32_t tag, float mean, float std, void* stream);
 
 #ifdef __cplusplus
 }

@@ -43,15 +43,18 @@ __global__ __launch_bounds__(1024) void jet_order_kernel(const float* __restrict
     int* hist = jo + B;              // [N + 2]: hist[k + 1] = jets with key k, then its prefix sums
     int* wcnt = jo + B + N + 2;      // [waves][N + 1]: jets with key k in wave w, then in the waves before w
     const int nw = (B + 63) / 64, lane = threadIdx.x & 63;
-    for (int t = threadIdx.x; t < B; t += blockDim.x) keys[t] = 0;
     for (int t = threadIdx.x; t < N + 2; t += blockDim.x) hist[t] = 0;
     for (int t = threadIdx.x; t < nw * (N + 1); t += blockDim.x) wcnt[t] = 0;
     __syncthreads();
-    for (int e = threadIdx.x; e < B * N; e += blockDim.x)
-        if (mask[e] != 0.f) atomicAdd(&keys[e / N], 1);
-    __syncthreads();
+    // a thread counts its jet's particles itself: the N loads of a thread are independent (all in flight together) and the
+    // threads of a wave walk one contiguous 64 N-float window -- one round trip instead of B N / 1024 rounds of LDS atomics,
+    // thirty to an address
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        const int k = N - keys[b];
+        const float* mb = mask + (size_t)b * N;
+        int c = 0;
+#pragma unroll 8
+        for (int i = 0; i < N; ++i) c += mb[i] != 0.f;
+        const int k = N - c;
         keys[b] = k;
         atomicAdd(&hist[k + 1], 1);
         atomicAdd(&wcnt[(b >> 6) * (N + 1) + k], 1);
@@ -105,6 +108,9 @@ MPG_DEV float wave_sum(float x) {
     return x;
 }
 
+MPG_DEV void disc_head_bwd_jet(const MpgDiscHead& p, const int b, const int lane, const float out, const float aux0);
+
+template <bool FUSED>
 __global__ __launch_bounds__(256) void disc_head_fwd_kernel(const MpgDiscHead p) {
     const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= p.B) return;
@@ -137,6 +143,8 @@ __global__ __launch_bounds__(256) void disc_head_fwd_kernel(const MpgDiscHead p)
         p.out[b] = out;
         if (p.aux != nullptr) { p.aux[2 * b] = keep * pool_scale; p.aux[2 * b + 1] = 0.f; }
     }
+    // with a loss named (mpg_disc_head_loss) the jet's backward follows at once: its loss gradient needs nothing but its own output
+    if (FUSED) disc_head_bwd_jet(p, b, lane, out, keep * pool_scale);
 }
 
 // dL/dout of jet b for the named loss (and its loss term); t = 1 for a jet scored against the "real" target
@@ -157,10 +165,9 @@ MPG_DEV float loss_grad(int loss, float out, float t, float& term) {
     }
 }
 
-__global__ __launch_bounds__(256) void disc_head_bwd_kernel(const MpgDiscHead p) {
-    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= p.B) return;
-    const float out = p.out[b];
+// the backward of jet b (one wave), given its output: dL/dout from the named loss (or the upstream gradient), through the
+// final activation, the dropout and the pooling down to dy; the per-jet loss term and d/d(pre-dropout z) are left for the reduction
+MPG_DEV void disc_head_bwd_jet(const MpgDiscHead& p, const int b, const int lane, const float out, const float aux0) {
     float g;  // dL/dout
     if (p.loss >= 0) {
         // D step: jets [0, n_real) are scored against 1, the rest against 0 (hinge: margins); G step (n_real = B with
@@ -173,8 +180,8 @@ __global__ __launch_bounds__(256) void disc_head_bwd_kernel(const MpgDiscHead p)
         g = p.gout[b];
     }
     const float gz = g * (p.sigmoid ? out * (1.f - out) : 1.f);        // through the sigmoid
-    const float gp = gz * p.aux[2 * b];                                // through dropout and the pooling normalisation
-    if (lane == 0) p.aux[2 * b + 1] = gz * (p.aux[2 * b] != 0.f ? (p.thr ? p.dscale : 1.f) : 0.f);  // d/d(pre-dropout z): for db, dw
+    const float gp = gz * aux0;                                        // through dropout and the pooling normalisation
+    if (lane == 0) p.aux[2 * b + 1] = gz * (aux0 != 0.f ? (p.thr ? p.dscale : 1.f) : 0.f);  // d/d(pre-dropout z): for db, dw
     if (p.dy == nullptr) return;
     float* db_ = p.dy + (size_t)b * p.N * p.ld_dy;
     for (int f0 = 0; f0 < p.F; f0 += 32) {
@@ -183,6 +190,12 @@ __global__ __launch_bounds__(256) void disc_head_bwd_kernel(const MpgDiscHead p)
         const float wf = p.w[f] * gp;
         for (int i = lane >> 5; i < p.N; i += 2) db_[(size_t)i * p.ld_dy + f] = (p.mask ? p.mask[(size_t)b * p.N + i] : 1.f) * wf;
     }
+}
+
+__global__ __launch_bounds__(256) void disc_head_bwd_kernel(const MpgDiscHead p) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= p.B) return;
+    disc_head_bwd_jet(p, b, lane, p.out[b], p.aux[2 * b]);
 }
 
 // workgroup 0: the loss value (sum of the per-jet terms, fixed order); workgroups 1..: the head's own parameter gradients,
@@ -390,7 +403,18 @@ extern "C" int mpg_gen_tail_bwd(const float* dout, int ldd, const float* out, in
 
 extern "C" int mpg_disc_head_fwd(const MpgDiscHead* p, void* stream) {
     if (p->B <= 0 || p->N <= 0 || p->F <= 0 || p->out == nullptr || p->aux == nullptr) return -1;
-    hipLaunchKernelGGL(disc_head_fwd_kernel, dim3((p->B + 3) / 4), dim3(256), 0, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL(disc_head_fwd_kernel<false>, dim3((p->B + 3) / 4), dim3(256), 0, (hipStream_t)stream, *p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mpg_disc_head_loss(const MpgDiscHead* p, void* stream) {
+    if (p->B <= 0 || p->N <= 0 || p->F <= 0 || p->out == nullptr || p->aux == nullptr) return -1;
+    if (p->loss < 0 || p->terms == nullptr) return -2;
+    if (p->dw != nullptr && p->pooled == nullptr) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(disc_head_fwd_kernel<true>, dim3((p->B + 3) / 4), dim3(256), 0, st, *p);
+    if (p->loss_out != nullptr || p->dw != nullptr)
+        hipLaunchKernelGGL(disc_head_reduce_kernel, dim3(1 + (p->dw != nullptr ? (p->F + 1 + 7) / 8 : 0)), dim3(256), 0, st, *p);
     return (int)hipGetLastError();
 }
 

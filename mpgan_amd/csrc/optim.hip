@@ -9,13 +9,15 @@
 //   adadelta            lr, rho = 0.9, eps = 1e-6
 //                       v = rho v + (1-rho) g^2 ; d = sqrt(u + eps)/sqrt(v + eps) * g ; u = rho u + (1-rho) d^2 ; p -= lr d
 // `gscale` multiplies the gradient first (1/world_size after a summing all-reduce).  Adam's step count lives in
-// device memory (a captured hipGraph must see it advance on every replay).
+// device memory (a captured hipGraph must see it advance on every replay).  `zero_grad` != 0: the gradient buffer is
+// cleared behind its last use (the next backward accumulates into zeros: optimizer.zero_grad() of train.py:419 / :494
+// without a launch of its own).
 #include "common.h"
 #include "../../include/mpgan_amd.h"
 
 namespace {
-__global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v, size_t n,
-                               float lr, float alpha, float eps, float gscale) {
+__global__ void rmsprop_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ v, size_t n,
+                               float lr, float alpha, float eps, float gscale, int zero_grad) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -23,12 +25,13 @@ __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ 
         const float vi = alpha * v[i] + (1.f - alpha) * gi * gi;
         v[i] = vi;
         p[i] -= lr * gi / (sqrtf(vi) + eps);
+        if (zero_grad) g[i] = 0.f;
     }
 }
 
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             const float* __restrict__ step, size_t n, float lr, float b1, float b2, float eps, float wd,
-                            float gscale) {
+                            float gscale, int zero_grad) {
     const float t = *step + 1.f;
     const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
     const float step_size = lr / bc1;
@@ -42,12 +45,13 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         m[i] = mi;
         v[i] = vi;
         p[i] = pi - step_size * mi / (sqrtf(vi) / bc2s + eps);
+        if (zero_grad) g[i] = 0.f;
     }
 }
 __global__ void step_inc_kernel(float* step) { *step += 1.f; }
 
-__global__ void adadelta_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v, float* __restrict__ u,
-                                size_t n, float lr, float rho, float eps, float gscale) {
+__global__ void adadelta_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ v, float* __restrict__ u,
+                                size_t n, float lr, float rho, float eps, float gscale, int zero_grad) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -57,34 +61,63 @@ __global__ void adadelta_kernel(float* __restrict__ p, const float* __restrict__
         v[i] = vi;
         u[i] = rho * u[i] + (1.f - rho) * d * d;
         p[i] -= lr * d;
+        if (zero_grad) g[i] = 0.f;
+    }
+}
+
+// out[i] = mean + std * z_i, z ~ N(0, 1): counter-based (two hashes of (seed, tag, pair index) -> Box-Muller, one pair of
+// values per thread), so a captured hipGraph draws fresh values on every replay from the device-resident seed alone
+__global__ void normal_kernel(float* __restrict__ out, size_t n, const uint64_t* __restrict__ seed, uint32_t tag, float mean, float std) {
+    const uint64_t sd = *seed;
+    const uint32_t lo = (uint32_t)sd, hi = (uint32_t)(sd >> 32);
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, npair = (n + 1) / 2;
+    for (; i < npair; i += stride) {
+        // (the pair index goes through the mixer twice, the second time with the words swapped: two independent 32-bit streams)
+        uint32_t a = drop_word(lo, hi, tag, (uint32_t)i, (uint32_t)(i >> 32));
+        uint32_t b = drop_word(hi ^ 0x9E3779B9u, lo, tag + 0x7F4A7C15u, (uint32_t)i ^ a, (uint32_t)(i >> 32) + 1u);
+        const float u1 = ((float)(a >> 8) + 0.5f) * (1.f / 16777216.f);      // (0, 1)
+        const float u2 = ((float)(b >> 8) + 0.5f) * (1.f / 16777216.f);
+        const float r = sqrtf(-2.f * logf(u1)) * std;
+        float sn, cs;
+        sincosf(6.283185307179586f * u2, &sn, &cs);
+        out[2 * i] = mean + r * cs;
+        if (2 * i + 1 < n) out[2 * i + 1] = mean + r * sn;
     }
 }
 
 inline int nblocks(uint64_t n) { return (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048); }
 }  // namespace
 
-extern "C" int mpg_rmsprop(float* p, const float* g, float* v, uint64_t n, float lr, float alpha, float eps,
-                           float gscale, void* stream) {
+extern "C" int mpg_rmsprop(float* p, float* g, float* v, uint64_t n, float lr, float alpha, float eps,
+                           float gscale, int zero_grad, void* stream) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(rmsprop_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, v, (size_t)n, lr, alpha,
-                       eps, gscale);
+                       eps, gscale, zero_grad);
     return (int)hipGetLastError();
 }
 
-extern "C" int mpg_adam(float* p, const float* g, float* m, float* v, float* step, uint64_t n, float lr, float beta1,
-                        float beta2, float eps, float weight_decay, float gscale, void* stream) {
+extern "C" int mpg_adam(float* p, float* g, float* m, float* v, float* step, uint64_t n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, float gscale, int zero_grad, void* stream) {
     if (n == 0) return 0;
     if (step == nullptr) return -1;
     hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, step, (size_t)n, lr,
-                       beta1, beta2, eps, weight_decay, gscale);
+                       beta1, beta2, eps, weight_decay, gscale, zero_grad);
     hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
     return (int)hipGetLastError();
 }
 
-extern "C" int mpg_adadelta(float* p, const float* g, float* v, float* u, uint64_t n, float lr, float rho, float eps,
-                            float gscale, void* stream) {
+extern "C" int mpg_adadelta(float* p, float* g, float* v, float* u, uint64_t n, float lr, float rho, float eps,
+                            float gscale, int zero_grad, void* stream) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(adadelta_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, v, u, (size_t)n, lr, rho,
-                       eps, gscale);
+                       eps, gscale, zero_grad);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mpg_normal(float* out, uint64_t n, const uint64_t* seed, uint32_t tag, float mean, float std, void* stream) {
+    if (n == 0) return 0;
+    if (seed == nullptr || !(std >= 0.f)) return -1;
+    hipLaunchKernelGGL(normal_kernel, dim3(nblocks((n + 1) / 2)), dim3(256), 0, (hipStream_t)stream, out, (size_t)n, seed, tag, mean, std);
     return (int)hipGetLastError();
 }

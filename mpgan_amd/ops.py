@@ -151,6 +151,19 @@ def bump_seed(device="cuda"):
     seed_tensor(device).add_(0x1E3779B97F4A7C15)
 
 
+NOISE_TAG = 0x4E000000   # site tags of ``normal_noise`` (dropout sites stay below 2^27: next_tag)
+
+
+def normal_noise(shape, std: float, site: int = 0, device="cuda", mean: float = 0.0) -> torch.Tensor:
+    """A fresh [*shape] tensor of N(mean, std^2) samples from the counter-based stream of ``mpg_normal``: keyed by the
+    device's seed (``bump_seed`` once per iteration) and ``site`` (which draw of the iteration).  The generator's input noise
+    (train.py:100-141) inside a captured iteration: no torch generator state to carry through the graph."""
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    check(_lib.lib().mpg_normal(_p(out), out.numel(), _p(seed_tensor(out.device)), NOISE_TAG + int(site), mean, std, _stream()),
+          "mpg_normal")
+    return out
+
+
 def next_tag(device="cuda") -> int:
     """A fresh dropout-site tag base (8 sites per call) for one fused-op invocation on ``device``."""
     st = dev_state(device)
@@ -1369,14 +1382,13 @@ def disc_head_loss(y, mask, w, b, *, mean, sigmoid, p_drop, training, loss, n_re
     terms = torch.empty((B,), device=dev, dtype=torch.float32)
     tag = next_tag(dev) + TAG_GENERIC
     h = _head_struct(y, m, w.reshape(-1), b, mean, sigmoid, p_drop, training, tag, out, pooled, aux)
-    check(_lib.lib().mpg_disc_head_fwd(C.byref(h), _stream()), "mpg_disc_head_fwd")
     h.loss, h.gen_step, h.n_real, h.inv_count = LOSS_CODES[loss], int(gen_step), n_real, 1.0 / count
     h.terms, h.loss_out = _p(terms), _p(loss_out)
     dy = torch.empty((B, N, F), device=dev, dtype=torch.float32) if want_dy else None
     h.dy, h.ld_dy = _p(dy), F
     if wgrad is not None:
         h.dw, h.db, h.accumulate = _p(wgrad[0]), _p(wgrad[1]), 1
-    check(_lib.lib().mpg_disc_head_bwd(C.byref(h), _stream()), "mpg_disc_head_bwd")
+    check(_lib.lib().mpg_disc_head_loss(C.byref(h), _stream()), "mpg_disc_head_loss")
     return out, dy
 
 

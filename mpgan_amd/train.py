@@ -140,21 +140,23 @@ class FlatParams:
         self.grad.zero_()
 
     # -- the fused step -----------------------------------------------------------------------------
-    def step(self, lr: float, gscale: float = 1.0):
-        """One optimiser step over the flat buffer; ``gscale`` multiplies the gradient first."""
+    def step(self, lr: float, gscale: float = 1.0, zero_grad: bool = False):
+        """One optimiser step over the flat buffer; ``gscale`` multiplies the gradient first; ``zero_grad``: the gradient
+        buffer is cleared by the same launch, behind its last use."""
         self.lr = lr
         vp = lambda t: C.c_void_p(t.data_ptr())
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         L = _lib.lib()
+        z = int(zero_grad)
         if self.optimizer == "rmsprop":
-            _lib.check(L.mpg_rmsprop(vp(self.flat), vp(self.grad), vp(self.sq), self.n, lr, 0.99, 1e-8, gscale, st),
+            _lib.check(L.mpg_rmsprop(vp(self.flat), vp(self.grad), vp(self.sq), self.n, lr, 0.99, 1e-8, gscale, z, st),
                        "mpg_rmsprop")
         elif self.optimizer == "adam":
             _lib.check(L.mpg_adam(vp(self.flat), vp(self.grad), vp(self.aux), vp(self.sq), vp(self.step_count), self.n,
-                                  lr, self.betas[0], self.betas[1], 1e-8, self.weight_decay, gscale, st), "mpg_adam")
+                                  lr, self.betas[0], self.betas[1], 1e-8, self.weight_decay, gscale, z, st), "mpg_adam")
         else:
             _lib.check(L.mpg_adadelta(vp(self.flat), vp(self.grad), vp(self.sq), vp(self.aux), self.n, lr, 0.9, 1e-6,
-                                      gscale, st), "mpg_adadelta")
+                                      gscale, z, st), "mpg_adadelta")
         if not (self.flat.is_cuda and torch.cuda.is_current_stream_capturing()):  # a capture records the launch, it does not run it
             self._host_steps += 1
 
@@ -369,11 +371,17 @@ class TrainStep:
         self._wside = None
         self.fixed_noise = None  # tests: (noise_D, noise_G) used instead of fresh samples
         self._seen_versions = (self.fD.versions(), self.fG.versions())
+        # the flat gradient buffers start as zeros and every optimizer launch of an iteration leaves them cleared again
+        # (FlatParams.step(zero_grad=True)): no memset of its own at the top of train_D / train_G.  A caller that accumulates
+        # into the networks' .grad between iterations calls ``mark_grads_dirty()``.
+        self._clean = {"D": True, "G": True}
 
     # -- the three segments between collectives ------------------------------------------------
     def _noise(self, which: int = 0):
         if self.fixed_noise is not None:
             return self.fixed_noise[which]
+        if self.dev.type == "cuda":   # counter-based, keyed by the device seed (bumped once per iteration) and the draw's site
+            return ops.normal_noise((self.B, self.N, self.latent), self.noise_std, site=which, device=self.dev)
         return torch.empty(self.B, self.N, self.latent, device=self.dev).normal_(0.0, self.noise_std)
 
     def _fused_ends(self) -> bool:
@@ -401,7 +409,9 @@ class TrainStep:
         if self.gen_ahead:
             self._fork_generator()
         self.G.eval()
-        self.fD.zero_grad()
+        if not self._clean["D"]:     # (cleared by the optimizer launch of the iteration before: see _seg_G)
+            self.fD.zero_grad()
+        self._clean["D"] = False
         _set_requires_grad(self.fD, True)
         try:
             self._seg_D_body()
@@ -496,10 +506,14 @@ class TrainStep:
             ops.refresh_many(packs)
 
     def _seg_G(self):  # D_optimizer.step() (train.py:461) + train_G up to backward (:494-520)
-        self.fD.step(self.lr_disc, gscale=1.0 / self.world)
+        # optimizer.zero_grad() of the next train_D (train.py:419) rides in this launch: the buffer is cleared behind its last use
+        self.fD.step(self.lr_disc, gscale=1.0 / self.world, zero_grad=True)
+        self._clean["D"] = True
         self._refresh_packed(self.D)
         self.G.train()
-        self.fG.zero_grad()
+        if not self._clean["G"]:
+            self.fG.zero_grad()
+        self._clean["G"] = False
         _set_requires_grad(self.fD, False)
         fake, self._fake_ahead = self._fake_ahead, None
         if fake is None:
@@ -516,9 +530,14 @@ class TrainStep:
         _set_requires_grad(self.fD, True)
 
     def _seg_end(self):  # G_optimizer.step() (train.py:521)
-        self.fG.step(self.lr_gen, gscale=1.0 / self.world)
+        self.fG.step(self.lr_gen, gscale=1.0 / self.world, zero_grad=True)
+        self._clean["G"] = True
         self._refresh_packed(self.G)
         self.state.grad_into_param = False
+
+    def mark_grads_dirty(self):
+        """Tell the step that something outside it wrote the networks' .grad buffers: the next iteration clears them first."""
+        self._clean = {"D": False, "G": False}
 
     def _allreduce(self, flat: FlatParams):
         mdist.allreduce_sum_(flat.grad, self.pg, self.world)  # sum; 1/world is folded into the optimiser step

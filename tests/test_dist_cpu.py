@@ -37,11 +37,14 @@ class ToyD(torch.nn.Module):
         return torch.sigmoid(self.net(x.reshape(x.shape[0], -1)) + labels)
 
 
-def _torch_rmsprop(self, lr, gscale=1.0):
+def _torch_rmsprop(self, lr, gscale=1.0, zero_grad=False):
     """FlatParams.step for CPU tensors: mpg_rmsprop's arithmetic (csrc/optim.hip) in torch."""
+    self.last_grad = self.grad.clone()      # (what the step consumed: the buffer itself is cleared below)
     g = self.grad * gscale
     self.sq.mul_(0.99).addcmul_(g, g, value=0.01)
     self.flat.addcdiv_(g, self.sq.sqrt() + 1e-8, value=-lr)
+    if zero_grad:
+        self.grad.zero_()
     self._host_steps += 1
     self.lr = lr
 
@@ -73,7 +76,7 @@ def _run(world, rank, pg, steps=3, loss="ls"):
     ts.fixed_noise = (nD[sl], nG[sl])
     for _ in range(steps):
         ts.step()
-    return ts.fD.flat.clone(), ts.fG.flat.clone(), ts.fD.grad.clone(), float(ts.D_loss), ts
+    return ts.fD.flat.clone(), ts.fG.flat.clone(), ts.fD.last_grad.clone(), float(ts.D_loss), ts
 
 
 def _worker(rank, world, port, out):

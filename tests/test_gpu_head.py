@@ -155,3 +155,36 @@ def test_disc_head_fused_loss_vs_reference_golden(loss):
         want_g = g[f"{loss}_dG_df"] if gen_step else np.concatenate([g[f"{loss}_dD_dr"], g[f"{loss}_dD_df"]])
         assert abs(float(loss_out) - want_L) < 1e-5 * max(1.0, abs(want_L)), (loss, gen_step)
         assert rel_err(dy.reshape(-1).cpu().numpy(), want_g.reshape(-1)) < 1e-5, (loss, gen_step)
+
+
+def test_normal_noise_stream():
+    """``mpg_normal`` (the generator's input noise inside a captured iteration): moments of N(0, 0.2^2) over 2e6 values, no
+    correlation between neighbours or between the two values of a Box-Muller pair, a Kolmogorov distance to the normal CDF
+    at the sampling-noise level, the same values for the same (seed, site) and unrelated ones for another site or seed."""
+    from mpgan_amd import ops
+    import math
+    dev = torch.device("cuda:0")
+    ops.set_seed(2024, dev)
+    n = 2_000_001   # (odd: the last pair is half used)
+    a = ops.normal_noise((n,), 0.2, site=0, device=dev)
+    b = ops.normal_noise((n,), 0.2, site=0, device=dev)
+    c = ops.normal_noise((n,), 0.2, site=1, device=dev)
+    ops.bump_seed(dev)
+    d = ops.normal_noise((n,), 0.2, site=0, device=dev)
+    assert torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, d)
+    z = (a.double() / 0.2).cpu()
+    assert bool(torch.isfinite(z).all())
+    se = 1.0 / math.sqrt(n)
+    assert abs(float(z.mean())) < 5 * se
+    assert abs(float(z.var()) - 1.0) < 5 * math.sqrt(2.0) * se
+    assert abs(float((z ** 3).mean())) < 5 * math.sqrt(15.0) * se
+    assert abs(float((z ** 4).mean()) - 3.0) < 5 * math.sqrt(96.0) * se
+    for x, y in ((z[:-1], z[1:]), (z[0:-1:2], z[1::2]), (z[:-2], z[2:])):
+        assert abs(float((x * y).mean())) < 5 / math.sqrt(x.numel())
+    for x, y in ((z, (c.double() / 0.2).cpu()), (z, (d.double() / 0.2).cpu())):
+        assert abs(float((x * y).mean())) < 5 * se
+    zs, _ = torch.sort(z)
+    cdf = 0.5 * (1 + torch.erf(zs / math.sqrt(2.0)))
+    ks = float((cdf - torch.arange(1, n + 1, dtype=torch.float64) / n).abs().max())
+    assert ks < 2.0 / math.sqrt(n), ks      # (1.36 / sqrt(n) is the 5 % point of the Kolmogorov statistic)
+    assert float(z.abs().max()) > 4.5       # the tails are there

@@ -341,7 +341,8 @@ def test_fused_optimizers_vs_torch(opt):
         for p, q, gr in zip(net.parameters(), ref.parameters(), grads):
             p.grad.copy_(2.0 * gr)          # "summed over 2 ranks"
             q.grad = gr.double()
-        fp.step(lr, gscale=0.5)
+        fp.step(lr, gscale=0.5, zero_grad=it % 2 == 1)
+        assert (float(fp.grad.abs().max()) == 0.0) == (it % 2 == 1)   # cleared behind its last use, only when asked
         to.step()
     for p, q in zip(net.parameters(), ref.parameters()):
         assert rel_err(p.detach().cpu().numpy(), q.detach().cpu().numpy()) < 1e-5
