@@ -236,15 +236,18 @@ typedef struct MpgEdgeBwd {
 } MpgEdgeBwd;
 int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream);
 
-/* mpg_edge_bwd_fn: mpg_edge_bwd with the node network's input-gradient chain as the PROLOGUE of every workgroup -- one
- * launch for the backward of  x = fn(cat((A, x))) ; A = sum_j mask * fe(...)  (mpgan/model.py:256-279) from dy down to
- * da, dc.  `c` is the chain mpg_chain would be given for the node network's backward (three transposed layers with the
- * gates of the forward's activations / dropouts, input = dy with the trailing dropout's gate, outputs dz2, dz1 and
- * [dagg | dx(node path)]); its last output must be the rows p->dagg points at.  Each workgroup runs it on its own 32
- * receivers, then goes on as mpg_edge_bwd; results are bit-identical to mpg_chain followed by mpg_edge_bwd.
- * Covered: SC = 1, no edge scalars, bf16 images, layer widths K <= 32 -> (224, 256] -> (224, 256] -> N <= 256, one dropout
- * mode.  Anything else returns MPG_FN_NA without launching. */
-int mpg_edge_bwd_fn(const MpgEdgeBwd* p, const MpgChain* c, void* stream);
+/* mpg_edge_bwd_fn: mpg_edge_bwd with EPILOGUE chains on every workgroup's own jet -- one launch for the backward of an
+ * MPLayer (mpgan/model.py:256-279) from dagg down to its input gradient, and on through the node network of the layer below:
+ *   cdx  the "dx from da | dc" chain mpg_chain would be given behind this call: one layer, input A = p->da (96 columns) | A2 =
+ *        p->dc, the stacked transposed W1 image, residual = the node path's dx, output dx [B*N, F <= 32];
+ *   cnx  (or NULL) the node network's input-gradient chain of the NEXT-LOWER layer (three transposed layers with the gates of
+ *        its forward, input = those dx rows with the trailing dropout's gate, outputs dz2, dz1, [dagg | dx]) as mpg_chain
+ *        takes it.
+ * A workgroup runs them on its 32 nodes when its own sender loop is done, while the fullest jets' workgroups are still in
+ * theirs.  Results are bit-identical to mpg_edge_bwd followed by the mpg_chain calls.
+ * Covered: a whole jet per workgroup (N <= 32, SC = 1), no edge scalars, bf16 images, one dropout mode; cnx widths K <= 32 ->
+ * (224, 256] -> (224, 256] -> N <= 256.  Anything else returns MPG_FN_NA without launching. */
+int mpg_edge_bwd_fn(const MpgEdgeBwd* p, const MpgChain* cdx, const MpgChain* cnx, void* stream);
 
 /* mpg_edge_dw: weight gradients of fe.net.1 / fe.net.2 (and their biases) from the fragments parked by
  * mpg_edge_bwd:  dW3 = dscale * sum_e dZ3 E2^T [192,160], dW2 = dscale * sum_e dZ2 E1^T [160,96],

@@ -179,7 +179,7 @@ SIGNATURES = {
     "mpg_edge_fwd": (C.c_int, [C.POINTER(MpgEdgeFwd), C.c_void_p]),
     "mpg_edge_fwd_fn": (C.c_int, [C.POINTER(MpgEdgeFwd), C.POINTER(MpgChain), C.POINTER(MpgChain), C.c_void_p]),
     "mpg_edge_bwd": (C.c_int, [C.POINTER(MpgEdgeBwd), C.c_void_p]),
-    "mpg_edge_bwd_fn": (C.c_int, [C.POINTER(MpgEdgeBwd), C.POINTER(MpgChain), C.c_void_p]),
+    "mpg_edge_bwd_fn": (C.c_int, [C.POINTER(MpgEdgeBwd), C.POINTER(MpgChain), C.POINTER(MpgChain), C.c_void_p]),
     "mpg_edge_dw": (C.c_int, [C.POINTER(MpgEdgeDw), C.c_void_p]),
     "mpg_attn_fwd": (C.c_int, [C.POINTER(MpgAttn), C.c_void_p]),
     "mpg_attn_bwd": (C.c_int, [C.POINTER(MpgAttn), C.c_void_p]),

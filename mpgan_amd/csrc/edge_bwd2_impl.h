@@ -96,14 +96,20 @@ MPG_DEV f32x16 mma(const f16x8 a, const f16x8 b, const f32x16 c) { return __buil
 
 // DROP: 0 off, 1 byte mode, 2 bit mode (see common.h); NQ: edge scalars (0 or MPG_EDGE_SCALARS): Z1 = a_i + c_j + sum_q es wq[q],
 // and the kernel also returns des = dZ1 . wq[q] per edge and daq = sum_j es dZ1 per receiver
-// FNB: 0 = dagg comes from memory as it is; 1 / 2 = the workgroup first runs the node network's INPUT-GRADIENT chain (the
-// backward of mpgan/model.py:279: dz2 = gate(V3^T dy), dz1 = gate(V2^T dz2), [dagg | dx] = V1^T dz1 -- the chain `cp`, as
-// mpg_chain takes it) on its own 32 receivers, with chain2's schedule (chain2_impl.h; 2: the last layer's rows are not whole
-// 16-byte groups), and then goes on with the rows of dagg it has just written -- one launch instead of two.  Needs the
-// receivers of a block in ONE workgroup (SC = 1).
-static_assert(C2_LDS <= B2_LDS_BYTES, "the chain's buffers must fit the data-gradient kernel's LDS");
-template <int DROP, bool NEEDW, int NQ, int FNB>
-MPG_DEV void edge_bwd_body(const MpgEdgeBwd& p, const MpgChain* const cp) {
+// EPI: what the workgroup does BEHIND its data-gradient work, as an epilogue on its own 32 nodes (a whole jet per workgroup:
+// N <= 32, SC = 1 -- then the jet's rows of da AND dc are this workgroup's own stores):
+//   0  nothing;
+//   1 / 2 / 3  the layer's input gradient  dx = [da | dc] [W1a ; W1c] + dx(node path)  (the chain `cdx`: mpg_chain's "dx from da | dc"
+//      call) and -- 1, 2, when `cnx` has layers -- the NEXT-LOWER MPLayer's node-network input-gradient chain on those dx rows
+//      (the backward of its fn, mpgan/model.py:279, as mpg_chain takes it: dz2 = gate(V3^T dy), dz1 = gate(V2^T dz2),
+//      [dagg | dx] = V1^T dz1), with chain2's schedule (chain2_impl.h).  2: that chain's last rows are not whole 16-byte groups
+//      (a 195-column [dagg | dx]); 3: dx's own rows are not (3 features) and nothing follows.
+// A workgroup whose jet has few senders does this while the fullest jets' workgroups are still in their sender loops: the
+// launch is as long as its slowest workgroup, and the chains of most jets hide in its tail (measured for the forward's epilogue,
+// edge_fwd2_impl.h: +2.8 %; as a PROLOGUE -- on every workgroup's critical path -- the same chain was 1.2 % slower than its own launch).
+static_assert(C2_LDS <= B2_LDS_BYTES, "the chains' buffers must fit the data-gradient kernel's LDS");
+template <int DROP, bool NEEDW, int NQ, int EPI>
+MPG_DEV void edge_bwd_body(const MpgEdgeBwd& p, const MpgChain* const cdxp, const MpgChain* const cnxp) {
     constexpr int QB = NQ > 0 ? B2_Q_BYTES : B2_B2_BYTES;   // bytes between the a tile and the rows of c
     typedef f16x8 V;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -132,21 +138,6 @@ MPG_DEV void edge_bwd_body(const MpgEdgeBwd& p, const MpgChain* const cp) {
     int* lnv = reinterpret_cast<int*>(lst + (NQ > 0 ? B2_LIST_MAX_Q : B2_LIST_MAX));
     float* lmx = reinterpret_cast<float*>(smem + B2_LDS_BYTES - 16);                // wave maxima of |dagg|
 
-    if constexpr (FNB != 0) {
-        // ---- the node network's input-gradient chain on this workgroup's receivers (rows b N + 32 rb ..): its buffers take the
-        //      LDS the weight copy below will overwrite; dz3 / dz2 / dz1 (for the weight gradients) and [dagg | dx] go to memory
-        //      as the stand-alone launch writes them
-        const MpgChain& c = *cp;
-        const int m0 = b * p.N + rb * 32, nrows = min(32, p.N - rb * 32);
-        auto stage = [&](auto&& first_tile, auto&& bias_request, auto&& bias_store, const uint32_t s_lo, const uint32_t s_hi, const float ascale) {
-            c2_stage_rows<false, 2, DROP>(c, m0, nrows, smem, first_tile, bias_request, bias_store, s_lo, s_hi, ascale);
-        };
-        c2_body<false, 2, 16, 16, DROP, 3, 0, FNB == 2>(c, m0, nrows, smem, smem + C2_FB, reinterpret_cast<float*>(smem + 2 * C2_FB), stage);
-        // the rows of dagg this workgroup reads below are the ones it has just written: ordered within the workgroup
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
     // ---- prologue (whole workgroup): weights and the per-receiver tiles into LDS, the list of unmasked senders
     copy_to_lds(l3t, t3g, 2 * NF3T * 64, tid);
     // upstream gradient dagg (scaled) and the layer-1 receiver term a, both in the register order the chain layout
@@ -618,28 +609,59 @@ MPG_DEV void edge_bwd_body(const MpgEdgeBwd& p, const MpgChain* const cp) {
             }
         });
     }
+    if constexpr (EPI != 0) {
+        // ---- epilogue chains on this jet's nodes.  The rows of da (just written above) and of dc (written sender by sender in
+        //      the loop, zeros for masked senders in the prologue) are this workgroup's own stores: ordered within the workgroup.
+        const int m0 = b * p.N + rb * 32, nrows = min(32, p.N - rb * 32);
+        {
+            const MpgChain& c = *cdxp;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            auto stage = [&](auto&& first_tile, auto&& bias_request, auto&& bias_store, const uint32_t s_lo, const uint32_t s_hi, const float ascale) {
+                c2_stage_rows<false, 12, 0>(c, m0, nrows, smem, first_tile, bias_request, bias_store, s_lo, s_hi, ascale);
+            };
+            c2_body<false, 12, 0, 0, 0, 0, 1, EPI == 3>(c, m0, nrows, smem, smem + C2_FB, reinterpret_cast<float*>(smem + 2 * C2_FB), stage);
+        }
+        if constexpr (EPI != 3) {
+            if (cnxp->nlayers > 0) {
+                const MpgChain& c = *cnxp;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                auto stage = [&](auto&& first_tile, auto&& bias_request, auto&& bias_store, const uint32_t s_lo, const uint32_t s_hi, const float ascale) {
+                    c2_stage_rows<false, 2, DROP>(c, m0, nrows, smem, first_tile, bias_request, bias_store, s_lo, s_hi, ascale);
+                };
+                c2_body<false, 2, 16, 16, DROP, 3, 0, EPI == 2>(c, m0, nrows, smem, smem + C2_FB, reinterpret_cast<float*>(smem + 2 * C2_FB), stage);
+            }
+        }
+    }
 }
 
 template <int DROP, bool NEEDW, int NQ>
-__global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) { edge_bwd_body<DROP, NEEDW, NQ, 0>(p, nullptr); }
+__global__ __launch_bounds__(256, 1) void edge_bwd_kernel(const MpgEdgeBwd p) { edge_bwd_body<DROP, NEEDW, NQ, 0>(p, nullptr, nullptr); }
 
-template <int DROP, bool NEEDW, bool SL>
-__global__ __launch_bounds__(256, 1) void edge_bwd_fn_kernel(const MpgEdgeBwd p, const MpgChain c) {
-    edge_bwd_body<DROP, NEEDW, 0, SL ? 2 : 1>(p, &c);
+template <int DROP, bool NEEDW, int EPI>
+__global__ __launch_bounds__(256, 1) void edge_bwd_fn_kernel(const MpgEdgeBwd p, const MpgChain cdx, const MpgChain cnx) {
+    edge_bwd_body<DROP, NEEDW, 0, EPI>(p, &cdx, &cnx);
 }
 
-// the chain-prologue form of one dropout mode / NEEDW (edge_bwd_fn_*.hip: one translation unit each)
+// the epilogue forms of one dropout mode / NEEDW (edge_bwd_fn_*.hip: one translation unit each); epi = 1, 2, 3 as above
 template <int D, bool NEEDW>
-int b2_launch_fn(const MpgEdgeBwd* p, const MpgChain* c, bool sl, hipStream_t st) {
+int b2_launch_fn(const MpgEdgeBwd* p, const MpgChain* cdx, const MpgChain* cnx, int epi, hipStream_t st) {
     const int RB = (p->N + 31) / 32;
     dim3 grid(p->B * RB), block(256);
-    if (sl) {
-        MPG_ENSURE_LDS((edge_bwd_fn_kernel<D, NEEDW, true>), B2_LDS_BYTES);
-        hipLaunchKernelGGL((edge_bwd_fn_kernel<D, NEEDW, true>), grid, block, B2_LDS_BYTES, st, *p, *c);
-    } else {
-        MPG_ENSURE_LDS((edge_bwd_fn_kernel<D, NEEDW, false>), B2_LDS_BYTES);
-        hipLaunchKernelGGL((edge_bwd_fn_kernel<D, NEEDW, false>), grid, block, B2_LDS_BYTES, st, *p, *c);
-    }
+    MpgChain none = {};   // nlayers = 0: no second chain
+    if (cnx == nullptr) cnx = &none;
+#define MPG_B2FN(E)                                                                                        \
+    do {                                                                                                   \
+        MPG_ENSURE_LDS((edge_bwd_fn_kernel<D, NEEDW, E>), B2_LDS_BYTES);                                   \
+        hipLaunchKernelGGL((edge_bwd_fn_kernel<D, NEEDW, E>), grid, block, B2_LDS_BYTES, st, *p, *cdx, *cnx); \
+    } while (0)
+    if (epi == 1) MPG_B2FN(1);
+    else if (epi == 2) MPG_B2FN(2);
+    else MPG_B2FN(3);
+#undef MPG_B2FN
     return (int)hipGetLastError();
 }
 

@@ -1,5 +1,5 @@
-// The data-gradient kernel with the node network's input-gradient chain as its prologue (mpg_edge_bwd_fn, see edge_bwd_fn.hip),
+// The data-gradient kernel with its epilogue chains (mpg_edge_bwd_fn, see edge_bwd_fn.hip),
 // dropout mode 0, data path only.
 #include "edge_bwd2_impl.h"
 
-int mpg_edge_bwd_fn_d0w0(const MpgEdgeBwd* p, const MpgChain* c, bool sl, hipStream_t st) { return b2_launch_fn<0, false>(p, c, sl, st); }
+int mpg_edge_bwd_fn_d0w0(const MpgEdgeBwd* p, const MpgChain* cdx, const MpgChain* cnx, int epi, hipStream_t st) { return b2_launch_fn<0, false>(p, cdx, cnx, epi, st); }

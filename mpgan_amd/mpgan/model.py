@@ -300,11 +300,13 @@ class MPLayer(nn.Module):
         handoff = None
         nxt = self.__dict__.get("_next_layer")
         ac_in = getattr(x, "_mpg_ac", None)
-        if packed is not None and (ac_in is not None or nxt is not None):
+        # (x straight out of another fused layer: this layer's backward may run that layer's input-gradient chain in its own launch)
+        prev_node = x.grad_fn if (x.grad_fn is not None and type(x.grad_fn).__name__ == "FusedMPLayerFnBackward") else None
+        if packed is not None and (ac_in is not None or nxt is not None or prev_node is not None):
             nx = None
             if nxt is not None and nxt.fused and not nxt._diff_cols and nxt.training == self.training and nxt.n_es == 0:
                 nx = (nxt._packed(), nxt.fe.net[0].bias)
-            handoff = ops.LayerHandoff(next=nx, ac_in=ac_in)
+            handoff = ops.LayerHandoff(next=nx, ac_in=ac_in, prev_node=prev_node)
         y = ops.FusedMPLayerFn.apply(
             x, mask if use_mask else None,
             W1, fe[0].bias, fe[1].weight, fe[1].bias, fe[2].weight, fe[2].bias,

@@ -36,10 +36,9 @@ OPTIONS = {
     # the node network fn as the epilogue of the fused edge forward (mpg_edge_fwd_fn: one launch instead of two, same bits);
     # False = mpg_edge_fwd followed by mpg_chain
     "fn_epilogue": os.environ.get("MPG_FN_EPILOGUE", "1") != "0",
-    # ... and its input-gradient chain as the prologue of the data-gradient kernel (mpg_edge_bwd_fn); False = mpg_chain + mpg_edge_bwd
-    # (measured, same box, 300 iterations: +0.1 .. +0.6 % without the weight-gradient side stream, -1.2 % with it -- the prologue
-    # is on every workgroup's critical path, nothing of it hides in the launch's tail -- so it is off by default)
-    "fn_prologue": os.environ.get("MPG_FN_PROLOGUE", "0") != "0",
+    # ... and, in the backward, the layer's dx chain and the layer-below's node-network input-gradient chain as the epilogue of the
+    # data-gradient kernel (mpg_edge_bwd_fn: one launch instead of three); False = mpg_edge_bwd followed by the mpg_chain calls
+    "bwd_epilogue": os.environ.get("MPG_BWD_EPILOGUE", "1") != "0",
 }
 NUM_CUS = 256
 # Forward products (they decide LeakyReLU signs) are split as fp16 hi/lo with the operand scales below (~2^-21 per
@@ -520,15 +519,56 @@ def dw_workgroups(nblk, N):
     return min(nruns, max(256, -(-nruns // (64 // R))))
 
 
+def _fn_grad_chain(ctx, gy2):
+    """Buffers and the ``MpgChain`` block of the node network's input-gradient chain of the layer behind ``ctx`` (the backward
+    of mpgan/model.py:279) for the upstream gradient rows ``gy2`` [B*N, out]: (dz3, dz2, dz1, dh0, chain)."""
+    x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3 = ctx.saved_tensors[:14]
+    pk = ctx.packed
+    B, N, F, agg_scale, alpha, thr, dscale, tag = ctx.cfg[:8]
+    V, dev = B * N, gy2.device
+    n1, n2, out_f = V1.shape[0], V2.shape[0], V3.shape[0]
+    dz3 = torch.empty_like(gy2) if thr else gy2
+    dz2 = torch.empty((V, n2), device=dev, dtype=torch.float32)
+    dz1 = torch.empty((V, n1), device=dev, dtype=torch.float32)
+    dh0 = torch.empty((V, V1.shape[1]), device=dev, dtype=torch.float32)  # [dagg | dx(node path) | (conditioning columns)]
+    c = chain_struct(V, [dict(img=pk.ptr("V3T"), K=out_f, N=n2, gate=(h2, True, tag + TAG_N1, thr, dscale), out=dz2),
+                         dict(img=pk.ptr("V2T"), K=n2, N=n1, gate=(h1, True, tag + TAG_N0, thr, dscale), out=dz1),
+                         dict(img=pk.ptr("V1T"), K=n1, N=V1.shape[1], out=dh0)],
+                     A=gy2, lda=gy2.stride(0), K1=out_f, in_gate=(tag + TAG_N2, thr, dscale), in_out=dz3 if thr else None,
+                     alpha=alpha, seed_t=seed_tensor(dev), f16=False)
+    return dz3, dz2, dz1, dh0, c
+
+
+def _below_chain(prev, dx, x2, thr, alpha, V):
+    """``_fn_grad_chain`` of the layer that produced this layer's input (``prev``: its backward context), fed with this layer's
+    ``dx`` rows -- or None when that layer cannot take it: not a fused layer's direct output, another dropout mode or slope,
+    rows that are not this layer's x, no backward pending there."""
+    if prev is None or getattr(prev, "cfg", None) is None or getattr(prev, "packed", None) is None:
+        return None
+    try:
+        saved = prev.saved_tensors
+    except RuntimeError:   # (already released: its backward has run)
+        return None
+    pB, pN, pF, _, palpha, pthr, _, _ = prev.cfg[:8]
+    h1, h2, V3 = saved[4], saved[5], saved[13]
+    if h1 is None or h2 is None or pB * pN != V or V3.shape[0] != dx.shape[1] or pthr != thr or palpha != alpha:
+        return None
+    if not any(prev.needs_input_grad):
+        return None
+    return _fn_grad_chain(prev, dx)
+
+
 class LayerHandoff:
     """What consecutive fused MPLayers of one network pass to each other around ``FusedMPLayerFn`` (``MPNet`` wires it):
     ``next`` = (PackedMPLayer, fe.net.0.bias) of the layer that will take this layer's output; ``ac_in`` / ``ac_out`` =
     (a | c [B*N, 192], the PackedMPLayer whose W1 image produced it, data pointer of the rows it was computed from, that
     set's parameter key)."""
-    __slots__ = ("next", "ac_in", "ac_out")
+    __slots__ = ("next", "ac_in", "ac_out", "prev_node")
 
-    def __init__(self, next=None, ac_in=None):
-        self.next, self.ac_in, self.ac_out = next, ac_in, None
+    def __init__(self, next=None, ac_in=None, prev_node=None):
+        # prev_node: the autograd node (a FusedMPLayerFn backward context) that produced this layer's x, or None -- this
+        # layer's backward may then run that layer's node-network input-gradient chain in its own launch (mpg_edge_bwd_fn)
+        self.next, self.ac_in, self.ac_out, self.prev_node = next, ac_in, None, prev_node
 
 
 class FusedMPLayerFn(torch.autograd.Function):
@@ -660,6 +700,8 @@ class FusedMPLayerFn(torch.autograd.Function):
             agg = aggp[0] if SC == 1 else aggp.sum(0)
             chain(V, fn_layers, A=agg, lda=H3, K1=H3, **fn_kw)
         ctx.packed = pk
+        ctx.prev_node = handoff.prev_node if (handoff is not None and need_grad) else None
+        ctx.pre = None   # filled by the backward of the layer ABOVE when it has run this layer's input-gradient chain already
 
         ctx.save_for_backward(x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3, nbr, stE2, es, wq, xf2, order)
         ctx.cfg = (B, N, F, agg_scale, alpha, thr, dscale, tag, SC, f16, nq)
@@ -683,18 +725,15 @@ class FusedMPLayerFn(torch.autograd.Function):
         need_w = any(ctx.needs_input_grad[2:14])   # False in the G step: D's weights get no update there
         need_x = ctx.needs_input_grad[0]
 
-        # ---- node network fn (mpgan/model.py:279) backward
+        # ---- node network fn (mpgan/model.py:279) backward: its input-gradient chain -- already run by the layer above as the
+        #      epilogue of its data-gradient launch (ctx.pre, for exactly this upstream gradient), or launched below
         n1, n2, out_f = V1.shape[0], V2.shape[0], V3.shape[0]
-        dz3 = torch.empty_like(gy2) if thr else gy2
-        dz2 = torch.empty((V, n2), device=dev, dtype=torch.float32)
-        dz1 = torch.empty((V, n1), device=dev, dtype=torch.float32)
-        dh0 = torch.empty((V, V1.shape[1]), device=dev, dtype=torch.float32)  # [dagg | dx(node path) | (conditioning columns)]
-        # (launched below: as the prologue of the data-gradient kernel where that form covers the call, mpg_edge_bwd_fn)
-        fnb = chain_struct(V, [dict(img=pk.ptr("V3T"), K=out_f, N=n2, gate=(h2, True, tag + TAG_N1, thr, dscale), out=dz2),
-                               dict(img=pk.ptr("V2T"), K=n2, N=n1, gate=(h1, True, tag + TAG_N0, thr, dscale), out=dz1),
-                               dict(img=pk.ptr("V1T"), K=n1, N=V1.shape[1], out=dh0)],
-                           A=gy2, lda=gy2.stride(0), K1=out_f, in_gate=(tag + TAG_N2, thr, dscale), in_out=dz3 if thr else None,
-                           alpha=alpha, seed_t=seed_t, f16=False)
+        pre, fnb = ctx.pre, None
+        ctx.pre = None
+        if pre is not None and pre["gy_ptr"] == gy2.data_ptr() and tuple(gy2.shape) == (V, out_f):
+            dz3, dz2, dz1, dh0 = pre["dz3"], pre["dz2"], pre["dz1"], pre["dh0"]
+        else:
+            dz3, dz2, dz1, dh0, fnb = _fn_grad_chain(ctx, gy2)
         dV1 = dV2 = dV3 = dc1 = dc2 = dc3 = None
         wb = WgradBatch()  # all six weight gradients of the layer go out as one grouped launch (below)
         # DeviceState.grad_into_param: add into the parameters' .grad buffers directly and return None for them
@@ -742,13 +781,29 @@ class FusedMPLayerFn(torch.autograd.Function):
             des = torch.zeros_like(es)   # (zero-masked senders' rows are not written)
             daq = torch.empty((SC, V, EDGE_SCALARS, H1), device=dev, dtype=torch.float32)
             e.es, e.wq, e.des, e.daq = _p(es), _p(wq), _p(des), _p(daq)
-        rc = _lib.MPG_FN_NA
-        if OPTIONS["fn_prologue"] and SC == 1 and es is None:
-            rc = _lib.lib().mpg_edge_bwd_fn(C.byref(e), C.byref(fnb), _stream())
-            if rc != _lib.MPG_FN_NA:
-                check(rc, "mpg_edge_bwd_fn")
-        if rc == _lib.MPG_FN_NA:
+        if fnb is not None:
             check(_lib.lib().mpg_chain(C.byref(fnb), _stream()), "mpg_chain")
+        # dx = dx(node path) + [da | dc] [W1a ; W1c]: one chained layer over the stacked transposed view -- as the epilogue of
+        # the data-gradient launch where that form covers the call (a whole jet per workgroup), and behind it the node
+        # network's input-gradient chain of the layer BELOW, which produced x (its backward then finds its work done)
+        dx = cdx = None
+        rc = _lib.MPG_FN_NA
+        if need_x:
+            dx = torch.empty((V, F), device=dev, dtype=torch.float32)
+            if SC == 1 and RB == 1:
+                cdx = chain_struct(V, [dict(img=pk.ptr("W1ST"), K=2 * H1, N=F, resid=dh0[:, H3:H3 + F], out=dx)],
+                                   A=dap, lda=H1, K1=H1, A2=dcp, lda2=H1, alpha=alpha, f16=False)
+            if cdx is not None and OPTIONS["bwd_epilogue"] and es is None:
+                below = _below_chain(ctx.prev_node, dx, x2, thr, alpha, V)
+                rc = _lib.lib().mpg_edge_bwd_fn(C.byref(e), C.byref(cdx), None if below is None else C.byref(below[4]), _stream())
+                if rc == _lib.MPG_FN_NA and below is not None:   # (the pair is not covered: the layer alone may be)
+                    below = None
+                    rc = _lib.lib().mpg_edge_bwd_fn(C.byref(e), C.byref(cdx), None, _stream())
+                if rc != _lib.MPG_FN_NA:
+                    check(rc, "mpg_edge_bwd_fn")
+                    if below is not None:
+                        ctx.prev_node.pre = dict(gy_ptr=dx.data_ptr(), keep=dx, dz3=below[0], dz2=below[1], dz1=below[2], dh0=below[3])
+        if rc == _lib.MPG_FN_NA:
             check(_lib.lib().mpg_edge_bwd(C.byref(e), _stream()), "mpg_edge_bwd")
         da = dap[0] if SC == 1 else dap.sum(0)
         dc = dcp[0] if RB == 1 else dcp.sum(0)
@@ -809,12 +864,10 @@ class FusedMPLayerFn(torch.autograd.Function):
                     dW1[:, 2 * F:2 * F + nq] = dWq
             if direct:  # already in .grad: autograd gets nothing to accumulate
                 dW1 = db1 = dW2 = db2 = dW3 = db3 = dV1 = dc1 = dV2 = dc2 = dV3 = dc3 = None
-        dx = None
         if need_x:
-            # dx = dx(node path) + [da | dc] [W1a ; W1c]: one chained layer over the stacked transposed view
-            dx = torch.empty((V, F), device=dev, dtype=torch.float32)
-            chain(V, [dict(img=pk.ptr("W1ST"), K=2 * H1, N=F, resid=dh0[:, H3:H3 + F], out=dx)],
-                  A=dap, lda=H1, K1=H1, a_slabs=SC, a_slab_stride=V * H1, A2=dc, lda2=dc.stride(0), alpha=alpha, f16=False)
+            if rc == _lib.MPG_FN_NA:   # (not done by the data-gradient launch: its own launch)
+                chain(V, [dict(img=pk.ptr("W1ST"), K=2 * H1, N=F, resid=dh0[:, H3:H3 + F], out=dx)],
+                      A=dap, lda=H1, K1=H1, a_slabs=SC, a_slab_stride=V * H1, A2=dc, lda2=dc.stride(0), alpha=alpha, f16=False)
             dx = dx.reshape(B, N, F)
         dxfn = None
         if len(ctx.needs_input_grad) > 23 and ctx.needs_input_grad[23] and dh0.shape[1] > H3 + F:

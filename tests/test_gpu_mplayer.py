@@ -739,8 +739,8 @@ def test_jet_order_and_heaviest_first_launches_change_no_result():
 ])
 def test_node_network_as_edge_epilogue_is_bit_identical(B, N, F, out, p_drop, use_mask, train):
     """``mpg_edge_fwd_fn`` (fn as the epilogue of the edge forward's workgroups, mpgan/model.py:256-279 in one launch) against
-    ``mpg_edge_fwd`` + ``mpg_chain``, and ``mpg_edge_bwd_fn`` (fn's input-gradient chain as the prologue of the data-gradient
-    kernel's workgroups) against ``mpg_chain`` + ``mpg_edge_bwd``: the layer's output, the by-products kept for the backward (agg, both hidden activations)
+    ``mpg_edge_fwd`` + ``mpg_chain``, and ``mpg_edge_bwd_fn`` (the dx chain as the epilogue of the data-gradient kernel's
+    workgroups) against ``mpg_edge_bwd`` + ``mpg_chain``: the layer's output, the by-products kept for the backward (agg, both hidden activations)
     and every gradient must be BIT-identical -- same sums in the same order, same dropout sites -- in all three dropout modes,
     for both output widths, a strided x, two receiver blocks, and without gradients."""
     import itertools
@@ -762,7 +762,11 @@ def test_node_network_as_edge_epilogue_is_bit_identical(B, N, F, out, p_drop, us
     up = torch.from_numpy(rs.normal(size=(B, N, out))).float().to(dev)
 
     def run(fused):
-        ops.OPTIONS["fn_epilogue"] = ops.OPTIONS["fn_prologue"] = fused
+        ops.OPTIONS["fn_epilogue"] = ops.OPTIONS["bwd_epilogue"] = fused
+        if fused:
+            del calls.names[:]       # (the launches of the fused run are what is checked below)
+        else:
+            calls.restore()
         st = ops.dev_state(dev)
         st.tags = itertools.count(55)
         ops.set_seed(4321, dev)
@@ -780,22 +784,23 @@ def test_node_network_as_edge_epilogue_is_bit_identical(B, N, F, out, p_drop, us
         return res
 
     import os
-    calls = _count_calls(ops)
+    from mpgan_amd import ops as _ops
+    calls = _count_calls(_ops)
     if N <= 64:
         os.environ["MPG_FORCE_SC"] = "1"     # (a handful of jets would be cut into sender chunks to fill the chip: the whole-jet form)
-    saved_opts = (ops.OPTIONS["fn_epilogue"], ops.OPTIONS["fn_prologue"])
+    saved_opts = (ops.OPTIONS["fn_epilogue"], ops.OPTIONS["bwd_epilogue"])
     try:
         a, b_ = run(True), run(False)
     finally:
-        ops.OPTIONS["fn_epilogue"], ops.OPTIONS["fn_prologue"] = saved_opts
+        ops.OPTIONS["fn_epilogue"], ops.OPTIONS["bwd_epilogue"] = saved_opts
         os.environ.pop("MPG_FORCE_SC", None)
         calls.restore()
     want = ["mpg_chain", "mpg_edge_fwd_fn"] if N <= 64 else ["mpg_chain", "mpg_edge_fwd", "mpg_chain"]
     names = [k for k in calls.names if k != "mpg_pack_many"]   # (the first call builds the weight images)
     assert names[:len(want)] == want, names[:4]
-    if train:   # ... and the backward: the input-gradient chain as the prologue of the data-gradient kernel (mpg_edge_bwd_fn)
-        nb = names[len(want):names.index("mpg_edge_dw")]
-        assert nb == (["mpg_edge_bwd_fn"] if N <= 64 else ["mpg_chain", "mpg_edge_bwd"]), nb
+    if train:   # ... and the backward: the dx chain as the epilogue of the data-gradient kernel (a whole jet per workgroup: N <= 32)
+        nb = [k for k in names[len(want):] if k in ("mpg_chain", "mpg_edge_bwd", "mpg_edge_bwd_fn")]
+        assert nb == (["mpg_chain", "mpg_edge_bwd_fn"] if N <= 32 else ["mpg_chain", "mpg_edge_bwd", "mpg_chain"]), nb
     assert bool(torch.isfinite(a["y"]).all())
     for k in a:
         assert torch.equal(a[k], b_[k]), (k, float((a[k] - b_[k]).abs().max()))
@@ -849,8 +854,9 @@ def test_node_network_epilogue_takes_one_launch():
 def test_layers_hand_over_their_node_terms(which, train):
     """A whole network at the headline batch: every layer's edge launch runs the node network as its epilogue AND, for all
     layers but the last, the next layer's a | c projection behind it (``ops.LayerHandoff``) -- one ``mpg_chain`` launch per
-    network forward (the first layer's projection) instead of four, outputs and gradients bit-identical to the launches
-    taken one by one, dropout on in D."""
+    network forward (the first layer's projection) instead of four -- and, in the backward, every data-gradient launch carries
+    its layer's dx chain and the lower layer's input-gradient chain as its epilogue (one ``mpg_chain`` launch instead of five);
+    outputs and gradients bit-identical to the launches taken one by one, dropout on in D."""
     import itertools
     from mpgan_amd import ops, train as mtrain
     dev = _dev()
@@ -868,33 +874,40 @@ def test_layers_hand_over_their_node_terms(which, train):
         xin = synthetic_batch(B, N, seed=3)[0].to(dev)
 
     def run(fused):
-        ops.OPTIONS["fn_epilogue"] = fused
+        ops.OPTIONS["fn_epilogue"] = ops.OPTIONS["bwd_epilogue"] = fused
         st = ops.dev_state(dev)
         st.tags = itertools.count(91)
         ops.set_seed(99, dev)
         net.zero_grad()
         x = xin.clone().requires_grad_(train)
         calls = _count_calls(ops)
+        keep = ("mpg_chain", "mpg_edge_fwd", "mpg_edge_fwd_fn", "mpg_edge_bwd", "mpg_edge_bwd_fn")
         try:
             with torch.set_grad_enabled(train):
                 y = net(x, labels)
+            names = [k for k in calls.names if k in keep]
+            del calls.names[:]
+            res = {"y": y.detach().clone()}
+            if train:
+                y.sum().backward()
+                res["dx"] = x.grad.clone()
+                res.update({k: q.grad.clone() for k, q in net.named_parameters() if q.grad is not None})
         finally:
             calls.restore()
-        names = [k for k in calls.names if k in ("mpg_chain", "mpg_edge_fwd", "mpg_edge_fwd_fn")]
-        res = {"y": y.detach().clone()}
-        if train:
-            y.sum().backward()
-            res["dx"] = x.grad.clone()
-            res.update({k: q.grad.clone() for k, q in net.named_parameters() if q.grad is not None})
-        return res, names
+        return res, names, [k for k in calls.names if k in keep]
 
-    saved = ops.OPTIONS["fn_epilogue"]
+    saved = (ops.OPTIONS["fn_epilogue"], ops.OPTIONS["bwd_epilogue"])
     try:
         net(xin, labels)   # (weight images built)
-        (a, na), (b_, nb) = run(True), run(False)
+        (a, na, ba), (b_, nb, bb) = run(True), run(False)
     finally:
-        ops.OPTIONS["fn_epilogue"] = saved
+        ops.OPTIONS["fn_epilogue"], ops.OPTIONS["bwd_epilogue"] = saved
     assert na == ["mpg_chain", "mpg_edge_fwd_fn", "mpg_edge_fwd_fn"], na
     assert nb == ["mpg_chain", "mpg_edge_fwd", "mpg_chain"] * 2, nb
+    if train:
+        # backward: the top layer's input-gradient chain is the only mpg_chain launch; its data-gradient launch carries its dx
+        # and the lower layer's chain, the lower layer's data-gradient launch its own dx
+        assert ba == ["mpg_chain", "mpg_edge_bwd_fn", "mpg_edge_bwd_fn"], ba
+        assert bb == ["mpg_chain", "mpg_edge_bwd", "mpg_chain", "mpg_chain", "mpg_edge_bwd", "mpg_chain"], bb
     for k in a:
         assert torch.equal(a[k], b_[k]), (k, float((a[k] - b_[k]).abs().max()))
