@@ -51,9 +51,9 @@ for l in pm.splitlines():
         vals[cur] = float(m.group(3))
 def kb(c, k): return vals.get((c, k), 0.0)
 def tot(k): return (2 * kb("FETCH_SIZE", k) + kb("WRITE_SIZE", k)) * 1024
-rows = [("edge_fwd_kernel<0", "forward, no dropout"), ("edge_fwd_kernel<2", "forward, p = 1/2"),
-        ("edge_bwd_kernel<0, true", "backward + staging"), ("edge_bwd_kernel<0, false", "backward, data path only"),
-        ("edge_bwd_kernel<2, true", "backward + staging, p = 1/2"), ("edge_bwd_kernel<2, false", "backward, data path, p = 1/2"),
+rows = [("edge_fwd_fn_kernel<0", "forward, no dropout"), ("edge_fwd_fn_kernel<2", "forward, p = 1/2"),
+        ("edge_bwd_fn_kernel<0, true", "backward + staging"), ("edge_bwd_fn_kernel<0, false", "backward, data path only"),
+        ("edge_bwd_fn_kernel<2, true", "backward + staging, p = 1/2"), ("edge_bwd_fn_kernel<2, false", "backward, data path, p = 1/2"),
         ("edge_dw_kernel<0", "weight gradients"), ("edge_dw_kernel<2", "weight gradients, p = 1/2"),
         ("chain2_kernel", "chained node layers (all uses)"), ("gemm_group_kernel", "grouped dense weight gradients")]
 txt = ("# HBM traffic of the fused kernels: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (one counter per pass, as\n"
@@ -73,25 +73,25 @@ def rate(sub, key):
     d = [v for k, v in dur.items() if sub in k]
     return tot(key) / d[0] / 1e12 if d else float("nan")
 txt += ("#\n# Achieved HBM rate at B=256 (bytes above / rocprof average duration in " + f"{tag}_bench_kernel_stats.csv" + "; HBM3E peak 8 TB/s):\n"
-        f"#   edge_fwd_kernel<0, true>   {rate('edge_fwd_kernel<0, true', 'edge_fwd_kernel<0'):5.2f} TB/s  (compute bound: see the SQ counters)\n"
-        f"#   edge_bwd_kernel<0, true>   {rate('edge_bwd_kernel<0, true', 'edge_bwd_kernel<0, true'):5.2f} TB/s\n"
+        f"#   edge_fwd_fn_kernel<0, true>   {rate('edge_fwd_fn_kernel<0, true', 'edge_fwd_fn_kernel<0'):5.2f} TB/s  (compute bound: see the SQ counters)\n"
+        f"#   edge_bwd_fn_kernel<0, true>   {rate('edge_bwd_fn_kernel<0, true', 'edge_bwd_fn_kernel<0, true'):5.2f} TB/s\n"
         f"#   edge_dw_kernel<0>          {rate('edge_dw_kernel<0', 'edge_dw_kernel<0'):5.2f} TB/s\n")
 txt += ("#\n# forward: a|c in, agg + sign words out (algorithmic 17.7 MB) + 10 KiB of fp16 E2 fragments per unmasked (jet, sender) block,\n"
         "# parked for the backward (which reads them for the LeakyReLU gate instead of recomputing the layer) and for mpg_edge_dw;\n"
         "# backward + staging: 10 KiB of fp16 dZ2 fragments per block; mpg_edge_dw reads both back and writes 256 per-workgroup\n"
         "# partial sums.\n#\n" + pm)
 open(os.path.join(P, f"{tag}_pmc_hbm_traffic.txt"), "w").write(txt)
-w, wo = tot("edge_bwd_kernel<2, true"), tot("edge_bwd_kernel<2, false")
-w0 = tot("edge_bwd_kernel<0, true")
+w, wo = tot("edge_bwd_fn_kernel<2, true"), tot("edge_bwd_fn_kernel<2, false")
+w0 = tot("edge_bwd_fn_kernel<0, true")
 traffic = {
-    "note": f"bytes per launch from profiles/{tag}_pmc_hbm_traffic.txt (2 x FETCH_SIZE + WRITE_SIZE), B=256, N=30. edge_bwd_kernel: "
+    "note": f"bytes per launch from profiles/{tag}_pmc_hbm_traffic.txt (2 x FETCH_SIZE + WRITE_SIZE), B=256, N=30, the launches with their epilogue chains (node network / dx). edge_bwd_fn_kernel: "
             "launch-weighted mean over the 6 launches of one default bench step (2 at 2B = 512 jets with staging [D, p = 1/2], "
-            "2 at B = 256 data path only [D in the G step], 2 at B = 256 with staging [G, no dropout]); edge_fwd_kernel: mean over "
+            "2 at B = 256 data path only [D in the G step], 2 at B = 256 with staging [G, no dropout]); edge_fwd_fn_kernel: mean over "
             "its 8 launches (2 at B without by-products, 2 at 512 jets and 4 at B with sign words + parked E2)",
     # forward: 2 launches at B without by-products for a backward (the generator in the D step: a|c in, agg out = 13.3 MB
     # algorithmic, not in the PMC workload), 2 at 2B and 4 at B with sign words and parked E2
-    "edge_fwd_kernel": {"bytes_per_launch": int((2 * 13.3e6 + 2 * 2 * tot("edge_fwd_kernel<2") + 4 * tot("edge_fwd_kernel<0")) / 8)},
-    "edge_bwd_kernel": {"bytes_per_launch": int((2 * 2 * w + 2 * wo + 2 * w0) / 6)},
+    "edge_fwd_fn_kernel": {"bytes_per_launch": int((2 * 13.3e6 + 2 * 2 * tot("edge_fwd_fn_kernel<2") + 4 * tot("edge_fwd_fn_kernel<0")) / 8)},
+    "edge_bwd_fn_kernel": {"bytes_per_launch": int((2 * 2 * w + 2 * wo + 2 * w0) / 6)},
     "edge_dw_kernel": {"bytes_per_launch": int(tot("edge_dw_kernel<2"))},
 }
 json.dump(traffic, open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
