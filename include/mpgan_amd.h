@@ -297,9 +297,10 @@ int mpg_attn_bwd(const MpgAttn* p, void* stream);
 /* ---- the per-jet pieces around the message-passing layers ----------------------------------------
  * mpg_rank_mask: MPGenerator._get_mask, mask_c branch (mpgan/model.py:689-699; GAPT_G :255-258): with
  * n_b = int(labels[b] * N), mask[b, i] = 1 for the n_b particles of jet b with the smallest first feature
- * x[b*ld_jet + i*ld_part] (rank = argsort(argsort(.)); ties by index), else 0.  mask is [B, N] contiguous. */
+ * x[b*ld_jet + i*ld_part] (rank = argsort(argsort(.)); ties by index), else 0.  mask is [B, N] contiguous; `ignore`
+ * (or NULL) receives 1 - mask in the same pass: the key mask GAPT's attention blocks take (_attn_mask, gapt/model.py:194-202). */
 int mpg_rank_mask(const float* x, int ld_jet, int ld_part, const float* labels, int ld_lab, int B, int N,
-                  float* mask, void* stream);
+                  float* mask, float* ignore, void* stream);
 
 /* mpg_jet_order: the jets of a batch by decreasing number of unmasked particles (ties by index), order[0] the fullest --
  * MpgEdgeFwd.order / MpgEdgeBwd.order.  The edge kernels take a workgroup per jet and as long as the jet has senders; when a

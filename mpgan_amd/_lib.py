@@ -186,7 +186,7 @@ SIGNATURES = {
     "mpg_mab_fwd": (C.c_int, [C.POINTER(MpgMab), C.c_void_p]),
     "mpg_mab_bwd": (C.c_int, [C.POINTER(MpgMab), C.c_void_p]),
     "mpg_knn_sets": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_void_p]),
-    "mpg_rank_mask": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, C.c_void_p]),
+    "mpg_rank_mask": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_void_p]),
     "mpg_jet_order": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_void_p]),
     "mpg_gen_tail_fwd": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mpg_gen_tail_bwd": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -17,7 +17,7 @@ namespace {
 // rank of particle i among its jet's first features (ties by index) by counting; one workgroup per jet
 __global__ __launch_bounds__(256) void rank_mask_kernel(const float* __restrict__ x, int ld_jet, int ld_part,
                                                         const float* __restrict__ labels, int ld_lab, int N,
-                                                        float* __restrict__ mask) {
+                                                        float* __restrict__ mask, float* __restrict__ ignore) {
     extern __shared__ float xs[];
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < N; i += blockDim.x) xs[i] = x[(size_t)b * ld_jet + (size_t)i * ld_part];
@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void rank_mask_kernel(const float* __restrict_
             rank += (xj < xi) || (xj == xi && j < i);
         }
         mask[(size_t)b * N + i] = rank <= n_minus_1 ? 1.f : 0.f;
+        if (ignore != nullptr) ignore[(size_t)b * N + i] = rank <= n_minus_1 ? 0.f : 1.f;   // the attention blocks' key mask: 1 - mask
     }
 }
 
@@ -372,10 +373,10 @@ extern "C" int mpg_layernorm_bwd(const float* g, int ldg, const float* x, int ld
 }
 
 extern "C" int mpg_rank_mask(const float* x, int ld_jet, int ld_part, const float* labels, int ld_lab, int B, int N,
-                             float* mask, void* stream) {
+                             float* mask, float* ignore, void* stream) {
     if (B <= 0 || N <= 0 || N > 8192) return -1;
     hipLaunchKernelGGL(rank_mask_kernel, dim3(B), dim3(N <= 64 ? 64 : 256), N * sizeof(float), (hipStream_t)stream, x, ld_jet, ld_part,
-                       labels, ld_lab, N, mask);
+                       labels, ld_lab, N, mask, ignore);
     return (int)hipGetLastError();
 }
 

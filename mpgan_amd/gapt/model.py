@@ -60,12 +60,7 @@ class MAB(nn.Module):
         B, L, E = x.shape
         S = y.shape[1]
         att = self.attention
-        ignore = None
-        if y_mask is not None:
-            ignore = getattr(y_mask, "_mpg_ignore", None)  # float key mask prepared once per network forward
-            if ignore is None or ignore.numel() != B * S:
-                km = y_mask if y_mask.dim() == 2 else y_mask[:, 0, :]
-                ignore = km.reshape(B * S).float().contiguous()
+        ignore = self._ignore_of(y_mask, B, S)
         x2 = x.reshape(B * L, E)
         if x.is_cuda and ops.double_backward_on(x.device):
             return self._forward_dd(x, y, ignore)
@@ -125,6 +120,17 @@ class MAB(nn.Module):
             zf = torch.nn.functional.layer_norm(zf, (E,), self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return torch.nn.functional.dropout(zf, self.dropout_p, self.training).reshape(B, L, E)
 
+    @staticmethod
+    def _ignore_of(y_mask, B: int, S: int):
+        """The float key mask [B*S] (1 = ignore) the kernels take, from the bool / float mask the blocks pass around."""
+        if y_mask is None:
+            return None
+        ignore = getattr(y_mask, "_mpg_ignore", None)  # float key mask prepared once per network forward
+        if ignore is None or ignore.numel() != B * S:
+            km = y_mask if y_mask.dim() == 2 else y_mask[:, 0, :]
+            ignore = km.reshape(B * S).float().contiguous()
+        return ignore
+
     # -- the whole block as one launch (ops.mab_forward; csrc/mab.hip) ------------------------------------------
     def _fused_ok(self, x: Tensor, L: int, S: int) -> bool:
         return (MAB.fused and x.is_cuda and not self.layer_norm and len(self.ff.net) == 1 and self.ff.plain
@@ -152,7 +158,8 @@ class MAB(nn.Module):
         kw = dict(alpha=self.ff.leaky_relu_alpha, ff_act=not self.ff.final_linear, p_mab=self.dropout_p,
                   p_ff=self.ff.dropout_p, training=self.training)
         if not torch.is_grad_enabled():
-            x2 = x.reshape(B * L, E).contiguous()
+            # (one query row for all jets -- PMA's seed -- is read with row stride 0)
+            x2 = x.reshape(1, E).contiguous().expand(B, E) if (x.shape[0] == 1 and B > 1) else x.reshape(B * L, E).contiguous()
             y2 = None if x is y else y.reshape(B * S, E).contiguous()
             out, _, _, _ = ops.mab_forward(x2, y2, ignore, self._packed(), att.in_proj_bias, att.out_proj.bias, lin.bias,
                                            B, L, S, self.num_heads, **kw)
@@ -179,6 +186,9 @@ class PMA(nn.Module):
         self.mab = MAB(embed_dim, **mab_args)
 
     def forward(self, x: Tensor, mask: Tensor = None):
+        if self.S.shape[1] == 1 and x.is_cuda and x.size(0) > 1 and self.mab._fused_ok(x, 1, x.shape[1]) and not ops.double_backward_on(x.device):
+            # one seed: the one-launch block reads the single row for every jet (no B copies, no reduction launch for its gradient)
+            return self.mab._fused(self.S, x, self.mab._ignore_of(_key_mask(mask), x.size(0), x.shape[1]), x.size(0), 1, x.shape[1])
         seeds = self.S.expand(x.size(0), -1, -1).contiguous()
         return self.mab(seeds, x, _key_mask(mask))
 
@@ -245,15 +255,17 @@ class GAPT_G(nn.Module):
                                   final_linear=True, **linear_args)
 
     def _mask(self, x, labels):
+        """(mask [B, N, 1] or None, the attention mask built from it): on the GPU one launch writes both."""
         if not self.use_mask:
-            return None
+            return None, None
         if x.is_cuda:
-            return ops.rank_mask(x[:, :, 0], labels, self.num_particles).unsqueeze(2)
-        return _rank_mask(x[:, :, 0], labels, self.num_particles)
+            mask, ign = ops.rank_mask(x[:, :, 0], labels, self.num_particles, with_ignore=True)
+            return mask.unsqueeze(2), _ignore_mask(ign.unsqueeze(2))
+        mask = _rank_mask(x[:, :, 0], labels, self.num_particles)
+        return mask, _attn_mask(mask)
 
     def forward(self, x: Tensor, labels: Tensor = None):
-        mask = self._mask(x, labels)
-        am = _attn_mask(mask)
+        mask, am = self._mask(x, labels)
         for sab in self.sabs:
             x = sab(x, am)
         x = self.final_fc(x)
@@ -265,8 +277,7 @@ class GAPT_G(nn.Module):
     def generate_into(self, x: Tensor, labels: Tensor, out: Tensor) -> Tensor:
         """``forward`` into caller-owned output rows, no gradient (``train.TrainStep``'s D step)."""
         assert not torch.is_grad_enabled() and x.is_cuda
-        mask = self._mask(x, labels)
-        am = _attn_mask(mask)
+        mask, am = self._mask(x, labels)
         for sab in self.sabs:
             x = sab(x, am)
         return ops.gen_tail_into(self.final_fc(x), mask, ops.ACT_CODES["tanh"], out)
@@ -309,7 +320,7 @@ class GAPT_D(nn.Module):
             else:
                 am = _ignore_mask(0.5 - x.detach()[..., -1:])   # (no gradient flows through the mask column: :336-338, bool mask)
             x = x[..., :-1]
-        x = self.input_embedding(x.contiguous())
+        x = self.input_embedding(x)   # (a column slice of the [.., 4] rows: the GEMM takes the row stride as it is)
         for sab in self.sabs:
             x = sab(x, am)
         return self.pma(x, am), None

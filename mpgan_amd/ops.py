@@ -900,7 +900,9 @@ class FusedLinearFn(torch.autograd.Function):
     def forward(ctx, x, W, b, act, alpha, p_drop, training, resid=None):
         _chk(x, "x")
         shp = x.shape
-        x2 = x.reshape(-1, shp[-1]).contiguous()
+        x2 = x.reshape(-1, shp[-1])
+        if x2.stride(1) != 1 or x2.stride(0) < shp[-1]:   # (rows of any stride are fine -- a column slice of wider rows, D's x[..., :-1] -- only unit column stride matters)
+            x2 = x2.contiguous()
         thr, dscale = drop_params(p_drop) if training else (0, 1.0)
         seed_t = seed_tensor(x.device)
         tag = next_tag(x.device)
@@ -1196,14 +1198,22 @@ class FusedMABFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, y, ignore, Win, bin_, Wo, bo, Wf, bf, H, alpha, ff_act, p_mab, p_ff, training, pk):
+        """``x`` [1, 1, E] with ``y`` [B, S, E], B > 1: ONE query row shared by all jets (PMA's learned seed, gapt/model.py:170-174:
+        ``S.repeat(B, 1, 1)``) -- read with row stride 0 instead of being copied B times, and its gradient summed over the jets by
+        the grouped weight-gradient launch (as a bias sum) instead of a reduction launch of its own."""
         B, L, E = x.shape
+        bcast = B == 1 and L == 1 and y is not None and y.shape[0] > 1
+        if bcast:
+            B = y.shape[0]
         S = L if y is None else y.shape[1]
-        x2 = x.reshape(B * L, E).contiguous()
+        x2 = x.reshape(1, E).contiguous().expand(B, E) if bcast else x.reshape(B * L, E).contiguous()   # (row stride 0)
         y2 = None if y is None else y.reshape(B * S, E).contiguous()
+        ctx.bcast = bcast
         out, o, z, tag = mab_forward(x2, y2, ignore, pk, bin_, bo, bf, B, L, S, H, alpha=alpha, ff_act=ff_act,
                                      p_mab=p_mab, p_ff=p_ff, training=training, save=True)
         ctx.save_for_backward(x2, y2, ignore, o, z, bin_, bo, bf)
         ctx.pk, ctx.params = pk, (Win, bin_, Wo, bo, Wf, bf)
+        ctx.seed = x if (bcast and x.is_leaf) else None     # (the parameter itself: its .grad takes the summed gradient directly)
         ctx.cfg = (B, L, S, E, H, alpha, ff_act, tag, p_mab if training else 0.0, p_ff if training else 0.0)
         return out.reshape(B, L, E)
 
@@ -1266,14 +1276,27 @@ class FusedMABFn(torch.autograd.Function):
                     grads[0], grads[1] = wgrad(dqkv, x2)
                 grads[2], grads[3] = wgrad(dza, o)
                 grads[4], grads[5] = wgrad(du, z)
+        if ctx.bcast and dx is not None:
+            # the shared query row's gradient: the sum over the jets -- a bias-sum job of the grouped launch when there is one
+            st = dev_state(dev)
+            gS = _grad_target(ctx.seed) if (st.grad_into_param and st.deferred_wgrad is not None and ctx.seed is not None) else None
+            if gS is not None:
+                st.deferred_wgrad.add(dx, dx[:, :1], out=torch.empty((E, 1), device=dev, dtype=torch.float32), bias_out=gS.reshape(-1),
+                                      accumulate=True)
+                dx = None
+            else:
+                dx = dx.sum(0).reshape(1, 1, E)
+            return (dx, None if dy is None else dy.reshape(B, S, E), None, *grads, None, None, None, None, None, None, None)
         return (None if dx is None else dx.reshape(B, L, E), None if dy is None else dy.reshape(B, S, E), None,
                 *grads, None, None, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------- per-jet pieces around the layers
-def rank_mask(first_feature: torch.Tensor, labels: torch.Tensor, num_particles: int, out: Optional[torch.Tensor] = None):
+def rank_mask(first_feature: torch.Tensor, labels: torch.Tensor, num_particles: int, out: Optional[torch.Tensor] = None,
+              with_ignore: bool = False):
     """mask_c (mpgan/model.py:689-699): [B, N] floats, 1 for the n = int(label * N) particles of each jet with the
-    smallest first feature.  ``first_feature`` [B, N] may be a strided view (x[:, :, 0]); one launch."""
+    smallest first feature.  ``first_feature`` [B, N] may be a strided view (x[:, :, 0]); one launch.  ``with_ignore``: returns
+    (mask, 1 - mask), the second written by the same launch (the key mask of GAPT's attention blocks)."""
     _chk(first_feature, "first_feature")
     B, N = first_feature.shape
     lab = labels[:, -1]
@@ -1281,9 +1304,10 @@ def rank_mask(first_feature: torch.Tensor, labels: torch.Tensor, num_particles: 
         lab = lab.float()
     if out is None:
         out = torch.empty((B, N), device=first_feature.device, dtype=torch.float32)
+    ign = torch.empty((B, N), device=first_feature.device, dtype=torch.float32) if with_ignore else None
     check(_lib.lib().mpg_rank_mask(_p(first_feature), first_feature.stride(0), first_feature.stride(1), _p(lab), lab.stride(0),
-                                   B, N, _p(out), _stream()), "mpg_rank_mask")
-    return out
+                                   B, N, _p(out), _p(ign), _stream()), "mpg_rank_mask")
+    return (out, ign) if with_ignore else out
 
 
 def knn_sets(x: torch.Tensor, mask: Optional[torch.Tensor], num_knn: int, self_loops: bool = True):
