@@ -274,6 +274,23 @@ class GAPT_G(nn.Module):
         x = torch.tanh(x)
         return torch.cat((x, mask - 0.5), dim=2) if mask is not None else x
 
+    def generate_parts(self, x: Tensor, labels: Tensor, feat_out: Tensor = None, mask_out: Tensor = None, ign_out: Tensor = None):
+        """``forward`` without gluing the mask column on: (particle features [B, N, F] after tanh, mask [B, N, 1], 1 - mask
+        [B, N]); see ``MPGenerator.generate_parts``."""
+        assert x.is_cuda and self.use_mask
+        B = x.shape[0]
+        mask2d, ign = ops.rank_mask(x[:, :, 0], labels, self.num_particles, out=None if mask_out is None else mask_out.view(B, -1),
+                                    with_ignore=True, ignore_out=None if ign_out is None else ign_out.view(B, -1))
+        mask = mask2d.unsqueeze(2)
+        am = _ignore_mask(ign.unsqueeze(2))
+        for sab in self.sabs:
+            x = sab(x, am)
+        x = self.final_fc(x)
+        if feat_out is not None:
+            assert not torch.is_grad_enabled()
+            return ops.gen_tail_into(x, None, ops.ACT_CODES["tanh"], feat_out), mask, ign
+        return ops.GenTailFn.apply(x, None, ops.ACT_CODES["tanh"]), mask, ign
+
     def generate_into(self, x: Tensor, labels: Tensor, out: Tensor) -> Tensor:
         """``forward`` into caller-owned output rows, no gradient (``train.TrainStep``'s D step)."""
         assert not torch.is_grad_enabled() and x.is_cuda
@@ -321,6 +338,19 @@ class GAPT_D(nn.Module):
                 am = _ignore_mask(0.5 - x.detach()[..., -1:])   # (no gradient flows through the mask column: :336-338, bool mask)
             x = x[..., :-1]
         x = self.input_embedding(x)   # (a column slice of the [.., 4] rows: the GEMM takes the row stride as it is)
+        for sab in self.sabs:
+            x = sab(x, am)
+        return self.pma(x, am), None
+
+    def parts_ok(self) -> bool:
+        return bool(self.use_mask)
+
+    def features_parts(self, x3: Tensor, mask: Tensor, labels: Tensor = None, ignore: Tensor = None):
+        """``features`` for callers that hold the particle features [B, N, F], the mask and 1 - mask [B, N] apart."""
+        B, N = x3.shape[:2]
+        inv = (1 - mask) if ignore is None else ignore
+        am = _ignore_mask(inv.reshape(B, N, 1))
+        x = self.input_embedding(x3)
         for sab in self.sabs:
             x = sab(x, am)
         return self.pma(x, am), None

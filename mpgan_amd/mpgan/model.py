@@ -507,6 +507,22 @@ class MPGenerator(MPNet):
         x = self._run_layers(x, use_mask, mask, labels, njp)
         return ops.gen_tail_into(x, mask, ops.ACT_CODES[self.final_activation], out)
 
+    def generate_parts(self, x: Tensor, labels: Tensor, feat_out: Tensor = None, mask_out: Tensor = None, ign_out: Tensor = None):
+        """``forward`` without gluing the mask column on: (particle features [B, N, F] after the final activation, mask
+        [B, N, 1], None).  A discriminator's ``features_parts`` takes them as they are -- no mask column to write, to split off
+        again and to pad a gradient for (``train.TrainStep``; the modules' ``forward`` keeps the reference's [B, N, F+1]
+        tensors).  ``feat_out`` / ``mask_out`` (without gradients): the caller's rows to write into."""
+        assert x.is_cuda and self.mask_args.get("mask_c", True) and not self.mask_args.get("mask_feat_bin", False)
+        x = self._pre_mp(x, labels)
+        mask2d = ops.rank_mask(x[:, :, 0], labels, self.num_particles, out=None if mask_out is None else mask_out.view(x.shape[0], -1))
+        mask = mask2d.unsqueeze(2)
+        x = self._run_layers(x, True, mask, labels, None)
+        act = ops.ACT_CODES[self.final_activation]
+        if feat_out is not None:
+            assert not torch.is_grad_enabled()
+            return ops.gen_tail_into(x, None, act, feat_out), mask, None
+        return ops.GenTailFn.apply(x, None, act), mask, None
+
     def _final_mask(self, x, mask, mask_feat_bin: bool = False, **mask_args):
         _unsupported(mask_feat_bin=mask_feat_bin)
         return torch.cat((x, mask - 0.5), dim=2) if mask is not None else x
@@ -554,6 +570,18 @@ class MPDiscriminator(MPNet):
         x, use_mask, mask, njp = self._get_mask(x, labels, **self.mask_args)
         x = self._run_layers(x, use_mask, mask, labels, njp)
         return x, (mask if use_mask else None)
+
+    def parts_ok(self) -> bool:
+        """Whether ``features_parts`` is ``features`` (the mask is used as a mask only: the reference's default)."""
+        a = self.mask_args
+        return (bool(a.get("mask_c", True)) and not a.get("mask_fne_np", False) and not a.get("mask_fnd_np", False)
+                and not self.mask_fnd_np and not any(l.clabels or l.mask_fne_np for l in self.mp_layers))
+
+    def features_parts(self, x3: Tensor, mask: Tensor, labels: Tensor = None, ignore: Tensor = None):
+        """``features`` for callers that hold the particle features [B, N, F] and the mask [B, N, 1] apart (``parts_ok``)."""
+        x = self._pre_mp(x3, labels)
+        x = self._run_layers(x, True, mask, labels, None)
+        return x, mask
 
     def forward(self, x: Tensor, labels: Tensor = None) -> Tensor:
         head = self.fused_head() if (x.is_cuda and not ops.double_backward_on(x.device)) else None

@@ -1293,7 +1293,7 @@ class FusedMABFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------- per-jet pieces around the layers
 def rank_mask(first_feature: torch.Tensor, labels: torch.Tensor, num_particles: int, out: Optional[torch.Tensor] = None,
-              with_ignore: bool = False):
+              with_ignore: bool = False, ignore_out: Optional[torch.Tensor] = None):
     """mask_c (mpgan/model.py:689-699): [B, N] floats, 1 for the n = int(label * N) particles of each jet with the
     smallest first feature.  ``first_feature`` [B, N] may be a strided view (x[:, :, 0]); one launch.  ``with_ignore``: returns
     (mask, 1 - mask), the second written by the same launch (the key mask of GAPT's attention blocks)."""
@@ -1304,10 +1304,11 @@ def rank_mask(first_feature: torch.Tensor, labels: torch.Tensor, num_particles: 
         lab = lab.float()
     if out is None:
         out = torch.empty((B, N), device=first_feature.device, dtype=torch.float32)
-    ign = torch.empty((B, N), device=first_feature.device, dtype=torch.float32) if with_ignore else None
+    ign = ignore_out if ignore_out is not None else (torch.empty((B, N), device=first_feature.device, dtype=torch.float32) if with_ignore else None)
+    assert out.is_contiguous() and (ign is None or ign.is_contiguous())
     check(_lib.lib().mpg_rank_mask(_p(first_feature), first_feature.stride(0), first_feature.stride(1), _p(lab), lab.stride(0),
                                    B, N, _p(out), _p(ign), _stream()), "mpg_rank_mask")
-    return (out, ign) if with_ignore else out
+    return (out, ign) if (with_ignore or ignore_out is not None) else out
 
 
 def knn_sets(x: torch.Tensor, mask: Optional[torch.Tensor], num_knn: int, self_loops: bool = True):

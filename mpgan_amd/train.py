@@ -344,6 +344,15 @@ class TrainStep:
         # generator's output rows land in the second half; labels likewise
         self._dcat = torch.zeros(2 * batch_size, num_particles, 4, device=dev)
         self._labels2 = torch.zeros(2 * batch_size, 1, device=dev)
+        # ... and, where both networks take it (``generate_parts`` / ``features_parts``), held APART: particle features, mask and
+        # 1 - mask of the 2B jets.  The reference glues the mask on as a fourth column, D splits it off again and autograd pads
+        # the gradient back to four columns: three elementwise launches per pass that carry no information
+        self._x3 = torch.zeros(2 * batch_size, num_particles, 3, device=dev)
+        self._mask2 = torch.zeros(2 * batch_size, num_particles, 1, device=dev)
+        self._ign2 = torch.zeros(2 * batch_size, num_particles, device=dev)
+        self.parts = (dev.type == "cuda" and hasattr(G, "generate_parts") and hasattr(D, "features_parts") and D.parts_ok()
+                      and getattr(G, "use_mask", True) and not getattr(G, "lfc", False)
+                      and getattr(G, "mask_args", {}).get("mask_c", True) and os.environ.get("MPG_PARTS", "1") != "0")
         self.D_loss = torch.zeros((), device=dev)
         self.G_loss = torch.zeros((), device=dev)
         self.use_graphs = use_graphs and dev.type == "cuda"
@@ -404,6 +413,7 @@ class TrainStep:
     def _seg_D(self):  # train_D up to and including backward (train.py:419-460)
         # parameter gradients are added straight into the flat buffers (no AccumulateGrad kernel per parameter)
         self.state.grad_into_param = True
+        self.state.order_cache = None   # (ops.jet_order: the masks of this iteration live where last iteration's did)
         ops.bump_seed(self.dev)
         self.D.train()
         if self.gen_ahead:
@@ -432,15 +442,26 @@ class TrainStep:
                 m._packed().ensure()
         self._side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self._side):
-            self._fake_ahead = self.G(self._noise(1), self.labels)
-        self._fake_ahead.record_stream(torch.cuda.current_stream(self.dev))   # (its consumer, the G step, runs on this stream)
+            if self.parts and self._fused_ends():
+                self._fake_ahead = self.G.generate_parts(self._noise(1), self.labels)
+            else:
+                self._fake_ahead = self.G(self._noise(1), self.labels)
+        for t in (self._fake_ahead if isinstance(self._fake_ahead, tuple) else (self._fake_ahead,)):
+            if t is not None:
+                t.record_stream(torch.cuda.current_stream(self.dev))   # (its consumer, the G step, runs on this stream)
 
     def _seg_D_body(self):
         if self._fused_ends():
             # real jets sit in the first half of the static batch; the generator writes the second half itself
-            with torch.no_grad():
-                self.G.generate_into(self._noise(0), self.labels, self._dcat[self.B:])
-            y, mask = self.D.features(self._dcat, self._labels2)
+            B = self.B
+            if self.parts:
+                with torch.no_grad():
+                    self.G.generate_parts(self._noise(0), self.labels, feat_out=self._x3[B:], mask_out=self._mask2[B:], ign_out=self._ign2[B:])
+                y, mask = self.D.features_parts(self._x3, self._mask2, self._labels2, ignore=self._ign2)
+            else:
+                with torch.no_grad():
+                    self.G.generate_into(self._noise(0), self.labels, self._dcat[B:])
+                y, mask = self.D.features(self._dcat, self._labels2)
             dy = self._head_loss(y, mask, False, 2 * self.B, self.D_loss, True)
             self._backward(y, dy)
             return
@@ -516,9 +537,14 @@ class TrainStep:
         self._clean["G"] = False
         _set_requires_grad(self.fD, False)
         fake, self._fake_ahead = self._fake_ahead, None
+        parts = self.parts and self._fused_ends()
         if fake is None:
-            fake = self.G(self._noise(1), self.labels)
-        if self._fused_ends():
+            fake = self.G.generate_parts(self._noise(1), self.labels) if parts else self.G(self._noise(1), self.labels)
+        if parts:
+            y, mask = self.D.features_parts(fake[0], fake[1], self.labels, ignore=fake[2])
+            dy = self._head_loss(y, mask, True, self.B, self.G_loss, False)
+            self._backward(y, dy)
+        elif self._fused_ends():
             y, mask = self.D.features(fake, self.labels)
             dy = self._head_loss(y, mask, True, self.B, self.G_loss, False)
             self._backward(y, dy)
@@ -611,6 +637,9 @@ class TrainStep:
         self.data.copy_(data, non_blocking=True)
         self.labels.copy_(labels, non_blocking=True)
         self._dcat[:self.B].copy_(self.data)
+        self._x3[:self.B].copy_(self.data[..., :3])
+        self._mask2[:self.B].copy_(self.data[..., 3:] + 0.5)
+        self._ign2[:self.B].copy_(0.5 - self.data[..., 3])
         self._labels2[:self.B].copy_(self.labels)
         self._labels2[self.B:].copy_(self.labels)
 

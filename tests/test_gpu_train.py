@@ -746,3 +746,19 @@ def test_weight_gradient_side_stream_changes_no_result(use_graphs, split, B):
     finally:
         os.environ.pop("MPG_WGRAD_SIDE", None)
     assert torch.equal(with_it[0], without[0]) and torch.equal(with_it[1], without[1]) and with_it[2:] == without[2:]
+
+
+@pytest.mark.parametrize("model", ["mpgan", "gapt"])
+def test_features_and_mask_held_apart_change_no_result(model):
+    """TrainStep hands the generator's particle features and mask to the discriminator APART (``generate_parts`` /
+    ``features_parts``: no mask column glued on, split off again and padded back in the gradient).  Same weights, data and
+    noise with the reference's [B, N, 4] tensors between the networks (MPG_PARTS=0): parameters after three iterations are
+    bit-identical, under hipGraphs."""
+    import os
+    with_it = _three_steps(64, 30, True, model=model)
+    os.environ["MPG_PARTS"] = "0"
+    try:
+        without = _three_steps(64, 30, True, model=model)
+    finally:
+        os.environ.pop("MPG_PARTS", None)
+    assert torch.equal(with_it[0], without[0]) and torch.equal(with_it[1], without[1]) and with_it[2:] == without[2:]
