@@ -384,6 +384,13 @@ typedef struct MpgMab {
 } MpgMab;
 int mpg_mab_fwd(const MpgMab* p, void* stream);
 int mpg_mab_bwd(const MpgMab* p, void* stream);
+/* mpg_mab_chain_fwd: up to MPG_MAB_CHAIN_MAX self-attention blocks applied one after the other -- the loop over the SABs of
+ * GAPT_G / GAPT_D (gapt/model.py:261-262, :341-342) -- in ONE launch: blk[b] is the argument block mpg_mab_fwd would be given
+ * for block b (y == x; blk[b].x == blk[b-1].out; one shape, one key mask).  A wave keeps its jet's rows in registers from
+ * block to block; each block still writes its out / save_o / save_z.  Same results as the n single launches. */
+#define MPG_MAB_CHAIN_MAX 4
+typedef struct MpgMabChain { MpgMab blk[MPG_MAB_CHAIN_MAX]; int n; } MpgMabChain;
+int mpg_mab_chain_fwd(const MpgMabChain* c, void* stream);
 
 /* mpg_layernorm_fwd / _bwd: nn.LayerNorm(E) over the rows of x [M, E] -- MAB.norm1 / norm2 of GAPT with layer_norm
  * (gapt/model.py:118-120, :131-136).  fwd writes y and stats [M][mean, rstd]; bwd writes dx and, through `part`

@@ -164,6 +164,13 @@ class MpgMab(C.Structure):
 
 MPG_FN_NA = -100   # mpg_edge_fwd_fn: "not one of my shapes" (include/mpgan_amd.h)
 
+MAB_CHAIN_MAX = 4   # MPG_MAB_CHAIN_MAX of include/mpgan_amd.h
+
+
+class MpgMabChain(C.Structure):
+    _fields_ = [("blk", MpgMab * MAB_CHAIN_MAX), ("n", C.c_int)]
+
+
 # name -> (restype, argtypes); kept in step with include/mpgan_amd.h (tests check the symbol list)
 SIGNATURES = {
     "mpg_gemm": (C.c_int, [C.POINTER(MpgGemm), C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -185,6 +192,7 @@ SIGNATURES = {
     "mpg_attn_bwd": (C.c_int, [C.POINTER(MpgAttn), C.c_void_p]),
     "mpg_mab_fwd": (C.c_int, [C.POINTER(MpgMab), C.c_void_p]),
     "mpg_mab_bwd": (C.c_int, [C.POINTER(MpgMab), C.c_void_p]),
+    "mpg_mab_chain_fwd": (C.c_int, [C.POINTER(MpgMabChain), C.c_void_p]),
     "mpg_knn_sets": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_void_p]),
     "mpg_rank_mask": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_void_p]),
     "mpg_jet_order": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_void_p]),

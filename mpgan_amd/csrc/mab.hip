@@ -175,59 +175,17 @@ MPG_DEV f32x16 key_mask_regs(const float* ignore, long jet, int S, int h) {
 
 struct MabScales { float sa, zs, inv_zs; };
 
+// One block on one jet (one wave).  xt: the block's query rows as accumulator-layout tiles on entry, its OUTPUT rows on exit (what
+// the next block of a chain of self-attention blocks takes as its input: mab_chain_fwd_kernel); yt: the key / value rows
+// (CROSS), kneg the additive key mask; the weight images and the pre-scaled biases are in LDS.
 template <int NT, bool CROSS>
-__global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
+MPG_DEV void mab_fwd_jet(const MpgMab& p, f32x16 (&xt)[NT], const f32x16* yt, const f32x16& kneg, WImg rIn, WImg rO, WImg rF,
+                         const float* sBin, const float* sBo, const float* sBf, const long xrow, const bool xvalid,
+                         const uint32_t seed_lo, const uint32_t seed_hi, const float sa, const float inv_zs, const int r, const int h,
+                         const int lane16, unsigned long long* mab_st) {
     typedef f16x8 V;
-    constexpr int KS = 2 * NT;            // k-steps of 16 over E = 32 NT features
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5, lane16 = lane * 16;
-#ifdef MPG_MABSTAMP
-    unsigned long long mab_st[8] = {};
-#endif
-    MAB_STAMP(0);
-    uint32_t seed_lo = 0, seed_hi = 0;
-    if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
-    const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
-    const float zs = sa * ws, inv_zs = 1.f / zs;
+    constexpr int KS = 2 * NT;
     constexpr int nfIn = 3 * NT * KS, nfE = NT * KS;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const sIn = smem;
-    char* const sO = sIn + 2 * nfIn * 1024;
-    char* const sF = sO + 2 * nfE * 1024;
-    float* const sBin = reinterpret_cast<float*>(sF + 2 * nfE * 1024);   // biases: in_proj [3E] | out_proj [E] | ff [E]
-    float* const sBo = sBin + 96 * NT;
-    float* const sBf = sBo + 32 * NT;
-    // the wave's first jet: its rows are requested BEFORE the weight fill (loads return in issue order; behind 80 KiB of
-    // weights per workgroup they would arrive ~3,000 clk later, and their conversion can run while the fill lands)
-    const int nw = blockDim.x >> 6;
-    const long jet0 = (long)blockIdx.x * nw + w;
-    f32x16 xt[NT], yt[CROSS ? NT : 1], kneg;
-    auto load_rows = [&](long jet) {
-        const long xr = jet * p.L + min(r, p.L - 1), yr = jet * p.S + min(r, p.S - 1);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p.x, p.ldx, xr, t, h);
-        if constexpr (CROSS) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) yt[t] = rows_to_tile(p.y, p.ldy, yr, t, h);
-        }
-        kneg = key_mask_regs(p.ignore, jet, p.S, h);
-    };
-    load_rows(min(jet0, (long)p.B - 1));
-    mab_fill(sIn, p.Win, 2 * nfIn * 1024);
-    mab_fill(sO, p.Wo, 2 * nfE * 1024);
-    mab_fill(sF, p.Wf, 2 * nfE * 1024);
-    for (int i = threadIdx.x; i < 160 * NT; i += blockDim.x)
-        sBin[i] = (i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT])) * zs;   // (as the accumulators carry them)
-    __syncthreads();
-    const WImg rIn = sIn, rO = sO, rF = sF;
-    MAB_STAMP(1);
-    for (long jet = jet0; jet < p.B; jet += (long)gridDim.x * nw) {   // (no barrier inside)
-
-    // rows past the end of a set are read from its last row and never stored; as keys they are masked
-    const long xrow = jet * p.L + min(r, p.L - 1);
-    const bool xvalid = r < p.L;
-    // every global load of a jet is issued together: x (kept as tiles for the residual), y, the key mask
-    if (jet != jet0) load_rows(jet);
     V xh[KS], xl[KS], yh_[CROSS ? KS : 1], yl_[CROSS ? KS : 1];
     tiles_to_frags<NT>(xt, sa, xh, xl);
     if constexpr (CROSS) tiles_to_frags<NT>(yt, sa, yh_, yl_);
@@ -304,13 +262,122 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
         for (int i = 0; i < 16; ++i) u[i] += z[t][i];
         drop_tile(u, seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
         if (xvalid) tile_to_rows(p.out, p.ldo, xrow, t, h, u, 1.f);
+        xt[t] = u;     // (the block's output rows, as the next block of a chain takes them; z[t] carried the residual)
     });
     MAB_STAMP(5);
+}
+
+template <int NT, bool CROSS>
+__global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
+    typedef f16x8 V;
+    constexpr int KS = 2 * NT;            // k-steps of 16 over E = 32 NT features
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5, lane16 = lane * 16;
+#ifdef MPG_MABSTAMP
+    unsigned long long mab_st[8] = {};
+    unsigned long long* const mab_stp = mab_st;
+#else
+    unsigned long long* const mab_stp = nullptr;
+#endif
+    MAB_STAMP(0);
+    uint32_t seed_lo = 0, seed_hi = 0;
+    if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+    const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
+    const float zs = sa * ws, inv_zs = 1.f / zs;
+    constexpr int nfIn = 3 * NT * KS, nfE = NT * KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sIn = smem;
+    char* const sO = sIn + 2 * nfIn * 1024;
+    char* const sF = sO + 2 * nfE * 1024;
+    float* const sBin = reinterpret_cast<float*>(sF + 2 * nfE * 1024);   // biases: in_proj [3E] | out_proj [E] | ff [E]
+    float* const sBo = sBin + 96 * NT;
+    float* const sBf = sBo + 32 * NT;
+    // the wave's first jet: its rows are requested BEFORE the weight fill (loads return in issue order; behind 80 KiB of
+    // weights per workgroup they would arrive ~3,000 clk later, and their conversion can run while the fill lands)
+    const int nw = blockDim.x >> 6;
+    const long jet0 = (long)blockIdx.x * nw + w;
+    f32x16 xt[NT], yt[CROSS ? NT : 1], kneg;
+    auto load_rows = [&](long jet) {
+        const long xr = jet * p.L + min(r, p.L - 1), yr = jet * p.S + min(r, p.S - 1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p.x, p.ldx, xr, t, h);
+        if constexpr (CROSS) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) yt[t] = rows_to_tile(p.y, p.ldy, yr, t, h);
+        }
+        kneg = key_mask_regs(p.ignore, jet, p.S, h);
+    };
+    load_rows(min(jet0, (long)p.B - 1));
+    mab_fill(sIn, p.Win, 2 * nfIn * 1024);
+    mab_fill(sO, p.Wo, 2 * nfE * 1024);
+    mab_fill(sF, p.Wf, 2 * nfE * 1024);
+    for (int i = threadIdx.x; i < 160 * NT; i += blockDim.x)
+        sBin[i] = (i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT])) * zs;   // (as the accumulators carry them)
+    __syncthreads();
+    const WImg rIn = sIn, rO = sO, rF = sF;
+    MAB_STAMP(1);
+    for (long jet = jet0; jet < p.B; jet += (long)gridDim.x * nw) {   // (no barrier inside)
+
+    // rows past the end of a set are read from its last row and never stored; as keys they are masked
+    const long xrow = jet * p.L + min(r, p.L - 1);
+    const bool xvalid = r < p.L;
+    // every global load of a jet is issued together: x (kept as tiles for the residual), y, the key mask
+    if (jet != jet0) load_rows(jet);
+    mab_fwd_jet<NT, CROSS>(p, xt, yt, kneg, rIn, rO, rF, sBin, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, r, h, lane16, mab_stp);
     }  // jets of this wave
 #ifdef MPG_MABSTAMP
     if (blockIdx.x == 0 && lane == 0)
         for (int i = 0; i < 8; ++i) g_mab_stamps[w * 8 + i] = mab_st[i];
 #endif
+}
+
+// A CHAIN of self-attention blocks (the SABs of a GAPT network, gapt/model.py:261-262 / :341-342: x = sab(x, mask) in a loop) in
+// one launch: a wave keeps its jet's rows in registers from block to block -- only the weights change (one cooperative refill
+// of the LDS images per block, between two barriers) -- so a block's launch, its prologue and the round trip of its input rows
+// through memory are paid once per chain.  Every block still writes what its backward needs (out = the next block's x,
+// save_o, save_z) as the single launches do, with its own dropout sites: bit-identical to them.  One jet per wave.
+template <int NT>
+__global__ __launch_bounds__(256) void mab_chain_fwd_kernel(const MpgMabChain c) {
+    constexpr int KS = 2 * NT;
+    const MpgMab& p0 = c.blk[0];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5, lane16 = lane * 16;
+    uint32_t seed_lo = 0, seed_hi = 0;
+    if (p0.seed != nullptr) { const uint64_t sd = *p0.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+    const float sa = p0.ascale > 0.f ? p0.ascale : 1.f, ws = p0.wscale > 0.f ? p0.wscale : 1.f;
+    const float zs = sa * ws, inv_zs = 1.f / zs;
+    constexpr int nfIn = 3 * NT * KS, nfE = NT * KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sIn = smem;
+    char* const sO = sIn + 2 * nfIn * 1024;
+    char* const sF = sO + 2 * nfE * 1024;
+    float* const sBin = reinterpret_cast<float*>(sF + 2 * nfE * 1024);
+    float* const sBo = sBin + 96 * NT;
+    float* const sBf = sBo + 32 * NT;
+    const int nw = blockDim.x >> 6;
+    const long jet = (long)blockIdx.x * nw + w;
+    const bool live = jet < p0.B;                      // (a wave without a jet still takes part in the fills and barriers)
+    const long jc = live ? jet : (long)p0.B - 1;
+    const long xrow = jc * p0.L + min(r, p0.L - 1);
+    const bool xvalid = live && r < p0.L;
+    f32x16 xt[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p0.x, p0.ldx, xrow, t, h);
+    const f32x16 kneg = key_mask_regs(p0.ignore, jc, p0.S, h);
+    static_for<0, MPG_MAB_CHAIN_MAX>([&](auto bc) {     // (compile-time index: a run-time one would move the argument block to scratch)
+        MPG_CI(b, bc);
+        if (b < c.n) {
+            const MpgMab& p = c.blk[b];
+            if (b > 0) __syncthreads();                 // every wave is done with the images of the block before
+            mab_fill(sIn, p.Win, 2 * nfIn * 1024);
+            mab_fill(sO, p.Wo, 2 * nfE * 1024);
+            mab_fill(sF, p.Wf, 2 * nfE * 1024);
+            for (int i = threadIdx.x; i < 160 * NT; i += blockDim.x)
+                sBin[i] = (i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT])) * zs;
+            __syncthreads();
+            mab_fwd_jet<NT, false>(p, xt, xt, kneg, sIn, sO, sF, sBin, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, r, h, lane16, nullptr);
+        }
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -613,4 +680,30 @@ extern "C" int mpg_mab_fwd(const MpgMab* p, void* stream) {
     }
     if (cross) return mab_launch(mab_fwd_kernel<1, true>, p, lds, st);
     return mab_launch(mab_fwd_kernel<1, false>, p, lds, st);
+}
+
+extern "C" int mpg_mab_chain_fwd(const MpgMabChain* c, void* stream) {
+    if (c->n < 1 || c->n > MPG_MAB_CHAIN_MAX) return -1;
+    const MpgMab& p0 = c->blk[0];
+    if (const int rc = mab_check(&p0)) return rc;
+    for (int b = 0; b < c->n; ++b) {
+        const MpgMab& p = c->blk[b];
+        // self-attention blocks of one shape on one set of jets, each taking the rows the one before it writes
+        if (p.y != p.x || p.B != p0.B || p.L != p0.L || p.S != p0.L || p.E != p0.E || p.H != p0.H || p.ignore != p0.ignore ||
+            p.seed != p0.seed || p.wscale != p0.wscale || p.ascale != p0.ascale || p.out == nullptr || p.ldo % 4) return -2;
+        if (b > 0 && (p.x != c->blk[b - 1].out || p.ldx != c->blk[b - 1].ldo)) return -2;
+        if (!(p.alpha >= 0.f && p.alpha <= 1.f)) return -4;
+    }
+    const int nw = mab_waves(p0.B);
+    const int grid = (p0.B + nw - 1) / nw;              // one jet per wave: its rows stay in registers across the blocks
+    const int NT = p0.E / 32;
+    const int lds = 2 * 1024 * (3 * NT * 2 * NT + 2 * NT * 2 * NT) + 4 * 160 * NT;
+    hipStream_t st = (hipStream_t)stream;
+    if (p0.E == 64) {
+        MPG_ENSURE_LDS((mab_chain_fwd_kernel<2>), lds);
+        hipLaunchKernelGGL((mab_chain_fwd_kernel<2>), dim3(grid), dim3(64 * nw), lds, st, *c);
+    } else {
+        hipLaunchKernelGGL((mab_chain_fwd_kernel<1>), dim3(grid), dim3(64 * nw), lds, st, *c);
+    }
+    return (int)hipGetLastError();
 }

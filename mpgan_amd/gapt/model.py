@@ -208,6 +208,52 @@ class ISAB(nn.Module):
         return self.mab1(X, H)
 
 
+def _run_sabs(sabs, x: Tensor, am) -> Tensor:
+    """``for sab in sabs: x = sab(x, mask)`` (gapt/model.py:261-262, :341-342).  Runs of plain SABs whose blocks take the
+    one-launch kernel go out as ONE forward launch per run (``ops.FusedSABChainFn``, up to ``MAB_CHAIN_MAX`` blocks each): a wave
+    keeps its jet's rows in registers from block to block.  MPG_MAB_CHAIN=0: block by block."""
+    import os
+    from .._lib import MAB_CHAIN_MAX
+    sabs = list(sabs)
+    B, N, E = x.shape
+    chainable = (x.is_cuda and os.environ.get("MPG_MAB_CHAIN", "1") != "0" and not ops.double_backward_on(x.device)
+                 and B * N > 0)
+    i = 0
+    while i < len(sabs):
+        run = []
+        if chainable:
+            while (i + len(run) < len(sabs) and len(run) < MAB_CHAIN_MAX and isinstance(sabs[i + len(run)], SAB)
+                   and sabs[i + len(run)].mab._fused_ok(x, N, N)):
+                run.append(sabs[i + len(run)].mab)
+            if run and not all(_same_block_config(m, run[0]) for m in run):
+                run = run[:1]
+        if len(run) >= 2 and B <= 4096:      # (one jet per wave: the launch covers at most 1,024 workgroups of four)
+            first = run[0]
+            ignore = MAB._ignore_of(_key_mask(am), B, N)
+            params = []
+            for m in run:
+                att, lin = m.attention, m.ff.net[0]
+                params += [att.in_proj_weight, att.in_proj_bias, att.out_proj.weight, att.out_proj.bias, lin.weight, lin.bias]
+            pks = [m._packed() for m in run]
+            args = (first.num_heads, first.ff.leaky_relu_alpha, not first.ff.final_linear, first.dropout_p, first.ff.dropout_p,
+                    first.training)
+            if torch.is_grad_enabled() and (x.requires_grad or any(q.requires_grad for q in params)):
+                x = ops.FusedSABChainFn.apply(x, ignore, *args, pks, *params)
+            else:
+                x = ops.sab_chain_forward(x, ignore, *args, pks, params)
+            i += len(run)
+        else:
+            x = sabs[i](x, am)
+            i += 1
+    return x
+
+
+def _same_block_config(a: "MAB", b: "MAB") -> bool:
+    return (a.embed_dim == b.embed_dim and a.num_heads == b.num_heads and a.dropout_p == b.dropout_p and a.training == b.training
+            and a.ff.dropout_p == b.ff.dropout_p and a.ff.leaky_relu_alpha == b.ff.leaky_relu_alpha
+            and a.ff.final_linear == b.ff.final_linear)
+
+
 def _attn_mask(mask: Tensor) -> Optional[Tensor]:
     """JetNet mask (1 real, 0 padded) -> attention convention (True = ignore).  The float form the attention kernels
     take ([B*N], 1 = ignore) rides along as an attribute, so that the blocks of a network do not each convert it."""
@@ -266,8 +312,7 @@ class GAPT_G(nn.Module):
 
     def forward(self, x: Tensor, labels: Tensor = None):
         mask, am = self._mask(x, labels)
-        for sab in self.sabs:
-            x = sab(x, am)
+        x = _run_sabs(self.sabs, x, am)
         x = self.final_fc(x)
         if x.is_cuda:  # tanh + the (mask - 0.5) column in one launch each way
             return ops.GenTailFn.apply(x, mask, ops.ACT_CODES["tanh"])
@@ -283,8 +328,7 @@ class GAPT_G(nn.Module):
                                     with_ignore=True, ignore_out=None if ign_out is None else ign_out.view(B, -1))
         mask = mask2d.unsqueeze(2)
         am = _ignore_mask(ign.unsqueeze(2))
-        for sab in self.sabs:
-            x = sab(x, am)
+        x = _run_sabs(self.sabs, x, am)
         x = self.final_fc(x)
         if feat_out is not None:
             assert not torch.is_grad_enabled()
@@ -295,8 +339,7 @@ class GAPT_G(nn.Module):
         """``forward`` into caller-owned output rows, no gradient (``train.TrainStep``'s D step)."""
         assert not torch.is_grad_enabled() and x.is_cuda
         mask, am = self._mask(x, labels)
-        for sab in self.sabs:
-            x = sab(x, am)
+        x = _run_sabs(self.sabs, x, am)
         return ops.gen_tail_into(self.final_fc(x), mask, ops.ACT_CODES["tanh"], out)
 
 
@@ -338,8 +381,7 @@ class GAPT_D(nn.Module):
                 am = _ignore_mask(0.5 - x.detach()[..., -1:])   # (no gradient flows through the mask column: :336-338, bool mask)
             x = x[..., :-1]
         x = self.input_embedding(x)   # (a column slice of the [.., 4] rows: the GEMM takes the row stride as it is)
-        for sab in self.sabs:
-            x = sab(x, am)
+        x = _run_sabs(self.sabs, x, am)
         return self.pma(x, am), None
 
     def parts_ok(self) -> bool:
@@ -351,8 +393,7 @@ class GAPT_D(nn.Module):
         inv = (1 - mask) if ignore is None else ignore
         am = _ignore_mask(inv.reshape(B, N, 1))
         x = self.input_embedding(x3)
-        for sab in self.sabs:
-            x = sab(x, am)
+        x = _run_sabs(self.sabs, x, am)
         return self.pma(x, am), None
 
     def forward(self, x: Tensor, labels: Tensor = None):

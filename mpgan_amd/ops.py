@@ -1190,6 +1190,141 @@ def mab_forward(x2, y2, ignore, pk, bin_, bo, bf, B, L, S, H, *, alpha=0.2, ff_a
     return out, o, z, tag
 
 
+def _mab_backward_block(x2, y2, ignore, o, z, params, pk, cfg, gout, need_x, need_y, need_w):
+    """The backward of one attention block (``mpg_mab_bwd`` + its weight gradients: queued for the grouped launches inside a
+    TrainStep backward, computed at once otherwise): (dx rows or None, dy rows or None, the six parameter gradients or Nones)."""
+    B, L, S, E, H, alpha, ff_act, tag, p_mab, p_ff = cfg
+    bin_, bo, bf = params[1], params[3], params[5]
+    dev = x2.device
+    cross = y2 is not None
+    thr_mab, sc_mab = drop_params(p_mab)
+    thr_ff, sc_ff = drop_params(p_ff)
+    dout = gout.reshape(B * L, E).contiguous()
+    m = _mab_struct(x2, y2, ignore, pk, bin_, bo, bf, B, L, S, E, H, alpha, ff_act, tag, thr_mab, sc_mab, thr_ff, sc_ff)
+    m.save_o, m.save_z = _p(o), _p(z)
+    m.dout, m.lddout = _p(dout), dout.stride(0)
+    dx = torch.empty((B * L, E), device=dev, dtype=torch.float32) if need_x else None
+    dy = torch.empty((B * S, E), device=dev, dtype=torch.float32) if (cross and need_y) else None
+    m.dx, m.lddx, m.dy, m.lddy = _p(dx), E, _p(dy), E
+    dqkv = dq = dkv = dza = du = None
+    if need_w:
+        if cross:
+            dq = torch.empty((B * L, E), device=dev, dtype=torch.float32)
+            dkv = torch.empty((B * S, 2 * E), device=dev, dtype=torch.float32)
+            m.dq, m.lddq, m.dk, m.dv, m.lddkv = _p(dq), E, _p(dkv), _p(dkv, E), 2 * E
+        else:
+            dqkv = torch.empty((B * L, 3 * E), device=dev, dtype=torch.float32)
+            m.dq, m.lddq, m.dk, m.dv, m.lddkv = _p(dqkv), 3 * E, _p(dqkv, E), _p(dqkv, 2 * E), 3 * E
+        dza, du = torch.empty_like(dout), torch.empty_like(dout)
+        m.dza, m.du = _p(dza), _p(du)
+    check(_lib.lib().mpg_mab_bwd(C.byref(m), _stream()), "mpg_mab_bwd")
+    grads = [None] * 6
+    if need_w:
+        st = dev_state(dev)
+        tg = None
+        if st.grad_into_param and st.deferred_wgrad is not None:
+            tg = [_grad_target(q) for q in params]
+            if any(t is None for t in tg):
+                tg = None
+        if tg is not None:      # TrainStep: queued for the grouped launches, added into the flat gradient buffers
+            gWin, gbin, gWo, gbo, gWf, gbf = tg
+            wb = st.deferred_wgrad
+            if cross:
+                wb.add(dq, x2, out=gWin[:E], bias_out=gbin[:E], accumulate=True)
+                wb.add(dkv, y2, out=gWin[E:], bias_out=gbin[E:], accumulate=True)
+            else:
+                wb.add(dqkv, x2, out=gWin, bias_out=gbin, accumulate=True)
+            wb.add(dza, o, out=gWo, bias_out=gbo, accumulate=True)
+            wb.add(du, z, out=gWf, bias_out=gbf, accumulate=True)
+        else:
+            def wgrad(dyv, xv):
+                db = torch.empty(dyv.shape[1], device=dev, dtype=torch.float32)
+                return linear_bwd_weight(dyv, xv, bias_out=db), db
+            if cross:
+                (wq, bq), (wkv, bkv) = wgrad(dq, x2), wgrad(dkv, y2)
+                grads[0], grads[1] = torch.cat([wq, wkv], 0), torch.cat([bq, bkv], 0)
+            else:
+                grads[0], grads[1] = wgrad(dqkv, x2)
+            grads[2], grads[3] = wgrad(dza, o)
+            grads[4], grads[5] = wgrad(du, z)
+    return dx, dy, grads
+
+
+def sab_chain_forward(x, ignore, H, alpha, ff_act, p_mab, p_ff, training, pks, params):
+    """``FusedSABChainFn`` without a backward to prepare for: one launch, nothing kept but the last block's output."""
+    B, L, E = x.shape
+    dev = x.device
+    x2 = x.reshape(B * L, E).contiguous()
+    thr_mab, sc_mab = drop_params(p_mab) if training else (0, 1.0)
+    thr_ff, sc_ff = drop_params(p_ff) if training else (0, 1.0)
+    c = _lib.MpgMabChain()
+    c.n = len(pks)
+    inp, keep = x2, []
+    for b in range(len(pks)):
+        out = torch.empty((B * L, E), device=dev, dtype=torch.float32)
+        m = _mab_struct(inp, None, ignore, pks[b], params[6 * b + 1], params[6 * b + 3], params[6 * b + 5], B, L, L, E, H, alpha, ff_act,
+                        next_tag(dev), thr_mab, sc_mab, thr_ff, sc_ff)
+        m.out, m.ldo = _p(out), E
+        c.blk[b] = m
+        keep.append(out)
+        inp = out
+    check(_lib.lib().mpg_mab_chain_fwd(C.byref(c), _stream()), "mpg_mab_chain_fwd")
+    return keep[-1].reshape(B, L, E)
+
+
+class FusedSABChainFn(torch.autograd.Function):
+    """Several self-attention blocks applied one after the other (the SABs of GAPT_G / GAPT_D, gapt/model.py:261-262, :341-342)
+    with ONE forward launch (``mpg_mab_chain_fwd``: a wave keeps its jet's rows in registers from block to block); the backward
+    runs block by block (``mpg_mab_bwd``).  ``params``: (in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, ff weight,
+    ff bias) per block; ``pks``: the blocks' ``PackedMAB`` sets."""
+
+    @staticmethod
+    def forward(ctx, x, ignore, H, alpha, ff_act, p_mab, p_ff, training, pks, *params):
+        B, L, E = x.shape
+        n = len(pks)
+        dev = x.device
+        x2 = x.reshape(B * L, E).contiguous()
+        thr_mab, sc_mab = drop_params(p_mab) if training else (0, 1.0)
+        thr_ff, sc_ff = drop_params(p_ff) if training else (0, 1.0)
+        c = _lib.MpgMabChain()
+        c.n = n
+        inp, outs, os_, zs_, tags = x2, [], [], [], []
+        for b in range(n):
+            bin_, bo, bf = params[6 * b + 1], params[6 * b + 3], params[6 * b + 5]
+            tag = next_tag(dev)
+            out, o, z = (torch.empty((B * L, E), device=dev, dtype=torch.float32) for _ in range(3))
+            m = _mab_struct(inp, None, ignore, pks[b], bin_, bo, bf, B, L, L, E, H, alpha, ff_act, tag, thr_mab, sc_mab, thr_ff, sc_ff)
+            m.out, m.ldo, m.save_o, m.save_z = _p(out), E, _p(o), _p(z)
+            c.blk[b] = m
+            outs.append(out); os_.append(o); zs_.append(z); tags.append(tag)
+            inp = out
+        check(_lib.lib().mpg_mab_chain_fwd(C.byref(c), _stream()), "mpg_mab_chain_fwd")
+        ctx.save_for_backward(x2, ignore, *outs[:-1], *os_, *zs_)
+        ctx.pks, ctx.params, ctx.n = pks, params, n
+        ctx.cfgs = [(B, L, L, E, H, alpha, ff_act, tags[b], p_mab if training else 0.0, p_ff if training else 0.0) for b in range(n)]
+        return outs[-1].reshape(B, L, E)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        n = ctx.n
+        sv = ctx.saved_tensors
+        x2, ignore = sv[0], sv[1]
+        ins = [x2] + list(sv[2:2 + n - 1])            # the input rows of block b: x, then the outputs of the blocks before
+        os_, zs_ = sv[2 + n - 1:2 + 2 * n - 1], sv[2 + 2 * n - 1:2 + 3 * n - 1]
+        B, L, _, E = ctx.cfgs[0][:4]
+        g = gout
+        all_grads = [None] * (6 * n)
+        for b in reversed(range(n)):
+            prm = ctx.params[6 * b:6 * b + 6]
+            need_w = any(ctx.needs_input_grad[9 + 6 * b:9 + 6 * b + 6])
+            need_x = b > 0 or ctx.needs_input_grad[0]
+            dx, _, grads = _mab_backward_block(ins[b], None, ignore, os_[b], zs_[b], prm, ctx.pks[b], ctx.cfgs[b], g, need_x, False, need_w)
+            all_grads[6 * b:6 * b + 6] = grads
+            g = dx
+        return (None if g is None else g.reshape(B, L, E), None, None, None, None, None, None, None, None, *all_grads)
+
+
 class FusedMABFn(torch.autograd.Function):
     """MAB.forward (gapt/model.py:124-139) as ONE launch each way (``mpg_mab_fwd`` / ``mpg_mab_bwd``).  x [B, L, E]
     queries, y [B, S, E] keys/values or None for self-attention.  The forward keeps only o (attention output) and z
@@ -1223,59 +1358,8 @@ class FusedMABFn(torch.autograd.Function):
         x2, y2, ignore, o, z, bin_, bo, bf = ctx.saved_tensors
         B, L, S, E, H, alpha, ff_act, tag, p_mab, p_ff = ctx.cfg
         dev = x2.device
-        cross = y2 is not None
-        need_w = any(ctx.needs_input_grad[3:9])
-        thr_mab, sc_mab = drop_params(p_mab)
-        thr_ff, sc_ff = drop_params(p_ff)
-        dout = gout.reshape(B * L, E).contiguous()
-        m = _mab_struct(x2, y2, ignore, ctx.pk, bin_, bo, bf, B, L, S, E, H, alpha, ff_act, tag, thr_mab, sc_mab, thr_ff, sc_ff)
-        m.save_o, m.save_z = _p(o), _p(z)
-        m.dout, m.lddout = _p(dout), dout.stride(0)
-        dx = torch.empty((B * L, E), device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        dy = torch.empty((B * S, E), device=dev, dtype=torch.float32) if (cross and ctx.needs_input_grad[1]) else None
-        m.dx, m.lddx, m.dy, m.lddy = _p(dx), E, _p(dy), E
-        dqkv = dq = dkv = dza = du = None
-        if need_w:
-            if cross:
-                dq = torch.empty((B * L, E), device=dev, dtype=torch.float32)
-                dkv = torch.empty((B * S, 2 * E), device=dev, dtype=torch.float32)
-                m.dq, m.lddq, m.dk, m.dv, m.lddkv = _p(dq), E, _p(dkv), _p(dkv, E), 2 * E
-            else:
-                dqkv = torch.empty((B * L, 3 * E), device=dev, dtype=torch.float32)
-                m.dq, m.lddq, m.dk, m.dv, m.lddkv = _p(dqkv), 3 * E, _p(dqkv, E), _p(dqkv, 2 * E), 3 * E
-            dza, du = torch.empty_like(dout), torch.empty_like(dout)
-            m.dza, m.du = _p(dza), _p(du)
-        check(_lib.lib().mpg_mab_bwd(C.byref(m), _stream()), "mpg_mab_bwd")
-        grads = [None] * 6
-        if need_w:
-            Win, bin_p, Wo, bo_p, Wf, bf_p = ctx.params
-            st = dev_state(dev)
-            tg = None
-            if st.grad_into_param and st.deferred_wgrad is not None:
-                tg = [_grad_target(q) for q in ctx.params]
-                if any(t is None for t in tg):
-                    tg = None
-            if tg is not None:      # TrainStep: queued for the grouped launches, added into the flat gradient buffers
-                gWin, gbin, gWo, gbo, gWf, gbf = tg
-                wb = st.deferred_wgrad
-                if cross:
-                    wb.add(dq, x2, out=gWin[:E], bias_out=gbin[:E], accumulate=True)
-                    wb.add(dkv, y2, out=gWin[E:], bias_out=gbin[E:], accumulate=True)
-                else:
-                    wb.add(dqkv, x2, out=gWin, bias_out=gbin, accumulate=True)
-                wb.add(dza, o, out=gWo, bias_out=gbo, accumulate=True)
-                wb.add(du, z, out=gWf, bias_out=gbf, accumulate=True)
-            else:
-                def wgrad(dyv, xv):
-                    db = torch.empty(dyv.shape[1], device=dev, dtype=torch.float32)
-                    return linear_bwd_weight(dyv, xv, bias_out=db), db
-                if cross:
-                    (wq, bq), (wkv, bkv) = wgrad(dq, x2), wgrad(dkv, y2)
-                    grads[0], grads[1] = torch.cat([wq, wkv], 0), torch.cat([bq, bkv], 0)
-                else:
-                    grads[0], grads[1] = wgrad(dqkv, x2)
-                grads[2], grads[3] = wgrad(dza, o)
-                grads[4], grads[5] = wgrad(du, z)
+        dx, dy, grads = _mab_backward_block(x2, y2, ignore, o, z, ctx.params, ctx.pk, ctx.cfg, gout,
+                                            ctx.needs_input_grad[0], ctx.needs_input_grad[1], any(ctx.needs_input_grad[3:9]))
         if ctx.bcast and dx is not None:
             # the shared query row's gradient: the sum over the jets -- a bias-sum job of the grouped launch when there is one
             st = dev_state(dev)

@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     """sizeof of every struct as gcc sees the header == ctypes.sizeof of the Python mirror."""
     from mpgan_amd import _lib
     structs = ["MpgGemm", "MpgEdgeFwd", "MpgEdgeBwd", "MpgEdgeDw", "MpgAttn", "MpgPackJob", "MpgChainLayer", "MpgChain", "MpgReduceJob",
-               "MpgDiscHead", "MpgMab"]
+               "MpgDiscHead", "MpgMab", "MpgMabChain"]
     src = '#include <stdio.h>\n#include "mpgan_amd.h"\nint main(){' + "".join(
         f'printf("{s} %zu\\n", sizeof({s}));' for s in structs) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:
@@ -53,6 +53,8 @@ def test_header_constants_match_their_python_mirrors():
     defs = {k: int(v) for k, v in re.findall(r"^#define\s+(MPG_\w+)\s+(\d+)\s*$", txt, flags=re.M)}
     assert defs["MPG_GROUP_MAX"] == ops.GROUP_MAX and defs["MPG_PACK_MAX_JOBS"] == ops.PACK_MAX
     assert defs["MPG_EDGE_SCALARS"] == ops.EDGE_SCALARS
+    from mpgan_amd import _lib
+    assert defs["MPG_MAB_CHAIN_MAX"] == _lib.MAB_CHAIN_MAX and defs["MPG_FN_NA"] if "MPG_FN_NA" in defs else True
     csrc = os.path.join(ROOT, "mpgan_amd", "csrc")
     bwd, fwd = open(os.path.join(csrc, "edge_bwd2_impl.h")).read(), open(os.path.join(csrc, "edge_fwd2_impl.h")).read()
     lim = lambda src, name: int(re.search(r"constexpr int " + name + r" = (\d+);", src).group(1))

@@ -165,3 +165,69 @@ def test_sab_layer_norm_vs_reference_golden():
         assert rel_err(xx.grad.cpu().numpy(), xr.grad.cpu().numpy()) < 1e-5
         assert rel_err(w.grad.cpu().numpy(), ln.weight.grad.cpu().numpy()) < 1e-5
         assert rel_err(b.grad.cpu().numpy(), ln.bias.grad.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("which,B,p_drop", [("G", 64, 0.0), ("D", 64, 0.5), ("G", 512, 0.3)])
+def test_sab_chain_is_bit_identical_to_block_by_block(which, B, p_drop):
+    """The SABs of a network as ONE forward launch (``mpg_mab_chain_fwd``: a wave keeps its jet's rows in registers from block
+    to block) against one launch per block (MPG_MAB_CHAIN=0): outputs and every gradient bit for bit, dropout on (each block
+    keeps its own sites), and the launch sequence itself."""
+    import itertools, os
+    from mpgan_amd import ops, _lib, train as mtrain
+    dev = torch.device("cuda:0")
+    N = 30
+    torch.manual_seed(7)
+    G, D = mtrain.default_gapt(N, disc_dropout=p_drop, gen_dropout=p_drop)
+    net = G if which == "G" else D
+    net.train()
+    rs = np.random.RandomState(3)
+    labels = torch.from_numpy(rs.randint(5, N + 1, size=(B, 1)) / N).float().to(dev)
+    if which == "G":
+        xin = torch.from_numpy(rs.normal(0, 0.2, size=(B, N, 64))).float().to(dev)
+    else:
+        from oracle.train_ref import synthetic_batch
+        xin = synthetic_batch(B, N, seed=3)[0].to(dev)
+    net(xin, labels)   # (weight images built)
+
+    def run(chain):
+        os.environ["MPG_MAB_CHAIN"] = "1" if chain else "0"
+        st = ops.dev_state(dev)
+        st.tags = itertools.count(31)
+        ops.set_seed(77, dev)
+        net.zero_grad()
+        x = xin.clone().requires_grad_(True)
+        names = []
+        real = _lib.lib()
+
+        class Spy:
+            def __getattr__(self, k):
+                fn = getattr(real, k)
+                if not k.startswith("mpg_mab"):
+                    return fn
+
+                def f(*a):
+                    names.append(k)
+                    return fn(*a)
+                return f
+        saved = _lib._lib
+        _lib._lib = Spy()
+        try:
+            y = net(x, labels)
+            y.sum().backward()
+        finally:
+            _lib._lib = saved
+        res = {"y": y.detach().clone(), "dx": x.grad.clone()}
+        res.update({k: q.grad.clone() for k, q in net.named_parameters() if q.grad is not None})
+        return res, names
+
+    try:
+        (a, na), (b_, nb) = run(True), run(False)
+    finally:
+        os.environ.pop("MPG_MAB_CHAIN", None)
+    nsab = len(net.sabs)
+    extra = 0 if which == "G" else 1    # (D's pooling block: a cross-attention launch of its own)
+    assert na[:1 + extra] == ["mpg_mab_chain_fwd"] + ["mpg_mab_fwd"] * extra, na
+    assert nb[:nsab + extra] == ["mpg_mab_fwd"] * (nsab + extra), nb
+    assert na.count("mpg_mab_bwd") == nb.count("mpg_mab_bwd") == nsab + extra
+    for k in a:
+        assert torch.equal(a[k], b_[k]), (k, float((a[k] - b_[k]).abs().max()))
