@@ -22,6 +22,14 @@ def test_world1_nccl_group_three_segments_equal_eager():
     import torch.distributed as dist
     from test_gpu_train import _three_steps
     a = _three_steps(16, 30, use_graphs=False)
+    # (the reference point without the side streams: the weight-gradient stream joins BEFORE each all-reduce -- in the
+    # three-segment form and inside the one-graph form alike -- so every run below must land on these very bits)
+    os.environ.update(MPG_WGRAD_SIDE="0", MPG_GEN_AHEAD="0")
+    try:
+        a0 = _three_steps(16, 30, use_graphs=False)
+    finally:
+        os.environ.pop("MPG_WGRAD_SIDE", None); os.environ.pop("MPG_GEN_AHEAD", None)
+    assert torch.equal(a[0], a0[0]) and torch.equal(a[1], a0[1]) and a[2:] == a0[2:]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
