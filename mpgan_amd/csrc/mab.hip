@@ -380,6 +380,166 @@ __global__ __launch_bounds__(256) void mab_chain_fwd_kernel(const MpgMabChain c)
     });
 }
 
+// ---- TWO WAVES PER JET (E = 64, self-attention).  A block is a dependent chain of ~150 MFMAs and the hi/lo splits between
+// them on ONE wave, and a launch of 512 jets leaves half of the chip's SIMDs without a wave.  Here wave `T` of a pair owns
+// feature tile T of every tensor of the block -- heads 2T and 2T + 1 of the attention (which never look at the other heads),
+// tile T of the out-projection, of the feed-forward layer and of the output -- and the pair meets twice per block in LDS:
+// the attention output and z are needed by both as B fragments of the next product (each writes its two k-steps, reads the
+// partner's two).  In a chain the output rows go across a third time, as the next block's x fragments.  Half the MFMAs, half
+// the splits and half the softmax per wave; same arithmetic per element, hence the same bits as the one-wave form.
+constexpr int MAB_XCH = 4 * 2 * 1024;   // one exchange buffer of a pair: [k-step][hi | lo][lane] 16 B
+
+template <int T>
+MPG_DEV void mab_fwd_half(const MpgMab& p, f16x8* xh, f16x8* xl, f32x16& xtile, const f32x16& kneg, WImg rIn, WImg rO, WImg rF,
+                          const float* sBin, const float* sBo, const float* sBf, const long xrow, const bool xvalid,
+                          const uint32_t seed_lo, const uint32_t seed_hi, const float sa, const float inv_zs, const int r, const int h,
+                          const int lane, char* xchA, char* xchB, const bool next_x) {
+    typedef f16x8 V;
+    constexpr int NT = 2, KS = 4, nfIn = 3 * NT * KS, nfE = NT * KS, O = 1 - T;
+    const int lane16 = lane * 16;
+    V* const fa = reinterpret_cast<V*>(xchA);
+    V* const fb = reinterpret_cast<V*>(xchB);
+    auto put = [&](V* f, int ks, const V& hi, const V& lo) { f[(ks * 2 + 0) * 64 + lane] = hi; f[(ks * 2 + 1) * 64 + lane] = lo; };
+    auto get = [&](const V* f, int ks, V& hi, V& lo) { hi = f[(ks * 2 + 0) * 64 + lane]; lo = f[(ks * 2 + 1) * 64 + lane]; };
+    V oh[KS], ol[KS];
+    {
+        const f32x16 Qn = proj_n<KS>(rIn, nfIn, T, xh, xl, bias_regs(sBin, T, h), lane16);
+        const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + T, xh, xl, bias_regs(sBin, NT + T, h), lane16);
+        const f32x16 Vt = proj_t<KS>(rIn, nfIn, 2 * NT + T, xh, xl, bias_lanes(sBin, 2 * NT + T, r), lane16);
+        V vh[2], vl[2];
+        tile_frag(Vt, 0, inv_zs * sa, vh[0], vl[0]);
+        tile_frag(Vt, 1, inv_zs * sa, vh[1], vl[1]);
+        f32x16 Ot;
+        static_for<0, 2>([&](auto ac) {
+            MPG_CI(a, ac);
+            V qh, ql, kh, kl;
+            tile_frag(Qn, a, inv_zs * sa * 0.25f, qh, ql);
+            tile_frag(Kn, a, inv_zs * sa, kh, kl);
+            f32x16 sc = mfma3(kh, kl, qh, ql, zero16());
+            const float sc2 = 1.44269504088896341f / (sa * sa);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sc[i] = sc[i] * sc2 + kneg[i]; mx = fmaxf(mx, sc[i]); }
+            mx = fmaxf(mx, other_half(mx));
+            float den = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sc[i] = __builtin_amdgcn_exp2f(sc[i] - mx); den += sc[i]; }
+            den += other_half(den);
+            const float pn = MAB_SP / den;
+            V ph[2], pl[2];
+            tile_frag(sc, 0, pn, ph[0], pl[0]);
+            tile_frag(sc, 1, pn, ph[1], pl[1]);
+            f32x16 oa = mfma3(vh[0], vl[0], ph[0], pl[0], zero16());
+            oa = mfma3(vh[1], vl[1], ph[1], pl[1], oa);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Ot[8 * a + j] = oa[8 * a + j];
+        });
+        if (p.save_o != nullptr && xvalid) tile_to_rows(p.save_o, p.E, xrow, T, h, Ot, 1.f / (MAB_SP * sa));
+        tile_frag(Ot, 0, 1.f / MAB_SP, oh[2 * T], ol[2 * T]);
+        tile_frag(Ot, 1, 1.f / MAB_SP, oh[2 * T + 1], ol[2 * T + 1]);
+    }
+    put(fa, 2 * T, oh[2 * T], ol[2 * T]);
+    put(fa, 2 * T + 1, oh[2 * T + 1], ol[2 * T + 1]);
+    __syncthreads();
+    get(fa, 2 * O, oh[2 * O], ol[2 * O]);
+    get(fa, 2 * O + 1, oh[2 * O + 1], ol[2 * O + 1]);
+    // za = x + o Wo' + bo ; z = dropout(za): tile T
+    f32x16 z;
+    V zh[KS], zl[KS];
+    {
+        const f32x16 acc = proj_n<KS>(rO, nfE, T, oh, ol, bias_regs(sBo, T, h), lane16);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) z[i] = acc[i] * inv_zs + xtile[i];
+        drop_tile(z, seed_lo, seed_hi, p.tag + 0, (uint32_t)xrow, T, h, p.thr_mab, p.sc_mab);
+        if (p.save_z != nullptr && xvalid) tile_to_rows(p.save_z, p.E, xrow, T, h, z, 1.f);
+        tile_frag(z, 0, sa, zh[2 * T], zl[2 * T]);
+        tile_frag(z, 1, sa, zh[2 * T + 1], zl[2 * T + 1]);
+    }
+    put(fb, 2 * T, zh[2 * T], zl[2 * T]);
+    put(fb, 2 * T + 1, zh[2 * T + 1], zl[2 * T + 1]);
+    __syncthreads();
+    get(fb, 2 * O, zh[2 * O], zl[2 * O]);
+    get(fb, 2 * O + 1, zh[2 * O + 1], zl[2 * O + 1]);
+    // out = dropout(z + dropout_ff(LeakyReLU(z Wf' + bf))): tile T
+    f32x16 u = proj_n<KS>(rF, nfE, T, zh, zl, bias_regs(sBf, T, h), lane16);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float v = u[i] * inv_zs;
+        u[i] = p.ff_act ? lrelu(v, p.alpha) : v;
+    }
+    drop_tile(u, seed_lo, seed_hi, p.tag + 1, (uint32_t)xrow, T, h, p.thr_ff, p.sc_ff);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) u[i] += z[i];
+    drop_tile(u, seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, T, h, p.thr_mab, p.sc_mab);
+    if (xvalid) tile_to_rows(p.out, p.ldo, xrow, T, h, u, 1.f);
+    xtile = u;
+    if (next_x) {   // the next block's x fragments: own k-steps from the registers, the partner's through the first buffer
+        tile_frag(u, 0, sa, xh[2 * T], xl[2 * T]);
+        tile_frag(u, 1, sa, xh[2 * T + 1], xl[2 * T + 1]);
+        put(fa, 2 * T, xh[2 * T], xl[2 * T]);          // (the partner read its o fragments before the second barrier)
+        put(fa, 2 * T + 1, xh[2 * T + 1], xl[2 * T + 1]);
+        __syncthreads();
+        get(fa, 2 * O, xh[2 * O], xl[2 * O]);
+        get(fa, 2 * O + 1, xh[2 * O + 1], xl[2 * O + 1]);
+    }
+}
+
+// the chain of self-attention blocks with two waves per jet; a workgroup of four waves carries two jets
+__global__ __launch_bounds__(256) void mab_chain_fwd2_kernel(const MpgMabChain c) {
+    typedef f16x8 V;
+    constexpr int NT = 2, KS = 4;
+    const MpgMab& p0 = c.blk[0];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int pair = w >> 1, role = w & 1;
+    uint32_t seed_lo = 0, seed_hi = 0;
+    if (p0.seed != nullptr) { const uint64_t sd = *p0.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+    const float sa = p0.ascale > 0.f ? p0.ascale : 1.f, ws = p0.wscale > 0.f ? p0.wscale : 1.f;
+    const float zs = sa * ws, inv_zs = 1.f / zs;
+    constexpr int nfIn = 3 * NT * KS, nfE = NT * KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sIn = smem;
+    char* const sO = sIn + 2 * nfIn * 1024;
+    char* const sF = sO + 2 * nfE * 1024;
+    float* const sBin = reinterpret_cast<float*>(sF + 2 * nfE * 1024);
+    float* const sBo = sBin + 96 * NT;
+    float* const sBf = sBo + 32 * NT;
+    char* const xchA = reinterpret_cast<char*>(sBf + 32 * NT) + pair * 2 * MAB_XCH;
+    char* const xchB = xchA + MAB_XCH;
+    const int npair = blockDim.x >> 7;
+    const long jet = (long)blockIdx.x * npair + pair;
+    const bool live = jet < p0.B;                      // (a pair without a jet still takes part in the fills and barriers)
+    const long jc = live ? jet : (long)p0.B - 1;
+    const long xrow = jc * p0.L + min(r, p0.L - 1);
+    const bool xvalid = live && r < p0.L;
+    V xh[KS], xl[KS];
+    f32x16 xtile;
+    {
+        f32x16 xt[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p0.x, p0.ldx, xrow, t, h);
+        tiles_to_frags<NT>(xt, sa, xh, xl);
+        xtile = role == 0 ? xt[0] : xt[1];
+    }
+    const f32x16 kneg = key_mask_regs(p0.ignore, jc, p0.S, h);
+    static_for<0, MPG_MAB_CHAIN_MAX>([&](auto bc) {
+        MPG_CI(b, bc);
+        if (b < c.n) {
+            const MpgMab& p = c.blk[b];
+            if (b > 0) __syncthreads();                 // every wave is done with the images of the block before
+            mab_fill(sIn, p.Win, 2 * nfIn * 1024);
+            mab_fill(sO, p.Wo, 2 * nfE * 1024);
+            mab_fill(sF, p.Wf, 2 * nfE * 1024);
+            for (int i = threadIdx.x; i < 160 * NT; i += blockDim.x)
+                sBin[i] = (i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT])) * zs;
+            __syncthreads();
+            const bool nx = b + 1 < c.n;
+            if (role == 0) mab_fwd_half<0>(p, xh, xl, xtile, kneg, sIn, sO, sF, sBin, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, r, h, lane, xchA, xchB, nx);
+            else mab_fwd_half<1>(p, xh, xl, xtile, kneg, sIn, sO, sF, sBin, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, r, h, lane, xchA, xchB, nx);
+        }
+    });
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Backward of the block, one wave per jet again.  q, k, v, P and u are recomputed from x, y and the saved z with the
 // forward's own arithmetic; gradients run as bf16 hi/lo products.  With S' = K Q' (keys in registers) the softmax
@@ -699,7 +859,13 @@ extern "C" int mpg_mab_chain_fwd(const MpgMabChain* c, void* stream) {
     const int NT = p0.E / 32;
     const int lds = 2 * 1024 * (3 * NT * 2 * NT + 2 * NT * 2 * NT) + 4 * 160 * NT;
     hipStream_t st = (hipStream_t)stream;
-    if (p0.E == 64) {
+    static const int split = getenv("MPG_MAB_SPLIT") ? atoi(getenv("MPG_MAB_SPLIT")) : 1;   // (experiments: 0 = one wave per jet)
+    if (p0.E == 64 && split) {
+        // two waves per jet, two jets per workgroup
+        const int lds2 = lds + 2 * 2 * MAB_XCH;
+        MPG_ENSURE_LDS(mab_chain_fwd2_kernel, lds2);
+        hipLaunchKernelGGL(mab_chain_fwd2_kernel, dim3((p0.B + 1) / 2), dim3(256), lds2, st, *c);
+    } else if (p0.E == 64) {
         MPG_ENSURE_LDS((mab_chain_fwd_kernel<2>), lds);
         hipLaunchKernelGGL((mab_chain_fwd_kernel<2>), dim3(grid), dim3(64 * nw), lds, st, *c);
     } else {
