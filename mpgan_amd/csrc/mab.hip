@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void mab_chain_fwd_kernel(const MpgMabChain c)
 constexpr int MAB_XCH = 4 * 2 * 1024;   // one exchange buffer of a pair: [k-step][hi | lo][lane] 16 B
 
 template <int T>
-MPG_DEV void mab_fwd_half(const MpgMab& p, f16x8* xh, f16x8* xl, f32x16& xtile, const f32x16& kneg, WImg rIn, WImg rO, WImg rF,
+MPG_DEV void mab_fwd_half(const MpgMab& p, f16x8* xh, f16x8* xl, const f16x8* yh, const f16x8* yl, f32x16& xtile, const f32x16& kneg, WImg rIn, WImg rO, WImg rF,
                           const float* sBin, const float* sBo, const float* sBf, const long xrow, const bool xvalid,
                           const uint32_t seed_lo, const uint32_t seed_hi, const float sa, const float inv_zs, const int r, const int h,
                           const int lane, char* xchA, char* xchB, const bool next_x) {
@@ -404,8 +404,8 @@ MPG_DEV void mab_fwd_half(const MpgMab& p, f16x8* xh, f16x8* xl, f32x16& xtile, 
     V oh[KS], ol[KS];
     {
         const f32x16 Qn = proj_n<KS>(rIn, nfIn, T, xh, xl, bias_regs(sBin, T, h), lane16);
-        const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + T, xh, xl, bias_regs(sBin, NT + T, h), lane16);
-        const f32x16 Vt = proj_t<KS>(rIn, nfIn, 2 * NT + T, xh, xl, bias_lanes(sBin, 2 * NT + T, r), lane16);
+        const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + T, yh, yl, bias_regs(sBin, NT + T, h), lane16);
+        const f32x16 Vt = proj_t<KS>(rIn, nfIn, 2 * NT + T, yh, yl, bias_lanes(sBin, 2 * NT + T, r), lane16);
         V vh[2], vl[2];
         tile_frag(Vt, 0, inv_zs * sa, vh[0], vl[0]);
         tile_frag(Vt, 1, inv_zs * sa, vh[1], vl[1]);
@@ -534,10 +534,66 @@ __global__ __launch_bounds__(256) void mab_chain_fwd2_kernel(const MpgMabChain c
                 sBin[i] = (i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT])) * zs;
             __syncthreads();
             const bool nx = b + 1 < c.n;
-            if (role == 0) mab_fwd_half<0>(p, xh, xl, xtile, kneg, sIn, sO, sF, sBin, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, r, h, lane, xchA, xchB, nx);
-            else mab_fwd_half<1>(p, xh, xl, xtile, kneg, sIn, sO, sF, sBin, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, r, h, lane, xchA, xchB, nx);
+            if (role == 0) mab_fwd_half<0>(p, xh, xl, xh, xl, xtile, kneg, sIn, sO, sF, sBin, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, r, h, lane, xchA, xchB, nx);
+            else mab_fwd_half<1>(p, xh, xl, xh, xl, xtile, kneg, sIn, sO, sF, sBin, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, r, h, lane, xchA, xchB, nx);
         }
     });
+}
+
+// one block with two waves per jet, self- or cross-attention (the key / value rows y as a second set of fragments)
+template <bool CROSS>
+__global__ __launch_bounds__(256) void mab_fwd2_kernel(const MpgMab p) {
+    typedef f16x8 V;
+    constexpr int NT = 2, KS = 4;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int pair = w >> 1, role = w & 1;
+    uint32_t seed_lo = 0, seed_hi = 0;
+    if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+    const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
+    const float zs = sa * ws, inv_zs = 1.f / zs;
+    constexpr int nfIn = 3 * NT * KS, nfE = NT * KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sIn = smem;
+    char* const sO = sIn + 2 * nfIn * 1024;
+    char* const sF = sO + 2 * nfE * 1024;
+    float* const sBin = reinterpret_cast<float*>(sF + 2 * nfE * 1024);
+    float* const sBo = sBin + 96 * NT;
+    float* const sBf = sBo + 32 * NT;
+    char* const xchA = reinterpret_cast<char*>(sBf + 32 * NT) + pair * 2 * MAB_XCH;
+    char* const xchB = xchA + MAB_XCH;
+    const int npair = blockDim.x >> 7;
+    const long jet = (long)blockIdx.x * npair + pair;
+    const bool live = jet < p.B;
+    const long jc = live ? jet : (long)p.B - 1;
+    const long xrow = jc * p.L + min(r, p.L - 1), yrow = jc * p.S + min(r, p.S - 1);
+    const bool xvalid = live && r < p.L;
+    V xh[KS], xl[KS], yh_[CROSS ? KS : 1], yl_[CROSS ? KS : 1];
+    f32x16 xtile;
+    {
+        f32x16 xt[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p.x, p.ldx, xrow, t, h);
+        tiles_to_frags<NT>(xt, sa, xh, xl);
+        xtile = role == 0 ? xt[0] : xt[1];
+        if constexpr (CROSS) {
+            f32x16 yt[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) yt[t] = rows_to_tile(p.y, p.ldy, yrow, t, h);
+            tiles_to_frags<NT>(yt, sa, yh_, yl_);
+        }
+    }
+    const V* yh = CROSS ? yh_ : xh;
+    const V* yl = CROSS ? yl_ : xl;
+    const f32x16 kneg = key_mask_regs(p.ignore, jc, p.S, h);
+    mab_fill(sIn, p.Win, 2 * nfIn * 1024);
+    mab_fill(sO, p.Wo, 2 * nfE * 1024);
+    mab_fill(sF, p.Wf, 2 * nfE * 1024);
+    for (int i = threadIdx.x; i < 160 * NT; i += blockDim.x)
+        sBin[i] = (i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT])) * zs;
+    __syncthreads();
+    if (role == 0) mab_fwd_half<0>(p, xh, xl, yh, yl, xtile, kneg, sIn, sO, sF, sBin, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, r, h, lane, xchA, xchB, false);
+    else mab_fwd_half<1>(p, xh, xl, yh, yl, xtile, kneg, sIn, sO, sF, sBin, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, r, h, lane, xchA, xchB, false);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -775,6 +831,252 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
 #endif
 }
 
+// ---- The backward with TWO WAVES PER JET (E = 64), the split of mab_fwd_half: wave T owns tile T of du, dz, dza, the two heads
+// of tile T in the attention (q, k, v, P recomputed for those heads only) and tile T of dx (dy).  Three meetings in LDS: du and
+// dza are B fragments of products over ALL features, and the input gradient contracts over all of dq | dk | dv.  Each wave
+// adds the terms of its dx tile in the order the one-wave kernel does, so the two give the same bits.  The weight images fill
+// the LDS (144 of 160 KiB), so the exchange buffers are the images nobody needs any more, each behind one more barrier:
+//     du  -> Wf   (free once every wave has recomputed u)         dza -> WfT (free once every wave has dz)
+//     dq | dk | dv -> Win (free once every wave is through the attention)
+template <int T, typename V>
+MPG_DEV void acc_wt1(WImg rT, int nfragT, int KST, int ks0, const V* fh, const V* fl, f32x16& acc, int lane16) {
+    static_for<0, 2>([&](auto sc) {
+        MPG_CI(s, sc);
+        const V wh = mab_wfrag<V>(rT, T * KST + ks0 + s, lane16), wl = mab_wfrag<V>(rT, nfragT + T * KST + ks0 + s, lane16);
+        acc = mfma3(wh, wl, fh[s], fl[s], acc);
+    });
+}
+
+template <int T, bool CROSS>
+MPG_DEV void mab_bwd2_body(const MpgMab& p) {
+    typedef f16x8 VF;
+    typedef bf16x8 VB;
+    constexpr int NT = 2, KS = 4, O = 1 - T;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5, lane16 = lane * 16, pair = w >> 1;
+    uint32_t seed_lo = 0, seed_hi = 0;
+    if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+    const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
+    const float zs = sa * ws, inv_zs = 1.f / zs, sc2 = 1.44269504088896341f / (sa * sa);
+    constexpr int nfIn = 3 * NT * KS, nfE = NT * KS, nfInT = NT * 3 * KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sIn = smem;
+    char* const sF = sIn + 2 * nfIn * 1024;
+    char* const sInT = sF + 2 * nfE * 1024;
+    char* const sOT = sInT + 2 * nfInT * 1024;
+    char* const sFT = sOT + 2 * nfE * 1024;
+    const int npair = blockDim.x >> 7;
+    const long jet_raw = (long)blockIdx.x * npair + pair;
+    const bool live = jet_raw < p.B;                   // (a pair without a jet goes through the motions: fills and barriers)
+    const long jet = live ? jet_raw : (long)p.B - 1;
+    const long xrow = jet * p.L + min(r, p.L - 1), yrow = jet * p.S + min(r, p.S - 1);
+    f32x16 dzf = rows_to_tile(p.dout, p.lddout, xrow, T, h), zt[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) zt[t] = rows_to_tile(p.save_z, p.E, xrow, t, h);
+    mab_fill(sIn, p.Win, 2 * nfIn * 1024);
+    mab_fill(sF, p.Wf, 2 * nfE * 1024);
+    mab_fill(sInT, p.WinT, 2 * nfInT * 1024);
+    mab_fill(sOT, p.WoT, 2 * nfE * 1024);
+    mab_fill(sFT, p.WfT, 2 * nfE * 1024);
+    float* const sBin = reinterpret_cast<float*>(sFT + 2 * nfE * 1024);
+    float* const sBf = sBin + 96 * NT;
+    for (int i = threadIdx.x; i < 128 * NT; i += blockDim.x) sBin[i] = (i < 96 * NT ? p.bin[i] : p.bf[i - 96 * NT]) * zs;
+    __syncthreads();
+    const WImg rIn = sIn, rF = sF, rInT = sInT, rOT = sOT, rFT = sFT;
+    // exchange slots of 1 KiB: [k-step or fragment index][hi | lo][lane]
+    auto put = [&](char* base, int slot, const VB& hi, const VB& lo) {
+        reinterpret_cast<VB*>(base)[(slot * 2 + 0) * 64 + lane] = hi;
+        reinterpret_cast<VB*>(base)[(slot * 2 + 1) * 64 + lane] = lo;
+    };
+    auto get = [&](const char* base, int slot, VB& hi, VB& lo) {
+        hi = reinterpret_cast<const VB*>(base)[(slot * 2 + 0) * 64 + lane];
+        lo = reinterpret_cast<const VB*>(base)[(slot * 2 + 1) * 64 + lane];
+    };
+    const bool xvalid = live && r < p.L, yvalid = live && r < p.S;
+    const float xlive = r < p.L ? 1.f : 0.f;
+    const f32x16 kneg = key_mask_regs(p.ignore, jet, p.S, h);
+    bool key_off = !(r < p.S);
+    if (p.ignore != nullptr) key_off = key_off || p.ignore[jet * p.S + min(r, p.S - 1)] != 0.f;
+    VF xh[KS], xl[KS], yh_[CROSS ? KS : 1], yl_[CROSS ? KS : 1];
+    {
+        f32x16 xt[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p.x, p.ldx, xrow, t, h);
+        tiles_to_frags<NT>(xt, sa, xh, xl);
+        if constexpr (CROSS) {
+            f32x16 yt[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) yt[t] = rows_to_tile(p.y, p.ldy, yrow, t, h);
+            tiles_to_frags<NT>(yt, sa, yh_, yl_);
+        }
+    }
+    const VF* yh = CROSS ? yh_ : xh;
+    const VF* yl = CROSS ? yl_ : xl;
+
+    // ---- feed-forward half, tile T
+    VB dzah[KS], dzal[KS];
+    f32x16 dxa;
+    {
+        VF zh[KS], zl[KS];
+        tiles_to_frags<NT>(zt, sa, zh, zl);
+        VB duh[KS], dul[KS];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dzf[i] *= xlive;
+        drop_tile(dzf, seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, T, h, p.thr_mab, p.sc_mab);
+        const f32x16 u = proj_n<KS>(rF, nfE, T, zh, zl, bias_regs(sBf, T, h), lane16);
+        f32x16 du;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) du[i] = dzf[i] * ((p.ff_act && !(u[i] > 0.f)) ? p.alpha : 1.f);
+        drop_tile(du, seed_lo, seed_hi, p.tag + 1, (uint32_t)xrow, T, h, p.thr_ff, p.sc_ff);
+        if (p.du != nullptr && xvalid) tile_to_rows(p.du, p.E, xrow, T, h, du, 1.f);
+        tile_frag(du, 0, 1.f, duh[2 * T], dul[2 * T]);
+        tile_frag(du, 1, 1.f, duh[2 * T + 1], dul[2 * T + 1]);
+        __syncthreads();                               // every wave has its u: Wf's image is dead
+        char* const x1 = sF + pair * (KS * 2048);
+        put(x1, 2 * T, duh[2 * T], dul[2 * T]);
+        put(x1, 2 * T + 1, duh[2 * T + 1], dul[2 * T + 1]);
+        __syncthreads();
+        get(x1, 2 * O, duh[2 * O], dul[2 * O]);
+        get(x1, 2 * O + 1, duh[2 * O + 1], dul[2 * O + 1]);
+        f32x16 dz = proj_n<KS>(rFT, nfE, T, duh, dul, dzf, lane16);
+        drop_tile(dz, seed_lo, seed_hi, p.tag + 0, (uint32_t)xrow, T, h, p.thr_mab, p.sc_mab);
+        if (p.dza != nullptr && xvalid) tile_to_rows(p.dza, p.E, xrow, T, h, dz, 1.f);
+        tile_frag(dz, 0, 1.f, dzah[2 * T], dzal[2 * T]);
+        tile_frag(dz, 1, 1.f, dzah[2 * T + 1], dzal[2 * T + 1]);
+        dxa = dz;
+        __syncthreads();                               // every wave has its dz: WfT's image is dead
+        char* const x2 = sFT + pair * (KS * 2048);
+        put(x2, 2 * T, dzah[2 * T], dzal[2 * T]);
+        put(x2, 2 * T + 1, dzah[2 * T + 1], dzal[2 * T + 1]);
+        __syncthreads();
+        get(x2, 2 * O, dzah[2 * O], dzal[2 * O]);
+        get(x2, 2 * O + 1, dzah[2 * O + 1], dzal[2 * O + 1]);
+    }
+    f32x16 dya = zero16();
+
+    // ---- the attention of heads 2T, 2T + 1 (mab_bwd_kernel's tile loop body with t = T)
+    VB gq_h[NT][2], gq_l[NT][2], gk_h[NT][2], gk_l[NT][2], gv_h[NT][2], gv_l[NT][2];
+    {
+        constexpr int t = T;
+        const f32x16 dOn = proj_n<KS>(rOT, nfE, t, dzah, dzal, zero16(), lane16);
+        const f32x16 dOp = proj_t<KS>(rOT, nfE, t, dzah, dzal, zero16(), lane16);
+        const f32x16 Qn = proj_n<KS>(rIn, nfIn, t, xh, xl, bias_regs(sBin, t, h), lane16);
+        const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(sBin, NT + t, h), lane16);
+        const f32x16 Vn = proj_n<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_regs(sBin, 2 * NT + t, h), lane16);
+        const f32x16 Qp = proj_t<KS>(rIn, nfIn, t, xh, xl, bias_lanes(sBin, t, r), lane16);
+        const f32x16 Kp = proj_t<KS>(rIn, nfIn, NT + t, yh, yl, bias_lanes(sBin, NT + t, r), lane16);
+        VB kph[2], kpl[2], qph[2], qpl[2], doph[2], dopl[2];
+        static_for<0, 2>([&](auto sc) {
+            MPG_CI(s, sc);
+            tile_frag(Kp, s, inv_zs, kph[s], kpl[s]);
+            tile_frag(Qp, s, inv_zs, qph[s], qpl[s]);
+            tile_frag(dOp, s, 1.f, doph[s], dopl[s]);
+        });
+        f32x16 dQt, dKt, dVt;
+        static_for<0, 2>([&](auto ac) {
+            MPG_CI(a, ac);
+            VF qh, ql, kh, kl;
+            tile_frag(Qn, a, inv_zs * sa * 0.25f, qh, ql);
+            tile_frag(Kn, a, inv_zs * sa, kh, kl);
+            VB vbh, vbl, dobh, dobl;
+            tile_frag(Vn, a, inv_zs, vbh, vbl);
+            tile_frag(dOn, a, 1.f, dobh, dobl);
+            f32x16 s = mfma3(kh, kl, qh, ql, zero16());
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] = s[i] * sc2 + kneg[i]; mx = fmaxf(mx, s[i]); }
+            mx = fmaxf(mx, other_half(mx));
+            float den = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] = __builtin_amdgcn_exp2f(s[i] - mx); den += s[i]; }
+            den += other_half(den);
+            const float inv_den = 1.f / den, cq = mx + __builtin_amdgcn_logf(den);
+            const f32x16 dP = mfma3(vbh, vbl, dobh, dobl, zero16());
+            float D = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] *= inv_den; D += s[i] * dP[i]; }
+            D += other_half(D);
+            f32x16 dS;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dS[i] = s[i] * (dP[i] - D) * 0.25f;
+            VB dsh[2], dsl[2];
+            tile_frag(dS, 0, 1.f, dsh[0], dsl[0]);
+            tile_frag(dS, 1, 1.f, dsh[1], dsl[1]);
+            f32x16 dq = mfma3(kph[0], kpl[0], dsh[0], dsl[0], zero16());
+            dq = mfma3(kph[1], kpl[1], dsh[1], dsl[1], dq);
+            f32x16 sT = mfma3(qh, ql, kh, kl, zero16());
+            const f32x16 dPT = mfma3(dobh, dobl, vbh, vbl, zero16());
+            f32x16 pT, dST;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * g + e, qi = 8 * g + 4 * h + e;
+                    const float c_q = __shfl(cq, qi), D_q = __shfl(D, qi);
+                    const float pr = key_off ? 0.f : __builtin_amdgcn_exp2f(sT[i] * sc2 - c_q);
+                    pT[i] = pr;
+                    dST[i] = pr * (dPT[i] - D_q) * 0.25f;
+                }
+            VB pth[2], ptl[2], dsth[2], dstl[2];
+            static_for<0, 2>([&](auto sc) {
+                MPG_CI(s2, sc);
+                tile_frag(pT, s2, 1.f, pth[s2], ptl[s2]);
+                tile_frag(dST, s2, 1.f, dsth[s2], dstl[s2]);
+            });
+            f32x16 dk = mfma3(qph[0], qpl[0], dsth[0], dstl[0], zero16());
+            dk = mfma3(qph[1], qpl[1], dsth[1], dstl[1], dk);
+            f32x16 dv = mfma3(doph[0], dopl[0], pth[0], ptl[0], zero16());
+            dv = mfma3(doph[1], dopl[1], pth[1], ptl[1], dv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dQt[8 * a + j] = dq[8 * a + j]; dKt[8 * a + j] = dk[8 * a + j]; dVt[8 * a + j] = dv[8 * a + j]; }
+        });
+        if (p.dq != nullptr && xvalid) tile_to_rows(p.dq, p.lddq, xrow, t, h, dQt, 1.f);
+        if (p.dk != nullptr && yvalid) {
+            tile_to_rows(p.dk, p.lddkv, yrow, t, h, dKt, 1.f);
+            tile_to_rows(p.dv, p.lddkv, yrow, t, h, dVt, 1.f);
+        }
+        static_for<0, 2>([&](auto sc) {
+            MPG_CI(s, sc);
+            tile_frag(dQt, s, 1.f, gq_h[T][s], gq_l[T][s]);
+            tile_frag(dKt, s, 1.f, gk_h[T][s], gk_l[T][s]);
+            tile_frag(dVt, s, 1.f, gv_h[T][s], gv_l[T][s]);
+        });
+    }
+    __syncthreads();                                   // every wave is through the attention: Win's image is dead
+    char* const x3 = sIn + pair * (12 * 2048);         // slots: [tile][q | k | v][s]
+    static_for<0, 2>([&](auto sc) {
+        MPG_CI(s, sc);
+        put(x3, (T * 3 + 0) * 2 + s, gq_h[T][s], gq_l[T][s]);
+        put(x3, (T * 3 + 1) * 2 + s, gk_h[T][s], gk_l[T][s]);
+        put(x3, (T * 3 + 2) * 2 + s, gv_h[T][s], gv_l[T][s]);
+    });
+    __syncthreads();
+    static_for<0, 2>([&](auto sc) {
+        MPG_CI(s, sc);
+        get(x3, (O * 3 + 0) * 2 + s, gq_h[O][s], gq_l[O][s]);
+        get(x3, (O * 3 + 1) * 2 + s, gk_h[O][s], gk_l[O][s]);
+        get(x3, (O * 3 + 2) * 2 + s, gv_h[O][s], gv_l[O][s]);
+    });
+    // input gradients of tile T: dx += dq Wq ; (dy or dx) += dk Wk + dv Wv, the heads' tiles in the one-wave kernel's order
+    f32x16& dkv = CROSS ? dya : dxa;
+    static_for<0, NT>([&](auto tc) {
+        MPG_CI(t, tc);
+        acc_wt1<T>(rInT, nfInT, 3 * KS, 2 * t, gq_h[t], gq_l[t], dxa, lane16);
+        acc_wt1<T>(rInT, nfInT, 3 * KS, 2 * (NT + t), gk_h[t], gk_l[t], dkv, lane16);
+        acc_wt1<T>(rInT, nfInT, 3 * KS, 2 * (2 * NT + t), gv_h[t], gv_l[t], dkv, lane16);
+    });
+    if (p.dx != nullptr && xvalid) tile_to_rows(p.dx, p.lddx, xrow, T, h, dxa, 1.f);
+    if constexpr (CROSS) {
+        if (p.dy != nullptr && yvalid) tile_to_rows(p.dy, p.lddy, yrow, T, h, dya, 1.f);
+    }
+}
+
+template <bool CROSS>
+__global__ __launch_bounds__(256) void mab_bwd2_kernel(const MpgMab p) {
+    if (((threadIdx.x >> 6) & 1) == 0) mab_bwd2_body<0, CROSS>(p);
+    else mab_bwd2_body<1, CROSS>(p);
+}
+
 int mab_check(const MpgMab* p) {
     if (p->B < 1 || p->L < 1 || p->S < 1 || p->L > 32 || p->S > 32) return -1;
     if ((p->E != 32 && p->E != 64) || p->H * 16 != p->E) return -2;
@@ -799,6 +1101,16 @@ int mab_waves(int B) {
     return B <= 256 ? 1 : (B <= 512 ? 2 : 4);
 }
 
+// E = 64: two waves per jet (mab_fwd_half, mab_bwd2_body) while the launch has fewer jets than the chip has SIMDs to give
+// each two (256 CUs x 4 / 2 = 512): a shorter chain per wave on SIMDs that would idle.  Past that every SIMD has a jet of its
+// own and the split only adds the exchanges.  MPG_MAB_SPLIT=0 keeps one wave per jet, =2 splits at any size; read at every
+// launch, so a test can hold the two forms against each other in one process (they give the same bits).
+bool mab_split(int B) {
+    const char* e = getenv("MPG_MAB_SPLIT");
+    const int mode = e == nullptr ? 1 : atoi(e);
+    return mode == 2 || (mode == 1 && B <= 512);
+}
+
 template <typename K>
 int mab_launch(K kernel, const MpgMab* p, int lds_bytes, hipStream_t st, bool one_jet_per_wave = false) {
     const int nw = mab_waves(p->B);
@@ -818,6 +1130,17 @@ extern "C" int mpg_mab_bwd(const MpgMab* p, void* stream) {
     const bool cross = p->y != p->x;
     const int NT = p->E / 32;
     const int lds = 2 * 1024 * (2 * 3 * NT * 2 * NT + 3 * NT * 2 * NT) + 4 * 128 * NT;   // Win, WinT (3E x E) + Wf, WoT, WfT (E x E) + biases
+    if (p->E == 64 && mab_split(p->B)) {
+        // two waves per jet, two jets per workgroup
+        if (cross) {
+            MPG_ENSURE_LDS((mab_bwd2_kernel<true>), lds);
+            hipLaunchKernelGGL((mab_bwd2_kernel<true>), dim3((p->B + 1) / 2), dim3(256), lds, st, *p);
+        } else {
+            MPG_ENSURE_LDS((mab_bwd2_kernel<false>), lds);
+            hipLaunchKernelGGL((mab_bwd2_kernel<false>), dim3((p->B + 1) / 2), dim3(256), lds, st, *p);
+        }
+        return (int)hipGetLastError();
+    }
     if (p->E == 64) {
         if (cross) { MPG_ENSURE_LDS((mab_bwd_kernel<2, true>), lds); return mab_launch(mab_bwd_kernel<2, true>, p, lds, st, true); }
         MPG_ENSURE_LDS((mab_bwd_kernel<2, false>), lds);
@@ -833,6 +1156,17 @@ extern "C" int mpg_mab_fwd(const MpgMab* p, void* stream) {
     const bool cross = p->y != p->x;
     const int NT = p->E / 32;
     const int lds = 2 * 1024 * (3 * NT * 2 * NT + 2 * NT * 2 * NT) + 4 * 160 * NT;   // Win + Wo, Wf + biases
+    if (p->E == 64 && mab_split(p->B)) {
+        const int lds2 = lds + 2 * 2 * MAB_XCH;
+        if (cross) {
+            MPG_ENSURE_LDS((mab_fwd2_kernel<true>), lds2);
+            hipLaunchKernelGGL((mab_fwd2_kernel<true>), dim3((p->B + 1) / 2), dim3(256), lds2, st, *p);
+        } else {
+            MPG_ENSURE_LDS((mab_fwd2_kernel<false>), lds2);
+            hipLaunchKernelGGL((mab_fwd2_kernel<false>), dim3((p->B + 1) / 2), dim3(256), lds2, st, *p);
+        }
+        return (int)hipGetLastError();
+    }
     if (p->E == 64) {
         if (cross) { MPG_ENSURE_LDS((mab_fwd_kernel<2, true>), lds); return mab_launch(mab_fwd_kernel<2, true>, p, lds, st); }
         MPG_ENSURE_LDS((mab_fwd_kernel<2, false>), lds);
@@ -859,8 +1193,7 @@ extern "C" int mpg_mab_chain_fwd(const MpgMabChain* c, void* stream) {
     const int NT = p0.E / 32;
     const int lds = 2 * 1024 * (3 * NT * 2 * NT + 2 * NT * 2 * NT) + 4 * 160 * NT;
     hipStream_t st = (hipStream_t)stream;
-    static const int split = getenv("MPG_MAB_SPLIT") ? atoi(getenv("MPG_MAB_SPLIT")) : 1;   // (experiments: 0 = one wave per jet)
-    if (p0.E == 64 && split) {
+    if (p0.E == 64 && mab_split(p0.B)) {
         // two waves per jet, two jets per workgroup
         const int lds2 = lds + 2 * 2 * MAB_XCH;
         MPG_ENSURE_LDS(mab_chain_fwd2_kernel, lds2);

@@ -231,3 +231,52 @@ def test_sab_chain_is_bit_identical_to_block_by_block(which, B, p_drop):
     assert na.count("mpg_mab_bwd") == nb.count("mpg_mab_bwd") == nsab + extra
     for k in a:
         assert torch.equal(a[k], b_[k]), (k, float((a[k] - b_[k]).abs().max()))
+
+
+@pytest.mark.parametrize("which,B,p_drop", [("G", 63, 0.3), ("D", 64, 0.5), ("D", 511, 0.0), ("G", 700, 0.2)])
+def test_two_waves_per_jet_give_the_bits_of_one(which, B, p_drop):
+    """E = 64 blocks run with two waves per jet (mab.hip: mab_fwd_half / mab_bwd2_body -- each wave owns one feature tile
+    and its two heads; fragments cross in LDS): forward, chain, cross-attention pooling block and every backward against the
+    one-wave kernels (MPG_MAB_SPLIT=0) bit for bit, odd jet counts (a pair without a jet) and, forced (=2), past the size
+    the launcher stops splitting at."""
+    import itertools, os
+    from mpgan_amd import ops, train as mtrain
+    dev = torch.device("cuda:0")
+    N = 30
+    torch.manual_seed(11)
+    G, D = mtrain.default_gapt(N, disc_dropout=p_drop, gen_dropout=p_drop)
+    net = G if which == "G" else D
+    net.train()
+    rs = np.random.RandomState(5)
+    labels = torch.from_numpy(rs.randint(3, N + 1, size=(B, 1)) / N).float().to(dev)
+    if which == "G":
+        xin = torch.from_numpy(rs.normal(0, 0.2, size=(B, N, 64))).float().to(dev)
+    else:
+        from oracle.train_ref import synthetic_batch
+        xin = synthetic_batch(B, N, seed=5)[0].to(dev)
+    net(xin, labels)
+
+    def run(mode, chain):
+        os.environ["MPG_MAB_SPLIT"] = mode
+        os.environ["MPG_MAB_CHAIN"] = chain
+        st = ops.dev_state(dev)
+        st.tags = itertools.count(41)
+        ops.set_seed(123, dev)
+        net.zero_grad()
+        x = xin.clone().requires_grad_(True)
+        y = net(x, labels)
+        (y * y).sum().backward()
+        res = {"y": y.detach().clone(), "dx": x.grad.clone()}
+        res.update({k: q.grad.clone() for k, q in net.named_parameters() if q.grad is not None})
+        return res
+
+    try:
+        one = run("0", "1")
+        for mode, chain in (("2", "1"), ("2", "0"), ("1", "1")):
+            two = run(mode, chain)
+            for k in one:
+                assert torch.equal(one[k], two[k]), (mode, chain, k, float((one[k] - two[k]).abs().max()))
+    finally:
+        os.environ.pop("MPG_MAB_SPLIT", None)
+        os.environ.pop("MPG_MAB_CHAIN", None)
+    assert float(one["dx"].abs().max()) > 0
