@@ -25,8 +25,10 @@
 #ifdef MPG_MABSTAMP  // diagnostic build (tools/mab_stamps.py): s_memtime at the phase boundaries, the waves of workgroup 0
 __device__ unsigned long long g_mab_stamps[2 * 4 * 8];   // [forward | backward][wave][stamp]
 #define MAB_STAMP(i) do { mab_st[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MAB_STAMPP(i) do { if (mab_st != nullptr) mab_st[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define MAB_STAMP(i) do {} while (0)
+#define MAB_STAMPP(i) do {} while (0)
 #endif
 
 namespace {
@@ -42,12 +44,23 @@ template <typename V>
 MPG_DEV V mab_wfrag(WImg w, int frag, int lane16) {
     return *reinterpret_cast<const V*>(w + frag * 1024 + lane16);
 }
-// (LDS-DMA: 1 KiB per wave-instruction straight into LDS, no register staging, all of a wave's pieces in flight at once)
+// (LDS-DMA: 1 KiB per wave-instruction straight into LDS, no register staging, all of a wave's pieces in flight at once.
+// Every workgroup of a launch wants the same image at the same moment; walking it from the same end they would all stand
+// at the same few L2 channels, so each starts at a piece of its own; -DMPG_MAB_NOROT builds the A/B.)
 MPG_DEV void mab_fill(char* dst, const void* src, int bytes) {
     const int wave = threadIdx.x >> 6, nwav = blockDim.x >> 6, lane = threadIdx.x & 63;
-    for (int c = wave; c < bytes / 1024; c += nwav)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(src) + c * 1024 + lane * 16),
-                                         (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
+    const int n = bytes / 1024;
+#ifdef MPG_MAB_NOROT
+    const int rot = 0;
+#else
+    const int rot = ((int)(blockIdx.x >> 3) * 5) % n;      // (workgroups 8 apart share an XCD and its L2)
+#endif
+    for (int c = wave; c < n; c += nwav) {
+        int cc = c + rot;
+        cc = cc >= n ? cc - n : cc;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(src) + cc * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(dst + cc * 1024), 16, 0, 0);
+    }
 }
 
 // rows of a [*, E] matrix as B (or A) fragments: k-step ks, element j of lane half h = feature 16 ks + 8 (j >> 2) + 4 h + (j & 3)
@@ -158,19 +171,32 @@ MPG_DEV void drop_tile(f32x16& t, uint32_t seed_lo, uint32_t seed_hi, uint32_t t
     }
 }
 
-// additive key mask for the registers of a score tile with KEYS in registers: register 4g+e = key 8g + 4h + e
-MPG_DEV f32x16 key_mask_regs(const float* ignore, long jet, int S, int h) {
+// additive key mask for the registers of a score tile with KEYS in registers: register 4g+e = key 8g + 4h + e.  In two halves,
+// so that the loads can be issued ahead of a weight fill and the selects run behind it, and WITHOUT a branch on the pointer:
+// tested per element, each load sat in a block of its own behind an s_waitcnt vmcnt(0) -- sixteen round trips to memory in
+// a row at the head of every kernel; tested once, the join still waited for all of them before the fill was issued.  With no
+// mask the sixteen loads read `safe` (any 32 readable floats: the caller passes its x rows) and the values are not looked at.
+struct KeyIgn { float v[16]; bool on; };
+MPG_DEV KeyIgn key_mask_load(const float* ignore, const float* safe, long jet, int S, int h) {
+    KeyIgn k;
+    k.on = ignore != nullptr;
+    const float* const row = k.on ? ignore + jet * S : safe;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) k.v[4 * g + e] = row[min(8 * g + 4 * h + e, S - 1)];
+    return k;
+}
+MPG_DEV f32x16 key_mask_from(const KeyIgn& k, int S, int h) {
     f32x16 t;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int key = 8 * g + 4 * h + e;
-            bool off = key >= S;
-            if (ignore != nullptr) off = off || ignore[jet * S + min(key, S - 1)] != 0.f;
-            t[4 * g + e] = off ? -INFINITY : 0.f;
-        }
+        for (int e = 0; e < 4; ++e) t[4 * g + e] = (8 * g + 4 * h + e >= S || (k.on && k.v[4 * g + e] != 0.f)) ? -INFINITY : 0.f;
     return t;
+}
+MPG_DEV f32x16 key_mask_regs(const float* ignore, const float* safe, long jet, int S, int h) {
+    return key_mask_from(key_mask_load(ignore, safe, jet, S, h), S, h);
 }
 
 struct MabScales { float sa, zs, inv_zs; };
@@ -280,8 +306,9 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
     unsigned long long* const mab_stp = nullptr;
 #endif
     MAB_STAMP(0);
-    uint32_t seed_lo = 0, seed_hi = 0;
-    if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+    // (no branch on the pointer: behind one, the wave waits for the seed before it issues its first load)
+    const uint64_t sd = *(p.seed != nullptr ? p.seed : reinterpret_cast<const uint64_t*>(p.x));
+    const uint32_t seed_lo = p.seed != nullptr ? (uint32_t)sd : 0u, seed_hi = p.seed != nullptr ? (uint32_t)(sd >> 32) : 0u;
     const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
     const float zs = sa * ws, inv_zs = 1.f / zs;
     constexpr int nfIn = 3 * NT * KS, nfE = NT * KS;
@@ -305,7 +332,7 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) yt[t] = rows_to_tile(p.y, p.ldy, yr, t, h);
         }
-        kneg = key_mask_regs(p.ignore, jet, p.S, h);
+        kneg = key_mask_regs(p.ignore, p.x, jet, p.S, h);
     };
     load_rows(min(jet0, (long)p.B - 1));
     mab_fill(sIn, p.Win, 2 * nfIn * 1024);
@@ -342,8 +369,9 @@ __global__ __launch_bounds__(256) void mab_chain_fwd_kernel(const MpgMabChain c)
     const MpgMab& p0 = c.blk[0];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5, lane16 = lane * 16;
-    uint32_t seed_lo = 0, seed_hi = 0;
-    if (p0.seed != nullptr) { const uint64_t sd = *p0.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+    // (no branch on the pointer: behind one, the wave waits for the seed before it issues its first load)
+    const uint64_t sd = *(p0.seed != nullptr ? p0.seed : reinterpret_cast<const uint64_t*>(p0.x));
+    const uint32_t seed_lo = p0.seed != nullptr ? (uint32_t)sd : 0u, seed_hi = p0.seed != nullptr ? (uint32_t)(sd >> 32) : 0u;
     const float sa = p0.ascale > 0.f ? p0.ascale : 1.f, ws = p0.wscale > 0.f ? p0.wscale : 1.f;
     const float zs = sa * ws, inv_zs = 1.f / zs;
     constexpr int nfIn = 3 * NT * KS, nfE = NT * KS;
@@ -363,7 +391,7 @@ __global__ __launch_bounds__(256) void mab_chain_fwd_kernel(const MpgMabChain c)
     f32x16 xt[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p0.x, p0.ldx, xrow, t, h);
-    const f32x16 kneg = key_mask_regs(p0.ignore, jc, p0.S, h);
+    const f32x16 kneg = key_mask_regs(p0.ignore, p0.x, jc, p0.S, h);
     static_for<0, MPG_MAB_CHAIN_MAX>([&](auto bc) {     // (compile-time index: a run-time one would move the argument block to scratch)
         MPG_CI(b, bc);
         if (b < c.n) {
@@ -393,7 +421,7 @@ template <int T>
 MPG_DEV void mab_fwd_half(const MpgMab& p, f16x8* xh, f16x8* xl, const f16x8* yh, const f16x8* yl, f32x16& xtile, const f32x16& kneg, WImg rIn, WImg rO, WImg rF,
                           const float* sBin, const float* sBo, const float* sBf, const long xrow, const bool xvalid,
                           const uint32_t seed_lo, const uint32_t seed_hi, const float sa, const float inv_zs, const int r, const int h,
-                          const int lane, char* xchA, char* xchB, const bool next_x) {
+                          const int lane, char* xchA, char* xchB, const bool next_x, unsigned long long* mab_st = nullptr) {
     typedef f16x8 V;
     constexpr int NT = 2, KS = 4, nfIn = 3 * NT * KS, nfE = NT * KS, O = 1 - T;
     const int lane16 = lane * 16;
@@ -409,6 +437,7 @@ MPG_DEV void mab_fwd_half(const MpgMab& p, f16x8* xh, f16x8* xl, const f16x8* yh
         V vh[2], vl[2];
         tile_frag(Vt, 0, inv_zs * sa, vh[0], vl[0]);
         tile_frag(Vt, 1, inv_zs * sa, vh[1], vl[1]);
+        MAB_STAMPP(2);
         f32x16 Ot;
         static_for<0, 2>([&](auto ac) {
             MPG_CI(a, ac);
@@ -438,11 +467,13 @@ MPG_DEV void mab_fwd_half(const MpgMab& p, f16x8* xh, f16x8* xl, const f16x8* yh
         tile_frag(Ot, 0, 1.f / MAB_SP, oh[2 * T], ol[2 * T]);
         tile_frag(Ot, 1, 1.f / MAB_SP, oh[2 * T + 1], ol[2 * T + 1]);
     }
+    MAB_STAMPP(3);
     put(fa, 2 * T, oh[2 * T], ol[2 * T]);
     put(fa, 2 * T + 1, oh[2 * T + 1], ol[2 * T + 1]);
     __syncthreads();
     get(fa, 2 * O, oh[2 * O], ol[2 * O]);
     get(fa, 2 * O + 1, oh[2 * O + 1], ol[2 * O + 1]);
+    MAB_STAMPP(4);
     // za = x + o Wo' + bo ; z = dropout(za): tile T
     f32x16 z;
     V zh[KS], zl[KS];
@@ -455,11 +486,13 @@ MPG_DEV void mab_fwd_half(const MpgMab& p, f16x8* xh, f16x8* xl, const f16x8* yh
         tile_frag(z, 0, sa, zh[2 * T], zl[2 * T]);
         tile_frag(z, 1, sa, zh[2 * T + 1], zl[2 * T + 1]);
     }
+    MAB_STAMPP(5);
     put(fb, 2 * T, zh[2 * T], zl[2 * T]);
     put(fb, 2 * T + 1, zh[2 * T + 1], zl[2 * T + 1]);
     __syncthreads();
     get(fb, 2 * O, zh[2 * O], zl[2 * O]);
     get(fb, 2 * O + 1, zh[2 * O + 1], zl[2 * O + 1]);
+    MAB_STAMPP(6);
     // out = dropout(z + dropout_ff(LeakyReLU(z Wf' + bf))): tile T
     f32x16 u = proj_n<KS>(rF, nfE, T, zh, zl, bias_regs(sBf, T, h), lane16);
 #pragma unroll
@@ -473,6 +506,7 @@ MPG_DEV void mab_fwd_half(const MpgMab& p, f16x8* xh, f16x8* xl, const f16x8* yh
     drop_tile(u, seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, T, h, p.thr_mab, p.sc_mab);
     if (xvalid) tile_to_rows(p.out, p.ldo, xrow, T, h, u, 1.f);
     xtile = u;
+    MAB_STAMPP(7);
     if (next_x) {   // the next block's x fragments: own k-steps from the registers, the partner's through the first buffer
         tile_frag(u, 0, sa, xh[2 * T], xl[2 * T]);
         tile_frag(u, 1, sa, xh[2 * T + 1], xl[2 * T + 1]);
@@ -492,8 +526,9 @@ __global__ __launch_bounds__(256) void mab_chain_fwd2_kernel(const MpgMabChain c
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int pair = w >> 1, role = w & 1;
-    uint32_t seed_lo = 0, seed_hi = 0;
-    if (p0.seed != nullptr) { const uint64_t sd = *p0.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+    // (no branch on the pointer: behind one, the wave waits for the seed before it issues its first load)
+    const uint64_t sd = *(p0.seed != nullptr ? p0.seed : reinterpret_cast<const uint64_t*>(p0.x));
+    const uint32_t seed_lo = p0.seed != nullptr ? (uint32_t)sd : 0u, seed_hi = p0.seed != nullptr ? (uint32_t)(sd >> 32) : 0u;
     const float sa = p0.ascale > 0.f ? p0.ascale : 1.f, ws = p0.wscale > 0.f ? p0.wscale : 1.f;
     const float zs = sa * ws, inv_zs = 1.f / zs;
     constexpr int nfIn = 3 * NT * KS, nfE = NT * KS;
@@ -512,16 +547,14 @@ __global__ __launch_bounds__(256) void mab_chain_fwd2_kernel(const MpgMabChain c
     const long jc = live ? jet : (long)p0.B - 1;
     const long xrow = jc * p0.L + min(r, p0.L - 1);
     const bool xvalid = live && r < p0.L;
+    // the jet's rows and key mask are REQUESTED before the first weight fill (a fill takes the CU ~2,500 clk to issue, at 32 B
+    // a clock, and loads return in issue order) and converted behind it, while the images land
     V xh[KS], xl[KS];
-    f32x16 xtile;
-    {
-        f32x16 xt[NT];
+    f32x16 xtile, kneg;
+    f32x16 xt[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p0.x, p0.ldx, xrow, t, h);
-        tiles_to_frags<NT>(xt, sa, xh, xl);
-        xtile = role == 0 ? xt[0] : xt[1];
-    }
-    const f32x16 kneg = key_mask_regs(p0.ignore, jc, p0.S, h);
+    for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p0.x, p0.ldx, xrow, t, h);
+    const KeyIgn kig = key_mask_load(p0.ignore, p0.x, jc, p0.S, h);
     static_for<0, MPG_MAB_CHAIN_MAX>([&](auto bc) {
         MPG_CI(b, bc);
         if (b < c.n) {
@@ -532,6 +565,11 @@ __global__ __launch_bounds__(256) void mab_chain_fwd2_kernel(const MpgMabChain c
             mab_fill(sF, p.Wf, 2 * nfE * 1024);
             for (int i = threadIdx.x; i < 160 * NT; i += blockDim.x)
                 sBin[i] = (i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT])) * zs;
+            if (b == 0) {
+                tiles_to_frags<NT>(xt, sa, xh, xl);
+                xtile = role == 0 ? xt[0] : xt[1];
+                kneg = key_mask_from(kig, p0.S, h);
+            }
             __syncthreads();
             const bool nx = b + 1 < c.n;
             if (role == 0) mab_fwd_half<0>(p, xh, xl, xh, xl, xtile, kneg, sIn, sO, sF, sBin, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, r, h, lane, xchA, xchB, nx);
@@ -548,8 +586,16 @@ __global__ __launch_bounds__(256) void mab_fwd2_kernel(const MpgMab p) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int pair = w >> 1, role = w & 1;
-    uint32_t seed_lo = 0, seed_hi = 0;
-    if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+#ifdef MPG_MABSTAMP
+    unsigned long long mab_stv[8] = {};
+    unsigned long long* const mab_st = mab_stv;
+#else
+    unsigned long long* const mab_st = nullptr;
+#endif
+    MAB_STAMPP(0);
+    // (no branch on the pointer: behind one, the wave waits for the seed before it issues its first load)
+    const uint64_t sd = *(p.seed != nullptr ? p.seed : reinterpret_cast<const uint64_t*>(p.x));
+    const uint32_t seed_lo = p.seed != nullptr ? (uint32_t)sd : 0u, seed_hi = p.seed != nullptr ? (uint32_t)(sd >> 32) : 0u;
     const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
     const float zs = sa * ws, inv_zs = 1.f / zs;
     constexpr int nfIn = 3 * NT * KS, nfE = NT * KS;
@@ -568,32 +614,36 @@ __global__ __launch_bounds__(256) void mab_fwd2_kernel(const MpgMab p) {
     const long jc = live ? jet : (long)p.B - 1;
     const long xrow = jc * p.L + min(r, p.L - 1), yrow = jc * p.S + min(r, p.S - 1);
     const bool xvalid = live && r < p.L;
+    // rows and key mask requested ahead of the weight fill, converted behind it (see mab_chain_fwd2_kernel)
     V xh[KS], xl[KS], yh_[CROSS ? KS : 1], yl_[CROSS ? KS : 1];
     f32x16 xtile;
-    {
-        f32x16 xt[NT];
+    f32x16 xt[NT], yt[CROSS ? NT : 1];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p.x, p.ldx, xrow, t, h);
-        tiles_to_frags<NT>(xt, sa, xh, xl);
-        xtile = role == 0 ? xt[0] : xt[1];
-        if constexpr (CROSS) {
-            f32x16 yt[NT];
+    for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p.x, p.ldx, xrow, t, h);
+    if constexpr (CROSS) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) yt[t] = rows_to_tile(p.y, p.ldy, yrow, t, h);
-            tiles_to_frags<NT>(yt, sa, yh_, yl_);
-        }
+        for (int t = 0; t < NT; ++t) yt[t] = rows_to_tile(p.y, p.ldy, yrow, t, h);
     }
-    const V* yh = CROSS ? yh_ : xh;
-    const V* yl = CROSS ? yl_ : xl;
-    const f32x16 kneg = key_mask_regs(p.ignore, jc, p.S, h);
+    const KeyIgn kig = key_mask_load(p.ignore, p.x, jc, p.S, h);
     mab_fill(sIn, p.Win, 2 * nfIn * 1024);
     mab_fill(sO, p.Wo, 2 * nfE * 1024);
     mab_fill(sF, p.Wf, 2 * nfE * 1024);
     for (int i = threadIdx.x; i < 160 * NT; i += blockDim.x)
         sBin[i] = (i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT])) * zs;
+    tiles_to_frags<NT>(xt, sa, xh, xl);
+    xtile = role == 0 ? xt[0] : xt[1];
+    if constexpr (CROSS) tiles_to_frags<NT>(yt, sa, yh_, yl_);
+    const V* yh = CROSS ? yh_ : xh;
+    const V* yl = CROSS ? yl_ : xl;
+    const f32x16 kneg = key_mask_from(kig, p.S, h);
     __syncthreads();
-    if (role == 0) mab_fwd_half<0>(p, xh, xl, yh, yl, xtile, kneg, sIn, sO, sF, sBin, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, r, h, lane, xchA, xchB, false);
-    else mab_fwd_half<1>(p, xh, xl, yh, yl, xtile, kneg, sIn, sO, sF, sBin, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, r, h, lane, xchA, xchB, false);
+    MAB_STAMPP(1);
+    if (role == 0) mab_fwd_half<0>(p, xh, xl, yh, yl, xtile, kneg, sIn, sO, sF, sBin, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, r, h, lane, xchA, xchB, false, mab_st);
+    else mab_fwd_half<1>(p, xh, xl, yh, yl, xtile, kneg, sIn, sO, sF, sBin, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, r, h, lane, xchA, xchB, false, mab_st);
+#ifdef MPG_MABSTAMP
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) g_mab_stamps[w * 8 + i] = mab_stv[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -630,8 +680,9 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
     unsigned long long mab_st[8] = {};
 #endif
     MAB_STAMP(0);
-    uint32_t seed_lo = 0, seed_hi = 0;
-    if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+    // (no branch on the pointer: behind one, the wave waits for the seed before it issues its first load)
+    const uint64_t sd = *(p.seed != nullptr ? p.seed : reinterpret_cast<const uint64_t*>(p.x));
+    const uint32_t seed_lo = p.seed != nullptr ? (uint32_t)sd : 0u, seed_hi = p.seed != nullptr ? (uint32_t)(sd >> 32) : 0u;
     const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
     const float zs = sa * ws, inv_zs = 1.f / zs, sc2 = 1.44269504088896341f / (sa * sa);   // (scores in the base-2 domain)
     constexpr int nfIn = 3 * NT * KS, nfE = NT * KS, nfInT = NT * 3 * KS;
@@ -669,9 +720,10 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
     {
     const bool xvalid = r < p.L, yvalid = r < p.S;
     const float xlive = xvalid ? 1.f : 0.f;
-    const f32x16 kneg = key_mask_regs(p.ignore, jet, p.S, h);
-    bool key_off = !yvalid;               // this lane as a KEY (transposed tiles)
-    if (p.ignore != nullptr) key_off = key_off || p.ignore[jet * p.S + min(r, p.S - 1)] != 0.f;
+    const f32x16 kneg = key_mask_regs(p.ignore, p.x, jet, p.S, h);
+    // this lane as a KEY (transposed tiles); no branch on the pointer, as in key_mask_load
+    const float ign_r = (p.ignore != nullptr ? p.ignore + jet * p.S : p.x)[min(r, p.S - 1)];
+    const bool key_off = !yvalid || (p.ignore != nullptr && ign_r != 0.f);
     f32x16 xt[NT], yt[CROSS ? NT : 1];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -854,8 +906,13 @@ MPG_DEV void mab_bwd2_body(const MpgMab& p) {
     constexpr int NT = 2, KS = 4, O = 1 - T;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5, lane16 = lane * 16, pair = w >> 1;
-    uint32_t seed_lo = 0, seed_hi = 0;
-    if (p.seed != nullptr) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+#ifdef MPG_MABSTAMP
+    unsigned long long mab_st[8] = {};
+#endif
+    MAB_STAMP(0);
+    // (no branch on the pointer: behind one, the wave waits for the seed before it issues its first load)
+    const uint64_t sd = *(p.seed != nullptr ? p.seed : reinterpret_cast<const uint64_t*>(p.x));
+    const uint32_t seed_lo = p.seed != nullptr ? (uint32_t)sd : 0u, seed_hi = p.seed != nullptr ? (uint32_t)(sd >> 32) : 0u;
     const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
     const float zs = sa * ws, inv_zs = 1.f / zs, sc2 = 1.44269504088896341f / (sa * sa);
     constexpr int nfIn = 3 * NT * KS, nfE = NT * KS, nfInT = NT * 3 * KS;
@@ -870,9 +927,19 @@ MPG_DEV void mab_bwd2_body(const MpgMab& p) {
     const bool live = jet_raw < p.B;                   // (a pair without a jet goes through the motions: fills and barriers)
     const long jet = live ? jet_raw : (long)p.B - 1;
     const long xrow = jet * p.L + min(r, p.L - 1), yrow = jet * p.S + min(r, p.S - 1);
-    f32x16 dzf = rows_to_tile(p.dout, p.lddout, xrow, T, h), zt[NT];
+    // every row of the jet is requested ahead of the 144 KiB fill -- dout and z first, which the feed-forward half starts
+    // from -- and converted behind it
+    f32x16 dzf = rows_to_tile(p.dout, p.lddout, xrow, T, h), zt[NT], xt[NT], yt[CROSS ? NT : 1];
 #pragma unroll
     for (int t = 0; t < NT; ++t) zt[t] = rows_to_tile(p.save_z, p.E, xrow, t, h);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p.x, p.ldx, xrow, t, h);
+    if constexpr (CROSS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) yt[t] = rows_to_tile(p.y, p.ldy, yrow, t, h);
+    }
+    const KeyIgn kig = key_mask_load(p.ignore, p.x, jet, p.S, h);
+    const float ign_r = (kig.on ? p.ignore + jet * p.S : p.x)[min(r, p.S - 1)];   // this lane as a KEY (transposed tiles)
     mab_fill(sIn, p.Win, 2 * nfIn * 1024);
     mab_fill(sF, p.Wf, 2 * nfE * 1024);
     mab_fill(sInT, p.WinT, 2 * nfInT * 1024);
@@ -881,8 +948,15 @@ MPG_DEV void mab_bwd2_body(const MpgMab& p) {
     float* const sBin = reinterpret_cast<float*>(sFT + 2 * nfE * 1024);
     float* const sBf = sBin + 96 * NT;
     for (int i = threadIdx.x; i < 128 * NT; i += blockDim.x) sBin[i] = (i < 96 * NT ? p.bin[i] : p.bf[i - 96 * NT]) * zs;
+    VF xh[KS], xl[KS], yh_[CROSS ? KS : 1], yl_[CROSS ? KS : 1], zh[KS], zl[KS];
+    tiles_to_frags<NT>(zt, sa, zh, zl);
+    tiles_to_frags<NT>(xt, sa, xh, xl);
+    if constexpr (CROSS) tiles_to_frags<NT>(yt, sa, yh_, yl_);
+    const f32x16 kneg = key_mask_from(kig, p.S, h);
+    const bool key_off = !(r < p.S) || (kig.on && ign_r != 0.f);
     __syncthreads();
     const WImg rIn = sIn, rF = sF, rInT = sInT, rOT = sOT, rFT = sFT;
+    MAB_STAMP(1);
     // exchange slots of 1 KiB: [k-step or fragment index][hi | lo][lane]
     auto put = [&](char* base, int slot, const VB& hi, const VB& lo) {
         reinterpret_cast<VB*>(base)[(slot * 2 + 0) * 64 + lane] = hi;
@@ -894,22 +968,6 @@ MPG_DEV void mab_bwd2_body(const MpgMab& p) {
     };
     const bool xvalid = live && r < p.L, yvalid = live && r < p.S;
     const float xlive = r < p.L ? 1.f : 0.f;
-    const f32x16 kneg = key_mask_regs(p.ignore, jet, p.S, h);
-    bool key_off = !(r < p.S);
-    if (p.ignore != nullptr) key_off = key_off || p.ignore[jet * p.S + min(r, p.S - 1)] != 0.f;
-    VF xh[KS], xl[KS], yh_[CROSS ? KS : 1], yl_[CROSS ? KS : 1];
-    {
-        f32x16 xt[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p.x, p.ldx, xrow, t, h);
-        tiles_to_frags<NT>(xt, sa, xh, xl);
-        if constexpr (CROSS) {
-            f32x16 yt[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) yt[t] = rows_to_tile(p.y, p.ldy, yrow, t, h);
-            tiles_to_frags<NT>(yt, sa, yh_, yl_);
-        }
-    }
     const VF* yh = CROSS ? yh_ : xh;
     const VF* yl = CROSS ? yl_ : xl;
 
@@ -917,8 +975,6 @@ MPG_DEV void mab_bwd2_body(const MpgMab& p) {
     VB dzah[KS], dzal[KS];
     f32x16 dxa;
     {
-        VF zh[KS], zl[KS];
-        tiles_to_frags<NT>(zt, sa, zh, zl);
         VB duh[KS], dul[KS];
 #pragma unroll
         for (int i = 0; i < 16; ++i) dzf[i] *= xlive;
@@ -931,6 +987,7 @@ MPG_DEV void mab_bwd2_body(const MpgMab& p) {
         if (p.du != nullptr && xvalid) tile_to_rows(p.du, p.E, xrow, T, h, du, 1.f);
         tile_frag(du, 0, 1.f, duh[2 * T], dul[2 * T]);
         tile_frag(du, 1, 1.f, duh[2 * T + 1], dul[2 * T + 1]);
+        MAB_STAMP(2);
         __syncthreads();                               // every wave has its u: Wf's image is dead
         char* const x1 = sF + pair * (KS * 2048);
         put(x1, 2 * T, duh[2 * T], dul[2 * T]);
@@ -938,6 +995,7 @@ MPG_DEV void mab_bwd2_body(const MpgMab& p) {
         __syncthreads();
         get(x1, 2 * O, duh[2 * O], dul[2 * O]);
         get(x1, 2 * O + 1, duh[2 * O + 1], dul[2 * O + 1]);
+        MAB_STAMP(3);
         f32x16 dz = proj_n<KS>(rFT, nfE, T, duh, dul, dzf, lane16);
         drop_tile(dz, seed_lo, seed_hi, p.tag + 0, (uint32_t)xrow, T, h, p.thr_mab, p.sc_mab);
         if (p.dza != nullptr && xvalid) tile_to_rows(p.dza, p.E, xrow, T, h, dz, 1.f);
@@ -953,6 +1011,7 @@ MPG_DEV void mab_bwd2_body(const MpgMab& p) {
         get(x2, 2 * O + 1, dzah[2 * O + 1], dzal[2 * O + 1]);
     }
     f32x16 dya = zero16();
+    MAB_STAMP(4);
 
     // ---- the attention of heads 2T, 2T + 1 (mab_bwd_kernel's tile loop body with t = T)
     VB gq_h[NT][2], gq_l[NT][2], gk_h[NT][2], gk_l[NT][2], gv_h[NT][2], gv_l[NT][2];
@@ -1042,6 +1101,7 @@ MPG_DEV void mab_bwd2_body(const MpgMab& p) {
             tile_frag(dVt, s, 1.f, gv_h[T][s], gv_l[T][s]);
         });
     }
+    MAB_STAMP(5);
     __syncthreads();                                   // every wave is through the attention: Win's image is dead
     char* const x3 = sIn + pair * (12 * 2048);         // slots: [tile][q | k | v][s]
     static_for<0, 2>([&](auto sc) {
@@ -1057,6 +1117,7 @@ MPG_DEV void mab_bwd2_body(const MpgMab& p) {
         get(x3, (O * 3 + 1) * 2 + s, gk_h[O][s], gk_l[O][s]);
         get(x3, (O * 3 + 2) * 2 + s, gv_h[O][s], gv_l[O][s]);
     });
+    MAB_STAMP(6);
     // input gradients of tile T: dx += dq Wq ; (dy or dx) += dk Wk + dv Wv, the heads' tiles in the one-wave kernel's order
     f32x16& dkv = CROSS ? dya : dxa;
     static_for<0, NT>([&](auto tc) {
@@ -1069,6 +1130,11 @@ MPG_DEV void mab_bwd2_body(const MpgMab& p) {
     if constexpr (CROSS) {
         if (p.dy != nullptr && yvalid) tile_to_rows(p.dy, p.lddy, yrow, T, h, dya, 1.f);
     }
+    MAB_STAMP(7);
+#ifdef MPG_MABSTAMP
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) g_mab_stamps[32 + w * 8 + i] = mab_st[i];
+#endif
 }
 
 template <bool CROSS>

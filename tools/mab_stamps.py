@@ -21,11 +21,18 @@ torch.cuda.synchronize()
 lib = C.CDLL(_lib.LIBPATH)
 buf = (C.c_ulonglong * 64)()
 assert lib.mpg_debug_mab_stamps(buf) == 0
-names = ["start", "weights in LDS", "rows loaded", "attention done", "out-projection done", "stored"]
+split = os.environ.get("MPG_MAB_SPLIT", "1") != "0" and B <= 512
+if split:   # two waves per jet (mab_fwd2_kernel / mab_bwd2_kernel): waves 0, 1 = the first jet's pair
+    names = ["start", "weights in LDS", "q k v", "attention", "o exchanged", "z", "z exchanged", "stored"]
+    bnames = ["start", "weights in LDS", "du", "du exchanged", "dza exchanged", "attention", "dq dk dv exchanged", "stored"]
+    n = 8
+else:
+    names = ["start", "weights in LDS", "rows loaded", "attention done", "out-projection done", "stored"]
+    bnames = ["start", "weights in LDS", "rows loaded", "feed-forward half done", "attention + input gradients done", "stored"]
+    n = 6
 for w in range(4):
-    st = [buf[w * 8 + i] for i in range(6)]
-    print("forward  wave", w, " ".join(f"{names[i]}={st[i] - st[0]}" for i in range(1, 6) if st[i]))
-bnames = ["start", "weights in LDS", "rows loaded", "feed-forward half done", "attention + input gradients done", "stored"]
+    st = [buf[w * 8 + i] for i in range(n)]
+    print("forward  wave", w, " ".join(f"{names[i]}={st[i] - st[0]}" for i in range(1, n) if st[i]))
 for w in range(4):
-    st = [buf[32 + w * 8 + i] for i in range(6)]
-    print("backward wave", w, " ".join(f"{bnames[i]}={st[i] - st[0]}" for i in range(1, 6) if st[i]))
+    st = [buf[32 + w * 8 + i] for i in range(n)]
+    print("backward wave", w, " ".join(f"{bnames[i]}={st[i] - st[0]}" for i in range(1, n) if st[i]))
