@@ -83,6 +83,39 @@ MPG_DEV f32x16 rows_to_tile(const float* base, int ld, long row, int tile, int h
     }
     return t;
 }
+// ---- Row loads the compiler does not count.  While an LDS-DMA fill is in flight hipcc answers the first use of ANY loaded
+// register with s_waitcnt vmcnt(0): a jet's rows, requested ahead of the fill, could only be touched once the whole image had
+// landed, and their hi/lo conversion (~1,500 clk of VALU) ran behind the fill instead of under it.  Loaded by inline assembly
+// the rows are invisible to that pass; rows_wait<N> is the counted wait -- N = the vector-memory instructions this wave has
+// issued SINCE the rows (loads return in issue order) -- and ties the registers to itself so nothing reads them earlier.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+MPG_DEV f32x4 ld4_hidden(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(v) : "v"(p), "n"(OFF) : "memory");
+    return v;
+}
+// the rows of NT tiles: piece 4t + g = features 32t + 8g + 4h .. +3 of the lane's row
+template <int NT>
+MPG_DEV void rows_request(const float* base, int ld, long row, int h, f32x4* q) {
+    const float* const p = base + row * ld + 4 * h;
+    static_for<0, 4 * NT>([&](auto ic) {
+        MPG_CI(i, ic);
+        q[i] = ld4_hidden<(32 * (i / 4) + 8 * (i % 4)) * 4>(p);
+    });
+}
+template <int N>
+MPG_DEV void rows_wait(f32x4* q) {     // eight pieces
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) : "n"(N) : "memory");
+}
+MPG_DEV f32x16 pieces_tile(const f32x4* q, int t) {
+    f32x16 o;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[4 * g + e] = q[4 * t + g][e];
+    return o;
+}
 MPG_DEV void tile_to_rows(float* base, int ld, long row, int tile, int h, const f32x16& t, float scale) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -547,29 +580,37 @@ __global__ __launch_bounds__(256) void mab_chain_fwd2_kernel(const MpgMabChain c
     const long jc = live ? jet : (long)p0.B - 1;
     const long xrow = jc * p0.L + min(r, p0.L - 1);
     const bool xvalid = live && r < p0.L;
-    // the jet's rows and key mask are REQUESTED before the first weight fill (a fill takes the CU ~2,500 clk to issue, at 32 B
-    // a clock, and loads return in issue order) and converted behind it, while the images land
+    // order of issue: a block's biases and (first block) the key mask -- plain loads, used last --, the jet's rows (loads
+    // the compiler does not count: rows_request), the fill; the rows are converted UNDER the fill, which takes the CU ~2,900 clk
+    // to issue alone (tools/ubench/fill_rate.hip)
     V xh[KS], xl[KS];
     f32x16 xtile, kneg;
-    f32x16 xt[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p0.x, p0.ldx, xrow, t, h);
     const KeyIgn kig = key_mask_load(p0.ignore, p0.x, jc, p0.S, h);
+    f32x4 xq[4 * NT];
+    const int bi0 = threadIdx.x, bi1 = min((int)threadIdx.x + 256, 160 * NT - 1);
+    static_assert(NT == 2, "rows_wait counts the fill of an E = 64 block on four waves");
     static_for<0, MPG_MAB_CHAIN_MAX>([&](auto bc) {
         MPG_CI(b, bc);
         if (b < c.n) {
             const MpgMab& p = c.blk[b];
+            auto bias_at = [&](int i) { return i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT]); };
+            const float bv0 = bias_at(bi0), bv1 = bias_at(bi1);
+            if (b == 0) rows_request<NT>(p0.x, p0.ldx, xrow, h, xq);
             if (b > 0) __syncthreads();                 // every wave is done with the images of the block before
             mab_fill(sIn, p.Win, 2 * nfIn * 1024);
             mab_fill(sO, p.Wo, 2 * nfE * 1024);
             mab_fill(sF, p.Wf, 2 * nfE * 1024);
-            for (int i = threadIdx.x; i < 160 * NT; i += blockDim.x)
-                sBin[i] = (i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT])) * zs;
             if (b == 0) {
+                rows_wait<20>(xq);
+                f32x16 xt[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) xt[t] = pieces_tile(xq, t);
                 tiles_to_frags<NT>(xt, sa, xh, xl);
                 xtile = role == 0 ? xt[0] : xt[1];
-                kneg = key_mask_from(kig, p0.S, h);
             }
+            sBin[bi0] = bv0 * zs;
+            if (threadIdx.x + 256 < 160 * NT) sBin[bi1] = bv1 * zs;
+            if (b == 0) kneg = key_mask_from(kig, p0.S, h);
             __syncthreads();
             const bool nx = b + 1 < c.n;
             if (role == 0) mab_fwd_half<0>(p, xh, xl, xh, xl, xtile, kneg, sIn, sO, sF, sBin, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, r, h, lane, xchA, xchB, nx);
@@ -617,24 +658,35 @@ __global__ __launch_bounds__(256) void mab_fwd2_kernel(const MpgMab p) {
     // rows and key mask requested ahead of the weight fill, converted behind it (see mab_chain_fwd2_kernel)
     V xh[KS], xl[KS], yh_[CROSS ? KS : 1], yl_[CROSS ? KS : 1];
     f32x16 xtile;
-    f32x16 xt[NT], yt[CROSS ? NT : 1];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p.x, p.ldx, xrow, t, h);
-    if constexpr (CROSS) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) yt[t] = rows_to_tile(p.y, p.ldy, yrow, t, h);
-    }
+    // order of issue: biases and key mask (plain loads, used last), the rows (uncounted loads), the fill; then the rows are
+    // converted UNDER the fill (20 LDS-DMA instructions per wave behind them: rows_wait<20>)
+    const int bi0 = threadIdx.x, bi1 = min((int)threadIdx.x + 256, 160 * NT - 1);
+    auto bias_at = [&](int i) { return i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT]); };
+    const float bv0 = bias_at(bi0), bv1 = bias_at(bi1);
     const KeyIgn kig = key_mask_load(p.ignore, p.x, jc, p.S, h);
+    f32x4 xq[4 * NT], yq[CROSS ? 4 * NT : 1];
+    if constexpr (CROSS) rows_request<NT>(p.y, p.ldy, yrow, h, yq);
+    rows_request<NT>(p.x, p.ldx, xrow, h, xq);
+    static_assert(NT == 2, "rows_wait counts the fill of an E = 64 block on four waves");
     mab_fill(sIn, p.Win, 2 * nfIn * 1024);
     mab_fill(sO, p.Wo, 2 * nfE * 1024);
     mab_fill(sF, p.Wf, 2 * nfE * 1024);
-    for (int i = threadIdx.x; i < 160 * NT; i += blockDim.x)
-        sBin[i] = (i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT])) * zs;
+    f32x16 xt[NT], yt[CROSS ? NT : 1];
+    if constexpr (CROSS) {
+        rows_wait<20 + 4 * NT>(yq);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) yt[t] = pieces_tile(yq, t);
+        tiles_to_frags<NT>(yt, sa, yh_, yl_);
+    }
+    rows_wait<20>(xq);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) xt[t] = pieces_tile(xq, t);
     tiles_to_frags<NT>(xt, sa, xh, xl);
     xtile = role == 0 ? xt[0] : xt[1];
-    if constexpr (CROSS) tiles_to_frags<NT>(yt, sa, yh_, yl_);
     const V* yh = CROSS ? yh_ : xh;
     const V* yl = CROSS ? yl_ : xl;
+    sBin[bi0] = bv0 * zs;
+    if (threadIdx.x + 256 < 160 * NT) sBin[bi1] = bv1 * zs;
     const f32x16 kneg = key_mask_from(kig, p.S, h);
     __syncthreads();
     MAB_STAMPP(1);
