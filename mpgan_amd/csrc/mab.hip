@@ -108,6 +108,14 @@ template <int N>
 MPG_DEV void rows_wait(f32x4* q) {     // eight pieces
     asm volatile("s_waitcnt vmcnt(%8)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) : "n"(N) : "memory");
 }
+// ... and eight more pieces that were requested BEFORE a set already waited for (in-order return: they are here too); the empty
+// statement only ties the registers to this point
+MPG_DEV void rows_pin(f32x4* q) {
+    asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) : : "memory");
+}
+MPG_DEV void rows_pin4(f32x4* q) {
+    asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : : "memory");
+}
 MPG_DEV f32x16 pieces_tile(const f32x4* q, int t) {
     f32x16 o;
 #pragma unroll
@@ -979,31 +987,48 @@ MPG_DEV void mab_bwd2_body(const MpgMab& p) {
     const bool live = jet_raw < p.B;                   // (a pair without a jet goes through the motions: fills and barriers)
     const long jet = live ? jet_raw : (long)p.B - 1;
     const long xrow = jet * p.L + min(r, p.L - 1), yrow = jet * p.S + min(r, p.S - 1);
-    // every row of the jet is requested ahead of the 144 KiB fill -- dout and z first, which the feed-forward half starts
-    // from -- and converted behind it
-    f32x16 dzf = rows_to_tile(p.dout, p.lddout, xrow, T, h), zt[NT], xt[NT], yt[CROSS ? NT : 1];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) zt[t] = rows_to_tile(p.save_z, p.E, xrow, t, h);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p.x, p.ldx, xrow, t, h);
-    if constexpr (CROSS) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) yt[t] = rows_to_tile(p.y, p.ldy, yrow, t, h);
-    }
+    // order of issue: biases and key mask (plain loads, used last), every row of the jet (loads the compiler does not count:
+    // rows_request), the 144 KiB fill (36 LDS-DMA instructions per wave); the rows are converted UNDER the fill
+    float* const sBin = reinterpret_cast<float*>(sFT + 2 * nfE * 1024);
+    float* const sBf = sBin + 96 * NT;
+    static_assert(NT == 2, "rows_wait counts the fill of an E = 64 block on four waves");
+    const int bi0 = threadIdx.x;                       // 128 NT = 256 biases: one per thread
+    const float bv0 = bi0 < 96 * NT ? p.bin[bi0] : p.bf[bi0 - 96 * NT];
     const KeyIgn kig = key_mask_load(p.ignore, p.x, jet, p.S, h);
     const float ign_r = (kig.on ? p.ignore + jet * p.S : p.x)[min(r, p.S - 1)];   // this lane as a KEY (transposed tiles)
+    f32x4 dq_[4], zq[4 * NT], xq[4 * NT], yq[CROSS ? 4 * NT : 1];
+    {
+        const float* const pd = p.dout + xrow * p.lddout + 4 * h + 32 * T;
+        static_for<0, 4>([&](auto ic) { MPG_CI(i, ic); dq_[i] = ld4_hidden<8 * i * 4>(pd); });
+    }
+    rows_request<NT>(p.save_z, p.E, xrow, h, zq);
+    if constexpr (CROSS) rows_request<NT>(p.y, p.ldy, yrow, h, yq);
+    rows_request<NT>(p.x, p.ldx, xrow, h, xq);
     mab_fill(sIn, p.Win, 2 * nfIn * 1024);
     mab_fill(sF, p.Wf, 2 * nfE * 1024);
     mab_fill(sInT, p.WinT, 2 * nfInT * 1024);
     mab_fill(sOT, p.WoT, 2 * nfE * 1024);
     mab_fill(sFT, p.WfT, 2 * nfE * 1024);
-    float* const sBin = reinterpret_cast<float*>(sFT + 2 * nfE * 1024);
-    float* const sBf = sBin + 96 * NT;
-    for (int i = threadIdx.x; i < 128 * NT; i += blockDim.x) sBin[i] = (i < 96 * NT ? p.bin[i] : p.bf[i - 96 * NT]) * zs;
+    rows_wait<36>(xq);                                 // (the youngest rows: everything requested before them is here too)
+    rows_pin(zq);
+    rows_pin4(dq_);
+    if constexpr (CROSS) rows_pin(yq);
+    f32x16 dzf, zt[NT], xt[NT], yt[CROSS ? NT : 1];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dzf[4 * g + e] = dq_[g][e];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { zt[t] = pieces_tile(zq, t); xt[t] = pieces_tile(xq, t); }
+    if constexpr (CROSS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) yt[t] = pieces_tile(yq, t);
+    }
     VF xh[KS], xl[KS], yh_[CROSS ? KS : 1], yl_[CROSS ? KS : 1], zh[KS], zl[KS];
     tiles_to_frags<NT>(zt, sa, zh, zl);
     tiles_to_frags<NT>(xt, sa, xh, xl);
     if constexpr (CROSS) tiles_to_frags<NT>(yt, sa, yh_, yl_);
+    sBin[bi0] = bv0 * zs;
     const f32x16 kneg = key_mask_from(kig, p.S, h);
     const bool key_off = !(r < p.S) || (kig.on && ign_r != 0.f);
     __syncthreads();
