@@ -560,7 +560,8 @@ MPG_DEV void mab_fwd_half(const MpgMab& p, f16x8* xh, f16x8* xl, const f16x8* yh
 }
 
 // the chain of self-attention blocks with two waves per jet; a workgroup of four waves carries two jets
-__global__ __launch_bounds__(256) void mab_chain_fwd2_kernel(const MpgMabChain c) {
+template <int NW>   // waves of a workgroup: 4 (two jets) or 8 (four jets, two waves to a SIMD)
+__global__ __launch_bounds__(64 * NW) void mab_chain_fwd2_kernel(const MpgMabChain c) {
     typedef f16x8 V;
     constexpr int NT = 2, KS = 4;
     const MpgMab& p0 = c.blk[0];
@@ -595,8 +596,8 @@ __global__ __launch_bounds__(256) void mab_chain_fwd2_kernel(const MpgMabChain c
     f32x16 xtile, kneg;
     const KeyIgn kig = key_mask_load(p0.ignore, p0.x, jc, p0.S, h);
     f32x4 xq[4 * NT];
-    const int bi0 = threadIdx.x, bi1 = min((int)threadIdx.x + 256, 160 * NT - 1);
-    static_assert(NT == 2, "rows_wait counts the fill of an E = 64 block on four waves");
+    const int bi0 = min((int)threadIdx.x, 160 * NT - 1), bi1 = min((int)threadIdx.x + 256, 160 * NT - 1);
+    static_assert(NT == 2 && (NW == 4 || NW == 8), "rows_wait counts the fill of an E = 64 block on NW waves");
     static_for<0, MPG_MAB_CHAIN_MAX>([&](auto bc) {
         MPG_CI(b, bc);
         if (b < c.n) {
@@ -609,15 +610,15 @@ __global__ __launch_bounds__(256) void mab_chain_fwd2_kernel(const MpgMabChain c
             mab_fill(sO, p.Wo, 2 * nfE * 1024);
             mab_fill(sF, p.Wf, 2 * nfE * 1024);
             if (b == 0) {
-                rows_wait<20>(xq);
+                rows_wait<80 / NW>(xq);
                 f32x16 xt[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) xt[t] = pieces_tile(xq, t);
                 tiles_to_frags<NT>(xt, sa, xh, xl);
                 xtile = role == 0 ? xt[0] : xt[1];
             }
-            sBin[bi0] = bv0 * zs;
-            if (threadIdx.x + 256 < 160 * NT) sBin[bi1] = bv1 * zs;
+            if (threadIdx.x < 160 * NT) sBin[bi0] = bv0 * zs;
+            if (NW == 4 && threadIdx.x + 256 < 160 * NT) sBin[bi1] = bv1 * zs;
             if (b == 0) kneg = key_mask_from(kig, p0.S, h);
             __syncthreads();
             const bool nx = b + 1 < c.n;
@@ -628,8 +629,8 @@ __global__ __launch_bounds__(256) void mab_chain_fwd2_kernel(const MpgMabChain c
 }
 
 // one block with two waves per jet, self- or cross-attention (the key / value rows y as a second set of fragments)
-template <bool CROSS>
-__global__ __launch_bounds__(256) void mab_fwd2_kernel(const MpgMab p) {
+template <bool CROSS, int NW>
+__global__ __launch_bounds__(64 * NW) void mab_fwd2_kernel(const MpgMab p) {
     typedef f16x8 V;
     constexpr int NT = 2, KS = 4;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -668,33 +669,33 @@ __global__ __launch_bounds__(256) void mab_fwd2_kernel(const MpgMab p) {
     f32x16 xtile;
     // order of issue: biases and key mask (plain loads, used last), the rows (uncounted loads), the fill; then the rows are
     // converted UNDER the fill (20 LDS-DMA instructions per wave behind them: rows_wait<20>)
-    const int bi0 = threadIdx.x, bi1 = min((int)threadIdx.x + 256, 160 * NT - 1);
+    const int bi0 = min((int)threadIdx.x, 160 * NT - 1), bi1 = min((int)threadIdx.x + 256, 160 * NT - 1);
     auto bias_at = [&](int i) { return i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT]); };
     const float bv0 = bias_at(bi0), bv1 = bias_at(bi1);
     const KeyIgn kig = key_mask_load(p.ignore, p.x, jc, p.S, h);
     f32x4 xq[4 * NT], yq[CROSS ? 4 * NT : 1];
     if constexpr (CROSS) rows_request<NT>(p.y, p.ldy, yrow, h, yq);
     rows_request<NT>(p.x, p.ldx, xrow, h, xq);
-    static_assert(NT == 2, "rows_wait counts the fill of an E = 64 block on four waves");
+    static_assert(NT == 2 && (NW == 4 || NW == 8), "rows_wait counts the fill of an E = 64 block on NW waves");
     mab_fill(sIn, p.Win, 2 * nfIn * 1024);
     mab_fill(sO, p.Wo, 2 * nfE * 1024);
     mab_fill(sF, p.Wf, 2 * nfE * 1024);
     f32x16 xt[NT], yt[CROSS ? NT : 1];
     if constexpr (CROSS) {
-        rows_wait<20 + 4 * NT>(yq);
+        rows_wait<80 / NW + 4 * NT>(yq);
 #pragma unroll
         for (int t = 0; t < NT; ++t) yt[t] = pieces_tile(yq, t);
         tiles_to_frags<NT>(yt, sa, yh_, yl_);
     }
-    rows_wait<20>(xq);
+    rows_wait<80 / NW>(xq);
 #pragma unroll
     for (int t = 0; t < NT; ++t) xt[t] = pieces_tile(xq, t);
     tiles_to_frags<NT>(xt, sa, xh, xl);
     xtile = role == 0 ? xt[0] : xt[1];
     const V* yh = CROSS ? yh_ : xh;
     const V* yl = CROSS ? yl_ : xl;
-    sBin[bi0] = bv0 * zs;
-    if (threadIdx.x + 256 < 160 * NT) sBin[bi1] = bv1 * zs;
+    if (threadIdx.x < 160 * NT) sBin[bi0] = bv0 * zs;
+    if (NW == 4 && threadIdx.x + 256 < 160 * NT) sBin[bi1] = bv1 * zs;
     const f32x16 kneg = key_mask_from(kig, p.S, h);
     __syncthreads();
     MAB_STAMPP(1);
@@ -1246,12 +1247,26 @@ int mab_waves(int B) {
 
 // E = 64: two waves per jet (mab_fwd_half, mab_bwd2_body) while the launch has fewer jets than the chip has SIMDs to give
 // each two (256 CUs x 4 / 2 = 512): a shorter chain per wave on SIMDs that would idle.  Past that every SIMD has a jet of its
-// own and the split only adds the exchanges.  MPG_MAB_SPLIT=0 keeps one wave per jet, =2 splits at any size; read at every
-// launch, so a test can hold the two forms against each other in one process (they give the same bits).
-bool mab_split(int B) {
+// own.  The FORWARD (under 256 registers) then doubles up to 1,024 jets: four jets = eight waves to a workgroup, two waves
+// to a SIMD, one issuing its hi/lo splits and softmax while the other's MFMAs run; the backward (340-400 registers, one wave
+// to a SIMD) keeps one wave per jet.  MPG_MAB_SPLIT=0 keeps one wave per jet everywhere, =2 splits at any size, =3 splits
+// up to 512 jets only (the A/B of the doubled forward); read at every launch, so a test can hold the forms against each
+// other in one process (they give the same bits).
+int mab_split_mode() {
     const char* e = getenv("MPG_MAB_SPLIT");
-    const int mode = e == nullptr ? 1 : atoi(e);
-    return mode == 2 || (mode == 1 && B <= 512);
+    return e == nullptr ? 1 : atoi(e);
+}
+bool mab_split(int B) {
+    const int mode = mab_split_mode();
+    return mode == 2 || ((mode == 1 || mode == 3) && B <= 512);
+}
+// waves per workgroup of the split forward: 0 = not split
+int mab_split_fwd_waves(int B) {
+    const int mode = mab_split_mode();
+    if (mode == 0) return 0;
+    if (B <= 512) return 4;
+    if (mode == 2 || (mode == 1 && B <= 1024)) return 8;
+    return 0;
 }
 
 template <typename K>
@@ -1299,15 +1314,12 @@ extern "C" int mpg_mab_fwd(const MpgMab* p, void* stream) {
     const bool cross = p->y != p->x;
     const int NT = p->E / 32;
     const int lds = 2 * 1024 * (3 * NT * 2 * NT + 2 * NT * 2 * NT) + 4 * 160 * NT;   // Win + Wo, Wf + biases
-    if (p->E == 64 && mab_split(p->B)) {
-        const int lds2 = lds + 2 * 2 * MAB_XCH;
-        if (cross) {
-            MPG_ENSURE_LDS((mab_fwd2_kernel<true>), lds2);
-            hipLaunchKernelGGL((mab_fwd2_kernel<true>), dim3((p->B + 1) / 2), dim3(256), lds2, st, *p);
-        } else {
-            MPG_ENSURE_LDS((mab_fwd2_kernel<false>), lds2);
-            hipLaunchKernelGGL((mab_fwd2_kernel<false>), dim3((p->B + 1) / 2), dim3(256), lds2, st, *p);
-        }
+    if (const int nw2 = p->E == 64 ? mab_split_fwd_waves(p->B) : 0) {
+        const int npair = nw2 / 2, lds2 = lds + npair * 2 * MAB_XCH, grid = (p->B + npair - 1) / npair;
+        if (cross && nw2 == 4) { MPG_ENSURE_LDS((mab_fwd2_kernel<true, 4>), lds2); hipLaunchKernelGGL((mab_fwd2_kernel<true, 4>), dim3(grid), dim3(256), lds2, st, *p); }
+        else if (cross) { MPG_ENSURE_LDS((mab_fwd2_kernel<true, 8>), lds2); hipLaunchKernelGGL((mab_fwd2_kernel<true, 8>), dim3(grid), dim3(512), lds2, st, *p); }
+        else if (nw2 == 4) { MPG_ENSURE_LDS((mab_fwd2_kernel<false, 4>), lds2); hipLaunchKernelGGL((mab_fwd2_kernel<false, 4>), dim3(grid), dim3(256), lds2, st, *p); }
+        else { MPG_ENSURE_LDS((mab_fwd2_kernel<false, 8>), lds2); hipLaunchKernelGGL((mab_fwd2_kernel<false, 8>), dim3(grid), dim3(512), lds2, st, *p); }
         return (int)hipGetLastError();
     }
     if (p->E == 64) {
@@ -1336,11 +1348,11 @@ extern "C" int mpg_mab_chain_fwd(const MpgMabChain* c, void* stream) {
     const int NT = p0.E / 32;
     const int lds = 2 * 1024 * (3 * NT * 2 * NT + 2 * NT * 2 * NT) + 4 * 160 * NT;
     hipStream_t st = (hipStream_t)stream;
-    if (p0.E == 64 && mab_split(p0.B)) {
-        // two waves per jet, two jets per workgroup
-        const int lds2 = lds + 2 * 2 * MAB_XCH;
-        MPG_ENSURE_LDS(mab_chain_fwd2_kernel, lds2);
-        hipLaunchKernelGGL(mab_chain_fwd2_kernel, dim3((p0.B + 1) / 2), dim3(256), lds2, st, *c);
+    if (const int nw2 = p0.E == 64 ? mab_split_fwd_waves(p0.B) : 0) {
+        // two waves per jet, two or four jets per workgroup
+        const int npair = nw2 / 2, lds2 = lds + npair * 2 * MAB_XCH, grid2 = (p0.B + npair - 1) / npair;
+        if (nw2 == 4) { MPG_ENSURE_LDS(mab_chain_fwd2_kernel<4>, lds2); hipLaunchKernelGGL(mab_chain_fwd2_kernel<4>, dim3(grid2), dim3(256), lds2, st, *c); }
+        else { MPG_ENSURE_LDS(mab_chain_fwd2_kernel<8>, lds2); hipLaunchKernelGGL(mab_chain_fwd2_kernel<8>, dim3(grid2), dim3(512), lds2, st, *c); }
     } else if (p0.E == 64) {
         MPG_ENSURE_LDS((mab_chain_fwd_kernel<2>), lds);
         hipLaunchKernelGGL((mab_chain_fwd_kernel<2>), dim3(grid), dim3(64 * nw), lds, st, *c);

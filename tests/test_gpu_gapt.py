@@ -233,12 +233,12 @@ def test_sab_chain_is_bit_identical_to_block_by_block(which, B, p_drop):
         assert torch.equal(a[k], b_[k]), (k, float((a[k] - b_[k]).abs().max()))
 
 
-@pytest.mark.parametrize("which,B,p_drop", [("G", 63, 0.3), ("D", 64, 0.5), ("D", 511, 0.0), ("G", 700, 0.2)])
+@pytest.mark.parametrize("which,B,p_drop", [("G", 63, 0.3), ("D", 64, 0.5), ("D", 511, 0.0), ("G", 700, 0.2), ("D", 1024, 0.5), ("D", 1021, 0.0)])
 def test_two_waves_per_jet_give_the_bits_of_one(which, B, p_drop):
     """E = 64 blocks run with two waves per jet (mab.hip: mab_fwd_half / mab_bwd2_body -- each wave owns one feature tile
     and its two heads; fragments cross in LDS): forward, chain, cross-attention pooling block and every backward against the
-    one-wave kernels (MPG_MAB_SPLIT=0) bit for bit, odd jet counts (a pair without a jet) and, forced (=2), past the size
-    the launcher stops splitting at."""
+    one-wave kernels (MPG_MAB_SPLIT=0) bit for bit, odd jet counts (pairs without a jet), the forward's four-jet workgroups
+    (513..1,024 jets: two waves to a SIMD) and, forced (=2), past the sizes the launcher stops splitting at."""
     import itertools, os
     from mpgan_amd import ops, train as mtrain
     dev = torch.device("cuda:0")
