@@ -421,13 +421,16 @@ int mpg_batchnorm_bwd(const float* g, int ldg, const float* x, int ldx, const fl
  *              device float holding the number of steps taken so far (advanced by the call)
  * mpg_adadelta (--optimizer adadelta): torch.optim.Adadelta (rho 0.9, eps 1e-6 by default).
  * zero_grad != 0: g is cleared behind its last use -- optimizer.zero_grad() of the NEXT train_D / train_G (train.py:419,
- * :494) without a launch of its own. */
+ * :494) without a launch of its own.
+ * counter != NULL: *counter += counter_add by the same launch -- the device-resident dropout / noise seed moved on to the
+ * next iteration's value by the iteration's last launch (no kernel may be reading it on another stream); NULL: nothing. */
 int mpg_rmsprop(float* p, float* g, float* v, uint64_t n, float lr, float alpha, float eps, float gscale, int zero_grad,
-                void* stream);
+                uint64_t* counter, uint64_t counter_add, void* stream);
 int mpg_adam(float* p, float* g, float* m, float* v, float* step, uint64_t n, float lr, float beta1,
-             float beta2, float eps, float weight_decay, float gscale, int zero_grad, void* stream);
+             float beta2, float eps, float weight_decay, float gscale, int zero_grad, uint64_t* counter, uint64_t counter_add,
+             void* stream);
 int mpg_adadelta(float* p, float* g, float* v, float* u, uint64_t n, float lr, float rho, float eps,
-                 float gscale, int zero_grad, void* stream);
+                 float gscale, int zero_grad, uint64_t* counter, uint64_t counter_add, void* stream);
 
 /* mpg_normal: out[i] = mean + std * z_i with z ~ N(0, 1) -- the generator's input noise (get_gen_noise, train.py:100-141:
  * torch.randn * sd) from a counter-based stream keyed by the device-resident 64-bit `seed` (the dropout seed, advanced

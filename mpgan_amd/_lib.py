@@ -208,10 +208,11 @@ SIGNATURES = {
     "mpg_batchnorm_apply": (C.c_int, [_fp, C.c_int, _fp, _fp, _fp, _fp, C.c_float, _fp, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mpg_batchnorm_bwd": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, C.c_float, _fp, C.c_int, _fp, _fp, C.c_int, _fp, _fp,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "mpg_rmsprop": (C.c_int, [_fp, _fp, _fp, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "mpg_rmsprop": (C.c_int, [_fp, _fp, _fp, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _fp, C.c_uint64, C.c_void_p]),
     "mpg_adam": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
-                           C.c_float, C.c_int, C.c_void_p]),
-    "mpg_adadelta": (C.c_int, [_fp, _fp, _fp, _fp, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+                           C.c_float, C.c_int, _fp, C.c_uint64, C.c_void_p]),
+    "mpg_adadelta": (C.c_int, [_fp, _fp, _fp, _fp, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _fp, C.c_uint64,
+                               C.c_void_p]),
     "mpg_normal": (C.c_int, [_fp, C.c_uint64, _fp, C.c_uint32, C.c_float, C.c_float, C.c_void_p]),
 }
 

@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void disc_head_bwd_kernel(const MpgDiscHead p)
 }
 
 // workgroup 0: the loss value (sum of the per-jet terms, fixed order); workgroups 1..: the head's own parameter gradients,
-// eight outputs each, 32 lanes per output striding over the jets (fixed summation order)
+// four outputs each, one wave per output striding over the jets with four loads in flight per lane (fixed summation order;
+// with 32 lanes per output and one dependent load after the other the 1,024 jets of a GAPT D step took 14 us)
 __global__ __launch_bounds__(256) void disc_head_reduce_kernel(const MpgDiscHead p) {
     __shared__ float red[256];
     const int tid = threadIdx.x;
@@ -217,20 +218,24 @@ __global__ __launch_bounds__(256) void disc_head_reduce_kernel(const MpgDiscHead
     }
     if (p.dw == nullptr) return;
     // dw_f = sum_b gzpre_b * pool_scale_b * pooled[b, f] ;  db = sum_b gzpre_b
-    const int f = (blockIdx.x - 1) * 8 + (tid >> 5);   // (f == F: the bias)
+    const int f = (blockIdx.x - 1) * 4 + (tid >> 6), lane = tid & 63;   // (f == F: the bias)
     if (f > p.F) return;
-    float s = 0.f;
-    for (int b = tid & 31; b < p.B; b += 32) {
+    const float ds = p.thr ? p.dscale : 1.f;
+    auto term = [&](int b) {
+        if (b >= p.B) return 0.f;
         const float gzp = p.aux[2 * b + 1];
-        if (f < p.F) {
-            const float ps = p.aux[2 * b] != 0.f ? p.aux[2 * b] / (p.thr ? p.dscale : 1.f) : 0.f;   // pooling normalisation alone
-            s += gzp * ps * p.pooled[(size_t)b * p.F + f];
-        } else {
-            s += gzp;
-        }
+        if (f >= p.F) return gzp;
+        const float a0 = p.aux[2 * b];
+        return gzp * (a0 != 0.f ? a0 / ds : 0.f) * p.pooled[(size_t)b * p.F + f];   // pooling normalisation alone
+    };
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int b = lane; b < p.B; b += 256) {
+        s0 += term(b); s1 += term(b + 64); s2 += term(b + 128); s3 += term(b + 192);
     }
+    float s = (s0 + s1) + (s2 + s3);
     s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
-    if ((tid & 31) == 0) {
+    s += __shfl_xor(s, 32, 64);
+    if (lane == 0) {
         if (f < p.F) p.dw[f] = s + (p.accumulate ? p.dw[f] : 0.f);
         else if (p.db != nullptr) p.db[0] = s + (p.accumulate ? p.db[0] : 0.f);
     }
@@ -415,7 +420,7 @@ extern "C" int mpg_disc_head_loss(const MpgDiscHead* p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(disc_head_fwd_kernel<true>, dim3((p->B + 3) / 4), dim3(256), 0, st, *p);
     if (p->loss_out != nullptr || p->dw != nullptr)
-        hipLaunchKernelGGL(disc_head_reduce_kernel, dim3(1 + (p->dw != nullptr ? (p->F + 1 + 7) / 8 : 0)), dim3(256), 0, st, *p);
+        hipLaunchKernelGGL(disc_head_reduce_kernel, dim3(1 + (p->dw != nullptr ? (p->F + 1 + 3) / 4 : 0)), dim3(256), 0, st, *p);
     return (int)hipGetLastError();
 }
 
@@ -426,6 +431,6 @@ extern "C" int mpg_disc_head_bwd(const MpgDiscHead* p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(disc_head_bwd_kernel, dim3((p->B + 3) / 4), dim3(256), 0, st, *p);
     if ((p->loss >= 0 && p->loss_out != nullptr) || p->dw != nullptr)
-        hipLaunchKernelGGL(disc_head_reduce_kernel, dim3(1 + (p->dw != nullptr ? (p->F + 1 + 7) / 8 : 0)), dim3(256), 0, st, *p);
+        hipLaunchKernelGGL(disc_head_reduce_kernel, dim3(1 + (p->dw != nullptr ? (p->F + 1 + 3) / 4 : 0)), dim3(256), 0, st, *p);
     return (int)hipGetLastError();
 }

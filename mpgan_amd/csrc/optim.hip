@@ -17,7 +17,8 @@
 
 namespace {
 __global__ void rmsprop_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ v, size_t n,
-                               float lr, float alpha, float eps, float gscale, int zero_grad) {
+                               float lr, float alpha, float eps, float gscale, int zero_grad, uint64_t* __restrict__ counter, uint64_t counter_add) {
+    if (counter != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *counter += counter_add;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -31,7 +32,8 @@ __global__ void rmsprop_kernel(float* __restrict__ p, float* __restrict__ g, flo
 
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             const float* __restrict__ step, size_t n, float lr, float b1, float b2, float eps, float wd,
-                            float gscale, int zero_grad) {
+                            float gscale, int zero_grad, uint64_t* __restrict__ counter, uint64_t counter_add) {
+    if (counter != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *counter += counter_add;
     const float t = *step + 1.f;
     const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
     const float step_size = lr / bc1;
@@ -51,7 +53,8 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float*
 __global__ void step_inc_kernel(float* step) { *step += 1.f; }
 
 __global__ void adadelta_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ v, float* __restrict__ u,
-                                size_t n, float lr, float rho, float eps, float gscale, int zero_grad) {
+                                size_t n, float lr, float rho, float eps, float gscale, int zero_grad, uint64_t* __restrict__ counter, uint64_t counter_add) {
+    if (counter != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *counter += counter_add;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -90,28 +93,29 @@ inline int nblocks(uint64_t n) { return (int)((n + 255) / 256 < 2048 ? (n + 255)
 }  // namespace
 
 extern "C" int mpg_rmsprop(float* p, float* g, float* v, uint64_t n, float lr, float alpha, float eps,
-                           float gscale, int zero_grad, void* stream) {
-    if (n == 0) return 0;
+                           float gscale, int zero_grad, uint64_t* counter, uint64_t counter_add, void* stream) {
+    if (n == 0) return counter != nullptr ? -1 : 0;
     hipLaunchKernelGGL(rmsprop_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, v, (size_t)n, lr, alpha,
-                       eps, gscale, zero_grad);
+                       eps, gscale, zero_grad, counter, counter_add);
     return (int)hipGetLastError();
 }
 
 extern "C" int mpg_adam(float* p, float* g, float* m, float* v, float* step, uint64_t n, float lr, float beta1,
-                        float beta2, float eps, float weight_decay, float gscale, int zero_grad, void* stream) {
-    if (n == 0) return 0;
+                        float beta2, float eps, float weight_decay, float gscale, int zero_grad, uint64_t* counter, uint64_t counter_add,
+                        void* stream) {
+    if (n == 0) return counter != nullptr ? -1 : 0;
     if (step == nullptr) return -1;
     hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, step, (size_t)n, lr,
-                       beta1, beta2, eps, weight_decay, gscale, zero_grad);
+                       beta1, beta2, eps, weight_decay, gscale, zero_grad, counter, counter_add);
     hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
     return (int)hipGetLastError();
 }
 
 extern "C" int mpg_adadelta(float* p, float* g, float* v, float* u, uint64_t n, float lr, float rho, float eps,
-                            float gscale, int zero_grad, void* stream) {
-    if (n == 0) return 0;
+                            float gscale, int zero_grad, uint64_t* counter, uint64_t counter_add, void* stream) {
+    if (n == 0) return counter != nullptr ? -1 : 0;
     hipLaunchKernelGGL(adadelta_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, v, u, (size_t)n, lr, rho,
-                       eps, gscale, zero_grad);
+                       eps, gscale, zero_grad, counter, counter_add);
     return (int)hipGetLastError();
 }
 

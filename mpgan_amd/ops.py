@@ -146,8 +146,11 @@ def set_seed(value: int, device="cuda"):
     seed_tensor(device).fill_(value & 0x7FFFFFFFFFFFFFFF)
 
 
+SEED_STEP = 0x1E3779B97F4A7C15   # what an iteration adds to the seed
+
+
 def bump_seed(device="cuda"):
-    seed_tensor(device).add_(0x1E3779B97F4A7C15)
+    seed_tensor(device).add_(SEED_STEP)
 
 
 NOISE_TAG = 0x4E000000   # site tags of ``normal_noise`` (dropout sites stay below 2^27: next_tag)

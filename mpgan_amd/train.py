@@ -140,23 +140,26 @@ class FlatParams:
         self.grad.zero_()
 
     # -- the fused step -----------------------------------------------------------------------------
-    def step(self, lr: float, gscale: float = 1.0, zero_grad: bool = False):
+    def step(self, lr: float, gscale: float = 1.0, zero_grad: bool = False, advance_seed: torch.Tensor = None):
         """One optimiser step over the flat buffer; ``gscale`` multiplies the gradient first; ``zero_grad``: the gradient
-        buffer is cleared by the same launch, behind its last use."""
+        buffer is cleared by the same launch, behind its last use; ``advance_seed``: the device's dropout / noise seed
+        (``ops.seed_tensor``) is moved on by ``ops.SEED_STEP`` in the same launch -- ``ops.bump_seed`` of the next iteration
+        without a kernel of its own."""
         self.lr = lr
         vp = lambda t: C.c_void_p(t.data_ptr())
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         L = _lib.lib()
         z = int(zero_grad)
+        cnt, add = (None, 0) if advance_seed is None else (vp(advance_seed), ops.SEED_STEP)
         if self.optimizer == "rmsprop":
-            _lib.check(L.mpg_rmsprop(vp(self.flat), vp(self.grad), vp(self.sq), self.n, lr, 0.99, 1e-8, gscale, z, st),
+            _lib.check(L.mpg_rmsprop(vp(self.flat), vp(self.grad), vp(self.sq), self.n, lr, 0.99, 1e-8, gscale, z, cnt, add, st),
                        "mpg_rmsprop")
         elif self.optimizer == "adam":
             _lib.check(L.mpg_adam(vp(self.flat), vp(self.grad), vp(self.aux), vp(self.sq), vp(self.step_count), self.n,
-                                  lr, self.betas[0], self.betas[1], 1e-8, self.weight_decay, gscale, z, st), "mpg_adam")
+                                  lr, self.betas[0], self.betas[1], 1e-8, self.weight_decay, gscale, z, cnt, add, st), "mpg_adam")
         else:
             _lib.check(L.mpg_adadelta(vp(self.flat), vp(self.grad), vp(self.sq), vp(self.aux), self.n, lr, 0.9, 1e-6,
-                                      gscale, z, st), "mpg_adadelta")
+                                      gscale, z, cnt, add, st), "mpg_adadelta")
         if not (self.flat.is_cuda and torch.cuda.is_current_stream_capturing()):  # a capture records the launch, it does not run it
             self._host_steps += 1
 
@@ -414,7 +417,7 @@ class TrainStep:
         # parameter gradients are added straight into the flat buffers (no AccumulateGrad kernel per parameter)
         self.state.grad_into_param = True
         self.state.order_cache = None   # (ops.jet_order: the masks of this iteration live where last iteration's did)
-        ops.bump_seed(self.dev)
+        # (the dropout / noise seed of this iteration was set by the last launch of the iteration before: _seg_end)
         self.D.train()
         if self.gen_ahead:
             self._fork_generator()
@@ -556,7 +559,8 @@ class TrainStep:
         _set_requires_grad(self.fD, True)
 
     def _seg_end(self):  # G_optimizer.step() (train.py:521)
-        self.fG.step(self.lr_gen, gscale=1.0 / self.world, zero_grad=True)
+        # ... and so does the next iteration's seed (what ops.bump_seed at the head of train_D would do in a launch of its own)
+        self.fG.step(self.lr_gen, gscale=1.0 / self.world, zero_grad=True, advance_seed=ops.seed_tensor(self.dev))
         self._clean["G"] = True
         self._refresh_packed(self.G)
         self.state.grad_into_param = False

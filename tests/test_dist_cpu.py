@@ -37,8 +37,11 @@ class ToyD(torch.nn.Module):
         return torch.sigmoid(self.net(x.reshape(x.shape[0], -1)) + labels)
 
 
-def _torch_rmsprop(self, lr, gscale=1.0, zero_grad=False):
+def _torch_rmsprop(self, lr, gscale=1.0, zero_grad=False, advance_seed=None):
     """FlatParams.step for CPU tensors: mpg_rmsprop's arithmetic (csrc/optim.hip) in torch."""
+    if advance_seed is not None:
+        from mpgan_amd import ops
+        advance_seed.add_(ops.SEED_STEP)
     self.last_grad = self.grad.clone()      # (what the step consumed: the buffer itself is cleared below)
     g = self.grad * gscale
     self.sq.mul_(0.99).addcmul_(g, g, value=0.01)
