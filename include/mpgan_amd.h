@@ -350,6 +350,42 @@ int mpg_disc_head_bwd(const MpgDiscHead* p, void* stream);
  * + mpg_disc_head_bwd).  Same results as the two calls. */
 int mpg_disc_head_loss(const MpgDiscHead* p, void* stream);
 
+/* mpg_bridge_fwd / mpg_bridge_bwd: the rows between a GAPT generator's last attention block and the discriminator's first
+ * one as ONE launch each way (csrc/bridge.hip) -- gen's final_fc (gapt/model.py:248, :263: Linear K -> F, no activation) and
+ * final tanh (:265), then disc's input_embedding (:300-302, :336-339: Linear F -> E, LeakyReLU, dropout), which otherwise run
+ * as mpg_gemm + mpg_gen_tail_fwd + mpg_gemm (and mpg_gate + mpg_gemm + mpg_gen_tail_bwd + mpg_gemm on the way back):
+ *   rows >= row0 (generated):  feat = act1(W1 x + b1), written to feat ;  rows < row0 (real jets): feat is read
+ *   every row:                 e = dropout(lrelu(W2 feat + b2))          (e == NULL: stage 1 alone)
+ * x [M - row0, K], feat [M, F], e [M, E]; K = E = 64, F in 1..4 or 8; act1: mpg_gen_tail_fwd's codes.
+ * bwd: g2 = ge through stage 2's dropout and LeakyReLU (what mpg_gate gives: the operand of W2's weight gradient), all rows;
+ * for rows >= row0, when g1 or dx is given: g1 = (g2 W2 + gfeat) act1'(feat) (the operand of W1's weight gradient) and
+ * dx = g1 W1.  Any of g2, g1, dx, gfeat may be NULL. */
+typedef struct MpgBridge {
+    const float* x; int ldx;
+    const float* W1; const float* b1;       /* [F, K], [F] or NULL                                   */
+    int act1;
+    float* feat; int ldf;
+    int M, row0, K, F, E;
+    const float* W2; const float* b2;       /* [E, F], [E] or NULL                                   */
+    int act2; float alpha;
+    const uint64_t* seed; uint32_t tag, thr; float dscale;   /* dropout on e (site tag)              */
+    float* e; int lde;
+} MpgBridge;
+typedef struct MpgBridgeBwd {
+    const float* ge; int ldge;              /* [M, E] gradient with respect to e                     */
+    const float* e; int lde;                /* stage 2's saved output                                */
+    const float* feat; int ldf;
+    const float* gfeat; int ldgf;           /* [M - row0, F] further gradient into feat, or NULL     */
+    const float* W1; const float* W2;
+    int M, row0, K, F, E, act1, act2; float alpha;
+    const uint64_t* seed; uint32_t tag, thr; float dscale;
+    float* g2; int ldg2;                    /* [M, E]                                                */
+    float* g1; int ldg1;                    /* [M - row0, F]                                         */
+    float* dx; int lddx;                    /* [M - row0, K]                                         */
+} MpgBridgeBwd;
+int mpg_bridge_fwd(const MpgBridge* p, void* stream);
+int mpg_bridge_bwd(const MpgBridgeBwd* p, void* stream);
+
 /* mpg_mab_fwd / mpg_mab_bwd: one launch per MAB.forward (gapt/model.py:124-139) and one for its backward, for sets of at
  * most 32 tokens, E in {32, 64}, heads of 16 features, no layer norm (csrc/mab.hip; anything else runs block by block
  * through mpg_gemm / mpg_attn_* / mpg_gate):

@@ -146,6 +146,28 @@ class MpgDiscHead(C.Structure):
     ]
 
 
+class MpgBridge(C.Structure):
+    _fields_ = [
+        ("x", _fp), ("ldx", C.c_int), ("W1", _fp), ("b1", _fp), ("act1", C.c_int),
+        ("feat", _fp), ("ldf", C.c_int),
+        ("M", C.c_int), ("row0", C.c_int), ("K", C.c_int), ("F", C.c_int), ("E", C.c_int),
+        ("W2", _fp), ("b2", _fp), ("act2", C.c_int), ("alpha", C.c_float),
+        ("seed", _fp), ("tag", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
+        ("e", _fp), ("lde", C.c_int),
+    ]
+
+
+class MpgBridgeBwd(C.Structure):
+    _fields_ = [
+        ("ge", _fp), ("ldge", C.c_int), ("e", _fp), ("lde", C.c_int), ("feat", _fp), ("ldf", C.c_int),
+        ("gfeat", _fp), ("ldgf", C.c_int), ("W1", _fp), ("W2", _fp),
+        ("M", C.c_int), ("row0", C.c_int), ("K", C.c_int), ("F", C.c_int), ("E", C.c_int), ("act1", C.c_int), ("act2", C.c_int),
+        ("alpha", C.c_float),
+        ("seed", _fp), ("tag", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
+        ("g2", _fp), ("ldg2", C.c_int), ("g1", _fp), ("ldg1", C.c_int), ("dx", _fp), ("lddx", C.c_int),
+    ]
+
+
 class MpgMab(C.Structure):
     _fields_ = [
         ("x", _fp), ("ldx", C.c_int), ("y", _fp), ("ldy", C.c_int), ("ignore", _fp),
@@ -213,6 +235,8 @@ SIGNATURES = {
                            C.c_float, C.c_int, _fp, C.c_uint64, C.c_void_p]),
     "mpg_adadelta": (C.c_int, [_fp, _fp, _fp, _fp, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _fp, C.c_uint64,
                                C.c_void_p]),
+    "mpg_bridge_fwd": (C.c_int, [C.POINTER(MpgBridge), C.c_void_p]),
+    "mpg_bridge_bwd": (C.c_int, [C.POINTER(MpgBridgeBwd), C.c_void_p]),
     "mpg_normal": (C.c_int, [_fp, C.c_uint64, _fp, C.c_uint32, C.c_float, C.c_float, C.c_void_p]),
 }
 

@@ -335,6 +335,25 @@ class GAPT_G(nn.Module):
             return ops.gen_tail_into(x, None, ops.ACT_CODES["tanh"], feat_out), mask, ign
         return ops.GenTailFn.apply(x, None, ops.ACT_CODES["tanh"]), mask, ign
 
+    def bridge_head(self):
+        """(weight [F, E], bias, activation code) of ``final_fc`` + tanh when they can run inside ``ops.GenDiscBridgeFn``
+        (one plain Linear, no dropout on it); else None."""
+        fc = self.final_fc
+        if len(fc.net) != 1 or not fc.plain or (fc.dropout_p and self.training):
+            return None
+        lin = fc.net[0]
+        return lin.weight, lin.bias, ops.ACT_CODES["tanh"]
+
+    def generate_rows(self, x: Tensor, labels: Tensor, mask_out: Tensor = None, ign_out: Tensor = None):
+        """``generate_parts`` up to the last attention block: (rows [B, N, E] that ``final_fc`` would take, mask [B, N, 1],
+        1 - mask [B, N]) -- for a caller that runs ``final_fc``, the tanh and the discriminator's embedding as one launch
+        (``GAPT_D.features_rows``)."""
+        assert x.is_cuda and self.use_mask
+        B = x.shape[0]
+        mask2d, ign = ops.rank_mask(x[:, :, 0], labels, self.num_particles, out=None if mask_out is None else mask_out.view(B, -1),
+                                    with_ignore=True, ignore_out=None if ign_out is None else ign_out.view(B, -1))
+        return _run_sabs(self.sabs, x, _ignore_mask(ign.unsqueeze(2))), mask2d.unsqueeze(2), ign
+
     def generate_into(self, x: Tensor, labels: Tensor, out: Tensor) -> Tensor:
         """``forward`` into caller-owned output rows, no gradient (``train.TrainStep``'s D step)."""
         assert not torch.is_grad_enabled() and x.is_cuda
@@ -393,6 +412,29 @@ class GAPT_D(nn.Module):
         inv = (1 - mask) if ignore is None else ignore
         am = _ignore_mask(inv.reshape(B, N, 1))
         x = self.input_embedding(x3)
+        x = _run_sabs(self.sabs, x, am)
+        return self.pma(x, am), None
+
+    def bridge_tail(self):
+        """(weight [E, F], bias, LeakyReLU alpha, dropout p) of ``input_embedding`` when it can run inside
+        ``ops.GenDiscBridgeFn`` (one plain Linear); else None."""
+        emb = self.input_embedding
+        if len(emb.net) != 1 or not emb.plain or emb.final_linear:
+            return None
+        lin = emb.net[0]
+        return lin.weight, lin.bias, emb.leaky_relu_alpha, emb.dropout_p
+
+    def features_rows(self, pre: Tensor, head, feat_buf: Tensor, mask: Tensor, labels: Tensor = None, ignore: Tensor = None):
+        """``features_parts`` for generated jets that are still the generator's rows ``pre`` [Bg, N, E] (``GAPT_G.generate_rows``;
+        ``head`` = its ``bridge_head()``): ``final_fc``, tanh and ``input_embedding`` in one launch.  ``feat_buf``: None, or
+        the [B, N, F] batch whose first B - Bg jets are real -- the generated features are written behind them."""
+        W2, b2, alpha, p = self.bridge_tail()
+        W1, b1, act1 = head
+        B = pre.shape[0] if feat_buf is None else feat_buf.shape[0]
+        N = pre.shape[1]
+        inv = (1 - mask) if ignore is None else ignore
+        am = _ignore_mask(inv.reshape(B, N, 1))
+        _, x = ops.GenDiscBridgeFn.apply(pre, W1, b1, feat_buf, W2, b2, act1, True, alpha, p, self.training)
         x = _run_sabs(self.sabs, x, am)
         return self.pma(x, am), None
 

@@ -1459,6 +1459,102 @@ class GenTailFn(torch.autograd.Function):
         return dy.reshape(B, N, F), None, None
 
 
+def bridge_fusable(K: int, F: int, E: int) -> bool:
+    """Shapes ``GenDiscBridgeFn`` takes (csrc/bridge.hip: sixteen lanes to a row of 64)."""
+    return K == 64 and E == 64 and (1 <= F <= 4 or F == 8)
+
+
+class GenDiscBridgeFn(torch.autograd.Function):
+    """The rows between a GAPT generator's last block and the discriminator's first one as ONE launch each way
+    (``mpg_bridge_fwd`` / ``mpg_bridge_bwd``):  feat = act1(pre W1' + b1)  (gen's ``final_fc`` + final activation,
+    gapt/model.py:263-265), then  e = dropout(LeakyReLU(feat W2' + b2))  (disc's ``input_embedding``, :336-339).
+
+    ``pre`` [Bg, N, K]: the generated jets' rows; ``feat_buf``: None, or a [B, N, F] batch whose first B - Bg jets are real
+    ones -- the generated features are written behind them, in place, and every row is embedded (the D step's real +
+    generated batch).  Returns (feat [Bg, N, F] -- None with ``feat_buf`` --, e [B, N, E]).  Weight gradients go through the grouped launches like
+    ``FusedLinearFn``'s."""
+
+    @staticmethod
+    def forward(ctx, pre, W1, b1, feat_buf, W2, b2, act1, act2, alpha, p_drop, training):
+        _chk(pre, "pre")
+        Bg, N, K = pre.shape
+        F, E = W1.shape[0], W2.shape[0]
+        pre2 = pre.reshape(Bg * N, K)
+        if pre2.stride(1) != 1 or pre2.stride(0) % 4:
+            pre2 = pre2.contiguous()
+        if feat_buf is None:
+            feat = torch.empty((Bg, N, F), device=pre.device, dtype=torch.float32)
+        else:
+            feat = feat_buf
+            assert feat.is_contiguous() and feat.shape[1:] == (N, F) and feat.shape[0] >= Bg
+        B = feat.shape[0]
+        e = torch.empty((B, N, E), device=pre.device, dtype=torch.float32)
+        thr, dscale = drop_params(p_drop) if training else (0, 1.0)
+        tag = next_tag(pre.device) + TAG_GENERIC
+        q = _lib.MpgBridge()
+        q.x, q.ldx, q.W1, q.b1, q.act1 = _p(pre2), pre2.stride(0), _p(W1), _p(b1), int(act1)
+        q.feat, q.ldf = _p(feat), F
+        q.M, q.row0, q.K, q.F, q.E = B * N, (B - Bg) * N, K, F, E
+        q.W2, q.b2, q.act2, q.alpha = _p(W2), _p(b2), int(act2), alpha
+        q.seed, q.tag, q.thr, q.dscale = _p(seed_tensor(pre.device)), tag, thr, dscale
+        q.e, q.lde = _p(e), E
+        check(_lib.lib().mpg_bridge_fwd(q, _stream()), "mpg_bridge_fwd")
+        ctx.save_for_backward(pre2, W1, W2, feat, e)
+        ctx.params = (W1, b1, W2, b2)
+        ctx.cfg = (Bg, B, N, K, F, E, int(act1), int(act2), alpha, thr, dscale, tag)
+        return (feat if feat_buf is None else None), e   # (a caller's own batch is written in place: nothing new to hand back)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gfeat, ge):
+        pre2, W1s, W2s, feat, e = ctx.saved_tensors
+        W1, b1, W2, b2 = ctx.params
+        Bg, B, N, K, F, E, act1, act2, alpha, thr, dscale, tag = ctx.cfg
+        need = ctx.needs_input_grad
+        want1 = need[1] or (b1 is not None and need[2])
+        want2 = need[4] or (b2 is not None and need[5])
+        M, row0 = B * N, (B - Bg) * N
+        dev = pre2.device
+        ge2 = ge.reshape(M, E)
+        if ge2.stride(1) != 1 or ge2.stride(0) % 4:
+            ge2 = ge2.contiguous()
+        g2 = torch.empty((M, E), device=dev, dtype=torch.float32) if want2 else None
+        g1 = torch.empty((Bg * N, F), device=dev, dtype=torch.float32) if want1 else None
+        dx = torch.empty((Bg * N, K), device=dev, dtype=torch.float32) if need[0] else None
+        gf = None
+        if gfeat is not None and (want1 or need[0]):
+            gf = gfeat.reshape(-1, F)[row0:] if gfeat.shape[0] == B else gfeat.reshape(-1, F)
+            gf = gf.contiguous()
+        q = _lib.MpgBridgeBwd()
+        q.ge, q.ldge, q.e, q.lde, q.feat, q.ldf = _p(ge2), ge2.stride(0), _p(e), E, _p(feat), F
+        q.gfeat, q.ldgf, q.W1, q.W2 = _p(gf), F, _p(W1s), _p(W2s)
+        q.M, q.row0, q.K, q.F, q.E, q.act1, q.act2, q.alpha = M, row0, K, F, E, act1, act2, alpha
+        q.seed, q.tag, q.thr, q.dscale = _p(seed_tensor(dev)), tag, thr, dscale
+        q.g2, q.ldg2, q.g1, q.ldg1, q.dx, q.lddx = _p(g2), E, _p(g1), F, _p(dx), K
+        if want1 or want2 or need[0]:
+            check(_lib.lib().mpg_bridge_bwd(q, _stream()), "mpg_bridge_bwd")
+        st = dev_state(dev)
+        outs = {}
+        for key, g, xin, W, b, nW, nb in (("1", g1, pre2, W1, b1, need[1], b1 is not None and need[2]),
+                                          ("2", g2, feat.reshape(M, F), W2, b2, need[4], b2 is not None and need[5])):
+            dW = db = None
+            if g is not None:
+                gW = gb = None
+                if nW and st.grad_into_param and st.deferred_wgrad is not None:
+                    gW, gb = _grad_target(W), _grad_target(b) if nb else None
+                if gW is not None and (not nb or gb is not None):
+                    st.deferred_wgrad.add(g, xin, out=gW, bias_out=gb, accumulate=True)
+                elif nW:
+                    if nb:
+                        db = torch.empty(W.shape[0], device=dev, dtype=torch.float32)
+                    dW = linear_bwd_weight(g, xin, bias_out=db)
+                elif nb:
+                    db = g.sum(0)
+            outs[key] = (dW, db)
+        return (None if dx is None else dx.reshape(Bg, N, K), outs["1"][0], outs["1"][1], None, outs["2"][0], outs["2"][1],
+                None, None, None, None, None)
+
+
 LOSS_CODES = {"ls": 0, "og": 1, "w": 2, "hinge": 3}
 
 

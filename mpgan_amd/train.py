@@ -381,6 +381,7 @@ class TrainStep:
         # serialising with the data path.  MPG_WGRAD_SIDE=0 switches it off.
         self.wgrad_side = dev.type == "cuda" and os.environ.get("MPG_WGRAD_SIDE", "1") != "0"
         self._wside = None
+        self.bridge = dev.type == "cuda" and os.environ.get("MPG_BRIDGE", "1") != "0"
         self.fixed_noise = None  # tests: (noise_D, noise_G) used instead of fresh samples
         self._seen_versions = (self.fD.versions(), self.fG.versions())
         # the flat gradient buffers start as zeros and every optimizer launch of an iteration leaves them cleared again
@@ -404,6 +405,15 @@ class TrainStep:
         return (self.dev.type == "cuda" and hasattr(self.G, "generate_into") and hasattr(self.D, "features")
                 and getattr(self.D, "fused_head", lambda: None)() is not None and self.batch_real_fake
                 and not self.gp_lambda)
+
+    def _bridge(self) -> bool:
+        """GAPT: gen's ``final_fc`` + tanh and disc's ``input_embedding`` as one launch each way (``ops.GenDiscBridgeFn``;
+        MPG_BRIDGE=0: the three launches)."""
+        if not self.bridge or not hasattr(self.G, "bridge_head") or not hasattr(self.D, "bridge_tail"):
+            return False
+        h, t = self.G.bridge_head(), self.D.bridge_tail()
+        return h is not None and t is not None and ops.bridge_fusable(h[0].shape[1], h[0].shape[0], t[0].shape[0]) \
+            and t[0].shape[1] == h[0].shape[0]
 
     def _head_loss(self, y, mask, gen_step: bool, n_jets: int, loss_out, wgrad: bool):
         w, b, mean, sigmoid, p = self.D.fused_head()
@@ -457,7 +467,14 @@ class TrainStep:
         if self._fused_ends():
             # real jets sit in the first half of the static batch; the generator writes the second half itself
             B = self.B
-            if self.parts:
+            if self.parts and self._bridge():
+                with torch.no_grad():
+                    pre, _, _ = self.G.generate_rows(self._noise(0), self.labels, mask_out=self._mask2[B:], ign_out=self._ign2[B:])
+                    W1, b1, act1 = self.G.bridge_head()
+                # (the generator takes no gradient in train_D: its final_fc enters the launch as plain data)
+                head = (W1.detach(), None if b1 is None else b1.detach(), act1)
+                y, mask = self.D.features_rows(pre, head, self._x3, self._mask2, self._labels2, ignore=self._ign2)
+            elif self.parts:
                 with torch.no_grad():
                     self.G.generate_parts(self._noise(0), self.labels, feat_out=self._x3[B:], mask_out=self._mask2[B:], ign_out=self._ign2[B:])
                 y, mask = self.D.features_parts(self._x3, self._mask2, self._labels2, ignore=self._ign2)
@@ -541,9 +558,16 @@ class TrainStep:
         _set_requires_grad(self.fD, False)
         fake, self._fake_ahead = self._fake_ahead, None
         parts = self.parts and self._fused_ends()
-        if fake is None:
+        bridge = parts and fake is None and self._bridge()
+        if bridge:
+            fake = self.G.generate_rows(self._noise(1), self.labels)
+        elif fake is None:
             fake = self.G.generate_parts(self._noise(1), self.labels) if parts else self.G(self._noise(1), self.labels)
-        if parts:
+        if bridge:
+            y, mask = self.D.features_rows(fake[0], self.G.bridge_head(), None, fake[1], self.labels, ignore=fake[2])
+            dy = self._head_loss(y, mask, True, self.B, self.G_loss, False)
+            self._backward(y, dy)
+        elif parts:
             y, mask = self.D.features_parts(fake[0], fake[1], self.labels, ignore=fake[2])
             dy = self._head_loss(y, mask, True, self.B, self.G_loss, False)
             self._backward(y, dy)

@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     """sizeof of every struct as gcc sees the header == ctypes.sizeof of the Python mirror."""
     from mpgan_amd import _lib
     structs = ["MpgGemm", "MpgEdgeFwd", "MpgEdgeBwd", "MpgEdgeDw", "MpgAttn", "MpgPackJob", "MpgChainLayer", "MpgChain", "MpgReduceJob",
-               "MpgDiscHead", "MpgMab", "MpgMabChain"]
+               "MpgDiscHead", "MpgMab", "MpgMabChain", "MpgBridge", "MpgBridgeBwd"]
     src = '#include <stdio.h>\n#include "mpgan_amd.h"\nint main(){' + "".join(
         f'printf("{s} %zu\\n", sizeof({s}));' for s in structs) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:

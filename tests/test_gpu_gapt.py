@@ -280,3 +280,63 @@ def test_two_waves_per_jet_give_the_bits_of_one(which, B, p_drop):
         os.environ.pop("MPG_MAB_SPLIT", None)
         os.environ.pop("MPG_MAB_CHAIN", None)
     assert float(one["dx"].abs().max()) > 0
+
+
+@pytest.mark.parametrize("p_drop,real_jets", [(0.0, 0), (0.3, 0), (0.5, 5)])
+def test_gen_disc_bridge_vs_torch(p_drop, real_jets):
+    """``ops.GenDiscBridgeFn`` (gen's final_fc + tanh + disc's input_embedding in one launch each way, csrc/bridge.hip) against
+    the same three layers in torch fp64 with the launch's own dropout mask: outputs, input gradient and the four parameter
+    gradients; with real jets in front (the D step's batch) only those rows' embedding."""
+    from mpgan_amd import ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    Bg, N, K, F, E = 7, 30, 64, 3, 64
+    B = Bg + real_jets
+    pre = torch.randn(Bg, N, K, device=dev, generator=gen).requires_grad_(True)
+    W1 = (torch.randn(F, K, device=dev, generator=gen) * 0.2).requires_grad_(True)
+    b1 = (torch.randn(F, device=dev, generator=gen) * 0.1).requires_grad_(True)
+    W2 = (torch.randn(E, F, device=dev, generator=gen) * 0.5).requires_grad_(True)
+    b2 = (torch.randn(E, device=dev, generator=gen) * 0.1).requires_grad_(True)
+    buf = None
+    if real_jets:
+        buf = torch.zeros(B, N, F, device=dev)
+        buf[:real_jets] = torch.randn(real_jets, N, F, device=dev, generator=gen).tanh()
+    real = None if buf is None else buf[:real_jets].clone()
+    up = torch.randn(B, N, E, device=dev, generator=gen)
+    upf = torch.randn(Bg, N, F, device=dev, generator=gen)
+    ops.set_seed(99, dev)
+    feat, e = ops.GenDiscBridgeFn.apply(pre, W1, b1, buf, W2, b2, ops.ACT_CODES["tanh"], True, 0.2, p_drop, True)
+    loss = (e * up).sum() + ((feat * upf).sum() if feat is not None else 0.0)
+    loss.backward()
+    thr, scale = ops.drop_params(p_drop)
+    keep = ops.dropout_mask(B * N, E, ops.last_tag(dev) + ops.TAG_GENERIC, thr, dev).reshape(B, N, E).double() * scale if thr \
+        else torch.ones(B, N, E, device=dev, dtype=torch.float64)
+    r = [t.detach().double().requires_grad_(True) for t in (pre, W1, b1, W2, b2)]
+    f_ref = torch.tanh(r[0] @ r[1].T + r[2])
+    f_all = f_ref if real is None else torch.cat([real.double(), f_ref], 0)
+    e_ref = torch.nn.functional.leaky_relu(f_all @ r[3].T + r[4], 0.2) * keep
+    ((e_ref * up.double()).sum() + ((f_ref * upf.double()).sum() if feat is not None else 0.0)).backward()
+    assert rel_err(e.detach().cpu().numpy(), e_ref.detach().cpu().numpy()) < 1e-5
+    got_f = feat if feat is not None else buf[real_jets:]
+    assert rel_err(got_f.detach().cpu().numpy(), f_ref.detach().cpu().numpy()) < 1e-5
+    if real is not None:
+        assert torch.equal(buf[:real_jets], real)
+    for a, b_, name in zip((pre, W1, b1, W2, b2), r, ("pre", "W1", "b1", "W2", "b2")):
+        assert rel_err(a.grad.cpu().numpy(), b_.grad.cpu().numpy()) < 1e-4, name
+
+
+def test_bridge_changes_no_result_of_a_training_step():
+    """TrainStep on GAPT with the bridge (default) against MPG_BRIDGE=0 (mpg_gemm + mpg_gen_tail + mpg_gemm): dropout off, three
+    graph-replayed iterations, parameters and losses agree."""
+    import os
+    from test_gpu_train import _three_steps
+    try:
+        os.environ["MPG_BRIDGE"] = "0"
+        a = _three_steps(64, 30, use_graphs=True, model="gapt")
+    finally:
+        os.environ.pop("MPG_BRIDGE", None)
+    b = _three_steps(64, 30, use_graphs=True, model="gapt")
+    for x, y in zip(a[:2], b[:2]):    # (RMSprop's first steps turn rounding-level gradient differences into lr-sized ones)
+        assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < 1e-3
+    for x, y in zip(a[2:], b[2:]):
+        assert abs(x - y) < 1e-4 * max(abs(x), 1e-3)
