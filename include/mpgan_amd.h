@@ -473,6 +473,10 @@ int mpg_adadelta(float* p, float* g, float* v, float* u, uint64_t n, float lr, f
  * once per iteration) and a site `tag`: a captured hipGraph draws fresh values on every replay, and torch's generator
  * (whose graph-safe state costs two fill launches in front of every replay) is not involved. */
 int mpg_normal(float* out, uint64_t n, const uint64_t* seed, uint32_t tag, float mean, float std, void* stream);
+/* mpg_normal_rank_mask: mpg_normal over a [B, N, L] noise tensor and mpg_rank_mask of its first feature (out[:, :, 0]) in one
+ * launch -- same values, same masks; mask / ignore [B, N] (ignore = 1 - mask, or NULL), labels read at stride ld_lab.  N L even. */
+int mpg_normal_rank_mask(float* out, int B, int N, int L, const uint64_t* seed, uint32_t tag, float mean, float std,
+                         const float* labels, int ld_lab, float* mask, float* ignore, void* stream);
 
 #ifdef __cplusplus
 }

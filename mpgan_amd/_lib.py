@@ -238,6 +238,8 @@ SIGNATURES = {
     "mpg_bridge_fwd": (C.c_int, [C.POINTER(MpgBridge), C.c_void_p]),
     "mpg_bridge_bwd": (C.c_int, [C.POINTER(MpgBridgeBwd), C.c_void_p]),
     "mpg_normal": (C.c_int, [_fp, C.c_uint64, _fp, C.c_uint32, C.c_float, C.c_float, C.c_void_p]),
+    "mpg_normal_rank_mask": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_uint32, C.c_float, C.c_float, _fp, C.c_int, _fp, _fp,
+                                       C.c_void_p]),
 }
 
 

@@ -89,6 +89,47 @@ __global__ void normal_kernel(float* __restrict__ out, size_t n, const uint64_t*
     }
 }
 
+// The generator's input noise AND its jets' masks (mask_c, mpgan/model.py:689-699: the n = int(label N) particles with the
+// smallest first noise feature) in one launch: the ranking reads nothing but the noise just drawn.  One workgroup per jet;
+// the values are mpg_normal's (same pair indices over the flat [B, N, L] tensor), the mask mpg_rank_mask's.
+__global__ __launch_bounds__(256) void normal_rank_mask_kernel(float* __restrict__ out, int N, int L, const uint64_t* __restrict__ seed,
+                                                               uint32_t tag, float mean, float std, const float* __restrict__ labels,
+                                                               int ld_lab, float* __restrict__ mask, float* __restrict__ ignore) {
+    extern __shared__ float first[];   // [N]: the first feature of every particle
+    const uint64_t sd = *seed;
+    const uint32_t lo = (uint32_t)sd, hi = (uint32_t)(sd >> 32);
+    const int b = blockIdx.x;
+    const size_t per_jet = (size_t)N * L, pair0 = (size_t)b * per_jet / 2, npair = per_jet / 2;   // (N L even: checked by the launcher)
+    for (size_t q = threadIdx.x; q < npair; q += blockDim.x) {
+        const size_t i = pair0 + q;
+        uint32_t a = drop_word(lo, hi, tag, (uint32_t)i, (uint32_t)(i >> 32));
+        uint32_t c = drop_word(hi ^ 0x9E3779B9u, lo, tag + 0x7F4A7C15u, (uint32_t)i ^ a, (uint32_t)(i >> 32) + 1u);
+        const float u1 = ((float)(a >> 8) + 0.5f) * (1.f / 16777216.f);
+        const float u2 = ((float)(c >> 8) + 0.5f) * (1.f / 16777216.f);
+        const float r = sqrtf(-2.f * logf(u1)) * std;
+        float sn, cs;
+        sincosf(6.283185307179586f * u2, &sn, &cs);
+        const float v0 = mean + r * cs, v1 = mean + r * sn;
+        out[2 * i] = v0;
+        out[2 * i + 1] = v1;
+        const size_t e0 = 2 * q;                       // element index within the jet
+        if (e0 % L == 0) first[e0 / L] = v0;
+        if ((e0 + 1) % L == 0) first[(e0 + 1) / L] = v1;   // (L == 1 only)
+    }
+    __syncthreads();
+    const int n_minus_1 = (int)(labels[(size_t)b * ld_lab] * (float)N) - 1;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const float xi = first[i];
+        int rank = 0;
+        for (int j = 0; j < N; ++j) {
+            const float xj = first[j];
+            rank += (xj < xi) || (xj == xi && j < i);
+        }
+        mask[(size_t)b * N + i] = rank <= n_minus_1 ? 1.f : 0.f;
+        if (ignore != nullptr) ignore[(size_t)b * N + i] = rank <= n_minus_1 ? 0.f : 1.f;
+    }
+}
+
 inline int nblocks(uint64_t n) { return (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048); }
 }  // namespace
 
@@ -123,5 +164,14 @@ extern "C" int mpg_normal(float* out, uint64_t n, const uint64_t* seed, uint32_t
     if (n == 0) return 0;
     if (seed == nullptr || !(std >= 0.f)) return -1;
     hipLaunchKernelGGL(normal_kernel, dim3(nblocks((n + 1) / 2)), dim3(256), 0, (hipStream_t)stream, out, (size_t)n, seed, tag, mean, std);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mpg_normal_rank_mask(float* out, int B, int N, int L, const uint64_t* seed, uint32_t tag, float mean, float std,
+                                    const float* labels, int ld_lab, float* mask, float* ignore, void* stream) {
+    if (B <= 0 || N <= 0 || L <= 0 || N > 8192 || ((size_t)N * L) % 2) return -1;
+    if (seed == nullptr || labels == nullptr || mask == nullptr || !(std >= 0.f)) return -1;
+    hipLaunchKernelGGL(normal_rank_mask_kernel, dim3(B), dim3(256), N * sizeof(float), (hipStream_t)stream, out, N, L, seed, tag, mean,
+                       std, labels, ld_lab, mask, ignore);
     return (int)hipGetLastError();
 }

@@ -319,13 +319,22 @@ class GAPT_G(nn.Module):
         x = torch.tanh(x)
         return torch.cat((x, mask - 0.5), dim=2) if mask is not None else x
 
-    def generate_parts(self, x: Tensor, labels: Tensor, feat_out: Tensor = None, mask_out: Tensor = None, ign_out: Tensor = None):
+    def noise_mask_ok(self) -> bool:
+        """The mask is a function of the input noise alone: a caller may draw both in one launch (``ops.normal_noise_masked``)
+        and hand the masks in as ``premask``."""
+        return bool(self.use_mask)
+
+    def generate_parts(self, x: Tensor, labels: Tensor, feat_out: Tensor = None, mask_out: Tensor = None, ign_out: Tensor = None,
+                       premask=None):
         """``forward`` without gluing the mask column on: (particle features [B, N, F] after tanh, mask [B, N, 1], 1 - mask
-        [B, N]); see ``MPGenerator.generate_parts``."""
+        [B, N]); see ``MPGenerator.generate_parts``.  ``premask``: (mask [B, N], 1 - mask) already drawn with the noise."""
         assert x.is_cuda and self.use_mask
         B = x.shape[0]
-        mask2d, ign = ops.rank_mask(x[:, :, 0], labels, self.num_particles, out=None if mask_out is None else mask_out.view(B, -1),
-                                    with_ignore=True, ignore_out=None if ign_out is None else ign_out.view(B, -1))
+        if premask is not None:
+            mask2d, ign = premask
+        else:
+            mask2d, ign = ops.rank_mask(x[:, :, 0], labels, self.num_particles, out=None if mask_out is None else mask_out.view(B, -1),
+                                        with_ignore=True, ignore_out=None if ign_out is None else ign_out.view(B, -1))
         mask = mask2d.unsqueeze(2)
         am = _ignore_mask(ign.unsqueeze(2))
         x = _run_sabs(self.sabs, x, am)
@@ -344,14 +353,17 @@ class GAPT_G(nn.Module):
         lin = fc.net[0]
         return lin.weight, lin.bias, ops.ACT_CODES["tanh"]
 
-    def generate_rows(self, x: Tensor, labels: Tensor, mask_out: Tensor = None, ign_out: Tensor = None):
+    def generate_rows(self, x: Tensor, labels: Tensor, mask_out: Tensor = None, ign_out: Tensor = None, premask=None):
         """``generate_parts`` up to the last attention block: (rows [B, N, E] that ``final_fc`` would take, mask [B, N, 1],
         1 - mask [B, N]) -- for a caller that runs ``final_fc``, the tanh and the discriminator's embedding as one launch
         (``GAPT_D.features_rows``)."""
         assert x.is_cuda and self.use_mask
         B = x.shape[0]
-        mask2d, ign = ops.rank_mask(x[:, :, 0], labels, self.num_particles, out=None if mask_out is None else mask_out.view(B, -1),
-                                    with_ignore=True, ignore_out=None if ign_out is None else ign_out.view(B, -1))
+        if premask is not None:
+            mask2d, ign = premask
+        else:
+            mask2d, ign = ops.rank_mask(x[:, :, 0], labels, self.num_particles, out=None if mask_out is None else mask_out.view(B, -1),
+                                        with_ignore=True, ignore_out=None if ign_out is None else ign_out.view(B, -1))
         return _run_sabs(self.sabs, x, _ignore_mask(ign.unsqueeze(2))), mask2d.unsqueeze(2), ign
 
     def generate_into(self, x: Tensor, labels: Tensor, out: Tensor) -> Tensor:

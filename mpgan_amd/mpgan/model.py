@@ -507,14 +507,23 @@ class MPGenerator(MPNet):
         x = self._run_layers(x, use_mask, mask, labels, njp)
         return ops.gen_tail_into(x, mask, ops.ACT_CODES[self.final_activation], out)
 
-    def generate_parts(self, x: Tensor, labels: Tensor, feat_out: Tensor = None, mask_out: Tensor = None, ign_out: Tensor = None):
+    def noise_mask_ok(self) -> bool:
+        """The mask is a function of the input noise alone (mask_c on the noise's own first feature: no latent layer in
+        front): a caller may draw both in one launch (``ops.normal_noise_masked``) and hand the mask in as ``premask``."""
+        return bool(self.mask_args.get("mask_c", True)) and not self.mask_args.get("mask_feat_bin", False) and not self.lfc
+
+    def generate_parts(self, x: Tensor, labels: Tensor, feat_out: Tensor = None, mask_out: Tensor = None, ign_out: Tensor = None,
+                       premask=None):
         """``forward`` without gluing the mask column on: (particle features [B, N, F] after the final activation, mask
         [B, N, 1], None).  A discriminator's ``features_parts`` takes them as they are -- no mask column to write, to split off
         again and to pad a gradient for (``train.TrainStep``; the modules' ``forward`` keeps the reference's [B, N, F+1]
         tensors).  ``feat_out`` / ``mask_out`` (without gradients): the caller's rows to write into."""
         assert x.is_cuda and self.mask_args.get("mask_c", True) and not self.mask_args.get("mask_feat_bin", False)
         x = self._pre_mp(x, labels)
-        mask2d = ops.rank_mask(x[:, :, 0], labels, self.num_particles, out=None if mask_out is None else mask_out.view(x.shape[0], -1))
+        if premask is not None:       # (mask [B, N], 1 - mask) drawn with the noise
+            mask2d = premask[0]
+        else:
+            mask2d = ops.rank_mask(x[:, :, 0], labels, self.num_particles, out=None if mask_out is None else mask_out.view(x.shape[0], -1))
         mask = mask2d.unsqueeze(2)
         x = self._run_layers(x, True, mask, labels, None)
         act = ops.ACT_CODES[self.final_activation]

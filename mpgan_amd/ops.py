@@ -336,6 +336,23 @@ def gate(g, H, *, gate_act, alpha, seed_t=None, tag=0, thr=0, scale=1.0):
     return out
 
 
+def normal_noise_masked(shape, std: float, labels: torch.Tensor, site: int = 0, device="cuda", mean: float = 0.0,
+                        mask_out: Optional[torch.Tensor] = None, ignore_out: Optional[torch.Tensor] = None):
+    """``normal_noise`` of a generator's input [B, N, L] AND ``rank_mask`` of its first feature (the jets' masks, mask_c of
+    mpgan/model.py:689-699) in one launch: (noise, mask [B, N], 1 - mask [B, N]).  Same values as the two calls."""
+    B, N, L = shape
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    lab = labels[:, -1]
+    if lab.dtype != torch.float32:
+        lab = lab.float()
+    mask = mask_out if mask_out is not None else torch.empty((B, N), device=device, dtype=torch.float32)
+    ign = ignore_out if ignore_out is not None else torch.empty((B, N), device=device, dtype=torch.float32)
+    assert mask.is_contiguous() and ign.is_contiguous() and mask.numel() == B * N and ign.numel() == B * N
+    check(_lib.lib().mpg_normal_rank_mask(_p(out), B, N, L, _p(seed_tensor(out.device)), NOISE_TAG + int(site), mean, std,
+                                          _p(lab), lab.stride(0), _p(mask), _p(ign), _stream()), "mpg_normal_rank_mask")
+    return out, mask.view(B, N), ign.view(B, N)
+
+
 def dropout_mask(rows: int, F: int, tag: int, thr: int, device="cuda"):
     """The {0,1} keep mask [rows, F] of dropout site ``tag`` under the current seed (tests)."""
     out = torch.empty((rows, F), device=device, dtype=torch.float32)
@@ -1500,6 +1517,7 @@ class GenDiscBridgeFn(torch.autograd.Function):
         q.e, q.lde = _p(e), E
         check(_lib.lib().mpg_bridge_fwd(q, _stream()), "mpg_bridge_fwd")
         ctx.save_for_backward(pre2, W1, W2, feat, e)
+        ctx.set_materialize_grads(False)   # (feat usually goes nowhere else: no zeros filled in for its gradient)
         ctx.params = (W1, b1, W2, b2)
         ctx.cfg = (Bg, B, N, K, F, E, int(act1), int(act2), alpha, thr, dscale, tag)
         return (feat if feat_buf is None else None), e   # (a caller's own batch is written in place: nothing new to hand back)
@@ -1511,6 +1529,8 @@ class GenDiscBridgeFn(torch.autograd.Function):
         W1, b1, W2, b2 = ctx.params
         Bg, B, N, K, F, E, act1, act2, alpha, thr, dscale, tag = ctx.cfg
         need = ctx.needs_input_grad
+        if ge is None:   # (only feat was used downstream)
+            ge = torch.zeros((B, N, E), device=pre2.device, dtype=torch.float32)
         want1 = need[1] or (b1 is not None and need[2])
         want2 = need[4] or (b2 is not None and need[5])
         M, row0 = B * N, (B - Bg) * N

@@ -382,6 +382,8 @@ class TrainStep:
         self.wgrad_side = dev.type == "cuda" and os.environ.get("MPG_WGRAD_SIDE", "1") != "0"
         self._wside = None
         self.bridge = dev.type == "cuda" and os.environ.get("MPG_BRIDGE", "1") != "0"
+        # the generator's noise and its jets' masks drawn by one launch (MPG_NOISE_MASK=0: mpg_normal, then mpg_rank_mask)
+        self.noise_mask = dev.type == "cuda" and os.environ.get("MPG_NOISE_MASK", "1") != "0"
         self.fixed_noise = None  # tests: (noise_D, noise_G) used instead of fresh samples
         self._seen_versions = (self.fD.versions(), self.fG.versions())
         # the flat gradient buffers start as zeros and every optimizer launch of an iteration leaves them cleared again
@@ -396,6 +398,17 @@ class TrainStep:
         if self.dev.type == "cuda":   # counter-based, keyed by the device seed (bumped once per iteration) and the draw's site
             return ops.normal_noise((self.B, self.N, self.latent), self.noise_std, site=which, device=self.dev)
         return torch.empty(self.B, self.N, self.latent, device=self.dev).normal_(0.0, self.noise_std)
+
+    def _noise_masked(self, which: int, mask_out=None, ign_out=None):
+        """(noise, premask): the generator's input and -- when its mask depends on nothing else (``noise_mask_ok``) -- the
+        jets' masks from the same launch, written into the caller's rows when given; premask None otherwise."""
+        if (self.fixed_noise is None and self.noise_mask and self.dev.type == "cuda"
+                and getattr(self.G, "noise_mask_ok", lambda: False)() and (self.N * self.latent) % 2 == 0):
+            z, m, ig = ops.normal_noise_masked((self.B, self.N, self.latent), self.noise_std, self.labels, site=which, device=self.dev,
+                                               mask_out=None if mask_out is None else mask_out.view(self.B, -1),
+                                               ignore_out=None if ign_out is None else ign_out.view(self.B, -1))
+            return z, (m, ig)
+        return self._noise(which), None
 
     def _fused_ends(self) -> bool:
         """Generator able to write its jets into a caller-owned batch and discriminator whose pooling / last Linear /
@@ -456,7 +469,8 @@ class TrainStep:
         self._side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self._side):
             if self.parts and self._fused_ends():
-                self._fake_ahead = self.G.generate_parts(self._noise(1), self.labels)
+                z, pm = self._noise_masked(1)
+                self._fake_ahead = self.G.generate_parts(z, self.labels, premask=pm)
             else:
                 self._fake_ahead = self.G(self._noise(1), self.labels)
         for t in (self._fake_ahead if isinstance(self._fake_ahead, tuple) else (self._fake_ahead,)):
@@ -469,14 +483,16 @@ class TrainStep:
             B = self.B
             if self.parts and self._bridge():
                 with torch.no_grad():
-                    pre, _, _ = self.G.generate_rows(self._noise(0), self.labels, mask_out=self._mask2[B:], ign_out=self._ign2[B:])
+                    z, pm = self._noise_masked(0, self._mask2[B:], self._ign2[B:])
+                    pre, _, _ = self.G.generate_rows(z, self.labels, mask_out=self._mask2[B:], ign_out=self._ign2[B:], premask=pm)
                     W1, b1, act1 = self.G.bridge_head()
                 # (the generator takes no gradient in train_D: its final_fc enters the launch as plain data)
                 head = (W1.detach(), None if b1 is None else b1.detach(), act1)
                 y, mask = self.D.features_rows(pre, head, self._x3, self._mask2, self._labels2, ignore=self._ign2)
             elif self.parts:
                 with torch.no_grad():
-                    self.G.generate_parts(self._noise(0), self.labels, feat_out=self._x3[B:], mask_out=self._mask2[B:], ign_out=self._ign2[B:])
+                    z, pm = self._noise_masked(0, self._mask2[B:], self._ign2[B:])
+                    self.G.generate_parts(z, self.labels, feat_out=self._x3[B:], mask_out=self._mask2[B:], ign_out=self._ign2[B:], premask=pm)
                 y, mask = self.D.features_parts(self._x3, self._mask2, self._labels2, ignore=self._ign2)
             else:
                 with torch.no_grad():
@@ -560,9 +576,14 @@ class TrainStep:
         parts = self.parts and self._fused_ends()
         bridge = parts and fake is None and self._bridge()
         if bridge:
-            fake = self.G.generate_rows(self._noise(1), self.labels)
+            z, pm = self._noise_masked(1)
+            fake = self.G.generate_rows(z, self.labels, premask=pm)
         elif fake is None:
-            fake = self.G.generate_parts(self._noise(1), self.labels) if parts else self.G(self._noise(1), self.labels)
+            if parts:
+                z, pm = self._noise_masked(1)
+                fake = self.G.generate_parts(z, self.labels, premask=pm)
+            else:
+                fake = self.G(self._noise(1), self.labels)
         if bridge:
             y, mask = self.D.features_rows(fake[0], self.G.bridge_head(), None, fake[1], self.labels, ignore=fake[2])
             dy = self._head_loss(y, mask, True, self.B, self.G_loss, False)

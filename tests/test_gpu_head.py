@@ -188,3 +188,21 @@ def test_normal_noise_stream():
     ks = float((cdf - torch.arange(1, n + 1, dtype=torch.float64) / n).abs().max())
     assert ks < 2.0 / math.sqrt(n), ks      # (1.36 / sqrt(n) is the 5 % point of the Kolmogorov statistic)
     assert float(z.abs().max()) > 4.5       # the tails are there
+
+
+def test_noise_and_masks_from_one_launch_equal_the_two_calls():
+    """``ops.normal_noise_masked`` (mpg_normal_rank_mask) against ``ops.normal_noise`` + ``ops.rank_mask``: the same noise,
+    the same masks, bit for bit; odd batch, labels as the trainer holds them."""
+    from mpgan_amd import ops
+    dev = torch.device("cuda:0")
+    B, N, L = 37, 30, 32
+    rs = np.random.RandomState(1)
+    labels = torch.from_numpy(rs.randint(1, N + 1, size=(B, 1)) / N).float().to(dev)
+    ops.set_seed(2024, dev)
+    z0 = ops.normal_noise((B, N, L), 0.2, site=1, device=dev)
+    m0, i0 = ops.rank_mask(z0[:, :, 0], labels, N, with_ignore=True)
+    mask_rows = torch.full((2 * B, N), -1.0, device=dev)
+    z1, m1, i1 = ops.normal_noise_masked((B, N, L), 0.2, labels, site=1, device=dev, mask_out=mask_rows[B:])
+    assert torch.equal(z0, z1) and torch.equal(m0, m1) and torch.equal(i0, i1)
+    assert torch.equal(mask_rows[B:], m0) and bool((mask_rows[:B] == -1).all())
+    assert float(m0.sum(1).sub(labels[:, 0] * N).abs().max()) < 0.5
