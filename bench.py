@@ -321,6 +321,19 @@ def _work(name, a):
             return fl, 4 * o.B * E * (L + cross * S + L + (2 * L if o.save_z else 0)) + wts
         rows_out = (L if o.dx else 0) + (S if o.dy else 0) + ((L + 2 * S + 2 * L) if o.dza else 0)
         return 2 * fl, 4 * o.B * E * (L + cross * S + 2 * L + rows_out) + 2 * wts
+    if name == "mpg_mab_chain_fwd":   # the blocks of mpg_mab_fwd back to back: a block's input rows are the registers of the one before
+        fl = by = 0
+        for b in range(o.n):
+            q = o.blk[b]
+            fl += q.B * (2 * q.E * q.E * 3 * q.L + 4 * q.L * q.L * q.E + 4 * q.L * q.E * q.E)
+            by += 4 * q.B * q.E * (q.L + (2 * q.L if q.save_z else 0)) + 4 * 5 * q.E * q.E
+        return fl, by + 4 * o.blk[0].B * o.blk[0].E * o.blk[0].L
+    if name == "mpg_bridge_fwd":      # rows in (K) -> features (F) -> rows out (E)
+        gen = o.M - o.row0
+        return 2 * gen * o.K * o.F + 2 * o.M * o.F * o.E, 4 * (gen * o.K + o.M * o.F + o.M * o.E)
+    if name == "mpg_bridge_bwd":
+        gen = o.M - o.row0
+        return 2 * gen * o.K * o.F + 2 * o.M * o.F * o.E, 4 * (2 * o.M * o.E + (o.M * o.E if o.g2 else 0) + (gen * o.K if o.dx else 0))
     if name == "mpg_gemm":
         return 2 * o.M * o.N * o.K, 4 * (o.M * o.K + o.N * o.K + o.M * o.N * (2 if o.resid else 1))
     if name == "mpg_chain":

@@ -119,9 +119,15 @@ __global__ __launch_bounds__(256) void disc_head_fwd_kernel(const MpgDiscHead p)
     float z = 0.f, msum = 0.f;
     for (int f0 = 0; f0 < p.F; f0 += 32) {
         const int f = f0 + (lane & 31);
-        float acc = 0.f;
+        // (four particles of the lane's parity in flight at a time: one dependent load after the other, the 75 steps of a
+        // 150-particle jet took 37 us)
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        auto term = [&](int i) {
+            return i < p.N ? (p.mask ? p.mask[(size_t)b * p.N + i] : 1.f) * yb[(size_t)i * p.ldy + f] : 0.f;
+        };
         if (f < p.F)
-            for (int i = lane >> 5; i < p.N; i += 2) acc += (p.mask ? p.mask[(size_t)b * p.N + i] : 1.f) * yb[(size_t)i * p.ldy + f];
+            for (int i = lane >> 5; i < p.N; i += 8) { a0 += term(i); a1 += term(i + 2); a2 += term(i + 4); a3 += term(i + 6); }
+        float acc = (a0 + a1) + (a2 + a3);
         acc += __shfl_xor(acc, 32, 64);              // both particle parities
         if (p.pooled != nullptr && lane < 32 && f < p.F) p.pooled[(size_t)b * p.F + f] = acc;   // (un-normalised sum)
         z += (lane < 32 && f < p.F) ? acc * p.w[f] : 0.f;

@@ -39,7 +39,7 @@ for c in SQ FETCH_SIZE WRITE_SIZE; do
   rm -rf $o
   if [ $c = SQ ]; then ctrs="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE"; else ctrs=$c; fi
   rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $o -o p -- python3 $R/bench.py --model gapt --steps 3 --warmup 2 --no-graphs --no-roofline --no-cpu-baseline > $o.log 2>&1 || { tail -5 $o.log; exit 1; }
-  for k in "mab_fwd_kernel<2, false" "mab_bwd_kernel<2, false" "mab_fwd_kernel<2, true" "mab_bwd_kernel<2, true"; do
+  for k in "mab_chain_fwd2_kernel<4" "mab_chain_fwd2_kernel<8" "mab_fwd2_kernel<true, 4" "mab_fwd2_kernel<true, 8" "mab_bwd2_kernel<false" "mab_bwd2_kernel<true" "mab_bwd_kernel<2, false" "mab_bwd_kernel<2, true" bridge_fwd_kernel bridge_bwd_kernel; do
     echo "== $c $k"; python3 $R/tools/pmc_summary.py $o "$k"
   done
 done > $R/gpurun_out/final/pmc_gapt_summary.txt 2>&1
