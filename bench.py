@@ -287,7 +287,8 @@ def run_workload(torch, dist, model, B, N, steps, warmup, dev, rank, world, pg, 
 # --------------------------------------------------------------------------- roofline leg
 def _work(name, a):
     """(algorithmic FLOPs, algorithmic HBM bytes) of one launch of entry point ``name`` with arguments ``a``."""
-    o = a[0]._obj if hasattr(a[0], "_obj") else None
+    import ctypes
+    o = a[0]._obj if hasattr(a[0], "_obj") else (a[0] if isinstance(a[0], ctypes.Structure) else None)   # (byref(struct) or the struct itself)
     if name == "mpg_edge_fwd_fn":   # the edge forward's two dense layers + the node network's three, one launch
         c = a[1]._obj
         edges, rows = o.B * o.N * o.N, o.B * o.N
