@@ -139,28 +139,44 @@ MPG_DEV void edge_bwd_body(const MpgEdgeBwd& p, const MpgChain* const cdxp, cons
     float* lmx = reinterpret_cast<float*>(smem + B2_LDS_BYTES - 16);                // wave maxima of |dagg|
 
     // ---- prologue (whole workgroup): weights and the per-receiver tiles into LDS, the list of unmasked senders
-    copy_to_lds(l3t, t3g, 2 * NF3T * 64, tid);
+    // Order of issue as in the forward (edge_fwd2_impl.h): the receivers' rows of dagg and a into registers, then W3^T's image by
+    // LDS-DMA; the registers go to LDS when everything has landed -- one wait for the whole prologue.
     // upstream gradient dagg (scaled) and the layer-1 receiver term a, both in the register order the chain layout
     // wants (zeros for padding lanes: they carry exact zeros all the way down)
+    static_assert(T3 * 4 * 64 == 6 * 256 && T1 * 4 * 64 == 3 * 256, "the prologue's register sets");
+    float4 dv[6], av[3];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int t = tid + 256 * u;
+        const int ln = t & 63, mg = t >> 6, rr = ln & 31, hh = ln >> 5, ii = min(rb * 32 + rr, p.N - 1);
+        const float* di = p.dagg + (size_t)(b * p.N + ii) * p.ld_dagg + 32 * (mg >> 2) + 8 * (mg & 3) + 4 * hh;
+        dv[u] = make_float4(di[0], di[1], di[2], di[3]);
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int t = tid + 256 * u;
+        const int ln = t & 63, qsu = t >> 6, rr = ln & 31, hh = ln >> 5, ii = min(rb * 32 + rr, p.N - 1);
+        av[u] = ld4(p.a + (size_t)(b * p.N + ii) * ldac + 8 * qsu + 4 * hh);
+    }
+    fill_lds_dma(l3t, t3g, 2 * NF3T * 1024, tid);
     float amax = 0.f;
-    for (int t = tid; t < T3 * 4 * 64; t += 256) {
-        const int ln = t & 63, mg = t >> 6, rr = ln & 31, hh = ln >> 5, ii = rb * 32 + rr;
-        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ii < p.N) {
-            const float* di = p.dagg + (size_t)(b * p.N + ii) * p.ld_dagg + 32 * (mg >> 2) + 8 * (mg & 3) + 4 * hh;
-            v4 = make_float4(di[0] * p.agg_scale, di[1] * p.agg_scale, di[2] * p.agg_scale, di[3] * p.agg_scale);
-        }
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int t = tid + 256 * u;
+        const bool in = rb * 32 + (t & 31) < p.N;
+        const float4 v4 = in ? make_float4(dv[u].x * p.agg_scale, dv[u].y * p.agg_scale, dv[u].z * p.agg_scale, dv[u].w * p.agg_scale)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
         ldg[t] = v4;
         amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v4.x), fabsf(v4.y))), fmaxf(fabsf(v4.z), fabsf(v4.w)));
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
     if (lane == 0) lmx[w] = amax;
-    for (int t = tid; t < T1 * 4 * 64; t += 256) {
-        const int ln = t & 63, qsu = t >> 6, rr = ln & 31, hh = ln >> 5, ii = rb * 32 + rr;
-        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ii < p.N) v4 = ld4(p.a + (size_t)(b * p.N + ii) * ldac + 8 * qsu + 4 * hh);
-        la[t] = make_float4(v4.x * SC_A, v4.y * SC_A, v4.z * SC_A, v4.w * SC_A);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int t = tid + 256 * u;
+        const bool in = rb * 32 + (t & 31) < p.N;
+        la[t] = in ? make_float4(av[u].x * SC_A, av[u].y * SC_A, av[u].z * SC_A, av[u].w * SC_A) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if constexpr (NQ > 0)
         for (int t = tid; t < NQ * H1; t += 256) lwq[t] = p.wq[t] * SC_A;

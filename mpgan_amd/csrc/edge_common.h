@@ -48,6 +48,17 @@ MPG_DEV V img_frag(__amdgpu_buffer_rsrc_t r, int lane16, int frag) {
     return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(r, lane16, frag * 1024, 0));
 }
 
+// global -> LDS copy by LDS-DMA: 1 KiB per wave-instruction straight into LDS (lane-linear: the image in LDS is the image in
+// memory), no registers, every piece of a wave in flight at once -- behind it the kernel's other prologue loads land while
+// the image streams in (tools/ubench/fill_rate.hip: 120 KiB on four waves in ~4,000 clk at the texture path's 28 B/clk/CU;
+// the register copy below took two dependent passes of 16 loads + 16 ds_writes each)
+MPG_DEV void fill_lds_dma(void* dst, const void* src, int bytes, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int c = wave; c < bytes / 1024; c += 4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(src) + c * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(static_cast<char*>(dst) + c * 1024), 16, 0, 0);
+}
+
 // global -> LDS copy with 16 x 16 B loads in flight per thread (a plain copy loop runs one L2 round
 // trip per iteration: ~10 us for the 150 KiB of weight images)
 template <typename V>

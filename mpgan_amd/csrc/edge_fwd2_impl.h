@@ -105,15 +105,36 @@ MPG_DEV void edge_fwd_body(const MpgEdgeFwd& p, const MpgChain* const cp, const 
 
     // ---- prologue (whole workgroup): W3 and the receivers' layer-1 terms into LDS, biases in the accumulators' scales,
     //      the list of the chunk's senders (the unmasked ones: a zero-masked sender adds exactly 0)
-    copy_to_lds(l3, g3, 2 * NF3 * 64, tid);
-    for (int t = tid; t < H2 + H3; t += 256) lb2[t] = t < H2 ? p.b2[t] * SC_E2 : p.b3[t - H2] * SC_E3;
+    // Order of issue: the small loads first (biases, the receivers' rows of a: into registers), then W3's image by LDS-DMA;
+    // the registers go to LDS once everything has landed -- ONE wait for the whole prologue instead of a round trip per piece
+    // (two copy passes, biases, rows: four, each behind the one before).
+    static_assert(H2 + H3 <= 2 * 256 && T1 * 4 * 64 == 3 * 256, "the prologue's register sets");
+    float bv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = min(tid + 256 * u, H2 + H3 - 1);
+        bv[u] = t < H2 ? p.b2[t] : p.b3[t - H2];
+    }
+    float4 av[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int t = tid + 256 * u;
+        const int ln = t & 63, qsu = t >> 6, rr = ln & 31, hh = ln >> 5, ii = min(rb * 32 + rr, p.N - 1);
+        av[u] = ld4(p.a + (size_t)(b * p.N + ii) * ldac + 8 * qsu + 4 * hh);
+    }
+    fill_lds_dma(l3, g3, 2 * NF3 * 1024, tid);
     if constexpr (NQ > 0)
         for (int t = tid; t < NQ * H1; t += 256) reinterpret_cast<float*>(smem + F2_Q_OFF)[t] = p.wq[t] * SC_A;
-    for (int t = tid; t < T1 * 4 * 64; t += 256) {
-        const int ln = t & 63, qsu = t >> 6, rr = ln & 31, hh = ln >> 5, ii = rb * 32 + rr;
-        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ii < p.N) v4 = ld4(p.a + (size_t)(b * p.N + ii) * ldac + 8 * qsu + 4 * hh);
-        la[t] = make_float4(v4.x * SC_A, v4.y * SC_A, v4.z * SC_A, v4.w * SC_A);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = tid + 256 * u;
+        if (t < H2 + H3) lb2[t] = bv[u] * (t < H2 ? SC_E2 : SC_E3);
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int t = tid + 256 * u;
+        const bool in = rb * 32 + (t & 31) < p.N;
+        la[t] = in ? make_float4(av[u].x * SC_A, av[u].y * SC_A, av[u].z * SC_A, av[u].w * SC_A) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // A jet whose senders all fit the list (N <= F2_LIST_MAX) is listed WHOLE and the list cut into SC equal parts: chunks by
     // sender index are as uneven as the mask (150 particles, 117 unmasked, 3 chunks: 50 / 50 / 17 senders -- the launch lasts
