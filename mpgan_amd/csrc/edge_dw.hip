@@ -313,6 +313,21 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
 
     const bool third = cg < 4;  // chunk groups 0..3 own a third 160-feature piece and a second E1 chunk
     auto e1tile = [&](int n) { return n == 0 || third ? 2 * n + (cg >> 2) : (cg >> 2); };  // 0..2
+    // p = 1/2 (one keep BIT per element, one hashed word per (edge row, 32-feature tile)): the four adjacent lanes that hold one
+    // receiver's chunk groups need the SAME five words of a block -- the dZ3 tiles 2n + (cg >> 2), n = 0..2, and the E1 tiles
+    // e1tile(0), e1tile(1) -- and used to hash all five each.  Now lane q of the quad hashes word q (one instruction sequence for
+    // four different words: the site and tile ride in a per-lane constant), everyone word four, and a DPP quad broadcast hands
+    // them round: two hash sequences + five moves per block instead of five sequences (a tenth of what a builder wave issues; measured
+    // in tools/ubench/dw_bench.hip: 115.5 -> 113.6 us at 512 jets, 70.4 -> 69.8 at 256 -- the builders are not bound by what they
+    // issue alone: the sections that request memory take 1.0k of a block's 3.6k clk for ~100 instructions).
+    uint32_t hcA = 0, hcB = 0;   // (grp + tag * 0x10001) * 0x85EBCA77 + seed_hi of drop_word, for this lane's word / the fifth
+    if constexpr (DROP == 2) {
+        const int ql = bt & 3;
+        const uint32_t tagA = p.tag_base + (ql < 3 ? TAG_E2 : TAG_E0);
+        const uint32_t grpA = DROP_BIT_GRP + (uint32_t)(ql < 3 ? 2 * ql + (cg >> 2) : e1tile(0));
+        hcA = (grpA + tagA * 0x10001u) * 0x85EBCA77u + seed_hi;
+        hcB = (DROP_BIT_GRP + (uint32_t)e1tile(1) + (p.tag_base + TAG_E0) * 0x10001u) * 0x85EBCA77u + seed_hi;
+    }
     // Threads of chunk groups 4..7 have no third piece of the 160-feature tensors (and no second E1 chunk): they
     // redo their previous piece instead (same data to the same place), which keeps the whole build free of
     // branches -- inside a branch the compiler waits for ALL outstanding loads, i.e. for the prefetches too.
@@ -424,12 +439,29 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
         // sums take it without the factor
         const float in_set = (p.nbr == nullptr || ((S.nbw >> (j & 31)) & 1u)) ? 1.f : 0.f;
         const float dscl_1 = S.dscl * in_set * dth, dscl_a = dscl_1 * p.alpha;   // (the dither factor rides in the slope constants)
-        DW_STAMP(0);   // block setup (index arithmetic, units) -- and whatever the barrier before it cost
+        uint32_t kz3[3] = {0xffu, 0xffu, 0xffu}, ke1[2] = {0xffu, 0xffu};   // keep bits of the block's chunks
+        if constexpr (DROP == 2) {
+            const uint32_t x0 = (erow + seed_lo) * 0x9E3779B1u;
+            auto fin = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; };
+            const uint32_t wA = fin(x0 ^ hcA), wB = fin(x0 ^ hcB);
+            auto bits = [&](uint32_t w) { w >>= f0; return (w & 0xfu) | ((w >> 4) & 0xf0u); };   // bits f0..f0+3 and f0+8..f0+11
+            kz3[0] = bits((uint32_t)__builtin_amdgcn_update_dpp(0, (int)wA, 0x00, 0xf, 0xf, false));   // quad_perm [0,0,0,0]
+            kz3[1] = bits((uint32_t)__builtin_amdgcn_update_dpp(0, (int)wA, 0x55, 0xf, 0xf, false));   // [1,1,1,1]
+            kz3[2] = bits((uint32_t)__builtin_amdgcn_update_dpp(0, (int)wA, 0xAA, 0xf, 0xf, false));   // [2,2,2,2]
+            ke1[0] = bits((uint32_t)__builtin_amdgcn_update_dpp(0, (int)wA, 0xFF, 0xf, 0xf, false));   // [3,3,3,3]
+            ke1[1] = bits(wB);
+        } else if constexpr (DROP == 1) {
+#pragma unroll
+            for (int n = 0; n < 3; ++n) kz3[n] = dw_chunk_keep<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, 2 * n + (cg >> 2), f0, p.thr);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) ke1[n] = dw_chunk_keep<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, e1tile(n), f0, p.thr);
+        }
+        DW_STAMP(0);   // block setup (index arithmetic, units, keep words) -- and whatever the barrier before it cost
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
             const int m = 2 * n + (cg >> 2), c = cg + 8 * n;
             float v[8];
-            const uint32_t keep = dw_chunk_keep<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, m, f0, p.thr);
+            const uint32_t keep = kz3[n];
             // sign bit of element k: bit 31 - (16 (m & 1) + 8 cs + k) of the lane's word -- shifted once so that the bit index
             // is a compile-time constant (v_bfe + v_bfi instead of shift, and, compare, select)
             const uint32_t swn = S.sw[n] << (16 * (m & 1) + 8 * cs);
@@ -456,7 +488,7 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
             const int q = e1tile(n), c = 4 * q + (cg & 3);
             const float cc[8] = {S.cv[n][0].x, S.cv[n][0].y, S.cv[n][0].z, S.cv[n][0].w, S.cv[n][1].x, S.cv[n][1].y, S.cv[n][1].z, S.cv[n][1].w};
             float v[8];
-            const uint32_t keep = dw_chunk_keep<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, q, f0, p.thr);
+            const uint32_t keep = ke1[n];
             float wqv[NQ > 0 ? NQ : 1][8];
             if constexpr (NQ > 0) {
 #pragma unroll
