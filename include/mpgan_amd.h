@@ -417,6 +417,13 @@ typedef struct MpgMab {
     float* dx; int lddx; float* dy; int lddy;
     float* dq; int lddq; float* dk; float* dv; int lddkv;
     float* dza; float* du;
+    /* layer_norm=True (gapt/model.py:118-120, :131-136): nn.LayerNorm(E) behind each residual, or all NULL.  za -> norm1 -> dropout;
+     * z + ff(z) -> norm2 -> dropout.  fwd keeps za (before norm1) in save_za for the backward; bwd writes, per row, the
+     * gradient with respect to each norm's OUTPUT (dn1, dn2: their column sums are the norms' bias gradients) and that times
+     * the normalised input (gn1, gn2: column sums = weight gradients).  One wave per jet (the two-wave kernels step aside). */
+    const float* ln1_w; const float* ln1_b; const float* ln2_w; const float* ln2_b; float ln_eps;
+    float* save_za;
+    float* dn1; float* gn1; float* dn2; float* gn2;
 } MpgMab;
 int mpg_mab_fwd(const MpgMab* p, void* stream);
 int mpg_mab_bwd(const MpgMab* p, void* stream);

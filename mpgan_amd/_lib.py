@@ -181,6 +181,8 @@ class MpgMab(C.Structure):
         ("dout", _fp), ("lddout", C.c_int), ("dx", _fp), ("lddx", C.c_int), ("dy", _fp), ("lddy", C.c_int),
         ("dq", _fp), ("lddq", C.c_int), ("dk", _fp), ("dv", _fp), ("lddkv", C.c_int),
         ("dza", _fp), ("du", _fp),
+        ("ln1_w", _fp), ("ln1_b", _fp), ("ln2_w", _fp), ("ln2_b", _fp), ("ln_eps", C.c_float),
+        ("save_za", _fp), ("dn1", _fp), ("gn1", _fp), ("dn2", _fp), ("gn2", _fp),
     ]
 
 

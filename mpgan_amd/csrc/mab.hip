@@ -242,10 +242,43 @@ MPG_DEV f32x16 key_mask_regs(const float* ignore, const float* safe, long jet, i
 
 struct MabScales { float sa, zs, inv_zs; };
 
+// ---- LayerNorm over the E = 32 NT features of a token (gapt/model.py:118-120: nn.LayerNorm(embed_dim), biased variance).  A
+// token's features sit in the NT tiles' registers of lanes r and r + 32, so the two sums are in-lane adds and one exchange
+// with the other half.  ln_stats: mean and 1 / sqrt(var + eps) (two passes: the variance from the centred values);
+// ln_apply: t -> (t - mean) rstd w + b in place.
+template <int NT>
+MPG_DEV void ln_stats(const f32x16 (&t)[NT], float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += t[tt][i];
+    s += other_half(s);
+    mean = s * (1.f / (32 * NT));
+    float q = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const float d = t[tt][i] - mean; q = fmaf(d, d, q); }
+    q += other_half(q);
+    rstd = 1.f / sqrtf(q * (1.f / (32 * NT)) + eps);
+}
+template <int NT>
+MPG_DEV void ln_apply(f32x16 (&t)[NT], const float* w, const float* b, float eps, int h) {
+    float mean, rstd;
+    ln_stats<NT>(t, eps, mean, rstd);
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        const f32x16 wv = bias_regs(w, tt, h), bv = bias_regs(b, tt, h);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[tt][i] = fmaf((t[tt][i] - mean) * rstd, wv[i], bv[i]);
+    }
+}
+
 // One block on one jet (one wave).  xt: the block's query rows as accumulator-layout tiles on entry, its OUTPUT rows on exit (what
 // the next block of a chain of self-attention blocks takes as its input: mab_chain_fwd_kernel); yt: the key / value rows
 // (CROSS), kneg the additive key mask; the weight images and the pre-scaled biases are in LDS.
-template <int NT, bool CROSS>
+template <int NT, bool CROSS, bool LN = false>
 MPG_DEV void mab_fwd_jet(const MpgMab& p, f32x16 (&xt)[NT], const f32x16* yt, const f32x16& kneg, WImg rIn, WImg rO, WImg rF,
                          const float* sBin, const float* sBo, const float* sBf, const long xrow, const bool xvalid,
                          const uint32_t seed_lo, const uint32_t seed_hi, const float sa, const float inv_zs, const int r, const int h,
@@ -304,18 +337,32 @@ MPG_DEV void mab_fwd_jet(const MpgMab& p, f32x16 (&xt)[NT], const f32x16* yt, co
     // za = x + o Wo' + bo ; z = dropout(za)
     f32x16 z[NT];
     V zh[KS], zl[KS];
+    if constexpr (LN) {
+        // ... with norm1 between the residual and the dropout: every tile of za first (kept for the backward), then the norm
+        static_for<0, NT>([&](auto tc) {
+            MPG_CI(t, tc);
+            const f32x16 acc = proj_n<KS>(rO, nfE, t, oh, ol, bias_regs(sBo, t, h), lane16);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[t][i] = acc[i] * inv_zs + xt[t][i];
+            if (p.save_za != nullptr && xvalid) tile_to_rows(p.save_za, p.E, xrow, t, h, z[t], 1.f);
+        });
+        ln_apply<NT>(z, p.ln1_w, p.ln1_b, p.ln_eps, h);
+    }
     static_for<0, NT>([&](auto tc) {
         MPG_CI(t, tc);
-        const f32x16 acc = proj_n<KS>(rO, nfE, t, oh, ol, bias_regs(sBo, t, h), lane16);
+        if constexpr (!LN) {
+            const f32x16 acc = proj_n<KS>(rO, nfE, t, oh, ol, bias_regs(sBo, t, h), lane16);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) z[t][i] = acc[i] * inv_zs + xt[t][i];
+            for (int i = 0; i < 16; ++i) z[t][i] = acc[i] * inv_zs + xt[t][i];
+        }
         drop_tile(z[t], seed_lo, seed_hi, p.tag + 0, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
         if (p.save_z != nullptr && xvalid) tile_to_rows(p.save_z, p.E, xrow, t, h, z[t], 1.f);
         tile_frag(z[t], 0, sa, zh[2 * t], zl[2 * t]);
         tile_frag(z[t], 1, sa, zh[2 * t + 1], zl[2 * t + 1]);
     });
     MAB_STAMP(4);
-    // out = dropout(z + dropout_ff(LeakyReLU(z Wf' + bf)))
+    // out = dropout([norm2](z + dropout_ff(LeakyReLU(z Wf' + bf))))
+    f32x16 op[LN ? NT : 1];
     static_for<0, NT>([&](auto tc) {
         MPG_CI(t, tc);
         f32x16 u = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(sBf, t, h), lane16);
@@ -327,14 +374,27 @@ MPG_DEV void mab_fwd_jet(const MpgMab& p, f32x16 (&xt)[NT], const f32x16* yt, co
         drop_tile(u, seed_lo, seed_hi, p.tag + 1, (uint32_t)xrow, t, h, p.thr_ff, p.sc_ff);
 #pragma unroll
         for (int i = 0; i < 16; ++i) u[i] += z[t][i];
-        drop_tile(u, seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
-        if (xvalid) tile_to_rows(p.out, p.ldo, xrow, t, h, u, 1.f);
-        xt[t] = u;     // (the block's output rows, as the next block of a chain takes them; z[t] carried the residual)
+        if constexpr (LN) {
+            op[t] = u;
+        } else {
+            drop_tile(u, seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
+            if (xvalid) tile_to_rows(p.out, p.ldo, xrow, t, h, u, 1.f);
+            xt[t] = u;     // (the block's output rows, as the next block of a chain takes them; z[t] carried the residual)
+        }
     });
+    if constexpr (LN) {
+        ln_apply<NT>(op, p.ln2_w, p.ln2_b, p.ln_eps, h);
+        static_for<0, NT>([&](auto tc) {
+            MPG_CI(t, tc);
+            drop_tile(op[t], seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
+            if (xvalid) tile_to_rows(p.out, p.ldo, xrow, t, h, op[t], 1.f);
+            xt[t] = op[t];
+        });
+    }
     MAB_STAMP(5);
 }
 
-template <int NT, bool CROSS>
+template <int NT, bool CROSS, bool LN = false>
 __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
     typedef f16x8 V;
     constexpr int KS = 2 * NT;            // k-steps of 16 over E = 32 NT features
@@ -391,7 +451,7 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
     const bool xvalid = r < p.L;
     // every global load of a jet is issued together: x (kept as tiles for the residual), y, the key mask
     if (jet != jet0) load_rows(jet);
-    mab_fwd_jet<NT, CROSS>(p, xt, yt, kneg, rIn, rO, rF, sBin, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, r, h, lane16, mab_stp);
+    mab_fwd_jet<NT, CROSS, LN>(p, xt, yt, kneg, rIn, rO, rF, sBin, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, r, h, lane16, mab_stp);
     }  // jets of this wave
 #ifdef MPG_MABSTAMP
     if (blockIdx.x == 0 && lane == 0)
@@ -730,7 +790,43 @@ MPG_DEV void acc_wt(WImg rT, int nfragT, int KST, int ks0, const V* fh, const V*
     });
 }
 
-template <int NT, bool CROSS>
+// LayerNorm backward for the tokens of a wave, in place on the gradient tiles: on entry g = dL/d(norm output), xin = the
+// norm's INPUT (its statistics are recomputed); the rows of g and of g * xhat go to dn / gn (their column sums are the norm's
+// bias and weight gradients: the grouped weight-gradient launch adds them up); on exit g = dL/d(norm input):
+//   rstd (g w - mean_f(g w) - xhat mean_f(g w xhat)).
+template <int NT>
+MPG_DEV void ln_backward(f32x16 (&g)[NT], const f32x16 (&xin)[NT], const float* w, float eps, float* dn, float* gn, int E,
+                         long row, bool valid, int h) {
+    float mean, rstd;
+    ln_stats<NT>(xin, eps, mean, rstd);
+    float m1 = 0.f, m2 = 0.f;
+    f32x16 xh[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x16 wv = bias_regs(w, t, h);
+        f32x16 gx;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            xh[t][i] = (xin[t][i] - mean) * rstd;
+            gx[i] = g[t][i] * xh[t][i];
+        }
+        if (dn != nullptr && valid) { tile_to_rows(dn, E, row, t, h, g[t], 1.f); tile_to_rows(gn, E, row, t, h, gx, 1.f); }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            g[t][i] *= wv[i];
+            m1 += g[t][i];
+            m2 = fmaf(g[t][i], xh[t][i], m2);
+        }
+    }
+    m1 += other_half(m1); m2 += other_half(m2);
+    m1 *= 1.f / (32 * NT); m2 *= 1.f / (32 * NT);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g[t][i] = rstd * (g[t][i] - m1 - xh[t][i] * m2);
+}
+
+template <int NT, bool CROSS, bool LN = false>
 __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
     typedef f16x8 VF;
     typedef bf16x8 VB;
@@ -760,11 +856,12 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
     const long jet_raw = (long)blockIdx.x * nw + w;
     const long jet = min(jet_raw, (long)p.B - 1);
     const long xrow = jet * p.L + min(r, p.L - 1), yrow = jet * p.S + min(r, p.S - 1);
-    f32x16 dzf[NT], zt[NT];
+    f32x16 dzf[NT], zt[NT], zat[LN ? NT : 1];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         dzf[t] = rows_to_tile(p.dout, p.lddout, xrow, t, h);
         zt[t] = rows_to_tile(p.save_z, p.E, xrow, t, h);
+        if constexpr (LN) zat[t] = rows_to_tile(p.save_za, p.E, xrow, t, h);
     }
     mab_fill(sIn, p.Win, 2 * nfIn * 1024);
     mab_fill(sF, p.Wf, 2 * nfE * 1024);
@@ -805,12 +902,41 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
         VF zh[KS], zl[KS];
         tiles_to_frags<NT>(zt, sa, zh, zl);
         VB duh[KS], dul[KS];
+        f32x16 ut[LN ? NT : 1];
+        if constexpr (LN) {
+            // norm2 sits between the second residual and the last dropout: its input z + dropout_ff(act(u)) is rebuilt as the
+            // forward built it (u is needed below anyway), the gradient goes through the norm, and dzf is then what it is
+            // without a norm -- the gradient with respect to that sum
+            f32x16 op[NT];
+            static_for<0, NT>([&](auto tc) {
+                MPG_CI(t, tc);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dzf[t][i] *= xlive;
+                drop_tile(dzf[t], seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
+                ut[t] = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(sBf, t, h), lane16);
+                f32x16 a;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float v = ut[t][i] * inv_zs;
+                    a[i] = p.ff_act ? lrelu(v, p.alpha) : v;
+                }
+                drop_tile(a, seed_lo, seed_hi, p.tag + 1, (uint32_t)xrow, t, h, p.thr_ff, p.sc_ff);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) op[t][i] = zt[t][i] + a[i];
+            });
+            ln_backward<NT>(dzf, op, p.ln2_w, p.ln_eps, p.dn2, p.gn2, p.E, xrow, xvalid, h);
+        }
         static_for<0, NT>([&](auto tc) {
             MPG_CI(t, tc);
+            f32x16 u;
+            if constexpr (LN) {
+                u = ut[t];
+            } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) dzf[t][i] *= xlive;
-            drop_tile(dzf[t], seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
-            const f32x16 u = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(sBf, t, h), lane16);
+                for (int i = 0; i < 16; ++i) dzf[t][i] *= xlive;
+                drop_tile(dzf[t], seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
+                u = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(sBf, t, h), lane16);
+            }
             f32x16 du;
 #pragma unroll
             for (int i = 0; i < 16; ++i) du[i] = dzf[t][i] * ((p.ff_act && !(u[i] > 0.f)) ? p.alpha : 1.f);
@@ -819,15 +945,34 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
             tile_frag(du, 0, 1.f, duh[2 * t], dul[2 * t]);
             tile_frag(du, 1, 1.f, duh[2 * t + 1], dul[2 * t + 1]);
         });
-        static_for<0, NT>([&](auto tc) {
-            MPG_CI(t, tc);
-            f32x16 dz = proj_n<KS>(rFT, nfE, t, duh, dul, dzf[t], lane16);
-            drop_tile(dz, seed_lo, seed_hi, p.tag + 0, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
-            if (p.dza != nullptr && xvalid) tile_to_rows(p.dza, p.E, xrow, t, h, dz, 1.f);
-            tile_frag(dz, 0, 1.f, dzah[2 * t], dzal[2 * t]);
-            tile_frag(dz, 1, 1.f, dzah[2 * t + 1], dzal[2 * t + 1]);
-            dxa[t] = dz;
-        });
+        if constexpr (LN) {
+            // dz of every tile, through the first dropout: the gradient with respect to norm1's output; through the norm (its
+            // input za was kept by the forward); what comes out is dza
+            f32x16 dn[NT];
+            static_for<0, NT>([&](auto tc) {
+                MPG_CI(t, tc);
+                dn[t] = proj_n<KS>(rFT, nfE, t, duh, dul, dzf[t], lane16);
+                drop_tile(dn[t], seed_lo, seed_hi, p.tag + 0, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
+            });
+            ln_backward<NT>(dn, zat, p.ln1_w, p.ln_eps, p.dn1, p.gn1, p.E, xrow, xvalid, h);
+            static_for<0, NT>([&](auto tc) {
+                MPG_CI(t, tc);
+                if (p.dza != nullptr && xvalid) tile_to_rows(p.dza, p.E, xrow, t, h, dn[t], 1.f);
+                tile_frag(dn[t], 0, 1.f, dzah[2 * t], dzal[2 * t]);
+                tile_frag(dn[t], 1, 1.f, dzah[2 * t + 1], dzal[2 * t + 1]);
+                dxa[t] = dn[t];
+            });
+        } else {
+            static_for<0, NT>([&](auto tc) {
+                MPG_CI(t, tc);
+                f32x16 dz = proj_n<KS>(rFT, nfE, t, duh, dul, dzf[t], lane16);
+                drop_tile(dz, seed_lo, seed_hi, p.tag + 0, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
+                if (p.dza != nullptr && xvalid) tile_to_rows(p.dza, p.E, xrow, t, h, dz, 1.f);
+                tile_frag(dz, 0, 1.f, dzah[2 * t], dzal[2 * t]);
+                tile_frag(dz, 1, 1.f, dzah[2 * t + 1], dzal[2 * t + 1]);
+                dxa[t] = dz;
+            });
+        }
     }
     MAB_STAMP(3);
     f32x16 dya[CROSS ? NT : 1];
@@ -1288,6 +1433,17 @@ extern "C" int mpg_mab_bwd(const MpgMab* p, void* stream) {
     const bool cross = p->y != p->x;
     const int NT = p->E / 32;
     const int lds = 2 * 1024 * (2 * 3 * NT * 2 * NT + 3 * NT * 2 * NT) + 4 * 128 * NT;   // Win, WinT (3E x E) + Wf, WoT, WfT (E x E) + biases
+    if (p->ln1_w != nullptr) {   // layer_norm=True: one wave per jet
+        if (p->ln2_w == nullptr || p->save_za == nullptr || !(p->ln_eps > 0.f) || (p->dn1 == nullptr) != (p->gn1 == nullptr) ||
+            (p->dn1 == nullptr) != (p->dn2 == nullptr) || (p->dn1 == nullptr) != (p->gn2 == nullptr)) return -6;
+        if (p->E == 64) {
+            if (cross) { MPG_ENSURE_LDS((mab_bwd_kernel<2, true, true>), lds); return mab_launch(mab_bwd_kernel<2, true, true>, p, lds, st, true); }
+            MPG_ENSURE_LDS((mab_bwd_kernel<2, false, true>), lds);
+            return mab_launch(mab_bwd_kernel<2, false, true>, p, lds, st, true);
+        }
+        if (cross) return mab_launch(mab_bwd_kernel<1, true, true>, p, lds, st, true);
+        return mab_launch(mab_bwd_kernel<1, false, true>, p, lds, st, true);
+    }
     if (p->E == 64 && mab_split(p->B)) {
         // two waves per jet, two jets per workgroup
         if (cross) {
@@ -1314,6 +1470,17 @@ extern "C" int mpg_mab_fwd(const MpgMab* p, void* stream) {
     const bool cross = p->y != p->x;
     const int NT = p->E / 32;
     const int lds = 2 * 1024 * (3 * NT * 2 * NT + 2 * NT * 2 * NT) + 4 * 160 * NT;   // Win + Wo, Wf + biases
+    const bool ln = p->ln1_w != nullptr;
+    if (ln) {   // layer_norm=True: one wave per jet (a token's statistics run over both feature tiles)
+        if (p->ln1_b == nullptr || p->ln2_w == nullptr || p->ln2_b == nullptr || !(p->ln_eps > 0.f)) return -6;
+        if (p->E == 64) {
+            if (cross) { MPG_ENSURE_LDS((mab_fwd_kernel<2, true, true>), lds); return mab_launch(mab_fwd_kernel<2, true, true>, p, lds, st); }
+            MPG_ENSURE_LDS((mab_fwd_kernel<2, false, true>), lds);
+            return mab_launch(mab_fwd_kernel<2, false, true>, p, lds, st);
+        }
+        if (cross) return mab_launch(mab_fwd_kernel<1, true, true>, p, lds, st);
+        return mab_launch(mab_fwd_kernel<1, false, true>, p, lds, st);
+    }
     if (const int nw2 = p->E == 64 ? mab_split_fwd_waves(p->B) : 0) {
         const int npair = nw2 / 2, lds2 = lds + npair * 2 * MAB_XCH, grid = (p->B + npair - 1) / npair;
         if (cross && nw2 == 4) { MPG_ENSURE_LDS((mab_fwd2_kernel<true, 4>), lds2); hipLaunchKernelGGL((mab_fwd2_kernel<true, 4>), dim3(grid), dim3(256), lds2, st, *p); }
@@ -1339,7 +1506,7 @@ extern "C" int mpg_mab_chain_fwd(const MpgMabChain* c, void* stream) {
         const MpgMab& p = c->blk[b];
         // self-attention blocks of one shape on one set of jets, each taking the rows the one before it writes
         if (p.y != p.x || p.B != p0.B || p.L != p0.L || p.S != p0.L || p.E != p0.E || p.H != p0.H || p.ignore != p0.ignore ||
-            p.seed != p0.seed || p.wscale != p0.wscale || p.ascale != p0.ascale || p.out == nullptr || p.ldo % 4) return -2;
+            p.seed != p0.seed || p.wscale != p0.wscale || p.ascale != p0.ascale || p.out == nullptr || p.ldo % 4 || p.ln1_w != nullptr) return -2;
         if (b > 0 && (p.x != c->blk[b - 1].out || p.ldx != c->blk[b - 1].ldo)) return -2;
         if (!(p.alpha >= 0.f && p.alpha <= 1.f)) return -4;
     }

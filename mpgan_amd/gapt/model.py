@@ -133,7 +133,7 @@ class MAB(nn.Module):
 
     # -- the whole block as one launch (ops.mab_forward; csrc/mab.hip) ------------------------------------------
     def _fused_ok(self, x: Tensor, L: int, S: int) -> bool:
-        return (MAB.fused and x.is_cuda and not self.layer_norm and len(self.ff.net) == 1 and self.ff.plain
+        return (MAB.fused and x.is_cuda and len(self.ff.net) == 1 and self.ff.plain
                 and ops.mab_fusable(self.embed_dim, self.num_heads, L, S))
 
     def _packed(self) -> "ops.PackedMAB":
@@ -157,13 +157,22 @@ class MAB(nn.Module):
         E = self.embed_dim
         kw = dict(alpha=self.ff.leaky_relu_alpha, ff_act=not self.ff.final_linear, p_mab=self.dropout_p,
                   p_ff=self.ff.dropout_p, training=self.training)
+        ln = (self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, self.norm1.eps) if self.layer_norm else None
         if not torch.is_grad_enabled():
             # (one query row for all jets -- PMA's seed -- is read with row stride 0)
             x2 = x.reshape(1, E).contiguous().expand(B, E) if (x.shape[0] == 1 and B > 1) else x.reshape(B * L, E).contiguous()
             y2 = None if x is y else y.reshape(B * S, E).contiguous()
-            out, _, _, _ = ops.mab_forward(x2, y2, ignore, self._packed(), att.in_proj_bias, att.out_proj.bias, lin.bias,
-                                           B, L, S, self.num_heads, **kw)
+            out = ops.mab_forward(x2, y2, ignore, self._packed(), att.in_proj_bias, att.out_proj.bias, lin.bias,
+                                  B, L, S, self.num_heads, ln=ln, **kw)[0]
             return out.reshape(B, L, E)
+        if ln is not None:   # layer_norm=True: both norms inside the block's launches (ops.FusedMABLayerNormFn)
+            assert self.norm1.eps == self.norm2.eps
+            if x.shape[0] == 1 and B > 1:
+                x = x.expand(B, L, E)     # (a shared query row: autograd sums its gradient over the jets)
+            return ops.FusedMABLayerNormFn.apply(x, None if x is y else y, ignore, att.in_proj_weight, att.in_proj_bias,
+                                                 att.out_proj.weight, att.out_proj.bias, lin.weight, lin.bias, ln[0], ln[1], ln[2], ln[3],
+                                                 ln[4], self.num_heads, kw["alpha"], kw["ff_act"], kw["p_mab"], kw["p_ff"],
+                                                 kw["training"], self._packed())
         return ops.FusedMABFn.apply(x, None if x is y else y, ignore, att.in_proj_weight, att.in_proj_bias,
                                     att.out_proj.weight, att.out_proj.bias, lin.weight, lin.bias, self.num_heads,
                                     kw["alpha"], kw["ff_act"], kw["p_mab"], kw["p_ff"], kw["training"], self._packed())
@@ -223,7 +232,7 @@ def _run_sabs(sabs, x: Tensor, am) -> Tensor:
         run = []
         if chainable:
             while (i + len(run) < len(sabs) and len(run) < MAB_CHAIN_MAX and isinstance(sabs[i + len(run)], SAB)
-                   and sabs[i + len(run)].mab._fused_ok(x, N, N)):
+                   and sabs[i + len(run)].mab._fused_ok(x, N, N) and not sabs[i + len(run)].mab.layer_norm):
                 run.append(sabs[i + len(run)].mab)
             if run and not all(_same_block_config(m, run[0]) for m in run):
                 run = run[:1]

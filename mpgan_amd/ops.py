@@ -1190,10 +1190,18 @@ def _mab_struct(x2, y2, ignore, pk, bin_, bo, bf, B, L, S, E, H, alpha, ff_act, 
     return m
 
 
+def _mab_set_ln(m, ln):
+    if ln is not None:
+        w1, b1, w2, b2, eps = ln
+        m.ln1_w, m.ln1_b, m.ln2_w, m.ln2_b, m.ln_eps = _p(w1), _p(b1), _p(w2), _p(b2), float(eps)
+
+
 def mab_forward(x2, y2, ignore, pk, bin_, bo, bf, B, L, S, H, *, alpha=0.2, ff_act=True, p_mab=0.0, p_ff=0.0,
-                training=False, tag=None, save=False):
+                training=False, tag=None, save=False, ln=None):
     """``mpg_mab_fwd``: x2 [B*L, E] queries, y2 [B*S, E] keys/values or None (self-attention), ignore [B*S] floats or
-    None.  Returns (out [B*L, E], o, z, tag) -- o and z only with ``save`` (what the backward needs)."""
+    None.  Returns (out [B*L, E], o, z, tag) -- o and z only with ``save`` (what the backward needs).  ``ln``: (norm1.weight,
+    norm1.bias, norm2.weight, norm2.bias, eps) of a block with ``layer_norm=True``; ``save`` then also keeps za (the input of
+    norm1) and the return value is (out, o, z, tag, za)."""
     _chk(x2, "x")
     E = x2.shape[1]
     dev = x2.device
@@ -1206,13 +1214,39 @@ def mab_forward(x2, y2, ignore, pk, bin_, bo, bf, B, L, S, H, *, alpha=0.2, ff_a
     z = torch.empty_like(out) if save else None
     m = _mab_struct(x2, y2, ignore, pk, bin_, bo, bf, B, L, S, E, H, alpha, ff_act, tag, thr_mab, sc_mab, thr_ff, sc_ff)
     m.out, m.ldo, m.save_o, m.save_z = _p(out), out.stride(0), _p(o), _p(z)
+    za = None
+    if ln is not None:
+        _mab_set_ln(m, ln)
+        za = torch.empty_like(out) if save else None
+        m.save_za = _p(za)
     check(_lib.lib().mpg_mab_fwd(C.byref(m), _stream()), "mpg_mab_fwd")
-    return out, o, z, tag
+    return (out, o, z, tag) if ln is None else (out, o, z, tag, za)
 
 
-def _mab_backward_block(x2, y2, ignore, o, z, params, pk, cfg, gout, need_x, need_y, need_w):
+def _ln_param_grads(dn, gn, w, b, need_w, need_b):
+    """(d weight, d bias) of a LayerNorm from the rows the block's backward left -- dn = gradient with respect to the norm's
+    output, gn = dn times the normalised input: their column sums.  Inside a TrainStep backward they ride in the grouped
+    weight-gradient launch as bias-sum jobs (and Nones are returned); otherwise summed here."""
+    st = dev_state(dn.device)
+    E = dn.shape[1]
+    out = [None, None]
+    for k, (rows, prm, need) in enumerate(((gn, w, need_w), (dn, b, need_b))):
+        if not need:
+            continue
+        tgt = _grad_target(prm) if (st.grad_into_param and st.deferred_wgrad is not None) else None
+        if tgt is not None:
+            st.deferred_wgrad.add(rows, rows[:, :1], out=torch.empty((E, 1), device=dn.device, dtype=torch.float32),
+                                  bias_out=tgt.reshape(-1), accumulate=True)
+        else:
+            out[k] = rows.sum(0)
+    return out
+
+
+def _mab_backward_block(x2, y2, ignore, o, z, params, pk, cfg, gout, need_x, need_y, need_w, ln=None, za=None, need_ln=False):
     """The backward of one attention block (``mpg_mab_bwd`` + its weight gradients: queued for the grouped launches inside a
-    TrainStep backward, computed at once otherwise): (dx rows or None, dy rows or None, the six parameter gradients or Nones)."""
+    TrainStep backward, computed at once otherwise): (dx rows or None, dy rows or None, the six parameter gradients or Nones).
+    ``ln`` / ``za``: the block's norms and the input of norm1 kept by the forward; with ``need_ln`` the rows for the norms'
+    parameter gradients are produced and returned as a fourth value (dn1, gn1, dn2, gn2)."""
     B, L, S, E, H, alpha, ff_act, tag, p_mab, p_ff = cfg
     bin_, bo, bf = params[1], params[3], params[5]
     dev = x2.device
@@ -1237,6 +1271,13 @@ def _mab_backward_block(x2, y2, ignore, o, z, params, pk, cfg, gout, need_x, nee
             m.dq, m.lddq, m.dk, m.dv, m.lddkv = _p(dqkv), 3 * E, _p(dqkv, E), _p(dqkv, 2 * E), 3 * E
         dza, du = torch.empty_like(dout), torch.empty_like(dout)
         m.dza, m.du = _p(dza), _p(du)
+    lnrows = None
+    if ln is not None:
+        _mab_set_ln(m, ln)
+        m.save_za = _p(za)
+        if need_ln:
+            lnrows = tuple(torch.empty((B * L, E), device=dev, dtype=torch.float32) for _ in range(4))
+            m.dn1, m.gn1, m.dn2, m.gn2 = (_p(t) for t in lnrows)
     check(_lib.lib().mpg_mab_bwd(C.byref(m), _stream()), "mpg_mab_bwd")
     grads = [None] * 6
     if need_w:
@@ -1267,7 +1308,7 @@ def _mab_backward_block(x2, y2, ignore, o, z, params, pk, cfg, gout, need_x, nee
                 grads[0], grads[1] = wgrad(dqkv, x2)
             grads[2], grads[3] = wgrad(dza, o)
             grads[4], grads[5] = wgrad(du, z)
-    return dx, dy, grads
+    return (dx, dy, grads) if ln is None else (dx, dy, grads, lnrows)
 
 
 def sab_chain_forward(x, ignore, H, alpha, ff_act, p_mab, p_ff, training, pks, params):
@@ -1393,6 +1434,44 @@ class FusedMABFn(torch.autograd.Function):
             return (dx, None if dy is None else dy.reshape(B, S, E), None, *grads, None, None, None, None, None, None, None)
         return (None if dx is None else dx.reshape(B, L, E), None if dy is None else dy.reshape(B, S, E), None,
                 *grads, None, None, None, None, None, None, None)
+
+
+class FusedMABLayerNormFn(torch.autograd.Function):
+    """``FusedMABFn`` for a block with ``layer_norm=True`` (gapt/model.py:118-120, :131-136): ``nn.LayerNorm`` behind each of
+    the two residuals, inside the same launch each way (``mpg_mab_fwd`` / ``mpg_mab_bwd`` with the norms' parameters set: one wave
+    per jet).  The forward also keeps za, the input of norm1; the backward leaves, per row, the gradients with respect to the
+    norms' outputs and those times the normalised inputs -- their column sums, the norms' parameter gradients, ride in the grouped
+    weight-gradient launch.  x [B, L, E], y [B, S, E] or None."""
+
+    @staticmethod
+    def forward(ctx, x, y, ignore, Win, bin_, Wo, bo, Wf, bf, n1w, n1b, n2w, n2b, eps, H, alpha, ff_act, p_mab, p_ff, training, pk):
+        B, L, E = x.shape
+        S = L if y is None else y.shape[1]
+        x2 = x.reshape(B * L, E).contiguous()
+        y2 = None if y is None else y.reshape(B * S, E).contiguous()
+        ln = (n1w, n1b, n2w, n2b, eps)
+        out, o, z, tag, za = mab_forward(x2, y2, ignore, pk, bin_, bo, bf, B, L, S, H, alpha=alpha, ff_act=ff_act,
+                                         p_mab=p_mab, p_ff=p_ff, training=training, save=True, ln=ln)
+        ctx.save_for_backward(x2, y2, ignore, o, z, za, n1w, n1b, n2w, n2b)
+        ctx.pk, ctx.params, ctx.eps = pk, (Win, bin_, Wo, bo, Wf, bf), eps
+        ctx.cfg = (B, L, S, E, H, alpha, ff_act, tag, p_mab if training else 0.0, p_ff if training else 0.0)
+        return out.reshape(B, L, E)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x2, y2, ignore, o, z, za, n1w, n1b, n2w, n2b = ctx.saved_tensors
+        B, L, S, E = ctx.cfg[:4]
+        need = ctx.needs_input_grad
+        need_ln = any(need[9:13])
+        dx, dy, grads, rows = _mab_backward_block(x2, y2, ignore, o, z, ctx.params, ctx.pk, ctx.cfg, gout, need[0], need[1],
+                                                  any(need[3:9]), ln=(n1w, n1b, n2w, n2b, ctx.eps), za=za, need_ln=need_ln)
+        g1 = g2 = (None, None)
+        if need_ln:
+            g1 = _ln_param_grads(rows[0], rows[1], n1w, n1b, need[9], need[10])
+            g2 = _ln_param_grads(rows[2], rows[3], n2w, n2b, need[11], need[12])
+        return (None if dx is None else dx.reshape(B, L, E), None if dy is None else dy.reshape(B, S, E), None, *grads,
+                g1[0], g1[1], g2[0], g2[1], None, None, None, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------- per-jet pieces around the layers
@@ -1708,8 +1787,10 @@ class BatchNormFn(torch.autograd.Function):
         dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
         wp, bp = ctx.params
         st = dev_state(g.device)
-        gw = _grad_target(wp) if st.grad_into_param else None
-        gb = _grad_target(bp) if st.grad_into_param else None
+        # (a frozen norm -- the discriminator's inside train_G -- keeps its .grad buffer as the optimizer launch left it: cleared)
+        wanted = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        gw = _grad_target(wp) if (st.grad_into_param and wanted) else None
+        gb = _grad_target(bp) if (st.grad_into_param and wanted) else None
         direct = gw is not None and gb is not None
         dw = gw if direct else torch.empty(F, device=g.device, dtype=torch.float32)
         db = gb if direct else torch.empty(F, device=g.device, dtype=torch.float32)
@@ -1763,14 +1844,20 @@ class LayerNormFn(torch.autograd.Function):
         part = torch.empty((nwaves, 2, E), device=g.device, dtype=torch.float32)
         st = dev_state(g.device)
         wp, bp = ctx.params
-        gw = _grad_target(wp) if st.grad_into_param else None
-        gb = _grad_target(bp) if st.grad_into_param else None
         dw = db = None
-        if gw is not None and gb is not None:
-            tw, tb, acc = gw, gb, 1
+        if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            # frozen norm (the discriminator's inside train_G): no parameter gradient is formed at all -- its .grad buffer was
+            # cleared by the optimizer launch before and must stay clean for the next train_D (TrainStep has no zero_grad there)
+            tw = tb = None
+            acc = 0
         else:
-            dw, db = torch.empty_like(w), torch.empty_like(w)
-            tw, tb, acc = dw, db, 0
+            gw = _grad_target(wp) if st.grad_into_param else None
+            gb = _grad_target(bp) if st.grad_into_param else None
+            if gw is not None and gb is not None:
+                tw, tb, acc = gw, gb, 1
+            else:
+                dw, db = torch.empty_like(w), torch.empty_like(w)
+                tw, tb, acc = dw, db, 0
         check(_lib.lib().mpg_layernorm_bwd(_p(g2), g2.stride(0), _p(x2), x2.stride(0), _p(w), _p(stats), _p(dx), E, _p(part),
                                            nwaves, _p(tw), _p(tb), acc, M, E, _stream()), "mpg_layernorm_bwd")
         return dx.reshape(ctx.shp), dw, db, None

@@ -340,3 +340,55 @@ def test_bridge_changes_no_result_of_a_training_step():
         assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < 1e-3
     for x, y in zip(a[2:], b[2:]):
         assert abs(x - y) < 1e-4 * max(abs(x), 1e-3)
+
+
+def test_layer_norm_networks_train_on_the_one_launch_blocks():
+    """GAPT with ``layer_norm=True`` inside a ``TrainStep``: every block (SABs and the pooling block) runs as one launch each way with
+    its norms inside (``ops.FusedMABLayerNormFn``), the norms' parameter gradients ride in the grouped weight-gradient launch
+    as column sums.  hipGraph replay == eager bit for bit; against the block-by-block route (``MAB.fused = False``:
+    ``mpg_layernorm_*`` launches) losses and parameters agree -- which also pins that a frozen norm (the discriminator's inside
+    train_G) leaves its gradient buffer alone on both routes; the norms' parameters move."""
+    from mpgan_amd import train, ops
+    from mpgan_amd.gapt import GAPT_G, GAPT_D, MAB
+    from oracle.train_ref import synthetic_batch
+    B, N = 48, 30
+    lin = {"leaky_relu_alpha": 0.2, "dropout_p": 0.0, "batch_norm": False, "spectral_norm": False}
+    common = {"num_particles": N, "num_heads": 4, "embed_dim": 64, "sab_fc_layers": [], "use_mask": True, "use_isab": False,
+              "num_isab_nodes": 10, "final_fc_layers": [], "dropout_p": 0.0, "layer_norm": True, "linear_args": lin}
+
+    def run(graphs, fused=True):
+        torch.manual_seed(21)
+        G = GAPT_G(sab_layers=2, output_feat_size=3, **common).cuda()
+        D = GAPT_D(sab_layers=2, input_feat_size=3, **common).cuda()
+        with torch.no_grad():   # (norm weights away from their initial ones / zeros)
+            for net in (G, D):
+                for k, q in net.named_parameters():
+                    if ".norm" in k:
+                        q.add_(0.1 * torch.randn_like(q))
+        n0 = {k: q.detach().clone() for k, q in D.named_parameters() if ".norm" in k}
+        MAB.fused = fused
+        try:
+            ts = train.TrainStep(G, D, B, N, latent=64, lr_disc=train.LR_GAPT[0], lr_gen=train.LR_GAPT[1], use_graphs=graphs)
+            data, labels = synthetic_batch(B, N, seed=4)
+            ts.set_batch(data.cuda(), labels.cuda())
+            gen = torch.Generator(device="cuda").manual_seed(8)
+            ts.fixed_noise = (torch.randn(B, N, 64, device="cuda", generator=gen) * 0.2,
+                              torch.randn(B, N, 64, device="cuda", generator=gen) * 0.2)
+            for _ in range(3):
+                ts.step()
+            torch.cuda.synchronize()
+        finally:
+            MAB.fused = True
+        moved = max(float((q.detach() - n0[k]).abs().max()) for k, q in D.named_parameters() if ".norm" in k)
+        return ts.fD.flat.clone(), ts.fG.flat.clone(), float(ts.D_loss), float(ts.G_loss), moved
+
+    a, b, c = run(False), run(True), run(False, fused=False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2:4] == b[2:4]
+    assert a[4] > 0
+    # (RMSprop's first steps turn rounding-level gradient differences into lr-sized ones -- an entry whose gradient is within
+    # rounding of zero moves by +-10 lr per step whatever its size: three steps of 1.5e-4 against weights of ~0.15; the
+    # gradients themselves are pinned by tests/test_gpu_mab.py::test_layer_norm_block_exact_dropout_vs_oracle)
+    for x, y in zip(a[:2], c[:2]):
+        assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < 1e-2
+    for x, y in zip(a[2:4], c[2:4]):
+        assert abs(x - y) < 1e-4 * max(abs(x), 1e-3)

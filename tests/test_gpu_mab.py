@@ -186,3 +186,50 @@ def test_fused_equals_block_by_block():
     assert rel_err(dx1.cpu().numpy(), dx0.cpu().numpy()) < TIGHT
     for k in g1:
         assert rel_err(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < TIGHT, k
+
+
+def test_layer_norm_block_exact_dropout_vs_oracle(launches):
+    """``layer_norm=True`` blocks on the one-launch kernels (``ops.FusedMABLayerNormFn``: norm1 / norm2 inside ``mpg_mab_fwd`` /
+    ``mpg_mab_bwd``): training mode with dropout at all three sites, E = 64 and 32, self- and cross-attention, padded keys,
+    random norm weights -- against autograd on the fp64 oracle fed with the very masks the kernels drew: output, input
+    gradients, the six block parameters and the four norm parameters.  One launch each way."""
+    from oracle import train_ref as T, gapt_ref as R
+    from mpgan_amd import ops
+    from mpgan_amd.gapt import MAB
+    for E, H, p, L in ((64, 4, 0.5, 30), (32, 2, 0.3, 30), (64, 4, 0.0, 10), (32, 2, 0.5, 7)):
+        la = dict(LA, dropout_p=p)
+        blk = MAB(E, H, ff_layers=[], final_linear=False, layer_norm=True, dropout_p=p, linear_args=la).cuda().train()
+        shapes = dict(T._mab_shapes("mab", E))
+        shapes.update({"mab.norm1.weight": (E,), "mab.norm1.bias": (E,), "mab.norm2.weight": (E,), "mab.norm2.bias": (E,)})
+        sd = T.init_state_dict(shapes, 13, torch.float32)
+        for k in ("mab.norm1.weight", "mab.norm2.weight"):   # (around 1, as a trained norm's)
+            sd[k] = 1.0 + 0.3 * sd[k] / sd[k].abs().max()
+        blk.load_state_dict({k[len("mab."):]: v for k, v in sd.items()})
+        B, N = 9, 30
+        gen = torch.Generator().manual_seed(6)
+        yk = torch.randn(B, N, E, generator=gen)
+        xq = yk if L == N else torch.randn(B, L, E, generator=gen)
+        ign = torch.rand(B, N, generator=gen) > 0.8
+        ign[:, 0] = False
+        gy = torch.randn(B, L, E, generator=gen)
+        xg = xq.cuda().requires_grad_(True)
+        yg = xg if L == N else yk.cuda().requires_grad_(True)
+        launches.clear()
+        out = blk(xg, yg, ign.cuda())
+        tag = ops.last_tag()
+        (out * gy.cuda()).sum().backward()
+        assert launches.get("mpg_mab_fwd") == 1 and launches.get("mpg_mab_bwd") == 1 and "mpg_layernorm_fwd" not in launches, launches
+        thr, _ = ops.drop_params(p)
+        keeps = ({k: ops.dropout_mask(B * L, E, tag + site, thr).double().cpu().reshape(B, L, E)
+                  for site, k in enumerate(("a", "f", "o"))} if thr else None)
+        sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+        xo = xq.double().requires_grad_(True)
+        yo = xo if L == N else yk.double().requires_grad_(True)
+        ref = R.mab_forward(sd64, "mab", xo, yo, ign, num_heads=H, p=thr / 256.0, keeps=keeps, layer_norm=True)
+        (ref * gy.double()).sum().backward()
+        assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < TIGHT, (E, p, L)
+        assert rel_err(xg.grad.cpu().numpy(), xo.grad.numpy()) < TIGHT, (E, p, L)
+        if L != N:
+            assert rel_err(yg.grad.cpu().numpy(), yo.grad.numpy()) < TIGHT, (E, p, L)
+        for k, q in blk.named_parameters():
+            assert rel_err(q.grad.cpu().numpy(), sd64["mab." + k].grad.numpy()) < TIGHT, (E, p, L, k)
