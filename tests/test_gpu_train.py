@@ -764,3 +764,44 @@ def test_features_and_mask_held_apart_change_no_result(model):
         os.environ.pop("MPG_PARTS", None)
         os.environ.pop("MPG_BRIDGE", None)
     assert torch.equal(with_it[0], without[0]) and torch.equal(with_it[1], without[1]) and with_it[2:] == without[2:]
+
+
+@pytest.mark.parametrize("cfg", ["mpgan", "mpgan_bn", "gapt", "gapt_ln", "gapt_ln_blocks"])
+def test_train_G_leaves_the_discriminators_gradient_buffer_clean(cfg):
+    """``TrainStep`` has no ``zero_grad`` launch at the top of train_D: D's flat gradient buffer is cleared by D's optimizer launch and
+    must stay clear through train_G (where D's parameters are frozen: train.py:494-521 forms their gradients and throws them away).
+    Checked for the default networks, a batch-norm discriminator and layer-norm attention blocks on both of their routes."""
+    from mpgan_amd import train
+    from mpgan_amd.gapt import GAPT_G, GAPT_D, MAB
+    from oracle.train_ref import synthetic_batch
+    B, N = 16, 30
+    fused = True
+    if cfg.startswith("mpgan"):
+        G, D = train.default_mpgan(N, disc_dropout=0.0, batch_norm_disc=(cfg == "mpgan_bn"))
+        latent, lrs = 32, train.LR["g"]
+    elif cfg == "gapt":
+        G, D = train.default_gapt(N, disc_dropout=0.0)
+        latent, lrs = 64, train.LR_GAPT
+    else:
+        lin = {"leaky_relu_alpha": 0.2, "dropout_p": 0.0, "batch_norm": False, "spectral_norm": False}
+        common = {"num_particles": N, "num_heads": 4, "embed_dim": 64, "sab_fc_layers": [], "use_mask": True, "use_isab": False,
+                  "num_isab_nodes": 10, "final_fc_layers": [], "dropout_p": 0.0, "layer_norm": True, "linear_args": lin}
+        G = GAPT_G(sab_layers=2, output_feat_size=3, **common).cuda()
+        D = GAPT_D(sab_layers=2, input_feat_size=3, **common).cuda()
+        latent, lrs = 64, train.LR_GAPT
+        fused = cfg == "gapt_ln"
+    MAB.fused = fused
+    try:
+        ts = train.TrainStep(G, D, B, N, latent=latent, lr_disc=lrs[0], lr_gen=lrs[1], use_graphs=False)
+        data, labels = synthetic_batch(B, N, seed=2)
+        ts.set_batch(data.cuda(), labels.cuda())
+        for _ in range(2):
+            ts._seg_D()
+            assert float(ts.fD.grad.abs().max()) > 0
+            ts._seg_G()
+            assert float(ts.fD.grad.abs().max()) == 0.0, cfg
+            assert float(ts.fG.grad.abs().max()) > 0
+            ts._seg_end()
+            assert float(ts.fG.grad.abs().max()) == 0.0
+    finally:
+        MAB.fused = True
