@@ -233,3 +233,39 @@ def test_layer_norm_block_exact_dropout_vs_oracle(launches):
             assert rel_err(yg.grad.cpu().numpy(), yo.grad.numpy()) < TIGHT, (E, p, L)
         for k, q in blk.named_parameters():
             assert rel_err(q.grad.cpu().numpy(), sd64["mab." + k].grad.numpy()) < TIGHT, (E, p, L, k)
+
+
+@pytest.mark.parametrize("kind", ["pma", "isab"])
+def test_layer_norm_pooling_and_induced_blocks_equal_block_by_block(kind):
+    """PMA (one seed row shared by all jets) and ISAB with ``layer_norm=True``: the one-launch route against the block-by-block one
+    (``MAB.fused = False``: ``mpg_layernorm_*`` launches) -- outputs, input gradient and every parameter gradient, the seed /
+    inducing points and the norms' parameters among them."""
+    from mpgan_amd.gapt import MAB, PMA, ISAB, _attn_mask
+    torch.manual_seed(4)
+    args = dict(SAB_ARGS, layer_norm=True)
+    blk = (PMA(num_seeds=1, **args) if kind == "pma" else ISAB(10, **args)).cuda()
+    with torch.no_grad():
+        for k, q in blk.named_parameters():
+            if ".norm" in k:
+                q.add_(0.2 * torch.randn_like(q))
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(6, 30, 64, generator=gen).cuda()
+    mask = (torch.rand(6, 30, 1, generator=gen) < 0.7).float().cuda()
+    mask[:, 0] = 1
+    res = []
+    for fused in (True, False):
+        MAB.fused = fused
+        try:
+            blk.zero_grad()
+            xx = x.clone().requires_grad_(True)
+            y = blk(xx, _attn_mask(mask))
+            y.square().sum().backward()
+            res.append((y.detach(), xx.grad, {k: p.grad.clone() for k, p in blk.named_parameters()}))
+        finally:
+            MAB.fused = True
+    (y1, dx1, g1), (y0, dx0, g0) = res
+    assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < TIGHT
+    assert rel_err(dx1.cpu().numpy(), dx0.cpu().numpy()) < TIGHT
+    assert any(".norm" in k for k in g1)
+    for k in g1:
+        assert rel_err(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < TIGHT, k
