@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void bridge_bwd_kernel(const MpgBridgeBwd p) {
 template <typename P>
 int bridge_check(const P* p) {
     if (p->M <= 0 || p->row0 < 0 || p->row0 > p->M) return -1;
-    if (p->K != 64 || p->E != 64 || p->F < 1 || p->F > BR_FMAX) return -2;      // (the sixteen-lane layout: 64-wide sides)
+    if (p->K != 64 || p->E != 64 || p->F < 1 || (p->F > 4 && p->F != BR_FMAX)) return -2;   // (the sixteen-lane layout: 64-wide sides; 1..4 or 8 features)
     return 0;
 }
 
@@ -143,7 +143,6 @@ extern "C" int mpg_bridge_fwd(const MpgBridge* p, void* stream) {
     if (p->row0 < p->M && (p->x == nullptr || p->W1 == nullptr || p->ldx % 4)) return -3;
     if (p->e != nullptr && (p->W2 == nullptr || p->lde % 4)) return -3;
     if (p->thr && p->seed == nullptr) return -4;
-    if (p->F > 4 && p->F != BR_FMAX) return -2;
     BR_DISPATCH(bridge_fwd_kernel, p, (hipStream_t)stream);
     return (int)hipGetLastError();
 }
@@ -154,7 +153,6 @@ extern "C" int mpg_bridge_bwd(const MpgBridgeBwd* p, void* stream) {
     if ((p->g1 != nullptr || p->dx != nullptr) && (p->feat == nullptr || p->W2 == nullptr)) return -3;
     if (p->dx != nullptr && (p->W1 == nullptr || p->lddx % 4)) return -3;
     if (p->thr && p->seed == nullptr) return -4;
-    if (p->F > 4 && p->F != BR_FMAX) return -2;
     BR_DISPATCH(bridge_bwd_kernel, p, (hipStream_t)stream);
     return (int)hipGetLastError();
 }

@@ -392,3 +392,33 @@ def test_layer_norm_networks_train_on_the_one_launch_blocks():
         assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < 1e-2
     for x, y in zip(a[2:4], c[2:4]):
         assert abs(x - y) < 1e-4 * max(abs(x), 1e-3)
+
+
+@pytest.mark.parametrize("F", [1, 2, 4, 8])
+def test_bridge_widths_and_refusals(F):
+    """``mpg_bridge_fwd`` / ``mpg_bridge_bwd`` at every middle width they take (1..4 and 8 features), sigmoid instead of tanh, no
+    biases, odd row counts; and the shapes they refuse (sides other than 64 wide, 5..7 features) come back as errors, not launches."""
+    from mpgan_amd import ops, _lib
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cuda").manual_seed(10 + F)
+    Bg, N, K, E = 3, 7, 64, 64
+    pre = torch.randn(Bg, N, K, device=dev, generator=gen).requires_grad_(True)
+    W1 = (torch.randn(F, K, device=dev, generator=gen) * 0.2).requires_grad_(True)
+    W2 = (torch.randn(E, F, device=dev, generator=gen) * 0.5).requires_grad_(True)
+    up = torch.randn(Bg, N, E, device=dev, generator=gen)
+    feat, e = ops.GenDiscBridgeFn.apply(pre, W1, None, None, W2, None, ops.ACT_CODES["sigmoid"], True, 0.2, 0.0, False)
+    (e * up).sum().backward()
+    r = [t.detach().double().requires_grad_(True) for t in (pre, W1, W2)]
+    f_ref = torch.sigmoid(r[0] @ r[1].T)
+    e_ref = torch.nn.functional.leaky_relu(f_ref @ r[2].T, 0.2)
+    (e_ref * up.double()).sum().backward()
+    assert rel_err(feat.detach().cpu().numpy(), f_ref.detach().cpu().numpy()) < 1e-5
+    assert rel_err(e.detach().cpu().numpy(), e_ref.detach().cpu().numpy()) < 1e-5
+    for a, b_ in zip((pre, W1, W2), r):
+        assert rel_err(a.grad.cpu().numpy(), b_.grad.cpu().numpy()) < 1e-4
+    assert ops.bridge_fusable(64, F, 64) and not ops.bridge_fusable(64, 5, 64) and not ops.bridge_fusable(32, 3, 64)
+    q = _lib.MpgBridge()
+    q.M, q.row0, q.K, q.F, q.E = 8, 0, 32, 3, 64
+    assert _lib.lib().mpg_bridge_fwd(q, None) == -2
+    q.K, q.F = 64, 6
+    assert _lib.lib().mpg_bridge_fwd(q, None) == -2

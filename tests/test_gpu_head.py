@@ -206,3 +206,21 @@ def test_noise_and_masks_from_one_launch_equal_the_two_calls():
     assert torch.equal(z0, z1) and torch.equal(m0, m1) and torch.equal(i0, i1)
     assert torch.equal(mask_rows[B:], m0) and bool((mask_rows[:B] == -1).all())
     assert float(m0.sum(1).sub(labels[:, 0] * N).abs().max()) < 0.5
+
+
+@pytest.mark.parametrize("B,N,L", [(1, 30, 64), (5, 150, 32), (3, 31, 2)])
+def test_noise_and_masks_from_one_launch_other_sizes(B, N, L):
+    """``mpg_normal_rank_mask`` at one jet, at 150 particles and at an odd particle count: the two-call values bit for bit; an odd
+    number of values per jet is refused (pairs of values must not straddle jets)."""
+    from mpgan_amd import ops, _lib
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(B)
+    labels = torch.from_numpy(rs.randint(1, N + 1, size=(B, 1)) / N).float().to(dev)
+    ops.set_seed(7, dev)
+    z0 = ops.normal_noise((B, N, L), 0.2, site=0, device=dev)
+    m0, i0 = ops.rank_mask(z0[:, :, 0], labels, N, with_ignore=True)
+    z1, m1, i1 = ops.normal_noise_masked((B, N, L), 0.2, labels, site=0, device=dev)
+    assert torch.equal(z0, z1) and torch.equal(m0, m1) and torch.equal(i0, i1)
+    out = torch.empty(3 * 5, device=dev)
+    rc = _lib.lib().mpg_normal_rank_mask(ops._p(out), 1, 3, 5, ops._p(ops.seed_tensor(dev)), 0, 0.0, 1.0, ops._p(labels), 1, ops._p(m0), None, None)
+    assert rc == -1
