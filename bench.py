@@ -295,10 +295,16 @@ def _work(name, a):
         fn = sum(2 * rows * c.L[l].K * c.L[l].N for l in range(3))
         return edges * 2 * (H1 * H2 + H2 * H3) + fn, rows * (2 * H1 + (c.L[0].K - H3) + c.L[2].N) * 4
     if name == "mpg_edge_bwd_fn":   # the data-gradient products + the node network's three transposed layers, one launch
-        c = a[1]._obj
+        # (a[1] = the layer's dx chain, cdx.nlayers layers; a[2] = the lower layer's node-network input-gradient chain or NULL)
         edges, rows = o.B * o.N * o.N, o.B * o.N
-        fn = sum(2 * rows * c.L[l].K * c.L[l].N for l in range(3))
-        return edges * 2 * (H1 * H2 + H2 * H3) + fn, rows * (2 * H1 + c.L[0].K + c.L[2].N + 2 * H1) * 4
+        fn, io = 0, 2 * H1 + 2 * H1
+        for arg in a[1:3]:
+            c = getattr(arg, "_obj", None)
+            if c is None or c.nlayers <= 0:
+                continue
+            fn += sum(2 * rows * c.L[l].K * c.L[l].N for l in range(c.nlayers))
+            io += c.L[c.nlayers - 1].N
+        return edges * 2 * (H1 * H2 + H2 * H3) + fn, rows * (io + H3) * 4
     if name in ("mpg_edge_fwd", "mpg_edge_bwd", "mpg_edge_dw"):
         edges = o.B * o.N * o.N
         # the two dense layers the kernel fuses per edge: forward e2 = W2 e1, e3 = W3 e2; backward dE2 = W3^T dZ3,

@@ -137,11 +137,18 @@ int bridge_check(const P* p) {
     default: hipLaunchKernelGGL(KERNEL<BR_FMAX>, dim3(((p)->M + 15) / 16), dim3(256), 0, st, *(p)); break;                \
     }
 
+// float4 accesses: the leading dimensions are checked in floats, the base addresses here (a view into a flat parameter buffer
+// at an offset that is not a multiple of four floats, or a storage-offset view of the rows, would be a misaligned vector access)
+static inline bool br_al16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+    return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) == 0;
+}
+
 extern "C" int mpg_bridge_fwd(const MpgBridge* p, void* stream) {
     if (const int rc = bridge_check(p)) return rc;
     if (p->feat == nullptr || p->ldf < p->F) return -3;
     if (p->row0 < p->M && (p->x == nullptr || p->W1 == nullptr || p->ldx % 4)) return -3;
     if (p->e != nullptr && (p->W2 == nullptr || p->lde % 4)) return -3;
+    if (!br_al16(p->x, p->W1, p->e)) return -5;
     if (p->thr && p->seed == nullptr) return -4;
     BR_DISPATCH(bridge_fwd_kernel, p, (hipStream_t)stream);
     return (int)hipGetLastError();
@@ -153,6 +160,7 @@ extern "C" int mpg_bridge_bwd(const MpgBridgeBwd* p, void* stream) {
     if ((p->g1 != nullptr || p->dx != nullptr) && (p->feat == nullptr || p->W2 == nullptr)) return -3;
     if (p->dx != nullptr && (p->W1 == nullptr || p->lddx % 4)) return -3;
     if (p->thr && p->seed == nullptr) return -4;
+    if (!br_al16(p->ge, p->e, p->g2, p->dx) || (p->dx != nullptr && !br_al16(p->W1))) return -5;
     BR_DISPATCH(bridge_bwd_kernel, p, (hipStream_t)stream);
     return (int)hipGetLastError();
 }

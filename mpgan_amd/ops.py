@@ -71,8 +71,10 @@ class DeviceState:
     def __init__(self, index: int):
         self.index = index
         self._seed = None
+        self.seed_is_default = True   # nobody has called set_seed on this device yet (TrainStep then seeds it itself)
         self.tags = itertools.count(1)
         self.last_tag = 0
+        self.tag_log = None
         self.grad_into_param = False
         self.deferred_wgrad = None
         self.wgrad_stream = None
@@ -142,8 +144,26 @@ def range_status(device="cuda", clear: bool = False) -> int:
     return v
 
 
-def set_seed(value: int, device="cuda"):
-    seed_tensor(device).fill_(value & 0x7FFFFFFFFFFFFFFF)
+def set_seed(value: int, device="cuda", _auto: bool = False):
+    """Set the device-resident 64-bit seed that keys every counter-based stream of the fused path on ``device``: the dropout
+    masks and -- inside ``train.TrainStep`` -- the generator's input noise.  ``torch.manual_seed`` does NOT reach these
+    streams.  ``TrainStep`` seeds a device nobody has seeded from ``torch.initial_seed()`` and its rank (so that
+    ``torch.manual_seed(seed)`` keeps the reference's meaning, setup_training.py:184, and ranks draw different noise and
+    masks); call this after constructing it to choose the value yourself, with a different value on every rank
+    (``dist.rank_seed``)."""
+    v = int(value) & 0xFFFFFFFFFFFFFFFF          # the 64-bit pattern as the kernels read it (an int64 tensor holds it signed)
+    seed_tensor(device).fill_(v - (1 << 64) if v >= (1 << 63) else v)
+    dev_state(device).seed_is_default = _auto   # (TrainStep's own choice does not count as the caller's)
+
+
+def derived_seed(torch_seed: int, rank: int) -> int:
+    """The device seed ``TrainStep`` derives from torch's seed and the data-parallel rank: distinct per (seed, rank)."""
+    return (torch_seed * 0x9E3779B97F4A7C15 + (rank + 1) * 0xD1B54A32D192ED03 + 0x243F6A8885A308D3) & 0x7FFFFFFFFFFFFFFF
+
+
+def get_seed(device="cuda") -> int:
+    """The seed's current value as an unsigned 64-bit number (synchronises; checkpoints)."""
+    return int(seed_tensor(device).item()) & 0xFFFFFFFFFFFFFFFF
 
 
 SEED_STEP = 0x1E3779B97F4A7C15   # what an iteration adds to the seed
@@ -166,10 +186,14 @@ def normal_noise(shape, std: float, site: int = 0, device="cuda", mean: float = 
     return out
 
 
-def next_tag(device="cuda") -> int:
-    """A fresh dropout-site tag base (8 sites per call) for one fused-op invocation on ``device``."""
+def next_tag(device="cuda", kind: str = "", thr: int = 0) -> int:
+    """A fresh dropout-site tag base (8 sites per call) for one fused-op invocation on ``device``.  ``kind`` / ``thr`` name the
+    invocation in ``DeviceState.tag_log`` (tests: a list there collects (kind, tag base, thr) of every invocation, in host
+    order, so that a whole iteration's keep masks can be dumped site by site with ``dropout_mask``)."""
     st = dev_state(device)
     st.last_tag = (next(st.tags) % (1 << 24)) * 8
+    if st.tag_log is not None:
+        st.tag_log.append((kind, st.last_tag, int(thr)))
     return st.last_tag
 
 
@@ -616,7 +640,7 @@ class FusedMPLayerFn(torch.autograd.Function):
         dev = x.device
         thr, dscale = drop_params(p_drop) if training else (0, 1.0)
         seed_t = seed_tensor(dev)
-        tag = next_tag(dev)
+        tag = next_tag(dev, "mplayer", thr)
         x2 = x.reshape(V, F)          # a view when x is a feature slice of a contiguous tensor (D's x[..., :-1]) ...
         if x2.stride(1) != 1:
             x2 = x2.contiguous()      # ... every consumer below takes the row stride, only unit column stride matters
@@ -925,7 +949,7 @@ class FusedLinearFn(torch.autograd.Function):
             x2 = x2.contiguous()
         thr, dscale = drop_params(p_drop) if training else (0, 1.0)
         seed_t = seed_tensor(x.device)
-        tag = next_tag(x.device)
+        tag = next_tag(x.device, "linear", thr)
         if resid is not None and act:  # (the backward reads the activation's sign off the saved output)
             raise NotImplementedError("FusedLinearFn: a fused residual needs a layer without activation")
         r2 = None if resid is None else resid.reshape(-1, W.shape[0]).contiguous()
@@ -1032,7 +1056,7 @@ class FusedDropoutFn(torch.autograd.Function):
             return x
         _chk(x, "x")
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
-        tag = next_tag(x.device) + TAG_GENERIC
+        tag = next_tag(x.device, "dropout", thr) + TAG_GENERIC
         ctx.cfg = (tag, thr, scale, x.shape)
         return gate(x2, None, gate_act=False, alpha=0.0, seed_t=seed_tensor(x.device), tag=tag, thr=thr,
                     scale=scale).reshape(x.shape)
@@ -1208,7 +1232,7 @@ def mab_forward(x2, y2, ignore, pk, bin_, bo, bf, B, L, S, H, *, alpha=0.2, ff_a
     thr_mab, sc_mab = drop_params(p_mab) if training else (0, 1.0)
     thr_ff, sc_ff = drop_params(p_ff) if training else (0, 1.0)
     if tag is None:
-        tag = next_tag(dev)
+        tag = next_tag(dev, "mab", max(thr_mab, thr_ff))
     out = torch.empty((B * L, E), device=dev, dtype=torch.float32)
     o = torch.empty_like(out) if save else None
     z = torch.empty_like(out) if save else None
@@ -1324,7 +1348,7 @@ def sab_chain_forward(x, ignore, H, alpha, ff_act, p_mab, p_ff, training, pks, p
     for b in range(len(pks)):
         out = torch.empty((B * L, E), device=dev, dtype=torch.float32)
         m = _mab_struct(inp, None, ignore, pks[b], params[6 * b + 1], params[6 * b + 3], params[6 * b + 5], B, L, L, E, H, alpha, ff_act,
-                        next_tag(dev), thr_mab, sc_mab, thr_ff, sc_ff)
+                        next_tag(dev, "mab", max(thr_mab, thr_ff)), thr_mab, sc_mab, thr_ff, sc_ff)
         m.out, m.ldo = _p(out), E
         c.blk[b] = m
         keep.append(out)
@@ -1352,7 +1376,7 @@ class FusedSABChainFn(torch.autograd.Function):
         inp, outs, os_, zs_, tags = x2, [], [], [], []
         for b in range(n):
             bin_, bo, bf = params[6 * b + 1], params[6 * b + 3], params[6 * b + 5]
-            tag = next_tag(dev)
+            tag = next_tag(dev, "mab", max(thr_mab, thr_ff))
             out, o, z = (torch.empty((B * L, E), device=dev, dtype=torch.float32) for _ in range(3))
             m = _mab_struct(inp, None, ignore, pks[b], bin_, bo, bf, B, L, L, E, H, alpha, ff_act, tag, thr_mab, sc_mab, thr_ff, sc_ff)
             m.out, m.ldo, m.save_o, m.save_z = _p(out), E, _p(o), _p(z)
@@ -1586,7 +1610,7 @@ class GenDiscBridgeFn(torch.autograd.Function):
         B = feat.shape[0]
         e = torch.empty((B, N, E), device=pre.device, dtype=torch.float32)
         thr, dscale = drop_params(p_drop) if training else (0, 1.0)
-        tag = next_tag(pre.device) + TAG_GENERIC
+        tag = next_tag(pre.device, "bridge", thr) + TAG_GENERIC
         q = _lib.MpgBridge()
         q.x, q.ldx, q.W1, q.b1, q.act1 = _p(pre2), pre2.stride(0), _p(W1), _p(b1), int(act1)
         q.feat, q.ldf = _p(feat), F
@@ -1693,7 +1717,7 @@ class DiscHeadFn(torch.autograd.Function):
         out = torch.empty((B,), device=dev, dtype=torch.float32)
         pooled = torch.empty((B, F), device=dev, dtype=torch.float32)
         aux = torch.empty((2 * B,), device=dev, dtype=torch.float32)
-        tag = next_tag(dev) + TAG_GENERIC
+        tag = next_tag(dev, "head", drop_params(p_drop)[0] if training else 0) + TAG_GENERIC
         wv = w.reshape(-1)
         h = _head_struct(y, m, wv, b, mean, sigmoid, p_drop, training, tag, out, pooled, aux)
         check(_lib.lib().mpg_disc_head_fwd(C.byref(h), _stream()), "mpg_disc_head_fwd")
@@ -1740,7 +1764,7 @@ def disc_head_loss(y, mask, w, b, *, mean, sigmoid, p_drop, training, loss, n_re
     pooled = torch.empty((B, F), device=dev, dtype=torch.float32)
     aux = torch.empty((2 * B,), device=dev, dtype=torch.float32)
     terms = torch.empty((B,), device=dev, dtype=torch.float32)
-    tag = next_tag(dev) + TAG_GENERIC
+    tag = next_tag(dev, "head", drop_params(p_drop)[0] if training else 0) + TAG_GENERIC
     h = _head_struct(y, m, w.reshape(-1), b, mean, sigmoid, p_drop, training, tag, out, pooled, aux)
     h.loss, h.gen_step, h.n_real, h.inv_count = LOSS_CODES[loss], int(gen_step), n_real, 1.0 / count
     h.terms, h.loss_out = _p(terms), _p(loss_out)

@@ -135,6 +135,9 @@ class FlatParams:
             off += k
         self.n = n
         self.lr = None  # last learning rate used (for state_dict's param_groups)
+        # TrainStep: the device whose dropout / noise seed travels with this optimizer's state dict (``SEED_KEY`` in its
+        # parameter group: torch.optim's own load_state_dict carries unknown group keys along untouched)
+        self.seed_device = None
 
     def zero_grad(self):
         self.grad.zero_()
@@ -177,6 +180,7 @@ class FlatParams:
 
     # -- torch.optim-compatible state ---------------------------------------------------------------
     _STATE_KEYS = {"rmsprop": ("square_avg", None), "adam": ("exp_avg_sq", "exp_avg"), "adadelta": ("square_avg", "acc_delta")}
+    SEED_KEY = "mpgan_amd_seed"
 
     def _torch_optimizer(self, lr):
         """A torch.optim instance over detached CPU stand-ins of the parameters: the source of truth for the
@@ -206,6 +210,8 @@ class FlatParams:
                 if k_aux is not None:
                     ent[k_aux] = self.aux[off:off + k].view(shape).clone()
                 sd["state"][i if filtered else self._trained_idx[i]] = ent
+        if self.seed_device is not None:
+            sd["param_groups"][0][self.SEED_KEY] = ops.get_seed(self.seed_device)
         return sd
 
     def load_state_dict(self, sd: dict):
@@ -247,6 +253,9 @@ class FlatParams:
         self.step_count.fill_(steps)
         self._host_steps = int(steps)
         self.lr = groups[0].get("lr", self.lr)
+        if self.seed_device is not None and self.SEED_KEY in groups[0]:
+            # a resumed run goes on with the noise / dropout stream where the saved one stopped, not from its start
+            ops.set_seed(int(groups[0][self.SEED_KEY]), self.seed_device)
         return self.lr
 
     def versions(self) -> int:
@@ -340,6 +349,17 @@ class TrainStep:
         self.state = ops.dev_state(dev)
         self.fG = FlatParams(G, optimizer, betas)
         self.fD = FlatParams(D, optimizer, betas)
+        if dev.type == "cuda":
+            # The generator's noise and every dropout mask come from counter-based streams keyed by the DEVICE seed, which
+            # torch.manual_seed does not reach.  Unless the caller has set it (ops.set_seed), derive it here from torch's
+            # seed -- the reference's contract: torch.manual_seed(seed), setup_training.py:184 -- and this process's rank,
+            # so that data-parallel ranks never share noise or masks; it is saved / restored with G's optimizer state.
+            if self.state.seed_is_default:
+                rank = 0
+                if torch.distributed.is_available() and torch.distributed.is_initialized():
+                    rank = torch.distributed.get_rank(process_group)
+                ops.set_seed(ops.derived_seed(torch.initial_seed(), rank), dev, _auto=True)
+            self.fG.seed_device = dev
         self.data = torch.zeros(batch_size, num_particles, 4, device=dev)
         self.labels = torch.zeros(batch_size, 1, device=dev)
         self._real = torch.cat([torch.ones(batch_size, device=dev), torch.zeros(batch_size, device=dev)])
@@ -425,8 +445,10 @@ class TrainStep:
         if not self.bridge or not hasattr(self.G, "bridge_head") or not hasattr(self.D, "bridge_tail"):
             return False
         h, t = self.G.bridge_head(), self.D.bridge_tail()
+        # (final_fc's weight is a view into the flat parameter buffer: the launch reads its rows as float4 -- a generator composed
+        # so that the view starts off a 16-byte boundary takes the three launches instead)
         return h is not None and t is not None and ops.bridge_fusable(h[0].shape[1], h[0].shape[0], t[0].shape[0]) \
-            and t[0].shape[1] == h[0].shape[0]
+            and t[0].shape[1] == h[0].shape[0] and h[0].data_ptr() % 16 == 0
 
     def _head_loss(self, y, mask, gen_step: bool, n_jets: int, loss_out, wgrad: bool):
         w, b, mean, sigmoid, p = self.D.fused_head()
@@ -611,8 +633,14 @@ class TrainStep:
         self.state.grad_into_param = False
 
     def mark_grads_dirty(self):
-        """Tell the step that something outside it wrote the networks' .grad buffers: the next iteration clears them first."""
-        self._clean = {"D": False, "G": False}
+        """Tell the step that something outside it wrote the networks' .grad buffers (they are views of the flat gradient
+        buffers): both are cleared HERE, eagerly, on the current stream.  The iteration itself has no memset -- every optimizer
+        launch leaves its buffer cleared behind its last use, so ``.grad`` reads as zeros after ``step()`` (log gradient norms
+        between ``_seg_D`` / ``_seg_G`` and the following segment) -- and a captured hipGraph contains none either: a host
+        flag read at capture time could not reach a replay."""
+        self.fD.zero_grad()
+        self.fG.zero_grad()
+        self._clean = {"D": True, "G": True}
 
     def _allreduce(self, flat: FlatParams):
         mdist.allreduce_sum_(flat.grad, self.pg, self.world)  # sum; 1/world is folded into the optimiser step

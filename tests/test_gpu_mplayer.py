@@ -202,23 +202,34 @@ def _run_case(B, N, F, out, use_mask, sum_agg, seed, skip=True, alpha=0.2, contr
     return errs, frac, margin
 
 
+# how the gradient tensors of the kinked cases passed (printed and bounded by test_kink_flip_hatch_is_rare)
+HATCH = {"outright": 0, "control": 0, "hatch": 0}
+
+
 def _assert_gradients_up_to_kink_flips(errs, frac, control, margin):
     """Gradient bar for the default (kinked) activation.  LeakyReLU' jumps at 0, so an element whose pre-activation
     lies within the forward rounding error of zero may take the other slope -- in the reference's own fp32
     arithmetic just as here (``control`` = fp32 oracle vs fp64 oracle on the same input: (error, off-fraction) per
-    tensor).  A tensor passes when it meets the 1e-3 bar outright, or three times fp32's own error on this input;
-    failing that, only as an isolated flip: error below 2e-2 AND no more elements off than 3x fp32's or 1 %."""
+    tensor).  A tensor passes when it meets the 1e-3 bar outright ("outright"), or three times fp32's own error on this
+    input ("control"); failing that, only as an isolated flip ("hatch"): fp32 ITSELF beyond the bar on this tensor (the
+    input does sit on a kink), error below 2e-2 AND no more elements off than 3x fp32's or 1 %.  ``HATCH`` counts the three."""
     print("errs", errs, "\nfrac", frac, "\ncontrol", control, "margin", margin)
     bad = {}
     for k in errs:
         if k == "y":
             continue
         ce, cf = control[k]
-        if errs[k] < max(TOL, 3 * ce):
+        if errs[k] < TOL:
+            HATCH["outright"] += 1
             continue
-        if errs[k] < 2e-2 and frac[k] <= max(3 * cf, 1e-2):
+        if errs[k] < 3 * ce:
+            HATCH["control"] += 1
+            continue
+        if ce > TOL and errs[k] < 2e-2 and frac[k] <= max(3 * cf, 1e-2):
+            HATCH["hatch"] += 1
             continue
         bad[k] = (errs[k], frac[k], ce, cf)
+    print("passed so far:", HATCH)
     assert not bad, (bad, margin)
 
 
@@ -263,6 +274,16 @@ def test_mplayer_plain_relu(case):
     errs, frac, margin = _run_case(*case, seed=77 + case[0], alpha=0.0, control=control)
     assert errs["y"] < TIGHT, errs
     _assert_gradients_up_to_kink_flips(errs, frac, control, margin)
+
+
+def test_kink_flip_hatch_is_rare():
+    """Over the kinked cases above (default slope, plain ReLU): the isolated-flip hatch of
+    ``_assert_gradients_up_to_kink_flips`` may carry at most 5 % of the gradient tensors."""
+    n = sum(HATCH.values())
+    print("gradient tensors of the kinked cases:", HATCH)
+    if n < 100:
+        pytest.skip("the kinked cases did not run in this session")
+    assert HATCH["hatch"] <= 0.05 * n, HATCH
 
 
 def test_mplayer_plain_relu_strict_when_away_from_the_kink():
@@ -440,11 +461,11 @@ def test_mplayer_full_size():
       (1) the RATE of such disagreements: counted directly from the signs the HIP forward saw (a|c terms, the packed
           sign words, the node network's outputs) against the fp64 oracle, it must stay within 3x of the fp32
           oracle's own count (+10 for Poisson noise) -- a kernel whose forward were less accurate than fp32 fails;
-      (2) the size of their effect: every parameter gradient within the 1e-3 bar for most seeds (median), never a gross
-          error (5e-2); dx -- where one flipped sign in the node network shows at ~1e-2 in that node's rows, for fp32
+      (2) the size of their effect: every parameter gradient of EVERY seed within max(1e-3, 3x the fp32 oracle's own error
+          on that tensor and seed), never a gross error (5e-2); dx -- where one flipped sign in the node network shows at ~1e-2 in that node's rows, for fp32
           as for the kernels -- with less than 1e-3 of its elements off by more than 1e-3."""
     seeds = (7, 8, 9)
-    all_errs, n_hip, n_ctl = [], {}, {}
+    all_errs, all_ctl, n_hip, n_ctl = [], [], {}, {}
     for seed in seeds:
         control, flips = {}, {}
         errs, frac, margin = _run_case(256, 30, 32, 32, True, True, seed=seed, control=control, flips=flips)
@@ -454,16 +475,17 @@ def test_mplayer_full_size():
         assert max(errs.values()) < 5e-2, errs
         assert frac["dx"] < 1e-3, frac["dx"]
         all_errs.append(errs)
+        all_ctl.append(control)
         for k in flips["hip"]:
             n_hip[k] = n_hip.get(k, 0) + flips["hip"][k]
             n_ctl[k] = n_ctl.get(k, 0) + flips["fp32"][k]
     print("sign disagreements summed over seeds: HIP", n_hip, "fp32 oracle", n_ctl)
     assert sum(n_hip.values()) <= 3 * sum(n_ctl.values()) + 10, (n_hip, n_ctl)
-    for k in all_errs[0]:
-        if k == "dx":
-            continue
-        med = sorted(e[k] for e in all_errs)[len(seeds) // 2]
-        assert med < TOL, (k, [e[k] for e in all_errs])
+    for errs, control, seed in zip(all_errs, all_ctl, seeds):
+        for k in errs:
+            if k == "dx":
+                continue
+            assert errs[k] < max(TOL, 3 * control[k][0]), (seed, k, errs[k], control[k])
 
 
 def test_mplayer_gradient_units_across_binades_and_zero_jets():
@@ -517,19 +539,24 @@ def test_mplayer_gradient_units_across_binades_and_zero_jets():
     _assert_smooth_bars(dict(errs, dx=worst))
 
 
-@pytest.mark.parametrize("p_drop", [0.5, 0.3])
-def test_mplayer_dropout_exact(p_drop):
+@pytest.mark.parametrize("p_drop,F,alpha", [(0.5, 32, 1.0), (0.3, 32, 1.0), (0.5, 3, 1.0), (0.3, 3, 1.0),
+                                            (0.5, 3, 0.2), (0.5, 32, 0.2), (0.3, 3, 0.2)])
+def test_mplayer_dropout_exact(p_drop, F, alpha):
     """Dropout on (training mode): the kernels' counter-based keep masks are dumped with
     mpg_dropout_mask and fed to the oracle, so forward AND backward can be compared exactly
-    (p = 0.5 takes the one-bit fast path, p = 0.3 the byte-threshold path; slope 1 keeps it smooth)."""
+    (p = 0.5 takes the one-bit fast path, p = 0.3 the byte-threshold path).  F = 3 is the discriminator's first layer -- the
+    layer that carries dropout in the bench -- with x the strided 3-column view of [B, N, 4] jets it gets there.  Slope 1
+    keeps the layer smooth (strict bars); the default slope 0.2 is held to the 1e-3 bar with the oracle's own fp32
+    evaluation -- same masks -- as the kink-flip control."""
     import oracle
+    from conftest import assert_grads
     from oracle import train_ref as T
     from mpgan_amd import ops
     from mpgan_amd.mpgan import MPLayer
-    B, N, F, out = 3, 30, 32, 32
+    B, N, out = 3, 30, 32
     V = B * N
     sd64 = T.init_state_dict(_mplayer_shapes(F, out), seed=77, dtype=torch.float64)
-    layer = MPLayer(F, [96, 160, 192], [256, 256], out, leaky_relu_alpha=1.0, dropout_p=p_drop).to(_dev())
+    layer = MPLayer(F, [96, 160, 192], [256, 256], out, leaky_relu_alpha=alpha, dropout_p=p_drop).to(_dev())
     layer.load_state_dict({k: v.float() for k, v in sd64.items()})
     layer.train()
     rs = np.random.RandomState(5)
@@ -538,10 +565,16 @@ def test_mplayer_dropout_exact(p_drop):
     mask64 = torch.from_numpy((rs.uniform(size=(B, N, 1)) < 0.8).astype(np.float64))
     mask64[:, 0] = 1
     ops.set_seed(4242)
-    x = x64.float().to(_dev()).requires_grad_(True)
+    if F == 3:   # as MPDiscriminator hands it over: a column slice of the [B, N, 4] batch
+        x4 = torch.cat([x64.float(), mask64.float() - 0.5], 2).to(_dev()).requires_grad_(True)
+        x = x4[..., :3]
+        assert not x.is_contiguous()
+    else:
+        x4 = x = x64.float().to(_dev()).requires_grad_(True)
     y = layer(x, True, mask64.float().to(_dev()))
     tag = ops.last_tag(_dev())
     (y * g64.float().to(_dev())).sum().backward()
+    dx = x4.grad[..., :F]
     thr, scale = ops.drop_params(p_drop)
     widths = {"e0": 96, "e1": 160, "e2": 192, "n0": 256, "n1": 256, "n2": out}
     sites = {"e0": ops.TAG_E0, "e1": ops.TAG_E1, "e2": ops.TAG_E2, "n0": ops.TAG_N0, "n1": ops.TAG_N1, "n2": ops.TAG_N2}
@@ -556,12 +589,23 @@ def test_mplayer_dropout_exact(p_drop):
         assert abs(frac - q) < max(0.01, 5 * (q * (1 - q) / m.numel()) ** 0.5), (k, frac)
     sdo = {"L." + k: v.clone().requires_grad_(True) for k, v in sd64.items()}
     xo = x64.clone().requires_grad_(True)
-    yo = oracle.mplayer_forward(sdo, "L", xo, mask64, alpha=1.0, p=thr / 256.0, keeps=keeps)
+    yo = oracle.mplayer_forward(sdo, "L", xo, mask64, alpha=alpha, p=thr / 256.0, keeps=keeps)
     (yo * g64).sum().backward()
-    errs = {"y": rel_err(y.detach().cpu().numpy(), yo.detach().numpy()), "dx": rel_err(x.grad.cpu().numpy(), xo.grad.numpy())}
+    errs = {"y": rel_err(y.detach().cpu().numpy(), yo.detach().numpy()), "dx": rel_err(dx.cpu().numpy(), xo.grad.numpy())}
     errs.update({k: rel_err(p.grad.cpu().numpy(), sdo["L." + k].grad.numpy()) for k, p in layer.named_parameters()})
     print("errs", errs)
-    _assert_smooth_bars(errs, p_drop)
+    if alpha == 1.0:
+        _assert_smooth_bars(errs, (p_drop, F))
+        return
+    assert errs["y"] < TIGHT, errs
+    sd32 = {"L." + k: v.float().requires_grad_(True) for k, v in sd64.items()}
+    x32 = x64.float().requires_grad_(True)
+    y32 = oracle.mplayer_forward(sd32, "L", x32, mask64.float(), alpha=alpha, p=thr / 256.0, keeps={k: v.float() for k, v in keeps.items()})
+    (y32 * g64.float()).sum().backward()
+    got = {"dx": dx.double().cpu().numpy(), **{k: p.grad.double().cpu().numpy() for k, p in layer.named_parameters()}}
+    ref = {"dx": xo.grad.numpy(), **{k: sdo["L." + k].grad.numpy() for k, _ in layer.named_parameters()}}
+    ctl = {"dx": x32.grad.double().numpy(), **{k: sd32["L." + k].grad.double().numpy() for k, _ in layer.named_parameters()}}
+    assert_grads(got, ref, TOL, control=ctl, what=(p_drop, F, alpha))
 
 
 def _option_cases():

@@ -805,3 +805,153 @@ def test_train_G_leaves_the_discriminators_gradient_buffer_clean(cfg):
             assert float(ts.fG.grad.abs().max()) == 0.0
     finally:
         MAB.fused = True
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The headline's own mode: D in training mode with dropout 1/2 in BOTH half-steps (train.py:419-421, :494-495).
+def _site_masks(log, n_jets, N, model, dev):
+    """Keep masks of one discriminator pass over ``n_jets`` jets, dumped site by site with ``mpg_dropout_mask`` from the
+    (kind, tag base, thr) entries ``ops.next_tag`` logged for it (those that carry dropout), as float32 {0, 1} tensors in
+    the oracle's ``keeps`` layout."""
+    from mpgan_amd import ops
+    ent = [e for e in log if e[2] > 0]
+    thr = ent[0][2]
+    dm = lambda rows, F, tag: ops.dropout_mask(rows, F, tag, thr, dev).cpu()
+    if model == "mpgan":
+        assert [e[0] for e in ent] == ["mplayer", "mplayer", "head"], log
+        widths = {"e0": 96, "e1": 160, "e2": 192, "n0": 256, "n1": 256, "n2": 32}
+        sites = {"e0": ops.TAG_E0, "e1": ops.TAG_E1, "e2": ops.TAG_E2, "n0": ops.TAG_N0, "n1": ops.TAG_N1, "n2": ops.TAG_N2}
+        layers = []
+        for _, tag, _ in ent[:2]:
+            k = {}
+            for s, wdt in widths.items():
+                if s.startswith("e"):
+                    k[s] = dm(n_jets * N * N, wdt, tag + sites[s]).reshape(n_jets, N, N, wdt)
+                else:
+                    k[s] = dm(n_jets * N, wdt, tag + sites[s]).reshape(n_jets, N, wdt)
+            layers.append(k)
+        return {"layers": layers, "fnd": dm(n_jets, 1, ent[2][1] + ops.TAG_GENERIC).reshape(n_jets, 1)}
+    kinds = [e[0] for e in ent]
+    assert kinds in (["bridge", "mab", "mab", "mab", "head"], ["linear", "mab", "mab", "mab", "head"]), log
+    E = 64
+    blk = lambda tag, L: {k: dm(n_jets * L, E, tag + s).reshape(n_jets, L, E) for s, k in enumerate(("a", "f", "o"))}
+    return {"emb": dm(n_jets * N, E, ent[0][1] + ops.TAG_GENERIC).reshape(n_jets, N, E),
+            "sab0": blk(ent[1][1], N), "sab1": blk(ent[2][1], N), "pma": blk(ent[3][1], 1),
+            "fc": dm(n_jets, 1, ent[4][1] + ops.TAG_GENERIC).reshape(n_jets, 1)}
+
+
+def _slice_keeps(k, lo, hi):
+    if isinstance(k, dict):
+        return {a: _slice_keeps(v, lo, hi) for a, v in k.items()}
+    if isinstance(k, list):
+        return [_slice_keeps(v, lo, hi) for v in k]
+    return k[lo:hi]
+
+
+def _oracle_keeps(k, model):
+    """(keeps as ``oracle.train_ref._fwd_D`` takes them for ``model``)"""
+    if model == "mpgan":
+        return dict(enumerate(k["layers"]), fnd=k["fnd"])
+    return k
+
+
+@pytest.mark.parametrize("model,B", [("mpgan", 8), ("mpgan", 64), ("gapt", 8), ("gapt", 64)])
+def test_train_iteration_with_dropout_vs_oracle(model, B):
+    """One whole train_D + train_G at ``disc_dropout = 0.5`` -- the bench's configuration: one-bit dropout in both
+    message-passing layers / every attention block of D, in its embedding and in its head, the fused epilogues, the
+    real + generated pass over 2B jets, the generator -> discriminator bridge -- against the oracle's iteration fed with the
+    very keep masks the launches drew (dumped per site; the site tags come from ``ops.next_tag``'s log).  Losses 1e-4,
+    first-iteration gradients of both networks 1e-3 with the oracle's own fp32 evaluation as the kink-flip control."""
+    from oracle import train_ref as T
+    from oracle.train_ref import synthetic_batch
+    from mpgan_amd import train, ops
+    N = 30
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if model == "mpgan":
+        G, D = train.default_mpgan(N, disc_dropout=0.5)
+        shG, shD, latent, lrs = T.mpgan_param_shapes(True), T.mpgan_param_shapes(False), 32, train.LR["g"]
+    else:
+        G, D = train.default_gapt(N, disc_dropout=0.5)
+        shG, shD, latent, lrs = T.gapt_param_shapes(True), T.gapt_param_shapes(False), 64, train.LR_GAPT
+    sdG = T.init_state_dict(shG, 41, torch.float64)
+    sdD = T.init_state_dict(shD, 42, torch.float64)
+    G.load_state_dict({k: v.float() for k, v in sdG.items()})
+    D.load_state_dict({k: v.float() for k, v in sdD.items()})
+    data, labels = synthetic_batch(B, N, seed=21)
+    gen = torch.Generator().manual_seed(9)
+    nD, nG = torch.randn(B, N, latent, generator=gen) * 0.2, torch.randn(B, N, latent, generator=gen) * 0.2
+    # (lr_disc = 0: see test_train_step_n150_vs_oracle -- RMSprop's first step is -10 lr sign(g), and the G step is compared
+    # on the SAME discriminator here and in the oracle)
+    ts = train.TrainStep(G, D, B, N, latent=latent, use_graphs=False, lr_disc=0.0, lr_gen=lrs[1])
+    ts.set_batch(data.cuda(), labels.cuda())
+    ts.fixed_noise = (nD.cuda(), nG.cuda())
+    ops.set_seed(0x5EED0000 + B)
+    st = ops.dev_state(dev)
+    st.tag_log = []
+    try:
+        ts._seg_D()
+        log_D, st.tag_log = st.tag_log, []
+        gradD = {k: p.grad.detach().double().cpu().numpy().copy() for k, p in D.named_parameters()}
+        kD = _site_masks(log_D, 2 * B, N, model, dev)       # (the seed moves on in _seg_end: dump before)
+        ts._seg_G()
+        log_G = st.tag_log
+        gradG = {k: p.grad.detach().double().cpu().numpy().copy() for k, p in G.named_parameters()}
+        kG = _site_masks(log_G, B, N, model, dev)
+    finally:
+        st.tag_log = None
+    ts._seg_end()
+    torch.cuda.synchronize()
+    frac = float(kD["fnd" if model == "mpgan" else "fc"].mean())
+    print("tag log D step", log_D, "\nG step", log_G, "; head keep fraction", frac)
+    keeps = (_oracle_keeps(_slice_keeps(kD, 0, B), model), _oracle_keeps(_slice_keeps(kD, B, 2 * B), model),
+             _oracle_keeps(kG, model))
+    c32 = lambda sd: {k: v.float() for k, v in sd.items()}
+    _, _, cD, cG = T.train_iteration(model, c32(sdD), c32(sdG), {}, {}, data.float(), labels.float(), nD.float(), nG.float(),
+                                     0.0, lrs[1], p_disc=0.5, keeps=keeps, return_grads=True)
+    dl, gl, gD, gG = T.train_iteration(model, sdD, sdG, {}, {}, data.double(), labels.double(), nD.double(), nG.double(),
+                                       0.0, lrs[1], p_disc=0.5, keeps=keeps, return_grads=True)
+    num = lambda d: {k: v.detach().double().numpy() for k, v in d.items()}
+    print("losses: HIP", float(ts.D_loss), float(ts.G_loss), "oracle", dl, gl)
+    assert abs(float(ts.D_loss) - dl) < 1e-4 * abs(dl) and abs(float(ts.G_loss) - gl) < 1e-4 * abs(gl)
+    assert_grads(gradD, num(gD), 1e-3, control=num(cD), what=(model, B, "D"))
+    assert_grads(gradG, num(gG), 1e-3, control=num(cG), what=(model, B, "G"))
+
+
+def test_device_seed_follows_torch_seed_and_travels_with_the_checkpoint():
+    """The noise / dropout streams are keyed by the device seed: ``TrainStep`` derives it from ``torch.initial_seed()`` and the
+    rank (torch.manual_seed keeps the reference's meaning, setup_training.py:184), an explicit ``ops.set_seed`` is never
+    overwritten, and the value rides in G's optimizer state dict so that a resumed run continues the stream."""
+    from mpgan_amd import train, ops
+    from oracle.train_ref import synthetic_batch
+    B, N = 4, 30
+    dev = torch.device("cuda", torch.cuda.current_device())
+    st = ops.dev_state(dev)
+    before = torch.initial_seed()
+    try:
+        st.seed_is_default = True
+        torch.manual_seed(5)
+        G, D = _setup(B, N, disc_dropout=0.5)
+        ts = train.TrainStep(G, D, B, N, use_graphs=False)
+        assert ops.get_seed(dev) == ops.derived_seed(5, 0) and st.seed_is_default
+        assert len({ops.derived_seed(s, r) for s in (5, 6) for r in range(8)}) == 16
+        torch.manual_seed(6)
+        ts = train.TrainStep(G, D, B, N, use_graphs=False)
+        assert ops.get_seed(dev) == ops.derived_seed(6, 0)
+        ops.set_seed(123, dev)
+        ts = train.TrainStep(G, D, B, N, use_graphs=False)
+        assert ops.get_seed(dev) == 123                   # the caller's choice stands
+        data, labels = synthetic_batch(B, N, seed=2)
+        ts.set_batch(data.cuda(), labels.cuda())
+        ts.step()
+        torch.cuda.synchronize()
+        now = ops.get_seed(dev)
+        assert now == (123 + ops.SEED_STEP) & 0xFFFFFFFFFFFFFFFF   # one iteration on
+        sdD, sdG = ts.optimizer_state_dicts()
+        assert sdG["param_groups"][0][train.FlatParams.SEED_KEY] == now and train.FlatParams.SEED_KEY not in sdD["param_groups"][0]
+        torch.optim.RMSprop([torch.zeros(tuple(p.shape)) for p in G.parameters()], lr=1.0).load_state_dict(sdG)   # torch reads it
+        ops.set_seed(999, dev)
+        ts.load_optimizer_state_dicts(sdD, sdG)
+        assert ops.get_seed(dev) == now
+    finally:
+        st.seed_is_default = True
+        torch.manual_seed(before)

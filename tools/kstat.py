@@ -6,7 +6,8 @@ usage: kstat.py file.hip [extra hipcc flags ...]   (run from anywhere; include p
 import os, re, subprocess, sys, tempfile
 src = os.path.abspath(sys.argv[1])
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))) if False else os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = tempfile.mktemp(suffix=".s")
+fd, out = tempfile.mkstemp(suffix=".s")
+os.close(fd)
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-I", os.path.join(root, "include"),
        "-I", os.path.join(root, "mpgan_amd", "csrc"), "--cuda-device-only", "-S", src, "-o", out] + sys.argv[2:]
 subprocess.check_call(cmd)
