@@ -302,6 +302,15 @@ int mpg_attn_bwd(const MpgAttn* p, void* stream);
 int mpg_rank_mask(const float* x, int ld_jet, int ld_part, const float* labels, int ld_lab, int B, int N,
                   float* mask, float* ignore, void* stream);
 
+/* mpg_edge_waves: which form the plain edge launches take from now on, process-wide -- fwd for mpg_edge_fwd, bwd for mpg_edge_bwd:
+ * 8 = eight waves per workgroup (two per SIMD, one sender per wave: csrc/edge_fwd1_impl.h, edge_bwd1_impl.h), 4 = four waves
+ * (one per SIMD, senders in pairs: edge_fwd2_impl.h, edge_bwd2_impl.h), 0 = as the environment says (MPG_FWD_WAVES / MPG_BWD_WAVES;
+ * default 8).  Same function either way; the sums over senders (agg, da) are ordered differently, so results agree to fp32
+ * rounding, not bit for bit.  The epilogue forms (mpg_edge_fwd_fn, mpg_edge_bwd_fn) are four-wave kernels.  Returns 0, or -1 for
+ * any other value.  (No reference counterpart: a launch-shape switch.) */
+int mpg_edge_waves(int fwd, int bwd);
+int mpg_edge_waves_get(int which);   /* the value set for fwd (which = 0) / bwd (1) */
+
 /* mpg_jet_order: the jets of a batch by decreasing number of unmasked particles (ties by index), order[0] the fullest --
  * MpgEdgeFwd.order / MpgEdgeBwd.order.  The edge kernels take a workgroup per jet and as long as the jet has senders; when a
  * launch has more workgroups than the chip has CUs (the discriminator's real + generated batch), handing them out heaviest

@@ -220,6 +220,8 @@ SIGNATURES = {
     "mpg_knn_sets": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_void_p]),
     "mpg_rank_mask": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_void_p]),
     "mpg_jet_order": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_void_p]),
+    "mpg_edge_waves": (C.c_int, [C.c_int, C.c_int]),
+    "mpg_edge_waves_get": (C.c_int, [C.c_int]),
     "mpg_gen_tail_fwd": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mpg_gen_tail_bwd": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mpg_disc_head_fwd": (C.c_int, [C.POINTER(MpgDiscHead), C.c_void_p]),
@@ -262,6 +264,33 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _includes(path, seen):
+    """Transitive closure of the quoted includes of ``path`` (resolved beside the including file, then in INCLUDE)."""
+    import re
+    if path in seen:
+        return
+    seen.add(path)
+    with open(path, "r", errors="replace") as f:
+        text = f.read()
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+        for root in (os.path.dirname(path), INCLUDE):
+            cand = os.path.normpath(os.path.join(root, inc))
+            if os.path.isfile(cand):
+                _includes(cand, seen)
+                break
+
+
+def _digest(src, flags) -> str:
+    import hashlib
+    deps = set()
+    _includes(os.path.abspath(src), deps)
+    h = hashlib.sha1(" ".join(flags).encode())
+    for d in sorted(deps):
+        with open(d, "rb") as f:
+            h.update(os.path.relpath(d, CSRC).encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()[:16]
+
+
 def _compiler_env():
     """Environment for the hipcc children: without a profiler's preload.  ``rocprofv3`` injects a library that
     initialises the GPU in every process it is loaded into; hipcc then execs clang -- a GPU-initialised exec, which
@@ -295,12 +324,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         env = _compiler_env()
         tmpdir = tempfile.mkdtemp(prefix=".build.", dir=LIBDIR)
+        # Object cache (LIBDIR/obj, git-ignored with the library): an object is reused when the digest of its source, of
+        # every header it includes (transitively, quoted includes) and of the compiler flags is unchanged -- editing one kernel
+        # recompiles its translation units only.  ``force`` (the driver's "does it build" check) ignores the cache.
+        objdir = os.path.join(LIBDIR, "obj")
+        os.makedirs(objdir, exist_ok=True)
         try:
-            jobs = []
+            jobs, objs = [], []
+            flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + EXTRA_FLAGS
             for src in sources():
-                obj = os.path.join(tmpdir, os.path.basename(src)[:-4] + ".o")
-                jobs.append((obj, [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + EXTRA_FLAGS
-                             + ["-I", INCLUDE, "-c", src, "-o", obj]))
+                base = os.path.basename(src)[:-4]
+                obj = os.path.join(objdir, "%s.%s.o" % (base, _digest(src, flags)))
+                objs.append(obj)
+                if force or not os.path.isfile(obj):
+                    tmpobj = os.path.join(tmpdir, base + ".o")
+                    jobs.append((tmpobj, [hipcc] + flags + ["-I", INCLUDE, "-c", src, "-o", tmpobj], obj, base))
             # the translation units are independent (one takes over a minute): compile them side by side
             from concurrent.futures import ThreadPoolExecutor
 
@@ -308,9 +346,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 if verbose:
                     print(" ".join(job[1]))
                 subprocess.run(job[1], check=True, env=env)
-                return job[0]
-            with ThreadPoolExecutor(max_workers=max(1, min(os.cpu_count() or 4, 8, len(jobs)))) as ex:
-                objs = list(ex.map(run, jobs))
+                for old in glob.glob(os.path.join(objdir, job[3] + ".*.o")):   # superseded objects of this unit
+                    os.remove(old)
+                os.replace(job[0], job[2])
+            if jobs:
+                with ThreadPoolExecutor(max_workers=max(1, min(os.cpu_count() or 4, 8, len(jobs)))) as ex:
+                    list(ex.map(run, jobs))
             tmplib = os.path.join(tmpdir, "libmpgan_amd.so")
             subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmplib] + objs, check=True, env=env)
             os.replace(tmplib, LIBPATH)

@@ -57,11 +57,17 @@ MPG_DEV bool c2_keep(uint32_t word, int g, int t, uint32_t thr) {
 // with the input rows as B fragments ([k-step][hi|lo][lane], ascale * x) and, around its own loads, calls
 // first_tile(I0), bias_request(), first_tile(I1), bias_store() in that order (the first weight tiles are requested as
 // early as the caller's own loads allow: vector memory completes in issue order).
-template <bool F16, int KS0, int KS1, int KS2, int DROP, int GATES, int RESID, bool SL, typename Stage>
+// NW: waves of the workgroup.  4 (one per SIMD, 512 registers each): a wave owns up to TWO output tiles of a layer (w, w + 4), whole
+// weight tiles in two register slots, the first tile's epilogue in the MFMA slots of the second.  8 (two per SIMD, 256 registers
+// each: the epilogue of the eight-wave edge forward, edge_fwd1_impl.h): a wave owns ONE tile (w) in one slot; its epilogue runs
+// beside its SIMD partner's MFMAs instead.  Same arithmetic per element either way.
+template <bool F16, int KS0, int KS1, int KS2, int DROP, int GATES, int RESID, bool SL, int NW = 4, typename Stage>
 MPG_DEV void c2_body(const MpgChain& p, const int m0, const int nrows, char* fb0, char* fb1, float* sbias, Stage&& stage,
                      unsigned long long* c2_st = nullptr) {
     typedef typename FragT<F16>::type V;
     constexpr int NL = 1 + (KS1 > 0) + (KS2 > 0);
+    constexpr int NSL = 8 / NW;   // register slots (tiles per wave and layer)
+    static_assert(NW == 4 || NW == 8, "four or eight waves");
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5, lane16 = lane * 16;
@@ -88,12 +94,12 @@ MPG_DEV void c2_body(const MpgChain& p, const int m0, const int nrows, char* fb0
         static_for<0, NL>([&](auto lc) {
             MPG_CI(l, lc);
             const float so = p.L[l].drop_thr ? p.L[l].drop_scale : 1.f;   // the layer's dropout scale rides on bias and product
-            sbias[256 * l + tid] = bv[l] * so;
+            if (NW == 4 || tid < 256) sbias[256 * l + tid] = bv[l] * so;
         });
     };
 
     C2_STAMP(18);
-    V wb[2][16][2];   // [slot A | slot B][k-step][hi | lo]: whole tiles
+    V wb[NSL][16][2];   // [slot A | slot B][k-step][hi | lo]: whole tiles
     auto load_tile = [&](auto lc, auto bc, int tile) {
         MPG_CI(l, lc);
         MPG_CI(b, bc);
@@ -112,7 +118,9 @@ MPG_DEV void c2_body(const MpgChain& p, const int m0, const int nrows, char* fb0
     // behind 64 KiB of weights per wave
     auto first_tile = [&](auto bc) {
         MPG_CI(b, bc);
-        if (w + 4 * b < (p.L[0].N + 31) / 32) load_tile(I0{}, bc, w + 4 * b);
+        if constexpr (b < NSL) {
+            if (w + NW * b < (p.L[0].N + 31) / 32) load_tile(I0{}, bc, w + NW * b);
+        }
     };
 
     stage(first_tile, bias_request, bias_store, seed_lo, seed_hi, ascale);
@@ -129,7 +137,7 @@ MPG_DEV void c2_body(const MpgChain& p, const int m0, const int nrows, char* fb0
         const V* fin = reinterpret_cast<const V*>((l & 1) ? fb1 : fb0);
         V* fout = reinterpret_cast<V*>((l & 1) ? fb0 : fb1);
         const int MT = (L.N + 31) / 32;
-        const bool actA = w < MT, actB = w + 4 < MT;
+        const bool actA = w < MT, actB = NSL == 2 && w + 4 < MT;
         const float zscale = (L.wscale > 0.f ? L.wscale : 1.f) * ascale, inv_z = 1.f / zscale;
         const float alpha_eff = L.act ? p.alpha : 1.f;
         const bool has_gate = L.gateH != nullptr;
@@ -276,8 +284,7 @@ MPG_DEV void c2_body(const MpgChain& p, const int m0, const int nrows, char* fb0
         // descriptors of the next layer's image for this wave's two slots (zero length where it has no tile there)
         const void* imgn = last ? p.L[l].Wimg : p.L[last ? l : l + 1].Wimg;
         const __amdgpu_buffer_rsrc_t rwnA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(imgn), 0, (!last && w < MTn) ? 2 * nfragn * 1024 : 0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rwnB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(imgn), 0, (!last && w + 4 < MTn) ? 2 * nfragn * 1024 : 0, 0x00020000);
-        C2Tile TA, TB;
+        C2Tile TA;
         if (actA) {
             request(TA, w);
             kloop(I0{}, I0{}, TA, TA, rwnA, w);
@@ -285,15 +292,21 @@ MPG_DEV void c2_body(const MpgChain& p, const int m0, const int nrows, char* fb0
             if (w < MTn) load_tile(std::integral_constant<int, l + 1>{}, I0{}, w);            // (no loop to ride in)
         }
         C2_STAMP(3 + 5 * l);
-        if (actB) {
-            request(TB, w + 4);
-            kloop(I1{}, std::integral_constant<int, NU>{}, TB, TA, rwnB, w + 4);              // ... with tile A's epilogue
-        } else if constexpr (!last) {
-            if (w + 4 < MTn) load_tile(std::integral_constant<int, l + 1>{}, I1{}, w + 4);
+        if constexpr (NSL == 2) {
+            const __amdgpu_buffer_rsrc_t rwnB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(imgn), 0, (!last && w + 4 < MTn) ? 2 * nfragn * 1024 : 0, 0x00020000);
+            C2Tile TB;
+            if (actB) {
+                request(TB, w + 4);
+                kloop(I1{}, std::integral_constant<int, NU>{}, TB, TA, rwnB, w + 4);          // ... with tile A's epilogue
+            } else if constexpr (!last) {
+                if (w + 4 < MTn) load_tile(std::integral_constant<int, l + 1>{}, I1{}, w + 4);
+            }
+            C2_STAMP(4 + 5 * l);
+            if (actB) static_for<0, NU>([&](auto uc) { unit(uc, TB); });
+            else if (actA) static_for<0, NU>([&](auto uc) { unit(uc, TA); });
+        } else {
+            if (actA) static_for<0, NU>([&](auto uc) { unit(uc, TA); });
         }
-        C2_STAMP(4 + 5 * l);
-        if (actB) static_for<0, NU>([&](auto uc) { unit(uc, TB); });
-        else if (actA) static_for<0, NU>([&](auto uc) { unit(uc, TA); });
         C2_STAMP(5 + 5 * l);
         __syncthreads();
         C2_STAMP(6 + 5 * l);
@@ -304,7 +317,7 @@ MPG_DEV void c2_body(const MpgChain& p, const int m0, const int nrows, char* fb0
 // B fragments into fb0: unit = (k-step, lane) = 8 features of one row.  Only the first ``nrows`` rows are this workgroup's
 // (the others are staged as zeros and their in_out is not written).  The ``stage`` argument of c2_body for callers whose
 // rows come from memory: the stand-alone kernel and the fused data-gradient kernel's prologue.
-template <bool F16, int KS0, int DROP, typename FT, typename BR, typename BS>
+template <bool F16, int KS0, int DROP, int NW = 4, typename FT, typename BR, typename BS>
 MPG_DEV void c2_stage_rows(const MpgChain& p, const int m0, const int nrows, char* fb0, FT&& first_tile, BR&& bias_request, BS&& bias_store,
                            const uint32_t seed_lo, const uint32_t seed_hi, const float ascale, unsigned long long* c2_st = nullptr) {
     typedef typename FragT<F16>::type V;
@@ -320,7 +333,8 @@ MPG_DEV void c2_stage_rows(const MpgChain& p, const int m0, const int nrows, cha
                           (p.in_out == nullptr || ((p.ld_in_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in_out) & 15) == 0)));
         if (fast) {
             // every load of the thread's (up to four) units first, then the arithmetic
-            constexpr int NI = (KS0 * 64 + 255) / 256;
+            constexpr int NTH = 64 * NW;
+            constexpr int NI = (KS0 * 64 + NTH - 1) / NTH;
             float4 x[NI][2];
             const float* a2 = p.A2 != nullptr ? p.A2 : p.A;
             // unit u = (row rr, k-step ks, half hh), row-major: the 2 KS0 units of a row sit on adjacent lanes, so a wave
@@ -328,7 +342,7 @@ MPG_DEV void c2_stage_rows(const MpgChain& p, const int m0, const int nrows, cha
             // requests per instruction, 2k clk of the texture path per workgroup before the first weight tile could be asked for)
             static_for<0, NI>([&](auto ic) {
                 MPG_CI(i, ic);
-                const int u = min(tid + 256 * i, KS0 * 64 - 1), rr = u / (2 * KS0), rem = u - rr * (2 * KS0), ks = rem >> 1, hh = rem & 1;
+                const int u = min(tid + NTH * i, KS0 * 64 - 1), rr = u / (2 * KS0), rem = u - rr * (2 * KS0), ks = rem >> 1, hh = rem & 1;
                 const size_t row = (size_t)min(m0 + rr, p.M - 1);
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
@@ -348,7 +362,7 @@ MPG_DEV void c2_stage_rows(const MpgChain& p, const int m0, const int nrows, cha
                 p.in_out, 0, p.in_out != nullptr ? (int)((size_t)p.M * p.ld_in_out * 4) : 0, 0x00020000);
             static_for<0, NI>([&](auto ic) {
                 MPG_CI(i, ic);
-                const int u = tid + 256 * i, uc = min(u, KS0 * 64 - 1), rr = uc / (2 * KS0), rem = uc - rr * (2 * KS0), ks = rem >> 1, hh = rem & 1;
+                const int u = tid + NTH * i, uc = min(u, KS0 * 64 - 1), rr = uc / (2 * KS0), rem = uc - rr * (2 * KS0), ks = rem >> 1, hh = rem & 1;
                 const int ln = rr + 32 * hh;
                 const int mm = m0 + rr;
                 const bool live = rr < nrows && mm < p.M;
@@ -388,7 +402,7 @@ MPG_DEV void c2_stage_rows(const MpgChain& p, const int m0, const int nrows, cha
         } else {
             bias_request();
             bias_store();
-            for (int u = tid; u < KS0 * 64; u += 256) {
+            for (int u = tid; u < KS0 * 64; u += 64 * NW) {
                 const int ks = u >> 6, ln = u & 63, rr = ln & 31, hh = ln >> 5;
                 const int mm = m0 + rr;
                 float v[8];

@@ -1,7 +1,7 @@
 // mpg_edge_fwd (the fused edge network's forward: edge_fwd2_impl.h holds the kernel; this unit has the entry point and the
 // no-dropout variants, the variants with dropout are edge_fwd_d1.hip / edge_fwd_d2.hip so that the three parts of the
 // slow-to-compile template build side by side) and mpg_pack_weights (the weight images every fused kernel takes).
-#include "edge_fwd2_impl.h"
+#include "edge_fwd1_impl.h"
 
 int mpg_edge_fwd_d1(const MpgEdgeFwd* p, hipStream_t st);   // edge_fwd_d1.hip: byte-threshold dropout
 int mpg_edge_fwd_q0(const MpgEdgeFwd* p, hipStream_t st);   // edge_fwd_q{0,1,2}.hip: with edge scalars, by dropout mode
@@ -40,6 +40,18 @@ __global__ void pack_kernel(const float* __restrict__ W, int ldw, int rows, int 
 }  // namespace
 
 
+// mpg_edge_waves: 0 = as the environment says (MPG_FWD_WAVES / MPG_BWD_WAVES, default eight), 4 / 8 = that form of the plain
+// forward (fwd) and of mpg_edge_bwd (bwd) from now on, process-wide.  The two forms give the same results up to the order of the
+// sums over senders (agg, da); tests that pin launch forms against each other bit for bit choose one.
+static std::atomic<int> g_edge_waves[2];
+extern "C" int mpg_edge_waves_get(int which) { return g_edge_waves[which & 1].load(std::memory_order_relaxed); }
+extern "C" int mpg_edge_waves(int fwd, int bwd) {
+    if ((fwd != 0 && fwd != 4 && fwd != 8) || (bwd != 0 && bwd != 4 && bwd != 8)) return -1;
+    g_edge_waves[0].store(fwd, std::memory_order_relaxed);
+    g_edge_waves[1].store(bwd, std::memory_order_relaxed);
+    return 0;
+}
+
 extern "C" int mpg_pack_weights(const float* W, int ldw, int rows, int cols, int transpose, float scale, int f16,
                                 void* img, void* stream) {
     const int MT = (rows + 31) / 32, QT = (cols + 31) / 32;
@@ -63,13 +75,17 @@ extern "C" int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream) {
     if (p->stageE2 != nullptr && (long long)p->B * ((p->N + 31) / 32) * p->N * 10240LL > 0x7fffffffLL) return -7;
     hipStream_t st = (hipStream_t)stream;
 #ifdef MPG_SINGLE_VARIANT  // tools/ubench/fwd_bench.hip: one dropout mode, seconds to compile
+#ifdef MPG_FWD1   // (-DMPG_FWD1: the eight-wave form, edge_fwd1_impl.h)
+    return f1_launch<MPG_SINGLE_VARIANT>(p, st);
+#else
     return f2_launch<MPG_SINGLE_VARIANT>(p, st);
+#endif
 #else
     const int dm = p->thr == 0 ? 0 : (p->thr == 128 ? 2 : 1);
     if (p->es != nullptr) {
         if (p->wq == nullptr) return -3;
         return dm == 0 ? mpg_edge_fwd_q0(p, st) : (dm == 1 ? mpg_edge_fwd_q1(p, st) : mpg_edge_fwd_q2(p, st));
     }
-    return dm == 0 ? f2_launch<0>(p, st) : (dm == 1 ? mpg_edge_fwd_d1(p, st) : mpg_edge_fwd_d2(p, st));
+    return dm == 0 ? (fwd_eight_waves() ? f1_launch<0>(p, st) : f2_launch<0>(p, st)) : (dm == 1 ? mpg_edge_fwd_d1(p, st) : mpg_edge_fwd_d2(p, st));
 #endif
 }

@@ -1,0 +1,522 @@
+// Fused edge network, forward -- the EIGHT-WAVE form: two waves per SIMD, every wave one sender at a time.
+//
+// Same function, same memory formats (a | c rows in, agg rows, sign words and parked E2 fragments out) and the same
+// per-element arithmetic as edge_fwd2_impl.h (bias first, then per k-step lo*hi, hi*lo, hi*hi, k ascending); what changes
+// is who does what.  The four-wave kernel gives one wave per SIMD all 512 registers and walks its senders in pairs; it is
+// bound by VALU ISSUE: ~2,700 vector instructions against 540 MFMAs per pair, one wave issuing one vector instruction per
+// ~5-7 clk (tools/ubench/valu_rate2.hip), where a second wave on the SIMD issues beside the first at the same rate.  Here a
+// workgroup has eight waves of <= 256 registers; a wave owns ONE sender per round (agg 96 + layer-2 accumulators 80 or E2
+// fragments 80 + two layer-3 tiles 32 + weight fragments), so that one wave's MFMA-free stretches (the E2 split, the e1
+// build) run beside its SIMD partner's MFMAs.  Weight delivery: W3 hi | lo from LDS, 2 KiB per three MFMAs per wave
+// (85 B/clk/CU of 256); W2 hi | lo streams from L2 through a five-tile register ring, one k-step ahead.
+// With 256 registers there are no AGPR copies: the accumulators are VGPRs the epilogues read in place (the four-wave form
+// spends 500 of its 2,700 vector instructions per pair on v_accvgpr_read / _write).
+#pragma once
+#include "edge_fwd2_impl.h"
+#include <stdlib.h>
+
+#ifndef MPG_F1_STAGGER
+#define MPG_F1_STAGGER 0   // experiment (tools/ubench/fwd_bench.hip): waves 4..7 start this many s_sleep(16) (~1k clk each) late
+#endif
+
+#ifdef MPG_F1_STAMP   // diagnostic build (tools/ubench/fwd_bench.hip): s_memtime per section of a wave's senders, summed per wave
+__device__ unsigned long long f1_stamps[4096 * 8 * 8];
+#define F1_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); f1_acc[i] += t_ - f1_t; f1_t = t_; }
+#else
+#define F1_STAMP(i)
+#endif
+
+namespace {
+
+constexpr int F1_NW = 8;
+static_assert(F1_NW * H1 * 4 == F2_C_BYTES, "one row of c per wave in the four-wave kernel's two-rows-per-wave area");
+
+MPG_DEV void fill_lds_dma8(void* dst, const void* src, int bytes, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int c = wave; c < bytes / 1024; c += F1_NW)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(src) + c * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(static_cast<char*>(dst) + c * 1024), 16, 0, 0);
+}
+
+// FN / cp / cp2: as edge_fwd_body's (the node network and the next layer's a | c projection as the workgroup's epilogue), run
+// by c2_body's eight-wave form.
+template <int DROP, bool SIGN, int NQ, int FN>
+MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = nullptr, const MpgChain* const cp2 = nullptr) {
+    typedef f16x8 V;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef MPG_F1_STAMP
+    const unsigned long long f1_k0 = __builtin_amdgcn_s_memtime(), f1_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int RB = (p.N + 31) / 32;
+    int bid = blockIdx.x;
+    const int sc = bid % p.SC; bid /= p.SC;
+    const int rb = bid % RB;
+    const int b = p.order != nullptr ? p.order[bid / RB] : bid / RB;
+    const int i = rb * 32 + r;
+    const bool vi = i < p.N;
+    const int JC = (p.N + p.SC - 1) / p.SC;
+    const int jbeg = sc * JC, jend = min(p.N, jbeg + JC);
+    const int ldac = p.ld_ac ? p.ld_ac : H1;
+
+    const __amdgpu_buffer_rsrc_t r2 = img_rsrc(p.W2img, 2 * NF2);   // W2 hi | lo
+    const int lane16 = lane * 16;
+    const V* g3 = reinterpret_cast<const V*>(p.W3img);
+    V* l3 = reinterpret_cast<V*>(smem);
+    float4* la = reinterpret_cast<float4*>(smem + F2_W_BYTES);
+    float* lb2 = reinterpret_cast<float*>(smem + F2_W_BYTES + F2_A_BYTES);
+    float* lb3 = lb2 + H2;
+    float* lcw = lb3 + H3 + w * H1;                                            // this wave's row of c
+    unsigned short* lst = reinterpret_cast<unsigned short*>(smem + F2_W_BYTES + F2_A_BYTES + F2_B_BYTES + F2_C_BYTES);
+    int* lnv = reinterpret_cast<int*>(lst + F2_LIST_MAX);
+
+    // ---- prologue (as the four-wave kernel's, on 512 threads): small loads first, W3's image by LDS-DMA behind them
+    static_assert(H2 + H3 <= 512 && T1 * 4 * 64 == 512 + 256, "the prologue's register sets");
+    const int tb = min(tid, H2 + H3 - 1);
+    const float bv = tb < H2 ? p.b2[tb] : p.b3[tb - H2];
+    float4 av[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = min(tid + 512 * u, T1 * 4 * 64 - 1);
+        const int ln = t & 63, qsu = t >> 6, rr = ln & 31, hh = ln >> 5, ii = min(rb * 32 + rr, p.N - 1);
+        av[u] = ld4(p.a + (size_t)(b * p.N + ii) * ldac + 8 * qsu + 4 * hh);
+    }
+    fill_lds_dma8(l3, g3, 2 * NF3 * 1024, tid);
+    if constexpr (NQ > 0)
+        for (int t = tid; t < NQ * H1; t += 512) reinterpret_cast<float*>(smem + F2_Q_OFF)[t] = p.wq[t] * SC_A;
+    if (tid < H2 + H3) lb2[tid] = bv * (tid < H2 ? SC_E2 : SC_E3);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = tid + 512 * u;
+        const bool in = rb * 32 + (t & 31) < p.N;
+        if (t < T1 * 4 * 64)
+            la[t] = in ? make_float4(av[u].x * SC_A, av[u].y * SC_A, av[u].z * SC_A, av[u].w * SC_A) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const bool whole = p.N <= F2_LIST_MAX;
+    const int lbeg = whole ? 0 : jbeg, lend = whole ? p.N : jend;
+    if (w == 0) {
+        int cnt = 0;
+        for (int j0 = lbeg; j0 < lend; j0 += 64) {
+            const int j = j0 + lane;
+            const bool ok = j < lend && (!(p.skip_masked & 1) || p.mask == nullptr || p.mask[b * p.N + j] != 0.f);
+            const unsigned long long bits = __ballot(ok);
+            if (ok) lst[cnt + __popcll(bits & ((1ull << lane) - 1ull))] = (unsigned short)j;
+            cnt += __popcll(bits);
+        }
+        if (lane == 0) *lnv = cnt;
+    }
+    __syncthreads();
+    int nvalid = __builtin_amdgcn_readfirstlane(*lnv);
+    if (whole) {
+        const int per = (nvalid + p.SC - 1) / p.SC, l0 = min(nvalid, sc * per);
+        lst += l0;
+        nvalid = min(per, nvalid - l0);
+    }
+
+    uint32_t seed_lo = 0, seed_hi = 0;
+    if (DROP) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+
+    const uint32_t lb3hi = lds_base(smem, lane16), lb3lo = lds_base(smem, NF3 * 1024 + lane16);
+    const uint32_t lbla = lds_base(smem, F2_W_BYTES + lane16);
+    const uint32_t lbc = lds_base(smem, F2_W_BYTES + F2_A_BYTES + F2_B_BYTES + w * (H1 * 4) + 16 * h);
+    const uint32_t lbq = lds_base(smem, F2_Q_OFF + 16 * h);
+    // (the bias columns through one opaque base + immediate offsets: plain pointer arithmetic makes the compiler keep one
+    // address register per 16-byte group, hoisted out of the sender loop -- 44 registers this kernel does not have)
+    const uint32_t lbb = lds_base(smem, F2_W_BYTES + F2_A_BYTES + 16 * h);
+
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(p.sign3, 0, SIGN ? p.B * RB * p.N * (T3 * 32 * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(p.stageE2, 0, (SIGN && p.stageE2 != nullptr) ? p.B * RB * p.N * (NFR2 * 1024) : 0, 0x00020000);
+
+    f32x16 agg[T3];
+#pragma unroll
+    for (int m = 0; m < T3; ++m)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) agg[m][k] = 0.f;
+
+    // the sender's row of c is requested one round ahead
+    float pc0, pc1;
+    float pes[NQ > 0 ? NQ : 1];
+    auto prefetch = [&](int sn) {
+        const int jn = __builtin_amdgcn_readfirstlane((int)lst[max(0, min(sn, nvalid - 1))]);
+        const float* cj = p.c + (size_t)(b * p.N + jn) * ldac;
+        pc0 = cj[lane];
+        pc1 = cj[64 + (lane & 31)];
+        if constexpr (NQ > 0) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) pes[q] = p.es[((size_t)(b * p.N + jn) * NQ + q) * p.N + (vi ? i : 0)];
+        }
+    };
+    prefetch(w);
+#if MPG_F1_STAGGER
+    if (w >= 4)
+        for (int t = 0; t < MPG_F1_STAGGER; ++t) __builtin_amdgcn_s_sleep(16);
+#endif
+#ifdef MPG_F1_STAMP
+    unsigned long long f1_acc[8] = {}, f1_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long f1_t0 = f1_t;
+#endif
+    for (int s = w; s < nvalid; s += F1_NW) {
+        F1_STAMP(4)
+        const int jj = __builtin_amdgcn_readfirstlane((int)lst[s]);
+        const float mj = p.mask ? p.mask[b * p.N + jj] : 1.f;
+        float mjs = mj * p.dscale * (1.f / SC_E3);   // (the layer-3 output carries SC_E3)
+        if (p.nbr != nullptr) {
+            const unsigned int wb = p.nbr[(size_t)(b * p.N + (vi ? i : 0)) * ((p.N + 31) >> 5) + (jj >> 5)];
+            mjs = ((wb >> (jj & 31)) & 1u) ? mjs : 0.f;
+        }
+        const uint32_t erow = (uint32_t)((b * p.N + i) * p.N + jj);
+        lcw[lane] = pc0 * SC_A;
+        if (lane < H1 - 64) lcw[64 + lane] = pc1 * SC_A;
+        float esv[NQ > 0 ? NQ : 1];
+        if constexpr (NQ > 0) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) esv[q] = pes[q];
+        }
+        prefetch(s + F1_NW);
+
+        F1_STAMP(0)
+        // ---- layer 2: Z2 = W2' E1 + b2, k-outer; e1 = drop(lrelu(a_i + c_j)) built one k-step ahead; W2's fragments in a
+        //      ring of five tiles: tile m's pair of k-step k + 1 is requested behind tile m's MFMAs of k-step k
+        f32x16 acc[T2];
+        {
+            constexpr int KS = T1 * 2;
+            V eh[2], el[2];          // [buffer] e1 fragment (hi, lo) of a k-step
+            V wh[T2], wl[T2];        // [tile] W2 fragments of the k-step in flight
+            float v1[8];
+            PairSplit<V> ps1[4];
+            f32x4 a4[2], c4[2];
+            f32x4 q4[NQ > 0 ? NQ : 1][2];
+            auto load_w = [&](auto kc, auto mc) {
+                MPG_CI(k, kc); MPG_CI(m, mc);
+                wh[m] = img_frag<V>(r2, lane16, m * KS + k);
+                wl[m] = img_frag<V>(r2, lane16, NF2 + m * KS + k);
+            };
+            auto load_a = [&](auto kc) {
+                MPG_CI(k, kc);
+                a4[0] = lds_frag<f32x4>(lbla, (k * 2 + 0) * 1024);
+                a4[1] = lds_frag<f32x4>(lbla, (k * 2 + 1) * 1024);
+#pragma unroll
+                for (int uh = 0; uh < 2; ++uh) c4[uh] = lds_frag<f32x4>(lbc, (16 * k + 8 * uh) * 4);
+                if constexpr (NQ > 0) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int uh = 0; uh < 2; ++uh) q4[q][uh] = lds_frag<f32x4>(lbq, (q * H1 + 16 * k + 8 * uh) * 4);
+                }
+            };
+            // build units of the e1 fragment of k-step k = (q, s): 8 element units + 4 pairs x 2 halves = 16
+            auto buildA = [&](auto kc, auto uc) {
+                MPG_CI(k, kc); MPG_CI(u, uc);
+                constexpr int q = k >> 1, s2 = k & 1;
+                if constexpr (u < 8) {
+                    constexpr int uh = u >> 2, t = u & 3;  // element 4 uh + t  <->  feature 32q + 16s + 8uh + 4h + t
+                    float cc = c4[uh][t] + a4[uh][t];
+                    if constexpr (NQ > 0) {
+#pragma unroll
+                        for (int qq = 0; qq < NQ; ++qq) cc = fmaf(esv[qq], q4[qq][uh][t], cc);
+                    }
+                    const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, q, 4 * s2 + 2 * uh + h, h);
+                    v1[u] = drop_apply<DROP>(lrelu(cc, p.alpha), wd, 16 * s2 + 8 * uh + t, t, p.thr);
+                } else {
+                    constexpr int pr = (u - 8) >> 1;
+                    if constexpr (((u - 8) & 1) == 0) ps1[pr].first(v1[2 * pr], v1[2 * pr + 1]);
+                    else ps1[pr].second(v1[2 * pr + 1], eh[k & 1], el[k & 1], 2 * pr);
+                }
+            };
+            using K0 = std::integral_constant<int, 0>;
+            static_for<0, T2>([&](auto mc) { load_w(K0{}, mc); });
+            load_a(K0{});
+            static_for<0, 16>([&](auto uc) { buildA(K0{}, uc); });
+#pragma unroll
+            for (int m = 0; m < T2; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b4 = lds_frag<f32x4>(lbb, (32 * m + 8 * g) * 4);
+                    acc[m][4 * g + 0] = b4[0]; acc[m][4 * g + 1] = b4[1]; acc[m][4 * g + 2] = b4[2]; acc[m][4 * g + 3] = b4[3];
+                }
+            static_for<0, KS>([&](auto kc) {
+                MPG_CI(k, kc);
+                if constexpr (k + 1 < KS) load_a(std::integral_constant<int, k + 1>{});
+                const V bh0 = eh[k & 1], bl0 = el[k & 1];
+                static_for<0, T2>([&](auto mc) {
+                    MPG_CI(m, mc);
+                    auto slot = [&](auto slc) {
+                        MPG_CI(SL, slc);
+                        if constexpr (k + 1 < KS) f2_slot<16, 13, SL - 2>([&](auto uc) { buildA(std::integral_constant<int, k + 1>{}, uc); });
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    const V a_h = wh[m], a_l = wl[m];
+                    acc[m] = f2_mma(a_l, bh0, acc[m]); slot(std::integral_constant<int, 3 * m + 0>{});
+                    acc[m] = f2_mma(a_h, bl0, acc[m]); slot(std::integral_constant<int, 3 * m + 1>{});
+                    acc[m] = f2_mma(a_h, bh0, acc[m]);
+                    if constexpr (k + 1 < KS) load_w(std::integral_constant<int, k + 1>{}, mc);
+                    slot(std::integral_constant<int, 3 * m + 2>{});
+                });
+            });
+        }
+
+        F1_STAMP(1)
+        // ---- E2 = drop(lrelu(Z2)) as B fragments (hi, lo): tile mm, k-step half s -> fragment 2 mm + s
+        f2_u32x4 e2h[T2 * 2], e2l[T2 * 2];
+        const int sts = ((b * RB + rb) * p.N + jj) * (NFR2 * 1024);
+        static_for<0, T2>([&](auto mc) {
+            MPG_CI(mm, mc);
+            uint32_t wd2 = 0u;
+            if constexpr (DROP == 2) wd2 = drop_tile_word<2>(seed_lo, seed_hi, p.tag_base + TAG_E1, erow, mm, 0, h);
+            float x2[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int g = u >> 2, t = u & 3;
+                uint32_t wd = wd2;
+                if constexpr (DROP == 1) wd = drop_tile_word<1>(seed_lo, seed_hi, p.tag_base + TAG_E1, erow, mm, 2 * g + h, h);
+                x2[u] = drop_apply<DROP>(lrelu(acc[mm][u], p.alpha), wd, 8 * g + t, t, p.thr);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                V hi, lo;
+                split8(x2 + 8 * s2, hi, lo);
+                e2h[2 * mm + s2] = __builtin_bit_cast(f2_u32x4, hi);
+                e2l[2 * mm + s2] = __builtin_bit_cast(f2_u32x4, lo);
+                if constexpr (SIGN) __builtin_amdgcn_raw_buffer_store_b128(e2h[2 * mm + s2], rsE, lane16, sts + (2 * mm + s2) * 1024, 0);
+            }
+        });
+
+        F1_STAMP(2)
+        // ---- layer 3: Z3 = W3' E2 + b3 tile by tile; the epilogue of tile m - 1 (sign bit, LeakyReLU, dropout, m_j-weighted sum
+        //      into agg) rides in the MFMA slots of tile m
+        {
+            constexpr int KS = T2 * 2;
+            f32x16 a3[2];   // [tile parity]
+            uint32_t sgn[T3 / 2] = {0u, 0u, 0u};
+            auto bias_init = [&](auto mc) {
+                MPG_CI(m, mc);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b4 = lds_frag<f32x4>(lbb, (H2 + 32 * m + 8 * g) * 4);
+                    a3[m & 1][4 * g + 0] = b4[0]; a3[m & 1][4 * g + 1] = b4[1]; a3[m & 1][4 * g + 2] = b4[2]; a3[m & 1][4 * g + 3] = b4[3];
+                }
+            };
+            auto epi3 = [&](auto mc, auto uc) {
+                MPG_CI(mm, mc); MPG_CI(e, uc);
+                constexpr int g = e >> 2, t = e & 3;
+                const uint32_t wd = drop_tile_word<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, mm, 2 * g + h, h);
+                const float z = a3[mm & 1][e];
+                if constexpr (SIGN) sgn[mm >> 1] = __builtin_amdgcn_alignbit(sgn[mm >> 1], __builtin_bit_cast(uint32_t, z), 31);
+                const float x = drop_apply<DROP>(lrelu(z, p.alpha), wd, 8 * g + t, t, p.thr);
+                agg[mm][e] += mjs * x;
+            };
+            bias_init(std::integral_constant<int, 0>{});
+            static_for<0, T3>([&](auto mc) {
+                MPG_CI(m, mc);
+                V ah[2], al[2];
+                ah[0] = lds_frag<V>(lb3hi, (m * KS) * 1024);
+                al[0] = lds_frag<V>(lb3lo, (m * KS) * 1024);
+                static_for<0, KS>([&](auto kc) {
+                    MPG_CI(k, kc);
+                    if constexpr (k + 1 < KS) {
+                        ah[(k + 1) & 1] = lds_frag<V>(lb3hi, (m * KS + k + 1) * 1024);
+                        al[(k + 1) & 1] = lds_frag<V>(lb3lo, (m * KS + k + 1) * 1024);
+                    }
+                    const V bh0 = __builtin_bit_cast(V, e2h[k]), bl0 = __builtin_bit_cast(V, e2l[k]);
+                    auto slot = [&](auto slc) {
+                        MPG_CI(SL, slc);   // 3 KS - 3 slots: the last k-step's are left to the next tile's bias load
+                        if constexpr (m > 0) f2_slot<16, 3 * KS - 3, SL>([&](auto uc) { epi3(std::integral_constant<int, m - 1>{}, uc); });
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    const V a_h = ah[k & 1], a_l = al[k & 1];
+                    a3[m & 1] = f2_mma(a_l, bh0, a3[m & 1]); slot(std::integral_constant<int, 3 * k + 0>{});
+                    a3[m & 1] = f2_mma(a_h, bl0, a3[m & 1]); slot(std::integral_constant<int, 3 * k + 1>{});
+                    a3[m & 1] = f2_mma(a_h, bh0, a3[m & 1]); slot(std::integral_constant<int, 3 * k + 2>{});
+                    if constexpr (k == KS - 1 && m + 1 < T3) {
+                        bias_init(std::integral_constant<int, m + 1>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+            });
+            static_for<0, 16>([&](auto uc) { epi3(std::integral_constant<int, T3 - 1>{}, uc); });
+            if constexpr (SIGN) {
+                const int soff = ((b * RB + rb) * p.N + jj) * (T3 * 32 * 4);
+#pragma unroll
+                for (int q = 0; q < T3 / 2; ++q) __builtin_amdgcn_raw_buffer_store_b32(sgn[q], rsS, lane * 4, soff + q * 256, 0);
+            }
+        }
+        F1_STAMP(3)
+    }
+
+#ifdef MPG_F1_STAMP
+    if (lane == 0) {
+        unsigned long long* o = f1_stamps + ((size_t)blockIdx.x * 8 + w) * 8;
+        for (int q = 0; q < 5; ++q) o[q] = f1_acc[q];
+        o[5] = (nvalid - w + F1_NW - 1) / F1_NW; o[6] = f1_t0; o[7] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+    // ---- reduce the eight waves' partial sums through LDS (the weight area holds four waves' worth: waves 4..7 hand theirs to
+    //      waves 0..3 first) and write agg[b, i, :]
+    __syncthreads();  // everyone is done with the weight copy
+    float* red = reinterpret_cast<float*>(smem);
+    if (w >= 4) {
+#pragma unroll
+        for (int m = 0; m < T3; ++m)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) red[(((w - 4) * T3 + m) * 16 + k) * 64 + lane] = agg[m][k];
+    }
+    __syncthreads();
+    if (w < 4) {
+#pragma unroll
+        for (int m = 0; m < T3; ++m)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) agg[m][k] += red[((w * T3 + m) * 16 + k) * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < T3; ++m)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) red[((w * T3 + m) * 16 + k) * 64 + lane] = agg[m][k];
+    }
+    __syncthreads();
+    if constexpr (FN == 0) {
+        // (16 bytes per lane: registers 4g .. 4g+3 of a tile are four consecutive features of the lane's receiver -- element by
+        // element every lane of a store instruction wrote 4 bytes into a 128-byte line of its own, 6,144 line requests per
+        // workgroup; the LDS reads stay lane-consecutive)
+        float* out = p.agg + ((size_t)sc * p.B + b) * p.N * H3;
+        for (int u = tid; u < T3 * 4 * 64; u += 512) {
+            const int ln = u & 63, mg = u >> 6, m = mg >> 2, g = mg & 3;
+            float4 v;
+            float* vp = reinterpret_cast<float*>(&v);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int e = (m * 16 + 4 * g + t) * 64 + ln;
+                vp[t] = (red[e] + red[e + T3 * 1024] + red[e + 2 * T3 * 1024] + red[e + 3 * T3 * 1024]) * p.agg_scale;
+            }
+            const int ii = rb * 32 + (ln & 31);
+            if (ii < p.N) *reinterpret_cast<float4*>(out + (size_t)ii * H3 + 32 * m + 8 * g + 4 * (ln >> 5)) = v;
+        }
+    } else {
+        // ---- the node network on these 32 receivers (edge_fwd2_impl.h: registers 8s .. 8s+7 of accumulator tile m ARE the B
+        //      fragment of k-step 2m + s of fn's first layer).  Eight waves: wave w sums k-steps w and w + 8 (< 12) of the four
+        //      slabs -- in the plain path's order, times agg_scale: the values that path writes -- and lays them down as hi/lo
+        //      fragments beside the slabs; waves 4, 5 also stage the x columns (k-steps 12, 13).
+        static_assert(F2_FN_BIAS + C2_BIAS * 4 <= F2_LDS_BYTES, "fn's buffers must fit the edge kernel's LDS");
+        const MpgChain& c = *cp;
+        const int m0 = b * p.N + rb * 32, nrows = min(32, p.N - rb * 32);
+        using I0 = std::integral_constant<int, 0>;
+        auto stage = [&](auto&& first_tile, auto&& bias_request, auto&& bias_store, const uint32_t, const uint32_t, const float ascale) {
+            first_tile(I0{});   // (every register of the sender loop is free: the wave's weight tile is on its way during the staging)
+            bias_request();
+            V* fb = reinterpret_cast<V*>(smem + F2_FN_FB0);
+            const __amdgpu_buffer_rsrc_t ragg = __builtin_amdgcn_make_buffer_rsrc(p.agg, 0, p.agg != nullptr ? p.B * p.N * (H3 * 4) : 0, 0x00020000);
+            const int rowoff = vi ? (b * p.N + i) * (H3 * 4) : -1;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ks = w + 8 * q, mm = ks >> 1, s2 = ks & 1;
+                if (ks < 2 * T3) {
+                    float av8[8], v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int e = (mm * 16 + 8 * s2 + j) * 64 + lane;
+                        const float sum = red[e] + red[e + T3 * 1024] + red[e + 2 * T3 * 1024] + red[e + 3 * T3 * 1024];
+                        av8[j] = sum * p.agg_scale;
+                        v[j] = av8[j] * ascale;
+                    }
+#pragma unroll
+                    for (int half = 0; half < 2; ++half)
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            f2_u32x4{__builtin_bit_cast(uint32_t, av8[4 * half]), __builtin_bit_cast(uint32_t, av8[4 * half + 1]),
+                                     __builtin_bit_cast(uint32_t, av8[4 * half + 2]), __builtin_bit_cast(uint32_t, av8[4 * half + 3])},
+                            ragg, vi ? rowoff + (32 * mm + 16 * s2 + 8 * half + 4 * h) * 4 : -1, 0, 0);
+                    V hi, lo;
+                    split8(v, hi, lo);
+                    fb[(ks * 2 + 0) * 64 + lane] = hi;
+                    fb[(ks * 2 + 1) * 64 + lane] = lo;
+                }
+            }
+            if (w == 4 || w == 5) {   // the x columns [192, K) of cat((agg, x)): k-steps 12 and 13
+                const int ks = 8 + w, KX = c.L[0].K - H3;
+                const float* xr = c.A2 + (size_t)(m0 + r) * c.lda2;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int f = 16 * (w - 4) + 8 * (j >> 2) + 4 * h + (j & 3);
+                    v[j] = (vi && f < KX) ? xr[f] * ascale : 0.f;
+                }
+                V hi, lo;
+                split8(v, hi, lo);
+                fb[(ks * 2 + 0) * 64 + lane] = hi;
+                fb[(ks * 2 + 1) * 64 + lane] = lo;
+            }
+            bias_store();
+        };
+        c2_body<true, 14, 16, 16, DROP, 0, 0, FN == 2, F1_NW>(c, m0, nrows, smem + F2_FN_FB0, smem, reinterpret_cast<float*>(smem + F2_FN_BIAS), stage);
+        if (cp2->nlayers > 0) {
+            // the next layer's a | c on the rows just written (this workgroup's own stores: ordered within the workgroup)
+            const MpgChain& c2 = *cp2;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            auto stage2 = [&](auto&& first_tile, auto&& bias_request, auto&& bias_store, const uint32_t s_lo, const uint32_t s_hi, const float ascale) {
+                c2_stage_rows<true, 2, 0, F1_NW>(c2, m0, nrows, smem, first_tile, bias_request, bias_store, s_lo, s_hi, ascale);
+            };
+            c2_body<true, 2, 0, 0, 0, 0, 0, false, F1_NW>(c2, m0, nrows, smem, smem + C2_FB, reinterpret_cast<float*>(smem + 2 * C2_FB), stage2);
+        }
+    }
+#ifdef MPG_F1_STAMP
+    if (lane == 0) {   // whole-kernel figures in the slots the per-section sums do not use: prologue, kernel length, 100 MHz ticks
+        unsigned long long* o = f1_stamps + ((size_t)blockIdx.x * 8 + w) * 8;
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        o[4] = o[6] - f1_k0;                                    // prologue: kernel start -> loop start  (loop top sum dropped)
+        o[6] = t1 - o[7];                                       // epilogue: loop end -> kernel end
+        o[7] = ((t1 - f1_k0) << 20) | (__builtin_amdgcn_s_memrealtime() - f1_r0);   // kernel clk | realtime ticks
+    }
+#endif
+}
+
+template <int DROP, bool SIGN, int NQ>
+__global__ __launch_bounds__(512) void edge_fwd1_kernel(const MpgEdgeFwd p) { edge_fwd1_body<DROP, SIGN, NQ, 0>(p); }
+
+template <int DROP, bool SIGN, bool SL>
+__global__ __launch_bounds__(512) void edge_fwd1_fn_kernel(const MpgEdgeFwd p, const MpgChain c, const MpgChain c2) {
+    edge_fwd1_body<DROP, SIGN, 0, SL ? 2 : 1>(p, &c, &c2);
+}
+
+template <int D, int NQ = 0>
+int f1_launch(const MpgEdgeFwd* p, hipStream_t st) {
+    const int RB = (p->N + 31) / 32;
+    dim3 grid(p->B * RB * p->SC), block(512);
+    if (p->sign3 != nullptr) {
+        MPG_ENSURE_LDS((edge_fwd1_kernel<D, true, NQ>), F2_LDS_BYTES);
+        hipLaunchKernelGGL((edge_fwd1_kernel<D, true, NQ>), grid, block, F2_LDS_BYTES, st, *p);
+    } else {
+        MPG_ENSURE_LDS((edge_fwd1_kernel<D, false, NQ>), F2_LDS_BYTES);
+        hipLaunchKernelGGL((edge_fwd1_kernel<D, false, NQ>), grid, block, F2_LDS_BYTES, st, *p);
+    }
+    return (int)hipGetLastError();
+}
+
+// Which form the plain forward takes (the FN form is four-wave only: c2_body's eight-wave form spills): mpg_edge_waves() when
+// it has been called with a non-zero value, else MPG_FWD_WAVES (4: the four-wave kernels of edge_fwd2_impl.h), else eight
+extern "C" int mpg_edge_waves_get(int which);   // edge.hip
+inline bool fwd_eight_waves() {
+    const int o = mpg_edge_waves_get(0);
+    if (o) return o != 4;
+    static const bool v = [] { const char* e = getenv("MPG_FWD_WAVES"); return e == nullptr || atoi(e) != 4; }();
+    return v;
+}
+
+// the fused forward + node network of one dropout mode / SIGN (edge_fwd_fn_*.hip: one translation unit each)
+template <int D, bool SIGN>
+int f1_launch_fn(const MpgEdgeFwd* p, const MpgChain* c, const MpgChain* c2, bool sl, hipStream_t st) {
+    const int RB = (p->N + 31) / 32;
+    dim3 grid(p->B * RB), block(512);
+    MpgChain none = {};   // nlayers = 0: no second chain
+    if (c2 == nullptr) c2 = &none;
+    if (sl) {
+        MPG_ENSURE_LDS((edge_fwd1_fn_kernel<D, SIGN, true>), F2_LDS_BYTES);
+        hipLaunchKernelGGL((edge_fwd1_fn_kernel<D, SIGN, true>), grid, block, F2_LDS_BYTES, st, *p, *c, *c2);
+    } else {
+        MPG_ENSURE_LDS((edge_fwd1_fn_kernel<D, SIGN, false>), F2_LDS_BYTES);
+        hipLaunchKernelGGL((edge_fwd1_fn_kernel<D, SIGN, false>), grid, block, F2_LDS_BYTES, st, *p, *c, *c2);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace

@@ -312,7 +312,7 @@ class MPLayer(nn.Module):
             W1, fe[0].bias, fe[1].weight, fe[1].bias, fe[2].weight, fe[2].bias,
             fn[0].weight, fn[0].bias, fn[1].weight, fn[1].bias, fn[2].weight, fn[2].bias,
             self.sum, self.fe.leaky_relu_alpha, self.fe.dropout_p, self.training, packed, nbr, self.num_knn,
-            es, self.n_es, xfn, handoff)
+            es, self.n_es, xfn, handoff, not torch.is_grad_enabled())
         if handoff is not None and handoff.ac_out is not None:
             y._mpg_ac = handoff.ac_out
         return y

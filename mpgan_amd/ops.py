@@ -75,6 +75,7 @@ class DeviceState:
         self.tags = itertools.count(1)
         self.last_tag = 0
         self.tag_log = None
+        self.sign_tap = None   # tests: a list that collects, per fused MPLayer call with a backward, the tensors its kink decisions can be read from
         self.grad_into_param = False
         self.deferred_wgrad = None
         self.wgrad_stream = None
@@ -210,6 +211,15 @@ def drop_params(p: float):
     if thr >= 256:
         raise ValueError("dropout p too close to 1")
     return thr, 256.0 / (256.0 - thr)
+
+
+def edge_waves(fwd: int = 0, bwd: int = 0):
+    """Launch form of the plain fused edge kernels from now on (``mpg_edge_waves``): 8 = eight waves per workgroup, 4 = four,
+    0 = the environment's choice (MPG_FWD_WAVES / MPG_BWD_WAVES, default 8).  Returns the previous (fwd, bwd) pair."""
+    L = _lib.lib()
+    prev = (L.mpg_edge_waves_get(0), L.mpg_edge_waves_get(1))
+    check(L.mpg_edge_waves(int(fwd), int(bwd)), "mpg_edge_waves")
+    return prev
 
 
 def _stream():
@@ -621,7 +631,7 @@ class FusedMPLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mask, W1, b1, W2, b2, W3, b3, V1, c1, V2, c2, V3, c3, sum_agg, alpha, p_drop, training,
-                packed=None, nbr=None, num_knn=0, es=None, nq=0, xfn=None, handoff=None):
+                packed=None, nbr=None, num_knn=0, es=None, nq=0, xfn=None, handoff=None, no_grad=False):
         """``nbr`` (from ``knn_sets``) restricts receiver i's senders to its ``num_knn`` nearest neighbours
         (``fully_connected=False``, mpgan/model.py:319-381); the mean then divides by ``num_knn`` (:267).
 
@@ -689,7 +699,10 @@ class FusedMPLayerFn(torch.autograd.Function):
         if m1 is not None and OPTIONS["lpt_order"] and B * RB * SC > NUM_CUS and B + N + 2 + (B + 63) // 64 * (N + 1) <= 16384:
             order = jet_order(m1.view(B, N))
             e.order = C.c_void_p(order.data_ptr())
-        need_grad = any(ctx.needs_input_grad)
+        # ``no_grad``: the caller's torch.is_grad_enabled() was off (train_D's generator call): inside forward() grad mode is
+        # always off and needs_input_grad still says what the PARAMETERS want, so without the flag such a call would write
+        # everything a backward reads -- sign words, 10 KB of parked fragments per block, agg, h1, h2 -- for nothing
+        need_grad = any(ctx.needs_input_grad) and not no_grad
         if need_grad and B * RB * N * PARK_BYTES_PER_BLOCK > 0x7fffffff:
             # (mpg_edge_fwd / mpg_edge_bwd return -7: the parked fragments are addressed with 32-bit offsets)
             raise RuntimeError(f"FusedMPLayerFn: {B} jets x {N} particles park {B * RB * N * PARK_BYTES_PER_BLOCK / 2**30:.1f} GiB of "
@@ -747,6 +760,8 @@ class FusedMPLayerFn(torch.autograd.Function):
         ctx.prev_node = handoff.prev_node if (handoff is not None and need_grad) else None
         ctx.pre = None   # filled by the backward of the layer ABOVE when it has run this layer's input-gradient chain already
 
+        if need_grad and dev_state(dev).sign_tap is not None:
+            dev_state(dev).sign_tap.append(dict(B=B, N=N, ac=ac, stE2=stE2, sign3=sign3, h1=h1, h2=h2))
         ctx.save_for_backward(x2, m1, ac, agg, h1, h2, W1, b2, b3, W2, W3, V1, V2, V3, sign3, nbr, stE2, es, wq, xf2, order)
         ctx.cfg = (B, N, F, agg_scale, alpha, thr, dscale, tag, SC, f16, nq)
         return y.reshape(B, N, V3.shape[0])
@@ -919,7 +934,7 @@ class FusedMPLayerFn(torch.autograd.Function):
             # tail of dh0; the x columns of xfn are the same nodes as x, whose node-path gradient is already in dx above
             dxfn = torch.cat((torch.zeros((V, F), device=dev, dtype=torch.float32), dh0[:, H3 + F:]), dim=1).reshape(B, N, -1)
         return (dx, None, dW1, db1, dW2, db2, dW3, db3, dV1, dc1, dV2, dc2, dV3, dc3,
-                None, None, None, None, None, None, None, des, None, dxfn, None)[:len(ctx.needs_input_grad)]
+                None, None, None, None, None, None, None, des, None, dxfn, None, None)[:len(ctx.needs_input_grad)]
 
 
 def _grad_target(t):

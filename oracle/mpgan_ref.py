@@ -40,8 +40,13 @@ MPGAN_DEFAULTS = dict(
 )
 
 
-def leaky(t: Tensor, alpha: float) -> Tensor:
+def leaky(t: Tensor, alpha: float, neg: Optional[Tensor] = None) -> Tensor:
     # phi(t) = max(t,0) + alpha*min(t,0); F.leaky_relu semantics (mpgan/model.py:80)
+    # ``neg`` (tests only): the branch of every element decided by the caller instead of by the sign of t -- the
+    # "sign-conditioned" evaluation: gradients of the function the device kernels computed, whose kink decisions within
+    # rounding of zero may differ from fp64's (the decisions themselves are counted against fp32's by the tests)
+    if neg is not None:
+        return torch.where(neg, t * alpha, t)
     return torch.where(t > 0, t, t * alpha)
 
 
@@ -105,6 +110,7 @@ def mplayer_forward(
     exact_concat: bool = False,
     probe: Optional[list] = None,
     knn: Optional[tuple] = None,
+    signs: Optional[Dict[str, Tensor]] = None,
 ) -> Tensor:
     """One message-passing layer, fully connected or (``knn`` = (num_knn, self_loops)) over each node's nearest
     neighbours as ``MPLayer._getA_knn`` picks them (mpgan/model.py:319-381): distances || s_j x_j - x_i + 1e-12 || with
@@ -115,9 +121,12 @@ def mplayer_forward(
            'n0','n1','n2' with shape [B,N,out_l].
     Edge row (b, i, j) = [x_i ; x_j] (receiver first) -- mpgan/model.py:294-295,315.
     Mask multiplies the SENDER axis j only (:262); mean divides by N (:267).
+    signs: optional dict 'fe1','fe2','fe3' [B,N,N,H_l] / 'fn1','fn2' [B,N,*] of bool "took the negative branch" (see ``leaky``;
+           fully connected form only).
     """
     B, N, F = x.shape
     k = keeps or {}
+    sg = signs or {}
     w1 = sd[f"{prefix}.fe.net.0.weight"]
     b1 = sd[f"{prefix}.fe.net.0.bias"]
     if knn is not None:
@@ -153,20 +162,20 @@ def mplayer_forward(
         e = a.unsqueeze(2) + c.unsqueeze(1)  # [B,N(i),N(j),H1]
     if probe is not None:  # pre-activations, for the tests' distance-from-the-kink check
         probe.append(e.detach())
-    e = _drop(leaky(e, alpha), k.get("e0"), p)
+    e = _drop(leaky(e, alpha, sg.get("fe1")), k.get("e0"), p)
     for l in range(1, n_fe):
         w = sd[f"{prefix}.fe.net.{l}.weight"]
         b = sd[f"{prefix}.fe.net.{l}.bias"]
         e = e @ w.t() + b
         if probe is not None:
             probe.append(e.detach())
-        e = _drop(leaky(e, alpha), k.get(f"e{l}"), p)
+        e = _drop(leaky(e, alpha, sg.get(f"fe{l + 1}")), k.get(f"e{l}"), p)
     if mask is not None:
         e = e * mask.reshape(B, 1, N, 1)
     agg = e.sum(dim=2)
     if not sum_agg:
         agg = agg / N
-    return _node_net(sd, prefix, agg, x, n_fn, alpha, p, k, probe)
+    return _node_net(sd, prefix, agg, x, n_fn, alpha, p, k, probe, sg)
 
 
 def mplayer_forward_general(
@@ -256,8 +265,9 @@ def mplayer_forward_general(
     return h.reshape(B, N, -1)
 
 
-def _node_net(sd, prefix, agg, x, n_fn, alpha, p, k, probe):
+def _node_net(sd, prefix, agg, x, n_fn, alpha, p, k, probe, sg=None):
     """fn on [agg ; x] (mpgan/model.py:268-279)."""
+    sg = sg or {}
     h = torch.cat((agg, x), dim=2)
     for l in range(n_fn):
         w = sd[f"{prefix}.fn.net.{l}.weight"]
@@ -266,7 +276,7 @@ def _node_net(sd, prefix, agg, x, n_fn, alpha, p, k, probe):
         if l != n_fn - 1:
             if probe is not None:
                 probe.append(h.detach())
-            h = leaky(h, alpha)
+            h = leaky(h, alpha, sg.get(f"fn{l + 1}"))
         h = _drop(h, k.get(f"n{l}"), p)
     return h
 
@@ -289,13 +299,15 @@ def mpgen_forward(
     p: float = 0.0,
     keeps: Optional[Sequence[Optional[Dict[str, Tensor]]]] = None,
     tanh: bool = True,
+    signs: Optional[Sequence[Optional[Dict[str, Tensor]]]] = None,
 ) -> Tensor:
     """MPGenerator.forward, default config (mask_c, no lfc): mpgan/model.py:498-523,:689-704,:752."""
     mask = gen_mask_from_labels(noise[:, :, 0], labels, num_particles)
     x = noise
     for l in range(mp_iters):
         x = mplayer_forward(
-            sd, f"mp_layers.{l}", x, mask, sum_agg, alpha, p, None if keeps is None else keeps[l]
+            sd, f"mp_layers.{l}", x, mask, sum_agg, alpha, p, None if keeps is None else keeps[l],
+            signs=None if signs is None else signs[l]
         )
     if tanh:
         x = torch.tanh(x)
@@ -313,6 +325,7 @@ def mpdisc_forward(
     keeps: Optional[Sequence[Optional[Dict[str, Tensor]]]] = None,
     keep_fnd: Optional[Tensor] = None,
     sigmoid: bool = True,
+    signs: Optional[Sequence[Optional[Dict[str, Tensor]]]] = None,
 ) -> Tensor:
     """MPDiscriminator.forward, default config (mask_c, dea, dea_sum, fnd=[]):
     mask = x[...,-1:]+0.5 (:881); features = x[...,:-1] (:884); pooled = sum_i x_i*mask_i
@@ -321,7 +334,8 @@ def mpdisc_forward(
     x = data[:, :, :-1]
     for l in range(mp_iters):
         x = mplayer_forward(
-            sd, f"mp_layers.{l}", x, mask, sum_agg, alpha, p, None if keeps is None else keeps[l]
+            sd, f"mp_layers.{l}", x, mask, sum_agg, alpha, p, None if keeps is None else keeps[l],
+            signs=None if signs is None else signs[l]
         )
     pooled = (x * mask).sum(dim=1)
     if not sum_agg:

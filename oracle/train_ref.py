@@ -136,16 +136,16 @@ def rmsprop_step(params: Dict[str, Tensor], grads: Dict[str, Tensor], state: Dic
 
 
 # ----------------------------------------------------------------------------- one iteration
-def _fwd_G(model, sdG, noise, labels, N, cfg):
+def _fwd_G(model, sdG, noise, labels, N, cfg, signs=None):
     if model == "mpgan":
-        return M.mpgen_forward(sdG, noise, labels, num_particles=N, **cfg.get("G", {}))
+        return M.mpgen_forward(sdG, noise, labels, num_particles=N, signs=signs, **cfg.get("G", {}))
     return A.gapt_g_forward(sdG, noise, labels, num_particles=N, **cfg.get("G", {}))
 
 
-def _fwd_D(model, sdD, x, labels, p, keeps, cfg):
+def _fwd_D(model, sdD, x, labels, p, keeps, cfg, signs=None):
     if model == "mpgan":
         return M.mpdisc_forward(sdD, x, labels, p=p, keeps=keeps,
-                                keep_fnd=None if keeps is None else keeps.get("fnd"),
+                                keep_fnd=None if keeps is None else keeps.get("fnd"), signs=signs,
                                 **cfg.get("D", {}))
     return A.gapt_d_forward(sdD, x, labels, p=p, keeps=keeps, **cfg.get("D", {}))
 
@@ -207,31 +207,35 @@ def train_iteration(
     cfg: Optional[dict] = None,
     return_grads: bool = False,
     loss: str = "ls",
+    signs: Optional[Tuple] = None,
 ):
     """One train_D + train_G (num_critic = num_gen = 1), RMSprop; ``loss`` = ls (default) / og / w / hinge as
     ``calc_D_loss`` (train.py:331-395) and ``calc_G_loss`` (:465-476) define them (for w / hinge the caller passes
     ``cfg={"D": {"sigmoid": False}}``, setup_training.py:1250).  Parameters in
     ``sdD``/``sdG`` are updated in place.  ``keeps`` = (keeps for D(real), D(fake) in the
     D step, D(fake) in the G step) or None; each is a dict as taken by the D forward, or a
-    ``RandKeeps()`` to draw Bernoulli masks.  Returns (D_loss, G_loss[, gradsD, gradsG])."""
+    ``RandKeeps()`` to draw Bernoulli masks.  ``signs`` (MPGAN, tests): the sign-conditioned evaluation
+    (``mpgan_ref.leaky``) -- per-layer sign dicts for (D(real), D(fake) in the D step, G and D(fake) in the G step).
+    Returns (D_loss, G_loss[, gradsD, gradsG])."""
     cfg = cfg or {}
     N = data.shape[1]
     kr, kf, kg = keeps if keeps is not None else (None, None, None)
+    sr, sf, sgg, sgd = signs if signs is not None else (None, None, None, None)
 
     # ---- train_D (train.py:398-462)
     pD = {k: v.detach().requires_grad_(True) for k, v in sdD.items()}
     with torch.no_grad():
         fake = _fwd_G(model, sdG, noise_D, labels, N, cfg)
-    out_r = _fwd_D(model, pD, data, labels, p_disc, kr, cfg)
-    out_f = _fwd_D(model, pD, fake, labels, p_disc, kf, cfg)
+    out_r = _fwd_D(model, pD, data, labels, p_disc, kr, cfg, sr)
+    out_f = _fwd_D(model, pD, fake, labels, p_disc, kf, cfg, sf)
     D_loss = d_loss_ref(loss, out_r, out_f)
     gD = dict(zip(pD.keys(), torch.autograd.grad(D_loss, list(pD.values()))))
     rmsprop_step(sdD, gD, stD, lr_disc)
 
     # ---- train_G (train.py:479-523)
     pG = {k: v.detach().requires_grad_(True) for k, v in sdG.items()}
-    fake = _fwd_G(model, pG, noise_G, labels, N, cfg)
-    out = _fwd_D(model, sdD, fake, labels, p_disc, kg, cfg)
+    fake = _fwd_G(model, pG, noise_G, labels, N, cfg, sgg)
+    out = _fwd_D(model, sdD, fake, labels, p_disc, kg, cfg, sgd)
     G_loss = g_loss_ref(loss, out)
     gG = dict(zip(pG.keys(), torch.autograd.grad(G_loss, list(pG.values()))))
     rmsprop_step(sdG, gG, stG, lr_gen)

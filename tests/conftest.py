@@ -115,3 +115,33 @@ def option_case_oracle_kwargs(kw):
         o["knn"] = (kw["num_knn"], kw.get("self_loops", True))
     o["sum_agg"] = kw.get("sum", True)
     return o
+
+
+def hip_signs_from(ac, stE2, sign3, h1, h2, B, N):
+    """Signs (True = negative) of the pre-activations a fused MPLayer forward saw, where it keeps them: fe layer 1 from the
+    saved a|c terms (z1 = a_i + c_j in fp32, as the kernel adds them), fe layer 2 from the sign bits of the parked E2
+    fragments (edge_fwd2_impl.h: block (b, rb, j) = 10 fragments x 64 lanes x 8 halves; fragment 2 mm + s, lane (r, h),
+    element jj <-> feature 32 mm + 16 s + 8 (jj >> 2) + 4 h + (jj & 3) of receiver 32 rb + r; LeakyReLU keeps the sign, -0.0
+    for plain ReLU), fe layer 3 from the packed sign words (word q of lane (r, h), bit 31 - (16 (tile & 1) + reg) for
+    tile >> 1 == q; reg 4g+t <-> feature 32 tile + 8g + 4h + t), the node network from the sign bits of its saved outputs.
+    [B,N,N,*] / [B,N,*] like the oracle's probes; the fe layers are only defined for unmasked senders (skipped blocks are
+    never written) and, under dropout, for kept elements (a dropped one is +0: its branch multiplies a zero)."""
+    import torch
+    a, c = ac[:, :96].reshape(B, N, 96), ac[:, 96:].reshape(B, N, 96)
+    z1neg = ((a.unsqueeze(2) + c.unsqueeze(1)) < 0).cpu()
+    RB = (N + 31) // 32
+    e2 = torch.signbit(stE2.reshape(B, RB, N, 5, 2, 2, 32, 2, 4)).cpu()          # [b, rb, j, mm, s, h, r, u, t]
+    z2neg = e2.permute(0, 1, 6, 2, 3, 4, 7, 5, 8).reshape(B, RB * 32, N, 160)[:, :N].contiguous()   # [b, i, j, 32mm+16s+8u+4h+t]
+    w = sign3.reshape(B, RB, N, 3, 64).cpu().numpy().astype(np.uint32)           # [b, rb, j, q, lane]
+    z3neg = np.zeros((B, N, N, 192), dtype=bool)
+    for tile in range(6):
+        for reg in range(16):
+            bit = (w[:, :, :, tile >> 1, :] >> np.uint32(31 - (16 * (tile & 1) + reg))) & 1   # [b, rb, j, lane]
+            g, t = reg >> 2, reg & 3
+            for hh in range(2):
+                f = 32 * tile + 8 * g + 4 * hh + t
+                for rb in range(RB):
+                    n_i = min(32, N - 32 * rb)
+                    z3neg[:, 32 * rb:32 * rb + n_i, :, f] = bit[:, rb, :, 32 * hh:32 * hh + n_i].transpose(0, 2, 1) != 0
+    return {"fe1": z1neg, "fe2": z2neg, "fe3": torch.from_numpy(z3neg), "fn1": torch.signbit(h1.reshape(B, N, -1)).cpu(),
+            "fn2": torch.signbit(h2.reshape(B, N, -1)).cpu()}

@@ -86,6 +86,33 @@ int main(int argc, char** argv) {
 #endif
     printf("  inputs: a %016llx c %016llx dagg %016llx mask %016llx sign %016llx W3T %016llx W2T %016llx\n", checksum(a, ha.size() * 4), checksum(c, hc.size() * 4),
            checksum(d, hd.size() * 4), checksum(m, hm.size() * 4), checksum(sg, (size_t)nblk * 192 * 4), checksum(i3t, 2 * 60 * 1024), checksum(i2t, 2 * 30 * 1024));
+#ifdef MPG_B1_STAMP
+    {
+        std::vector<unsigned long long> st((size_t)B * RB * SC * 8 * 10);
+        hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(b1_stamps), st.size() * 8);
+        double acc[5] = {}, pro = 0, epi = 0, kclk = 0, ticks = 0; long n = 0, nw = 0;
+        for (size_t wv = 0; wv < st.size() / 10; ++wv) {
+            const unsigned long long* o = &st[wv * 10];
+            if (o[5] < 3) continue;
+            for (int q = 0; q < 5; ++q) acc[q] += (double)o[q];
+            n += (long)o[5]; pro += (double)o[6]; epi += (double)o[7]; kclk += (double)o[8]; ticks += (double)o[9]; ++nw;
+        }
+        printf("  clk per sender (waves with >= 3 senders, %ld senders): setup %.0f  B %.0f  gate %.0f  C %.0f  dZ1 %.0f  = %.0f\n"
+               "  per wave: prologue %.0f  epilogue %.0f  kernel %.0f clk = %.1f us at %.0f MHz\n",
+               n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, (acc[0] + acc[1] + acc[2] + acc[3] + acc[4]) / n,
+               pro / nw, epi / nw, kclk / nw, ticks / nw / 100.0, kclk / ticks * 100.0);
+    }
+#endif
+    {   // da as numbers (its sum over senders is ordered differently by the four- and the eight-wave form: compare to ~1e-6)
+        std::vector<float> h(dab / 4); hipMemcpy(h.data(), da, dab, hipMemcpyDeviceToHost);
+        double s1 = 0, s2 = 0; for (float v : h) { s1 += v; s2 += fabs(v); }
+        printf("  da sum %.9g |sum| %.9g\n", s1, s2);
+    }
+#ifdef MPG_BWD1
+    printf("8 waves ");
+#else
+    printf("4 waves ");
+#endif
     printf("DROP=%d B=%d N=%d SC=%d %s ragged=%d: %.1f us   checksums da %016llx dc %016llx E2 %016llx dZ2 %016llx\n",
            MPG_SINGLE_VARIANT, B, N, SC, needw ? "dW" : "data", ragged, ms * 1e3f / R, checksum(da, dab), checksum(dc, dcb),
            checksum(sE, stb), needw ? checksum(sZ, stb) : 0ull);
