@@ -197,10 +197,12 @@ def main():
             sec = {"metric": o2["metric"], "value": o2["value"], "unit": o2["unit"], "ms_per_step": o2["ms_per_step"],
                    "steps": 100, "warmup": 20, "config": o2["config"], "losses": o2["losses"]}
             if not args.no_roofline:
-                sec["roofline"], sec["kernels"] = roofline(torch, ts2, model2, dev, measured_traffic=False)
+                sec["roofline"], sec["kernels"] = roofline(torch, ts2, model2, dev, measured_traffic=False, workload=key)
+            del ts2
+            if not args.no_cpu_baseline:   # the oracle's iteration of THIS workload on the host cores, a short bounded sample
+                sec["cpu_baseline"] = cpu_baseline(torch, model2, N2, B2, short=True)
             out["secondary"][key] = sec
             log("secondary", key, f"{o2['value']:.0f} jets/s")
-            del ts2
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -353,7 +355,7 @@ def _work(name, a):
     return 0, 0
 
 
-def roofline(torch, ts, model, dev, measured_traffic=True):
+def roofline(torch, ts, model, dev, measured_traffic=True, workload=None):
     """Time every launch of every C-ABI entry point with HIP events on the launch stream during a few eager
     (un-captured) iterations of the same step, and price the one that takes the most time."""
     from mpgan_amd import _lib
@@ -399,8 +401,13 @@ def roofline(torch, ts, model, dev, measured_traffic=True):
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     # PMC measurement of this kernel (tools/pmc.sh, FETCH_SIZE x2 + WRITE_SIZE), bytes per launch; it belongs to the
     # headline workload the counters were collected on and is left null for any other
-    if measured_traffic and os.path.isfile(tpath):
-        traffic = json.load(open(tpath)).get(kname, {}).get("bytes_per_launch")
+    # (``workload``: the secondary workloads' own entries, profiles/hbm_traffic.json: {"secondary": {workload: {kernel: ...}}})
+    if os.path.isfile(tpath):
+        tj = json.load(open(tpath))
+        if workload is not None:
+            traffic = tj.get("secondary", {}).get(workload, {}).get(kname, {}).get("bytes_per_launch")
+        elif measured_traffic:
+            traffic = tj.get(kname, {}).get("bytes_per_launch")
     # MPGAN's fused edge kernels are MFMA-bound by >100x; GAPT's launches are HBM / latency bound
     mfma = name.startswith("mpg_edge") or (flop_sum / max(byte_sum, 1) > PEAK_MFMA_16BIT / PEAK_HBM)
     if mfma:
@@ -426,7 +433,7 @@ def roofline(torch, ts, model, dev, measured_traffic=True):
 
 
 # --------------------------------------------------------------------------- CPU leg
-def cpu_baseline(torch, model, N, B_gpu):
+def cpu_baseline(torch, model, N, B_gpu, short=False):
     """The oracle's restatement of the same iteration on this box's host cores, bounded samples: BASELINE config 1
     (B = 32; >= 10 timed iterations after a warm-up) and the GPU leg's own batch size (as many as fit ~15 s), fp32,
     D dropout 0.5 (Bernoulli masks)."""
@@ -461,7 +468,11 @@ def cpu_baseline(torch, model, N, B_gpu):
 
     # BASELINE config 1's batch (32) where an iteration takes a fraction of a second (N = 30); at N = 150 one
     # iteration of 32 jets is ~20 s of CPU: the sample there is the GPU leg's own batch alone
-    small = sample(32, 10, 8.0) if N <= 40 else sample(B_gpu, 3, 15.0)
+    # (``short``: the secondary workloads' legs -- fewer iterations, so that the default run stays within a few minutes)
+    if short:
+        small = sample(32, 4, 4.0) if N <= 40 else sample(B_gpu, 2, 8.0)
+    else:
+        small = sample(32, 10, 8.0) if N <= 40 else sample(B_gpu, 3, 15.0)
     res = {"value": small["value"], "unit": "jets/s", "cores": torch.get_num_threads(), "kind": "port",
            "sample": f"{small['iterations']} timed G+D iterations (after 1 warm-up) at B={small['batch']}, N={N}"
                      f"{' (BASELINE config 1 batch)' if small['batch'] == 32 else ''}, {model}, fp32, torch {torch.__version__} "
@@ -469,7 +480,7 @@ def cpu_baseline(torch, model, N, B_gpu):
                      "train_D, D weight gradients in train_G)",
            "ms_per_step": small["ms_per_step"], "iterations": small["iterations"]}
     if B_gpu != small["batch"]:
-        big = sample(B_gpu, 3, 15.0)
+        big = sample(B_gpu, 2, 8.0) if short else sample(B_gpu, 3, 15.0)
         res["at_gpu_batch"] = {"value": big["value"], "unit": "jets/s", "batch": B_gpu, "ms_per_step": big["ms_per_step"],
                                "iterations": big["iterations"]}
     return res

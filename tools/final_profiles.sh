@@ -44,6 +44,20 @@ for c in SQ FETCH_SIZE WRITE_SIZE; do
   done
 done > $R/gpurun_out/final/pmc_gapt_summary.txt 2>&1
 echo "sq done"
+# HBM traffic of the SECONDARY workloads' kernels (bench.py's `secondary` rooflines): GAPT B = 512 comes from the passes above;
+# MPGAN N = 150, B = 16 (sender chunks: the plain eight-wave edge kernels) from a short bench run of its own
+for c in FETCH_SIZE WRITE_SIZE; do
+  o=$R/gpurun_out/final/pmc_n150_$c
+  rm -rf $o
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $o -o p -- python3 $R/bench.py --particles 150 --batch 16 --steps 3 --warmup 2 --no-graphs --no-roofline --no-cpu-baseline --no-secondary > $o.log 2>&1 || { tail -5 $o.log; exit 1; }
+  for k in edge_fwd edge_bwd edge_dw_kernel chain disc_head; do
+    echo "== mpgan_n150_b16 $c $k"; python3 $R/tools/pmc_summary.py $o "$k"
+  done
+  for k in mab_bwd mab_chain_fwd mab_fwd bridge; do
+    echo "== gapt_n30_b512 $c $k"; python3 $R/tools/pmc_summary.py $R/gpurun_out/final/pmc_gapt_$c "$k"
+  done
+done > $R/gpurun_out/final/pmc_secondary_summary.txt 2>&1
+echo "secondary pmc done"
 cd $R
 (timeout -k 10 120 tools/ubench/mfma_model; timeout -k 10 120 tools/ubench/mfma_model2; timeout -k 10 120 tools/ubench/mfma_power) > gpurun_out/final/ubench.txt 2>&1
 echo "ubench done"

@@ -94,6 +94,29 @@ traffic = {
     "edge_bwd_fn_kernel": {"bytes_per_launch": int((2 * 2 * w + 2 * wo + 2 * w0) / 6)},
     "edge_dw_kernel": {"bytes_per_launch": int(tot("edge_dw_kernel<2"))},
 }
+# ---- the secondary workloads' kernels (bench.py: secondary.*.roofline.traffic), launch-weighted over every dispatch whose name
+#      contains the entry point's stem (mab_bwd = mab_bwd_kernel + mab_bwd2_kernel, edge_fwd = the eight-wave edge_fwd1_kernel ...)
+sp = os.path.join(F, "pmc_secondary_summary.txt")
+if os.path.isfile(sp):
+    sv, cur = {}, None
+    for l in open(sp).read().splitlines():
+        m = re.match(r"== (\w+) (\w+) (.*)", l)
+        if m:
+            cur = m.groups(); continue
+        m = re.match(r"(\w+)\s+n=\s*(\d+) avg=\s*([\d.]+)", l)
+        if m and cur:
+            sv[cur] = float(m.group(3))
+    sec = {}
+    for wl, stems in (("gapt_n30_b512", ("mab_bwd", "mab_chain_fwd", "mab_fwd", "bridge")), ("mpgan_n150_b16", ("edge_fwd", "edge_bwd", "edge_dw_kernel", "chain", "disc_head"))):
+        for st in stems:
+            f, w_ = sv.get((wl, "FETCH_SIZE", st)), sv.get((wl, "WRITE_SIZE", st))
+            if f is not None and w_ is not None:
+                kn = st if st.endswith("_kernel") else st + "_kernel"
+                sec.setdefault(wl, {})[kn] = {"bytes_per_launch": int((2 * f + w_) * 1024)}
+    traffic["secondary"] = sec
+    traffic["note"] += ("; secondary: per launch, launch-weighted over every dispatch of the entry point's kernels in a short bench.py run "
+                        f"of that workload (gpurun_out/final/pmc_secondary_summary.txt -> profiles/{tag}_pmc_hbm_traffic_secondary.txt)")
+    shutil.copy(sp, os.path.join(P, f"{tag}_pmc_hbm_traffic_secondary.txt"))
 json.dump(traffic, open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
 # ---- SQ counters (tools/final_profiles.sh: pmc_sq_summary.txt)
 sq_path = os.path.join(F, "pmc_sq_summary.txt")
