@@ -210,7 +210,7 @@ int mpg_knn_sets(const float* x, int ldx, const float* mask, int B, int N, int F
  * says which (e is chosen from max |dagg| of the block's receivers).
  * All images are fp16 (f16 must be 1, error -8): W3Timg / W2Timg the images of the transposed weights packed with the
  * forward's scales (dscale * 64, dscale * 16); W2img and b2 are not read.  The two gradient products run as two fp16
- * terms (image hi + lo times the gradient rounded to fp16 in a per-sender unit).  A sender chunk (ceil(N / SC) senders) may hold at most 180 senders (error -6: raise SC), and
+ * terms (image hi + lo times the gradient rounded to fp16 in a per-sender unit).  A sender chunk (ceil(N / SC) senders) may hold at most 160 senders (error -6: raise SC), and
  * the staging buffers must stay below 2 GiB (error -7). */
 typedef struct MpgEdgeBwd {
     const float* a; const float* c; int ld_ac; const float* mask;

@@ -70,10 +70,12 @@ MPG_DEV void edge_bwd1_body(const MpgEdgeBwd& p) {
     f16x8* l3t = reinterpret_cast<f16x8*>(smem);
     float4* ldg = reinterpret_cast<float4*>(smem + B2_W_BYTES);                // [(m*4+g)][lane]
     float4* la = reinterpret_cast<float4*>(smem + B2_W_BYTES + B2_DG_BYTES);   // [(q*2+s)*2+u][lane]
-    float* lmx = reinterpret_cast<float*>(smem + B2_Q_OFF);                    // wave maxima of |dagg| (the 640 bytes b2 once had)
+    float* lmk = reinterpret_cast<float*>(smem + B2_Q_OFF);                    // the listed senders' mask entries (edge_bwd2_impl.h)
     float* lcw = reinterpret_cast<float*>(smem + B2_Q_OFF + B2_B2_BYTES) + w * H1;   // this wave's row of c
     unsigned short* lst = reinterpret_cast<unsigned short*>(smem + B2_Q_OFF + B2_B2_BYTES + B2_C_BYTES);
-    int* lnv = reinterpret_cast<int*>(lst + B2_LIST_MAX);
+    int* lnv = reinterpret_cast<int*>(lst + 180);
+    float* lmx = reinterpret_cast<float*>(lst + 180) - 8;                      // wave maxima of |dagg|: 32 bytes behind the list's 320
+    static_assert(2 * B2_LIST_MAX + 32 <= 360, "the eight maxima sit between the list and its count");
 
     // ---- prologue (the four-wave kernel's, on 512 threads)
     float4 dv[3], av[2];
@@ -119,9 +121,11 @@ MPG_DEV void edge_bwd1_body(const MpgEdgeBwd& p) {
         int cnt = 0;
         for (int j0 = lbeg; j0 < lend; j0 += 64) {
             const int j = j0 + lane;
-            const bool ok = j < lend && (p.mask == nullptr || p.mask[b * p.N + j] != 0.f);
+            const float mv = (j < lend && p.mask != nullptr) ? p.mask[b * p.N + j] : 1.f;
+            const bool ok = j < lend && mv != 0.f;
             const unsigned long long bits = __ballot(ok);
-            if (ok) lst[cnt + __popcll(bits & ((1ull << lane) - 1ull))] = (unsigned short)j;
+            const int pos = cnt + __popcll(bits & ((1ull << lane) - 1ull));
+            if (ok) { lst[pos] = (unsigned short)j; lmk[pos] = mv; }
             cnt += __popcll(bits);
         }
         if (lane == 0) *lnv = cnt;
@@ -138,6 +142,7 @@ MPG_DEV void edge_bwd1_body(const MpgEdgeBwd& p) {
     if (whole) {
         const int per = (nvalid + p.SC - 1) / p.SC, l0 = min(nvalid, sc * per);
         lst += l0;
+        lmk += l0;
         nvalid = min(per, nvalid - l0);
     }
     float mx8 = 0.f;
@@ -202,10 +207,7 @@ MPG_DEV void edge_bwd1_body(const MpgEdgeBwd& p) {
         }
         const int blk = (b * RB + rb) * p.N + jj;
         const float dth = dither_of((uint32_t)blk);   // this sender's unit within the workgroup's
-        // (the mask entry is loaded HERE, not with the row of c a round ahead: hoisted into the prefetch this one load faulted --
-        // 'Memory access fault', scattered masks, four- and eight-wave form alike, not under AMD_LOG_LEVEL=3 -- for a reason
-        // the generated code does not show; the loop-top form is the one every round has run)
-        const float mj = p.mask ? p.mask[b * p.N + jj] : 1.f;
+        const float mj = lmk[s];   // (from LDS: a load at the top of the round would wait for every store of the round before)
         const float mjs = mj * p.dscale * gunit;
         const float cpos = mjs * in_set * dth, cneg = mjs * p.alpha * in_set * dth;
         const int stsc = blk * (NFR2 * 1024);

@@ -55,7 +55,9 @@ constexpr int B2_DG_BYTES = T3 * 4 * 64 * 16;    //  24,576
 constexpr int B2_A_BYTES = T1 * 4 * 64 * 16;     //  12,288
 constexpr int B2_B2_BYTES = H2 * 4;              //     640
 constexpr int B2_C_BYTES = 4 * 2 * H1 * 4;       //   3,072
-constexpr int B2_LIST_MAX = 180;                 // senders per chunk (uint16 entries + count + 4 wave maxima of the prologue: 384 B)
+constexpr int B2_LIST_MAX = 160;                 // senders per chunk (uint16 entries + count + the wave maxima of the prologue: 384 B)
+// Without edge scalars the 640 bytes b2 once had hold the listed senders' MASK ENTRIES in list order (160 floats), and the
+// sender loop takes m_j from there instead of from memory at the top of a pair (see F2_MK_OFF, edge_fwd2_impl.h)
 constexpr int B2_LDS_BYTES = B2_W_BYTES + B2_DG_BYTES + B2_A_BYTES + B2_B2_BYTES + B2_C_BYTES + 384;
 static_assert(B2_LDS_BYTES <= 163840, "LDS plan exceeds 160 KiB");
 // with edge scalars (NQ > 0) the columns wq [2][96] take the 640 bytes left over from b2 (nothing is recomputed any more)
@@ -135,7 +137,8 @@ MPG_DEV void edge_bwd_body(const MpgEdgeBwd& p, const MpgChain* const cdxp, cons
     float* lwq = reinterpret_cast<float*>(smem + B2_Q_OFF);                    // wq [NQ][96] (times SC_A, like a and c)
     float* lcw = reinterpret_cast<float*>(smem + B2_Q_OFF + QB) + w * (2 * H1); // this wave's two rows of c
     unsigned short* lst = reinterpret_cast<unsigned short*>(smem + B2_Q_OFF + QB + B2_C_BYTES);
-    int* lnv = reinterpret_cast<int*>(lst + (NQ > 0 ? B2_LIST_MAX_Q : B2_LIST_MAX));
+    int* lnv = reinterpret_cast<int*>(lst + (NQ > 0 ? B2_LIST_MAX_Q : 180));
+    float* lmk = lwq;   // (NQ == 0 only)
     float* lmx = reinterpret_cast<float*>(smem + B2_LDS_BYTES - 16);                // wave maxima of |dagg|
 
     // ---- prologue (whole workgroup): weights and the per-receiver tiles into LDS, the list of unmasked senders
@@ -188,9 +191,14 @@ MPG_DEV void edge_bwd_body(const MpgEdgeBwd& p, const MpgChain* const cdxp, cons
         int cnt = 0;
         for (int j0 = lbeg; j0 < lend; j0 += 64) {
             const int j = j0 + lane;
-            const bool ok = j < lend && (p.mask == nullptr || p.mask[b * p.N + j] != 0.f);
+            const float mv = (j < lend && p.mask != nullptr) ? p.mask[b * p.N + j] : 1.f;
+            const bool ok = j < lend && mv != 0.f;
             const unsigned long long bits = __ballot(ok);
-            if (ok) lst[cnt + __popcll(bits & ((1ull << lane) - 1ull))] = (unsigned short)j;
+            const int pos = cnt + __popcll(bits & ((1ull << lane) - 1ull));
+            if (ok) {
+                lst[pos] = (unsigned short)j;
+                if constexpr (NQ == 0) lmk[pos] = mv;
+            }
             cnt += __popcll(bits);
         }
         if (lane == 0) *lnv = cnt;
@@ -207,6 +215,7 @@ MPG_DEV void edge_bwd_body(const MpgEdgeBwd& p, const MpgChain* const cdxp, cons
     if (whole) {
         const int per = (nvalid + p.SC - 1) / p.SC, l0 = min(nvalid, sc * per);
         lst += l0;
+        lmk += l0;
         nvalid = min(per, nvalid - l0);
     }
     // the workgroup's gradient unit 2^-e (see the head of this file): max |dZ3| <= max |dagg * agg_scale| * dscale (mask <= 1)
@@ -305,7 +314,9 @@ MPG_DEV void edge_bwd_body(const MpgEdgeBwd& p, const MpgChain* const cdxp, cons
         uint32_t sw[2][T3 / 2];     // this lane's 96 sign bits of Z3 per sender
 #pragma unroll
         for (int sd = 0; sd < 2; ++sd) {
-            const float mj = p.mask ? p.mask[b * p.N + jj[sd]] : 1.f;
+            float mj;
+            if constexpr (NQ == 0) mj = lmk[min(2 * pq + sd, nvalid - 1)];
+            else mj = p.mask ? p.mask[b * p.N + jj[sd]] : 1.f;
             const float mjs = (sd == 0 || has2) ? mj * p.dscale * gunit : 0.f;
             float in_set = 1.f;
             if (p.nbr != nullptr) {  // k-nearest-neighbour graph: the edge (i, j) exists only if j's bit is set in i's row

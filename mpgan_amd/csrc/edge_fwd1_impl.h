@@ -70,7 +70,8 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
     float* lb3 = lb2 + H2;
     float* lcw = lb3 + H3 + w * H1;                                            // this wave's row of c
     unsigned short* lst = reinterpret_cast<unsigned short*>(smem + F2_W_BYTES + F2_A_BYTES + F2_B_BYTES + F2_C_BYTES);
-    int* lnv = reinterpret_cast<int*>(lst + F2_LIST_MAX);
+    int* lnv = reinterpret_cast<int*>(lst + 180);   // (behind the list's 360 bytes)
+    float* lmk = reinterpret_cast<float*>(smem + F2_MK_OFF);   // the listed senders' mask entries (edge_fwd2_impl.h)
 
     // ---- prologue (as the four-wave kernel's, on 512 threads): small loads first, W3's image by LDS-DMA behind them
     static_assert(H2 + H3 <= 512 && T1 * 4 * 64 == 512 + 256, "the prologue's register sets");
@@ -100,9 +101,11 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
         int cnt = 0;
         for (int j0 = lbeg; j0 < lend; j0 += 64) {
             const int j = j0 + lane;
-            const bool ok = j < lend && (!(p.skip_masked & 1) || p.mask == nullptr || p.mask[b * p.N + j] != 0.f);
+            const float mv = (j < lend && p.mask != nullptr) ? p.mask[b * p.N + j] : 1.f;
+            const bool ok = j < lend && (!(p.skip_masked & 1) || mv != 0.f);
             const unsigned long long bits = __ballot(ok);
-            if (ok) lst[cnt + __popcll(bits & ((1ull << lane) - 1ull))] = (unsigned short)j;
+            const int pos = cnt + __popcll(bits & ((1ull << lane) - 1ull));
+            if (ok) { lst[pos] = (unsigned short)j; lmk[pos] = mv; }
             cnt += __popcll(bits);
         }
         if (lane == 0) *lnv = cnt;
@@ -112,6 +115,7 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
     if (whole) {
         const int per = (nvalid + p.SC - 1) / p.SC, l0 = min(nvalid, sc * per);
         lst += l0;
+        lmk += l0;
         nvalid = min(per, nvalid - l0);
     }
 
@@ -160,7 +164,7 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
     for (int s = w; s < nvalid; s += F1_NW) {
         F1_STAMP(4)
         const int jj = __builtin_amdgcn_readfirstlane((int)lst[s]);
-        const float mj = p.mask ? p.mask[b * p.N + jj] : 1.f;
+        const float mj = lmk[s];
         float mjs = mj * p.dscale * (1.f / SC_E3);   // (the layer-3 output carries SC_E3)
         if (p.nbr != nullptr) {
             const unsigned int wb = p.nbr[(size_t)(b * p.N + (vi ? i : 0)) * ((p.N + 31) >> 5) + (jj >> 5)];

@@ -42,9 +42,13 @@ constexpr int F2_W_BYTES = 2 * NF3 * 1024;       // 122,880
 constexpr int F2_A_BYTES = T1 * 4 * 64 * 16;     //  12,288
 constexpr int F2_B_BYTES = (H2 + H3) * 4;        //   1,408
 constexpr int F2_C_BYTES = 4 * 2 * H1 * 4;       //   3,072
-constexpr int F2_LIST_MAX = 180;                 // senders per chunk (uint16 entries + count: 384 B)
+constexpr int F2_LIST_MAX = 160;                 // senders per chunk (uint16 entries + count: 384 B)
 constexpr int F2_Q_OFF = F2_W_BYTES + F2_A_BYTES + F2_B_BYTES + F2_C_BYTES + 384;   // edge-scalar columns wq [3][96] (NQ > 0)
-constexpr int F2_LDS_BYTES = F2_Q_OFF + MPG_EDGE_SCALARS * H1 * 4;
+// ... and the listed senders' MASK ENTRIES, in list order (fp32): the sender loop takes m_j from here.  Loaded from memory at the
+// top of a sender's round it cost a full drain of the wave's vector-memory queue -- vmcnt counts the parking stores of the round
+// before too, and they complete in order -- 1.3-1.9k clk of a round's 20-27k (tools/ubench/fwd_bench.hip, -DMPG_F1_STAMP).
+constexpr int F2_MK_OFF = F2_Q_OFF + MPG_EDGE_SCALARS * H1 * 4;
+constexpr int F2_LDS_BYTES = F2_MK_OFF + F2_LIST_MAX * 4;
 static_assert(F2_LDS_BYTES <= 163840, "LDS plan exceeds 160 KiB");
 static_assert(4 * T3 * 16 * 64 * 4 <= F2_W_BYTES, "the final reduction reuses the weight area");
 
@@ -101,7 +105,8 @@ MPG_DEV void edge_fwd_body(const MpgEdgeFwd& p, const MpgChain* const cp, const 
     float* lb3 = lb2 + H2;
     float* lcw = lb3 + H3 + w * (2 * H1);                                      // this wave's two rows of c
     unsigned short* lst = reinterpret_cast<unsigned short*>(smem + F2_W_BYTES + F2_A_BYTES + F2_B_BYTES + F2_C_BYTES);
-    int* lnv = reinterpret_cast<int*>(lst + F2_LIST_MAX);
+    int* lnv = reinterpret_cast<int*>(lst + 180);   // (behind the list's 360 bytes)
+    float* lmk = reinterpret_cast<float*>(smem + F2_MK_OFF);
 
     // ---- prologue (whole workgroup): W3 and the receivers' layer-1 terms into LDS, biases in the accumulators' scales,
     //      the list of the chunk's senders (the unmasked ones: a zero-masked sender adds exactly 0)
@@ -146,9 +151,11 @@ MPG_DEV void edge_fwd_body(const MpgEdgeFwd& p, const MpgChain* const cp, const 
         int cnt = 0;
         for (int j0 = lbeg; j0 < lend; j0 += 64) {
             const int j = j0 + lane;
-            const bool ok = j < lend && (!(p.skip_masked & 1) || p.mask == nullptr || p.mask[b * p.N + j] != 0.f);
+            const float mv = (j < lend && p.mask != nullptr) ? p.mask[b * p.N + j] : 1.f;
+            const bool ok = j < lend && (!(p.skip_masked & 1) || mv != 0.f);
             const unsigned long long bits = __ballot(ok);
-            if (ok) lst[cnt + __popcll(bits & ((1ull << lane) - 1ull))] = (unsigned short)j;
+            const int pos = cnt + __popcll(bits & ((1ull << lane) - 1ull));
+            if (ok) { lst[pos] = (unsigned short)j; lmk[pos] = mv; }
             cnt += __popcll(bits);
         }
         if (lane == 0) *lnv = cnt;
@@ -159,6 +166,7 @@ MPG_DEV void edge_fwd_body(const MpgEdgeFwd& p, const MpgChain* const cp, const 
     if (whole) {
         const int per = (nvalid + p.SC - 1) / p.SC, l0 = min(nvalid, sc * per);
         lst += l0;
+        lmk += l0;
         nvalid = min(per, nvalid - l0);
     }
 
@@ -208,7 +216,7 @@ MPG_DEV void edge_fwd_body(const MpgEdgeFwd& p, const MpgChain* const cp, const 
         uint32_t erow[2];
 #pragma unroll
         for (int sd = 0; sd < 2; ++sd) {
-            const float mj = p.mask ? p.mask[b * p.N + jj[sd]] : 1.f;
+            const float mj = lmk[min(2 * pq + sd, nvalid - 1)];
             mjs[sd] = (sd == 0 || has2) ? mj * p.dscale * (1.f / SC_E3) : 0.f;   // (the layer-3 output carries SC_E3)
             if (p.nbr != nullptr) {  // k-nearest-neighbour graph: sender j counts for this lane's receiver only if its bit is set
                 const unsigned int wb = p.nbr[(size_t)(b * p.N + (vi ? i : 0)) * ((p.N + 31) >> 5) + (jj[sd] >> 5)];

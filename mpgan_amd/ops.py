@@ -521,7 +521,7 @@ def chain_struct(M, layers, *, A, lda, K1, A2=None, lda2=0, a_slabs=1, a_slab_st
 EDGE_SCALARS = 2          # MPG_EDGE_SCALARS of include/mpgan_amd.h
 MAX_CHUNK_SENDERS_ES = 116   # ... with edge scalars (their columns take part of the list's LDS)
 PARK_BYTES_PER_BLOCK = 10240   # E2 / dZ2 of one (jet, receiver block, sender) block as fp16 fragments: 160 x 32 x 2 bytes
-MAX_CHUNK_SENDERS = 180   # mpg_edge_bwd keeps the list of a chunk's unmasked senders in LDS (csrc/edge_bwd2.hip)
+MAX_CHUNK_SENDERS = 160   # mpg_edge_bwd keeps the list of a chunk's unmasked senders in LDS (csrc/edge_bwd2.hip)
 
 
 def jet_order(mask2d: torch.Tensor) -> torch.Tensor:
