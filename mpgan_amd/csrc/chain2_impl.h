@@ -99,17 +99,36 @@ MPG_DEV void c2_body(const MpgChain& p, const int m0, const int nrows, char* fb0
     };
 
     C2_STAMP(18);
-    V wb[NSL][16][2];   // [slot A | slot B][k-step][hi | lo]: whole tiles
-    auto load_tile = [&](auto lc, auto bc, int tile) {
+    // NSL == 2: [slot A | slot B][k-step][hi | lo]: whole tiles.  NSL == 1 (256 registers): a RING of eight k-steps over the chain's
+    // whole sequence of k-steps -- item g = (layer, k-step) sits in slot g % 8; the ring starts with items 0..7 and item g + 8 is
+    // requested into the slot item g has just left (a whole 16-k-step tile, 128 registers, did not fit beside the epilogue state:
+    // 72 registers spilled, and every scratch access drained the weight prefetch)
+    constexpr int RING = NSL == 1 ? 8 : 16;
+    V wb[NSL][RING][2];
+    constexpr int KSA[3] = {KS0, KS1, KS2};
+    constexpr int OFF1 = KS0, OFF2 = KS0 + KS1, NITEM = KS0 + KS1 + KS2;
+    auto load_item = [&](auto gc) {   // NSL == 1: item g of the sequence -> slot g % 8 (a wave without a tile in that layer reads zeros)
+        MPG_CI(g, gc);
+        if constexpr (g < NITEM) {
+            constexpr int l = (KS2 > 0 && g >= OFF2) ? 2 : ((KS1 > 0 && g >= OFF1) ? 1 : 0);
+            constexpr int ks = g - (l == 2 ? OFF2 : (l == 1 ? OFF1 : 0));
+            const int mt = (p.L[l].N + 31) / 32, nfrag = mt * KSA[l];
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.L[l].Wimg), 0, w < mt ? 2 * nfrag * 1024 : 0, 0x00020000);
+            wb[0][g % RING][0] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, (w * KSA[l] + ks) * 1024, 0));
+            wb[0][g % RING][1] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, (nfrag + w * KSA[l] + ks) * 1024, 0));
+        }
+    };
+    auto load_tile = [&](auto lc, auto bc, int tile) {   // (NSL == 2)
         MPG_CI(l, lc);
         MPG_CI(b, bc);
-        constexpr int KSC = l == 0 ? KS0 : (l == 1 ? KS1 : KS2);
-        const int nfrag = ((p.L[l].N + 31) / 32) * KSC;
+        constexpr int KSC = (l == 0 ? KS0 : (l == 1 ? KS1 : KS2)) <= RING ? (l == 0 ? KS0 : (l == 1 ? KS1 : KS2)) : RING;
+        constexpr int KST = l == 0 ? KS0 : (l == 1 ? KS1 : KS2);   // (KSC == KST for NSL == 2: the only caller)
+        const int nfrag = ((p.L[l].N + 31) / 32) * KST;
         const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.L[l].Wimg), 0, 2 * nfrag * 1024, 0x00020000);
         static_for<0, KSC>([&](auto kc) {
             MPG_CI(ks, kc);
-            wb[b][ks][0] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, (tile * KSC + ks) * 1024, 0));
-            wb[b][ks][1] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, (nfrag + tile * KSC + ks) * 1024, 0));
+            wb[b][ks][0] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, (tile * KST + ks) * 1024, 0));
+            wb[b][ks][1] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, (nfrag + tile * KST + ks) * 1024, 0));
         });
     };
     using I0 = std::integral_constant<int, 0>;
@@ -118,7 +137,9 @@ MPG_DEV void c2_body(const MpgChain& p, const int m0, const int nrows, char* fb0
     // behind 64 KiB of weights per wave
     auto first_tile = [&](auto bc) {
         MPG_CI(b, bc);
-        if constexpr (b < NSL) {
+        if constexpr (NSL == 1) {
+            if constexpr (b == 0) static_for<0, RING>([&](auto gc) { load_item(gc); });
+        } else {
             if (w + NW * b < (p.L[0].N + 31) / 32) load_tile(I0{}, bc, w + NW * b);
         }
     };
@@ -256,6 +277,21 @@ MPG_DEV void c2_body(const MpgChain& p, const int m0, const int nrows, char* fb0
             wb[B][ks][0] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rwn, lane16, (tile_n * KSN + ks) * 1024, 0));
             wb[B][ks][1] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rwn, lane16, (nfragn + tile_n * KSN + ks) * 1024, 0));
         };
+        constexpr int GOFF = l == 0 ? 0 : (l == 1 ? OFF1 : OFF2);   // (NSL == 1: the layer's first item of the ring's sequence)
+        auto kloop1 = [&](C2Tile& T) {   // NSL == 1: the wave's one tile, weights from the ring
+            V bh = fin[0 * 64 + lane], bl = fin[1 * 64 + lane];
+            static_for<0, KSC>([&](auto kc) {
+                MPG_CI(ks, kc);
+                constexpr int kn = ks + 1 < KSC ? ks + 1 : KSC - 1, g = GOFF + ks;
+                const V nh = fin[(kn * 2 + 0) * 64 + lane], nl = fin[(kn * 2 + 1) * 64 + lane];
+                T.acc = c2_mma<F16>(wb[0][g % RING][1], bh, T.acc);
+                T.acc = c2_mma<F16>(wb[0][g % RING][0], bl, T.acc);
+                T.acc = c2_mma<F16>(wb[0][g % RING][0], bh, T.acc);
+                load_item(std::integral_constant<int, g + RING>{});
+                __builtin_amdgcn_sched_barrier(0);
+                bh = nh; bl = nl;
+            });
+        };
         auto kloop = [&](auto bc, auto nue, C2Tile& T, C2Tile& E, const __amdgpu_buffer_rsrc_t& rwn, int tile_n) {
             MPG_CI(B, bc);
             MPG_CI(NUE, nue);
@@ -285,6 +321,19 @@ MPG_DEV void c2_body(const MpgChain& p, const int m0, const int nrows, char* fb0
         const void* imgn = last ? p.L[l].Wimg : p.L[last ? l : l + 1].Wimg;
         const __amdgpu_buffer_rsrc_t rwnA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(imgn), 0, (!last && w < MTn) ? 2 * nfragn * 1024 : 0, 0x00020000);
         C2Tile TA;
+        if constexpr (NSL == 1) {
+            // (the ring's sequence advances in every wave: one without a tile in this layer only issues the layer's requests --
+            // empty descriptors for its own missing tiles, the next layers' fragments where it has one)
+            if (actA) {
+                request(TA, w);
+                kloop1(TA);
+            } else {
+                static_for<0, KSC>([&](auto kc) { load_item(std::integral_constant<int, GOFF + decltype(kc)::value + RING>{}); });
+            }
+            C2_STAMP(3 + 5 * l);
+            C2_STAMP(4 + 5 * l);
+            if (actA) static_for<0, NU>([&](auto uc) { unit(uc, TA); });
+        } else {
         if (actA) {
             request(TA, w);
             kloop(I0{}, I0{}, TA, TA, rwnA, w);
@@ -292,6 +341,7 @@ MPG_DEV void c2_body(const MpgChain& p, const int m0, const int nrows, char* fb0
             if (w < MTn) load_tile(std::integral_constant<int, l + 1>{}, I0{}, w);            // (no loop to ride in)
         }
         C2_STAMP(3 + 5 * l);
+        }
         if constexpr (NSL == 2) {
             const __amdgpu_buffer_rsrc_t rwnB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(imgn), 0, (!last && w + 4 < MTn) ? 2 * nfragn * 1024 : 0, 0x00020000);
             C2Tile TB;
@@ -304,8 +354,6 @@ MPG_DEV void c2_body(const MpgChain& p, const int m0, const int nrows, char* fb0
             C2_STAMP(4 + 5 * l);
             if (actB) static_for<0, NU>([&](auto uc) { unit(uc, TB); });
             else if (actA) static_for<0, NU>([&](auto uc) { unit(uc, TA); });
-        } else {
-            if (actA) static_for<0, NU>([&](auto uc) { unit(uc, TA); });
         }
         C2_STAMP(5 + 5 * l);
         __syncthreads();

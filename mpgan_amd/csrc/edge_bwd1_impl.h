@@ -34,8 +34,8 @@ static_assert(B1_NW * H1 * 4 == B2_C_BYTES, "one row of c per wave in the four-w
 static_assert(T3 * 4 * 64 == 3 * 512 && T1 * 4 * 64 == 512 + 256, "the prologue's register sets");
 static_assert(B1_NW * T1 * 16 * 64 * 4 <= B2_W_BYTES, "the final reduction reuses the weight area");
 
-// Which form mpg_edge_bwd takes: mpg_edge_waves() when it has been called with a non-zero value, else MPG_BWD_WAVES (4: the
-// four-wave kernels of edge_bwd2_impl.h), else eight
+// Which form the data-gradient launches take: mpg_edge_waves() when it has been called with a non-zero value, else the environment --
+// MPG_BWD_WAVES for mpg_edge_bwd, MPG_BWD_FN_WAVES for the epilogue form (4: the four-wave kernels of edge_bwd2_impl.h) --, else the default
 extern "C" int mpg_edge_waves_get(int which);   // edge.hip
 inline bool bwd_eight_waves() {
     const int o = mpg_edge_waves_get(1);
@@ -43,9 +43,20 @@ inline bool bwd_eight_waves() {
     static const bool v = [] { const char* e = getenv("MPG_BWD_WAVES"); return e == nullptr || atoi(e) != 4; }();
     return v;
 }
+#ifndef MPG_BWD_FN_DEFAULT
+#define MPG_BWD_FN_DEFAULT 8
+#endif
+inline bool bwd_fn_eight_waves() {
+    const int o = mpg_edge_waves_get(1);
+    if (o) return o != 4;
+    static const bool v = [] { const char* e = getenv("MPG_BWD_FN_WAVES"); return (e == nullptr ? MPG_BWD_FN_DEFAULT : atoi(e)) != 4; }();
+    return v;
+}
 
-template <int DROP, bool NEEDW>
-MPG_DEV void edge_bwd1_body(const MpgEdgeBwd& p) {
+// EPI / cdxp / cnxp: the epilogue chains of edge_bwd_body (the layer's dx chain and the lower layer's node-network input-gradient
+// chain on this workgroup's own jet), run by c2_body's eight-wave form
+template <int DROP, bool NEEDW, int EPI>
+MPG_DEV void edge_bwd1_body(const MpgEdgeBwd& p, const MpgChain* const cdxp = nullptr, const MpgChain* const cnxp = nullptr) {
     typedef f16x8 V;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef MPG_B1_STAMP
@@ -449,6 +460,33 @@ MPG_DEV void edge_bwd1_body(const MpgEdgeBwd& p) {
         const int ii = rb * 32 + (ln & 31);
         if (ii < p.N) *reinterpret_cast<float4*>(out + (size_t)ii * H1 + 32 * q + 8 * g + 4 * (ln >> 5)) = v;
     }
+    if constexpr (EPI != 0) {
+        // ---- epilogue chains on this jet's nodes (edge_bwd2_impl.h): the rows of da (just written) and of dc (written sender by
+        //      sender in the loop, zeros for masked senders in the prologue) are this workgroup's own stores
+        const int m0 = b * p.N + rb * 32, nrows = min(32, p.N - rb * 32);
+        {
+            const MpgChain& c = *cdxp;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            auto stage = [&](auto&& first_tile, auto&& bias_request, auto&& bias_store, const uint32_t s_lo, const uint32_t s_hi, const float ascale) {
+                c2_stage_rows<false, 12, 0, B1_NW>(c, m0, nrows, smem, first_tile, bias_request, bias_store, s_lo, s_hi, ascale);
+            };
+            c2_body<false, 12, 0, 0, 0, 0, 1, EPI == 3, B1_NW>(c, m0, nrows, smem, smem + C2_FB, reinterpret_cast<float*>(smem + 2 * C2_FB), stage);
+        }
+        if constexpr (EPI != 3) {
+            if (cnxp->nlayers > 0) {
+                const MpgChain& c = *cnxp;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                auto stage = [&](auto&& first_tile, auto&& bias_request, auto&& bias_store, const uint32_t s_lo, const uint32_t s_hi, const float ascale) {
+                    c2_stage_rows<false, 2, DROP, B1_NW>(c, m0, nrows, smem, first_tile, bias_request, bias_store, s_lo, s_hi, ascale);
+                };
+                c2_body<false, 2, 16, 16, DROP, 3, 0, EPI == 2, B1_NW>(c, m0, nrows, smem, smem + C2_FB, reinterpret_cast<float*>(smem + 2 * C2_FB), stage);
+            }
+        }
+    }
 #ifdef MPG_B1_STAMP
     if (lane == 0) {
         unsigned long long* o = b1_stamps + ((size_t)blockIdx.x * 8 + w) * 10;
@@ -460,7 +498,31 @@ MPG_DEV void edge_bwd1_body(const MpgEdgeBwd& p) {
 }
 
 template <int DROP, bool NEEDW>
-__global__ __launch_bounds__(512) void edge_bwd1_kernel(const MpgEdgeBwd p) { edge_bwd1_body<DROP, NEEDW>(p); }
+__global__ __launch_bounds__(512) void edge_bwd1_kernel(const MpgEdgeBwd p) { edge_bwd1_body<DROP, NEEDW, 0>(p); }
+
+template <int DROP, bool NEEDW, int EPI>
+__global__ __launch_bounds__(512) void edge_bwd1_fn_kernel(const MpgEdgeBwd p, const MpgChain cdx, const MpgChain cnx) {
+    edge_bwd1_body<DROP, NEEDW, EPI>(p, &cdx, &cnx);
+}
+
+// the epilogue forms of one dropout mode / NEEDW (edge_bwd_fn_*.hip); epi = 1, 2, 3 as in edge_bwd2_impl.h
+template <int D, bool NEEDW>
+int b1_launch_fn(const MpgEdgeBwd* p, const MpgChain* cdx, const MpgChain* cnx, int epi, hipStream_t st) {
+    const int RB = (p->N + 31) / 32;
+    dim3 grid(p->B * RB), block(512);
+    MpgChain none = {};   // nlayers = 0: no second chain
+    if (cnx == nullptr) cnx = &none;
+#define MPG_B1FN(E)                                                                                         \
+    do {                                                                                                    \
+        MPG_ENSURE_LDS((edge_bwd1_fn_kernel<D, NEEDW, E>), B2_LDS_BYTES);                                   \
+        hipLaunchKernelGGL((edge_bwd1_fn_kernel<D, NEEDW, E>), grid, block, B2_LDS_BYTES, st, *p, *cdx, *cnx); \
+    } while (0)
+    if (epi == 1) MPG_B1FN(1);
+    else if (epi == 2) MPG_B1FN(2);
+    else MPG_B1FN(3);
+#undef MPG_B1FN
+    return (int)hipGetLastError();
+}
 
 template <int D>
 int b1_launch(const MpgEdgeBwd* p, hipStream_t st) {

@@ -496,13 +496,22 @@ int f1_launch(const MpgEdgeFwd* p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-// Which form the plain forward takes (the FN form is four-wave only: c2_body's eight-wave form spills): mpg_edge_waves() when
-// it has been called with a non-zero value, else MPG_FWD_WAVES (4: the four-wave kernels of edge_fwd2_impl.h), else eight
+// Which form the forward takes: mpg_edge_waves() when it has been called with a non-zero value, else the environment -- MPG_FWD_WAVES
+// for the plain launches, MPG_FWD_FN_WAVES for the epilogue form (4: the four-wave kernels of edge_fwd2_impl.h) --, else the default
 extern "C" int mpg_edge_waves_get(int which);   // edge.hip
 inline bool fwd_eight_waves() {
     const int o = mpg_edge_waves_get(0);
     if (o) return o != 4;
     static const bool v = [] { const char* e = getenv("MPG_FWD_WAVES"); return e == nullptr || atoi(e) != 4; }();
+    return v;
+}
+#ifndef MPG_FWD_FN_DEFAULT
+#define MPG_FWD_FN_DEFAULT 8
+#endif
+inline bool fwd_fn_eight_waves() {
+    const int o = mpg_edge_waves_get(0);
+    if (o) return o != 4;
+    static const bool v = [] { const char* e = getenv("MPG_FWD_FN_WAVES"); return (e == nullptr ? MPG_FWD_FN_DEFAULT : atoi(e)) != 4; }();
     return v;
 }
 

@@ -778,7 +778,8 @@ def test_jet_order_and_heaviest_first_launches_change_no_result():
     (6, 30, 32, 32, 0.0, False, False),   # no mask, no gradient (nothing kept for a backward)
     (2, 150, 32, 32, 0.0, True, True),    # N = 150: several sender chunks -- outside the epilogue form, both calls take two launches
 ])
-def test_node_network_as_edge_epilogue_is_bit_identical(B, N, F, out, p_drop, use_mask, train):
+@pytest.mark.parametrize("waves", [8, 4])
+def test_node_network_as_edge_epilogue_is_bit_identical(B, N, F, out, p_drop, use_mask, train, waves):
     """``mpg_edge_fwd_fn`` (fn as the epilogue of the edge forward's workgroups, mpgan/model.py:256-279 in one launch) against
     ``mpg_edge_fwd`` + ``mpg_chain``, and ``mpg_edge_bwd_fn`` (the dx chain as the epilogue of the data-gradient kernel's
     workgroups) against ``mpg_edge_bwd`` + ``mpg_chain``: the layer's output, the by-products kept for the backward (agg, both hidden activations)
@@ -830,9 +831,9 @@ def test_node_network_as_edge_epilogue_is_bit_identical(B, N, F, out, p_drop, us
     if N <= 64:
         os.environ["MPG_FORCE_SC"] = "1"     # (a handful of jets would be cut into sender chunks to fill the chip: the whole-jet form)
     saved_opts = (ops.OPTIONS["fn_epilogue"], ops.OPTIONS["bwd_epilogue"])
-    # (the epilogue forms are four-wave kernels; the separate launches take the four-wave form here too: the eight-wave one orders
-    # the sums over senders differently -- test_eight_wave_forms_agree_with_the_four_wave_ones)
-    prev_waves = ops.edge_waves(4, 4)
+    # (both sides in ONE launch form -- eight waves per workgroup, the default, or four: the two order the sums over senders
+    # differently, test_eight_wave_forms_agree_with_the_four_wave_ones)
+    prev_waves = ops.edge_waves(waves, waves)
     try:
         a, b_ = run(True), run(False)
     finally:
@@ -896,7 +897,8 @@ def test_node_network_epilogue_takes_one_launch():
 
 
 @pytest.mark.parametrize("which,train", [("G", True), ("D", True), ("G", False)])
-def test_layers_hand_over_their_node_terms(which, train):
+@pytest.mark.parametrize("waves", [8, 4])
+def test_layers_hand_over_their_node_terms(which, train, waves):
     """A whole network at the headline batch: every layer's edge launch runs the node network as its epilogue AND, for all
     layers but the last, the next layer's a | c projection behind it (``ops.LayerHandoff``) -- one ``mpg_chain`` launch per
     network forward (the first layer's projection) instead of four -- and, in the backward, every data-gradient launch carries
@@ -942,7 +944,7 @@ def test_layers_hand_over_their_node_terms(which, train):
         return res, names, [k for k in calls.names if k in keep]
 
     saved = (ops.OPTIONS["fn_epilogue"], ops.OPTIONS["bwd_epilogue"])
-    prev_waves = ops.edge_waves(4, 4)   # (see test_node_network_as_edge_epilogue_is_bit_identical)
+    prev_waves = ops.edge_waves(waves, waves)   # (see test_node_network_as_edge_epilogue_is_bit_identical)
     try:
         net(xin, labels)   # (weight images built)
         (a, na, ba), (b_, nb, bb) = run(True), run(False)
