@@ -19,7 +19,12 @@
 // it is and its partner E1 is multiplied by 2^(eG - gexp) / c, c the block's dither factor (a jet whose gradients are
 // 2^-24 of the largest jet's drops out of the fp16 range, and of any fp32 sum with that jet too).
 #include "edge_common.h"
+#include <stdlib.h>
+#include <string.h>
 
+#ifndef MPG_DW8_SETS
+#define MPG_DW8_SETS 1   // register sets of parked pieces in the uniform kernel (edge_dw8_kernel)
+#endif
 #ifndef MPG_DW_EXP
 #define MPG_DW_EXP 0  // experiment bits (tools/ubench/dw_bench.hip): 1 consumers idle, 2 builders idle, 4 no staged loads, 8 no LDS writes
 #endif
@@ -609,6 +614,419 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
     }
 }
 
+#ifdef MPG_DW8
+// ---------------------------------------------------------------------------------------------------------------------
+// EXPERIMENT, compiled with -DMPG_DW8 only (tools/ubench/dw_bench.hip) -- measured and NOT adopted: the same partials bit for bit,
+// 87.6 against 63.5 us at B = 256 and 131.5 against 97.4 us at 512 ragged jets (p = 1/2: 94.3 / 73.4, 147.9 / 114.5).  With every
+// wave of a SIMD in the same phase (one barrier per block keeps the eight waves in lock step) the second wave's instructions do
+// not issue beside the first's: a build is stores to LDS (13 clk each on the shared store path), buffer requests and
+// conversions, not the plain arithmetic of tools/ubench/valu_rate2.hip, and while everyone builds the matrix pipe idles.
+// The UNIFORM form (no edge scalars): all eight waves build AND multiply.  The kernel above is bound by the instruction issue of
+// its four builder waves (one per SIMD, ~7 clk per instruction, 378 instructions per block; with every staged load compiled
+// out it is no faster) while its four consumer waves multiply for a quarter of a block's time -- and a second wave on a SIMD
+// issues beside the first at the same rate (tools/ubench/valu_rate2.hip).  Here every wave takes 1 / 512 of a block's build (two
+// dZ3 chunks, two pieces each of the parked dZ2 / E2, one E1 chunk: 7 pieces where a builder thread had 11) and owns five or
+// six of the 45 output tiles; per block a wave builds block n + 1 into one image buffer and multiplies block n out of the other,
+// one barrier per block as before.  Same images, same order of the blocks in every accumulator and every bias sum: the
+// partials are those of the kernel above, bit for bit.
+// tiles of wave w: waves 0..4 the row m = w of dW3 (5 tiles) + tile (5, w); waves 5..7 five tiles of dW2 each
+__device__ constexpr DwTile DW8_TILES[45] = {
+    {0,0,0},{0,0,1},{0,0,2},{0,0,3},{0,0,4},{0,5,0},
+    {0,1,0},{0,1,1},{0,1,2},{0,1,3},{0,1,4},{0,5,1},
+    {0,2,0},{0,2,1},{0,2,2},{0,2,3},{0,2,4},{0,5,2},
+    {0,3,0},{0,3,1},{0,3,2},{0,3,3},{0,3,4},{0,5,3},
+    {0,4,0},{0,4,1},{0,4,2},{0,4,3},{0,4,4},{0,5,4},
+    {1,0,0},{1,0,1},{1,0,2},{1,1,0},{1,1,1},
+    {1,1,2},{1,2,0},{1,2,1},{1,2,2},{1,3,0},
+    {1,3,1},{1,3,2},{1,4,0},{1,4,1},{1,4,2}};
+constexpr bool dw8_same_rows(int t, int u) { return DW8_TILES[t].prod == DW8_TILES[u].prod && DW8_TILES[t].m == DW8_TILES[u].m; }
+constexpr bool dw8_leader(int t, int begin) { return t == begin || !dw8_same_rows(t, t - 1); }
+constexpr int dw8_group_end(int t, int end) { int e = t + 1; while (e < end && dw8_same_rows(t, e)) ++e; return e; }
+constexpr bool dw8_has_prod(int prod, int begin, int end) {
+    for (int t = begin; t < end; ++t) if (DW8_TILES[t].prod == prod) return true;
+    return false;
+}
+constexpr bool dw8_uses_n(int prod, int n, int begin, int end) {
+    for (int t = begin; t < end; ++t) if (DW8_TILES[t].prod == prod && DW8_TILES[t].n == n) return true;
+    return false;
+}
+
+// One block into the wave's accumulators.  A wave's tiles are one or two row groups (same product and m): their A fragments are
+// held (two at most would be 8 registers; three for the dW2 waves), the B fragments pass one at a time -- 4 registers where
+// holding a product's five cost 20 of the 256 this kernel has.
+template <int BEGIN, int END>
+MPG_DEV void dw8_consume(f32x16* acc, uint32_t buf, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int row = 8 * (g >> 1) + q, col = (16 * (g & 1) + 4 * pp) * 2;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        uint32_t bz3 = buf + DW_Z3H + row * DW_RS3 + col, be2 = buf + DW_E2H + row * DW_RS2 + col;
+        uint32_t bz2 = buf + DW_Z2H + row * DW_RS2 + col, be1 = buf + DW_E1H + row * DW_RS1 + col;
+        asm volatile("" : "+v"(bz3), "+v"(be2), "+v"(bz2), "+v"(be1));
+        static_for<0, 2>([&](auto pc) {
+            MPG_CI(prod, pc);
+            if constexpr (dw8_has_prod(prod, BEGIN, END)) {
+                constexpr int rsa = prod == 0 ? DW_RS3 : DW_RS2, rsb = prod == 0 ? DW_RS2 : DW_RS1, nb = prod == 0 ? T2 : T1, na = prod == 0 ? T3 : T2;
+                const uint32_t ba = prod == 0 ? bz3 : bz2, bb = prod == 0 ? be2 : be1;
+                f16x8 afr[na];   // (only the rows this wave owns are ever read: the others are never defined)
+                static_for<BEGIN, END>([&](auto tc) {
+                    MPG_CI(t, tc);
+                    if constexpr (DW8_TILES[t].prod == prod && dw8_leader(t, BEGIN)) afr[DW8_TILES[t].m] = dw_frag(ba, 16 * s * rsa + 64 * DW8_TILES[t].m, rsa);
+                });
+                static_for<0, nb>([&](auto nc) {
+                    MPG_CI(n, nc);
+                    if constexpr (dw8_uses_n(prod, n, BEGIN, END)) {
+                        const f16x8 b = dw_frag(bb, 16 * s * rsb + 64 * n, rsb);
+                        static_for<BEGIN, END>([&](auto tc) {
+                            MPG_CI(t, tc);
+                            if constexpr (DW8_TILES[t].prod == prod && DW8_TILES[t].n == n)
+                                acc[t - BEGIN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[DW8_TILES[t].m], b, acc[t - BEGIN], 0, 0, 0);
+                        });
+                    }
+                });
+            }
+        });
+    }
+}
+
+template <int BEGIN, int END>
+MPG_DEV void dw8_store(const f32x16* acc, float* part3, float* part2, int lane) {
+    const int cc = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int t = BEGIN; t < END; ++t) {
+        const DwTile d = DW8_TILES[t];
+        float* dst = d.prod == 0 ? part3 : part2;
+        const int ncol = d.prod == 0 ? H2 : H1;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int row = 32 * d.m + 8 * (k >> 2) + 4 * hh + (k & 3);
+            dst[(size_t)row * ncol + 32 * d.n + cc] = acc[t - BEGIN][k];
+        }
+    }
+}
+
+template <int DROP, int BEGIN, int END>
+MPG_DEV void dw8_wave(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk1, unsigned long long vbits) {
+    const int bt = threadIdx.x, lane = bt & 63;   // thread 0..511: receiver row r of the images, chunk group cg (0..15)
+    const int r = (bt >> 2) & 31, cg = ((bt >> 7) << 2) | (bt & 3);
+    const int RB = (p.N + 31) / 32;
+    const int tq = cg >> 2;                       // the thread's tile within a group of four: chunks 4 (tq + 4n) + (cg & 3)
+    const int cs = (cg >> 1) & 1, ch = cg & 1;
+    const int f0 = 16 * cs + 4 * ch;              // features of a chunk of tile t: 32 t + f0 + {0..3, 8..11}
+    // second pieces: dZ3 tiles tq + 4 (tq < 2), 160-feature tile 4 (tq == 0); E1 tile tq (tq < 3).  A thread without one redoes
+    // another piece instead (same data to the same place): no branch in the build
+    const bool z3b = tq < 2, p160b = tq == 0;
+    const int m3[2] = {tq, z3b ? tq + 4 : tq}, t160[2] = {tq, p160b ? 4 : tq}, te1 = tq < 3 ? tq : 2;
+
+    uint32_t seed_lo = 0, seed_hi = 0;
+    if (DROP) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
+
+    f32x16 acc[END - BEGIN];
+#pragma unroll
+    for (int t = 0; t < END - BEGIN; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    float db3[2][8], db2[2][8];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { db3[n][k] = 0.f; db2[n][k] = 0.f; }
+
+    struct Small {
+        float dreg[2][8], areg[8];      // dagg / a of this thread's Z3 / E1 chunks (raw)
+        float dscl;                     // agg_scale * dscale * 2^eG, or 0 for a padding receiver
+        uint32_t sw[2];                 // sign words of the Z3 chunks' lanes
+        unsigned int nbw;               // this receiver's neighbour word holding the block's sender (k-NN graphs)
+        float4 cv[2];                   // c_j of the E1 chunk
+    };
+    struct Big { f16x8 eh[2], zh[2]; };   // parked E2 / dZ2 pieces
+    Small S;
+    Big B0;
+#if MPG_DW8_SETS == 2
+    Big B1;
+#else
+    Big& B1 = B0;   // ONE set of parked pieces, requested one block ahead (two sets -- 16 more registers -- made the kernel spill)
+#endif
+    const int eG = dw_launch_exp(p);
+    const float unitG = __builtin_bit_cast(float, (uint32_t)(eG + 127) << 23);   // 2^eG (|eG| <= 100)
+    int eslot = eG;
+    {
+        const int t = blk0 + lane;
+        if (t < blk1) eslot = p.gexp[dw_block(t, R) / p.N];
+    }
+    asm volatile("" : "+v"(eslot));
+    int sblk, sj, sb, srb;
+    {
+        const int t = min(blk0 + lane, max(blk1 - 1, blk0));
+        sblk = dw_block(t, R);
+        const int brb = sblk / p.N;
+        sj = sblk - brb * p.N;
+        sb = brb / RB;
+        srb = brb - sb * RB;
+    }
+    asm volatile("" : "+v"(sblk), "+v"(sj), "+v"(sb), "+v"(srb));
+    struct Idx { int blk, j, b, rb; };
+    auto idx_of = [&](int slot) {
+        const int l = slot - blk0;
+        return Idx{__builtin_amdgcn_readlane(sblk, l), __builtin_amdgcn_readlane(sj, l), __builtin_amdgcn_readlane(sb, l),
+                   __builtin_amdgcn_readlane(srb, l)};
+    };
+    // p = 1/2: lane q of a quad of adjacent lanes hashes one of the quad's keep words -- dZ3 tiles 4n + q (quad lane 0..3 <-> the four
+    // tiles tq = 0..3 do NOT sit in one quad here: a quad shares tq) -- so every thread hashes its own three words
+    uint32_t hc3[2] = {0u, 0u}, hc1 = 0u;
+    if constexpr (DROP == 2) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) hc3[n] = (DROP_BIT_GRP + (uint32_t)m3[n] + (p.tag_base + TAG_E2) * 0x10001u) * 0x85EBCA77u + seed_hi;
+        hc1 = (DROP_BIT_GRP + (uint32_t)te1 + (p.tag_base + TAG_E0) * 0x10001u) * 0x85EBCA77u + seed_hi;
+    }
+
+    const int nblk = p.B * RB * p.N;
+    const __amdgpu_buffer_rsrc_t rE = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.stageE2), 0, nblk * (NFR2 * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.stageZ2), 0, nblk * (NFR2 * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int*>(p.sign3), 0, nblk * (T3 * 32 * 4), 0x00020000);
+    const int ldac = p.ld_ac ? p.ld_ac : H1;
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.c), 0, p.B * p.N * ldac * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.B * p.N * ldac * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dagg), 0, p.B * p.N * p.ld_dagg * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rN = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int*>(p.nbr), 0, p.nbr ? p.B * p.N * ((p.N + 31) >> 5) * 4 : 0, 0x00020000);
+    // per-thread offsets are recomputed where they are used from OPAQUE copies of (r, cg): hoisted out of the block loop they are
+    // a dozen registers the allocator spills (and every scratch access drains the prefetch queue: vmcnt(0))
+    auto opq = [](int v) { asm volatile("" : "+v"(v)); return v; };
+    auto vo160 = [&](int n) {   // byte offset of piece n inside a 10 KiB block: chunk c of receiver r is piece c * 32 + r
+        const int rr = opq(r), cc_ = opq(cg), t = n == 0 ? (cc_ >> 2) : ((cc_ >> 2) == 0 ? 4 : (cc_ >> 2));
+        return ((4 * t + (cc_ & 3)) * 32 + rr) * 16;
+    };
+    auto voS_ = [&]() { return (32 * (opq(cg) & 1) + opq(r)) * 4; };
+    auto voE1_ = [&]() { const int cc_ = opq(cg); return (32 * min(cc_ >> 2, 2) + 16 * ((cc_ >> 1) & 1) + 4 * (cc_ & 1)) * 4; };
+    auto ldb4 = [&](__amdgpu_buffer_rsrc_t rs, int vo, int so) {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
+    };
+    auto load_d = [&](Small& P, const Idx& X) {
+        const int ii = X.rb * 32 + r;
+        const bool ok = ii < p.N;
+        P.dscl = ok ? p.agg_scale * p.dscale * unitG : 0.f;
+        const int cgo = opq(cg), f0o = 16 * ((cgo >> 1) & 1) + 4 * (cgo & 1);
+        const int rowD = (ok ? ii : 0) * p.ld_dagg * 4 + f0o * 4, soD = X.b * p.N * p.ld_dagg * 4;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int tqo = opq(cg) >> 2, mo = n == 0 ? tqo : (tqo < 2 ? tqo + 4 : tqo);
+            const float4 u = ldb4(rD, rowD + 128 * mo, soD), v = ldb4(rD, rowD + 128 * mo + 32, soD);
+            P.dreg[n][0] = u.x; P.dreg[n][1] = u.y; P.dreg[n][2] = u.z; P.dreg[n][3] = u.w;
+            P.dreg[n][4] = v.x; P.dreg[n][5] = v.y; P.dreg[n][6] = v.z; P.dreg[n][7] = v.w;
+        }
+    };
+    auto load_a = [&](Small& P, const Idx& X) {
+        const int ii = X.rb * 32 + r;
+        const bool ok = ii < p.N;
+        const int rowA = (ok ? ii : 0) * ldac * 4, soA = X.b * p.N * ldac * 4;
+        const int voE1 = voE1_();
+        const float4 u = ldb4(rA, rowA + voE1, soA), v = ldb4(rA, rowA + voE1 + 32, soA);
+        P.areg[0] = u.x; P.areg[1] = u.y; P.areg[2] = u.z; P.areg[3] = u.w;
+        P.areg[4] = v.x; P.areg[5] = v.y; P.areg[6] = v.z; P.areg[7] = v.w;
+    };
+    auto load_nb = [&](Small& P, const Idx& X) {
+        const int ii = X.rb * 32 + r;
+        P.nbw = __builtin_amdgcn_raw_buffer_load_b32(rN, ((X.b * p.N + (ii < p.N ? ii : 0)) * ((p.N + 31) >> 5) + (X.j >> 5)) * 4, 0, 0);
+    };
+    auto load_sw = [&](Small& P, const Idx& X) {   // word (tile >> 1) of lane (r, h)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int tqo = opq(cg) >> 2, mo = n == 0 ? tqo : (tqo < 2 ? tqo + 4 : tqo);
+            P.sw[n] = __builtin_amdgcn_raw_buffer_load_b32(rS, voS_() + (mo >> 1) * 256, X.blk * (T3 * 32 * 4), 0);
+        }
+    };
+    auto load_c = [&](Small& P, const Idx& X) {
+        const int so = (X.b * p.N + X.j) * ldac * 4;
+        const int voE1 = voE1_();
+        P.cv[0] = ldb4(rC, voE1, so); P.cv[1] = ldb4(rC, voE1 + 32, so);
+    };
+    auto load_e2 = [&](Big& P, int blk, int n) {
+        P.eh[n] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rE, vo160(n), blk * (NFR2 * 1024), 0));
+    };
+    auto load_z2 = [&](Big& P, int blk, int n) {
+        P.zh[n] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rZ, vo160(n), blk * (NFR2 * 1024), 0));
+    };
+    auto load_small = [&](Small& P, const Idx& X) { load_d(P, X); load_sw(P, X); load_nb(P, X); load_c(P, X); load_a(P, X); };
+    auto load_big = [&](Big& Q, int blk) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) { load_z2(Q, blk, n); load_e2(Q, blk, n); }
+    };
+
+    // build the block of slot `slot` into buffer `buf` (dw_builder's build, on this thread's pieces)
+    auto build = [&](int slot, char* buf, int pre1_slot, int pre2_slot, Big& Q) {
+        const Idx X = idx_of(slot), X1 = idx_of(pre1_slot);
+        const int blk = X.blk, pre2 = MPG_DW8_SETS == 2 ? __builtin_amdgcn_readlane(sblk, pre2_slot - blk0) : X1.blk;
+        const bool newrun = X1.b != X.b || X1.rb != X.rb;
+        const int cgb = opq(cg), tqb = cgb >> 2, cql = cgb & 3;
+        const int m3b[2] = {tqb, tqb < 2 ? tqb + 4 : tqb}, t160b[2] = {tqb, tqb == 0 ? 4 : tqb}, te1b = min(tqb, 2);
+        const int j = X.j, ii = X.rb * 32 + opq(r);
+        const uint32_t erow = (uint32_t)((X.b * p.N + ii) * p.N + j);
+        const int de = eG - __builtin_amdgcn_readlane(eslot, slot - blk0);
+        const float dth = dither_of((uint32_t)blk), rdth = __builtin_amdgcn_rcpf(dth);
+        const float funit = __builtin_bit_cast(float, (uint32_t)max(de + 127, 0) << 23) * rdth;
+        const _Float16 rch = (_Float16)rdth;
+        const float in_set = (p.nbr == nullptr || ((S.nbw >> (j & 31)) & 1u)) ? 1.f : 0.f;
+        const float dscl_1 = S.dscl * in_set * dth, dscl_a = dscl_1 * p.alpha;
+        uint32_t kz3[2] = {0xffu, 0xffu}, ke1 = 0xffu;
+        if constexpr (DROP == 2) {
+            const uint32_t x0 = (erow + seed_lo) * 0x9E3779B1u;
+            auto fin = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; };
+            auto bits = [&](uint32_t w) { w >>= f0; return (w & 0xfu) | ((w >> 4) & 0xf0u); };   // bits f0..f0+3 and f0+8..f0+11
+            kz3[0] = bits(fin(x0 ^ hc3[0]));
+            kz3[1] = bits(fin(x0 ^ hc3[1]));
+            ke1 = bits(fin(x0 ^ hc1));
+        } else if constexpr (DROP == 1) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n) kz3[n] = dw_chunk_keep<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, m3[n], f0, p.thr);
+            ke1 = dw_chunk_keep<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, te1, f0, p.thr);
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int m = m3b[n], c = 4 * m + cql;
+            float v[8];
+            const uint32_t keep = kz3[n];
+            const uint32_t swn = S.sw[n] << (16 * (m & 1) + 8 * cs);
+            const float take = (n == 0 || z3b) ? rdth : 0.f;   // (a repeated piece adds nothing to the bias sums)
+            static_for<0, 8>([&](auto kc) {
+                MPG_CI(k, kc);
+                float x = S.dreg[n][k] * sel_by_bit<31 - k>(swn, dscl_a, dscl_1);
+                if (DROP && !((keep >> k) & 1u)) x = 0.f;
+                v[k] = x;
+                db3[n][k] = fmaf(x, take, db3[n][k]);
+            });
+            const f16x8 hh = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3], (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
+            *reinterpret_cast<f16x8*>(buf + DW_Z3H + opq(r) * DW_RS3 + c * 16) = hh;
+        }
+        load_sw(S, X1); load_nb(S, X1); if (newrun) load_d(S, X1);
+        {
+            const int c = 4 * te1b + cql;
+            const float cc[8] = {S.cv[0].x, S.cv[0].y, S.cv[0].z, S.cv[0].w, S.cv[1].x, S.cv[1].y, S.cv[1].z, S.cv[1].w};
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float x = lrelu(S.areg[k] + cc[k], p.alpha) * funit;
+                if (DROP && !((ke1 >> k) & 1u)) x = 0.f;
+                v[k] = x;
+            }
+            const f16x8 hh = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3], (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
+            *reinterpret_cast<f16x8*>(buf + DW_E1H + opq(r) * DW_RS1 + c * 16) = hh;
+        }
+        load_c(S, X1); if (newrun) load_a(S, X1);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int c = 4 * t160b[n] + cql;
+            *reinterpret_cast<f16x8*>(buf + DW_Z2H + opq(r) * DW_RS2 + c * 16) = Q.zh[n];
+            const float take = (n == 0 || p160b) ? funit : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) db2[n][k] += take * (float)Q.zh[n][k];
+            load_z2(Q, pre2, n);
+        }
+        const f16x8 rc8 = {rch, rch, rch, rch, rch, rch, rch, rch};
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int c = 4 * t160b[n] + cql;
+            *reinterpret_cast<f16x8*>(buf + DW_E2H + opq(r) * DW_RS2 + c * 16) = Q.eh[n] * rc8;
+            load_e2(Q, pre2, n);
+        }
+    };
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    int cur = dw_next_valid(vbits, blk0, blk0, blk1), it = 0;
+    int n1 = dw_next_valid(vbits, blk0, cur + 1, blk1), n2 = dw_next_valid(vbits, blk0, n1 + 1, blk1);
+    if (cur < blk1) {
+        load_small(S, idx_of(cur));
+        load_big(B0, idx_of(cur).blk);
+#if MPG_DW8_SETS == 2
+        load_big(B1, idx_of(min(n1, blk1 - 1)).blk);
+#endif
+        build(cur, smem, min(n1, blk1 - 1), min(n2, blk1 - 1), B0);
+    }
+    lds_barrier();
+#ifdef MPG_DWSTAMP
+    unsigned long long dw_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dw_t = __builtin_amdgcn_s_memtime();
+#endif
+    while (cur < blk1) {
+        {   // odd blocks: parked pieces from set 1
+            const int n3 = dw_next_valid(vbits, blk0, n2 + 1, blk1);
+            if (n1 < blk1) build(n1, smem + ((it + 1) & 1) * DW_BUF, min(n2, blk1 - 1), min(n3, blk1 - 1), B1);
+            DW_STAMP(0);
+            dw8_consume<BEGIN, END>(acc, lds0 + (it & 1) * DW_BUF, lane);
+            DW_STAMP(1);
+            lds_barrier();
+            DW_STAMP(2);
+            cur = n1; n1 = n2; n2 = n3; ++it;
+        }
+        if (!(cur < blk1)) break;
+        {   // even blocks: set 0
+            const int n3 = dw_next_valid(vbits, blk0, n2 + 1, blk1);
+            if (n1 < blk1) build(n1, smem + ((it + 1) & 1) * DW_BUF, min(n2, blk1 - 1), min(n3, blk1 - 1), B0);
+            DW_STAMP(0);
+            dw8_consume<BEGIN, END>(acc, lds0 + (it & 1) * DW_BUF, lane);
+            DW_STAMP(1);
+            lds_barrier();
+            DW_STAMP(2);
+            cur = n1; n1 = n2; n2 = n3; ++it;
+        }
+    }
+#ifdef MPG_DWSTAMP
+    if (blockIdx.x < 32 && lane == 0) {
+        dw_acc[6] = (unsigned long long)it;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) g_dw_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + q] = dw_acc[q];
+    }
+#endif
+    float* part = p.part + (size_t)blockIdx.x * (H3 * H2 + H2 * H1 + H3 + H2);
+    dw8_store<BEGIN, END>(acc, part, part + H3 * H2, lane);
+    // bias sums: add the 32 receivers of a chunk group -- 16 in this wave (lane bits 2..5), 16 in its neighbour wave (through
+    // LDS: the images are dead behind the loop's last barrier); fragment-order index fi = 8 c + k
+    float* red = reinterpret_cast<float*>(smem);   // [wave 0..7][lane & 3][n][k][db3 | db2]
+    const int bw = bt >> 6, bl = bt & 3;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float x = db3[n][k], y = db2[n][k];
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) { x += __shfl_xor(x, o, 64); y += __shfl_xor(y, o, 64); }
+            if (lane < 4) {
+                red[(((bw * 4 + bl) * 2 + n) * 8 + k) * 2 + 0] = x;
+                red[(((bw * 4 + bl) * 2 + n) * 8 + k) * 2 + 1] = y;
+            }
+        }
+    lds_barrier();
+    float* pb3 = part + H3 * H2 + H2 * H1, *pb2 = pb3 + H3;
+    if (r == 0) {   // lanes 0..3 of the even waves: their own 16 receivers + those of the odd neighbour
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i0 = (((bw * 4 + bl) * 2 + n) * 8 + k) * 2, i1 = ((((bw + 1) * 4 + bl) * 2 + n) * 8 + k) * 2;
+                if (n == 0 || z3b) pb3[8 * (4 * m3[n] + (cg & 3)) + k] = red[i0] + red[i1];
+                if (n == 0 || p160b) pb2[8 * (4 * t160[n] + (cg & 3)) + k] = red[i0 + 1] + red[i1 + 1];
+            }
+    }
+}
+
+template <int DROP>
+__global__ __launch_bounds__(512, 1) void edge_dw8_kernel(const MpgEdgeDw p, const int R) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int RB = (p.N + 31) / 32;
+    const int nruns = p.B * RB * p.N / R;
+    const int blk0 = 0, blk1 = R * ((nruns - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);   // slots of this workgroup
+    const unsigned long long vbits = dw_valid_bits(p, R, blk0, blk1);
+    if (w == 0) dw8_wave<DROP, 0, 6>(p, R, smem, blk0, blk1, vbits);
+    else if (w == 1) dw8_wave<DROP, 6, 12>(p, R, smem, blk0, blk1, vbits);
+    else if (w == 2) dw8_wave<DROP, 12, 18>(p, R, smem, blk0, blk1, vbits);
+    else if (w == 3) dw8_wave<DROP, 18, 24>(p, R, smem, blk0, blk1, vbits);
+    else if (w == 4) dw8_wave<DROP, 24, 30>(p, R, smem, blk0, blk1, vbits);
+    else if (w == 5) dw8_wave<DROP, 30, 35>(p, R, smem, blk0, blk1, vbits);
+    else if (w == 6) dw8_wave<DROP, 35, 40>(p, R, smem, blk0, blk1, vbits);
+    else dw8_wave<DROP, 40, 45>(p, R, smem, blk0, blk1, vbits);
+}
+
+#endif   // MPG_DW8
+
 template <int DROP, int NQ>
 __global__ __launch_bounds__(512, 1) void edge_dw_kernel(const MpgEdgeDw p, const int R) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -710,11 +1128,25 @@ extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(p->nwg), block(512);
     const int dm = p->thr == 0 ? 0 : (p->thr == 128 ? 2 : 1);
+#ifdef MPG_DW8   // (experiment build: MPG_DW_FORM=uniform picks the uniform kernel)
+    static const bool uniform = [] { const char* e = getenv("MPG_DW_FORM"); return e != nullptr && strcmp(e, "uniform") == 0; }();
+#define MPG_DW_ONE(D)                                                                                             \
+    do {                                                                                                          \
+        if (uniform) {                                                                                            \
+            MPG_ENSURE_LDS((edge_dw8_kernel<D>), DW_LDS_BYTES);                                                   \
+            hipLaunchKernelGGL((edge_dw8_kernel<D>), grid, block, DW_LDS_BYTES, st, *p, R);                       \
+        } else {                                                                                                  \
+            MPG_ENSURE_LDS((edge_dw_kernel<D, 0>), DW_LDS_BYTES);                                                 \
+            hipLaunchKernelGGL((edge_dw_kernel<D, 0>), grid, block, DW_LDS_BYTES, st, *p, R);                     \
+        }                                                                                                         \
+    } while (0)
+#else
 #define MPG_DW_ONE(D)                                                                                             \
     do {                                                                                                          \
         MPG_ENSURE_LDS((edge_dw_kernel<D, 0>), DW_LDS_BYTES);                                                     \
         hipLaunchKernelGGL((edge_dw_kernel<D, 0>), grid, block, DW_LDS_BYTES, st, *p, R);                         \
     } while (0)
+#endif
 #ifdef MPG_SINGLE_VARIANT  // tools/ubench/dw_bench.hip: one instantiation
     MPG_DW_ONE(MPG_SINGLE_VARIANT);
 #else

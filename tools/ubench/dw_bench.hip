@@ -1,9 +1,12 @@
 // Stand-alone timing of edge_dw_kernel<DROP> at N=30 on random data (no torch):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I include -DMPG_SINGLE_VARIANT=<0|2> [-DMPG_DW_EXP=n] tools/ubench/dw_bench.hip -o dw_bench
 //   dw_bench [B=256] [ragged]
+//   -DMPG_DW8: also compiles the uniform eight-wave form (every wave builds and multiplies; measured slower, see edge_dw.hip);
+//   MPG_DW_FORM=uniform in the environment picks it -- the checksums of both forms must agree bit for bit
 #include "../../mpgan_amd/csrc/edge_dw.hip"
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 256, N = 30, RB = 1, nblk = B * RB * N;
@@ -43,7 +46,10 @@ int main(int argc, char** argv) {
     {
         std::vector<unsigned long long> st(64 * 4 * 8);
         hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_dw_stamps), st.size() * 8);
-        const char* nm[6] = {"setup(+barrier before)", "dZ3", "requests+E1", "requests+dZ2", "E2", "barrier wait"};
+        const bool uni = getenv("MPG_DW_FORM") && !strcmp(getenv("MPG_DW_FORM"), "uniform");
+        const char* nmr[6] = {"setup(+barrier before)", "dZ3", "requests+E1", "requests+dZ2", "E2", "barrier wait"};
+        const char* nmu[6] = {"build", "consume", "barrier wait", "-", "-", "-"};
+        const char** nm = uni ? nmu : nmr;
         double tot[8] = {0};
         for (int w = 0; w < 64 * 4; ++w) for (int q = 0; q < 8; ++q) tot[q] += (double)st[w * 8 + q];
         const double nb = tot[6] > 0 ? tot[6] : 1;
@@ -51,7 +57,16 @@ int main(int argc, char** argv) {
         for (int q = 0; q < 6; ++q) printf("  %-24s %8.1f\n", nm[q], tot[q] / nb);
     }
 #endif
-    printf("edge_dw<%d> (+reduce) B=%d N=%d%s nwg=%d: %.1f us/launch   dW3[0..3] = %g %g %g %g\n", MPG_SINGLE_VARIANT, B, N,
+    {   // the outputs and the per-workgroup partials as checksums: the two forms of the kernel (MPG_DW_FORM=roles | uniform) must agree bit for bit
+        auto cks = [](const void* dev, size_t n) {
+            std::vector<unsigned int> hh(n / 4); hipMemcpy(hh.data(), dev, n, hipMemcpyDeviceToHost);
+            unsigned long long s_ = 0; for (size_t i = 0; i < hh.size(); ++i) s_ = s_ * 1099511628211ull + hh[i];
+            return s_;
+        };
+        printf("  checksums dW3 %016llx dW2 %016llx db3 %016llx db2 %016llx\n", cks(dW3, 192 * 160 * 4), cks(dW2, 160 * 96 * 4), cks(db3, 192 * 4), cks(db2, 160 * 4));
+    }
+    printf("edge_dw<%d> (+reduce) %s B=%d N=%d%s nwg=%d: %.1f us/launch   dW3[0..3] = %g %g %g %g\n", MPG_SINGLE_VARIANT,
+           getenv("MPG_DW_FORM") ? getenv("MPG_DW_FORM") : "roles", B, N,
            argc > 2 ? " ragged" : "", nwg, ms * 1e3 / R, h[0], h[1], h[2], h[3]);
     return 0;
 }
