@@ -144,7 +144,9 @@ int mpg_chain(const MpgChain* p, void* stream);
  * so that fe.net.0 applied to [x_i ; x_j] is a_i + c_j exactly.  Output
  *   agg[b,i,:] = agg_scale * sum_j mask[b,j] * fe([x_i ; x_j])        ([B,N,192], agg_scale = 1 | 1/N)
  * With SC > 1 the senders are split over SC workgroups and agg has a leading [SC] axis of partial
- * sums the caller adds up. */
+ * sums the caller adds up (mpg_edge_fwd_fn with `tickets` adds them up itself: the last workgroup to arrive for a
+ * (jet, receiver block) reads the SC slabs in chunk order -- a fixed order, whoever arrives last --, leaves the
+ * total in slab 0 and runs the epilogue). */
 typedef struct MpgEdgeFwd {
     const float* a; const float* c;       /* [B*N, 96], row stride ld_ac (0 = 96)             */
     int ld_ac;
@@ -170,6 +172,9 @@ typedef struct MpgEdgeFwd {
      * the caller's: a norm of a coordinate difference, a gather from a [B] table. */
     const float* es; const float* wq;
     const int* order;                     /* optional [B]: workgroup g works on jet order[g] (mpg_jet_order); NULL = in index order */
+    unsigned int* tickets;                /* mpg_edge_fwd_fn with SC > 1: [B*RB] arrival counters, ZERO on entry and left zero (the
+                                             workgroup of a (jet, receiver block) that arrives last adds up the SC partial slabs);
+                                             NULL = the epilogue form takes whole jets only (SC = 1) */
 } MpgEdgeFwd;
 #define MPG_EDGE_SCALARS 2
 int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream);

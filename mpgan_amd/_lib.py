@@ -48,7 +48,7 @@ class MpgEdgeFwd(C.Structure):
         ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
         ("skip_masked", C.c_int), ("f16", C.c_int),
         ("sign3", _fp), ("nbr", _fp), ("stageE2", _fp),
-        ("es", _fp), ("wq", _fp), ("order", _fp),
+        ("es", _fp), ("wq", _fp), ("order", _fp), ("tickets", _fp),
     ]
 
 

@@ -403,6 +403,58 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
         static_assert(F2_FN_BIAS + C2_BIAS * 4 <= F2_LDS_BYTES, "fn's buffers must fit the edge kernel's LDS");
         const MpgChain& c = *cp;
         const int m0 = b * p.N + rb * 32, nrows = min(32, p.N - rb * 32);
+        if (p.SC > 1) {
+            // ---- sender chunks: this workgroup holds ONE of the SC partial sums of its (jet, receiver block).  It publishes its
+            //      slab, draws a ticket, and the workgroup that draws the last one adds the slabs up IN CHUNK ORDER (the same sum
+            //      whoever is last), leaves the total in slab 0 (the backward's agg) and goes on to the epilogue; the others are done.
+            // Hand-off as MI355X_MICROARCH.md prices it (inter-workgroup visibility, the sc1 row of its table): every byte of the slab
+            // goes out by a 16-byte sc1 (write-through) store, every storing wave waits for its stores (vmcnt(0)) in front of the
+            // workgroup's barrier, ONE lane adds to the (jet, receiver block)'s counter with an agent-scope atomic, the workgroup whose
+            // add came last -- told by the value returned -- reads every slab by 16-byte sc1 loads (they bypass this CU's L1) behind a
+            // barrier.  (The textbook form -- plain stores, agent-scope release, acquire -- made every workgroup write back its XCD's
+            // whole L2, with 59 MB of freshly parked E2 in it: the N = 150 iteration went from 2.6 to 4.5 ms.)
+            const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc(p.agg, 0, p.SC * p.B * p.N * (H3 * 4), 0x00020000);
+            constexpr int SC1 = 16;   // cache-policy bit of the buffer instructions: sc1
+            const int slab0 = (sc * p.B + b) * p.N * (H3 * 4);
+            for (int u = tid; u < T3 * 4 * 64; u += 512) {
+                const int ln = u & 63, mg = u >> 6, m = mg >> 2, g = mg & 3;
+                f2_u32x4 v;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int e = (m * 16 + 4 * g + t) * 64 + ln;
+                    v[t] = __builtin_bit_cast(uint32_t, (red[e] + red[e + T3 * 1024] + red[e + 2 * T3 * 1024] + red[e + 3 * T3 * 1024]) * p.agg_scale);
+                }
+                const int ii = rb * 32 + (ln & 31);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsl, ii < p.N ? slab0 + (ii * H3 + 32 * m + 8 * g + 4 * (ln >> 5)) * 4 : -1, 0, SC1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                unsigned int* tk = p.tickets + (b * RB + rb);
+                const unsigned int old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool last = old == (unsigned int)(p.SC - 1);
+                if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (zero again for the next launch)
+                *lnv = last ? 1 : 0;   // (the list's count: dead behind the sender loop)
+            }
+            __syncthreads();
+            if (*lnv == 0) return;
+            for (int u = tid; u < T3 * 4 * 64; u += 512) {
+                const int ln = u & 63, mg = u >> 6, m = mg >> 2, g = mg & 3;
+                const int ii = rb * 32 + (ln & 31);
+                const int off = ii < p.N ? (ii * H3 + 32 * m + 8 * g + 4 * (ln >> 5)) * 4 : -1;   // (out of range: zeros)
+                f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < p.SC; ++q)   // in chunk order: the same sum whichever workgroup arrived last
+                    tot += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsl, off >= 0 ? (q * p.B + b) * p.N * (H3 * 4) + off : -1, 0, SC1));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int e = (m * 16 + 4 * g + t) * 64 + ln;
+                    red[e] = tot[t];
+                    red[e + T3 * 1024] = 0.f; red[e + 2 * T3 * 1024] = 0.f; red[e + 3 * T3 * 1024] = 0.f;
+                }
+            }
+            __syncthreads();
+        }
+        const float red_scale = p.SC > 1 ? 1.f : p.agg_scale;   // (the chunks' slabs carry agg_scale already)
         using I0 = std::integral_constant<int, 0>;
         auto stage = [&](auto&& first_tile, auto&& bias_request, auto&& bias_store, const uint32_t, const uint32_t, const float ascale) {
             first_tile(I0{});   // (every register of the sender loop is free: the wave's weight tile is on its way during the staging)
@@ -419,7 +471,7 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
                     for (int j = 0; j < 8; ++j) {
                         const int e = (mm * 16 + 8 * s2 + j) * 64 + lane;
                         const float sum = red[e] + red[e + T3 * 1024] + red[e + 2 * T3 * 1024] + red[e + 3 * T3 * 1024];
-                        av8[j] = sum * p.agg_scale;
+                        av8[j] = sum * red_scale;
                         v[j] = av8[j] * ascale;
                     }
 #pragma unroll
@@ -519,7 +571,7 @@ inline bool fwd_fn_eight_waves() {
 template <int D, bool SIGN>
 int f1_launch_fn(const MpgEdgeFwd* p, const MpgChain* c, const MpgChain* c2, bool sl, hipStream_t st) {
     const int RB = (p->N + 31) / 32;
-    dim3 grid(p->B * RB), block(512);
+    dim3 grid(p->B * RB * p->SC), block(512);
     MpgChain none = {};   // nlayers = 0: no second chain
     if (c2 == nullptr) c2 = &none;
     if (sl) {

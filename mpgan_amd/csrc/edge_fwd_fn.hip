@@ -16,7 +16,10 @@ extern "C" int mpg_edge_fwd_fn(const MpgEdgeFwd* p, const MpgChain* c, const Mpg
     if (!p->f16 || !c->f16) return -8;
     if (p->stageE2 != nullptr && (long long)p->B * ((p->N + 31) / 32) * p->N * 10240LL > 0x7fffffffLL) return -7;
     // what the epilogue form covers -- anything else: MPG_FN_NA, and the caller runs mpg_edge_fwd + mpg_chain
-    if (p->SC != 1 || p->N > 160 || p->es != nullptr) return MPG_FN_NA;
+    // (sender chunks: only with arrival counters -- the last workgroup of a (jet, receiver block) adds the chunks up -- and
+    // only in the eight-wave form: the per-mode units answer MPG_FN_NA otherwise)
+    if (p->SC < 1 || (p->SC != 1 && p->tickets == nullptr) || p->N > 160 * p->SC || p->es != nullptr) return MPG_FN_NA;
+    if ((p->N + p->SC - 1) / p->SC > 160) return MPG_FN_NA;
     if (c->nlayers != 3 || c->M != p->B * p->N || c->A2 == nullptr || c->in_thr != 0 || c->in_out != nullptr || c->seed != p->seed) return MPG_FN_NA;
     const int K = c->L[0].K;
     if (c->K1 != 192 || K < 192 || K > 224 || c->lda2 < K - 192 || c->L[1].K != c->L[0].N || c->L[2].K != c->L[1].N) return MPG_FN_NA;

@@ -39,6 +39,10 @@ OPTIONS = {
     # ... and, in the backward, the layer's dx chain and the layer-below's node-network input-gradient chain as the epilogue of the
     # data-gradient kernel (mpg_edge_bwd_fn: one launch instead of three); False = mpg_edge_bwd followed by the mpg_chain calls
     "bwd_epilogue": os.environ.get("MPG_BWD_EPILOGUE", "1") != "0",
+    # sender-chunked launches (N > 32 on few jets: SC > 1) keep the node network as the edge forward's epilogue too: the workgroup of
+    # a (jet, receiver block) that arrives LAST adds up the chunks' partial sums (mpg_edge_fwd_fn with MpgEdgeFwd.tickets); False =
+    # mpg_edge_fwd, a sum over the chunk axis and the mpg_chain calls
+    "fn_chunks": os.environ.get("MPG_FN_CHUNKS", "1") != "0",
 }
 NUM_CUS = 256
 # Forward products (they decide LeakyReLU signs) are split as fp16 hi/lo with the operand scales below (~2^-21 per
@@ -220,6 +224,24 @@ def edge_waves(fwd: int = 0, bwd: int = 0):
     prev = (L.mpg_edge_waves_get(0), L.mpg_edge_waves_get(1))
     check(L.mpg_edge_waves(int(fwd), int(bwd)), "mpg_edge_waves")
     return prev
+
+
+TICKET_SLOTS = 32
+
+
+def _tickets(device, n: int) -> torch.Tensor:
+    """Arrival counters for ONE launch whose workgroups hand a reduction to the last arriver: ``n`` zeros that the launch leaves
+    zero.  Every call gets the next of ``TICKET_SLOTS`` regions of a per-device buffer: launches that run side by side on two
+    streams (the generator-ahead branch beside the D step's own generator call) must not count on the same words, and a
+    captured launch keeps the region it was given."""
+    st = dev_state(device)
+    buf = getattr(st, "_tickets", None)
+    per = max(4096, n)
+    if buf is None or buf.shape[1] < per:
+        buf = torch.zeros((TICKET_SLOTS, per), dtype=torch.int32, device=device)
+        st._tickets, st._ticket_i = buf, 0
+    st._ticket_i = (st._ticket_i + 1) % TICKET_SLOTS
+    return buf[st._ticket_i]
 
 
 def _stream():
@@ -732,8 +754,10 @@ class FusedMPLayerFn(torch.autograd.Function):
                      dict(img=pk.ptr("V3"), K=n2, N=out_f, bias=c3, act=False, drop=dr(TAG_N2), out=y, wscale=SC_WN)]
         fn_kw = dict(A2=xf2, lda2=xf2.stride(0), alpha=alpha, seed_t=seed_t, f16=f16, ascale=SC_ACT)
         rc = _lib.MPG_FN_NA
-        if OPTIONS["fn_epilogue"] and SC == 1 and es is None:
-            if not need_grad:
+        if OPTIONS["fn_epilogue"] and es is None and (SC == 1 or OPTIONS["fn_chunks"]):
+            if SC > 1:
+                e.tickets = _p(_tickets(dev, B * RB))   # arrival counters of the (jet, receiver block)s: zero, and left zero
+            if not need_grad and SC == 1:   # (with sender chunks the partial sums travel through the slabs of agg)
                 e.agg = None
             cs = chain_struct(V, fn_layers, A=aggp, lda=H3, K1=H3, **fn_kw)
             cs2 = ac_next = None
@@ -748,13 +772,15 @@ class FusedMPLayerFn(torch.autograd.Function):
             rc = _lib.lib().mpg_edge_fwd_fn(C.byref(e), C.byref(cs), None if cs2 is None else C.byref(cs2), _stream())
             if rc != _lib.MPG_FN_NA:
                 check(rc, "mpg_edge_fwd_fn")
-                agg = aggp[0] if need_grad else None
+                agg = aggp[0] if need_grad else None   # (SC > 1: the last workgroup to arrive left the chunks' total in slab 0)
                 if cs2 is not None:
                     handoff.ac_out = (ac_next, pk_n, y.data_ptr(), pk_n._key)
         if rc == _lib.MPG_FN_NA:
             e.agg = _p(aggp)
             check(_lib.lib().mpg_edge_fwd(C.byref(e), _stream()), "mpg_edge_fwd")
-            agg = aggp[0] if SC == 1 else aggp.sum(0)
+            agg = aggp[0]
+            for q in range(1, SC):   # (in chunk order, slab by slab: the order the epilogue form's last arriver takes -- the two routes
+                agg = agg + aggp[q]  #  then agree bit for bit; torch.sum over the chunk axis adds in another order)
             chain(V, fn_layers, A=agg, lda=H3, K1=H3, **fn_kw)
         ctx.packed = pk
         ctx.prev_node = handoff.prev_node if (handoff is not None and need_grad) else None

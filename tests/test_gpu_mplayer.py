@@ -776,7 +776,10 @@ def test_jet_order_and_heaviest_first_launches_change_no_result():
     (4, 30, 32, 3, 0.0, True, True),      # G's last layer: rows of 3 floats (element stores)
     (3, 33, 32, 32, 0.0, True, True),     # two receiver blocks, the second with one receiver
     (6, 30, 32, 32, 0.0, False, False),   # no mask, no gradient (nothing kept for a backward)
-    (2, 150, 32, 32, 0.0, True, True),    # N = 150: several sender chunks -- outside the epilogue form, both calls take two launches
+    (2, 150, 32, 32, 0.0, True, True),    # N = 150: several sender chunks -- the workgroup that arrives last for a (jet, receiver
+                                          # block) adds the chunks up and runs the epilogue (eight-wave form); backward: separate launches
+    (3, 150, 32, 32, 0.5, True, True),
+    (2, 100, 3, 32, 0.0, True, False),
 ])
 @pytest.mark.parametrize("waves", [8, 4])
 def test_node_network_as_edge_epilogue_is_bit_identical(B, N, F, out, p_drop, use_mask, train, waves):
@@ -841,7 +844,9 @@ def test_node_network_as_edge_epilogue_is_bit_identical(B, N, F, out, p_drop, us
         ops.OPTIONS["fn_epilogue"], ops.OPTIONS["bwd_epilogue"] = saved_opts
         os.environ.pop("MPG_FORCE_SC", None)
         calls.restore()
-    want = ["mpg_chain", "mpg_edge_fwd_fn"] if N <= 64 else ["mpg_chain", "mpg_edge_fwd", "mpg_chain"]
+    # (sender chunks in the four-wave form: outside the epilogue form -- mpg_edge_fwd_fn answers MPG_FN_NA without launching -- both
+    # calls take the separate launches)
+    want = ["mpg_chain", "mpg_edge_fwd_fn"] if (N <= 64 or waves == 8) else ["mpg_chain", "mpg_edge_fwd_fn", "mpg_edge_fwd", "mpg_chain"]
     names = [k for k in calls.names if k != "mpg_pack_many"]   # (the first call builds the weight images)
     assert names[:len(want)] == want, names[:4]
     if train:   # ... and the backward: the dx chain as the epilogue of the data-gradient kernel (a whole jet per workgroup: N <= 32)
