@@ -28,6 +28,19 @@ __device__ unsigned long long f1_stamps[4096 * 8 * 8];
 
 namespace {
 
+// W2 streams from L2 through the CU's L1 (64 B/clk): 60 KiB per sender, and the eight waves of a workgroup walk layer 2 in lock step
+// (a round's layer 2 took 7.9k clk for 90 MFMAs per wave: 480 KiB through 64 B/clk).  The LDS left over beside W3 holds 21 of
+// W2's 60 fragments -- the hi halves of tiles 0..2 for every k-step and of tile 3 for k-steps 0..2 -- and those are read from there.
+constexpr int F1_W2L_OFF = F2_LDS_BYTES, F1_W2L_N = 21;
+constexpr int F1_LDS_BYTES = F1_W2L_OFF + F1_W2L_N * 1024;
+static_assert(F1_LDS_BYTES <= 163840, "LDS plan exceeds 160 KiB");
+#ifdef MPG_F1_NO_W2L   // (experiment: everything of W2 streamed)
+constexpr bool f1_w2_in_lds(int, int) { return false; }
+#else
+constexpr bool f1_w2_in_lds(int m, int k) { return m < 3 || (m == 3 && k < 3); }
+#endif
+constexpr int f1_w2_slot(int m, int k) { return m < 3 ? m * (T1 * 2) + k : 3 * (T1 * 2) + k; }
+
 constexpr int F1_NW = 8;
 static_assert(F1_NW * H1 * 4 == F2_C_BYTES, "one row of c per wave in the four-wave kernel's two-rows-per-wave area");
 
@@ -85,6 +98,11 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
         av[u] = ld4(p.a + (size_t)(b * p.N + ii) * ldac + 8 * qsu + 4 * hh);
     }
     fill_lds_dma8(l3, g3, 2 * NF3 * 1024, tid);
+    for (int c = w; c < F1_W2L_N; c += F1_NW) {   // W2's resident fragments: slot c <- fragment (tile m, k-step k) of the hi image
+        const int m = c < 3 * (T1 * 2) ? c / (T1 * 2) : 3, k = c - m * (T1 * 2);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(p.W2img) + (m * (T1 * 2) + k) * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(smem + F1_W2L_OFF + c * 1024), 16, 0, 0);
+    }
     if constexpr (NQ > 0)
         for (int t = tid; t < NQ * H1; t += 512) reinterpret_cast<float*>(smem + F2_Q_OFF)[t] = p.wq[t] * SC_A;
     if (tid < H2 + H3) lb2[tid] = bv * (tid < H2 ? SC_E2 : SC_E3);
@@ -129,6 +147,7 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
     // (the bias columns through one opaque base + immediate offsets: plain pointer arithmetic makes the compiler keep one
     // address register per 16-byte group, hoisted out of the sender loop -- 44 registers this kernel does not have)
     const uint32_t lbb = lds_base(smem, F2_W_BYTES + F2_A_BYTES + 16 * h);
+    const uint32_t lbw2 = lds_base(smem, F1_W2L_OFF + lane16);
 
     const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(p.sign3, 0, SIGN ? p.B * RB * p.N * (T3 * 32 * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(p.stageE2, 0, (SIGN && p.stageE2 != nullptr) ? p.B * RB * p.N * (NFR2 * 1024) : 0, 0x00020000);
@@ -194,8 +213,17 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
             f32x4 q4[NQ > 0 ? NQ : 1][2];
             auto load_w = [&](auto kc, auto mc) {
                 MPG_CI(k, kc); MPG_CI(m, mc);
-                wh[m] = img_frag<V>(r2, lane16, m * KS + k);
+                // (a resident hi fragment is read from LDS one TILE ahead, load_wl below: a whole k-step ahead it would sit in
+                // registers for ~1k clk -- twelve the dropout variants do not have)
+                if constexpr (!f1_w2_in_lds(m, k)) wh[m] = img_frag<V>(r2, lane16, m * KS + k);
                 wl[m] = img_frag<V>(r2, lane16, NF2 + m * KS + k);
+            };
+            V whl[2];   // resident hi fragments: [tile parity], the next tile's requested in front of this tile's MFMAs
+            auto load_wl = [&](auto kc, auto mc) {
+                MPG_CI(k, kc); MPG_CI(m, mc);
+                if constexpr (k < KS && m < T2) {
+                    if constexpr (f1_w2_in_lds(m, k)) whl[m & 1] = lds_frag<V>(lbw2, f1_w2_slot(m, k) * 1024);
+                }
             };
             auto load_a = [&](auto kc) {
                 MPG_CI(k, kc);
@@ -231,6 +259,7 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
             };
             using K0 = std::integral_constant<int, 0>;
             static_for<0, T2>([&](auto mc) { load_w(K0{}, mc); });
+            load_wl(K0{}, K0{});
             load_a(K0{});
             static_for<0, 16>([&](auto uc) { buildA(K0{}, uc); });
 #pragma unroll
@@ -251,7 +280,12 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
                         if constexpr (k + 1 < KS) f2_slot<16, 13, SL - 2>([&](auto uc) { buildA(std::integral_constant<int, k + 1>{}, uc); });
                         __builtin_amdgcn_sched_barrier(0);
                     };
-                    const V a_h = wh[m], a_l = wl[m];
+                    // next tile's resident fragment (the first tile of the next k-step behind the last tile)
+                    if constexpr (m + 1 < T2) load_wl(kc, std::integral_constant<int, m + 1>{});
+                    else load_wl(std::integral_constant<int, k + 1>{}, std::integral_constant<int, 0>{});
+                    V a_h;
+                    if constexpr (f1_w2_in_lds(m, k)) a_h = whl[m & 1]; else a_h = wh[m];
+                    const V a_l = wl[m];
                     acc[m] = f2_mma(a_l, bh0, acc[m]); slot(std::integral_constant<int, 3 * m + 0>{});
                     acc[m] = f2_mma(a_h, bl0, acc[m]); slot(std::integral_constant<int, 3 * m + 1>{});
                     acc[m] = f2_mma(a_h, bh0, acc[m]);
@@ -539,11 +573,11 @@ int f1_launch(const MpgEdgeFwd* p, hipStream_t st) {
     const int RB = (p->N + 31) / 32;
     dim3 grid(p->B * RB * p->SC), block(512);
     if (p->sign3 != nullptr) {
-        MPG_ENSURE_LDS((edge_fwd1_kernel<D, true, NQ>), F2_LDS_BYTES);
-        hipLaunchKernelGGL((edge_fwd1_kernel<D, true, NQ>), grid, block, F2_LDS_BYTES, st, *p);
+        MPG_ENSURE_LDS((edge_fwd1_kernel<D, true, NQ>), F1_LDS_BYTES);
+        hipLaunchKernelGGL((edge_fwd1_kernel<D, true, NQ>), grid, block, F1_LDS_BYTES, st, *p);
     } else {
-        MPG_ENSURE_LDS((edge_fwd1_kernel<D, false, NQ>), F2_LDS_BYTES);
-        hipLaunchKernelGGL((edge_fwd1_kernel<D, false, NQ>), grid, block, F2_LDS_BYTES, st, *p);
+        MPG_ENSURE_LDS((edge_fwd1_kernel<D, false, NQ>), F1_LDS_BYTES);
+        hipLaunchKernelGGL((edge_fwd1_kernel<D, false, NQ>), grid, block, F1_LDS_BYTES, st, *p);
     }
     return (int)hipGetLastError();
 }
@@ -575,11 +609,11 @@ int f1_launch_fn(const MpgEdgeFwd* p, const MpgChain* c, const MpgChain* c2, boo
     MpgChain none = {};   // nlayers = 0: no second chain
     if (c2 == nullptr) c2 = &none;
     if (sl) {
-        MPG_ENSURE_LDS((edge_fwd1_fn_kernel<D, SIGN, true>), F2_LDS_BYTES);
-        hipLaunchKernelGGL((edge_fwd1_fn_kernel<D, SIGN, true>), grid, block, F2_LDS_BYTES, st, *p, *c, *c2);
+        MPG_ENSURE_LDS((edge_fwd1_fn_kernel<D, SIGN, true>), F1_LDS_BYTES);
+        hipLaunchKernelGGL((edge_fwd1_fn_kernel<D, SIGN, true>), grid, block, F1_LDS_BYTES, st, *p, *c, *c2);
     } else {
-        MPG_ENSURE_LDS((edge_fwd1_fn_kernel<D, SIGN, false>), F2_LDS_BYTES);
-        hipLaunchKernelGGL((edge_fwd1_fn_kernel<D, SIGN, false>), grid, block, F2_LDS_BYTES, st, *p, *c, *c2);
+        MPG_ENSURE_LDS((edge_fwd1_fn_kernel<D, SIGN, false>), F1_LDS_BYTES);
+        hipLaunchKernelGGL((edge_fwd1_fn_kernel<D, SIGN, false>), grid, block, F1_LDS_BYTES, st, *p, *c, *c2);
     }
     return (int)hipGetLastError();
 }
