@@ -51,9 +51,9 @@ for l in pm.splitlines():
         vals[cur] = float(m.group(3))
 def kb(c, k): return vals.get((c, k), 0.0)
 def tot(k): return (2 * kb("FETCH_SIZE", k) + kb("WRITE_SIZE", k)) * 1024
-rows = [("edge_fwd_fn_kernel<0", "forward, no dropout"), ("edge_fwd_fn_kernel<2", "forward, p = 1/2"),
-        ("edge_bwd_fn_kernel<0, true", "backward + staging"), ("edge_bwd_fn_kernel<0, false", "backward, data path only"),
-        ("edge_bwd_fn_kernel<2, true", "backward + staging, p = 1/2"), ("edge_bwd_fn_kernel<2, false", "backward, data path, p = 1/2"),
+rows = [("edge_fwd1_fn_kernel<0", "forward, no dropout"), ("edge_fwd1_fn_kernel<2", "forward, p = 1/2"),
+        ("edge_bwd1_fn_kernel<0, true", "backward + staging"), ("edge_bwd1_fn_kernel<0, false", "backward, data path only"),
+        ("edge_bwd1_fn_kernel<2, true", "backward + staging, p = 1/2"), ("edge_bwd1_fn_kernel<2, false", "backward, data path, p = 1/2"),
         ("edge_dw_kernel<0", "weight gradients"), ("edge_dw_kernel<2", "weight gradients, p = 1/2"),
         ("chain2_kernel", "chained node layers (all uses)"), ("gemm_group_kernel", "grouped dense weight gradients")]
 txt = ("# HBM traffic of the fused kernels: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (one counter per pass, as\n"
@@ -73,16 +73,16 @@ def rate(sub, key):
     d = [v for k, v in dur.items() if sub in k]
     return tot(key) / d[0] / 1e12 if d else float("nan")
 txt += ("#\n# Achieved HBM rate at B=256 (bytes above / rocprof average duration in " + f"{tag}_bench_kernel_stats.csv" + "; HBM3E peak 8 TB/s):\n"
-        f"#   edge_fwd_fn_kernel<0, true>   {rate('edge_fwd_fn_kernel<0, true', 'edge_fwd_fn_kernel<0'):5.2f} TB/s  (compute bound: see the SQ counters)\n"
-        f"#   edge_bwd_fn_kernel<0, true>   {rate('edge_bwd_fn_kernel<0, true', 'edge_bwd_fn_kernel<0, true'):5.2f} TB/s\n"
+        f"#   edge_fwd1_fn_kernel<0, true>   {rate('edge_fwd1_fn_kernel<0, true', 'edge_fwd1_fn_kernel<0'):5.2f} TB/s  (compute bound: see the SQ counters)\n"
+        f"#   edge_bwd1_fn_kernel<0, true>   {rate('edge_bwd1_fn_kernel<0, true', 'edge_bwd1_fn_kernel<0, true'):5.2f} TB/s\n"
         f"#   edge_dw_kernel<0>          {rate('edge_dw_kernel<0', 'edge_dw_kernel<0'):5.2f} TB/s\n")
 txt += ("#\n# forward: a|c in, agg + sign words out (algorithmic 17.7 MB) + 10 KiB of fp16 E2 fragments per unmasked (jet, sender) block,\n"
         "# parked for the backward (which reads them for the LeakyReLU gate instead of recomputing the layer) and for mpg_edge_dw;\n"
         "# backward + staging: 10 KiB of fp16 dZ2 fragments per block; mpg_edge_dw reads both back and writes 256 per-workgroup\n"
         "# partial sums.\n#\n" + pm)
 open(os.path.join(P, f"{tag}_pmc_hbm_traffic.txt"), "w").write(txt)
-w, wo = tot("edge_bwd_fn_kernel<2, true"), tot("edge_bwd_fn_kernel<2, false")
-w0 = tot("edge_bwd_fn_kernel<0, true")
+w, wo = tot("edge_bwd1_fn_kernel<2, true"), tot("edge_bwd1_fn_kernel<2, false")
+w0 = tot("edge_bwd1_fn_kernel<0, true")
 traffic = {
     "note": f"bytes per launch from profiles/{tag}_pmc_hbm_traffic.txt (2 x FETCH_SIZE + WRITE_SIZE), B=256, N=30, the launches with their epilogue chains (node network / dx). edge_bwd_fn_kernel: "
             "launch-weighted mean over the 6 launches of one default bench step (2 at 2B = 512 jets with staging [D, p = 1/2], "
@@ -90,7 +90,7 @@ traffic = {
             "its 8 launches (2 at B without by-products, 2 at 512 jets and 4 at B with sign words + parked E2)",
     # forward: 2 launches at B without by-products for a backward (the generator in the D step: a|c in, agg out = 13.3 MB
     # algorithmic, not in the PMC workload), 2 at 2B and 4 at B with sign words and parked E2
-    "edge_fwd_fn_kernel": {"bytes_per_launch": int((2 * 13.3e6 + 2 * 2 * tot("edge_fwd_fn_kernel<2") + 4 * tot("edge_fwd_fn_kernel<0")) / 8)},
+    "edge_fwd_fn_kernel": {"bytes_per_launch": int((2 * 13.3e6 + 2 * 2 * tot("edge_fwd1_fn_kernel<2") + 4 * tot("edge_fwd1_fn_kernel<0")) / 8)},
     "edge_bwd_fn_kernel": {"bytes_per_launch": int((2 * 2 * w + 2 * wo + 2 * w0) / 6)},
     "edge_dw_kernel": {"bytes_per_launch": int(tot("edge_dw_kernel<2"))},
 }
@@ -132,18 +132,20 @@ if os.path.isfile(sq_path):
             tab[cur][m.group(1)] = float(m.group(3))
     txt = ("# SQ counters of the fused edge kernels (rocprofv3 --kernel-trace --pmc ..., workload tools/kbwd.py, B=256, N=30),\n"
            "# per dispatch.  Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over\n"
-           "# waves; SQ_VALU_MFMA_BUSY_CYCLES counts cycles (= 32 x number of 32x32x16 MFMAs) summed over SIMDs.  One wave per SIMD\n"
-           "# (two in edge_dw_kernel), so  MFMA share of wave time = MFMA_BUSY / (4 x WAVE_CYCLES / waves_per_SIMD).\n#\n"
-           "#   kernel                               MFMA busy / wave time   wave parked (WAIT_ANY)   issue stalled (WAIT_INST_ANY)   VALU active   VALU instr per MFMA\n")
+           "# waves; SQ_VALU_MFMA_BUSY_CYCLES counts cycles (= 32 x number of 32x32x16 MFMAs) summed over SIMDs.  Two waves per SIMD in every\n"
+           "# kernel (the eight-wave forms), so  MFMA share of wave time = MFMA_BUSY / (4 x WAVE_CYCLES / 2);  by DEVICE time (last column):\n"
+           "# MFMA_BUSY / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs).\n#\n"
+           "#   kernel                               MFMA busy / wave time   wave parked (WAIT_ANY)   issue stalled (WAIT_INST_ANY)   VALU active   VALU instr per MFMA   MFMA busy / device time\n")
     for k, v in tab.items():
         if not v.get("SQ_WAVE_CYCLES"):
             continue
-        wps = 2.0 if "edge_dw" in k else 1.0
+        wps = 2.0   # (eight waves per workgroup in every edge kernel: two per SIMD)
         wc = v["SQ_WAVE_CYCLES"]
         nm = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 32.0
         txt += (f"#   {k:38s} {v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (4 * wc / wps):8.2f} {v.get('SQ_WAIT_ANY', 0) / wc:22.2f} "
                 f"{v.get('SQ_WAIT_INST_ANY', 0) / wc:24.2f} {v.get('SQ_ACTIVE_INST_VALU', 0) / wc:22.2f} "
-                f"{(v.get('SQ_INSTS_VALU', 0) / nm if nm else 0):16.1f}\n")
+                f"{(v.get('SQ_INSTS_VALU', 0) / nm if nm else 0):16.1f} "
+                f"{(v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (v['GRBM_GUI_ACTIVE'] / 8 * 1024) if v.get('GRBM_GUI_ACTIVE') else 0):22.2f}\n")
     open(os.path.join(P, f"{tag}_pmc_sq_counters.txt"), "w").write(txt + "#\n" + sq)
 
 gp = os.path.join(F, "pmc_gapt_summary.txt")
