@@ -72,6 +72,14 @@ int mpg_gate(const float* in, int ldi, const float* H, int ldh, float* out, int 
              int gate_act, float alpha, const uint64_t* seed, uint32_t tag, uint32_t thr, float scale,
              void* stream);
 
+/* mpg_slab_sums: out[m, 0:cols] = sum_s A[s][m][0:cols], out[m, cols:2 cols] = sum_s B[s][m][0:cols] (slab s at A + s * strideA
+ * floats, rows dense; added in index order).  The partial receiver gradients da (one slab per sender chunk) and sender gradients dc
+ * (one slab per receiver block) of a sender-chunked mpg_edge_bwd launch, as the [da | dc] rows the layer's dx chain and its first
+ * layer's weight gradient read -- replaces the two `sum(0)` calls autograd would issue for the reference's
+ * `A.view(B, N, N, -1).sum(2)` backward (mpgan/model.py:257-267).  cols % 4 == 0, 16-byte aligned pointers (-5). */
+int mpg_slab_sums(const float* A, int slabsA, uint64_t strideA, const float* B, int slabsB, uint64_t strideB,
+                  float* out, int M, int cols, void* stream);
+
 /* Test helper: the {0,1} keep mask [rows, F] the kernels use for dropout site `tag`. */
 int mpg_dropout_mask(float* out, uint64_t rows, int F, const uint64_t* seed, uint32_t tag, uint32_t thr,
                      void* stream);

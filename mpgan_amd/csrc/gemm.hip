@@ -239,6 +239,26 @@ __global__ void gate_kernel(const float* __restrict__ in, int ldi, const float* 
     out[(size_t)m * ldo + n] = in[(size_t)m * ldi + n] * gt;
 }
 
+// out[m, 0:cols] = sum_s A[s][m][:],  out[m, cols:2 cols] = sum_s B[s][m][:]  -- the partial da (one slab per sender chunk) and
+// dc (one per receiver block) of a sender-chunked data-gradient launch, added slab by slab in index order; one float4 per thread.
+__global__ void slab_sums_kernel(const float* __restrict__ A, int slabsA, size_t strideA, const float* __restrict__ B, int slabsB,
+                                 size_t strideB, float* __restrict__ out, int M, int cols) {
+    const int q = cols / 4;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)M * 2 * q) return;
+    const int m = (int)(idx / (2 * q)), r = (int)(idx % (2 * q));
+    const bool second = r >= q;
+    const float* src = (second ? B : A) + (size_t)m * cols + 4 * (second ? r - q : r);
+    const int n = second ? slabsB : slabsA;
+    const size_t st = second ? strideB : strideA;
+    float4 acc = *reinterpret_cast<const float4*>(src);
+    for (int sl = 1; sl < n; ++sl) {
+        const float4 t = *reinterpret_cast<const float4*>(src + sl * st);
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    *reinterpret_cast<float4*>(out + (size_t)m * 2 * cols + 4 * r) = acc;
+}
+
 // out[n, col0 + k] = sum_z part[z][n][k]  (k < K);  bias[n] = sum_z part[z][n][K] when the GEMM carried a
 // ones column (ld of the partials = K + has_bias).  One launch replaces torch's sum + strided copy (+ bias sum).
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, int S, int N, int K, int has_bias,
@@ -337,6 +357,17 @@ extern "C" int mpg_gate(const float* in, int ldi, const float* H, int ldh, float
     if (tot == 0) return 0;
     hipLaunchKernelGGL(gate_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, ldi, H, ldh, out,
                        ldo, M, N, gate_act, alpha, seed, tag, thr, scale);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mpg_slab_sums(const float* A, int slabsA, uint64_t strideA, const float* B, int slabsB, uint64_t strideB,
+                             float* out, int M, int cols, void* stream) {
+    if (M <= 0) return 0;
+    if (cols <= 0 || cols % 4 != 0 || slabsA < 1 || slabsB < 1 || strideA % 4 != 0 || strideB % 4 != 0) return -2;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)out) & 15) return -5;
+    const size_t tot = (size_t)M * (cols / 2);
+    hipLaunchKernelGGL(slab_sums_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, slabsA, (size_t)strideA, B,
+                       slabsB, (size_t)strideB, out, M, cols);
     return (int)hipGetLastError();
 }
 

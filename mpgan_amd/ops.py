@@ -890,8 +890,13 @@ class FusedMPLayerFn(torch.autograd.Function):
                         ctx.prev_node.pre = dict(gy_ptr=dx.data_ptr(), keep=dx, dz3=below[0], dz2=below[1], dz1=below[2], dh0=below[3])
         if rc == _lib.MPG_FN_NA:
             check(_lib.lib().mpg_edge_bwd(C.byref(e), _stream()), "mpg_edge_bwd")
-        da = dap[0] if SC == 1 else dap.sum(0)
-        dc = dcp[0] if RB == 1 else dcp.sum(0)
+        if SC == 1 and RB == 1:
+            da, dc, dadc = dap[0], dcp[0], None
+        else:
+            # the chunks' partial da and the receiver blocks' partial dc, added slab by slab into [da | dc] rows: one launch
+            dadc = torch.empty((V, 2 * H1), device=dev, dtype=torch.float32)
+            check(_lib.lib().mpg_slab_sums(_p(dap), SC, V * H1, _p(dcp), RB, V * H1, _p(dadc), V, H1, _stream()), "mpg_slab_sums")
+            da, dc = dadc[:, :H1], dadc[:, H1:]
         dW1 = db1 = dW2 = db2 = dW3 = db3 = None
         # The weight-gradient launches below feed nothing before the optimizer: with a side stream set (TrainStep) they are
         # forked off here, behind the data-gradient kernel that produced their inputs, and this stream goes straight on
@@ -931,7 +936,7 @@ class FusedMPLayerFn(torch.autograd.Function):
             wb.add(dc, x2, out=dW1, out_col0=F, accumulate=direct)
             if side is not None:
                 # everything these launches read or write stays referenced until TrainStep joins the stream
-                st_dev.wgrad_keep.append((ac, m1, dh0, sign3, stE2, stZ2, gexp, part, da, dc, dap, dcp, x2, xf2, agg, h1, h2,
+                st_dev.wgrad_keep.append((ac, m1, dh0, sign3, stE2, stZ2, gexp, part, da, dc, dap, dcp, dadc, x2, xf2, agg, h1, h2,
                                           dz1, dz2, dz3, gy2, nbr, [j[7] for j in wb.jobs]))
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
@@ -951,8 +956,12 @@ class FusedMPLayerFn(torch.autograd.Function):
                 dW1 = db1 = dW2 = db2 = dW3 = db3 = dV1 = dc1 = dV2 = dc2 = dV3 = dc3 = None
         if need_x:
             if rc == _lib.MPG_FN_NA:   # (not done by the data-gradient launch: its own launch)
-                chain(V, [dict(img=pk.ptr("W1ST"), K=2 * H1, N=F, resid=dh0[:, H3:H3 + F], out=dx)],
-                      A=dap, lda=H1, K1=H1, a_slabs=SC, a_slab_stride=V * H1, A2=dc, lda2=dc.stride(0), alpha=alpha, f16=False)
+                if dadc is not None:
+                    chain(V, [dict(img=pk.ptr("W1ST"), K=2 * H1, N=F, resid=dh0[:, H3:H3 + F], out=dx)],
+                          A=dadc, lda=2 * H1, K1=2 * H1, alpha=alpha, f16=False)
+                else:
+                    chain(V, [dict(img=pk.ptr("W1ST"), K=2 * H1, N=F, resid=dh0[:, H3:H3 + F], out=dx)],
+                          A=dap, lda=H1, K1=H1, A2=dc, lda2=dc.stride(0), alpha=alpha, f16=False)
             dx = dx.reshape(B, N, F)
         dxfn = None
         if len(ctx.needs_input_grad) > 23 and ctx.needs_input_grad[23] and dh0.shape[1] > H3 + F:

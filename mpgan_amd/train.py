@@ -394,6 +394,13 @@ class TrainStep:
                           and os.environ.get("MPG_GEN_AHEAD", "1") != "0")
         self._side = None
         self._fake_ahead = None
+        # where the generator-ahead branch joins: at the end of the D segment when that segment is a hipGraph of its own (a
+        # capture must end with every forked stream joined), otherwise only where the G step picks its jets up -- so that the D
+        # all-reduce (graph_collectives: inside the one graph; eagerly: between the segments) waits for D's backward and its
+        # weight-gradient stream alone, not for the generator's forward beside them
+        self._defer_join = False
+        self._join_pending = False
+        self.gen_join = None       # ("seg_D" | "seg_G": where the last iteration / capture joined the branch; tests read it)
         # The launches that only produce weight gradients (mpg_edge_dw + reduction, the grouped node-network weight
         # gradients: about a quarter of the step) feed nothing before the optimizer: they run on a second side stream, forked
         # per layer behind mpg_edge_bwd and joined at the end of the backward (before the all-reduce / optimizer step), so
@@ -474,8 +481,12 @@ class TrainStep:
         try:
             self._seg_D_body()
         finally:
-            if self.gen_ahead:   # join: everything of this segment is ordered before whatever follows it
-                torch.cuda.current_stream(self.dev).wait_stream(self._side)
+            if self.gen_ahead:
+                if self._defer_join:
+                    self._join_pending = True
+                else:                # join: everything of this segment is ordered before whatever follows it
+                    torch.cuda.current_stream(self.dev).wait_stream(self._side)
+                    self.gen_join = "seg_D"
 
     def _fork_generator(self):
         """train_G's ``gen_data = gen(...)`` (train.py:500-511) on the side stream, in training mode."""
@@ -594,6 +605,10 @@ class TrainStep:
             self.fG.zero_grad()
         self._clean["G"] = False
         _set_requires_grad(self.fD, False)
+        if self._join_pending:       # (the deferred join of the generator-ahead branch: its jets are used from here on)
+            torch.cuda.current_stream(self.dev).wait_stream(self._side)
+            self._join_pending = False
+            self.gen_join = "seg_G"
         fake, self._fake_ahead = self._fake_ahead, None
         parts = self.parts and self._fused_ends()
         bridge = parts and fake is None and self._bridge()
@@ -646,9 +661,13 @@ class TrainStep:
         mdist.allreduce_sum_(flat.grad, self.pg, self.world)  # sum; 1/world is folded into the optimiser step
 
     def _eager(self):
-        self._seg_D(); self._allreduce(self.fD)
-        self._seg_G(); self._allreduce(self.fG)
-        self._seg_end()
+        self._defer_join = True
+        try:
+            self._seg_D(); self._allreduce(self.fD)
+            self._seg_G(); self._allreduce(self.fG)
+            self._seg_end()
+        finally:
+            self._defer_join = False
 
     def _training_state(self):
         """Everything an iteration changes: parameters, optimiser moments and step counters, the dropout seed, the losses --
@@ -703,9 +722,13 @@ class TrainStep:
             groups = [(self._seg_D, self._seg_G, self._seg_end)]
         for segs in groups:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
-                for seg in segs:
-                    seg()
+            self._defer_join = len(segs) > 1     # (D and G segments in ONE graph: the branch may stay open across them)
+            try:
+                with torch.cuda.graph(g, pool=pool):
+                    for seg in segs:
+                        seg()
+            finally:
+                self._defer_join = False
             pool = g.pool()
             graphs.append(g)
         self._graphs = graphs

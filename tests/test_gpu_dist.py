@@ -33,12 +33,15 @@ def test_world1_nccl_group_three_segments_equal_eager():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        b = _three_steps(16, 30, use_graphs=True, pg=dist.group.WORLD)   # graphs + collective
-        c = _three_steps(16, 30, use_graphs=False, pg=dist.group.WORLD)  # eager + collective
-        # the two all-reduces captured INSIDE the graph: the multi-rank iteration as one replay
+        # graphs + collective: every segment is a graph of its own, so the generator-ahead branch joins at the end of the D segment
+        b = _three_steps(16, 30, use_graphs=True, pg=dist.group.WORLD, gen_join="seg_D")
+        # eager + collective: the D all-reduce is ordered behind D's backward and its weight-gradient stream only -- the
+        # generator-ahead branch stays open across it and joins where the G step takes its jets
+        c = _three_steps(16, 30, use_graphs=False, pg=dist.group.WORLD, gen_join="seg_G")
+        # the two all-reduces captured INSIDE the graph: the multi-rank iteration as one replay, same edge as eagerly
         os.environ["MPG_GRAPH_COLLECTIVES"] = "1"
         try:
-            d = _three_steps(16, 30, use_graphs=True, pg=dist.group.WORLD, n_graphs=1)
+            d = _three_steps(16, 30, use_graphs=True, pg=dist.group.WORLD, n_graphs=1, gen_join="seg_G")
         finally:
             os.environ.pop("MPG_GRAPH_COLLECTIVES", None)
     finally:

@@ -168,7 +168,8 @@ def test_graph_replay_equals_eager():
     assert len(set(losses)) == 4  # fresh noise and fresh dropout masks on every replay
 
 
-def _three_steps(B, N, use_graphs, split=False, pg=None, model="mpgan", disc_dropout=0.0, steps=3, seed=3, n_graphs=None):
+def _three_steps(B, N, use_graphs, split=False, pg=None, model="mpgan", disc_dropout=0.0, steps=3, seed=3, n_graphs=None,
+                 gen_join=None):
     """Parameters after `steps` iterations from fixed weights / data / noise."""
     import os
     from mpgan_amd import train
@@ -198,6 +199,8 @@ def _three_steps(B, N, use_graphs, split=False, pg=None, model="mpgan", disc_dro
         for _ in range(steps):
             ts.step()
         torch.cuda.synchronize()
+        if gen_join is not None and ts.gen_ahead:    # where the generator-ahead branch joined (TrainStep.gen_join)
+            assert ts.gen_join == gen_join, (ts.gen_join, gen_join)
     finally:
         os.environ.pop("MPG_SPLIT_GRAPHS", None)
     return ts.fD.flat.clone(), ts.fG.flat.clone(), float(ts.D_loss), float(ts.G_loss)
