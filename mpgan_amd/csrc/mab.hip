@@ -1,4 +1,5 @@
-// One launch per multihead attention block of GAPT (MAB.forward, gapt/model.py:124-139), for sets of up to 32 tokens:
+// One launch per multihead attention block of GAPT (MAB.forward, gapt/model.py:124-139), for sets of up to 32 tokens (and, further
+// down, mab_fwdN_kernel / mab_bwdN_kernel for 33 ... 160):
 //
 //   q = x Wq' + bq ; k = y Wk' + bk ; v = y Wv' + bv            (nn.MultiheadAttention in-projection, packed [3E, E])
 //   P_h = softmax(q_h k_h' / sqrt(d) + key mask) ; o_h = P_h v_h (per head, d = 16)
@@ -18,9 +19,11 @@
 //                    tile, which is again the B operand of the out-projection.
 // Products run as fp16 hi/lo 3-term splits (common.h) with power-of-two operand scales; the backward kernel recomputes
 // the same values and carries gradients as bf16 hi/lo.
+#define MPG_CVT_BUILTIN 1   // (see common.h: cvt_pk_bf16)
 #include "common.h"
 #include "../../include/mpgan_amd.h"
 #include <stdlib.h>
+#include <algorithm>
 
 #ifdef MPG_MABSTAMP  // diagnostic build (tools/mab_stamps.py): s_memtime at the phase boundaries, the waves of workgroup 0
 __device__ unsigned long long g_mab_stamps[2 * 4 * 8];   // [forward | backward][wave][stamp]
@@ -275,6 +278,76 @@ MPG_DEV void ln_apply(f32x16 (&t)[NT], const float* w, const float* b, float eps
     }
 }
 
+// The half of a block behind the attention, on the 32 rows a wave holds: za = x + o Wo' + bo, [norm1], dropout, the feed-forward
+// layer with its residual, [norm2], dropout.  oh / ol: the attention output as B fragments; xt: the rows' input tiles on entry, the
+// block's OUTPUT rows on exit.  Shared by the one-wave kernels and the large-set kernel (a wave per tile of 32 queries).
+template <int NT, bool LN>
+MPG_DEV void mab_post(const MpgMab& p, f32x16 (&xt)[NT], const f16x8* oh, const f16x8* ol, WImg rO, WImg rF, const float* sBo, const float* sBf,
+                      const long xrow, const bool xvalid, const uint32_t seed_lo, const uint32_t seed_hi, const float sa, const float inv_zs,
+                      const int h, const int lane16, unsigned long long* mab_st) {
+    typedef f16x8 V;
+    constexpr int KS = 2 * NT;
+    constexpr int nfE = NT * KS;
+    MAB_STAMPP(3);
+    // za = x + o Wo' + bo ; z = dropout(za)
+    f32x16 z[NT];
+    V zh[KS], zl[KS];
+    if constexpr (LN) {
+        // ... with norm1 between the residual and the dropout: every tile of za first (kept for the backward), then the norm
+        static_for<0, NT>([&](auto tc) {
+            MPG_CI(t, tc);
+            const f32x16 acc = proj_n<KS>(rO, nfE, t, oh, ol, bias_regs(sBo, t, h), lane16);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[t][i] = acc[i] * inv_zs + xt[t][i];
+            if (p.save_za != nullptr && xvalid) tile_to_rows(p.save_za, p.E, xrow, t, h, z[t], 1.f);
+        });
+        ln_apply<NT>(z, p.ln1_w, p.ln1_b, p.ln_eps, h);
+    }
+    static_for<0, NT>([&](auto tc) {
+        MPG_CI(t, tc);
+        if constexpr (!LN) {
+            const f32x16 acc = proj_n<KS>(rO, nfE, t, oh, ol, bias_regs(sBo, t, h), lane16);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[t][i] = acc[i] * inv_zs + xt[t][i];
+        }
+        drop_tile(z[t], seed_lo, seed_hi, p.tag + 0, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
+        if (p.save_z != nullptr && xvalid) tile_to_rows(p.save_z, p.E, xrow, t, h, z[t], 1.f);
+        tile_frag(z[t], 0, sa, zh[2 * t], zl[2 * t]);
+        tile_frag(z[t], 1, sa, zh[2 * t + 1], zl[2 * t + 1]);
+    });
+    MAB_STAMPP(4);
+    // out = dropout([norm2](z + dropout_ff(LeakyReLU(z Wf' + bf))))
+    f32x16 op[LN ? NT : 1];
+    static_for<0, NT>([&](auto tc) {
+        MPG_CI(t, tc);
+        f32x16 u = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(sBf, t, h), lane16);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = u[i] * inv_zs;
+            u[i] = p.ff_act ? lrelu(v, p.alpha) : v;
+        }
+        drop_tile(u, seed_lo, seed_hi, p.tag + 1, (uint32_t)xrow, t, h, p.thr_ff, p.sc_ff);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) u[i] += z[t][i];
+        if constexpr (LN) {
+            op[t] = u;
+        } else {
+            drop_tile(u, seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
+            if (xvalid) tile_to_rows(p.out, p.ldo, xrow, t, h, u, 1.f);
+            xt[t] = u;     // (the block's output rows, as the next block of a chain takes them; z[t] carried the residual)
+        }
+    });
+    if constexpr (LN) {
+        ln_apply<NT>(op, p.ln2_w, p.ln2_b, p.ln_eps, h);
+        static_for<0, NT>([&](auto tc) {
+            MPG_CI(t, tc);
+            drop_tile(op[t], seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
+            if (xvalid) tile_to_rows(p.out, p.ldo, xrow, t, h, op[t], 1.f);
+            xt[t] = op[t];
+        });
+    }
+}
+
 // One block on one jet (one wave).  xt: the block's query rows as accumulator-layout tiles on entry, its OUTPUT rows on exit (what
 // the next block of a chain of self-attention blocks takes as its input: mab_chain_fwd_kernel); yt: the key / value rows
 // (CROSS), kneg the additive key mask; the weight images and the pre-scaled biases are in LDS.
@@ -333,64 +406,7 @@ MPG_DEV void mab_fwd_jet(const MpgMab& p, f32x16 (&xt)[NT], const f32x16* yt, co
         tile_frag(Ot, 1, 1.f / MAB_SP, oh[2 * t + 1], ol[2 * t + 1]);
     });
 
-    MAB_STAMP(3);
-    // za = x + o Wo' + bo ; z = dropout(za)
-    f32x16 z[NT];
-    V zh[KS], zl[KS];
-    if constexpr (LN) {
-        // ... with norm1 between the residual and the dropout: every tile of za first (kept for the backward), then the norm
-        static_for<0, NT>([&](auto tc) {
-            MPG_CI(t, tc);
-            const f32x16 acc = proj_n<KS>(rO, nfE, t, oh, ol, bias_regs(sBo, t, h), lane16);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) z[t][i] = acc[i] * inv_zs + xt[t][i];
-            if (p.save_za != nullptr && xvalid) tile_to_rows(p.save_za, p.E, xrow, t, h, z[t], 1.f);
-        });
-        ln_apply<NT>(z, p.ln1_w, p.ln1_b, p.ln_eps, h);
-    }
-    static_for<0, NT>([&](auto tc) {
-        MPG_CI(t, tc);
-        if constexpr (!LN) {
-            const f32x16 acc = proj_n<KS>(rO, nfE, t, oh, ol, bias_regs(sBo, t, h), lane16);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) z[t][i] = acc[i] * inv_zs + xt[t][i];
-        }
-        drop_tile(z[t], seed_lo, seed_hi, p.tag + 0, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
-        if (p.save_z != nullptr && xvalid) tile_to_rows(p.save_z, p.E, xrow, t, h, z[t], 1.f);
-        tile_frag(z[t], 0, sa, zh[2 * t], zl[2 * t]);
-        tile_frag(z[t], 1, sa, zh[2 * t + 1], zl[2 * t + 1]);
-    });
-    MAB_STAMP(4);
-    // out = dropout([norm2](z + dropout_ff(LeakyReLU(z Wf' + bf))))
-    f32x16 op[LN ? NT : 1];
-    static_for<0, NT>([&](auto tc) {
-        MPG_CI(t, tc);
-        f32x16 u = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(sBf, t, h), lane16);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float v = u[i] * inv_zs;
-            u[i] = p.ff_act ? lrelu(v, p.alpha) : v;
-        }
-        drop_tile(u, seed_lo, seed_hi, p.tag + 1, (uint32_t)xrow, t, h, p.thr_ff, p.sc_ff);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) u[i] += z[t][i];
-        if constexpr (LN) {
-            op[t] = u;
-        } else {
-            drop_tile(u, seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
-            if (xvalid) tile_to_rows(p.out, p.ldo, xrow, t, h, u, 1.f);
-            xt[t] = u;     // (the block's output rows, as the next block of a chain takes them; z[t] carried the residual)
-        }
-    });
-    if constexpr (LN) {
-        ln_apply<NT>(op, p.ln2_w, p.ln2_b, p.ln_eps, h);
-        static_for<0, NT>([&](auto tc) {
-            MPG_CI(t, tc);
-            drop_tile(op[t], seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
-            if (xvalid) tile_to_rows(p.out, p.ldo, xrow, t, h, op[t], 1.f);
-            xt[t] = op[t];
-        });
-    }
+    mab_post<NT, LN>(p, xt, oh, ol, rO, rF, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, h, lane16, mab_st);
     MAB_STAMP(5);
 }
 
@@ -457,6 +473,137 @@ __global__ __launch_bounds__(256) void mab_fwd_kernel(const MpgMab p) {
     if (blockIdx.x == 0 && lane == 0)
         for (int i = 0; i < 8; ++i) g_mab_stamps[w * 8 + i] = mab_st[i];
 #endif
+}
+
+// ---- LARGE SETS (33 ... 160 tokens: --num-hits 150, gapt/model.py has no size limit).  One workgroup per jet, one wave per TILE of
+// 32 queries.  A wave walks the key tiles with a running maximum / sum per (query, head) -- scores of one key tile at a time:
+// keys in registers, queries on lanes, exactly the one-wave kernel's products --, projecting each key tile's K and V from its
+// rows itself (the rows come out of L2; no exchange between the waves, no barrier behind the weight fill), rescales its output
+// accumulators when the maximum moves, and runs the half behind the attention (mab_post) on its own 32 rows.  A query whose keys
+// are all masked gets a zero attention output (torch's _safe_softmax).
+MPG_DEV f32x16 key_mask_tile(const float* ignore, const float* safe, long jet, int S, int h, int kt) {
+    const bool on = ignore != nullptr;
+    const float* const row = on ? ignore + jet * S : safe;
+    f32x16 t;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = 32 * kt + 8 * g + 4 * h + e;
+            const float v = row[on ? min(key, S - 1) : 0];
+            t[4 * g + e] = (key >= S || (on && v != 0.f)) ? -INFINITY : 0.f;
+        }
+    return t;
+}
+
+template <int NT, bool LN>
+__global__ __launch_bounds__(320) void mab_fwdN_kernel(const MpgMab p) {
+    typedef f16x8 V;
+    constexpr int KS = 2 * NT;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5, lane16 = lane * 16;
+    const uint64_t sd = *(p.seed != nullptr ? p.seed : reinterpret_cast<const uint64_t*>(p.x));
+    const uint32_t seed_lo = p.seed != nullptr ? (uint32_t)sd : 0u, seed_hi = p.seed != nullptr ? (uint32_t)(sd >> 32) : 0u;
+    const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
+    const float zs = sa * ws, inv_zs = 1.f / zs;
+    constexpr int nfIn = 3 * NT * KS, nfE = NT * KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sIn = smem;
+    char* const sO = sIn + 2 * nfIn * 1024;
+    char* const sF = sO + 2 * nfE * 1024;
+    float* const sBin = reinterpret_cast<float*>(sF + 2 * nfE * 1024);
+    float* const sBo = sBin + 96 * NT;
+    float* const sBf = sBo + 32 * NT;
+    const long jet = blockIdx.x;
+    const int nqt = (p.L + 31) >> 5, nkt = (p.S + 31) >> 5;
+    const int tok = 32 * w + r;
+    const long xrow = jet * p.L + min(tok, p.L - 1);
+    const bool xvalid = tok < p.L;
+    f32x16 xt[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) xt[t] = rows_to_tile(p.x, p.ldx, xrow, t, h);
+    mab_fill(sIn, p.Win, 2 * nfIn * 1024);
+    mab_fill(sO, p.Wo, 2 * nfE * 1024);
+    mab_fill(sF, p.Wf, 2 * nfE * 1024);
+    for (int i = threadIdx.x; i < 160 * NT; i += blockDim.x)
+        sBin[i] = (i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT])) * zs;
+    __syncthreads();
+    if (w >= nqt) return;                 // (a wave without a query tile: it has helped with the fill)
+    const WImg rIn = sIn, rO = sO, rF = sF;
+    V qh[2 * NT], ql[2 * NT];             // the queries' heads as B fragments: head 2t + a
+    {
+        V xh[KS], xl[KS];
+        tiles_to_frags<NT>(xt, sa, xh, xl);
+        static_for<0, NT>([&](auto tc) {
+            MPG_CI(t, tc);
+            const f32x16 Qn = proj_n<KS>(rIn, nfIn, t, xh, xl, bias_regs(sBin, t, h), lane16);
+            tile_frag(Qn, 0, inv_zs * sa * 0.25f, qh[2 * t], ql[2 * t]);      // 1/sqrt(d), d = 16
+            tile_frag(Qn, 1, inv_zs * sa * 0.25f, qh[2 * t + 1], ql[2 * t + 1]);
+        });
+    }
+    const float sc2 = 1.44269504088896341f / (sa * sa);   // scores in the base-2 domain
+    float mrun[2 * NT], den[2 * NT];
+    f32x16 oacc[2 * NT];
+#pragma unroll
+    for (int i = 0; i < 2 * NT; ++i) { mrun[i] = -INFINITY; den[i] = 0.f; oacc[i] = zero16(); }
+    for (int kt = 0; kt < nkt; ++kt) {
+        const long yrow = jet * p.S + min(32 * kt + r, p.S - 1);
+        V yh[KS], yl[KS];
+        rows_to_frags<KS>(p.y, p.ldy, yrow, sa, h, yh, yl);
+        const f32x16 kneg = key_mask_tile(p.ignore, p.x, jet, p.S, h, kt);
+        static_for<0, NT>([&](auto tc) {
+            MPG_CI(t, tc);
+            const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(sBin, NT + t, h), lane16);
+            const f32x16 Vt = proj_t<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_lanes(sBin, 2 * NT + t, r), lane16);
+            V vh[2], vl[2];
+            tile_frag(Vt, 0, inv_zs * sa, vh[0], vl[0]);
+            tile_frag(Vt, 1, inv_zs * sa, vh[1], vl[1]);
+            static_for<0, 2>([&](auto ac) {
+                MPG_CI(a, ac);
+                constexpr int hd = 2 * t + a;
+                V kh, kl;
+                tile_frag(Kn, a, inv_zs * sa, kh, kl);
+                f32x16 sx = mfma3(kh, kl, qh[hd], ql[hd], zero16());      // keys in registers, queries on lanes
+                float mx = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { sx[i] = sx[i] * sc2 + kneg[i]; mx = fmaxf(mx, sx[i]); }
+                mx = fmaxf(mx, other_half(mx));
+                const float mnew = fmaxf(mrun[hd], mx);
+                const float msafe = mnew == -INFINITY ? 0.f : mnew;       // (nothing but masked keys so far: every term below is 0)
+                const float resc = __builtin_amdgcn_exp2f(mrun[hd] - msafe);
+                mrun[hd] = mnew;
+                float part = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { sx[i] = __builtin_amdgcn_exp2f(sx[i] - msafe); part += sx[i]; }
+                part += other_half(part);
+                den[hd] = den[hd] * resc + part;
+                V ph[2], pl[2];
+                tile_frag(sx, 0, MAB_SP, ph[0], pl[0]);
+                tile_frag(sx, 1, MAB_SP, ph[1], pl[1]);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[hd][i] *= resc;
+                oacc[hd] = mfma3(vh[0], vl[0], ph[0], pl[0], oacc[hd]);
+                oacc[hd] = mfma3(vh[1], vl[1], ph[1], pl[1], oacc[hd]);
+            });
+        });
+    }
+    V oh[KS], ol[KS];
+    static_for<0, NT>([&](auto tc) {
+        MPG_CI(t, tc);
+        f32x16 Ot;
+        static_for<0, 2>([&](auto ac) {
+            MPG_CI(a, ac);
+            constexpr int hd = 2 * t + a;
+            const float inv = den[hd] > 0.f ? 1.f / den[hd] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Ot[8 * a + j] = oacc[hd][8 * a + j] * inv;
+        });
+        // Ot = 256 sa o  (features 32t .. 32t+31 x queries)
+        if (p.save_o != nullptr && xvalid) tile_to_rows(p.save_o, p.E, xrow, t, h, Ot, 1.f / (MAB_SP * sa));
+        tile_frag(Ot, 0, 1.f / MAB_SP, oh[2 * t], ol[2 * t]);
+        tile_frag(Ot, 1, 1.f / MAB_SP, oh[2 * t + 1], ol[2 * t + 1]);
+    });
+    mab_post<NT, LN>(p, xt, oh, ol, rO, rF, sBo, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, h, lane16, nullptr);
 }
 
 // A CHAIN of self-attention blocks (the SABs of a GAPT network, gapt/model.py:261-262 / :341-342: x = sab(x, mask) in a loop) in
@@ -826,6 +973,95 @@ MPG_DEV void ln_backward(f32x16 (&g)[NT], const f32x16 (&xin)[NT], const float* 
         for (int i = 0; i < 16; ++i) g[t][i] = rstd * (g[t][i] - m1 - xh[t][i] * m2);
 }
 
+// The feed-forward half of a block's backward on the 32 rows a wave holds: dzf = dropout'(dout) [through norm2] ;
+// du = dzf drop_ff' act'(u) ; dz = dzf + du Wf ; dza = dropout'(dz) [through norm1].  In: dzf = the rows of dout, zt = the saved z,
+// zat = the saved za (LN).  Out: du / dza rows (p.du, p.dza), dza as bf16 fragments, dxa = dza (the residual path of dx).
+template <int NT, bool LN>
+MPG_DEV void mab_bwd_ff(const MpgMab& p, f32x16 (&dzf)[NT], const f32x16 (&zt)[NT], const f32x16* zat, const float xlive, WImg rF, WImg rFT,
+                        const float* sBf, const long xrow, const bool xvalid, const uint32_t seed_lo, const uint32_t seed_hi, const float sa,
+                        const float inv_zs, const int h, const int lane16, bf16x8* dzah, bf16x8* dzal, f32x16 (&dxa)[NT]) {
+    typedef f16x8 VF;
+    typedef bf16x8 VB;
+    constexpr int KS = 2 * NT;
+    constexpr int nfE = NT * KS;
+    {
+        VF zh[KS], zl[KS];
+        tiles_to_frags<NT>(zt, sa, zh, zl);
+        VB duh[KS], dul[KS];
+        f32x16 ut[LN ? NT : 1];
+        if constexpr (LN) {
+            // norm2 sits between the second residual and the last dropout: its input z + dropout_ff(act(u)) is rebuilt as the
+            // forward built it (u is needed below anyway), the gradient goes through the norm, and dzf is then what it is
+            // without a norm -- the gradient with respect to that sum
+            f32x16 op[NT];
+            static_for<0, NT>([&](auto tc) {
+                MPG_CI(t, tc);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dzf[t][i] *= xlive;
+                drop_tile(dzf[t], seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
+                ut[t] = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(sBf, t, h), lane16);
+                f32x16 a;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float v = ut[t][i] * inv_zs;
+                    a[i] = p.ff_act ? lrelu(v, p.alpha) : v;
+                }
+                drop_tile(a, seed_lo, seed_hi, p.tag + 1, (uint32_t)xrow, t, h, p.thr_ff, p.sc_ff);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) op[t][i] = zt[t][i] + a[i];
+            });
+            ln_backward<NT>(dzf, op, p.ln2_w, p.ln_eps, p.dn2, p.gn2, p.E, xrow, xvalid, h);
+        }
+        static_for<0, NT>([&](auto tc) {
+            MPG_CI(t, tc);
+            f32x16 u;
+            if constexpr (LN) {
+                u = ut[t];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dzf[t][i] *= xlive;
+                drop_tile(dzf[t], seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
+                u = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(sBf, t, h), lane16);
+            }
+            f32x16 du;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) du[i] = dzf[t][i] * ((p.ff_act && !(u[i] > 0.f)) ? p.alpha : 1.f);
+            drop_tile(du, seed_lo, seed_hi, p.tag + 1, (uint32_t)xrow, t, h, p.thr_ff, p.sc_ff);
+            if (p.du != nullptr && xvalid) tile_to_rows(p.du, p.E, xrow, t, h, du, 1.f);
+            tile_frag(du, 0, 1.f, duh[2 * t], dul[2 * t]);
+            tile_frag(du, 1, 1.f, duh[2 * t + 1], dul[2 * t + 1]);
+        });
+        if constexpr (LN) {
+            // dz of every tile, through the first dropout: the gradient with respect to norm1's output; through the norm (its
+            // input za was kept by the forward); what comes out is dza
+            f32x16 dn[NT];
+            static_for<0, NT>([&](auto tc) {
+                MPG_CI(t, tc);
+                dn[t] = proj_n<KS>(rFT, nfE, t, duh, dul, dzf[t], lane16);
+                drop_tile(dn[t], seed_lo, seed_hi, p.tag + 0, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
+            });
+            ln_backward<NT>(dn, *reinterpret_cast<const f32x16 (*)[NT]>(zat), p.ln1_w, p.ln_eps, p.dn1, p.gn1, p.E, xrow, xvalid, h);
+            static_for<0, NT>([&](auto tc) {
+                MPG_CI(t, tc);
+                if (p.dza != nullptr && xvalid) tile_to_rows(p.dza, p.E, xrow, t, h, dn[t], 1.f);
+                tile_frag(dn[t], 0, 1.f, dzah[2 * t], dzal[2 * t]);
+                tile_frag(dn[t], 1, 1.f, dzah[2 * t + 1], dzal[2 * t + 1]);
+                dxa[t] = dn[t];
+            });
+        } else {
+            static_for<0, NT>([&](auto tc) {
+                MPG_CI(t, tc);
+                f32x16 dz = proj_n<KS>(rFT, nfE, t, duh, dul, dzf[t], lane16);
+                drop_tile(dz, seed_lo, seed_hi, p.tag + 0, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
+                if (p.dza != nullptr && xvalid) tile_to_rows(p.dza, p.E, xrow, t, h, dz, 1.f);
+                tile_frag(dz, 0, 1.f, dzah[2 * t], dzal[2 * t]);
+                tile_frag(dz, 1, 1.f, dzah[2 * t + 1], dzal[2 * t + 1]);
+                dxa[t] = dz;
+            });
+        }
+    }
+}
+
 template <int NT, bool CROSS, bool LN = false>
 __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
     typedef f16x8 VF;
@@ -898,82 +1134,7 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
     // ---- feed-forward half: dzf = dropout'(dout) ; du = dzf drop_ff' act'(u) ; dz = dzf + du Wf ; dza = dropout'(dz)
     VB dzah[KS], dzal[KS];
     f32x16 dxa[NT];                       // gradient with respect to x: starts as the residual path
-    {
-        VF zh[KS], zl[KS];
-        tiles_to_frags<NT>(zt, sa, zh, zl);
-        VB duh[KS], dul[KS];
-        f32x16 ut[LN ? NT : 1];
-        if constexpr (LN) {
-            // norm2 sits between the second residual and the last dropout: its input z + dropout_ff(act(u)) is rebuilt as the
-            // forward built it (u is needed below anyway), the gradient goes through the norm, and dzf is then what it is
-            // without a norm -- the gradient with respect to that sum
-            f32x16 op[NT];
-            static_for<0, NT>([&](auto tc) {
-                MPG_CI(t, tc);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) dzf[t][i] *= xlive;
-                drop_tile(dzf[t], seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
-                ut[t] = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(sBf, t, h), lane16);
-                f32x16 a;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float v = ut[t][i] * inv_zs;
-                    a[i] = p.ff_act ? lrelu(v, p.alpha) : v;
-                }
-                drop_tile(a, seed_lo, seed_hi, p.tag + 1, (uint32_t)xrow, t, h, p.thr_ff, p.sc_ff);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) op[t][i] = zt[t][i] + a[i];
-            });
-            ln_backward<NT>(dzf, op, p.ln2_w, p.ln_eps, p.dn2, p.gn2, p.E, xrow, xvalid, h);
-        }
-        static_for<0, NT>([&](auto tc) {
-            MPG_CI(t, tc);
-            f32x16 u;
-            if constexpr (LN) {
-                u = ut[t];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) dzf[t][i] *= xlive;
-                drop_tile(dzf[t], seed_lo, seed_hi, p.tag + 2, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
-                u = proj_n<KS>(rF, nfE, t, zh, zl, bias_regs(sBf, t, h), lane16);
-            }
-            f32x16 du;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) du[i] = dzf[t][i] * ((p.ff_act && !(u[i] > 0.f)) ? p.alpha : 1.f);
-            drop_tile(du, seed_lo, seed_hi, p.tag + 1, (uint32_t)xrow, t, h, p.thr_ff, p.sc_ff);
-            if (p.du != nullptr && xvalid) tile_to_rows(p.du, p.E, xrow, t, h, du, 1.f);
-            tile_frag(du, 0, 1.f, duh[2 * t], dul[2 * t]);
-            tile_frag(du, 1, 1.f, duh[2 * t + 1], dul[2 * t + 1]);
-        });
-        if constexpr (LN) {
-            // dz of every tile, through the first dropout: the gradient with respect to norm1's output; through the norm (its
-            // input za was kept by the forward); what comes out is dza
-            f32x16 dn[NT];
-            static_for<0, NT>([&](auto tc) {
-                MPG_CI(t, tc);
-                dn[t] = proj_n<KS>(rFT, nfE, t, duh, dul, dzf[t], lane16);
-                drop_tile(dn[t], seed_lo, seed_hi, p.tag + 0, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
-            });
-            ln_backward<NT>(dn, zat, p.ln1_w, p.ln_eps, p.dn1, p.gn1, p.E, xrow, xvalid, h);
-            static_for<0, NT>([&](auto tc) {
-                MPG_CI(t, tc);
-                if (p.dza != nullptr && xvalid) tile_to_rows(p.dza, p.E, xrow, t, h, dn[t], 1.f);
-                tile_frag(dn[t], 0, 1.f, dzah[2 * t], dzal[2 * t]);
-                tile_frag(dn[t], 1, 1.f, dzah[2 * t + 1], dzal[2 * t + 1]);
-                dxa[t] = dn[t];
-            });
-        } else {
-            static_for<0, NT>([&](auto tc) {
-                MPG_CI(t, tc);
-                f32x16 dz = proj_n<KS>(rFT, nfE, t, duh, dul, dzf[t], lane16);
-                drop_tile(dz, seed_lo, seed_hi, p.tag + 0, (uint32_t)xrow, t, h, p.thr_mab, p.sc_mab);
-                if (p.dza != nullptr && xvalid) tile_to_rows(p.dza, p.E, xrow, t, h, dz, 1.f);
-                tile_frag(dz, 0, 1.f, dzah[2 * t], dzal[2 * t]);
-                tile_frag(dz, 1, 1.f, dzah[2 * t + 1], dzal[2 * t + 1]);
-                dxa[t] = dz;
-            });
-        }
-    }
+    mab_bwd_ff<NT, LN>(p, dzf, zt, zat, xlive, rF, rFT, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, h, lane16, dzah, dzal, dxa);
     MAB_STAMP(3);
     f32x16 dya[CROSS ? NT : 1];
     if constexpr (CROSS) {
@@ -1087,6 +1248,303 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
     if (blockIdx.x == 0 && lane == 0)
         for (int i = 0; i < 8; ++i) g_mab_stamps[32 + w * 8 + i] = mab_st[i];
 #endif
+}
+
+// ---- LARGE SETS, backward (33 ... 160 tokens; the forward is mab_fwdN_kernel).  One workgroup per jet; wave w owns query tile w
+// (its rows of dout, z, x: the feed-forward half, dq, the query side of dx) AND key tile w (dk, dv, the key side of dx / dy).
+// Nothing is exchanged between the waves but (a) the rows of dza, which every wave writes for its own queries anyway (they are
+// the operand of Wo's weight gradient) and the key owners read back behind a barrier, and (b) two numbers per (query, head)
+// through LDS: c = max + log2(sum) of the scores and D = <dO, O> (= sum_keys P dP: the saved attention output makes the
+// row sum a dot product over the head's 16 features).  Every wave projects the other tiles' rows itself, from L2:
+//   keys in registers (own queries x every key tile, twice: the statistics, then dS):  dQ' = sum_kt K'[kt] dS[kt]
+//   queries in registers (own keys x every query tile):  dK' = sum_qt Q'[qt] dS^T[qt],  dV' = sum_qt dO'[qt] P^T[qt]
+// each sum in tile order inside one wave: deterministic.  Recomputing the projections costs ~2x the MFMAs of a kernel that
+// shared them, on waves that would otherwise idle: 5 waves per jet on a launch of 16 ... 64 jets.
+template <int NT, bool CROSS, bool LN>
+__global__ __launch_bounds__(320) void mab_bwdN_kernel(const MpgMab p) {
+    typedef f16x8 VF;
+    typedef bf16x8 VB;
+    constexpr int KS = 2 * NT, NH = 2 * NT, TOKMAX = 160;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5, lane16 = lane * 16;
+    const uint64_t sd = *(p.seed != nullptr ? p.seed : reinterpret_cast<const uint64_t*>(p.x));
+    const uint32_t seed_lo = p.seed != nullptr ? (uint32_t)sd : 0u, seed_hi = p.seed != nullptr ? (uint32_t)(sd >> 32) : 0u;
+    const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
+    const float zs = sa * ws, inv_zs = 1.f / zs, sc2 = 1.44269504088896341f / (sa * sa);   // (scores in the base-2 domain)
+    constexpr int nfIn = 3 * NT * KS, nfE = NT * KS, nfInT = NT * 3 * KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sIn = smem;
+    char* const sF = sIn + 2 * nfIn * 1024;
+    char* const sInT = sF + 2 * nfE * 1024;
+    char* const sOT = sInT + 2 * nfInT * 1024;
+    char* const sFT = sOT + 2 * nfE * 1024;
+    float* const sBin = reinterpret_cast<float*>(sFT + 2 * nfE * 1024);  // biases: in_proj [3E] | ff [E]
+    float* const sBf = sBin + 96 * NT;
+    float* const sCQ = sBin + 128 * NT;   // [head][token]: the maximum of a query's scores (+inf: the query attends to nothing)
+    float* const sID = sCQ + NH * TOKMAX; // [head][token]: 1 / sum_keys 2^(score - maximum)
+    float* const sDD = sID + NH * TOKMAX; // [head][token]: sum_keys P dP
+    const long jet = blockIdx.x;
+    const int nqt = (p.L + 31) >> 5, nkt = (p.S + 31) >> 5;
+    const bool isq = w < nqt, isk = w < nkt;
+    const int tok = 32 * w + r;
+    const long xrow = jet * p.L + min(tok, p.L - 1), yrow = jet * p.S + min(tok, p.S - 1);
+    const bool xvalid = isq && tok < p.L, yvalid = isk && tok < p.S;
+    f32x16 dzf[NT], zt[NT], zat[LN ? NT : 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        dzf[t] = rows_to_tile(p.dout, p.lddout, xrow, t, h);
+        zt[t] = rows_to_tile(p.save_z, p.E, xrow, t, h);
+        if constexpr (LN) zat[t] = rows_to_tile(p.save_za, p.E, xrow, t, h);
+    }
+    mab_fill(sIn, p.Win, 2 * nfIn * 1024);
+    mab_fill(sF, p.Wf, 2 * nfE * 1024);
+    mab_fill(sInT, p.WinT, 2 * nfInT * 1024);
+    mab_fill(sOT, p.WoT, 2 * nfE * 1024);
+    mab_fill(sFT, p.WfT, 2 * nfE * 1024);
+    for (int i = threadIdx.x; i < 128 * NT; i += blockDim.x) sBin[i] = (i < 96 * NT ? p.bin[i] : p.bf[i - 96 * NT]) * zs;
+    __syncthreads();
+    const WImg rIn = sIn, rF = sF, rInT = sInT, rOT = sOT, rFT = sFT;
+    f32x16 dxa[NT], dya[NT];              // (dya: the key side -- dy of a cross block, the second half of dx of a self-attention block)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { dxa[t] = zero16(); dya[t] = zero16(); }
+
+    if (isq) {
+        // ---- the feed-forward half on the wave's own queries: du, dza (rows + fragments), dxa = dza
+        VB dzah[KS], dzal[KS];
+        mab_bwd_ff<NT, LN>(p, dzf, zt, zat, xvalid ? 1.f : 0.f, rF, rFT, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, h, lane16, dzah, dzal, dxa);
+        // ---- the query side of the own tile: q heads and dO heads as B fragments, D = <dO, O>
+        VF qh[NH], ql[NH];
+        VB dobh[NH], dobl[NH];
+        float Dq[NH];
+        {
+            VF xh[KS], xl[KS];
+            rows_to_frags<KS>(p.x, p.ldx, xrow, sa, h, xh, xl);
+            static_for<0, NT>([&](auto tc) {
+                MPG_CI(t, tc);
+                const f32x16 Qn = proj_n<KS>(rIn, nfIn, t, xh, xl, bias_regs(sBin, t, h), lane16);
+                const f32x16 dOn = proj_n<KS>(rOT, nfE, t, dzah, dzal, zero16(), lane16);
+                static_for<0, 2>([&](auto ac) {
+                    MPG_CI(a, ac);
+                    tile_frag(Qn, a, inv_zs * sa * 0.25f, qh[2 * t + a], ql[2 * t + a]);
+                    tile_frag(dOn, a, 1.f, dobh[2 * t + a], dobl[2 * t + a]);
+                });
+            });
+        }
+        // ---- pass 1 over the key tiles: the running maximum, sum and sum of P dP of every (query, head).  D = sum_keys P dP is
+        // taken from the very dP values pass 2 works with (same products, same order): dS = P (dP - D) subtracts two numbers that
+        // share the common part of V -- its bias --, and <dO, O>, which is the same sum in exact arithmetic, does not share the 2^-17
+        // of the bf16 pairs with them (measured: 9e-4 on the heads with the largest biases, 7e-6 this way)
+        // P is formed as 2^(s - max) / sum in both passes and by the key owners: with c = max + log2(sum) folded into ONE
+        // subtraction the rounding of c (|c| up to ~100) left sum_keys P at 1 +- 1e-5, and dS = P (dP - D) no longer summed to zero
+        // over the keys -- times the common part of K (its bias) that was 1e-3 of dQ on the heads with the largest biases
+        float cq[NH], iden[NH];
+        {
+            float mrun[NH], den[NH];
+#pragma unroll
+            for (int i = 0; i < NH; ++i) { mrun[i] = -INFINITY; den[i] = 0.f; Dq[i] = 0.f; }
+            for (int kt = 0; kt < nkt; ++kt) {
+                const long kr = jet * p.S + min(32 * kt + r, p.S - 1);
+                VF yh[KS], yl[KS];
+                rows_to_frags<KS>(p.y, p.ldy, kr, sa, h, yh, yl);
+                const f32x16 kneg = key_mask_tile(p.ignore, p.x, jet, p.S, h, kt);
+                static_for<0, NT>([&](auto tc) {
+                    MPG_CI(t, tc);
+                    const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(sBin, NT + t, h), lane16);
+                    const f32x16 Vn = proj_n<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_regs(sBin, 2 * NT + t, h), lane16);
+                    static_for<0, 2>([&](auto ac) {
+                        MPG_CI(a, ac);
+                        constexpr int hd = 2 * t + a;
+                        VF kh, kl;
+                        tile_frag(Kn, a, inv_zs * sa, kh, kl);
+                        VB vbh, vbl;
+                        tile_frag(Vn, a, inv_zs, vbh, vbl);
+                        f32x16 sx = mfma3(kh, kl, qh[hd], ql[hd], zero16());
+                        const f32x16 dP = mfma3(vbh, vbl, dobh[hd], dobl[hd], zero16());
+                        float mx = -INFINITY;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { sx[i] = sx[i] * sc2 + kneg[i]; mx = fmaxf(mx, sx[i]); }
+                        mx = fmaxf(mx, other_half(mx));
+                        const float mnew = fmaxf(mrun[hd], mx);
+                        const float msafe = mnew == -INFINITY ? 0.f : mnew;
+                        float part = 0.f, dpart = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const float e = __builtin_amdgcn_exp2f(sx[i] - msafe);
+                            part += e;
+                            dpart = fmaf(e, dP[i], dpart);
+                        }
+                        part += other_half(part);
+                        dpart += other_half(dpart);
+                        const float resc = __builtin_amdgcn_exp2f(mrun[hd] - msafe);
+                        den[hd] = den[hd] * resc + part;
+                        Dq[hd] = Dq[hd] * resc + dpart;
+                        mrun[hd] = mnew;
+                    });
+                });
+            }
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {
+                const bool live = den[i] > 0.f && xvalid;
+                cq[i] = live ? mrun[i] : INFINITY;
+                iden[i] = live ? 1.f / den[i] : 0.f;
+                Dq[i] *= iden[i];
+                if (h == 0) { sCQ[i * TOKMAX + tok] = cq[i]; sID[i * TOKMAX + tok] = iden[i]; sDD[i * TOKMAX + tok] = Dq[i]; }
+            }
+        }
+        // ---- pass 2: dS tile by tile, dQ' accumulated over the key tiles
+        f32x16 dqa[NH];
+#pragma unroll
+        for (int i = 0; i < NH; ++i) dqa[i] = zero16();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const long kr = jet * p.S + min(32 * kt + r, p.S - 1);
+            VF yh[KS], yl[KS];
+            rows_to_frags<KS>(p.y, p.ldy, kr, sa, h, yh, yl);
+            const f32x16 kneg = key_mask_tile(p.ignore, p.x, jet, p.S, h, kt);
+            static_for<0, NT>([&](auto tc) {
+                MPG_CI(t, tc);
+                const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(sBin, NT + t, h), lane16);
+                const f32x16 Vn = proj_n<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_regs(sBin, 2 * NT + t, h), lane16);
+                const f32x16 Kp = proj_t<KS>(rIn, nfIn, NT + t, yh, yl, bias_lanes(sBin, NT + t, r), lane16);
+                VB kph[2], kpl[2];
+                tile_frag(Kp, 0, inv_zs, kph[0], kpl[0]);
+                tile_frag(Kp, 1, inv_zs, kph[1], kpl[1]);
+                static_for<0, 2>([&](auto ac) {
+                    MPG_CI(a, ac);
+                    constexpr int hd = 2 * t + a;
+                    VF kh, kl;
+                    tile_frag(Kn, a, inv_zs * sa, kh, kl);
+                    VB vbh, vbl;
+                    tile_frag(Vn, a, inv_zs, vbh, vbl);
+                    f32x16 sx = mfma3(kh, kl, qh[hd], ql[hd], zero16());
+                    const f32x16 dP = mfma3(vbh, vbl, dobh[hd], dobl[hd], zero16());
+                    f32x16 dS;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float pr = __builtin_amdgcn_exp2f(sx[i] * sc2 + kneg[i] - cq[hd]) * iden[hd];
+                        dS[i] = pr * (dP[i] - Dq[hd]) * 0.25f;
+                    }
+                    VB dsh[2], dsl[2];
+                    tile_frag(dS, 0, 1.f, dsh[0], dsl[0]);
+                    tile_frag(dS, 1, 1.f, dsh[1], dsl[1]);
+                    dqa[hd] = mfma3(kph[0], kpl[0], dsh[0], dsl[0], dqa[hd]);
+                    dqa[hd] = mfma3(kph[1], kpl[1], dsh[1], dsl[1], dqa[hd]);
+                });
+            });
+        }
+        static_for<0, NT>([&](auto tc) {
+            MPG_CI(t, tc);
+            f32x16 dQt;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dQt[j] = dqa[2 * t][j]; dQt[8 + j] = dqa[2 * t + 1][8 + j]; }
+            if (p.dq != nullptr && xvalid) tile_to_rows(p.dq, p.lddq, xrow, t, h, dQt, 1.f);
+            VB fh[2], fl[2];
+            tile_frag(dQt, 0, 1.f, fh[0], fl[0]); tile_frag(dQt, 1, 1.f, fh[1], fl[1]);
+            acc_wt<NT>(rInT, nfInT, 3 * KS, 2 * t, fh, fl, dxa, lane16);
+        });
+    }
+    __syncthreads();      // every query's c and D are in LDS, every row of dza in memory (workgroup scope)
+
+    if (isk) {
+        // ---- the wave's own keys against every query tile: dK', dV'
+        const float ign_r = (p.ignore != nullptr ? p.ignore + jet * p.S : p.x)[p.ignore != nullptr ? min(tok, p.S - 1) : 0];
+        const bool key_off = !yvalid || (p.ignore != nullptr && ign_r != 0.f);
+        f32x16* const dkv_acc = dya;
+        VF yh[KS], yl[KS];
+        rows_to_frags<KS>(p.y, p.ldy, yrow, sa, h, yh, yl);
+        static_for<0, NT>([&](auto tc) {
+            MPG_CI(t, tc);
+            VF kh[2], kl[2];
+            VB vbh[2], vbl[2];
+            {
+                const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(sBin, NT + t, h), lane16);
+                const f32x16 Vn = proj_n<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_regs(sBin, 2 * NT + t, h), lane16);
+                static_for<0, 2>([&](auto ac) {
+                    MPG_CI(a, ac);
+                    tile_frag(Kn, a, inv_zs * sa, kh[a], kl[a]);
+                    tile_frag(Vn, a, inv_zs, vbh[a], vbl[a]);
+                });
+            }
+            f32x16 dka[2] = {zero16(), zero16()}, dva[2] = {zero16(), zero16()};
+            for (int qt = 0; qt < nqt; ++qt) {
+                const int qtok = 32 * qt + r;
+                const long qrow = jet * p.L + min(qtok, p.L - 1);
+                VF qh[2], ql[2];
+                VB qph[2], qpl[2], dobh[2], dobl[2], doph[2], dopl[2];
+                {
+                    VF xh[KS], xl[KS];
+                    rows_to_frags<KS>(p.x, p.ldx, qrow, sa, h, xh, xl);
+                    const f32x16 Qn = proj_n<KS>(rIn, nfIn, t, xh, xl, bias_regs(sBin, t, h), lane16);
+                    const f32x16 Qp = proj_t<KS>(rIn, nfIn, t, xh, xl, bias_lanes(sBin, t, r), lane16);
+                    static_for<0, 2>([&](auto sc) {
+                        MPG_CI(s2, sc);
+                        tile_frag(Qn, s2, inv_zs * sa * 0.25f, qh[s2], ql[s2]);
+                        tile_frag(Qp, s2, inv_zs, qph[s2], qpl[s2]);
+                    });
+                }
+                {
+                    VB dzh[KS], dzl[KS];
+                    rows_to_frags<KS>(p.dza, p.E, qrow, qtok < p.L ? 1.f : 0.f, h, dzh, dzl);
+                    const f32x16 dOn = proj_n<KS>(rOT, nfE, t, dzh, dzl, zero16(), lane16);
+                    const f32x16 dOp = proj_t<KS>(rOT, nfE, t, dzh, dzl, zero16(), lane16);
+                    static_for<0, 2>([&](auto sc) {
+                        MPG_CI(s2, sc);
+                        tile_frag(dOn, s2, 1.f, dobh[s2], dobl[s2]);
+                        tile_frag(dOp, s2, 1.f, doph[s2], dopl[s2]);
+                    });
+                }
+                static_for<0, 2>([&](auto ac) {
+                    MPG_CI(a, ac);
+                    constexpr int hd = 2 * t + a;
+                    const f32x16 sT = mfma3(qh[a], ql[a], kh[a], kl[a], zero16());      // queries in registers, keys on lanes
+                    const f32x16 dPT = mfma3(dobh[a], dobl[a], vbh[a], vbl[a], zero16());
+                    f32x16 pT, dST;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int i = 4 * g + e, qi = 32 * qt + 8 * g + 4 * h + e;   // the query this register belongs to
+                            const float c_q = sCQ[hd * TOKMAX + qi], id_q = sID[hd * TOKMAX + qi], D_q = sDD[hd * TOKMAX + qi];
+                            const float pr = key_off ? 0.f : __builtin_amdgcn_exp2f(sT[i] * sc2 - c_q) * id_q;
+                            pT[i] = pr;
+                            dST[i] = pr * (dPT[i] - D_q) * 0.25f;
+                        }
+                    VB pth[2], ptl[2], dsth[2], dstl[2];
+                    static_for<0, 2>([&](auto sc) {
+                        MPG_CI(s2, sc);
+                        tile_frag(pT, s2, 1.f, pth[s2], ptl[s2]);
+                        tile_frag(dST, s2, 1.f, dsth[s2], dstl[s2]);
+                    });
+                    dka[a] = mfma3(qph[0], qpl[0], dsth[0], dstl[0], dka[a]);
+                    dka[a] = mfma3(qph[1], qpl[1], dsth[1], dstl[1], dka[a]);
+                    dva[a] = mfma3(doph[0], dopl[0], pth[0], ptl[0], dva[a]);
+                    dva[a] = mfma3(doph[1], dopl[1], pth[1], ptl[1], dva[a]);
+                });
+            }
+            f32x16 dKt, dVt;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dKt[j] = dka[0][j]; dKt[8 + j] = dka[1][8 + j]; dVt[j] = dva[0][j]; dVt[8 + j] = dva[1][8 + j]; }
+            if (p.dk != nullptr && yvalid) {
+                tile_to_rows(p.dk, p.lddkv, yrow, t, h, dKt, 1.f);
+                tile_to_rows(p.dv, p.lddkv, yrow, t, h, dVt, 1.f);
+            }
+            VB fh[2], fl[2];
+            tile_frag(dKt, 0, 1.f, fh[0], fl[0]); tile_frag(dKt, 1, 1.f, fh[1], fl[1]);
+            acc_wt<NT>(rInT, nfInT, 3 * KS, 2 * (NT + t), fh, fl, dkv_acc, lane16);
+            tile_frag(dVt, 0, 1.f, fh[0], fl[0]); tile_frag(dVt, 1, 1.f, fh[1], fl[1]);
+            acc_wt<NT>(rInT, nfInT, 3 * KS, 2 * (2 * NT + t), fh, fl, dkv_acc, lane16);
+        });
+    }
+    static_for<0, NT>([&](auto tc) {
+        MPG_CI(t, tc);
+        if constexpr (CROSS) {
+            if (p.dx != nullptr && xvalid) tile_to_rows(p.dx, p.lddx, xrow, t, h, dxa[t], 1.f);
+            if (p.dy != nullptr && yvalid) tile_to_rows(p.dy, p.lddy, yrow, t, h, dya[t], 1.f);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dxa[t][i] += dya[t][i];
+            if (p.dx != nullptr && xvalid) tile_to_rows(p.dx, p.lddx, xrow, t, h, dxa[t], 1.f);
+        }
+    });
 }
 
 // ---- The backward with TWO WAVES PER JET (E = 64), the split of mab_fwd_half: wave T owns tile T of du, dz, dza, the two heads
@@ -1367,7 +1825,7 @@ __global__ __launch_bounds__(256) void mab_bwd2_kernel(const MpgMab p) {
 }
 
 int mab_check(const MpgMab* p) {
-    if (p->B < 1 || p->L < 1 || p->S < 1 || p->L > 32 || p->S > 32) return -1;
+    if (p->B < 1 || p->L < 1 || p->S < 1 || p->L > 160 || p->S > 160) return -1;   // (sets of up to 5 tiles of 32 tokens)
     if ((p->E != 32 && p->E != 64) || p->H * 16 != p->E) return -2;
     if (!(p->alpha >= 0.f && p->alpha <= 1.f)) return -4;
     if (p->ldx % 4 || p->ldy % 4 || p->ldo % 4) return -3;
@@ -1433,6 +1891,22 @@ extern "C" int mpg_mab_bwd(const MpgMab* p, void* stream) {
     const bool cross = p->y != p->x;
     const int NT = p->E / 32;
     const int lds = 2 * 1024 * (2 * 3 * NT * 2 * NT + 3 * NT * 2 * NT) + 4 * 128 * NT;   // Win, WinT (3E x E) + Wf, WoT, WfT (E x E) + biases
+    if (p->L > 32 || p->S > 32 || getenv("MPG_MAB_BIG") != nullptr) {   // large sets: a workgroup per jet, a wave per tile of 32 tokens (mab_bwdN_kernel)
+        if (p->dza == nullptr) return -5;   // (the key owners read the rows of dza back)
+        const bool ln = p->ln1_w != nullptr;
+        if (ln && (p->ln2_w == nullptr || p->save_za == nullptr || !(p->ln_eps > 0.f) || (p->dn1 == nullptr) != (p->gn1 == nullptr) ||
+                   (p->dn1 == nullptr) != (p->dn2 == nullptr) || (p->dn1 == nullptr) != (p->gn2 == nullptr))) return -6;
+        const int nw = (std::max(p->L, p->S) + 31) / 32, ldsN = lds + 4 * 3 * (2 * NT) * 160;
+        const dim3 grid(p->B), block(64 * nw);
+#define MPG_BWDN(NTv, CR, LNv) do { MPG_ENSURE_LDS((mab_bwdN_kernel<NTv, CR, LNv>), ldsN); \
+        hipLaunchKernelGGL((mab_bwdN_kernel<NTv, CR, LNv>), grid, block, ldsN, st, *p); } while (0)
+        if (NT == 2) { if (cross) { if (ln) MPG_BWDN(2, true, true); else MPG_BWDN(2, true, false); }
+                       else { if (ln) MPG_BWDN(2, false, true); else MPG_BWDN(2, false, false); } }
+        else { if (cross) { if (ln) MPG_BWDN(1, true, true); else MPG_BWDN(1, true, false); }
+               else { if (ln) MPG_BWDN(1, false, true); else MPG_BWDN(1, false, false); } }
+#undef MPG_BWDN
+        return (int)hipGetLastError();
+    }
     if (p->ln1_w != nullptr) {   // layer_norm=True: one wave per jet
         if (p->ln2_w == nullptr || p->save_za == nullptr || !(p->ln_eps > 0.f) || (p->dn1 == nullptr) != (p->gn1 == nullptr) ||
             (p->dn1 == nullptr) != (p->dn2 == nullptr) || (p->dn1 == nullptr) != (p->gn2 == nullptr)) return -6;
@@ -1471,6 +1945,17 @@ extern "C" int mpg_mab_fwd(const MpgMab* p, void* stream) {
     const int NT = p->E / 32;
     const int lds = 2 * 1024 * (3 * NT * 2 * NT + 2 * NT * 2 * NT) + 4 * 160 * NT;   // Win + Wo, Wf + biases
     const bool ln = p->ln1_w != nullptr;
+    if (p->L > 32 || p->S > 32 || getenv("MPG_MAB_BIG") != nullptr) {   // large sets: a workgroup per jet, a wave per tile of 32 queries (mab_fwdN_kernel)
+        if (ln && (p->ln1_b == nullptr || p->ln2_w == nullptr || p->ln2_b == nullptr || !(p->ln_eps > 0.f))) return -6;
+        const int nw = (std::max(p->L, p->S) + 31) / 32;
+        const dim3 grid(p->B), block(64 * nw);
+#define MPG_FWDN(NTv, LNv) do { MPG_ENSURE_LDS((mab_fwdN_kernel<NTv, LNv>), lds); \
+        hipLaunchKernelGGL((mab_fwdN_kernel<NTv, LNv>), grid, block, lds, st, *p); } while (0)
+        if (NT == 2) { if (ln) MPG_FWDN(2, true); else MPG_FWDN(2, false); }
+        else { if (ln) MPG_FWDN(1, true); else MPG_FWDN(1, false); }
+#undef MPG_FWDN
+        return (int)hipGetLastError();
+    }
     if (ln) {   // layer_norm=True: one wave per jet (a token's statistics run over both feature tiles)
         if (p->ln1_b == nullptr || p->ln2_w == nullptr || p->ln2_b == nullptr || !(p->ln_eps > 0.f)) return -6;
         if (p->E == 64) {
@@ -1502,6 +1987,7 @@ extern "C" int mpg_mab_chain_fwd(const MpgMabChain* c, void* stream) {
     if (c->n < 1 || c->n > MPG_MAB_CHAIN_MAX) return -1;
     const MpgMab& p0 = c->blk[0];
     if (const int rc = mab_check(&p0)) return rc;
+    if (p0.L > 32) return -1;             // (the chain keeps a jet's rows in ONE wave's registers)
     for (int b = 0; b < c->n; ++b) {
         const MpgMab& p = c->blk[b];
         // self-attention blocks of one shape on one set of jets, each taking the rows the one before it writes

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 from torch import Tensor, nn
 
@@ -39,7 +41,8 @@ def _lin(x2, W, b, row0, rows):
 
 
 class MAB(nn.Module):
-    fused = True   # class-wide switch: eligible blocks run as one launch (tests compare both paths)
+    # class-wide switch: eligible blocks run as one launch (tests compare both paths; MPG_MAB_FUSED=0: block by block from the start)
+    fused = os.environ.get("MPG_MAB_FUSED", "1") != "0"
 
     def __init__(self, embed_dim: int, num_heads: int, ff_layers: list = [], layer_norm: bool = False,
                  dropout_p: float = 0.0, final_linear: bool = True, linear_args={}):
@@ -226,7 +229,7 @@ def _run_sabs(sabs, x: Tensor, am) -> Tensor:
     sabs = list(sabs)
     B, N, E = x.shape
     chainable = (x.is_cuda and os.environ.get("MPG_MAB_CHAIN", "1") != "0" and not ops.double_backward_on(x.device)
-                 and B * N > 0)
+                 and B * N > 0 and N <= ops.MAB_CHAIN_TOKENS)
     i = 0
     while i < len(sabs):
         run = []

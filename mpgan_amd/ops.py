@@ -1245,8 +1245,13 @@ class PackedMAB:
 
 
 def mab_fusable(E: int, H: int, L: int, S: int) -> bool:
-    """Shapes ``mpg_mab_fwd`` / ``mpg_mab_bwd`` take: sets of at most 32 tokens, E = 32 or 64, heads of 16 features."""
-    return E in (32, 64) and H * 16 == E and 1 <= L <= 32 and 1 <= S <= 32
+    """Shapes ``mpg_mab_fwd`` / ``mpg_mab_bwd`` take: sets of at most 160 tokens (up to 32: a wave or two per jet; beyond: a
+    workgroup per jet, a wave per tile of 32 tokens), E = 32 or 64, heads of 16 features."""
+    return E in (32, 64) and H * 16 == E and 1 <= L <= MAB_MAX_TOKENS and 1 <= S <= MAB_MAX_TOKENS
+
+
+MAB_MAX_TOKENS = 160
+MAB_CHAIN_TOKENS = 32      # (``mpg_mab_chain_fwd`` keeps a jet's rows in one wave's registers)
 
 
 def _mab_struct(x2, y2, ignore, pk, bin_, bo, bf, B, L, S, E, H, alpha, ff_act, tag, thr_mab, sc_mab, thr_ff, sc_ff):
@@ -1345,6 +1350,9 @@ def _mab_backward_block(x2, y2, ignore, o, z, params, pk, cfg, gout, need_x, nee
             m.dq, m.lddq, m.dk, m.dv, m.lddkv = _p(dqkv), 3 * E, _p(dqkv, E), _p(dqkv, 2 * E), 3 * E
         dza, du = torch.empty_like(dout), torch.empty_like(dout)
         m.dza, m.du = _p(dza), _p(du)
+    elif L > 32 or S > 32:   # (large sets: the waves that own the key tiles read the rows of dza back)
+        dza = torch.empty_like(dout)
+        m.dza = _p(dza)
     lnrows = None
     if ln is not None:
         _mab_set_ln(m, ln)

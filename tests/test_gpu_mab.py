@@ -50,7 +50,7 @@ def launches():
         _lib._lib = saved
 
 
-@pytest.mark.parametrize("name,ci", [("m30", 0), ("u30", 1)])
+@pytest.mark.parametrize("name,ci", [("m30", 0), ("u30", 1), ("m150", 2)])
 def test_forward_vs_reference_golden(name, ci, launches):
     """SAB / PMA / ISAB outputs of the fused launch (no autograd) against the reference's own outputs."""
     from oracle import train_ref as T
@@ -98,9 +98,11 @@ def test_forward_exact_dropout_and_embed32():
         assert abs(frac - (1 - p)) < 0.02
 
 
-@pytest.mark.parametrize("name,ci", [("m30", 0), ("u30", 1)])
+@pytest.mark.parametrize("name,ci", [("m30", 0), ("u30", 1), ("m150", 2)])
 def test_blocks_forward_backward_vs_reference_golden(name, ci, launches):
-    """SAB / PMA / ISAB through autograd: one launch each way per block, gradients against the reference's."""
+    """SAB / PMA / ISAB through autograd: one launch each way per block, gradients against the reference's.  m150: sets of 150
+    tokens (--num-hits 150) -- SAB 150 x 150, PMA 1 x 150, ISAB 10 x 150 and 150 x 10 -- on the large-set kernels (a workgroup per
+    jet, a wave per tile of 32 tokens)."""
     from oracle import train_ref as T
     from mpgan_amd.gapt import _attn_mask
     g = load_golden(f"gapt_blocks_{name}_f64.npz")
@@ -127,12 +129,16 @@ def test_backward_exact_dropout_vs_oracle():
     from oracle import train_ref as T, gapt_ref as R
     from mpgan_amd import ops
     from mpgan_amd.gapt import MAB
-    for E, H, p, L in ((64, 4, 0.5, 30), (32, 2, 0.3, 30), (64, 4, 0.5, 10)):
+    for E, H, p, L, N in ((64, 4, 0.5, 30, 30), (32, 2, 0.3, 30, 30), (64, 4, 0.5, 10, 30),
+                          # large sets (33 ... 160 tokens): self-attention at 150 and 33, both cross shapes of an ISAB, E = 32
+                          (64, 4, 0.5, 150, 150), (64, 4, 0.3, 33, 33), (64, 4, 0.5, 10, 150), (64, 4, 0.5, 150, 10),
+                          (32, 2, 0.5, 97, 97), (64, 4, 0.5, 1, 160)):
         la = dict(LA, dropout_p=p)
         blk = MAB(E, H, ff_layers=[], final_linear=False, layer_norm=False, dropout_p=p, linear_args=la).cuda().train()
         sd = T.init_state_dict(T._mab_shapes("mab", E), 11, torch.float32)
         blk.load_state_dict({k[len("mab."):]: v for k, v in sd.items()})
-        B, N = 7, 30
+        assert blk._fused_ok(torch.empty(1, device="cuda"), L, N)
+        B = 7 if N <= 32 else 3
         gen = torch.Generator().manual_seed(5)
         yk = torch.randn(B, N, E, generator=gen)
         xq = yk if L == N else torch.randn(B, L, E, generator=gen)
@@ -196,7 +202,9 @@ def test_layer_norm_block_exact_dropout_vs_oracle(launches):
     from oracle import train_ref as T, gapt_ref as R
     from mpgan_amd import ops
     from mpgan_amd.gapt import MAB
-    for E, H, p, L in ((64, 4, 0.5, 30), (32, 2, 0.3, 30), (64, 4, 0.0, 10), (32, 2, 0.5, 7)):
+    for E, H, p, L, N in ((64, 4, 0.5, 30, 30), (32, 2, 0.3, 30, 30), (64, 4, 0.0, 10, 30), (32, 2, 0.5, 7, 30),
+                          # large sets: the norms inside the workgroup-per-jet kernels
+                          (64, 4, 0.5, 150, 150), (64, 4, 0.3, 10, 150), (32, 2, 0.5, 70, 70)):
         la = dict(LA, dropout_p=p)
         blk = MAB(E, H, ff_layers=[], final_linear=False, layer_norm=True, dropout_p=p, linear_args=la).cuda().train()
         shapes = dict(T._mab_shapes("mab", E))
@@ -205,7 +213,7 @@ def test_layer_norm_block_exact_dropout_vs_oracle(launches):
         for k in ("mab.norm1.weight", "mab.norm2.weight"):   # (around 1, as a trained norm's)
             sd[k] = 1.0 + 0.3 * sd[k] / sd[k].abs().max()
         blk.load_state_dict({k[len("mab."):]: v for k, v in sd.items()})
-        B, N = 9, 30
+        B = 9 if N <= 32 else 3
         gen = torch.Generator().manual_seed(6)
         yk = torch.randn(B, N, E, generator=gen)
         xq = yk if L == N else torch.randn(B, L, E, generator=gen)
@@ -269,3 +277,43 @@ def test_layer_norm_pooling_and_induced_blocks_equal_block_by_block(kind):
     assert any(".norm" in k for k in g1)
     for k in g1:
         assert rel_err(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < TIGHT, k
+
+
+def test_large_set_kernels_on_small_sets_agree_with_the_one_wave_kernels(monkeypatch):
+    """``MPG_MAB_BIG=1`` sends sets of <= 32 tokens through the large-set kernels too (a workgroup per jet, a wave per tile of 32
+    tokens: running maximum / sum over the key tiles in the forward; statistics pass, dS pass and the key owners' pass in the
+    backward): the same block through two independent schedules -- SAB with padded keys, cross attention 10 x 30, PMA's shared
+    seed row, E = 32 -- agrees to rounding in the output and in every gradient."""
+    from mpgan_amd.gapt import SAB, PMA, MAB, _attn_mask
+    la = dict(LA, dropout_p=0.5)
+    gen = torch.Generator().manual_seed(8)
+    cases = [("sab", lambda: SAB(**dict(SAB_ARGS, dropout_p=0.5, linear_args=la)), 64),
+             ("pma", lambda: PMA(num_seeds=1, **SAB_ARGS), 64),
+             ("sab32", lambda: SAB(**dict(SAB_ARGS, embed_dim=32, num_heads=2)), 32)]
+    for name, ctor, E in cases:
+        torch.manual_seed(3)
+        blk = ctor().cuda().train()
+        x = torch.randn(7, 30, E, generator=gen).cuda()
+        mask = (torch.rand(7, 30, 1, generator=gen) < 0.7).float().cuda()
+        mask[:, 0] = 1
+        res = []
+        for big in (True, False):
+            if big:
+                monkeypatch.setenv("MPG_MAB_BIG", "1")
+            else:
+                monkeypatch.delenv("MPG_MAB_BIG", raising=False)
+            from mpgan_amd import ops
+            ops.set_seed(77)
+            import itertools
+            ops.dev_state(x.device).tags = itertools.count(5000)   # (the same dropout sites, hence masks, in both runs)
+            blk.zero_grad()
+            xx = x.clone().requires_grad_(True)
+            y = blk(xx, _attn_mask(mask))
+            y.square().sum().backward()
+            res.append((y.detach().cpu().numpy(), xx.grad.cpu().numpy(), {k: q.grad.cpu().numpy().copy() for k, q in blk.named_parameters()}))
+        (y1, dx1, g1), (y0, dx0, g0) = res
+        assert np.isfinite(y1).all() and np.isfinite(dx1).all(), name
+        assert rel_err(y1, y0) < 1e-5, name
+        assert rel_err(dx1, dx0) < 1e-4, name
+        for k in g1:
+            assert rel_err(g1[k], g0[k]) < 1e-4, (name, k)
