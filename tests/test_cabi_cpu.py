@@ -78,7 +78,8 @@ def test_host_helpers():
         sc = ops._sender_chunks(B, N)
         assert -(-N // sc) <= ops.MAX_CHUNK_SENDERS
     assert ops.mab_fusable(64, 4, 30, 30) and ops.mab_fusable(32, 2, 1, 30) and ops.mab_fusable(64, 4, 10, 30)
-    assert not ops.mab_fusable(64, 4, 150, 150) and not ops.mab_fusable(64, 8, 30, 30) and not ops.mab_fusable(128, 8, 30, 30)
+    assert ops.mab_fusable(64, 4, 150, 150) and ops.mab_fusable(64, 4, 1, 160) and not ops.mab_fusable(64, 4, 161, 161)   # (large-set kernels: 5 tiles of 32)
+    assert not ops.mab_fusable(64, 8, 30, 30) and not ops.mab_fusable(128, 8, 30, 30)
     a, b = ops.next_tag(), ops.next_tag()
     assert b - a == 8
 
