@@ -83,16 +83,14 @@ MPG_DEV void split8(const float* v, V& hi, V& lo) {
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 MPG_DEV uint32_t cvt_pk_bf16(float a, float b) {
     uint32_t r;
-#ifdef MPG_CVT_BUILTIN
-    // (the conversion as the compiler's own instruction: behind inline assembly the hazard recognizer neither sees the write
-    // that an MFMA reads two instructions later nor the read of an MFMA's result -- csrc/mab.hip's large-set backward lost the lo
-    // halves of some heads' fragments that way, 1e-3 of dQ / dK, until the instruction was visible to it)
+    // The conversion as the compiler's own instruction (a pair converts to ONE v_cvt_pk_bf16_f32), not inline assembly: behind
+    // assembly the hazard recognizer sees neither the write that an MFMA reads two instructions later nor the read of an MFMA's
+    // result.  csrc/mab.hip's large-set backward lost the lo halves of some heads' fragments that way -- 1e-3 of dQ / dK on those
+    // heads, gone with `s_nop 3` behind the instruction -- until the instruction was visible to the compiler.  Same values; the
+    // headline and GAPT benches are unchanged (128.9k / 129.0k, 986k / 981k jets/s, old and new library alternated on one box).
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     const f32x2_t ab = {a, b};
     r = __builtin_bit_cast(uint32_t, __builtin_convertvector(ab, bf16x2));
-#else
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-#endif
     return r;
 }
 template <>

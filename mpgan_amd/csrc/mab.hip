@@ -19,7 +19,6 @@
 //                    tile, which is again the B operand of the out-projection.
 // Products run as fp16 hi/lo 3-term splits (common.h) with power-of-two operand scales; the backward kernel recomputes
 // the same values and carries gradients as bf16 hi/lo.
-#define MPG_CVT_BUILTIN 1   // (see common.h: cvt_pk_bf16)
 #include "common.h"
 #include "../../include/mpgan_amd.h"
 #include <stdlib.h>
