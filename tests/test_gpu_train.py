@@ -264,6 +264,63 @@ def test_train_step_n150_vs_oracle():
     assert abs(float(ts.D_loss) - dl) < 1e-4 * abs(dl) and abs(float(ts.G_loss) - gl) < 1e-4 * abs(gl)
 
 
+def test_gapt_train_step_n150_vs_oracle():
+    """GAPT at --num-hits 150 (setup_training.py:415): one train_D + train_G against the oracle's iteration, B = 3, D dropout off.
+    Every attention block -- 4 + 2 SABs of 150 x 150 tokens, D's pooling block 1 x 150 -- runs as ONE launch each way on the
+    large-set kernels (asserted: no mpg_gemm / mpg_attn_* launch in the iteration); losses 1e-4, first-iteration gradients of both
+    networks 1e-3 with the oracle's own fp32 evaluation as the control."""
+    from oracle import train_ref as T
+    from oracle.train_ref import synthetic_batch
+    from mpgan_amd import train, _lib
+    B, N = 3, 150
+    G, D = train.default_gapt(N, disc_dropout=0.0)
+    sdG = T.init_state_dict(T.gapt_param_shapes(True), 41, torch.float64)
+    sdD = T.init_state_dict(T.gapt_param_shapes(False), 42, torch.float64)
+    G.load_state_dict({k: v.float() for k, v in sdG.items()})
+    D.load_state_dict({k: v.float() for k, v in sdD.items()})
+    data, labels = synthetic_batch(B, N, seed=12)
+    gen = torch.Generator().manual_seed(7)
+    nD, nG = torch.randn(B, N, 64, generator=gen) * 0.2, torch.randn(B, N, 64, generator=gen) * 0.2
+    ts = train.TrainStep(G, D, B, N, latent=64, use_graphs=False, lr_disc=0.0, lr_gen=train.LR_GAPT[1])
+    ts.set_batch(data.cuda(), labels.cuda())
+    ts.fixed_noise = (nD.cuda(), nG.cuda())
+    counts = {}
+    real = _lib.lib()
+
+    class Spy:
+        def __getattr__(self, name):
+            f = getattr(real, name)
+            if not name.startswith("mpg_"):
+                return f
+            def g(*a):
+                counts[name] = counts.get(name, 0) + 1
+                return f(*a)
+            return g
+    saved, _lib._lib = _lib._lib, Spy()
+    try:
+        ts._seg_D()
+        gradD = {k: p.grad.detach().double().cpu().numpy().copy() for k, p in D.named_parameters()}
+        ts._seg_G()
+        gradG = {k: p.grad.detach().double().cpu().numpy().copy() for k, p in G.named_parameters()}
+        ts._seg_end()
+    finally:
+        _lib._lib = saved
+    torch.cuda.synchronize()
+    print(counts)
+    assert counts.get("mpg_mab_fwd", 0) + 2 * counts.get("mpg_mab_chain_fwd", 0) >= 7 and counts.get("mpg_mab_bwd", 0) >= 7, counts
+    assert not any(k in counts for k in ("mpg_gemm", "mpg_attn_fwd", "mpg_attn_bwd", "mpg_gate")), counts
+    c32 = lambda sd: {k: v.float() for k, v in sd.items()}
+    c64 = lambda sd: {k: v.clone() for k, v in sd.items()}
+    _, _, cD, cG = T.train_iteration("gapt", c32(sdD), c32(sdG), {}, {}, data.float(), labels.float(), nD.float(), nG.float(),
+                                     0.0, train.LR_GAPT[1], return_grads=True)
+    dl, gl, gD, gG = T.train_iteration("gapt", c64(sdD), c64(sdG), {}, {}, data.double(), labels.double(), nD.double(),
+                                       nG.double(), 0.0, train.LR_GAPT[1], return_grads=True)
+    num = lambda d: {k: v.detach().double().numpy() for k, v in d.items()}
+    assert abs(float(ts.D_loss) - dl) < 1e-4 * abs(dl) and abs(float(ts.G_loss) - gl) < 1e-4 * abs(gl)
+    assert_grads(gradD, num(gD), 1e-3, control=num(cD), what=("gapt", N, "D"))
+    assert_grads(gradG, num(gG), 1e-3, control=num(cG), what=("gapt", N, "G"))
+
+
 def _assert_grads(module, ref, tol, control=None):
     """conftest.assert_grads on a module's .grad buffers (e.g. the last node-layer bias of D under the w / hinge
     losses has a gradient that vanishes by symmetry: real and generated jets have the same multiplicities and opposite
