@@ -6,9 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mpgan_amd import train, data, ops
 
-def run(model, B, steps, dropout):
+def run(model, B, steps, dropout, N=30):
     torch.manual_seed(4)
-    N = 30
     G, D = (train.default_mpgan(N, disc_dropout=dropout) if model == "mpgan" else train.default_gapt(N, disc_dropout=dropout))
     lr_g, lr_d = (1e-5, 3e-5) if model == "mpgan" else train.LR_GAPT
     ops.set_seed(1234, "cuda")
@@ -22,9 +21,11 @@ def run(model, B, steps, dropout):
     torch.cuda.synchronize()
     return ts.fD.flat.clone(), ts.fG.flat.clone(), float(ts.D_loss), float(ts.G_loss)
 
-for model, B, steps in (("gapt", 512, 300), ("gapt", 63, 100), ("mpgan", 256, 60)):
-    ref = run(model, B, steps, 0.5)
+# (N = 150: the sender-chunked launches, whose last-arriving workgroup adds the chunks' slabs -- in chunk order whoever it is --, and the
+# large-set attention blocks, whose waves hand rows to each other through memory behind one barrier)
+for model, B, steps, N in (("gapt", 512, 300, 30), ("gapt", 63, 100, 30), ("mpgan", 256, 60, 30), ("mpgan", 16, 40, 150), ("gapt", 32, 60, 150)):
+    ref = run(model, B, steps, 0.5, N)
     for rep in range(3):
-        got = run(model, B, steps, 0.5)
-        assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]) and ref[2:] == got[2:], (model, B, rep)
-    print(f"{model} B={B}: {steps} replayed iterations, 4 runs from scratch: identical bits (D loss {ref[2]:.4f}, G loss {ref[3]:.4f})")
+        got = run(model, B, steps, 0.5, N)
+        assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]) and ref[2:] == got[2:], (model, B, N, rep)
+    print(f"{model} B={B} N={N}: {steps} replayed iterations, 4 runs from scratch: identical bits (D loss {ref[2]:.4f}, G loss {ref[3]:.4f})", flush=True)

@@ -58,6 +58,18 @@ for c in FETCH_SIZE WRITE_SIZE; do
   done
 done > $R/gpurun_out/final/pmc_secondary_summary.txt 2>&1
 echo "secondary pmc done"
+# timelines of one replayed iteration of each workload (tools/timeline.py), from kernel traces of short runs of their own
+cd /tmp
+for w in "mpgan_n30:" "mpgan_n150:--particles 150 --batch 16" "gapt_n30:--model gapt" "gapt_n150:--model gapt --particles 150 --batch 64"; do
+  name=${w%%:*}; args=${w#*:}
+  o=$R/gpurun_out/final/trace_$name
+  rm -rf $o
+  rocprofv3 --kernel-trace --output-format csv -d $o -o t -- python3 $R/bench.py $args --steps 12 --warmup 4 --no-roofline --no-cpu-baseline --no-secondary > $o.log 2>&1 || { tail -5 $o.log; exit 1; }
+  python3 $R/tools/timeline.py $o > $R/gpurun_out/final/timeline_$name.txt 2>&1
+done
+echo "timelines done"
 cd $R
+(timeout -k 10 600 python3 tools/determinism.py) > gpurun_out/final/determinism.txt 2>&1 || { tail -5 gpurun_out/final/determinism.txt; exit 1; }
+echo "determinism done"
 (timeout -k 10 120 tools/ubench/mfma_model; timeout -k 10 120 tools/ubench/mfma_model2; timeout -k 10 120 tools/ubench/mfma_power) > gpurun_out/final/ubench.txt 2>&1
 echo "ubench done"

@@ -167,3 +167,13 @@ open(os.path.join(P, f"{tag}_ubench_mfma.txt"), "w").write(
     "# mfma_power : dependent MFMA chains on all 1024 SIMDs: with RANDOM operands the clock drops to ~1.4 GHz (22.7 ns per\n"
     "#              MFMA = 1.48 PFLOP/s dense f16 for the whole chip) against 14.9 ns = 2.26 PFLOP/s with constant operands.\n#\n" + ub)
 print("profiles written:", sorted(os.listdir(P)))
+
+# timelines of one replayed iteration per workload, and the determinism tool's output
+for name, out in (("mpgan_n30", "iteration_timeline"), ("mpgan_n150", "iteration_timeline_n150"), ("gapt_n30", "iteration_timeline_gapt"),
+                  ("gapt_n150", "iteration_timeline_gapt_n150")):
+    src = os.path.join(F, f"timeline_{name}.txt")
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(P, f"{tag}_{out}.txt"))
+src = os.path.join(F, "determinism.txt")
+if os.path.exists(src):
+    shutil.copy(src, os.path.join(P, f"{tag}_determinism.txt"))
