@@ -285,8 +285,14 @@ typedef struct MpgEdgeDw {
     const unsigned int* nbr;              /* as MpgEdgeFwd.nbr */
     const int* gexp;                      /* [B*RB] from mpg_edge_bwd */
     const float* es; const float* wq;     /* as MpgEdgeFwd (NULL = none): E1 is rebuilt with them */
+    int defer_reduce;                     /* 1: leave the per-workgroup partials in `part`; mpg_splitk_reduce_group_dw adds them up */
 } MpgEdgeDw;
 int mpg_edge_dw(const MpgEdgeDw* p, void* stream);
+/* The reduction of an mpg_edge_dw launch that ran with defer_reduce = 1 AND the grouped split-K reduction of n (0 ... MPG_GROUP_MAX)
+ * jobs of an earlier mpg_gemm_wgrad_group on the same stream, as ONE launch: the layer's edge-network and dense weight gradients
+ * land in their buffers together, and the weight-gradient tail of a layer's backward is one dependent launch shorter.  Same sums
+ * in the same order as mpg_edge_dw's own reduction + mpg_splitk_reduce_group. */
+int mpg_splitk_reduce_group_dw(const MpgReduceJob* jobs, int n, const MpgEdgeDw* p, void* stream);
 
 /* ---- attention core of GAPT's MAB ---------------------------------------------------------------
  * mpg_attn_fwd / mpg_attn_bwd: per (jet b, head h), d = E / H:

@@ -80,7 +80,7 @@ class MpgEdgeDw(C.Structure):
         ("alpha", C.c_float), ("agg_scale", C.c_float),
         ("seed", _fp), ("tag_base", C.c_uint32), ("thr", C.c_uint32), ("dscale", C.c_float),
         ("f16", C.c_int), ("nbr", _fp), ("gexp", _fp),
-        ("es", _fp), ("wq", _fp),
+        ("es", _fp), ("wq", _fp), ("defer_reduce", C.c_int),
     ]
 
 
@@ -201,6 +201,7 @@ SIGNATURES = {
     "mpg_splitk_reduce": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_void_p]),
     "mpg_gemm_wgrad_group": (C.c_int, [C.POINTER(MpgGemm), C.POINTER(C.c_int), C.c_int, C.c_void_p]),
     "mpg_splitk_reduce_group": (C.c_int, [C.POINTER(MpgReduceJob), C.c_int, C.c_void_p]),
+    "mpg_splitk_reduce_group_dw": (C.c_int, [C.POINTER(MpgReduceJob), C.c_int, C.POINTER(MpgEdgeDw), C.c_void_p]),
     "mpg_slab_sums": (C.c_int, [_fp, C.c_int, C.c_uint64, _fp, C.c_int, C.c_uint64, _fp, C.c_int, C.c_int, C.c_void_p]),
     "mpg_gate": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                            _fp, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]),

@@ -19,6 +19,7 @@
 // it is and its partner E1 is multiplied by 2^(eG - gexp) / c, c the block's dither factor (a jet whose gradients are
 // 2^-24 of the largest jet's drops out of the fp16 range, and of any fp32 sum with that jet too).
 #include "edge_common.h"
+#include "reduce_group.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -1044,10 +1045,9 @@ __global__ __launch_bounds__(512, 1) void edge_dw_kernel(const MpgEdgeDw p, cons
 
 // out = scale * 2^-eG * sum over workgroup partials, feature indices mapped back from fragment order.
 // 32 outputs x 8 partial-slices per block: the 256 partials of an output are read by 8 threads.
-__global__ __launch_bounds__(256) void edge_dw_reduce(const float* __restrict__ part, int nwg, float scale3, float scale, int accumulate,
-                                                      const int* __restrict__ gexp, int ngexp,
-                                                      float* __restrict__ dW3, float* __restrict__ dW2,
-                                                      float* __restrict__ db3, float* __restrict__ db2) {
+MPG_DEV void edge_dw_reduce_body(const int blk, const float* __restrict__ part, int nwg, float scale3, float scale, int accumulate,
+                                 const int* __restrict__ gexp, int ngexp, float* __restrict__ dW3, float* __restrict__ dW2,
+                                 float* __restrict__ db3, float* __restrict__ db2) {
     __shared__ float red[8][32];
     __shared__ int emin[4];
     {   // the launch's gradient unit (as dw_launch_exp)
@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(256) void edge_dw_reduce(const float* __restrict__ 
     }
     constexpr int PER = H3 * H2 + H2 * H1 + H3 + H2;
     const int ix = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int idx = blockIdx.x * 32 + ix;
+    const int idx = blk * 32 + ix;
     float s = 0.f;
     if (idx < PER) {   // (four independent partial sums: a thread's loads are in flight together; fixed summation order)
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -1092,6 +1092,23 @@ __global__ __launch_bounds__(256) void edge_dw_reduce(const float* __restrict__ 
         float* d = db2 + feat_of_fi(idx - H3 * H2 - H2 * H1 - H3);
         *d = s + (accumulate ? *d : 0.f);
     }
+}
+
+__global__ __launch_bounds__(256) void edge_dw_reduce(const float* __restrict__ part, int nwg, float scale3, float scale, int accumulate,
+                                                      const int* __restrict__ gexp, int ngexp,
+                                                      float* __restrict__ dW3, float* __restrict__ dW2,
+                                                      float* __restrict__ db3, float* __restrict__ db2) {
+    edge_dw_reduce_body((int)blockIdx.x, part, nwg, scale3, scale, accumulate, gexp, ngexp, dW3, dW2, db3, db2);
+}
+// ... and with the grouped split-K reductions of the layer's dense weight gradients riding in the same launch (blocks nb_dw ..):
+// one dependent launch less in the weight-gradient tail of every layer's backward
+__global__ __launch_bounds__(256) void edge_dw_reduce_group(const float* __restrict__ part, int nwg, float scale3, float scale, int accumulate,
+                                                            const int* __restrict__ gexp, int ngexp,
+                                                            float* __restrict__ dW3, float* __restrict__ dW2,
+                                                            float* __restrict__ db3, float* __restrict__ db2,
+                                                            const ReduceGroup R, const int nb_dw) {
+    if ((int)blockIdx.x < nb_dw) edge_dw_reduce_body((int)blockIdx.x, part, nwg, scale3, scale, accumulate, gexp, ngexp, dW3, dW2, db3, db2);
+    else splitk_reduce_group_body(R, (int)blockIdx.x - nb_dw);
 }
 
 }  // namespace
@@ -1158,10 +1175,23 @@ extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
     else MPG_DW_ONE(2);
 #endif
 #undef MPG_DW_ONE
+    if (p->defer_reduce) return (int)hipGetLastError();   // (mpg_splitk_reduce_group_dw adds the partials up)
     constexpr int PER = H3 * H2 + H2 * H1 + H3 + H2;
     // (the parked E2 carries the forward's operand scale SC_E2; db3 / db2 only the gradient unit)
     hipLaunchKernelGGL(edge_dw_reduce, dim3((PER + 31) / 32), dim3(256), 0, st, p->part, p->nwg, p->dscale / SC_E2, p->dscale, p->accumulate,
                        p->gexp, p->B * ((p->N + 31) / 32), p->dW3, p->dW2, p->db3, p->db2);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mpg_splitk_reduce_group_dw(const MpgReduceJob* jobs, int n, const MpgEdgeDw* p, void* stream) {
+    if (p == nullptr || p->nwg <= 0 || p->gexp == nullptr) return -1;
+    ReduceGroup R;
+    const int nb = make_reduce_group(jobs, n, R);
+    if (nb < 0) return -1;
+    constexpr int PER = H3 * H2 + H2 * H1 + H3 + H2;
+    const int nb_dw = (PER + 31) / 32;
+    hipLaunchKernelGGL(edge_dw_reduce_group, dim3(nb_dw + nb), dim3(256), 0, (hipStream_t)stream, p->part, p->nwg, p->dscale / SC_E2, p->dscale,
+                       p->accumulate, p->gexp, p->B * ((p->N + 31) / 32), p->dW3, p->dW2, p->db3, p->db2, R, nb_dw);
     return (int)hipGetLastError();
 }
 #endif

@@ -13,6 +13,7 @@
 // split to bf16 hi/lo while being staged into LDS in MFMA-fragment order (16 B per lane,
 // conflict-free ds_read_b128).
 #include "common.h"
+#include "reduce_group.h"
 #include "gemm.h"
 
 namespace {
@@ -198,28 +199,7 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup G) {
     gemm_body<false, false, F16>(g, local % tx, (local / tx) % ty, local / (tx * ty), G.splitk[q], fold);
 }
 
-struct ReduceGroup { MpgReduceJob j[MPG_GROUP_MAX]; int blk0[MPG_GROUP_MAX + 1]; int n; };
-__global__ void splitk_reduce_group_kernel(const ReduceGroup R) {
-    int q = 0;
-    while ((int)blockIdx.x >= R.blk0[q + 1]) ++q;
-    const MpgReduceJob& J = R.j[q];
-    const int idx = (blockIdx.x - R.blk0[q]) * blockDim.x + threadIdx.x;
-    const int ldp = J.K + J.has_bias;
-    if (idx >= J.N * ldp) return;
-    const int n = idx / ldp, k = idx % ldp;
-    // (four independent partial sums: the loads of a thread are then in flight together; the summation order is fixed)
-    const size_t zs = (size_t)J.N * ldp;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int z = 0;
-    for (; z + 4 <= J.S; z += 4) {
-        s0 += J.part[(size_t)z * zs + idx]; s1 += J.part[(size_t)(z + 1) * zs + idx];
-        s2 += J.part[(size_t)(z + 2) * zs + idx]; s3 += J.part[(size_t)(z + 3) * zs + idx];
-    }
-    for (; z < J.S; ++z) s0 += J.part[(size_t)z * zs + idx];
-    const float s = (s0 + s1) + (s2 + s3);
-    if (k < J.K) { float* d = J.out + (size_t)n * J.ldo + k; *d = s + (J.accumulate ? *d : 0.f); }
-    else if (J.bias != nullptr) J.bias[n] = s + (J.accumulate ? J.bias[n] : 0.f);
-}
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const ReduceGroup R) { splitk_reduce_group_body(R, (int)blockIdx.x); }
 
 // out[m,n] = in[m,n] * gate(H[m,n]) : the elementwise "backward through dropout (and leaky
 // relu)" step applied to an upstream gradient before it enters a GEMM.
@@ -327,17 +307,12 @@ extern "C" int mpg_gemm_wgrad_group(const MpgGemm* g, const int* splitk, int n, 
 }
 
 extern "C" int mpg_splitk_reduce_group(const MpgReduceJob* jobs, int n, void* stream) {
-    if (n < 1 || n > MPG_GROUP_MAX) return -1;
+    if (n < 1) return -1;
     ReduceGroup R;
-    R.n = n;
-    R.blk0[0] = 0;
-    for (int q = 0; q < n; ++q) {
-        R.j[q] = jobs[q];
-        const int tot = jobs[q].N * (jobs[q].K + jobs[q].has_bias);
-        R.blk0[q + 1] = R.blk0[q] + (tot + 255) / 256;
-    }
-    if (R.blk0[n] == 0) return 0;
-    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(R.blk0[n]), dim3(256), 0, (hipStream_t)stream, R);
+    const int nb = make_reduce_group(jobs, n, R);
+    if (nb < 0) return -1;
+    if (nb == 0) return 0;
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, R);
     return (int)hipGetLastError();
 }
 

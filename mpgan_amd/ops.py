@@ -43,6 +43,8 @@ OPTIONS = {
     # a (jet, receiver block) that arrives LAST adds up the chunks' partial sums (mpg_edge_fwd_fn with MpgEdgeFwd.tickets); False =
     # mpg_edge_fwd, a sum over the chunk axis and the mpg_chain calls
     "fn_chunks": os.environ.get("MPG_FN_CHUNKS", "1") != "0",
+    # the per-workgroup reduction of mpg_edge_dw inside the layer's grouped split-K reduction launch (mpg_splitk_reduce_group_dw)
+    "dw_reduce_grouped": os.environ.get("MPG_DW_REDUCE_GROUPED", "1") != "0",
 }
 NUM_CUS = 256
 # Forward products (they decide LeakyReLU signs) are split as fp16 hi/lo with the operand scales below (~2^-21 per
@@ -361,7 +363,11 @@ class WgradBatch:
         part = torch.empty((splitk, N, K + hb), device=dy.device, dtype=torch.float32)
         self.jobs.append((dy, x, out, out_col0, out_scale, bias_out, splitk, part, accumulate))
 
-    def flush(self):
+    def flush(self, dw=None):
+        """``dw``: an ``MpgEdgeDw`` whose launch ran with ``defer_reduce`` -- its per-workgroup reduction rides in the first group's
+        reduction launch (``mpg_splitk_reduce_group_dw``; with no job at all it is that launch alone)."""
+        if dw is not None and not self.jobs:
+            check(_lib.lib().mpg_splitk_reduce_group_dw(None, 0, C.byref(dw), _stream()), "mpg_splitk_reduce_group_dw")
         for i0 in range(0, len(self.jobs), GROUP_MAX):
             jobs = self.jobs[i0:i0 + GROUP_MAX]
             n = len(jobs)
@@ -380,7 +386,10 @@ class WgradBatch:
                 r.part, r.S, r.N, r.K, r.has_bias = _p(part), splitk, N, K, hb
                 r.out, r.ldo, r.bias, r.accumulate = _p(out, col0), out.stride(0), _p(bias_out), int(acc)
             check(_lib.lib().mpg_gemm_wgrad_group(gs, sk, n, _stream()), "mpg_gemm_wgrad_group")
-            check(_lib.lib().mpg_splitk_reduce_group(rj, n, _stream()), "mpg_splitk_reduce_group")
+            if dw is not None and i0 == 0:
+                check(_lib.lib().mpg_splitk_reduce_group_dw(rj, n, C.byref(dw), _stream()), "mpg_splitk_reduce_group_dw")
+            else:
+                check(_lib.lib().mpg_splitk_reduce_group(rj, n, _stream()), "mpg_splitk_reduce_group")
         self.jobs = []
 
 
@@ -924,6 +933,7 @@ class FusedMPLayerFn(torch.autograd.Function):
             d.alpha, d.agg_scale, d.nbr = alpha, agg_scale, nbr_p
             d.seed, d.tag_base, d.thr, d.dscale = _p(seed_t), tag, thr, dscale
             d.f16 = int(f16)
+            d.defer_reduce = int(OPTIONS["dw_reduce_grouped"])   # (its reduction rides in the grouped reduction launch below)
             if es is not None:
                 d.es, d.wq = _p(es), _p(wq)
             # layer 1 (fe.net.0): a = W1[:, :F] x + b1, c = W1[:, F:] x
@@ -941,10 +951,10 @@ class FusedMPLayerFn(torch.autograd.Function):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     check(_lib.lib().mpg_edge_dw(C.byref(d), _stream()), "mpg_edge_dw")
-                    wb.flush()
+                    wb.flush(dw=d if d.defer_reduce else None)
             else:
                 check(_lib.lib().mpg_edge_dw(C.byref(d), _stream()), "mpg_edge_dw")
-                wb.flush()
+                wb.flush(dw=d if d.defer_reduce else None)
             del stZ2
             if es is not None:   # the columns of the edge scalars: sum over receivers of daq
                 dWq = daq.sum((0, 1))[:nq].t()

@@ -400,6 +400,7 @@ class TrainStep:
         # weight-gradient stream alone, not for the generator's forward beside them
         self._defer_join = False
         self._join_pending = False
+        self._fork_late = False
         self.gen_join = None       # ("seg_D" | "seg_G": where the last iteration / capture joined the branch; tests read it)
         # The launches that only produce weight gradients (mpg_edge_dw + reduction, the grouped node-network weight
         # gradients: about a quarter of the step) feed nothing before the optimizer: they run on a second side stream, forked
@@ -471,7 +472,12 @@ class TrainStep:
         self.state.order_cache = None   # (ops.jet_order: the masks of this iteration live where last iteration's did)
         # (the dropout / noise seed of this iteration was set by the last launch of the iteration before: _seg_end)
         self.D.train()
-        if self.gen_ahead:
+        # the generator-ahead branch: forked at the top of the segment (MPG_GEN_AHEAD_LATE=0: beside the D step's own generator
+        # call), or -- default -- behind the D step's last data-gradient launch, beside the weight-gradient tail (_backward): the
+        # lower layer's mpg_edge_dw, its reduction, the grouped weight gradients, the optimizer and the packing are small or
+        # latency-bound launches that leave most CUs idle, and two full-chip forwards fill them
+        self._fork_late = self.gen_ahead and self.wgrad_side and os.environ.get("MPG_GEN_AHEAD_LATE", "1") != "0"
+        if self.gen_ahead and not self._fork_late:
             self._fork_generator()
         self.G.eval()
         if not self._clean["D"]:     # (cleared by the optimizer launch of the iteration before: see _seg_G)
@@ -576,6 +582,9 @@ class TrainStep:
             self.state.deferred_wgrad.flush()
         finally:
             self.state.deferred_wgrad = None
+            if getattr(self, "_fork_late", False):   # (D step only: _seg_G clears the flag before its own backward)
+                self._fork_late = False
+                self._fork_generator()
             if self.wgrad_side:
                 # join: the weight gradients are complete before whatever follows the backward (all-reduce, optimizer step)
                 self.state.wgrad_stream = None
@@ -596,6 +605,7 @@ class TrainStep:
             ops.refresh_many(packs)
 
     def _seg_G(self):  # D_optimizer.step() (train.py:461) + train_G up to backward (:494-520)
+        self._fork_late = False
         # optimizer.zero_grad() of the next train_D (train.py:419) rides in this launch: the buffer is cleared behind its last use
         self.fD.step(self.lr_disc, gscale=1.0 / self.world, zero_grad=True)
         self._clean["D"] = True

@@ -224,3 +224,28 @@ def test_noise_and_masks_from_one_launch_other_sizes(B, N, L):
     out = torch.empty(3 * 5, device=dev)
     rc = _lib.lib().mpg_normal_rank_mask(ops._p(out), 1, 3, 5, ops._p(ops.seed_tensor(dev)), 0, 0.0, 1.0, ops._p(labels), 1, ops._p(m0), None, None)
     assert rc == -1
+
+
+def test_slab_sums_equal_sequential_adds():
+    """``mpg_slab_sums``: [da | dc] rows from the sender chunks' da slabs and the receiver blocks' dc slabs of a sender-chunked data-gradient
+    launch -- slab by slab in index order: bit-identical to the same adds written out in torch; refusals for misaligned / odd shapes."""
+    import ctypes as C
+    from mpgan_amd import _lib, ops
+    gen = torch.Generator().manual_seed(3)
+    for SA, SB, M, cols in ((3, 5, 2400, 96), (1, 2, 33, 96), (4, 1, 7, 8)):
+        A = torch.randn(SA, M, cols, generator=gen).cuda()
+        Bm = torch.randn(SB, M, cols, generator=gen).cuda()
+        out = torch.empty(M, 2 * cols, device="cuda")
+        rc = _lib.lib().mpg_slab_sums(ops._p(A), SA, M * cols, ops._p(Bm), SB, M * cols, ops._p(out), M, cols, ops._stream())
+        assert rc == 0
+        ra, rb = A[0].clone(), Bm[0].clone()
+        for q in range(1, SA):
+            ra = ra + A[q]
+        for q in range(1, SB):
+            rb = rb + Bm[q]
+        assert torch.equal(out[:, :cols], ra) and torch.equal(out[:, cols:], rb), (SA, SB, M, cols)
+    A = torch.zeros(2, 4, 6, device="cuda")
+    out = torch.empty(4, 12, device="cuda")
+    assert _lib.lib().mpg_slab_sums(ops._p(A), 2, 24, ops._p(A), 2, 24, ops._p(out), 4, 6, ops._stream()) == -2      # cols % 4
+    A = torch.zeros(2 * 4 * 8 + 1, device="cuda")
+    assert _lib.lib().mpg_slab_sums(ops._p(A, 1), 2, 32, ops._p(A, 1), 2, 32, ops._p(out), 4, 8, ops._stream()) == -5  # 16-byte alignment
