@@ -6,9 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mpgan_amd import train, data
 
-for model, B, steps in (("mpgan", 256, 400), ("gapt", 512, 1000)):
+for model, B, steps, N in (("mpgan", 256, 400, 30), ("gapt", 512, 1000, 30), ("mpgan", 16, 200, 150), ("gapt", 64, 200, 150)):
     torch.manual_seed(4)
-    N = 30
     G, D = train.default_mpgan(N) if model == "mpgan" else train.default_gapt(N)
     lr_g, lr_d = (1e-5, 3e-5) if model == "mpgan" else train.LR_GAPT
     ts = train.TrainStep(G, D, B, N, latent=32 if model == "mpgan" else 64, lr_disc=lr_d, lr_gen=lr_g)
@@ -27,4 +26,4 @@ for model, B, steps in (("mpgan", 256, 400), ("gapt", 512, 1000)):
     for net in (G, D):
         for k, p in net.named_parameters():
             assert torch.isfinite(p).all(), (model, k)
-    print(f"{model}: {steps} iterations at B={B}: D loss in [{lo[0]:.3f}, {hi[0]:.3f}], G loss in [{lo[1]:.3f}, {hi[1]:.3f}], parameters finite")
+    print(f"{model} N={N}: {steps} iterations at B={B}: D loss in [{lo[0]:.3f}, {hi[0]:.3f}], G loss in [{lo[1]:.3f}, {hi[1]:.3f}], parameters finite", flush=True)
