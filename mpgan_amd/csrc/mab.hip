@@ -527,10 +527,10 @@ __global__ __launch_bounds__(320) void mab_fwdN_kernel(const MpgMab p) {
     for (int i = threadIdx.x; i < 160 * NT; i += blockDim.x)
         sBin[i] = (i < 96 * NT ? p.bin[i] : (i < 128 * NT ? p.bo[i - 96 * NT] : p.bf[i - 128 * NT])) * zs;
     __syncthreads();
-    if (w >= nqt) return;                 // (a wave without a query tile: it has helped with the fill)
     const WImg rIn = sIn, rO = sO, rF = sF;
+    const bool isq = w < nqt, isk = w < nkt;
     V qh[2 * NT], ql[2 * NT];             // the queries' heads as B fragments: head 2t + a
-    {
+    if (isq) {
         V xh[KS], xl[KS];
         tiles_to_frags<NT>(xt, sa, xh, xl);
         static_for<0, NT>([&](auto tc) {
@@ -540,28 +540,56 @@ __global__ __launch_bounds__(320) void mab_fwdN_kernel(const MpgMab p) {
             tile_frag(Qn, 1, inv_zs * sa * 0.25f, qh[2 * t + 1], ql[2 * t + 1]);
         });
     }
+    // ---- the key side ONCE per key tile: wave w projects K and V of key tile w, and behind a barrier -- every wave is done with
+    // Win's image then -- lays the fragments the attention takes down where that image was (3 tiles' worth) and in 32 KiB of
+    // their own behind the biases: [key tile][feature tile][kh0 kl0 kh1 kl1 | vh0 vl0 vh1 vl1][lane] 16 B.  (Projected by every
+    // query wave for itself they were 48 of the 84 MFMAs per key tile.)
+    constexpr int KVT = 8 * NT * 1024;    // bytes of one key tile's fragments
+    auto kv_slot = [&](int kt) -> char* {
+        constexpr int WIN_TILES = 3 * NT / 2;   // key tiles whose fragments fit Win's image (12 NT^2 KiB / 8 NT KiB)
+        return kt < WIN_TILES ? sIn + kt * KVT : reinterpret_cast<char*>(sBf + 32 * NT) + (kt - WIN_TILES) * KVT;
+    };
+    {
+        V kvf[8 * NT];
+        if (isk) {
+            const long yrow = jet * p.S + min(32 * w + r, p.S - 1);
+            V yh[KS], yl[KS];
+            rows_to_frags<KS>(p.y, p.ldy, yrow, sa, h, yh, yl);
+            static_for<0, NT>([&](auto tc) {
+                MPG_CI(t, tc);
+                const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(sBin, NT + t, h), lane16);
+                const f32x16 Vt = proj_t<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_lanes(sBin, 2 * NT + t, r), lane16);
+                tile_frag(Kn, 0, inv_zs * sa, kvf[8 * t + 0], kvf[8 * t + 1]);
+                tile_frag(Kn, 1, inv_zs * sa, kvf[8 * t + 2], kvf[8 * t + 3]);
+                tile_frag(Vt, 0, inv_zs * sa, kvf[8 * t + 4], kvf[8 * t + 5]);
+                tile_frag(Vt, 1, inv_zs * sa, kvf[8 * t + 6], kvf[8 * t + 7]);
+            });
+        }
+        __syncthreads();                  // every projection that reads Win's image is done
+        if (isk) {
+            V* const dst = reinterpret_cast<V*>(kv_slot(w));
+#pragma unroll
+            for (int i = 0; i < 8 * NT; ++i) dst[i * 64 + lane] = kvf[i];
+        }
+        __syncthreads();
+    }
+    if (!isq) return;                     // (a wave without a query tile: it has helped with the fill and the key side)
     const float sc2 = 1.44269504088896341f / (sa * sa);   // scores in the base-2 domain
     float mrun[2 * NT], den[2 * NT];
     f32x16 oacc[2 * NT];
 #pragma unroll
     for (int i = 0; i < 2 * NT; ++i) { mrun[i] = -INFINITY; den[i] = 0.f; oacc[i] = zero16(); }
     for (int kt = 0; kt < nkt; ++kt) {
-        const long yrow = jet * p.S + min(32 * kt + r, p.S - 1);
-        V yh[KS], yl[KS];
-        rows_to_frags<KS>(p.y, p.ldy, yrow, sa, h, yh, yl);
         const f32x16 kneg = key_mask_tile(p.ignore, p.x, jet, p.S, h, kt);
+        const V* const src = reinterpret_cast<const V*>(kv_slot(kt));
         static_for<0, NT>([&](auto tc) {
             MPG_CI(t, tc);
-            const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(sBin, NT + t, h), lane16);
-            const f32x16 Vt = proj_t<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_lanes(sBin, 2 * NT + t, r), lane16);
-            V vh[2], vl[2];
-            tile_frag(Vt, 0, inv_zs * sa, vh[0], vl[0]);
-            tile_frag(Vt, 1, inv_zs * sa, vh[1], vl[1]);
+            const V vh[2] = {src[(8 * t + 4) * 64 + lane], src[(8 * t + 6) * 64 + lane]};
+            const V vl[2] = {src[(8 * t + 5) * 64 + lane], src[(8 * t + 7) * 64 + lane]};
             static_for<0, 2>([&](auto ac) {
                 MPG_CI(a, ac);
                 constexpr int hd = 2 * t + a;
-                V kh, kl;
-                tile_frag(Kn, a, inv_zs * sa, kh, kl);
+                const V kh = src[(8 * t + 2 * a) * 64 + lane], kl = src[(8 * t + 2 * a + 1) * 64 + lane];
                 f32x16 sx = mfma3(kh, kl, qh[hd], ql[hd], zero16());      // keys in registers, queries on lanes
                 float mx = -INFINITY;
 #pragma unroll
@@ -1948,8 +1976,10 @@ extern "C" int mpg_mab_fwd(const MpgMab* p, void* stream) {
         if (ln && (p->ln1_b == nullptr || p->ln2_w == nullptr || p->ln2_b == nullptr || !(p->ln_eps > 0.f))) return -6;
         const int nw = (std::max(p->L, p->S) + 31) / 32;
         const dim3 grid(p->B), block(64 * nw);
-#define MPG_FWDN(NTv, LNv) do { MPG_ENSURE_LDS((mab_fwdN_kernel<NTv, LNv>), lds); \
-        hipLaunchKernelGGL((mab_fwdN_kernel<NTv, LNv>), grid, block, lds, st, *p); } while (0)
+        // (Win's image holds 3 key tiles' fragments at E = 64, 1 at E = 32; the rest of up to 5 behind the biases)
+        const int ldsF = lds + (5 - 3 * NT / 2) * 8 * NT * 1024;
+#define MPG_FWDN(NTv, LNv) do { MPG_ENSURE_LDS((mab_fwdN_kernel<NTv, LNv>), ldsF); \
+        hipLaunchKernelGGL((mab_fwdN_kernel<NTv, LNv>), grid, block, ldsF, st, *p); } while (0)
         if (NT == 2) { if (ln) MPG_FWDN(2, true); else MPG_FWDN(2, false); }
         else { if (ln) MPG_FWDN(1, true); else MPG_FWDN(1, false); }
 #undef MPG_FWDN
