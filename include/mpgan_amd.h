@@ -416,8 +416,8 @@ int mpg_bridge_bwd(const MpgBridgeBwd* p, void* stream);
 
 /* mpg_mab_fwd / mpg_mab_bwd: one launch per MAB.forward (gapt/model.py:124-139) and one for its backward, for sets of at
  * most 160 tokens (L, S <= 32: a wave or two per jet; 33 ... 160 -- --num-hits 150, setup_training.py:415 --: a workgroup per
- * jet, a wave per tile of 32 tokens, key tiles walked with a running maximum / sum; the backward then REQUIRES dza, whose rows
- * the waves hand to each other through memory: error -5 without it), E in {32, 64}, heads of 16 features, with or without the
+ * jet, a wave per tile of 32 tokens, key tiles walked with a running maximum / sum, projections made once per tile and
+ * shared through LDS), E in {32, 64}, heads of 16 features, with or without the
  * two layer norms (csrc/mab.hip; anything else runs block by block through mpg_gemm / mpg_attn_* / mpg_gate):
  *   q = x Wq' + bq, k|v = y Wkv' + bkv ; o = softmax(q k' / 4 + key mask) v per head ; za = x + o Wo' + bo ;
  *   z = dropout(za, site tag) ; u = z Wf' + bf ; out = dropout(z + dropout(act(u), site tag+1), site tag+2)

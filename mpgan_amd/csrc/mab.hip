@@ -22,6 +22,7 @@
 #include "common.h"
 #include "../../include/mpgan_amd.h"
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 
 #ifdef MPG_MABSTAMP  // diagnostic build (tools/mab_stamps.py): s_memtime at the phase boundaries, the waves of workgroup 0
@@ -1574,6 +1575,300 @@ __global__ __launch_bounds__(320) void mab_bwdN_kernel(const MpgMab p) {
     });
 }
 
+// ---- LARGE SETS, backward, the form that SHARES the projections (default; mab_bwdN_kernel above recomputes them and stays as the
+// A/B: MPG_MAB_BWDN=recompute).  Same ownership -- wave w: query tile w and key tile w --, but every projection is made ONCE, by its
+// tile's owner, and handed round through LDS as the fragments the products take.  The room comes from the weight images: Wf / WfT
+// are dead behind the feed-forward half and WinT is not loaded until its turn, which leaves 80 KiB beside Win and WoT -- the key
+// side of ONE feature tile for all five tiles (12 KiB each) or the query side (16 KiB each).  Per feature tile t:
+//   K-phase: owners write kh kl (per head) | vbh vbl (per head) | kph kpl (per k-step)      -> barrier
+//   P2:      own queries against every key tile: statistics pass, dS pass -> dQ' of t         -> barrier
+//   Q-phase: owners write qh ql | dobh dobl (per head) | qph qpl | doph dopl (per k-step)    -> barrier
+//   P3:      own keys against every query tile -> dK', dV' of t                              -> barrier
+//   WinT's image is filled over the exchange area                                             -> barrier
+//   tail:    dxa += dQ' Wq, (dya or dxa) += dK' Wk + dV' Wv                                   -> barrier
+// Every sum runs in tile order inside one wave (deterministic); nothing goes through memory any more (dza is written for Wo's weight
+// gradient only).  ~1,050 MFMAs per wave instead of ~1,950.
+template <int NT, bool CROSS, bool LN>
+__global__ __launch_bounds__(320) void mab_bwdS_kernel(const MpgMab p) {
+    typedef f16x8 VF;
+    typedef bf16x8 VB;
+    constexpr int KS = 2 * NT, NH = 2 * NT, TOKMAX = 160;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5, lane16 = lane * 16;
+    const uint64_t sd = *(p.seed != nullptr ? p.seed : reinterpret_cast<const uint64_t*>(p.x));
+    const uint32_t seed_lo = p.seed != nullptr ? (uint32_t)sd : 0u, seed_hi = p.seed != nullptr ? (uint32_t)(sd >> 32) : 0u;
+    const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
+    const float zs = sa * ws, inv_zs = 1.f / zs, sc2 = 1.44269504088896341f / (sa * sa);   // (scores in the base-2 domain)
+    constexpr int nfIn = 3 * NT * KS, nfE = NT * KS, nfInT = NT * 3 * KS;
+    constexpr int XCH = 80 * 1024;        // the exchange area: [Wf | WfT | room] -- later WinT's image
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sIn = smem;
+    char* const sOT = sIn + 2 * nfIn * 1024;
+    char* const sX = sOT + 2 * nfE * 1024;
+    char* const sF = sX;
+    char* const sFT = sF + 2 * nfE * 1024;
+    float* const sBin = reinterpret_cast<float*>(sX + XCH);   // biases: in_proj [3E] | ff [E]
+    float* const sBf = sBin + 96 * NT;
+    float* const sCQ = sBin + 128 * NT;   // [head][token]: the maximum of a query's scores (+inf: the query attends to nothing)
+    float* const sID = sCQ + NH * TOKMAX; // [head][token]: 1 / sum_keys 2^(score - maximum)
+    float* const sDD = sID + NH * TOKMAX; // [head][token]: sum_keys P dP
+    static_assert(2 * 2 * nfE * 1024 <= XCH && 2 * nfInT * 1024 <= XCH, "Wf, WfT and later WinT live in the exchange area");
+    const long jet = blockIdx.x;
+    const int nqt = (p.L + 31) >> 5, nkt = (p.S + 31) >> 5;
+    const bool isq = w < nqt, isk = w < nkt;
+    const int tok = 32 * w + r;
+    const long xrow = jet * p.L + min(tok, p.L - 1), yrow = jet * p.S + min(tok, p.S - 1);
+    const bool xvalid = isq && tok < p.L, yvalid = isk && tok < p.S;
+    f32x16 dzf[NT], zt[NT], zat[LN ? NT : 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        dzf[t] = rows_to_tile(p.dout, p.lddout, xrow, t, h);
+        zt[t] = rows_to_tile(p.save_z, p.E, xrow, t, h);
+        if constexpr (LN) zat[t] = rows_to_tile(p.save_za, p.E, xrow, t, h);
+    }
+    mab_fill(sIn, p.Win, 2 * nfIn * 1024);
+    mab_fill(sOT, p.WoT, 2 * nfE * 1024);
+    mab_fill(sF, p.Wf, 2 * nfE * 1024);
+    mab_fill(sFT, p.WfT, 2 * nfE * 1024);
+    for (int i = threadIdx.x; i < 128 * NT; i += blockDim.x) sBin[i] = (i < 96 * NT ? p.bin[i] : p.bf[i - 96 * NT]) * zs;
+    __syncthreads();
+    const WImg rIn = sIn, rF = sF, rOT = sOT, rFT = sFT, rInT = sX;
+    f32x16 dxa[NT], dya[NT];              // (dya: the key side -- dy of a cross block, the second half of dx of a self-attention block)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { dxa[t] = zero16(); dya[t] = zero16(); }
+    VB dzah[KS], dzal[KS];
+    if (isq) mab_bwd_ff<NT, LN>(p, dzf, zt, zat, xvalid ? 1.f : 0.f, rF, rFT, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, h, lane16, dzah, dzal, dxa);
+    __syncthreads();                      // every wave is through the feed-forward half: Wf and WfT are dead, the exchange area is free
+    const float ign_r = (p.ignore != nullptr ? p.ignore + jet * p.S : p.x)[p.ignore != nullptr ? min(tok, p.S - 1) : 0];
+    const bool key_off = !yvalid || (p.ignore != nullptr && ign_r != 0.f);
+    auto frag_at = [&](int tile, int per_tile, int i) -> VB* { return reinterpret_cast<VB*>(sX + ((tile * per_tile + i) * 64 + lane) * 16); };
+
+    static_for<0, NT>([&](auto tc) {
+        MPG_CI(t, tc);
+        // ---- K-phase: the key side of (own tile, t): [0..3] kh kl of heads 0, 1 (fp16) | [4..7] vbh vbl | [8..11] kph kpl of k-steps 0, 1
+        if (isk) {
+            VF yh[KS], yl[KS];
+            rows_to_frags<KS>(p.y, p.ldy, yrow, sa, h, yh, yl);
+            const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(sBin, NT + t, h), lane16);
+            const f32x16 Vn = proj_n<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_regs(sBin, 2 * NT + t, h), lane16);
+            const f32x16 Kp = proj_t<KS>(rIn, nfIn, NT + t, yh, yl, bias_lanes(sBin, NT + t, r), lane16);
+            static_for<0, 2>([&](auto ac) {
+                MPG_CI(a, ac);
+                VF kh, kl;
+                VB vh, vl, ph, pl;
+                tile_frag(Kn, a, inv_zs * sa, kh, kl);
+                tile_frag(Vn, a, inv_zs, vh, vl);
+                tile_frag(Kp, a, inv_zs, ph, pl);
+                *reinterpret_cast<VF*>(frag_at(w, 12, 2 * a)) = kh;
+                *reinterpret_cast<VF*>(frag_at(w, 12, 2 * a + 1)) = kl;
+                *frag_at(w, 12, 4 + 2 * a) = vh;
+                *frag_at(w, 12, 5 + 2 * a) = vl;
+                *frag_at(w, 12, 8 + 2 * a) = ph;
+                *frag_at(w, 12, 9 + 2 * a) = pl;
+            });
+        }
+        __syncthreads();
+        // ---- P2: the wave's own queries against every key tile
+        VF qh[2], ql[2];
+        VB dobh[2], dobl[2];
+        f32x16 dQt = zero16();
+        if (isq) {
+            {
+                VF xh[KS], xl[KS];
+                rows_to_frags<KS>(p.x, p.ldx, xrow, sa, h, xh, xl);
+                const f32x16 Qn = proj_n<KS>(rIn, nfIn, t, xh, xl, bias_regs(sBin, t, h), lane16);
+                const f32x16 dOn = proj_n<KS>(rOT, nfE, t, dzah, dzal, zero16(), lane16);
+                static_for<0, 2>([&](auto ac) {
+                    MPG_CI(a, ac);
+                    tile_frag(Qn, a, inv_zs * sa * 0.25f, qh[a], ql[a]);
+                    tile_frag(dOn, a, 1.f, dobh[a], dobl[a]);
+                });
+            }
+            // pass 1: the running maximum, sum and sum of P dP of every (query, head) -- D from the very dP values pass 2 works with
+            float cq[2], iden[2], Dq[2];
+            {
+                float mrun[2] = {-INFINITY, -INFINITY}, den[2] = {0.f, 0.f};
+                Dq[0] = Dq[1] = 0.f;
+                for (int kt = 0; kt < nkt; ++kt) {
+                    const f32x16 kneg = key_mask_tile(p.ignore, p.x, jet, p.S, h, kt);
+                    static_for<0, 2>([&](auto ac) {
+                        MPG_CI(a, ac);
+                        const VF kh = *reinterpret_cast<const VF*>(frag_at(kt, 12, 2 * a)), kl = *reinterpret_cast<const VF*>(frag_at(kt, 12, 2 * a + 1));
+                        const VB vbh = *frag_at(kt, 12, 4 + 2 * a), vbl = *frag_at(kt, 12, 5 + 2 * a);
+                        f32x16 sx = mfma3(kh, kl, qh[a], ql[a], zero16());
+                        const f32x16 dP = mfma3(vbh, vbl, dobh[a], dobl[a], zero16());
+                        float mx = -INFINITY;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { sx[i] = sx[i] * sc2 + kneg[i]; mx = fmaxf(mx, sx[i]); }
+                        mx = fmaxf(mx, other_half(mx));
+                        const float mnew = fmaxf(mrun[a], mx);
+                        const float msafe = mnew == -INFINITY ? 0.f : mnew;
+                        float part = 0.f, dpart = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const float e = __builtin_amdgcn_exp2f(sx[i] - msafe);
+                            part += e;
+                            dpart = fmaf(e, dP[i], dpart);
+                        }
+                        part += other_half(part);
+                        dpart += other_half(dpart);
+                        const float resc = __builtin_amdgcn_exp2f(mrun[a] - msafe);
+                        den[a] = den[a] * resc + part;
+                        Dq[a] = Dq[a] * resc + dpart;
+                        mrun[a] = mnew;
+                    });
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const bool live = den[a] > 0.f && xvalid;
+                    cq[a] = live ? mrun[a] : INFINITY;
+                    iden[a] = live ? 1.f / den[a] : 0.f;
+                    Dq[a] *= iden[a];
+                    const int hd = 2 * t + a;
+                    if (h == 0) { sCQ[hd * TOKMAX + tok] = cq[a]; sID[hd * TOKMAX + tok] = iden[a]; sDD[hd * TOKMAX + tok] = Dq[a]; }
+                }
+            }
+            // pass 2: dS tile by tile, dQ' accumulated over the key tiles
+            f32x16 dqa[2] = {zero16(), zero16()};
+            for (int kt = 0; kt < nkt; ++kt) {
+                const f32x16 kneg = key_mask_tile(p.ignore, p.x, jet, p.S, h, kt);
+                const VB kph[2] = {*frag_at(kt, 12, 8), *frag_at(kt, 12, 10)}, kpl[2] = {*frag_at(kt, 12, 9), *frag_at(kt, 12, 11)};
+                static_for<0, 2>([&](auto ac) {
+                    MPG_CI(a, ac);
+                    const VF kh = *reinterpret_cast<const VF*>(frag_at(kt, 12, 2 * a)), kl = *reinterpret_cast<const VF*>(frag_at(kt, 12, 2 * a + 1));
+                    const VB vbh = *frag_at(kt, 12, 4 + 2 * a), vbl = *frag_at(kt, 12, 5 + 2 * a);
+                    const f32x16 sx = mfma3(kh, kl, qh[a], ql[a], zero16());
+                    const f32x16 dP = mfma3(vbh, vbl, dobh[a], dobl[a], zero16());
+                    f32x16 dS;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float pr = __builtin_amdgcn_exp2f(sx[i] * sc2 + kneg[i] - cq[a]) * iden[a];
+                        dS[i] = pr * (dP[i] - Dq[a]) * 0.25f;
+                    }
+                    VB dsh[2], dsl[2];
+                    tile_frag(dS, 0, 1.f, dsh[0], dsl[0]);
+                    tile_frag(dS, 1, 1.f, dsh[1], dsl[1]);
+                    dqa[a] = mfma3(kph[0], kpl[0], dsh[0], dsl[0], dqa[a]);
+                    dqa[a] = mfma3(kph[1], kpl[1], dsh[1], dsl[1], dqa[a]);
+                });
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dQt[j] = dqa[0][j]; dQt[8 + j] = dqa[1][8 + j]; }
+            if (p.dq != nullptr && xvalid) tile_to_rows(p.dq, p.lddq, xrow, t, h, dQt, 1.f);
+        }
+        __syncthreads();                  // the key side of t is read; every query's statistics of t's heads are in LDS
+        // ---- Q-phase: the query side of (own tile, t): [0..3] qh ql of heads 0, 1 (fp16) | [4..7] dobh dobl | [8..11] qph qpl of k-steps 0, 1 |
+        //      [12..15] doph dopl
+        if (isq) {
+            VF xh[KS], xl[KS];
+            rows_to_frags<KS>(p.x, p.ldx, xrow, sa, h, xh, xl);
+            const f32x16 Qp = proj_t<KS>(rIn, nfIn, t, xh, xl, bias_lanes(sBin, t, r), lane16);
+            const f32x16 dOp = proj_t<KS>(rOT, nfE, t, dzah, dzal, zero16(), lane16);
+            static_for<0, 2>([&](auto ac) {
+                MPG_CI(a, ac);
+                VB ph, pl, oh, ol;
+                tile_frag(Qp, a, inv_zs, ph, pl);
+                tile_frag(dOp, a, 1.f, oh, ol);
+                *reinterpret_cast<VF*>(frag_at(w, 16, 2 * a)) = qh[a];
+                *reinterpret_cast<VF*>(frag_at(w, 16, 2 * a + 1)) = ql[a];
+                *frag_at(w, 16, 4 + 2 * a) = dobh[a];
+                *frag_at(w, 16, 5 + 2 * a) = dobl[a];
+                *frag_at(w, 16, 8 + 2 * a) = ph;
+                *frag_at(w, 16, 9 + 2 * a) = pl;
+                *frag_at(w, 16, 12 + 2 * a) = oh;
+                *frag_at(w, 16, 13 + 2 * a) = ol;
+            });
+        }
+        __syncthreads();
+        // ---- P3: the wave's own keys against every query tile
+        f32x16 dKt = zero16(), dVt = zero16();
+        if (isk) {
+            VF kh[2], kl[2];
+            VB vbh[2], vbl[2];
+            {
+                VF yh[KS], yl[KS];
+                rows_to_frags<KS>(p.y, p.ldy, yrow, sa, h, yh, yl);
+                const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(sBin, NT + t, h), lane16);
+                const f32x16 Vn = proj_n<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_regs(sBin, 2 * NT + t, h), lane16);
+                static_for<0, 2>([&](auto ac) {
+                    MPG_CI(a, ac);
+                    tile_frag(Kn, a, inv_zs * sa, kh[a], kl[a]);
+                    tile_frag(Vn, a, inv_zs, vbh[a], vbl[a]);
+                });
+            }
+            f32x16 dka[2] = {zero16(), zero16()}, dva[2] = {zero16(), zero16()};
+            for (int qt = 0; qt < nqt; ++qt) {
+                const VB qph[2] = {*frag_at(qt, 16, 8), *frag_at(qt, 16, 10)}, qpl[2] = {*frag_at(qt, 16, 9), *frag_at(qt, 16, 11)};
+                const VB doph[2] = {*frag_at(qt, 16, 12), *frag_at(qt, 16, 14)}, dopl[2] = {*frag_at(qt, 16, 13), *frag_at(qt, 16, 15)};
+                static_for<0, 2>([&](auto ac) {
+                    MPG_CI(a, ac);
+                    constexpr int hd = 2 * t + a;
+                    const VF qh2 = *reinterpret_cast<const VF*>(frag_at(qt, 16, 2 * a)), ql2 = *reinterpret_cast<const VF*>(frag_at(qt, 16, 2 * a + 1));
+                    const VB dbh = *frag_at(qt, 16, 4 + 2 * a), dbl = *frag_at(qt, 16, 5 + 2 * a);
+                    const f32x16 sT = mfma3(qh2, ql2, kh[a], kl[a], zero16());        // queries in registers, keys on lanes
+                    const f32x16 dPT = mfma3(dbh, dbl, vbh[a], vbl[a], zero16());
+                    f32x16 pT, dST;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int i = 4 * g + e, qi = 32 * qt + 8 * g + 4 * h + e;   // the query this register belongs to
+                            const float c_q = sCQ[hd * TOKMAX + qi], id_q = sID[hd * TOKMAX + qi], D_q = sDD[hd * TOKMAX + qi];
+                            const float pr = key_off ? 0.f : __builtin_amdgcn_exp2f(sT[i] * sc2 - c_q) * id_q;
+                            pT[i] = pr;
+                            dST[i] = pr * (dPT[i] - D_q) * 0.25f;
+                        }
+                    VB pth[2], ptl[2], dsth[2], dstl[2];
+                    static_for<0, 2>([&](auto sc) {
+                        MPG_CI(s2, sc);
+                        tile_frag(pT, s2, 1.f, pth[s2], ptl[s2]);
+                        tile_frag(dST, s2, 1.f, dsth[s2], dstl[s2]);
+                    });
+                    dka[a] = mfma3(qph[0], qpl[0], dsth[0], dstl[0], dka[a]);
+                    dka[a] = mfma3(qph[1], qpl[1], dsth[1], dstl[1], dka[a]);
+                    dva[a] = mfma3(doph[0], dopl[0], pth[0], ptl[0], dva[a]);
+                    dva[a] = mfma3(doph[1], dopl[1], pth[1], ptl[1], dva[a]);
+                });
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dKt[j] = dka[0][j]; dKt[8 + j] = dka[1][8 + j]; dVt[j] = dva[0][j]; dVt[8 + j] = dva[1][8 + j]; }
+            if (p.dk != nullptr && yvalid) {
+                tile_to_rows(p.dk, p.lddkv, yrow, t, h, dKt, 1.f);
+                tile_to_rows(p.dv, p.lddkv, yrow, t, h, dVt, 1.f);
+            }
+        }
+        __syncthreads();                  // the query side of t is read: the exchange area takes WinT's image
+        mab_fill(sX, p.WinT, 2 * nfInT * 1024);
+        __syncthreads();
+        // ---- input gradients of this feature tile's dq, dk, dv
+        {
+            VB fh[2], fl[2];
+            if (isq) {
+                tile_frag(dQt, 0, 1.f, fh[0], fl[0]); tile_frag(dQt, 1, 1.f, fh[1], fl[1]);
+                acc_wt<NT>(rInT, nfInT, 3 * KS, 2 * t, fh, fl, dxa, lane16);
+            }
+            if (isk) {
+                tile_frag(dKt, 0, 1.f, fh[0], fl[0]); tile_frag(dKt, 1, 1.f, fh[1], fl[1]);
+                acc_wt<NT>(rInT, nfInT, 3 * KS, 2 * (NT + t), fh, fl, dya, lane16);
+                tile_frag(dVt, 0, 1.f, fh[0], fl[0]); tile_frag(dVt, 1, 1.f, fh[1], fl[1]);
+                acc_wt<NT>(rInT, nfInT, 3 * KS, 2 * (2 * NT + t), fh, fl, dya, lane16);
+            }
+        }
+        if constexpr (t + 1 < NT) __syncthreads();   // WinT's image is read: the next feature tile's key side may land there
+    });
+    static_for<0, NT>([&](auto tc) {
+        MPG_CI(t, tc);
+        if constexpr (CROSS) {
+            if (p.dx != nullptr && xvalid) tile_to_rows(p.dx, p.lddx, xrow, t, h, dxa[t], 1.f);
+            if (p.dy != nullptr && yvalid) tile_to_rows(p.dy, p.lddy, yrow, t, h, dya[t], 1.f);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dxa[t][i] += dya[t][i];
+            if (p.dx != nullptr && xvalid) tile_to_rows(p.dx, p.lddx, xrow, t, h, dxa[t], 1.f);
+        }
+    });
+}
+
 // ---- The backward with TWO WAVES PER JET (E = 64), the split of mab_fwd_half: wave T owns tile T of du, dz, dza, the two heads
 // of tile T in the attention (q, k, v, P recomputed for those heads only) and tile T of dx (dy).  Three meetings in LDS: du and
 // dza are B fragments of products over ALL features, and the input gradient contracts over all of dq | dk | dv.  Each wave
@@ -1919,14 +2214,20 @@ extern "C" int mpg_mab_bwd(const MpgMab* p, void* stream) {
     const int NT = p->E / 32;
     const int lds = 2 * 1024 * (2 * 3 * NT * 2 * NT + 3 * NT * 2 * NT) + 4 * 128 * NT;   // Win, WinT (3E x E) + Wf, WoT, WfT (E x E) + biases
     if (p->L > 32 || p->S > 32 || getenv("MPG_MAB_BIG") != nullptr) {   // large sets: a workgroup per jet, a wave per tile of 32 tokens (mab_bwdN_kernel)
-        if (p->dza == nullptr) return -5;   // (the key owners read the rows of dza back)
+        if (p->dza == nullptr && getenv("MPG_MAB_BWDN") != nullptr) return -5;   // (the recomputing form's key owners read the rows of dza back)
         const bool ln = p->ln1_w != nullptr;
         if (ln && (p->ln2_w == nullptr || p->save_za == nullptr || !(p->ln_eps > 0.f) || (p->dn1 == nullptr) != (p->gn1 == nullptr) ||
                    (p->dn1 == nullptr) != (p->dn2 == nullptr) || (p->dn1 == nullptr) != (p->gn2 == nullptr))) return -6;
         const int nw = (std::max(p->L, p->S) + 31) / 32, ldsN = lds + 4 * 3 * (2 * NT) * 160;
+        // (the sharing form: Win + WoT + the 80 KiB exchange area + biases + statistics)
+        const int ldsS = 2 * 1024 * (3 * NT * 2 * NT + NT * 2 * NT) + 80 * 1024 + 4 * 128 * NT + 4 * 3 * (2 * NT) * 160;
+        const char* const form = getenv("MPG_MAB_BWDN");   // (read at every launch: a test holds the two forms against each other)
+        const bool recompute = form != nullptr && strcmp(form, "recompute") == 0;
         const dim3 grid(p->B), block(64 * nw);
-#define MPG_BWDN(NTv, CR, LNv) do { MPG_ENSURE_LDS((mab_bwdN_kernel<NTv, CR, LNv>), ldsN); \
-        hipLaunchKernelGGL((mab_bwdN_kernel<NTv, CR, LNv>), grid, block, ldsN, st, *p); } while (0)
+#define MPG_BWDN(NTv, CR, LNv) do { if (recompute) { MPG_ENSURE_LDS((mab_bwdN_kernel<NTv, CR, LNv>), ldsN); \
+        hipLaunchKernelGGL((mab_bwdN_kernel<NTv, CR, LNv>), grid, block, ldsN, st, *p); } else { \
+        MPG_ENSURE_LDS((mab_bwdS_kernel<NTv, CR, LNv>), ldsS); \
+        hipLaunchKernelGGL((mab_bwdS_kernel<NTv, CR, LNv>), grid, block, ldsS, st, *p); } } while (0)
         if (NT == 2) { if (cross) { if (ln) MPG_BWDN(2, true, true); else MPG_BWDN(2, true, false); }
                        else { if (ln) MPG_BWDN(2, false, true); else MPG_BWDN(2, false, false); } }
         else { if (cross) { if (ln) MPG_BWDN(1, true, true); else MPG_BWDN(1, true, false); }
