@@ -808,6 +808,31 @@ def test_weight_gradient_side_stream_changes_no_result(use_graphs, split, B):
     assert torch.equal(with_it[0], without[0]) and torch.equal(with_it[1], without[1]) and with_it[2:] == without[2:]
 
 
+@pytest.mark.parametrize("use_graphs,split,N,B", [(True, False, 30, 64), (True, True, 30, 64), (False, False, 30, 16), (True, False, 150, 4)])
+def test_tail_arrangements_change_no_result(use_graphs, split, N, B):
+    """Round 5's two changes around the weight-gradient tails -- the generator-ahead branch forked behind the D step's last
+    data-gradient launch (``MPG_GEN_AHEAD_LATE``) and ``mpg_edge_dw``'s reduction inside the layer's grouped split-K reduction launch
+    (``ops.OPTIONS['dw_reduce_grouped']``: ``mpg_splitk_reduce_group_dw``) -- are arrangements of the same launches and sums: parameters
+    after three iterations are bit-identical with either of them off, as one graph, as three segments, eagerly, and at 150 particles
+    (sender chunks)."""
+    import os
+    from mpgan_amd import ops
+    ref = _three_steps(B, N, use_graphs, split=split)
+    os.environ["MPG_GEN_AHEAD_LATE"] = "0"
+    try:
+        early = _three_steps(B, N, use_graphs, split=split)
+    finally:
+        os.environ.pop("MPG_GEN_AHEAD_LATE", None)
+    saved = ops.OPTIONS["dw_reduce_grouped"]
+    ops.OPTIONS["dw_reduce_grouped"] = False
+    try:
+        own = _three_steps(B, N, use_graphs, split=split)
+    finally:
+        ops.OPTIONS["dw_reduce_grouped"] = saved
+    for r in (early, own):
+        assert torch.equal(ref[0], r[0]) and torch.equal(ref[1], r[1]) and ref[2:] == r[2:]
+
+
 @pytest.mark.parametrize("model", ["mpgan", "gapt"])
 def test_features_and_mask_held_apart_change_no_result(model):
     """TrainStep hands the generator's particle features and mask to the discriminator APART (``generate_parts`` /
