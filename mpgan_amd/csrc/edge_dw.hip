@@ -26,6 +26,9 @@
 #ifndef MPG_DW8_SETS
 #define MPG_DW8_SETS 1   // register sets of parked pieces in the uniform kernel (edge_dw8_kernel)
 #endif
+#ifndef MPG_DW_DEFAULT_WAVES
+#define MPG_DW_DEFAULT_WAVES 12  // waves per workgroup of mpg_edge_dw unless MPG_DW_WAVES says otherwise (8 | 12)
+#endif
 #ifndef MPG_DW_EXP
 #define MPG_DW_EXP 0  // experiment bits (tools/ubench/dw_bench.hip): 1 consumers idle, 2 builders idle, 4 no staged loads, 8 no LDS writes
 #endif
@@ -65,11 +68,22 @@ __device__ constexpr DwTile DW_TILES[45] = {
     {0,4,0},{0,4,1},{0,4,2},{0,4,3},{0,4,4},{0,5,0},{0,5,1},{0,5,2},{0,5,3},{0,5,4},{1,1,0},
     {1,1,1},{1,1,2},{1,2,0},{1,2,1},{1,2,2},{1,3,0},{1,3,1},{1,3,2},{1,4,0},{1,4,1},{1,4,2}};
 
-constexpr bool dw_same_rows(int t, int u) { return DW_TILES[t].prod == DW_TILES[u].prod && DW_TILES[t].m == DW_TILES[u].m; }
-constexpr bool dw_leader(int t, int begin) { return t == begin || !dw_same_rows(t, t - 1); }
-constexpr int dw_group_end(int t, int end) {
+// six consumers (edge_dw12_kernel): consumer w < 5 owns row w of dW3 (5 tiles) and row w of dW2 (3 tiles), consumer 5 row 5 of dW3:
+// ranges [0,8) [8,16) [16,24) [24,32) [32,40) [40,45)
+__device__ constexpr DwTile DW_TILES6[45] = {
+    {0,0,0},{0,0,1},{0,0,2},{0,0,3},{0,0,4},{1,0,0},{1,0,1},{1,0,2},
+    {0,1,0},{0,1,1},{0,1,2},{0,1,3},{0,1,4},{1,1,0},{1,1,1},{1,1,2},
+    {0,2,0},{0,2,1},{0,2,2},{0,2,3},{0,2,4},{1,2,0},{1,2,1},{1,2,2},
+    {0,3,0},{0,3,1},{0,3,2},{0,3,3},{0,3,4},{1,3,0},{1,3,1},{1,3,2},
+    {0,4,0},{0,4,1},{0,4,2},{0,4,3},{0,4,4},{1,4,0},{1,4,1},{1,4,2},
+    {0,5,0},{0,5,1},{0,5,2},{0,5,3},{0,5,4}};
+template <int TBL> constexpr DwTile dw_tile(int t) { return TBL ? DW_TILES6[t] : DW_TILES[t]; }
+
+template <int TBL> constexpr bool dw_same_rows(int t, int u) { return dw_tile<TBL>(t).prod == dw_tile<TBL>(u).prod && dw_tile<TBL>(t).m == dw_tile<TBL>(u).m; }
+template <int TBL> constexpr bool dw_leader(int t, int begin) { return t == begin || !dw_same_rows<TBL>(t, t - 1); }
+template <int TBL> constexpr int dw_group_end(int t, int end) {
     int e = t + 1;
-    while (e < end && dw_same_rows(t, e)) ++e;
+    while (e < end && dw_same_rows<TBL>(t, e)) ++e;
     return e;
 }
 
@@ -89,19 +103,19 @@ MPG_DEV f16x8 dw_frag(uint32_t lane_addr, int off, int rs) {
     return __builtin_bit_cast(f16x8, v);
 }
 
-constexpr bool dw_has_prod(int prod, int begin, int end) {
-    for (int t = begin; t < end; ++t) if (DW_TILES[t].prod == prod) return true;
+template <int TBL> constexpr bool dw_has_prod(int prod, int begin, int end) {
+    for (int t = begin; t < end; ++t) if (dw_tile<TBL>(t).prod == prod) return true;
     return false;
 }
-constexpr bool dw_uses_n(int prod, int n, int begin, int end) {
-    for (int t = begin; t < end; ++t) if (DW_TILES[t].prod == prod && DW_TILES[t].n == n) return true;
+template <int TBL> constexpr bool dw_uses_n(int prod, int n, int begin, int end) {
+    for (int t = begin; t < end; ++t) if (dw_tile<TBL>(t).prod == prod && dw_tile<TBL>(t).n == n) return true;
     return false;
 }
 
 // One block into the wave's accumulators: per k-step (16 receivers) the B fragments the wave's tiles of a product need
 // are read ONCE (E2: all five, E1: up to three), then every row group (same product and m) reads its A fragment and
 // issues its MFMAs.  The transposing reads are what bounds this kernel (LDS bandwidth), so no fragment is read twice.
-template <int BEGIN, int END>
+template <int BEGIN, int END, int TBL = 0>
 MPG_DEV void dw_consume(f32x16* acc, uint32_t buf, int lane) {
     // lane 4q+p of 16-lane group g supplies row (8 (g>>1) + q), feature columns 16 (g&1) + 4p .. +3 of the block
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
@@ -115,22 +129,22 @@ MPG_DEV void dw_consume(f32x16* acc, uint32_t buf, int lane) {
         asm volatile("" : "+v"(bz3), "+v"(be2), "+v"(bz2), "+v"(be1));
         static_for<0, 2>([&](auto pc) {
             MPG_CI(prod, pc);
-            if constexpr (dw_has_prod(prod, BEGIN, END)) {
+            if constexpr (dw_has_prod<TBL>(prod, BEGIN, END)) {
                 constexpr int rsa = prod == 0 ? DW_RS3 : DW_RS2, rsb = prod == 0 ? DW_RS2 : DW_RS1, nb = prod == 0 ? T2 : T1;
                 const uint32_t ba = prod == 0 ? bz3 : bz2, bb = prod == 0 ? be2 : be1;
                 f16x8 bfr[nb];
                 static_for<0, nb>([&](auto nc) {
                     MPG_CI(n, nc);
-                    if constexpr (dw_uses_n(prod, n, BEGIN, END)) bfr[n] = dw_frag(bb, 16 * s * rsb + 64 * n, rsb);
+                    if constexpr (dw_uses_n<TBL>(prod, n, BEGIN, END)) bfr[n] = dw_frag(bb, 16 * s * rsb + 64 * n, rsb);
                 });
                 static_for<BEGIN, END>([&](auto tc) {
                     MPG_CI(t, tc);
-                    if constexpr (DW_TILES[t].prod == prod && dw_leader(t, BEGIN)) {
-                        constexpr int ge = dw_group_end(t, END);
-                        const f16x8 a = dw_frag(ba, 16 * s * rsa + 64 * DW_TILES[t].m, rsa);
+                    if constexpr (dw_tile<TBL>(t).prod == prod && dw_leader<TBL>(t, BEGIN)) {
+                        constexpr int ge = dw_group_end<TBL>(t, END);
+                        const f16x8 a = dw_frag(ba, 16 * s * rsa + 64 * dw_tile<TBL>(t).m, rsa);
                         static_for<t, ge>([&](auto uc) {
                             MPG_CI(u, uc);
-                            acc[u - BEGIN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfr[DW_TILES[u].n], acc[u - BEGIN], 0, 0, 0);
+                            acc[u - BEGIN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfr[dw_tile<TBL>(u).n], acc[u - BEGIN], 0, 0, 0);
                         });
                     }
                 });
@@ -139,12 +153,12 @@ MPG_DEV void dw_consume(f32x16* acc, uint32_t buf, int lane) {
     }
 }
 
-template <int BEGIN, int END>
+template <int BEGIN, int END, int TBL = 0>
 MPG_DEV void dw_store(const f32x16* acc, float* part3, float* part2, int lane) {
     const int cc = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int t = BEGIN; t < END; ++t) {
-        const DwTile d = DW_TILES[t];
+        const DwTile d = dw_tile<TBL>(t);
         float* dst = d.prod == 0 ? part3 : part2;
         const int ncol = d.prod == 0 ? H2 : H1;
 #pragma unroll
@@ -183,7 +197,7 @@ MPG_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::
 
 // The per-workgroup loop of one consumer wave (its output tiles BEGIN..END of DW_TILES).  Instantiated per
 // role: a run-time branch around the MFMA section would make the accumulators merge at every join.
-template <int BEGIN, int END, int NQ>
+template <int BEGIN, int END, int NQ, int TBL = 0>
 MPG_DEV void dw_consumer(const MpgEdgeDw& p, int blk0, int blk1, unsigned long long vbits) {
     const int lane = threadIdx.x & 63;
     if constexpr (NQ > 0) lds_barrier();   // (the builders lay down the edge-scalar columns behind this one)
@@ -197,13 +211,13 @@ MPG_DEV void dw_consumer(const MpgEdgeDw& p, int blk0, int blk1, unsigned long l
     int cur = dw_next_valid(vbits, blk0, blk0, blk1), it = 0;
     lds_barrier();  // block `cur` is in buffer 0
     while (cur < blk1) {
-        if (!(MPG_DW_EXP & 1)) dw_consume<BEGIN, END>(acc, lds0 + (it & 1) * DW_BUF, lane);
+        if (!(MPG_DW_EXP & 1)) dw_consume<BEGIN, END, TBL>(acc, lds0 + (it & 1) * DW_BUF, lane);
         lds_barrier();
         cur = dw_next_valid(vbits, blk0, cur + 1, blk1);
         ++it;
     }
     float* part = p.part + (size_t)blockIdx.x * (H3 * H2 + H2 * H1 + H3 + H2);
-    dw_store<BEGIN, END>(acc, part, part + H3 * H2, lane);
+    dw_store<BEGIN, END, TBL>(acc, part, part + H3 * H2, lane);
     lds_barrier();   // (the builders exchange their bias sums through LDS behind this one)
 }
 
@@ -238,9 +252,14 @@ MPG_DEV int dw_launch_exp(const MpgEdgeDw& p) {
 }
 
 // NQ: edge scalars (0 or MPG_EDGE_SCALARS): E1 = lrelu(a_i + c_j + sum_q es(i, j, q) wq[q]), as the forward adds it up
-template <int DROP, int NQ>
+// NB builder waves behind NC consumer waves: 4 + 4 (edge_dw_kernel) or 6 + 6 (edge_dw12_kernel).  A receiver's pieces are dealt to
+// CS = 2 NB chunk groups: thread (r, cg) owns chunks cg, cg + CS, ... of each tensor -- 3 | 3 | 2 (dZ3 | the 160-feature ones | E1)
+// per block with four waves, 2 | 2 | 1 with six.
+template <int DROP, int NQ, int NB = 4, int NC = 4>
 MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk1, unsigned long long vbits) {
-    const int bt = threadIdx.x - 256;     // builder thread 0..255
+    constexpr int CS = 2 * NB, CQ = CS / 4, NZ3 = 24 / CS, N160 = (20 + CS - 1) / CS, NE1 = (12 + CS - 1) / CS;
+    static_assert(24 % CS == 0 && CS % 4 == 0, "chunk groups of whole quads, dZ3's 24 chunks dealt evenly");
+    const int bt = threadIdx.x - 64 * NC;     // builder thread 0 .. 64 NB - 1
     if constexpr (NQ > 0) {
         float* lwq = reinterpret_cast<float*>(smem + DW_LDS_BYTES);
         if (bt < NQ * H1) lwq[bt] = p.wq[bt];
@@ -260,11 +279,15 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
     uint32_t seed_lo = 0, seed_hi = 0;
     if (DROP) { const uint64_t sd = *p.seed; seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32); }
 
-    float db3[3][8], db2[3][8];
+    float db3[NZ3][8], db2[N160][8];
 #pragma unroll
-    for (int n = 0; n < 3; ++n)
+    for (int n = 0; n < NZ3; ++n)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { db3[n][k] = 0.f; db2[n][k] = 0.f; }
+        for (int k = 0; k < 8; ++k) db3[n][k] = 0.f;
+#pragma unroll
+    for (int n = 0; n < N160; ++n)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) db2[n][k] = 0.f;
     // Everything of a block is fetched ahead, RAW: nothing may be computed from a prefetched value before the block that
     // needs it (a use right behind the load would make every iteration wait for its youngest load, i.e. drain the whole
     // prefetch queue).  The parked pieces come from HBM -- a round trip under load is longer than one block's build -- and
@@ -272,16 +295,16 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
     // requested one block ahead.  Vector memory operations complete in issue order, so within a build the one-ahead
     // requests are issued before the two-ahead ones: the next build waits for nothing younger than what it needs.
     struct Small {
-        float dreg[3][8], areg[2][8];   // dagg / a of this thread's Z3 / E1 chunks (raw)
+        float dreg[NZ3][8], areg[NE1][8];   // dagg / a of this thread's Z3 / E1 chunks (raw)
         float dscl;                     // agg_scale * dscale * 2^eG, or 0 for a padding receiver
-        uint32_t sw[3];                 // sign words of the Z3 chunks' lanes
+        uint32_t sw[NZ3];               // sign words of the Z3 chunks' lanes
         unsigned int nbw;               // this receiver's neighbour word holding the block's sender (k-NN graphs)
-        float4 cv[2][2];                // c_j of the E1 chunks
+        float4 cv[NE1][2];              // c_j of the E1 chunks
         float esq[NQ > 0 ? NQ : 1];     // edge scalars of (this receiver, the block's sender)
     };
     struct Big {
-        f16x8 eh[3];                    // parked E2 pieces
-        f16x8 zh[3];                    // parked dZ2 pieces (in their block's gradient unit)
+        f16x8 eh[N160];                 // parked E2 pieces
+        f16x8 zh[N160];                 // parked dZ2 pieces (in their block's gradient unit)
     };
     Small S;
     Big B0, B1;
@@ -317,8 +340,12 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
                    __builtin_amdgcn_readlane(srb, l)};
     };
 
-    const bool third = cg < 4;  // chunk groups 0..3 own a third 160-feature piece and a second E1 chunk
-    auto e1tile = [&](int n) { return n == 0 || third ? 2 * n + (cg >> 2) : (cg >> 2); };  // 0..2
+    // piece n of the 160-feature tensors is chunk cg + CS n while that is one of their 20 chunks, E1 chunk n lies in tile (cg >> 2) + CQ n
+    // while that is one of its 3 tiles; a thread without an n-th piece redoes its previous one (see chunk160 below)
+    auto valid160 = [&](int n) { return cg + CS * n < 20; };
+    auto validE1 = [&](int n) { return (cg >> 2) + CQ * n < 3; };
+    auto tileZ3 = [&](int n) { return CQ * n + (cg >> 2); };   // 0..5
+    auto e1tile = [&](int n) { return validE1(n) ? (cg >> 2) + CQ * n : (cg >> 2) + CQ * (n - 1); };  // 0..2
     // p = 1/2 (one keep BIT per element, one hashed word per (edge row, 32-feature tile)): the four adjacent lanes that hold one
     // receiver's chunk groups need the SAME five words of a block -- the dZ3 tiles 2n + (cg >> 2), n = 0..2, and the E1 tiles
     // e1tile(0), e1tile(1) -- and used to hash all five each.  Now lane q of the quad hashes word q (one instruction sequence for
@@ -326,18 +353,21 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
     // them round: two hash sequences + five moves per block instead of five sequences (a tenth of what a builder wave issues; measured
     // in tools/ubench/dw_bench.hip: 115.5 -> 113.6 us at 512 jets, 70.4 -> 69.8 at 256 -- the builders are not bound by what they
     // issue alone: the sections that request memory take 1.0k of a block's 3.6k clk for ~100 instructions).
+    // (the block's words: dZ3 tiles n = 0 .. NZ3 - 1, then E1 tiles n = 0 .. NE1 - 1 -- five with four builder waves, three with six;
+    // lane q of a quad hashes word q, a fifth word everyone)
     uint32_t hcA = 0, hcB = 0;   // (grp + tag * 0x10001) * 0x85EBCA77 + seed_hi of drop_word, for this lane's word / the fifth
     if constexpr (DROP == 2) {
-        const int ql = bt & 3;
-        const uint32_t tagA = p.tag_base + (ql < 3 ? TAG_E2 : TAG_E0);
-        const uint32_t grpA = DROP_BIT_GRP + (uint32_t)(ql < 3 ? 2 * ql + (cg >> 2) : e1tile(0));
+        const int ql = min(bt & 3, NZ3 + NE1 - 1);
+        const uint32_t tagA = p.tag_base + (ql < NZ3 ? TAG_E2 : TAG_E0);
+        const uint32_t grpA = DROP_BIT_GRP + (uint32_t)(ql < NZ3 ? tileZ3(ql) : e1tile(ql - NZ3));
         hcA = (grpA + tagA * 0x10001u) * 0x85EBCA77u + seed_hi;
-        hcB = (DROP_BIT_GRP + (uint32_t)e1tile(1) + (p.tag_base + TAG_E0) * 0x10001u) * 0x85EBCA77u + seed_hi;
+        if constexpr (NZ3 + NE1 > 4)
+            hcB = (DROP_BIT_GRP + (uint32_t)e1tile(4 - NZ3) + (p.tag_base + TAG_E0) * 0x10001u) * 0x85EBCA77u + seed_hi;
     }
     // Threads of chunk groups 4..7 have no third piece of the 160-feature tensors (and no second E1 chunk): they
     // redo their previous piece instead (same data to the same place), which keeps the whole build free of
     // branches -- inside a branch the compiler waits for ALL outstanding loads, i.e. for the prefetches too.
-    auto chunk160 = [&](int n) { return n < 2 || third ? cg + 8 * n : cg + 8; };
+    auto chunk160 = [&](int n) { return valid160(n) ? cg + CS * n : cg + CS * (n - 1); };
 
     // Every global read is a raw buffer load: resource in SGPRs, block-dependent part as scalar offset, one
     // thread-constant VGPR offset per stream (plain pointers cost two VGPRs of address per load in flight).
@@ -349,13 +379,15 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
     const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.c), 0, p.B * p.N * ldac * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.B * p.N * ldac * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dagg), 0, p.B * p.N * p.ld_dagg * 4, 0x00020000);
-    int vo160[3];  // byte offset of this thread's piece n inside a 10 KiB block
+    int vo160[N160];  // byte offset of this thread's piece n inside a 10 KiB block
 #pragma unroll
-    for (int n = 0; n < 3; ++n) vo160[n] = (chunk160(n) * 32 + r) * 16;
-    const int voS = (32 * ch + r) * 4;
-    int voE1[2];   // byte offset of E1 chunk n's first feature inside a 96-float row of a / c
+    for (int n = 0; n < N160; ++n) vo160[n] = (chunk160(n) * 32 + r) * 16;
+    int voS[NZ3];     // byte offset of the sign word of dZ3 chunk n (word tile >> 1 of lane (r, h)) inside a block's 768 B
 #pragma unroll
-    for (int n = 0; n < 2; ++n) voE1[n] = (32 * e1tile(n) + f0) * 4;
+    for (int n = 0; n < NZ3; ++n) voS[n] = (32 * ch + r) * 4 + (tileZ3(n) >> 1) * 256;
+    int voE1[NE1];    // byte offset of E1 chunk n's first feature inside a 96-float row of a / c
+#pragma unroll
+    for (int n = 0; n < NE1; ++n) voE1[n] = (32 * e1tile(n) + f0) * 4;
     auto ldb4 = [&](__amdgpu_buffer_rsrc_t rs, int vo, int so) {
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
     };
@@ -367,8 +399,8 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
         P.dscl = ok ? p.agg_scale * p.dscale * unitG : 0.f;
         const int rowD = (ok ? ii : 0) * p.ld_dagg * 4 + (32 * (cg >> 2) + f0) * 4, soD = b * p.N * p.ld_dagg * 4;
 #pragma unroll
-        for (int n = 0; n < 3; ++n) {
-            const float4 u = ldb4(rD, rowD + 256 * n, soD), v = ldb4(rD, rowD + 256 * n + 32, soD);
+        for (int n = 0; n < NZ3; ++n) {
+            const float4 u = ldb4(rD, rowD + 32 * CS * n, soD), v = ldb4(rD, rowD + 32 * CS * n + 32, soD);
             P.dreg[n][0] = u.x; P.dreg[n][1] = u.y; P.dreg[n][2] = u.z; P.dreg[n][3] = u.w;
             P.dreg[n][4] = v.x; P.dreg[n][5] = v.y; P.dreg[n][6] = v.z; P.dreg[n][7] = v.w;
         }
@@ -378,7 +410,7 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
         const bool ok = ii < p.N;
         const int rowA = (ok ? ii : 0) * ldac * 4, soA = b * p.N * ldac * 4;
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
+        for (int n = 0; n < NE1; ++n) {
             const float4 u = ldb4(rA, rowA + voE1[n], soA), v = ldb4(rA, rowA + voE1[n] + 32, soA);
             P.areg[n][0] = u.x; P.areg[n][1] = u.y; P.areg[n][2] = u.z; P.areg[n][3] = u.w;
             P.areg[n][4] = v.x; P.areg[n][5] = v.y; P.areg[n][6] = v.z; P.areg[n][7] = v.w;
@@ -393,13 +425,13 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
     // behind them, the top of a build waited for them across the loop's back edge with vmcnt(0) -- 60 -> 67 us)
     auto load_sw = [&](Small& P, const Idx& X) {  // word (tile >> 1) = n of lane (r, h)
 #pragma unroll
-        for (int n = 0; n < 3; ++n) P.sw[n] = __builtin_amdgcn_raw_buffer_load_b32(rS, voS, X.blk * (T3 * 32 * 4) + n * 256, 0);
+        for (int n = 0; n < NZ3; ++n) P.sw[n] = __builtin_amdgcn_raw_buffer_load_b32(rS, voS[n], X.blk * (T3 * 32 * 4), 0);
     };
     const __amdgpu_buffer_rsrc_t rES = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.es), 0, NQ > 0 ? p.B * p.N * NQ * p.N * 4 : 0, 0x00020000);
     auto load_c = [&](Small& P, const Idx& X) {
         const int j = X.j, b = X.b, so = (b * p.N + j) * ldac * 4;
 #pragma unroll
-        for (int n = 0; n < 2; ++n) { P.cv[n][0] = ldb4(rC, voE1[n], so); P.cv[n][1] = ldb4(rC, voE1[n] + 32, so); }
+        for (int n = 0; n < NE1; ++n) { P.cv[n][0] = ldb4(rC, voE1[n], so); P.cv[n][1] = ldb4(rC, voE1[n] + 32, so); }
         if constexpr (NQ > 0) {
             const int rb = X.rb, ii = rb * 32 + r;
 #pragma unroll
@@ -418,7 +450,7 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
     auto load_small = [&](Small& P, const Idx& X) { load_d(P, X); load_sw(P, X); load_nb(P, X); load_c(P, X); load_a(P, X); };
     auto load_big = [&](Big& Q, int blk) {
 #pragma unroll
-        for (int n = 0; n < 3; ++n) { load_z2(Q, blk, n); load_e2(Q, blk, n); }
+        for (int n = 0; n < N160; ++n) { load_z2(Q, blk, n); load_e2(Q, blk, n); }
     };
 
 #ifdef MPG_DWSTAMP
@@ -445,27 +477,28 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
         // sums take it without the factor
         const float in_set = (p.nbr == nullptr || ((S.nbw >> (j & 31)) & 1u)) ? 1.f : 0.f;
         const float dscl_1 = S.dscl * in_set * dth, dscl_a = dscl_1 * p.alpha;   // (the dither factor rides in the slope constants)
-        uint32_t kz3[3] = {0xffu, 0xffu, 0xffu}, ke1[2] = {0xffu, 0xffu};   // keep bits of the block's chunks
+        uint32_t kz3[3] = {0xffu, 0xffu, 0xffu}, ke1[2] = {0xffu, 0xffu};   // keep bits of the block's chunks (NZ3 | NE1 of them used)
         if constexpr (DROP == 2) {
             const uint32_t x0 = (erow + seed_lo) * 0x9E3779B1u;
             auto fin = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; };
             const uint32_t wA = fin(x0 ^ hcA), wB = fin(x0 ^ hcB);
             auto bits = [&](uint32_t w) { w >>= f0; return (w & 0xfu) | ((w >> 4) & 0xf0u); };   // bits f0..f0+3 and f0+8..f0+11
-            kz3[0] = bits((uint32_t)__builtin_amdgcn_update_dpp(0, (int)wA, 0x00, 0xf, 0xf, false));   // quad_perm [0,0,0,0]
-            kz3[1] = bits((uint32_t)__builtin_amdgcn_update_dpp(0, (int)wA, 0x55, 0xf, 0xf, false));   // [1,1,1,1]
-            kz3[2] = bits((uint32_t)__builtin_amdgcn_update_dpp(0, (int)wA, 0xAA, 0xf, 0xf, false));   // [2,2,2,2]
-            ke1[0] = bits((uint32_t)__builtin_amdgcn_update_dpp(0, (int)wA, 0xFF, 0xf, 0xf, false));   // [3,3,3,3]
-            ke1[1] = bits(wB);
+            const uint32_t q0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wA, 0x00, 0xf, 0xf, false);   // quad_perm [0,0,0,0]
+            const uint32_t q1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wA, 0x55, 0xf, 0xf, false);   // [1,1,1,1]
+            const uint32_t q2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wA, 0xAA, 0xf, 0xf, false);   // [2,2,2,2]
+            const uint32_t q3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wA, 0xFF, 0xf, 0xf, false);   // [3,3,3,3]
+            if constexpr (NZ3 == 3) { kz3[0] = bits(q0); kz3[1] = bits(q1); kz3[2] = bits(q2); ke1[0] = bits(q3); ke1[1] = bits(wB); }
+            else { kz3[0] = bits(q0); kz3[1] = bits(q1); ke1[0] = bits(q2); (void)q3; (void)wB; }
         } else if constexpr (DROP == 1) {
 #pragma unroll
-            for (int n = 0; n < 3; ++n) kz3[n] = dw_chunk_keep<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, 2 * n + (cg >> 2), f0, p.thr);
+            for (int n = 0; n < NZ3; ++n) kz3[n] = dw_chunk_keep<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E2, erow, tileZ3(n), f0, p.thr);
 #pragma unroll
-            for (int n = 0; n < 2; ++n) ke1[n] = dw_chunk_keep<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, e1tile(n), f0, p.thr);
+            for (int n = 0; n < NE1; ++n) ke1[n] = dw_chunk_keep<DROP>(seed_lo, seed_hi, p.tag_base + TAG_E0, erow, e1tile(n), f0, p.thr);
         }
         DW_STAMP(0);   // block setup (index arithmetic, units, keep words) -- and whatever the barrier before it cost
 #pragma unroll
-        for (int n = 0; n < 3; ++n) {
-            const int m = 2 * n + (cg >> 2), c = cg + 8 * n;
+        for (int n = 0; n < NZ3; ++n) {
+            const int m = tileZ3(n), c = cg + CS * n;
             float v[8];
             const uint32_t keep = kz3[n];
             // sign bit of element k: bit 31 - (16 (m & 1) + 8 cs + k) of the lane's word -- shifted once so that the bit index
@@ -490,7 +523,7 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
         // rounded once, by mpg_edge_bwd -- to the launch's unit multiplies the OTHER operand of its product, built in
         // fp32 anyway (chunk groups 4..7: the second chunk repeats the first)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
+        for (int n = 0; n < NE1; ++n) {
             const int q = e1tile(n), c = 4 * q + (cg & 3);
             const float cc[8] = {S.cv[n][0].x, S.cv[n][0].y, S.cv[n][0].z, S.cv[n][0].w, S.cv[n][1].x, S.cv[n][1].y, S.cv[n][1].z, S.cv[n][1].w};
             float v[8];
@@ -524,10 +557,10 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
         if (!exp_noload) { load_c(S, X1); if (newrun) load_a(S, X1); }
         // dZ2: as parked; the bias sums (fp32) in the launch's unit
 #pragma unroll
-        for (int n = 0; n < 3; ++n) {
+        for (int n = 0; n < N160; ++n) {
             const int c = chunk160(n);
             if (!exp_nowrite) *reinterpret_cast<f16x8*>(buf + DW_Z2H + r * DW_RS2 + c * 16) = Q.zh[n];
-            const float take = n < 2 || third ? funit : 0.f;
+            const float take = valid160(n) ? funit : 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) db2[n][k] += take * (float)Q.zh[n][k];
             if (!exp_noload) load_z2(Q, pre2, n);
@@ -536,7 +569,7 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
         // E2: as parked, divided by the block's dither factor (its partner dZ3 was built times that factor)
         const f16x8 rc8 = {rch, rch, rch, rch, rch, rch, rch, rch};
 #pragma unroll
-        for (int n = 0; n < 3; ++n) {
+        for (int n = 0; n < N160; ++n) {
             const int c = chunk160(n);
             const f16x8 e = Q.eh[n] * rc8;
             if (!exp_nowrite) *reinterpret_cast<f16x8*>(buf + DW_E2H + r * DW_RS2 + c * 16) = e;
@@ -585,32 +618,33 @@ MPG_DEV void dw_builder(const MpgEdgeDw& p, int R, char* smem, int blk0, int blk
 #endif
     // bias sums: add the 32 receivers of a chunk group -- 16 in this wave (lane bits 2..5), 16 in its neighbour wave
     // (through LDS: the images are dead after the loop's last barrier); fragment-order index fi = 8 c + k
-    float* red = reinterpret_cast<float*>(smem);   // [wave 0..3][lane & 3][n][k][db3 | db2]
+    float* red = reinterpret_cast<float*>(smem);   // [wave 0 .. NB - 1][lane & 3][n][k][db3 | db2]
+    constexpr int NM = NZ3 > N160 ? NZ3 : N160;
     const int bw = bt >> 6, bl = bt & 3;
 #pragma unroll
-    for (int n = 0; n < 3; ++n)
+    for (int n = 0; n < NM; ++n)
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            float x = db3[n][k], y = db2[n][k];
+            float x = n < NZ3 ? db3[n < NZ3 ? n : 0][k] : 0.f, y = n < N160 ? db2[n < N160 ? n : 0][k] : 0.f;
 #pragma unroll
             for (int o = 4; o < 64; o <<= 1) { x += __shfl_xor(x, o, 64); y += __shfl_xor(y, o, 64); }
             if ((bt & 63) < 4) {
-                red[(((bw * 4 + bl) * 3 + n) * 8 + k) * 2 + 0] = x;
-                red[(((bw * 4 + bl) * 3 + n) * 8 + k) * 2 + 1] = y;
+                red[(((bw * 4 + bl) * NM + n) * 8 + k) * 2 + 0] = x;
+                red[(((bw * 4 + bl) * NM + n) * 8 + k) * 2 + 1] = y;
             }
         }
     lds_barrier();   // (the consumers take part in it, see dw_consumer)
     float* part = p.part + (size_t)blockIdx.x * (H3 * H2 + H2 * H1 + H3 + H2);
     float* pb3 = part + H3 * H2 + H2 * H1, *pb2 = pb3 + H3;
-    if (r == 0) {   // lanes 0..3 of waves 0 and 2: their own 16 receivers + those of waves 1 and 3
+    if (r == 0) {   // lanes 0..3 of the even waves: their own 16 receivers + those of the wave behind them
 #pragma unroll
-        for (int n = 0; n < 3; ++n)
+        for (int n = 0; n < NM; ++n)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int i0 = (((bw * 4 + bl) * 3 + n) * 8 + k) * 2, i1 = ((((bw + 1) * 4 + bl) * 3 + n) * 8 + k) * 2;
-                const int c = cg + 8 * n;
-                pb3[8 * c + k] = red[i0] + red[i1];
-                if (c < 2 * NFR2) pb2[8 * c + k] = red[i0 + 1] + red[i1 + 1];  // (the repeated third piece added zeros)
+                const int i0 = (((bw * 4 + bl) * NM + n) * 8 + k) * 2, i1 = ((((bw + 1) * 4 + bl) * NM + n) * 8 + k) * 2;
+                const int c = cg + CS * n;
+                if (n < NZ3) pb3[8 * c + k] = red[i0] + red[i1];
+                if (n < N160 && c < 2 * NFR2) pb2[8 * c + k] = red[i0 + 1] + red[i1 + 1];  // (a repeated piece added zeros)
             }
     }
 }
@@ -1043,6 +1077,27 @@ __global__ __launch_bounds__(512, 1) void edge_dw_kernel(const MpgEdgeDw p, cons
     else dw_builder<DROP, NQ>(p, R, smem, blk0, blk1, vbits);
 }
 
+// TWELVE waves, three per SIMD at <= 168 registers: six consumers (eight output tiles each -- 128 accumulator registers -- of
+// DW_TILES6) and six builders.  The builders are what bounds this kernel and a wave issues one VALU instruction per ~7 clk whatever
+// shares its SIMD: half as many builder instructions per wave again, on the same four SIMDs, is a block built in
+// two thirds of the time -- for twice the B-fragment reads of the consumers (each reads all of E2's five).  Same partials bit for bit.
+template <int DROP>
+__global__ __launch_bounds__(768, 3) void edge_dw12_kernel(const MpgEdgeDw p, const int R) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int RB = (p.N + 31) / 32;
+    const int nruns = p.B * RB * p.N / R;
+    const int blk0 = 0, blk1 = R * ((nruns - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);   // slots of this workgroup
+    const unsigned long long vbits = dw_valid_bits(p, R, blk0, blk1);
+    if (w == 0) dw_consumer<0, 8, 0, 1>(p, blk0, blk1, vbits);
+    else if (w == 1) dw_consumer<8, 16, 0, 1>(p, blk0, blk1, vbits);
+    else if (w == 2) dw_consumer<16, 24, 0, 1>(p, blk0, blk1, vbits);
+    else if (w == 3) dw_consumer<24, 32, 0, 1>(p, blk0, blk1, vbits);
+    else if (w == 4) dw_consumer<32, 40, 0, 1>(p, blk0, blk1, vbits);
+    else if (w == 5) dw_consumer<40, 45, 0, 1>(p, blk0, blk1, vbits);
+    else dw_builder<DROP, 0, 6, 6>(p, R, smem, blk0, blk1, vbits);
+}
+
 // out = scale * 2^-eG * sum over workgroup partials, feature indices mapped back from fragment order.
 // 32 outputs x 8 partial-slices per block: the 256 partials of an output are read by 8 threads.
 MPG_DEV void edge_dw_reduce_body(const int blk, const float* __restrict__ part, int nwg, float scale3, float scale, int accumulate,
@@ -1137,7 +1192,8 @@ extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
     if (!p->f16) return -8;
     if (p->gexp == nullptr) return -9;
     int R = 1;   // run length: the largest divisor of N up to 6 (see dw_block)
-    for (int d = 2; d <= 6; ++d) if (p->N % d == 0) R = d;
+    static const int rmax = [] { const char* e = getenv("MPG_DW_RUN"); return e != nullptr ? atoi(e) : 6; }();   // (experiments: longer runs re-read fewer rows)
+    for (int d = 2; d <= rmax; ++d) if (p->N % d == 0) R = d;
     {
         const int nruns = p->B * ((p->N + 31) / 32) * p->N / R;
         if (R * ((nruns + p->nwg - 1) / p->nwg) > 64) return -5;  // a workgroup walks at most 64 blocks (one ballot of valid bits)
@@ -1158,10 +1214,17 @@ extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
         }                                                                                                         \
     } while (0)
 #else
+    // (MPG_DW_WAVES=12: six consumers + six builders, three waves per SIMD; 8: four + four, two per SIMD)
+    static const bool twelve = [] { const char* e = getenv("MPG_DW_WAVES"); return e != nullptr ? atoi(e) == 12 : MPG_DW_DEFAULT_WAVES == 12; }();
 #define MPG_DW_ONE(D)                                                                                             \
     do {                                                                                                          \
-        MPG_ENSURE_LDS((edge_dw_kernel<D, 0>), DW_LDS_BYTES);                                                     \
-        hipLaunchKernelGGL((edge_dw_kernel<D, 0>), grid, block, DW_LDS_BYTES, st, *p, R);                         \
+        if (twelve) {                                                                                             \
+            MPG_ENSURE_LDS((edge_dw12_kernel<D>), DW_LDS_BYTES);                                                  \
+            hipLaunchKernelGGL((edge_dw12_kernel<D>), grid, dim3(768), DW_LDS_BYTES, st, *p, R);                  \
+        } else {                                                                                                  \
+            MPG_ENSURE_LDS((edge_dw_kernel<D, 0>), DW_LDS_BYTES);                                                 \
+            hipLaunchKernelGGL((edge_dw_kernel<D, 0>), grid, block, DW_LDS_BYTES, st, *p, R);                     \
+        }                                                                                                         \
     } while (0)
 #endif
 #ifdef MPG_SINGLE_VARIANT  // tools/ubench/dw_bench.hip: one instantiation
