@@ -17,7 +17,7 @@ rm -rf $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o b -- python3 $R/bench.py --model gapt --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/final/gapt_under_rocprof.log 2>&1 || exit 1
 python3 $R/tools/prof_summary.py $out 40 > $R/gpurun_out/final/gapt_stats_summary.txt
 echo "stats done"
-KERNELS=("edge_fwd1_fn_kernel<0" "edge_fwd1_fn_kernel<2" "edge_bwd1_fn_kernel<0, true" "edge_bwd1_fn_kernel<0, false" "edge_bwd1_fn_kernel<2, true" "edge_bwd1_fn_kernel<2, false" "edge_dw_kernel<0" "edge_dw_kernel<2" chain2_kernel gemm_group_kernel)
+KERNELS=("edge_fwd1_fn_kernel<0" "edge_fwd1_fn_kernel<2" "edge_bwd1_fn_kernel<0, true" "edge_bwd1_fn_kernel<0, false" "edge_bwd1_fn_kernel<2, true" "edge_bwd1_fn_kernel<2, false" "edge_dw12_kernel<0" "edge_dw12_kernel<2" chain2_kernel gemm_group_kernel)
 for c in FETCH_SIZE WRITE_SIZE; do
   o=$R/gpurun_out/final/pmc_$c
   rm -rf $o
@@ -30,7 +30,7 @@ echo "pmc done"
 o=$R/gpurun_out/final/pmc_sq
 rm -rf $o
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $o -o p -- python3 $R/tools/kbwd.py > $o.log 2>&1 || { tail -5 $o.log; exit 1; }
-for k in "edge_fwd1_fn_kernel<0" "edge_fwd1_fn_kernel<2" "edge_bwd1_fn_kernel<0, true" "edge_bwd1_fn_kernel<0, false" "edge_bwd1_fn_kernel<2, true" "edge_bwd1_fn_kernel<2, false" "edge_dw_kernel<0" "edge_dw_kernel<2"; do
+for k in "edge_fwd1_fn_kernel<0" "edge_fwd1_fn_kernel<2" "edge_bwd1_fn_kernel<0, true" "edge_bwd1_fn_kernel<0, false" "edge_bwd1_fn_kernel<2, true" "edge_bwd1_fn_kernel<2, false" "edge_dw12_kernel<0" "edge_dw12_kernel<2"; do
   echo "== $k"; python3 $R/tools/pmc_summary.py $o "$k"
 done > $R/gpurun_out/final/pmc_sq_summary.txt 2>&1
 # the one-launch attention blocks of GAPT: SQ counters and HBM traffic from a short bench run (no timing legs)
@@ -50,7 +50,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   o=$R/gpurun_out/final/pmc_n150_$c
   rm -rf $o
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $o -o p -- python3 $R/bench.py --particles 150 --batch 16 --steps 3 --warmup 2 --no-graphs --no-roofline --no-cpu-baseline --no-secondary > $o.log 2>&1 || { tail -5 $o.log; exit 1; }
-  for k in edge_fwd edge_bwd edge_dw_kernel chain disc_head; do
+  for k in edge_fwd edge_bwd edge_dw1 chain disc_head; do
     echo "== mpgan_n150_b16 $c $k"; python3 $R/tools/pmc_summary.py $o "$k"
   done
   for k in mab_bwd mab_chain_fwd mab_fwd bridge; do

@@ -54,7 +54,7 @@ def tot(k): return (2 * kb("FETCH_SIZE", k) + kb("WRITE_SIZE", k)) * 1024
 rows = [("edge_fwd1_fn_kernel<0", "forward, no dropout"), ("edge_fwd1_fn_kernel<2", "forward, p = 1/2"),
         ("edge_bwd1_fn_kernel<0, true", "backward + staging"), ("edge_bwd1_fn_kernel<0, false", "backward, data path only"),
         ("edge_bwd1_fn_kernel<2, true", "backward + staging, p = 1/2"), ("edge_bwd1_fn_kernel<2, false", "backward, data path, p = 1/2"),
-        ("edge_dw_kernel<0", "weight gradients"), ("edge_dw_kernel<2", "weight gradients, p = 1/2"),
+        ("edge_dw12_kernel<0", "weight gradients"), ("edge_dw12_kernel<2", "weight gradients, p = 1/2"),
         ("chain2_kernel", "chained node layers (all uses)"), ("gemm_group_kernel", "grouped dense weight gradients")]
 txt = ("# HBM traffic of the fused kernels: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (one counter per pass, as\n"
        "# MI355X_MICROARCH.md prescribes); workload tools/kbwd.py = MPLayer forward+backward at B=256, N=30 (one launch = 256 jets,\n"
@@ -75,7 +75,7 @@ def rate(sub, key):
 txt += ("#\n# Achieved HBM rate at B=256 (bytes above / rocprof average duration in " + f"{tag}_bench_kernel_stats.csv" + "; HBM3E peak 8 TB/s):\n"
         f"#   edge_fwd1_fn_kernel<0, true>   {rate('edge_fwd1_fn_kernel<0, true', 'edge_fwd1_fn_kernel<0'):5.2f} TB/s  (compute bound: see the SQ counters)\n"
         f"#   edge_bwd1_fn_kernel<0, true>   {rate('edge_bwd1_fn_kernel<0, true', 'edge_bwd1_fn_kernel<0, true'):5.2f} TB/s\n"
-        f"#   edge_dw_kernel<0>          {rate('edge_dw_kernel<0', 'edge_dw_kernel<0'):5.2f} TB/s\n")
+        f"#   edge_dw12_kernel<0>        {rate('edge_dw12_kernel<0', 'edge_dw12_kernel<0'):5.2f} TB/s\n")
 txt += ("#\n# forward: a|c in, agg + sign words out (algorithmic 17.7 MB) + 10 KiB of fp16 E2 fragments per unmasked (jet, sender) block,\n"
         "# parked for the backward (which reads them for the LeakyReLU gate instead of recomputing the layer) and for mpg_edge_dw;\n"
         "# backward + staging: 10 KiB of fp16 dZ2 fragments per block; mpg_edge_dw reads both back and writes 256 per-workgroup\n"
@@ -92,7 +92,7 @@ traffic = {
     # algorithmic, not in the PMC workload), 2 at 2B and 4 at B with sign words and parked E2
     "edge_fwd_fn_kernel": {"bytes_per_launch": int((2 * 13.3e6 + 2 * 2 * tot("edge_fwd1_fn_kernel<2") + 4 * tot("edge_fwd1_fn_kernel<0")) / 8)},
     "edge_bwd_fn_kernel": {"bytes_per_launch": int((2 * 2 * w + 2 * wo + 2 * w0) / 6)},
-    "edge_dw_kernel": {"bytes_per_launch": int(tot("edge_dw_kernel<2"))},
+    "edge_dw_kernel": {"bytes_per_launch": int(tot("edge_dw12_kernel<2"))},
 }
 # ---- the secondary workloads' kernels (bench.py: secondary.*.roofline.traffic), launch-weighted over every dispatch whose name
 #      contains the entry point's stem (mab_bwd = mab_bwd_kernel + mab_bwd2_kernel, edge_fwd = the eight-wave edge_fwd1_kernel ...)
@@ -107,11 +107,11 @@ if os.path.isfile(sp):
         if m and cur:
             sv[cur] = float(m.group(3))
     sec = {}
-    for wl, stems in (("gapt_n30_b512", ("mab_bwd", "mab_chain_fwd", "mab_fwd", "bridge")), ("mpgan_n150_b16", ("edge_fwd", "edge_bwd", "edge_dw_kernel", "chain", "disc_head"))):
+    for wl, stems in (("gapt_n30_b512", ("mab_bwd", "mab_chain_fwd", "mab_fwd", "bridge")), ("mpgan_n150_b16", ("edge_fwd", "edge_bwd", "edge_dw1", "chain", "disc_head"))):
         for st in stems:
             f, w_ = sv.get((wl, "FETCH_SIZE", st)), sv.get((wl, "WRITE_SIZE", st))
             if f is not None and w_ is not None:
-                kn = st if st.endswith("_kernel") else st + "_kernel"
+                kn = "edge_dw_kernel" if st.startswith("edge_dw") else (st if st.endswith("_kernel") else st + "_kernel")
                 sec.setdefault(wl, {})[kn] = {"bytes_per_launch": int((2 * f + w_) * 1024)}
     traffic["secondary"] = sec
     traffic["note"] += ("; secondary: per launch, launch-weighted over every dispatch of the entry point's kernels in a short bench.py run "
@@ -132,14 +132,14 @@ if os.path.isfile(sq_path):
             tab[cur][m.group(1)] = float(m.group(3))
     txt = ("# SQ counters of the fused edge kernels (rocprofv3 --kernel-trace --pmc ..., workload tools/kbwd.py, B=256, N=30),\n"
            "# per dispatch.  Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over\n"
-           "# waves; SQ_VALU_MFMA_BUSY_CYCLES counts cycles (= 32 x number of 32x32x16 MFMAs) summed over SIMDs.  Two waves per SIMD in every\n"
-           "# kernel (the eight-wave forms), so  MFMA share of wave time = MFMA_BUSY / (4 x WAVE_CYCLES / 2);  by DEVICE time (last column):\n"
+           "# waves; SQ_VALU_MFMA_BUSY_CYCLES counts cycles (= 32 x number of 32x32x16 MFMAs) summed over SIMDs.  Two waves per SIMD in the\n"
+           "# eight-wave kernels (three in edge_dw12_kernel), so  MFMA share of wave time = MFMA_BUSY / (4 x WAVE_CYCLES / waves per SIMD);  by DEVICE time (last column):\n"
            "# MFMA_BUSY / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs).\n#\n"
            "#   kernel                               MFMA busy / wave time   wave parked (WAIT_ANY)   issue stalled (WAIT_INST_ANY)   VALU active   VALU instr per MFMA   MFMA busy / device time\n")
     for k, v in tab.items():
         if not v.get("SQ_WAVE_CYCLES"):
             continue
-        wps = 2.0   # (eight waves per workgroup in every edge kernel: two per SIMD)
+        wps = 3.0 if "edge_dw12" in k else 2.0   # (eight waves per workgroup in the edge kernels: two per SIMD; twelve in mpg_edge_dw: three)
         wc = v["SQ_WAVE_CYCLES"]
         nm = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 32.0
         txt += (f"#   {k:38s} {v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (4 * wc / wps):8.2f} {v.get('SQ_WAIT_ANY', 0) / wc:22.2f} "
