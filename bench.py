@@ -107,7 +107,15 @@ def parse_args():
                     help="mpgan = the headline config; gapt = BASELINE config 4 (not the bench line)")
     ap.add_argument("--batch", type=int, default=0, help="jets per GPU (weak scaling); default 256 (mpgan) / 512 (gapt)")
     ap.add_argument("--particles", type=int, default=30)
-    ap.add_argument("--dist", default="gluon", choices=["gluon", "uniform"], help="particle-multiplicity law")
+    ap.add_argument("--jets", default="g", choices=["g", "t", "q"],
+                    help="jet type (reference --jets): picks the learning rates of setup_training.py:848-872 and the synthetic "
+                         "multiplicity law; g = the headline, t = BASELINE config 3 (top jets)")
+    ap.add_argument("--dist", default=None, choices=["gluon", "top", "quark", "uniform"],
+                    help="particle-multiplicity law of the synthetic jets (default: the --jets type's own)")
+    ap.add_argument("--gp", type=float, default=0.0,
+                    help="gradient-penalty weight (reference --gp; train.py:286-324): the D step takes the double-backward route; "
+                         "implies --loss w unless given")
+    ap.add_argument("--loss", default=None, choices=["ls", "og", "w", "hinge"])
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -163,9 +171,11 @@ def main():
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     B, N = args.batch or (256 if args.model == "mpgan" else 512), args.particles
-    out, ts = run_workload(torch, dist, args.model, B, N, args.steps, args.warmup, dev, rank, world, pg, args.dist,
-                           not args.no_graphs, share)
-    headline = args.model == "mpgan" and N == 30 and B == 256
+    mult = args.dist or JET_LAW[args.jets]
+    loss = args.loss or ("w" if args.gp else "ls")
+    out, ts = run_workload(torch, dist, args.model, B, N, args.steps, args.warmup, dev, rank, world, pg, mult,
+                           not args.no_graphs, share, jets=args.jets, loss=loss, gp=args.gp)
+    headline = args.model == "mpgan" and N == 30 and B == 256 and args.jets == "g" and not args.gp and loss == "ls"
     if world > 1 or pg is not None:
         # what the exchange really was: ranks in the RCCL communicator, its version, and whether the two all-reduces sat
         # between three hipGraph segments (default) or inside one graph (MPG_GRAPH_COLLECTIVES=1)
@@ -193,7 +203,7 @@ def main():
         out["secondary"] = {}
         for key, (model2, B2, N2) in {"gapt_n30_b512": ("gapt", 512, 30), "mpgan_n150_b16": ("mpgan", 16, 150)}.items():
             torch.cuda.empty_cache()
-            o2, ts2 = run_workload(torch, dist, model2, B2, N2, 100, 20, dev, 0, 1, None, args.dist, not args.no_graphs, False)
+            o2, ts2 = run_workload(torch, dist, model2, B2, N2, 100, 20, dev, 0, 1, None, mult, not args.no_graphs, False)
             sec = {"metric": o2["metric"], "value": o2["value"], "unit": o2["unit"], "ms_per_step": o2["ms_per_step"],
                    "steps": 100, "warmup": 20, "config": o2["config"], "losses": o2["losses"]}
             if not args.no_roofline:
@@ -203,6 +213,14 @@ def main():
                 sec["cpu_baseline"] = cpu_baseline(torch, model2, N2, B2, short=True)
             out["secondary"][key] = sec
             log("secondary", key, f"{o2['value']:.0f} jets/s")
+        # the gradient-penalty route (reference --gp 10 --loss w, train.py:286-324): D(interpolated) on the double-backward
+        # route (mpg_gemm + ATen, the N x N edge tensor in memory), everything else on the fused kernels; eager -- its
+        # autograd.grad(create_graph=True) is host-driven -- a few iterations, its own timing only
+        torch.cuda.empty_cache()
+        o3, ts3 = run_workload(torch, dist, "mpgan", 256, 30, 10, 3, dev, 0, 1, None, mult, False, False, loss="w", gp=10.0)
+        del ts3
+        out["secondary"]["mpgan_n30_b256_gp"] = {k: o3[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "losses")}
+        log("secondary", "mpgan_n30_b256_gp", f"{o3['value']:.0f} jets/s")
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -215,15 +233,20 @@ def main():
         dist.destroy_process_group()
 
 
-def run_workload(torch, dist, model, B, N, steps, warmup, dev, rank, world, pg, mult, graphs, share):
+LOSS_NAME = {"ls": "LSGAN", "og": "BCE GAN", "w": "Wasserstein", "hinge": "hinge"}
+JET_LAW = {"g": "gluon", "t": "top", "q": "quark"}
+JET_NAME = {"g": "gluon", "t": "top", "q": "quark"}
+
+
+def run_workload(torch, dist, model, B, N, steps, warmup, dev, rank, world, pg, mult, graphs, share, jets="g", loss="ls", gp=0.0):
     """``warmup`` untimed + ``steps`` timed G+D iterations of ``model`` at B jets per GPU, N particles; returns the JSON
     line's fields for it (value = whole-job jets/s over the MAX time over ranks) and the TrainStep."""
     from mpgan_amd import train, ops, dist as mdist
     from mpgan_amd.data import synthetic_jets
     torch.manual_seed(4 + rank)  # setup_training.py:184 (+ rank: every rank draws its own noise)
     if model == "mpgan":
-        G, D = train.default_mpgan(N, disc_dropout=0.5, device=dev)
-        latent, (lr_d, lr_g) = 32, train.LR["g"]
+        G, D = train.default_mpgan(N, disc_dropout=0.5, device=dev, loss=loss)
+        latent, (lr_d, lr_g) = 32, train.LR[jets]      # setup_training.py:848-872: per jet type
     else:
         G, D = train.default_gapt(N, disc_dropout=0.5, device=dev)
         latent, (lr_d, lr_g) = 64, train.LR_GAPT
@@ -231,7 +254,7 @@ def run_workload(torch, dist, model, B, N, steps, warmup, dev, rank, world, pg, 
         mdist.broadcast_module(G, 0, pg)
         mdist.broadcast_module(D, 0, pg)
     ts = train.TrainStep(G, D, B, N, latent=latent, lr_disc=lr_d, lr_gen=lr_g, use_graphs=graphs,
-                         process_group=pg, world_size=world)
+                         process_group=pg, world_size=world, loss=loss, gp_lambda=gp)
     data, labels = synthetic_jets(B, N, seed=4 + rank, dist=mult)
     ts.set_batch(data.to(dev), labels.to(dev))
     ops.set_seed(mdist.rank_seed(0x5EED, rank), dev)
@@ -260,10 +283,11 @@ def run_workload(torch, dist, model, B, N, steps, warmup, dev, rank, world, pg, 
     log(f"timed {steps} steps in {dt:.3f} s -> {jets_per_s:.0f} jets/s")
     d_loss, g_loss = float(ts.D_loss), float(ts.G_loss)
 
-    headline = model == "mpgan" and N == 30 and B == 256
+    headline = model == "mpgan" and N == 30 and B == 256 and jets == "g" and not gp and loss == "ls"
+    variant = ("" if jets == "g" else f" {JET_NAME[jets]} jets") + (f" loss={loss}" if loss != "ls" else "") + (f" gp={gp:g}" if gp else "")
     out = {
         "metric": "jets/sec (G+D step) MPGAN gluon N=30 bs=256 @1/2/4/8 MI355X" if headline
-                  else f"jets/sec (G+D step) {model} N={N} bs={B}",
+                  else f"jets/sec (G+D step) {model} N={N} bs={B}{variant}",
         "value": jets_per_s, "unit": "jets/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "split-16-bit MFMA, fp32 accumulate, fp32 in/out: f16 hi/lo x3 terms (forward), f16 x2 / x1 "
@@ -271,8 +295,10 @@ def run_workload(torch, dist, model, B, N, steps, warmup, dev, rank, world, pg, 
                  "gradients)" if model == "mpgan" else
                  "split-16-bit MFMA, fp32 accumulate, fp32 in/out: f16 hi/lo x3 terms (forward), bf16 hi/lo x3 (gradients)",
         "data": "synthetic",
-        "config": {"workload": f"{model.upper()} gluon-like jets, N={N} particles, B={B} per GPU, one "
-                               "train_D+train_G iteration (LSGAN, RMSprop, D dropout 0.5)",
+        "config": {"workload": f"{model.upper()} {JET_NAME[jets]}-like jets (--jets {jets}: lr_disc {lr_d:g}, lr_gen {lr_g:g}), N={N} particles, "
+                               f"B={B} per GPU, one train_D+train_G iteration ({LOSS_NAME[loss]}"
+                               + (f" + gradient penalty {gp:g} on the double-backward route" if gp else "") + ", RMSprop, D dropout 0.5)",
+                   "jets": jets, "lr_disc": lr_d, "lr_gen": lr_g, "loss": loss, "gp_lambda": gp,
                    "global_batch": world * B, "particles": N, "multiplicity": mult,
                    "mean_multiplicity": valid_frac * N, "parallelism": f"dp{world}", "hip_graphs": graphs,
                    **({"rehearsal": "all ranks share cuda:0, gloo exchange (MPGAN_BENCH_SHARE_GPU)"} if share else {})},
@@ -397,23 +423,34 @@ def roofline(torch, ts, model, dev, measured_traffic=True, workload=None):
     name = max(tot, key=lambda k: tot[k][0])
     ms_sum, flop_sum, byte_sum, nl = tot[name]
     kname = name.replace("mpg_", "") + "_kernel"
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    # PMC measurement of this kernel (tools/pmc.sh, FETCH_SIZE x2 + WRITE_SIZE), bytes per launch; it belongs to the
+    # PMC measurement of this kernel (tools/final_profiles.sh, FETCH_SIZE x2 + WRITE_SIZE), bytes per launch; it belongs to the
     # headline workload the counters were collected on and is left null for any other
-    # (``workload``: the secondary workloads' own entries, profiles/hbm_traffic.json: {"secondary": {workload: {kernel: ...}}})
+    # (``workload``: the secondary workloads' own entries, profiles/hbm_traffic.json: {"secondary": {workload: {kernel: ...}}}).
+    # The counters are not collected in this run (rocprofv3 --pmc passes of their own): ``traffic_source`` says which committed
+    # profile the figure comes from and whether the kernel sources it was measured on are the ones this library was built from
+    # -- if not, the figure is DROPPED (null), not carried along stale.
     if os.path.isfile(tpath):
         tj = json.load(open(tpath))
         if workload is not None:
             traffic = tj.get("secondary", {}).get(workload, {}).get(kname, {}).get("bytes_per_launch")
         elif measured_traffic:
             traffic = tj.get(kname, {}).get("bytes_per_launch")
+        src = tj.get("source") or {}
+        now = _lib.source_digest()
+        traffic_source = {"file": "profiles/hbm_traffic.json", "profile": src.get("profile"),
+                          "measured_on_source_digest": src.get("source_digest"), "this_source_digest": now,
+                          "current": src.get("source_digest") == now}
+        if traffic is not None and not traffic_source["current"]:
+            traffic_source["dropped_stale_bytes_per_launch"] = traffic
+            traffic = None
     # MPGAN's fused edge kernels are MFMA-bound by >100x; GAPT's launches are HBM / latency bound
     mfma = name.startswith("mpg_edge") or (flop_sum / max(byte_sum, 1) > PEAK_MFMA_16BIT / PEAK_HBM)
     if mfma:
         ach = flop_sum / (ms_sum * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": PEAK_MFMA_16BIT / 1e12, "unit": "TFLOP/s",
-                "frac": ach * 1e12 / PEAK_MFMA_16BIT, "traffic": traffic,
+                "frac": ach * 1e12 / PEAK_MFMA_16BIT, "traffic": traffic, "traffic_source": traffic_source,
                 "flop_per_launch": flop_sum / nl, "avg_launch_ms": ms_sum / nl,
                 "note": "algorithmic FLOPs of the two fused dense layers (one MAC = 2 FLOP, all B*N*N edges) over the "
                         "HIP-event time of all launches of the kernel in a step; the forward issues 3 MFMA MACs per "
@@ -423,7 +460,7 @@ def roofline(torch, ts, model, dev, measured_traffic=True, workload=None):
     else:
         ach = byte_sum / (ms_sum * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                "frac": ach * 1e9 / PEAK_HBM, "traffic": traffic,
+                "frac": ach * 1e9 / PEAK_HBM, "traffic": traffic, "traffic_source": traffic_source,
                 "bytes_per_launch": byte_sum / nl, "avg_launch_ms": ms_sum / nl,
                 "launches_per_step_all_kernels": sum(v["launches_per_step"] for v in kern.values()),
                 "note": "algorithmic bytes (operands read once + results written once, fp32) over the HIP-event time of "

@@ -325,7 +325,8 @@ int mpg_rank_mask(const float* x, int ld_jet, int ld_part, const float* labels, 
  * 8 = eight waves per workgroup (two per SIMD, one sender per wave: csrc/edge_fwd1_impl.h, edge_bwd1_impl.h), 4 = four waves
  * (one per SIMD, senders in pairs: edge_fwd2_impl.h, edge_bwd2_impl.h), 0 = as the environment says (MPG_FWD_WAVES / MPG_BWD_WAVES;
  * default 8).  Same function either way; the sums over senders (agg, da) are ordered differently, so results agree to fp32
- * rounding, not bit for bit.  The epilogue forms (mpg_edge_fwd_fn, mpg_edge_bwd_fn) are four-wave kernels.  Returns 0, or -1 for
+ * rounding, not bit for bit.  The epilogue forms (mpg_edge_fwd_fn, mpg_edge_bwd_fn) follow the same switch (default eight; their own
+ * environment switches: MPG_FWD_FN_WAVES / MPG_BWD_FN_WAVES).  Returns 0, or -1 for
  * any other value.  (No reference counterpart: a launch-shape switch.) */
 int mpg_edge_waves(int fwd, int bwd);
 int mpg_edge_waves_get(int which);   /* the value set for fwd (which = 0) / bwd (1) */

@@ -282,14 +282,47 @@ def _includes(path, seen):
                 break
 
 
-def _digest(src, flags) -> str:
+_compiler_id_cache = {}
+
+
+def _compiler_id(hipcc: str) -> str:
+    """What identifies the compiler behind ``hipcc`` for the object cache: its resolved path and its own ``--version`` text (ROCm
+    / clang version, install directory); if that cannot be run, the binary's size and mtime.  A ROCm upgrade or another
+    HIPCC must not link objects of the old compiler into the library."""
+    if hipcc not in _compiler_id_cache:
+        real = os.path.realpath(hipcc)
+        try:
+            ver = subprocess.run([hipcc, "--version"], check=True, capture_output=True, text=True, env=_compiler_env(),
+                                 timeout=60).stdout
+        except Exception:   # noqa: BLE001 -- the fallback still tells two installs apart
+            st = os.stat(real) if os.path.exists(real) else None
+            ver = "unversioned %s %s" % ((st.st_size, int(st.st_mtime)) if st else ("?", "?"))
+        _compiler_id_cache[hipcc] = real + "\n" + ver
+    return _compiler_id_cache[hipcc]
+
+
+def _digest(src, flags, hipcc=None) -> str:
     import hashlib
     deps = set()
     _includes(os.path.abspath(src), deps)
     h = hashlib.sha1(" ".join(flags).encode())
+    if hipcc is not None:
+        h.update(b"\0" + _compiler_id(hipcc).encode() + b"\0")
     for d in sorted(deps):
         with open(d, "rb") as f:
             h.update(os.path.relpath(d, CSRC).encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()[:16]
+
+
+def source_digest() -> str:
+    """Digest of everything the library is compiled from (csrc/*.hip, csrc/*.h, include/*.h): what a measurement taken on the
+    built library belongs to.  ``profiles/hbm_traffic.json`` carries the digest of the tree its counters were collected on;
+    ``bench.py`` reports a measured ``roofline.traffic`` only while it still equals this one."""
+    import hashlib
+    h = hashlib.sha1()
+    for d in sorted(sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))):
+        with open(d, "rb") as f:
+            h.update(os.path.basename(d).encode() + b"\0" + f.read() + b"\0")
     return h.hexdigest()[:16]
 
 
@@ -327,7 +360,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         env = _compiler_env()
         tmpdir = tempfile.mkdtemp(prefix=".build.", dir=LIBDIR)
         # Object cache (LIBDIR/obj, git-ignored with the library): an object is reused when the digest of its source, of
-        # every header it includes (transitively, quoted includes) and of the compiler flags is unchanged -- editing one kernel
+        # every header it includes (transitively, quoted includes), of the compiler flags and of the compiler's identity
+        # (_compiler_id) is unchanged -- editing one kernel
         # recompiles its translation units only.  ``force`` (the driver's "does it build" check) ignores the cache.
         objdir = os.path.join(LIBDIR, "obj")
         os.makedirs(objdir, exist_ok=True)
@@ -336,7 +370,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + EXTRA_FLAGS
             for src in sources():
                 base = os.path.basename(src)[:-4]
-                obj = os.path.join(objdir, "%s.%s.o" % (base, _digest(src, flags)))
+                obj = os.path.join(objdir, "%s.%s.o" % (base, _digest(src, flags, hipcc)))
                 objs.append(obj)
                 if force or not os.path.isfile(obj):
                     tmpobj = os.path.join(tmpdir, base + ".o")

@@ -37,7 +37,8 @@ extern "C" int mpg_edge_fwd_fn(const MpgEdgeFwd* p, const MpgChain* c, const Mpg
             sl = true;
         }
     }
-    if ((size_t)p->B * p->N * 192 * 4 >= 0x7fffffffull) return MPG_FN_NA;
+    // (the sender chunks' slabs are addressed with 32-bit offsets through ONE buffer resource over all SC of them)
+    if ((size_t)p->SC * p->B * p->N * 192 * 4 >= 0x7fffffffull) return MPG_FN_NA;
     if (c2 != nullptr) {   // the next layer's a | c projection on fn's output rows: its own mpg_chain call (one layer, K <= 32)
         const MpgChainLayer& L = c2->L[0];
         if (c2->nlayers != 1 || !c2->f16 || c2->M != c->M || c2->a_slabs != 1 || c2->in_thr != 0 || c2->in_out != nullptr) return -2;

@@ -34,7 +34,10 @@ FEATURE_SHIFTS = [0.0, 0.0, -0.5, -0.5]    # gen.py:17, train.py:43
 def synthetic_jets(B: int, N: int, seed: int = 4, dist: str = "gluon", dtype=torch.float32):
     """``(data [B,N,4], labels [B,1])`` of synthetic JetNet-like jets, already normalised.
 
-    Multiplicity n per jet: ``gluon`` = clip(round(Normal(0.8 N, 0.15 N)), 1, N), ``uniform`` = UniformInt[1, N].
+    Multiplicity n per jet: ``gluon`` = clip(round(Normal(0.8 N, 0.15 N)), 1, N), ``uniform`` = UniformInt[1, N]; ``top`` =
+    clip(round(Normal(0.95 N, 0.08 N)), 1, N) and ``quark`` = clip(round(Normal(0.7 N, 0.18 N)), 1, N) -- stand-ins for the
+    other two jet types of the reference's ``--jets`` (top jets have more constituents than gluon jets, so nearly all fill the
+    N leading-pT slots; light-quark jets fewer); the dataset itself is not available here, the laws only shape the work.
     The first n particles are real: eta_rel, phi_rel ~ clip(Normal(0, 0.15), -1, 1), pT_rel ~ Uniform(-0.5, 0.5),
     mask = +0.5; padding particles are (0, 0, -0.5, -0.5).  ``labels = float32(n) * float32(1/N)`` -- the product
     with the reciprocal makes ``int(labels * N)`` return n for every n <= 150, n / N does not."""
@@ -43,6 +46,10 @@ def synthetic_jets(B: int, N: int, seed: int = 4, dist: str = "gluon", dtype=tor
         n = rs.randint(1, N + 1, size=B)
     elif dist == "gluon":
         n = np.clip(np.rint(rs.normal(0.8 * N, 0.15 * N, size=B)), 1, N).astype(np.int64)
+    elif dist == "top":
+        n = np.clip(np.rint(rs.normal(0.95 * N, 0.08 * N, size=B)), 1, N).astype(np.int64)
+    elif dist == "quark":
+        n = np.clip(np.rint(rs.normal(0.7 * N, 0.18 * N, size=B)), 1, N).astype(np.int64)
     else:
         raise ValueError(f"unknown multiplicity law {dist!r}")
     eta = np.clip(rs.normal(0, 0.15, size=(B, N)), -1, 1)

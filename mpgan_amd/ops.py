@@ -78,6 +78,7 @@ class DeviceState:
         self.index = index
         self._seed = None
         self.seed_is_default = True   # nobody has called set_seed on this device yet (TrainStep then seeds it itself)
+        self.auto_seed_key = None     # (torch seed, rank) TrainStep last seeded this device from: a second TrainStep under the same pair leaves the stream where it is
         self.tags = itertools.count(1)
         self.last_tag = 0
         self.tag_log = None
@@ -160,12 +161,27 @@ def set_seed(value: int, device="cuda", _auto: bool = False):
     (``dist.rank_seed``)."""
     v = int(value) & 0xFFFFFFFFFFFFFFFF          # the 64-bit pattern as the kernels read it (an int64 tensor holds it signed)
     seed_tensor(device).fill_(v - (1 << 64) if v >= (1 << 63) else v)
-    dev_state(device).seed_is_default = _auto   # (TrainStep's own choice does not count as the caller's)
+    st = dev_state(device)
+    st.seed_is_default = _auto   # (TrainStep's own choice does not count as the caller's)
+    if not _auto:
+        st.auto_seed_key = None
 
 
 def derived_seed(torch_seed: int, rank: int) -> int:
     """The device seed ``TrainStep`` derives from torch's seed and the data-parallel rank: distinct per (seed, rank)."""
     return (torch_seed * 0x9E3779B97F4A7C15 + (rank + 1) * 0xD1B54A32D192ED03 + 0x243F6A8885A308D3) & 0x7FFFFFFFFFFFFFFF
+
+
+RANK_TERM = 0xD1B54A32D192ED03   # what one step in rank adds to ``derived_seed``
+
+
+def rerank_seed(saved: int, saved_rank: int, rank: int) -> int:
+    """The seed a checkpoint written by rank ``saved_rank`` hands to rank ``rank``: the saved value moved by the rank term of
+    ``derived_seed`` once per rank of distance (mod 2^64).  The reference keeps ONE ``G_optim_<epoch>.pt`` per epoch
+    (train.py:534-535), written by one process: loaded as it is, every rank of a resumed data-parallel run would draw rank 0's
+    noise and dropout masks from there on.  The saving rank itself gets the saved value back bit for bit (resume == uninterrupted
+    run); the others get streams of their own, distinct for every rank."""
+    return (int(saved) + (int(rank) - int(saved_rank)) * RANK_TERM) & 0xFFFFFFFFFFFFFFFF
 
 
 def get_seed(device="cuda") -> int:
@@ -235,12 +251,21 @@ def _tickets(device, n: int) -> torch.Tensor:
     """Arrival counters for ONE launch whose workgroups hand a reduction to the last arriver: ``n`` zeros that the launch leaves
     zero.  Every call gets the next of ``TICKET_SLOTS`` regions of a per-device buffer: launches that run side by side on two
     streams (the generator-ahead branch beside the D step's own generator call) must not count on the same words, and a
-    captured launch keeps the region it was given."""
+    captured launch keeps the region it was given.  A buffer that has been handed out is NEVER freed (a replayed hipGraph keeps
+    raw pointers into it: a larger request gets a new buffer, the old one stays on ``DeviceState``), and a new buffer is zeroed
+    and the device synchronised before its first region goes out, whichever stream asks first -- inside a capture that cannot be
+    done, so a capture must find its buffer ready (``TrainStep.capture`` warms up eagerly)."""
     st = dev_state(device)
     buf = getattr(st, "_tickets", None)
     per = max(4096, n)
     if buf is None or buf.shape[1] < per:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("mpgan_amd: a capture needs a larger ticket buffer than any eager launch before it (warm the "
+                               "iteration up eagerly first: TrainStep.capture(warmup >= 1))")
+        if buf is not None:
+            st._tickets_retired = getattr(st, "_tickets_retired", []) + [buf]
         buf = torch.zeros((TICKET_SLOTS, per), dtype=torch.int32, device=device)
+        torch.cuda.synchronize(device)   # the zeros are there for every stream (the launches that use them run on several)
         st._tickets, st._ticket_i = buf, 0
     st._ticket_i = (st._ticket_i + 1) % TICKET_SLOTS
     return buf[st._ticket_i]

@@ -138,6 +138,7 @@ class FlatParams:
         # TrainStep: the device whose dropout / noise seed travels with this optimizer's state dict (``SEED_KEY`` in its
         # parameter group: torch.optim's own load_state_dict carries unknown group keys along untouched)
         self.seed_device = None
+        self.seed_rank = 0     # this process's rank in the data-parallel group (TrainStep sets it): saved beside the seed
 
     def zero_grad(self):
         self.grad.zero_()
@@ -181,6 +182,7 @@ class FlatParams:
     # -- torch.optim-compatible state ---------------------------------------------------------------
     _STATE_KEYS = {"rmsprop": ("square_avg", None), "adam": ("exp_avg_sq", "exp_avg"), "adadelta": ("square_avg", "acc_delta")}
     SEED_KEY = "mpgan_amd_seed"
+    SEED_RANK_KEY = "mpgan_amd_seed_rank"
 
     def _torch_optimizer(self, lr):
         """A torch.optim instance over detached CPU stand-ins of the parameters: the source of truth for the
@@ -212,6 +214,7 @@ class FlatParams:
                 sd["state"][i if filtered else self._trained_idx[i]] = ent
         if self.seed_device is not None:
             sd["param_groups"][0][self.SEED_KEY] = ops.get_seed(self.seed_device)
+            sd["param_groups"][0][self.SEED_RANK_KEY] = int(self.seed_rank)
         return sd
 
     def load_state_dict(self, sd: dict):
@@ -254,8 +257,12 @@ class FlatParams:
         self._host_steps = int(steps)
         self.lr = groups[0].get("lr", self.lr)
         if self.seed_device is not None and self.SEED_KEY in groups[0]:
-            # a resumed run goes on with the noise / dropout stream where the saved one stopped, not from its start
-            ops.set_seed(int(groups[0][self.SEED_KEY]), self.seed_device)
+            # a resumed run goes on with the noise / dropout stream where the saved one stopped, not from its start -- on the rank
+            # that wrote the file.  The reference's checkpoint is ONE file per epoch (train.py:534-535): every other rank of a
+            # resumed data-parallel run moves the saved value by its distance in rank (ops.rerank_seed), so that no two ranks
+            # share noise or masks behind a resume either.
+            ops.set_seed(ops.rerank_seed(int(groups[0][self.SEED_KEY]), int(groups[0].get(self.SEED_RANK_KEY, 0)), self.seed_rank),
+                         self.seed_device)
         return self.lr
 
     def versions(self) -> int:
@@ -354,12 +361,18 @@ class TrainStep:
             # torch.manual_seed does not reach.  Unless the caller has set it (ops.set_seed), derive it here from torch's
             # seed -- the reference's contract: torch.manual_seed(seed), setup_training.py:184 -- and this process's rank,
             # so that data-parallel ranks never share noise or masks; it is saved / restored with G's optimizer state.
-            if self.state.seed_is_default:
-                rank = 0
-                if torch.distributed.is_available() and torch.distributed.is_initialized():
-                    rank = torch.distributed.get_rank(process_group)
-                ops.set_seed(ops.derived_seed(torch.initial_seed(), rank), dev, _auto=True)
+            # A second TrainStep on the same device under the same (torch seed, rank) -- a bench's secondary workload, a step
+            # re-created for another batch size -- leaves the stream where the first one has brought it; a new torch.manual_seed
+            # in between starts it afresh.
+            rank = 0
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                rank = torch.distributed.get_rank(process_group)
+            key = (torch.initial_seed(), rank)
+            if self.state.seed_is_default and self.state.auto_seed_key != key:
+                ops.set_seed(ops.derived_seed(*key), dev, _auto=True)
+                self.state.auto_seed_key = key
             self.fG.seed_device = dev
+            self.fG.seed_rank = rank
         self.data = torch.zeros(batch_size, num_particles, 4, device=dev)
         self.labels = torch.zeros(batch_size, 1, device=dev)
         self._real = torch.cat([torch.ones(batch_size, device=dev), torch.zeros(batch_size, device=dev)])
@@ -490,7 +503,7 @@ class TrainStep:
             if self.gen_ahead:
                 if self._defer_join:
                     self._join_pending = True
-                else:                # join: everything of this segment is ordered before whatever follows it
+                elif self._side is not None:   # join: everything of this segment is ordered before whatever follows it
                     torch.cuda.current_stream(self.dev).wait_stream(self._side)
                     self.gen_join = "seg_D"
 
@@ -580,11 +593,12 @@ class TrainStep:
         try:
             torch.autograd.backward([root], None if grad is None else [grad])
             self.state.deferred_wgrad.flush()
-        finally:
-            self.state.deferred_wgrad = None
-            if getattr(self, "_fork_late", False):   # (D step only: _seg_G clears the flag before its own backward)
+            if self._fork_late:   # (D step only: _seg_G clears the flag before its own backward; never behind a failed backward)
                 self._fork_late = False
                 self._fork_generator()
+        finally:
+            self.state.deferred_wgrad = None
+            self._fork_late = False
             if self.wgrad_side:
                 # join: the weight gradients are complete before whatever follows the backward (all-reduce, optimizer step)
                 self.state.wgrad_stream = None
@@ -616,9 +630,10 @@ class TrainStep:
         self._clean["G"] = False
         _set_requires_grad(self.fD, False)
         if self._join_pending:       # (the deferred join of the generator-ahead branch: its jets are used from here on)
-            torch.cuda.current_stream(self.dev).wait_stream(self._side)
             self._join_pending = False
-            self.gen_join = "seg_G"
+            if self._side is not None:
+                torch.cuda.current_stream(self.dev).wait_stream(self._side)
+                self.gen_join = "seg_G"
         fake, self._fake_ahead = self._fake_ahead, None
         parts = self.parts and self._fused_ends()
         bridge = parts and fake is None and self._bridge()

@@ -65,24 +65,64 @@ def summary_err(name, t, golden):
     return float(max(np.abs(s[1:] - g[1:]).max() / scale, abs(s[0] - g[0]) / (l1 if l1 > 0 else 1.0)))
 
 
+# ---- parity evidence: what the gradient checks of a session measured, kept for profiles/  -------------------
+# Every check that lets a tensor pass on something else than its plain bar -- the fp32 control of ``assert_grads``, the
+# sign-conditioned oracle of the kinked MPLayer cases -- records what it measured here; a ``-m gpu`` session writes the records
+# to gpurun_out/parity_bars.txt when it ends (copied to profiles/ by whoever ran it).
+PARITY_LOG = []
+CONTROL_CEILING = 2e-2   # no tensor passes on the fp32 control beyond this, whatever fp32's own error on the input was
+
+
+def record_parity(kind, what, **fields):
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    PARITY_LOG.append((kind, test, str(what), fields))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not PARITY_LOG:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_bars.txt"), "w") as f:
+            f.write("# parity evidence of one pytest session (tests/conftest.py: PARITY_LOG); exit status %s\n" % exitstatus)
+            f.write("# assert_grads: per call the worst tensor -- err = max|got - fp64| / max|fp64|, bar = max(tol, 3 x fp32's own error) "
+                    "capped at %g, n_over_tol = tensors beyond tol that passed on the control\n" % CONTROL_CEILING)
+            for kind, test, what, fields in PARITY_LOG:
+                f.write("%s | %s | %s | %s\n" % (kind, test, what, " ".join("%s=%s" % (k, _fmt(v)) for k, v in fields.items())))
+    except OSError:   # (a read-only tree: the evidence is a by-product, never a reason to fail)
+        pass
+
+
+def _fmt(v):
+    return "%.3g" % v if isinstance(v, float) else str(v)
+
+
 def assert_grads(got, ref, tol, control=None, what=""):
     """Per-parameter gradient check against the fp64 oracle: max|got - ref| <= tol * max|ref|; a parameter whose true
     gradient vanishes by symmetry is held to tol * 1e-3 of the network's largest gradient instead of to its own
     rounding noise.  ``control`` = the SAME oracle evaluated in plain fp32 (the reference's arithmetic): a parameter
     beyond ``tol`` still passes within 3x of fp32's own error against fp64 on this input -- LeakyReLU' jumps at 0,
     so a pre-activation within rounding of zero takes the other slope in any finite arithmetic, fp32 included, and
-    in a short sum (few jets) one such edge is visible at ~1e-2."""
+    in a short sum (few jets) one such edge is visible at ~1e-2 -- but never beyond ``CONTROL_CEILING``.  Every call
+    leaves its worst tensor in ``PARITY_LOG``."""
     scale = max(float(np.abs(np.asarray(v)).max()) for v in ref.values())
-    bad = {}
+    bad, worst, n_over = {}, None, 0
     for k, r in ref.items():
         r = np.asarray(r, dtype=np.float64)
         den = max(np.abs(r).max(), 1e-3 * scale)
         err = float(np.abs(np.asarray(got[k], dtype=np.float64) - r).max() / den)
-        bar = tol
+        bar, ctl = tol, None
         if control is not None:
-            bar = max(tol, 3.0 * float(np.abs(np.asarray(control[k], dtype=np.float64) - r).max() / den))
+            ctl = float(np.abs(np.asarray(control[k], dtype=np.float64) - r).max() / den)
+            bar = min(max(tol, 3.0 * ctl), max(tol, CONTROL_CEILING))
         if not err <= bar:
             bad[k] = (err, bar)
+        n_over += int(err > tol)
+        if worst is None or err / bar > worst[1] / worst[2]:
+            worst = (k, err, bar, ctl)
+    record_parity("assert_grads", what, tensors=len(ref), tol=float(tol), worst=worst[0], err=worst[1], bar=worst[2],
+                  fp32_err=(-1.0 if worst[3] is None else worst[3]), n_over_tol=n_over, failed=len(bad))
     assert not bad, (what, bad)
 
 

@@ -225,6 +225,14 @@ def _assert_gradients_up_to_kink_flips(errs, conditioned, flips, margin, what=""
     HATCH["flips_hip"] += n_hip
     HATCH["flips_fp32"] += n_ctl
     print("passed so far:", HATCH)
+    from conftest import record_parity
+    grads = [k for k in errs if k != "y"]
+    wk = max(grads, key=lambda k: min(errs[k], conditioned[k]))
+    record_parity("kink_case", what, tensors=len(grads), outright=sum(errs[k] < TOL for k in grads),
+                  conditioned=sum(errs[k] >= TOL for k in grads) - len(bad), failed=len(bad), fwd_err=float(errs["y"]),
+                  fwd_err_conditioned=float(conditioned["y"]), worst=wk, err=float(errs[wk]), err_conditioned=float(conditioned[wk]),
+                  flips_hip=n_hip, flips_fp32=n_ctl, flips_hip_by_layer=str(flips["hip"]).replace(" ", ""),
+                  flips_fp32_by_layer=str(flips["fp32"]).replace(" ", ""), margin=float(margin))
     assert not bad, (bad, margin)
     assert n_hip <= 3 * n_ctl + 3, (flips, margin)
 
@@ -277,6 +285,8 @@ def test_kink_flips_are_rare():
     HIP forward against the fp32 oracle's in total (3x + 10)."""
     n = HATCH["outright"] + HATCH["conditioned"]
     print("gradient tensors of the kinked cases:", HATCH)
+    from conftest import record_parity
+    record_parity("HATCH", "kinked MPLayer cases of this session, in total", **HATCH)
     if n < 100:
         pytest.skip("the kinked cases did not run in this session")
     assert HATCH["flips_hip"] <= 3 * HATCH["flips_fp32"] + 10, HATCH
@@ -478,6 +488,16 @@ def test_mplayer_full_size():
         # at this size the independent roundings average out: against the conditioned oracle the edge network's gradients
         # sit where the smooth full-size test has them
         assert max(v for k, v in cond.items() if k == "dx" or k.startswith("fe.")) < 2e-4, cond
+        from conftest import record_parity
+        grads = [k for k in errs if k != "y"]
+        wk = max(grads, key=lambda k: min(errs[k], cond[k]))
+        record_parity("kink_case", ("full size B=256 N=30", seed), tensors=len(grads), outright=sum(errs[k] < TOL for k in grads),
+                      conditioned=sum(errs[k] >= TOL for k in grads), failed=0, fwd_err=float(errs["y"]),
+                      fwd_err_conditioned=float(cond["y"]), worst=wk, err=float(errs[wk]), err_conditioned=float(cond[wk]),
+                      worst_conditioned_fe_dx=float(max(v for k, v in cond.items() if k == "dx" or k.startswith("fe."))),
+                      flips_hip=sum(flips["hip"].values()), flips_fp32=sum(flips["fp32"].values()),
+                      flips_hip_by_layer=str(flips["hip"]).replace(" ", ""), flips_fp32_by_layer=str(flips["fp32"]).replace(" ", ""),
+                      margin=float(margin))
         for k in flips["hip"]:
             n_hip[k] = n_hip.get(k, 0) + flips["hip"][k]
             n_ctl[k] = n_ctl.get(k, 0) + flips["fp32"][k]

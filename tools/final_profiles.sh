@@ -7,10 +7,11 @@ mkdir -p $R/gpurun_out/final
 # build BEFORE any profiled process: a profiled python must never start hipcc (the profiler's preload initialises the
 # GPU in every child; hipcc then execs clang -- a GPU-initialised exec, forbidden on this pool)
 python3 $R/__graft_entry__.py || exit 1
+python3 -c "import sys; sys.path.insert(0, '$R'); from mpgan_amd import _lib; print(_lib.source_digest())" > $R/gpurun_out/final/source_digest.txt || exit 1
 cd /tmp && export TMPDIR=/tmp
 out=$R/gpurun_out/final/bench_stats
 rm -rf $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o b -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/final/bench_under_rocprof.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o b -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $R/gpurun_out/final/bench_under_rocprof.log 2>&1 || exit 1
 python3 $R/tools/prof_summary.py $out 40 > $R/gpurun_out/final/bench_stats_summary.txt
 out=$R/gpurun_out/final/gapt_stats
 rm -rf $out

@@ -24,8 +24,8 @@ if calls:
     agree = (f"# Agreement of the two clocks for {rk}: bench.py HIP events avg {k['avg_ms'] * 1e3:.1f} us over "
              f"{k['launches_per_step']} launches/step; rocprof launch-weighted avg {tot_ns / calls / 1e3:.1f} us over {calls} launches.\n")
 open(os.path.join(P, f"{tag}_bench_kernel_stats.txt"), "w").write(
-    "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline\n"
-    "# (MI355X, 1 GPU, MPGAN N=30, B=256, gluon-like multiplicity, D dropout 0.5; warm-up, capture warm-up, timed and\n"
+    "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary\n"
+    "# (MI355X, 1 GPU, MPGAN N=30, B=256, gluon-like multiplicity, D dropout 0.5 -- ONE workload: no secondary legs; warm-up, capture warm-up, timed and\n"
     "# the 4 eager roofline iterations all land in the trace).  Full table: " + f"{tag}_bench_kernel_stats.csv.\n"
     "# The bench line printed by this very run:\n# " + line + "\n#\n" + agree + summ)
 
@@ -117,6 +117,11 @@ if os.path.isfile(sp):
     traffic["note"] += ("; secondary: per launch, launch-weighted over every dispatch of the entry point's kernels in a short bench.py run "
                         f"of that workload (gpurun_out/final/pmc_secondary_summary.txt -> profiles/{tag}_pmc_hbm_traffic_secondary.txt)")
     shutil.copy(sp, os.path.join(P, f"{tag}_pmc_hbm_traffic_secondary.txt"))
+# what the counters belong to: the digest of the kernel sources they were collected on (tools/final_profiles.sh writes it on the
+# box) -- bench.py reports roofline.traffic only while the tree it runs on still has that digest
+dg = os.path.join(F, "source_digest.txt")
+traffic["source"] = {"profile": f"profiles/{tag}_pmc_hbm_traffic.txt",
+                     "source_digest": open(dg).read().strip() if os.path.isfile(dg) else None}
 json.dump(traffic, open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
 # ---- SQ counters (tools/final_profiles.sh: pmc_sq_summary.txt)
 sq_path = os.path.join(F, "pmc_sq_summary.txt")
