@@ -53,7 +53,15 @@ MPG_DEV void fill_lds_dma8(void* dst, const void* src, int bytes, int tid) {
 
 // FN / cp / cp2: as edge_fwd_body's (the node network and the next layer's a | c projection as the workgroup's epilogue), run
 // by c2_body's eight-wave form.
-template <int DROP, bool SIGN, int NQ, int FN>
+// LT: which of the hi/lo cross terms the two dense layers issue (the sender loop is bound by MFMA issue:
+// 270 MFMAs per sender in the three-term form, two waves to a SIMD).  0 = all three terms in both layers (fp32-level products).
+// Bit 0: layer 3 on TWO terms -- E2 as the ONE fp16 value that is parked anyway times W3 hi + lo (the E2 lo fragments, their
+// 40 registers and their split arithmetic are gone; 210 MFMAs); bit 1: layer 2 likewise, E1 as one fp16 value times W2 hi + lo
+// (180 MFMAs with both).  An activation rounded to fp16 carries a relative error of 2^-12 rms that is independent from edge to
+// edge, so it averages out over the senders of agg and over the edges of every gradient sum; a pre-activation of layer 3 / 2
+// is then known to ~1e-4 of its scale instead of ~5e-7, i.e. the LeakyReLU branch of elements that close to zero may differ from
+// fp32's -- the backward takes the forward's own sign bits either way.
+template <int DROP, bool SIGN, int NQ, int FN, int LT = 0>
 MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = nullptr, const MpgChain* const cp2 = nullptr) {
     typedef f16x8 V;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -186,10 +194,20 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
         const float mj = lmk[s];
         float mjs = mj * p.dscale * (1.f / SC_E3);   // (the layer-3 output carries SC_E3)
         if (p.nbr != nullptr) {
-            const unsigned int wb = p.nbr[(size_t)(b * p.N + (vi ? i : 0)) * ((p.N + 31) >> 5) + (jj >> 5)];
+            // (the lane's row index behind an opaque copy: left to itself the compiler hoists the 64-bit row address out of the
+            // sender loop, has no register pair for it across layer 2, and reloads it from scratch -- with a vmcnt(0) -- every sender)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int irow = min(rb * 32 + (ln & 31), p.N - 1);   // (= i for the lanes whose receiver exists; the others' sums are never stored)
+            const unsigned int wb = p.nbr[(size_t)(b * p.N + irow) * ((p.N + 31) >> 5) + (jj >> 5)];
             mjs = ((wb >> (jj & 31)) & 1u) ? mjs : 0.f;
         }
-        const uint32_t erow = (uint32_t)((b * p.N + i) * p.N + jj);
+        // (the dropout row of this (receiver, sender) from the lane id behind an opaque copy: (b N + i) N is loop-invariant, the
+        // compiler hoists it, finds no register for it across layer 2 in the dropout variants and reloads it from scratch at the
+        // top of every sender -- behind a vmcnt(0) that also waits for the W2 fragments just requested)
+        int lnr = lane;
+        asm volatile("" : "+v"(lnr));
+        const uint32_t erow = (uint32_t)((b * p.N + rb * 32 + (lnr & 31)) * p.N + jj);
         lcw[lane] = pc0 * SC_A;
         if (lane < H1 - 64) lcw[64 + lane] = pc1 * SC_A;
         float esv[NQ > 0 ? NQ : 1];
@@ -253,8 +271,15 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
                     v1[u] = drop_apply<DROP>(lrelu(cc, p.alpha), wd, 16 * s2 + 8 * uh + t, t, p.thr);
                 } else {
                     constexpr int pr = (u - 8) >> 1;
-                    if constexpr (((u - 8) & 1) == 0) ps1[pr].first(v1[2 * pr], v1[2 * pr + 1]);
-                    else ps1[pr].second(v1[2 * pr + 1], eh[k & 1], el[k & 1], 2 * pr);
+                    if constexpr (LT & 2) {   // E1 as one fp16 value: no lo half
+                        if constexpr (((u - 8) & 1) == 0) {
+                            const f16x2 hp = {(_Float16)v1[2 * pr], (_Float16)v1[2 * pr + 1]};
+                            eh[k & 1][2 * pr] = hp[0]; eh[k & 1][2 * pr + 1] = hp[1];
+                        }
+                    } else {
+                        if constexpr (((u - 8) & 1) == 0) ps1[pr].first(v1[2 * pr], v1[2 * pr + 1]);
+                        else ps1[pr].second(v1[2 * pr + 1], eh[k & 1], el[k & 1], 2 * pr);
+                    }
                 }
             };
             using K0 = std::integral_constant<int, 0>;
@@ -287,7 +312,8 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
                     if constexpr (f1_w2_in_lds(m, k)) a_h = whl[m & 1]; else a_h = wh[m];
                     const V a_l = wl[m];
                     acc[m] = f2_mma(a_l, bh0, acc[m]); slot(std::integral_constant<int, 3 * m + 0>{});
-                    acc[m] = f2_mma(a_h, bl0, acc[m]); slot(std::integral_constant<int, 3 * m + 1>{});
+                    if constexpr (!(LT & 2)) acc[m] = f2_mma(a_h, bl0, acc[m]);
+                    slot(std::integral_constant<int, 3 * m + 1>{});
                     acc[m] = f2_mma(a_h, bh0, acc[m]);
                     if constexpr (k + 1 < KS) load_w(std::integral_constant<int, k + 1>{}, mc);
                     slot(std::integral_constant<int, 3 * m + 2>{});
@@ -297,7 +323,7 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
 
         F1_STAMP(1)
         // ---- E2 = drop(lrelu(Z2)) as B fragments (hi, lo): tile mm, k-step half s -> fragment 2 mm + s
-        f2_u32x4 e2h[T2 * 2], e2l[T2 * 2];
+        f2_u32x4 e2h[T2 * 2], e2l[(LT & 1) ? 1 : T2 * 2];
         const int sts = ((b * RB + rb) * p.N + jj) * (NFR2 * 1024);
         static_for<0, T2>([&](auto mc) {
             MPG_CI(mm, mc);
@@ -314,9 +340,17 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 V hi, lo;
-                split8(x2 + 8 * s2, hi, lo);
+                if constexpr (LT & 1) {   // E2 as the one fp16 value that is parked
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const f16x2 hp = {(_Float16)x2[8 * s2 + j], (_Float16)x2[8 * s2 + j + 1]};
+                        hi[j] = hp[0]; hi[j + 1] = hp[1];
+                    }
+                } else {
+                    split8(x2 + 8 * s2, hi, lo);
+                    e2l[2 * mm + s2] = __builtin_bit_cast(f2_u32x4, lo);
+                }
                 e2h[2 * mm + s2] = __builtin_bit_cast(f2_u32x4, hi);
-                e2l[2 * mm + s2] = __builtin_bit_cast(f2_u32x4, lo);
                 if constexpr (SIGN) __builtin_amdgcn_raw_buffer_store_b128(e2h[2 * mm + s2], rsE, lane16, sts + (2 * mm + s2) * 1024, 0);
             }
         });
@@ -357,7 +391,7 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
                         ah[(k + 1) & 1] = lds_frag<V>(lb3hi, (m * KS + k + 1) * 1024);
                         al[(k + 1) & 1] = lds_frag<V>(lb3lo, (m * KS + k + 1) * 1024);
                     }
-                    const V bh0 = __builtin_bit_cast(V, e2h[k]), bl0 = __builtin_bit_cast(V, e2l[k]);
+                    const V bh0 = __builtin_bit_cast(V, e2h[k]), bl0 = __builtin_bit_cast(V, e2l[(LT & 1) ? 0 : k]);
                     auto slot = [&](auto slc) {
                         MPG_CI(SL, slc);   // 3 KS - 3 slots: the last k-step's are left to the next tile's bias load
                         if constexpr (m > 0) f2_slot<16, 3 * KS - 3, SL>([&](auto uc) { epi3(std::integral_constant<int, m - 1>{}, uc); });
@@ -365,7 +399,8 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
                     };
                     const V a_h = ah[k & 1], a_l = al[k & 1];
                     a3[m & 1] = f2_mma(a_l, bh0, a3[m & 1]); slot(std::integral_constant<int, 3 * k + 0>{});
-                    a3[m & 1] = f2_mma(a_h, bl0, a3[m & 1]); slot(std::integral_constant<int, 3 * k + 1>{});
+                    if constexpr (!(LT & 1)) a3[m & 1] = f2_mma(a_h, bl0, a3[m & 1]);
+                    slot(std::integral_constant<int, 3 * k + 1>{});
                     a3[m & 1] = f2_mma(a_h, bh0, a3[m & 1]); slot(std::integral_constant<int, 3 * k + 2>{});
                     if constexpr (k == KS - 1 && m + 1 < T3) {
                         bias_init(std::integral_constant<int, m + 1>{});
@@ -383,6 +418,7 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
         F1_STAMP(3)
     }
 
+    {   // ---- behind the sender loop (a scope of its own: see the ids below)
 #ifdef MPG_F1_STAMP
     if (lane == 0) {
         unsigned long long* o = f1_stamps + ((size_t)blockIdx.x * 8 + w) * 8;
@@ -392,6 +428,15 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
 #endif
     // ---- reduce the eight waves' partial sums through LDS (the weight area holds four waves' worth: waves 4..7 hand theirs to
     //      waves 0..3 first) and write agg[b, i, :]
+    // (the thread's ids are derived afresh behind an opaque copy: what the epilogue makes of them -- lane * 16, row offsets -- is
+    // otherwise computed in the prologue, kept across a sender loop that has no register to spare, and spilled to scratch)
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int tid = tid_e, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int i = rb * 32 + r;
+    const bool vi = i < p.N;
     __syncthreads();  // everyone is done with the weight copy
     float* red = reinterpret_cast<float*>(smem);
     if (w >= 4) {
@@ -558,10 +603,14 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
         o[7] = ((t1 - f1_k0) << 20) | (__builtin_amdgcn_s_memrealtime() - f1_r0);   // kernel clk | realtime ticks
     }
 #endif
+    }
 }
 
-template <int DROP, bool SIGN, int NQ>
-__global__ __launch_bounds__(512) void edge_fwd1_kernel(const MpgEdgeFwd p) { edge_fwd1_body<DROP, SIGN, NQ, 0>(p); }
+#ifndef MPG_F1_LT
+#define MPG_F1_LT 0   // (tools/ubench/fwd_bench.hip: the harness builds the plain kernel in one LT form)
+#endif
+template <int DROP, bool SIGN, int NQ, int LT = MPG_F1_LT>
+__global__ __launch_bounds__(512) void edge_fwd1_kernel(const MpgEdgeFwd p) { edge_fwd1_body<DROP, SIGN, NQ, 0, LT>(p); }
 
 template <int DROP, bool SIGN, bool SL>
 __global__ __launch_bounds__(512) void edge_fwd1_fn_kernel(const MpgEdgeFwd p, const MpgChain c, const MpgChain c2) {
