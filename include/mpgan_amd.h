@@ -183,6 +183,12 @@ typedef struct MpgEdgeFwd {
     unsigned int* tickets;                /* mpg_edge_fwd_fn with SC > 1: [B*RB] arrival counters, ZERO on entry and left zero (the
                                              workgroup of a (jet, receiver block) that arrives last adds up the SC partial slabs);
                                              NULL = the epilogue form takes whole jets only (SC = 1) */
+    int two_term;                         /* product form of the two dense layers: 0 = every product as three 16-bit terms (hi*hi +
+                                             hi*lo + lo*hi: fp32-level pre-activations); 1 = fe.net.2 on TWO terms -- its input, the
+                                             activation E2, rounded to the one fp16 value that is parked for the backward anyway,
+                                             times W3 hi + lo: 2/9 fewer MFMAs, pre-activations of fe.net.2 known to ~1e-4 of their
+                                             scale (an error that is independent from edge to edge and averages out in agg and in
+                                             every gradient sum).  Other values, and 1 together with edge scalars: error -8. */
 } MpgEdgeFwd;
 #define MPG_EDGE_SCALARS 2
 int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream);
@@ -320,16 +326,6 @@ int mpg_attn_bwd(const MpgAttn* p, void* stream);
  * (or NULL) receives 1 - mask in the same pass: the key mask GAPT's attention blocks take (_attn_mask, gapt/model.py:194-202). */
 int mpg_rank_mask(const float* x, int ld_jet, int ld_part, const float* labels, int ld_lab, int B, int N,
                   float* mask, float* ignore, void* stream);
-
-/* mpg_edge_waves: which form the plain edge launches take from now on, process-wide -- fwd for mpg_edge_fwd, bwd for mpg_edge_bwd:
- * 8 = eight waves per workgroup (two per SIMD, one sender per wave: csrc/edge_fwd1_impl.h, edge_bwd1_impl.h), 4 = four waves
- * (one per SIMD, senders in pairs: edge_fwd2_impl.h, edge_bwd2_impl.h), 0 = as the environment says (MPG_FWD_WAVES / MPG_BWD_WAVES;
- * default 8).  Same function either way; the sums over senders (agg, da) are ordered differently, so results agree to fp32
- * rounding, not bit for bit.  The epilogue forms (mpg_edge_fwd_fn, mpg_edge_bwd_fn) follow the same switch (default eight; their own
- * environment switches: MPG_FWD_FN_WAVES / MPG_BWD_FN_WAVES).  Returns 0, or -1 for
- * any other value.  (No reference counterpart: a launch-shape switch.) */
-int mpg_edge_waves(int fwd, int bwd);
-int mpg_edge_waves_get(int which);   /* the value set for fwd (which = 0) / bwd (1) */
 
 /* mpg_jet_order: the jets of a batch by decreasing number of unmasked particles (ties by index), order[0] the fullest --
  * MpgEdgeFwd.order / MpgEdgeBwd.order.  The edge kernels take a workgroup per jet and as long as the jet has senders; when a

@@ -49,6 +49,7 @@ class MpgEdgeFwd(C.Structure):
         ("skip_masked", C.c_int), ("f16", C.c_int),
         ("sign3", _fp), ("nbr", _fp), ("stageE2", _fp),
         ("es", _fp), ("wq", _fp), ("order", _fp), ("tickets", _fp),
+        ("two_term", C.c_int),
     ]
 
 
@@ -222,8 +223,6 @@ SIGNATURES = {
     "mpg_knn_sets": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_void_p]),
     "mpg_rank_mask": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_void_p]),
     "mpg_jet_order": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_void_p]),
-    "mpg_edge_waves": (C.c_int, [C.c_int, C.c_int]),
-    "mpg_edge_waves_get": (C.c_int, [C.c_int]),
     "mpg_gen_tail_fwd": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mpg_gen_tail_bwd": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mpg_disc_head_fwd": (C.c_int, [C.POINTER(MpgDiscHead), C.c_void_p]),

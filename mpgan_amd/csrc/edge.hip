@@ -40,18 +40,6 @@ __global__ void pack_kernel(const float* __restrict__ W, int ldw, int rows, int 
 }  // namespace
 
 
-// mpg_edge_waves: 0 = as the environment says (MPG_FWD_WAVES / MPG_BWD_WAVES, default eight), 4 / 8 = that form of the plain
-// forward (fwd) and of mpg_edge_bwd (bwd) from now on, process-wide.  The two forms give the same results up to the order of the
-// sums over senders (agg, da); tests that pin launch forms against each other bit for bit choose one.
-static std::atomic<int> g_edge_waves[2];
-extern "C" int mpg_edge_waves_get(int which) { return g_edge_waves[which & 1].load(std::memory_order_relaxed); }
-extern "C" int mpg_edge_waves(int fwd, int bwd) {
-    if ((fwd != 0 && fwd != 4 && fwd != 8) || (bwd != 0 && bwd != 4 && bwd != 8)) return -1;
-    g_edge_waves[0].store(fwd, std::memory_order_relaxed);
-    g_edge_waves[1].store(bwd, std::memory_order_relaxed);
-    return 0;
-}
-
 extern "C" int mpg_pack_weights(const float* W, int ldw, int rows, int cols, int transpose, float scale, int f16,
                                 void* img, void* stream) {
     const int MT = (rows + 31) / 32, QT = (cols + 31) / 32;
@@ -68,7 +56,7 @@ extern "C" int mpg_pack_weights(const float* W, int ldw, int rows, int cols, int
 extern "C" int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream) {
     if (p->B <= 0 || p->N <= 0 || p->SC <= 0) return -1;
     if (!(p->alpha >= 0.f && p->alpha <= 1.f)) return -4;  // lrelu() is max(v, alpha v)
-    if (!p->f16) return -8;                                // fp16 hi/lo images and activations
+    if (!p->f16 || !f1_terms_ok(p)) return -8;             // fp16 hi/lo images and activations; a product form that is built
     if ((p->N + p->SC - 1) / p->SC > F2_LIST_MAX) return -6;  // senders per chunk (their list lives in LDS)
     // the parked E2 fragments (10,240 bytes per block) and the sign words are addressed with 32-bit offsets behind a buffer
     // descriptor whose record count is an int: the same limit as mpg_edge_bwd's, refused here, before anything is written
@@ -86,6 +74,6 @@ extern "C" int mpg_edge_fwd(const MpgEdgeFwd* p, void* stream) {
         if (p->wq == nullptr) return -3;
         return dm == 0 ? mpg_edge_fwd_q0(p, st) : (dm == 1 ? mpg_edge_fwd_q1(p, st) : mpg_edge_fwd_q2(p, st));
     }
-    return dm == 0 ? (fwd_eight_waves() ? f1_launch<0>(p, st) : f2_launch<0>(p, st)) : (dm == 1 ? mpg_edge_fwd_d1(p, st) : mpg_edge_fwd_d2(p, st));
+    return dm == 0 ? f1_launch<0>(p, st) : (dm == 1 ? mpg_edge_fwd_d1(p, st) : mpg_edge_fwd_d2(p, st));
 #endif
 }

@@ -34,25 +34,6 @@ static_assert(B1_NW * H1 * 4 == B2_C_BYTES, "one row of c per wave in the four-w
 static_assert(T3 * 4 * 64 == 3 * 512 && T1 * 4 * 64 == 512 + 256, "the prologue's register sets");
 static_assert(B1_NW * T1 * 16 * 64 * 4 <= B2_W_BYTES, "the final reduction reuses the weight area");
 
-// Which form the data-gradient launches take: mpg_edge_waves() when it has been called with a non-zero value, else the environment --
-// MPG_BWD_WAVES for mpg_edge_bwd, MPG_BWD_FN_WAVES for the epilogue form (4: the four-wave kernels of edge_bwd2_impl.h) --, else the default
-extern "C" int mpg_edge_waves_get(int which);   // edge.hip
-inline bool bwd_eight_waves() {
-    const int o = mpg_edge_waves_get(1);
-    if (o) return o != 4;
-    static const bool v = [] { const char* e = getenv("MPG_BWD_WAVES"); return e == nullptr || atoi(e) != 4; }();
-    return v;
-}
-#ifndef MPG_BWD_FN_DEFAULT
-#define MPG_BWD_FN_DEFAULT 8
-#endif
-inline bool bwd_fn_eight_waves() {
-    const int o = mpg_edge_waves_get(1);
-    if (o) return o != 4;
-    static const bool v = [] { const char* e = getenv("MPG_BWD_FN_WAVES"); return (e == nullptr ? MPG_BWD_FN_DEFAULT : atoi(e)) != 4; }();
-    return v;
-}
-
 // EPI / cdxp / cnxp: the epilogue chains of edge_bwd_body (the layer's dx chain and the lower layer's node-network input-gradient
 // chain on this workgroup's own jet), run by c2_body's eight-wave form
 template <int DROP, bool NEEDW, int EPI>

@@ -32,6 +32,6 @@ extern "C" int mpg_edge_bwd(const MpgEdgeBwd* p, void* stream) {
         if ((p->N + p->SC - 1) / p->SC > B2_LIST_MAX_Q) return -6;
         return dm == 0 ? mpg_edge_bwd_q0(p, st) : (dm == 1 ? mpg_edge_bwd_q1(p, st) : mpg_edge_bwd_q2(p, st));
     }
-    return dm == 0 ? (bwd_eight_waves() ? b1_launch<0>(p, st) : b2_launch<0>(p, st)) : (dm == 1 ? mpg_edge_bwd_d1(p, st) : mpg_edge_bwd_d2(p, st));
+    return dm == 0 ? b1_launch<0>(p, st) : (dm == 1 ? mpg_edge_bwd_d1(p, st) : mpg_edge_bwd_d2(p, st));
 #endif
 }

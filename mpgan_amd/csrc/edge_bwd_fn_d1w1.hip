@@ -3,5 +3,5 @@
 #include "edge_bwd1_impl.h"
 
 int mpg_edge_bwd_fn_d1w1(const MpgEdgeBwd* p, const MpgChain* cdx, const MpgChain* cnx, int epi, hipStream_t st) {
-    return bwd_fn_eight_waves() ? b1_launch_fn<1, true>(p, cdx, cnx, epi, st) : b2_launch_fn<1, true>(p, cdx, cnx, epi, st);
+    return b1_launch_fn<1, true>(p, cdx, cnx, epi, st);
 }

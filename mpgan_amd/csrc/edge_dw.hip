@@ -26,9 +26,6 @@
 #ifndef MPG_DW8_SETS
 #define MPG_DW8_SETS 1   // register sets of parked pieces in the uniform kernel (edge_dw8_kernel)
 #endif
-#ifndef MPG_DW_DEFAULT_WAVES
-#define MPG_DW_DEFAULT_WAVES 12  // waves per workgroup of mpg_edge_dw unless MPG_DW_WAVES says otherwise (8 | 12)
-#endif
 #ifndef MPG_DW_EXP
 #define MPG_DW_EXP 0  // experiment bits (tools/ubench/dw_bench.hip): 1 consumers idle, 2 builders idle, 4 no staged loads, 8 no LDS writes
 #endif
@@ -1214,18 +1211,21 @@ extern "C" int mpg_edge_dw(const MpgEdgeDw* p, void* stream) {
         }                                                                                                         \
     } while (0)
 #else
-    // (MPG_DW_WAVES=12: six consumers + six builders, three waves per SIMD; 8: four + four, two per SIMD)
-    static const bool twelve = [] { const char* e = getenv("MPG_DW_WAVES"); return e != nullptr ? atoi(e) == 12 : MPG_DW_DEFAULT_WAVES == 12; }();
+    // six consumers + six builders, three waves per SIMD.  (The four + four form of round 4 -- edge_dw_kernel<D, 0>, what the
+    // edge-scalar variant still is -- lost its A/B by 1.5-3 % per launch and is built by the harness only: -DMPG_DW_FOUR.)
+#ifdef MPG_DW_FOUR
 #define MPG_DW_ONE(D)                                                                                             \
     do {                                                                                                          \
-        if (twelve) {                                                                                             \
-            MPG_ENSURE_LDS((edge_dw12_kernel<D>), DW_LDS_BYTES);                                                  \
-            hipLaunchKernelGGL((edge_dw12_kernel<D>), grid, dim3(768), DW_LDS_BYTES, st, *p, R);                  \
-        } else {                                                                                                  \
-            MPG_ENSURE_LDS((edge_dw_kernel<D, 0>), DW_LDS_BYTES);                                                 \
-            hipLaunchKernelGGL((edge_dw_kernel<D, 0>), grid, block, DW_LDS_BYTES, st, *p, R);                     \
-        }                                                                                                         \
+        MPG_ENSURE_LDS((edge_dw_kernel<D, 0>), DW_LDS_BYTES);                                                     \
+        hipLaunchKernelGGL((edge_dw_kernel<D, 0>), grid, block, DW_LDS_BYTES, st, *p, R);                         \
     } while (0)
+#else
+#define MPG_DW_ONE(D)                                                                                             \
+    do {                                                                                                          \
+        MPG_ENSURE_LDS((edge_dw12_kernel<D>), DW_LDS_BYTES);                                                      \
+        hipLaunchKernelGGL((edge_dw12_kernel<D>), grid, dim3(768), DW_LDS_BYTES, st, *p, R);                      \
+    } while (0)
+#endif
 #endif
 #ifdef MPG_SINGLE_VARIANT  // tools/ubench/dw_bench.hip: one instantiation
     MPG_DW_ONE(MPG_SINGLE_VARIANT);

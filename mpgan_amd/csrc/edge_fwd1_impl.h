@@ -612,59 +612,56 @@ MPG_DEV void edge_fwd1_body(const MpgEdgeFwd& p, const MpgChain* const cp = null
 template <int DROP, bool SIGN, int NQ, int LT = MPG_F1_LT>
 __global__ __launch_bounds__(512) void edge_fwd1_kernel(const MpgEdgeFwd p) { edge_fwd1_body<DROP, SIGN, NQ, 0, LT>(p); }
 
-template <int DROP, bool SIGN, bool SL>
+template <int DROP, bool SIGN, bool SL, int LT = 0>
 __global__ __launch_bounds__(512) void edge_fwd1_fn_kernel(const MpgEdgeFwd p, const MpgChain c, const MpgChain c2) {
-    edge_fwd1_body<DROP, SIGN, 0, SL ? 2 : 1>(p, &c, &c2);
+    edge_fwd1_body<DROP, SIGN, 0, SL ? 2 : 1, LT>(p, &c, &c2);
 }
 
-template <int D, int NQ = 0>
-int f1_launch(const MpgEdgeFwd* p, hipStream_t st) {
+// Which product form a launch takes (MpgEdgeFwd.two_term): 0 = three 16-bit terms in both dense layers, 1 = layer 3 on two terms
+// (LT = 1 above).  Anything else is not built into the library: the entry points answer -8.
+inline bool f1_terms_ok(const MpgEdgeFwd* p) { return p->two_term == 0 || p->two_term == 1; }
+
+template <int D, int NQ, int LT>
+int f1_launch_lt(const MpgEdgeFwd* p, hipStream_t st) {
     const int RB = (p->N + 31) / 32;
     dim3 grid(p->B * RB * p->SC), block(512);
     if (p->sign3 != nullptr) {
-        MPG_ENSURE_LDS((edge_fwd1_kernel<D, true, NQ>), F1_LDS_BYTES);
-        hipLaunchKernelGGL((edge_fwd1_kernel<D, true, NQ>), grid, block, F1_LDS_BYTES, st, *p);
+        MPG_ENSURE_LDS((edge_fwd1_kernel<D, true, NQ, LT>), F1_LDS_BYTES);
+        hipLaunchKernelGGL((edge_fwd1_kernel<D, true, NQ, LT>), grid, block, F1_LDS_BYTES, st, *p);
     } else {
-        MPG_ENSURE_LDS((edge_fwd1_kernel<D, false, NQ>), F1_LDS_BYTES);
-        hipLaunchKernelGGL((edge_fwd1_kernel<D, false, NQ>), grid, block, F1_LDS_BYTES, st, *p);
+        MPG_ENSURE_LDS((edge_fwd1_kernel<D, false, NQ, LT>), F1_LDS_BYTES);
+        hipLaunchKernelGGL((edge_fwd1_kernel<D, false, NQ, LT>), grid, block, F1_LDS_BYTES, st, *p);
     }
     return (int)hipGetLastError();
 }
-
-// Which form the forward takes: mpg_edge_waves() when it has been called with a non-zero value, else the environment -- MPG_FWD_WAVES
-// for the plain launches, MPG_FWD_FN_WAVES for the epilogue form (4: the four-wave kernels of edge_fwd2_impl.h) --, else the default
-extern "C" int mpg_edge_waves_get(int which);   // edge.hip
-inline bool fwd_eight_waves() {
-    const int o = mpg_edge_waves_get(0);
-    if (o) return o != 4;
-    static const bool v = [] { const char* e = getenv("MPG_FWD_WAVES"); return e == nullptr || atoi(e) != 4; }();
-    return v;
-}
-#ifndef MPG_FWD_FN_DEFAULT
-#define MPG_FWD_FN_DEFAULT 8
+template <int D, int NQ = 0>
+int f1_launch(const MpgEdgeFwd* p, hipStream_t st) {
+#ifdef MPG_SINGLE_VARIANT   // (tools/ubench/fwd_bench.hip: one form, -DMPG_F1_LT=n)
+    return f1_launch_lt<D, NQ, MPG_F1_LT>(p, st);
+#else
+    return p->two_term == 1 ? f1_launch_lt<D, NQ, 1>(p, st) : f1_launch_lt<D, NQ, 0>(p, st);
 #endif
-inline bool fwd_fn_eight_waves() {
-    const int o = mpg_edge_waves_get(0);
-    if (o) return o != 4;
-    static const bool v = [] { const char* e = getenv("MPG_FWD_FN_WAVES"); return (e == nullptr ? MPG_FWD_FN_DEFAULT : atoi(e)) != 4; }();
-    return v;
 }
 
 // the fused forward + node network of one dropout mode / SIGN (edge_fwd_fn_*.hip: one translation unit each)
-template <int D, bool SIGN>
-int f1_launch_fn(const MpgEdgeFwd* p, const MpgChain* c, const MpgChain* c2, bool sl, hipStream_t st) {
+template <int D, bool SIGN, int LT>
+int f1_launch_fn_lt(const MpgEdgeFwd* p, const MpgChain* c, const MpgChain* c2, bool sl, hipStream_t st) {
     const int RB = (p->N + 31) / 32;
     dim3 grid(p->B * RB * p->SC), block(512);
     MpgChain none = {};   // nlayers = 0: no second chain
     if (c2 == nullptr) c2 = &none;
     if (sl) {
-        MPG_ENSURE_LDS((edge_fwd1_fn_kernel<D, SIGN, true>), F1_LDS_BYTES);
-        hipLaunchKernelGGL((edge_fwd1_fn_kernel<D, SIGN, true>), grid, block, F1_LDS_BYTES, st, *p, *c, *c2);
+        MPG_ENSURE_LDS((edge_fwd1_fn_kernel<D, SIGN, true, LT>), F1_LDS_BYTES);
+        hipLaunchKernelGGL((edge_fwd1_fn_kernel<D, SIGN, true, LT>), grid, block, F1_LDS_BYTES, st, *p, *c, *c2);
     } else {
-        MPG_ENSURE_LDS((edge_fwd1_fn_kernel<D, SIGN, false>), F1_LDS_BYTES);
-        hipLaunchKernelGGL((edge_fwd1_fn_kernel<D, SIGN, false>), grid, block, F1_LDS_BYTES, st, *p, *c, *c2);
+        MPG_ENSURE_LDS((edge_fwd1_fn_kernel<D, SIGN, false, LT>), F1_LDS_BYTES);
+        hipLaunchKernelGGL((edge_fwd1_fn_kernel<D, SIGN, false, LT>), grid, block, F1_LDS_BYTES, st, *p, *c, *c2);
     }
     return (int)hipGetLastError();
+}
+template <int D, bool SIGN>
+int f1_launch_fn(const MpgEdgeFwd* p, const MpgChain* c, const MpgChain* c2, bool sl, hipStream_t st) {
+    return p->two_term == 1 ? f1_launch_fn_lt<D, SIGN, 1>(p, c, c2, sl, st) : f1_launch_fn_lt<D, SIGN, 0>(p, c, c2, sl, st);
 }
 
 }  // namespace

@@ -13,7 +13,7 @@ MPG_FN_DECL(0, 0); MPG_FN_DECL(0, 1); MPG_FN_DECL(1, 0); MPG_FN_DECL(1, 1); MPG_
 extern "C" int mpg_edge_fwd_fn(const MpgEdgeFwd* p, const MpgChain* c, const MpgChain* c2, void* stream) {
     if (p->B <= 0 || p->N <= 0) return -1;
     if (!(p->alpha >= 0.f && p->alpha <= 1.f) || c->alpha != p->alpha) return -4;
-    if (!p->f16 || !c->f16) return -8;
+    if (!p->f16 || !c->f16 || (p->two_term != 0 && p->two_term != 1)) return -8;
     if (p->stageE2 != nullptr && (long long)p->B * ((p->N + 31) / 32) * p->N * 10240LL > 0x7fffffffLL) return -7;
     // what the epilogue form covers -- anything else: MPG_FN_NA, and the caller runs mpg_edge_fwd + mpg_chain
     // (sender chunks: only with arrival counters -- the last workgroup of a (jet, receiver block) adds the chunks up -- and

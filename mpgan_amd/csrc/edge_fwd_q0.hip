@@ -1,4 +1,4 @@
 // The forward edge kernel with edge scalars (MpgEdgeFwd.es: delta_r, row-tiled conditioning columns), dropout mode 0 (see edge.hip).
 #include "edge_fwd2_impl.h"
 
-int mpg_edge_fwd_q0(const MpgEdgeFwd* p, hipStream_t st) { return f2_launch<0, MPG_EDGE_SCALARS>(p, st); }
+int mpg_edge_fwd_q0(const MpgEdgeFwd* p, hipStream_t st) { return p->two_term ? -8 : f2_launch<0, MPG_EDGE_SCALARS>(p, st); }   // (three-term products only)

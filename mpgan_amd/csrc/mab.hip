@@ -1,5 +1,5 @@
 // One launch per multihead attention block of GAPT (MAB.forward, gapt/model.py:124-139), for sets of up to 32 tokens (and, further
-// down, mab_fwdN_kernel / mab_bwdN_kernel for 33 ... 160):
+// down, mab_fwdN_kernel / mab_bwdS_kernel for 33 ... 160):
 //
 //   q = x Wq' + bq ; k = y Wk' + bk ; v = y Wv' + bv            (nn.MultiheadAttention in-projection, packed [3E, E])
 //   P_h = softmax(q_h k_h' / sqrt(d) + key mask) ; o_h = P_h v_h (per head, d = 16)
@@ -1278,305 +1278,8 @@ __global__ __launch_bounds__(256) void mab_bwd_kernel(const MpgMab p) {
 #endif
 }
 
-// ---- LARGE SETS, backward (33 ... 160 tokens; the forward is mab_fwdN_kernel).  One workgroup per jet; wave w owns query tile w
-// (its rows of dout, z, x: the feed-forward half, dq, the query side of dx) AND key tile w (dk, dv, the key side of dx / dy).
-// Nothing is exchanged between the waves but (a) the rows of dza, which every wave writes for its own queries anyway (they are
-// the operand of Wo's weight gradient) and the key owners read back behind a barrier, and (b) two numbers per (query, head)
-// through LDS: c = max + log2(sum) of the scores and D = <dO, O> (= sum_keys P dP: the saved attention output makes the
-// row sum a dot product over the head's 16 features).  Every wave projects the other tiles' rows itself, from L2:
-//   keys in registers (own queries x every key tile, twice: the statistics, then dS):  dQ' = sum_kt K'[kt] dS[kt]
-//   queries in registers (own keys x every query tile):  dK' = sum_qt Q'[qt] dS^T[qt],  dV' = sum_qt dO'[qt] P^T[qt]
-// each sum in tile order inside one wave: deterministic.  Recomputing the projections costs ~2x the MFMAs of a kernel that
-// shared them, on waves that would otherwise idle: 5 waves per jet on a launch of 16 ... 64 jets.
-template <int NT, bool CROSS, bool LN>
-__global__ __launch_bounds__(320) void mab_bwdN_kernel(const MpgMab p) {
-    typedef f16x8 VF;
-    typedef bf16x8 VB;
-    constexpr int KS = 2 * NT, NH = 2 * NT, TOKMAX = 160;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5, lane16 = lane * 16;
-    const uint64_t sd = *(p.seed != nullptr ? p.seed : reinterpret_cast<const uint64_t*>(p.x));
-    const uint32_t seed_lo = p.seed != nullptr ? (uint32_t)sd : 0u, seed_hi = p.seed != nullptr ? (uint32_t)(sd >> 32) : 0u;
-    const float sa = p.ascale > 0.f ? p.ascale : 1.f, ws = p.wscale > 0.f ? p.wscale : 1.f;
-    const float zs = sa * ws, inv_zs = 1.f / zs, sc2 = 1.44269504088896341f / (sa * sa);   // (scores in the base-2 domain)
-    constexpr int nfIn = 3 * NT * KS, nfE = NT * KS, nfInT = NT * 3 * KS;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const sIn = smem;
-    char* const sF = sIn + 2 * nfIn * 1024;
-    char* const sInT = sF + 2 * nfE * 1024;
-    char* const sOT = sInT + 2 * nfInT * 1024;
-    char* const sFT = sOT + 2 * nfE * 1024;
-    float* const sBin = reinterpret_cast<float*>(sFT + 2 * nfE * 1024);  // biases: in_proj [3E] | ff [E]
-    float* const sBf = sBin + 96 * NT;
-    float* const sCQ = sBin + 128 * NT;   // [head][token]: the maximum of a query's scores (+inf: the query attends to nothing)
-    float* const sID = sCQ + NH * TOKMAX; // [head][token]: 1 / sum_keys 2^(score - maximum)
-    float* const sDD = sID + NH * TOKMAX; // [head][token]: sum_keys P dP
-    const long jet = blockIdx.x;
-    const int nqt = (p.L + 31) >> 5, nkt = (p.S + 31) >> 5;
-    const bool isq = w < nqt, isk = w < nkt;
-    const int tok = 32 * w + r;
-    const long xrow = jet * p.L + min(tok, p.L - 1), yrow = jet * p.S + min(tok, p.S - 1);
-    const bool xvalid = isq && tok < p.L, yvalid = isk && tok < p.S;
-    f32x16 dzf[NT], zt[NT], zat[LN ? NT : 1];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        dzf[t] = rows_to_tile(p.dout, p.lddout, xrow, t, h);
-        zt[t] = rows_to_tile(p.save_z, p.E, xrow, t, h);
-        if constexpr (LN) zat[t] = rows_to_tile(p.save_za, p.E, xrow, t, h);
-    }
-    mab_fill(sIn, p.Win, 2 * nfIn * 1024);
-    mab_fill(sF, p.Wf, 2 * nfE * 1024);
-    mab_fill(sInT, p.WinT, 2 * nfInT * 1024);
-    mab_fill(sOT, p.WoT, 2 * nfE * 1024);
-    mab_fill(sFT, p.WfT, 2 * nfE * 1024);
-    for (int i = threadIdx.x; i < 128 * NT; i += blockDim.x) sBin[i] = (i < 96 * NT ? p.bin[i] : p.bf[i - 96 * NT]) * zs;
-    __syncthreads();
-    const WImg rIn = sIn, rF = sF, rInT = sInT, rOT = sOT, rFT = sFT;
-    f32x16 dxa[NT], dya[NT];              // (dya: the key side -- dy of a cross block, the second half of dx of a self-attention block)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { dxa[t] = zero16(); dya[t] = zero16(); }
-
-    if (isq) {
-        // ---- the feed-forward half on the wave's own queries: du, dza (rows + fragments), dxa = dza
-        VB dzah[KS], dzal[KS];
-        mab_bwd_ff<NT, LN>(p, dzf, zt, zat, xvalid ? 1.f : 0.f, rF, rFT, sBf, xrow, xvalid, seed_lo, seed_hi, sa, inv_zs, h, lane16, dzah, dzal, dxa);
-        // ---- the query side of the own tile: q heads and dO heads as B fragments, D = <dO, O>
-        VF qh[NH], ql[NH];
-        VB dobh[NH], dobl[NH];
-        float Dq[NH];
-        {
-            VF xh[KS], xl[KS];
-            rows_to_frags<KS>(p.x, p.ldx, xrow, sa, h, xh, xl);
-            static_for<0, NT>([&](auto tc) {
-                MPG_CI(t, tc);
-                const f32x16 Qn = proj_n<KS>(rIn, nfIn, t, xh, xl, bias_regs(sBin, t, h), lane16);
-                const f32x16 dOn = proj_n<KS>(rOT, nfE, t, dzah, dzal, zero16(), lane16);
-                static_for<0, 2>([&](auto ac) {
-                    MPG_CI(a, ac);
-                    tile_frag(Qn, a, inv_zs * sa * 0.25f, qh[2 * t + a], ql[2 * t + a]);
-                    tile_frag(dOn, a, 1.f, dobh[2 * t + a], dobl[2 * t + a]);
-                });
-            });
-        }
-        // ---- pass 1 over the key tiles: the running maximum, sum and sum of P dP of every (query, head).  D = sum_keys P dP is
-        // taken from the very dP values pass 2 works with (same products, same order): dS = P (dP - D) subtracts two numbers that
-        // share the common part of V -- its bias --, and <dO, O>, which is the same sum in exact arithmetic, does not share the 2^-17
-        // of the bf16 pairs with them (measured: 9e-4 on the heads with the largest biases, 7e-6 this way)
-        // P is formed as 2^(s - max) / sum in both passes and by the key owners: with c = max + log2(sum) folded into ONE
-        // subtraction the rounding of c (|c| up to ~100) left sum_keys P at 1 +- 1e-5, and dS = P (dP - D) no longer summed to zero
-        // over the keys -- times the common part of K (its bias) that was 1e-3 of dQ on the heads with the largest biases
-        float cq[NH], iden[NH];
-        {
-            float mrun[NH], den[NH];
-#pragma unroll
-            for (int i = 0; i < NH; ++i) { mrun[i] = -INFINITY; den[i] = 0.f; Dq[i] = 0.f; }
-            for (int kt = 0; kt < nkt; ++kt) {
-                const long kr = jet * p.S + min(32 * kt + r, p.S - 1);
-                VF yh[KS], yl[KS];
-                rows_to_frags<KS>(p.y, p.ldy, kr, sa, h, yh, yl);
-                const f32x16 kneg = key_mask_tile(p.ignore, p.x, jet, p.S, h, kt);
-                static_for<0, NT>([&](auto tc) {
-                    MPG_CI(t, tc);
-                    const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(sBin, NT + t, h), lane16);
-                    const f32x16 Vn = proj_n<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_regs(sBin, 2 * NT + t, h), lane16);
-                    static_for<0, 2>([&](auto ac) {
-                        MPG_CI(a, ac);
-                        constexpr int hd = 2 * t + a;
-                        VF kh, kl;
-                        tile_frag(Kn, a, inv_zs * sa, kh, kl);
-                        VB vbh, vbl;
-                        tile_frag(Vn, a, inv_zs, vbh, vbl);
-                        f32x16 sx = mfma3(kh, kl, qh[hd], ql[hd], zero16());
-                        const f32x16 dP = mfma3(vbh, vbl, dobh[hd], dobl[hd], zero16());
-                        float mx = -INFINITY;
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) { sx[i] = sx[i] * sc2 + kneg[i]; mx = fmaxf(mx, sx[i]); }
-                        mx = fmaxf(mx, other_half(mx));
-                        const float mnew = fmaxf(mrun[hd], mx);
-                        const float msafe = mnew == -INFINITY ? 0.f : mnew;
-                        float part = 0.f, dpart = 0.f;
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const float e = __builtin_amdgcn_exp2f(sx[i] - msafe);
-                            part += e;
-                            dpart = fmaf(e, dP[i], dpart);
-                        }
-                        part += other_half(part);
-                        dpart += other_half(dpart);
-                        const float resc = __builtin_amdgcn_exp2f(mrun[hd] - msafe);
-                        den[hd] = den[hd] * resc + part;
-                        Dq[hd] = Dq[hd] * resc + dpart;
-                        mrun[hd] = mnew;
-                    });
-                });
-            }
-#pragma unroll
-            for (int i = 0; i < NH; ++i) {
-                const bool live = den[i] > 0.f && xvalid;
-                cq[i] = live ? mrun[i] : INFINITY;
-                iden[i] = live ? 1.f / den[i] : 0.f;
-                Dq[i] *= iden[i];
-                if (h == 0) { sCQ[i * TOKMAX + tok] = cq[i]; sID[i * TOKMAX + tok] = iden[i]; sDD[i * TOKMAX + tok] = Dq[i]; }
-            }
-        }
-        // ---- pass 2: dS tile by tile, dQ' accumulated over the key tiles
-        f32x16 dqa[NH];
-#pragma unroll
-        for (int i = 0; i < NH; ++i) dqa[i] = zero16();
-        for (int kt = 0; kt < nkt; ++kt) {
-            const long kr = jet * p.S + min(32 * kt + r, p.S - 1);
-            VF yh[KS], yl[KS];
-            rows_to_frags<KS>(p.y, p.ldy, kr, sa, h, yh, yl);
-            const f32x16 kneg = key_mask_tile(p.ignore, p.x, jet, p.S, h, kt);
-            static_for<0, NT>([&](auto tc) {
-                MPG_CI(t, tc);
-                const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(sBin, NT + t, h), lane16);
-                const f32x16 Vn = proj_n<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_regs(sBin, 2 * NT + t, h), lane16);
-                const f32x16 Kp = proj_t<KS>(rIn, nfIn, NT + t, yh, yl, bias_lanes(sBin, NT + t, r), lane16);
-                VB kph[2], kpl[2];
-                tile_frag(Kp, 0, inv_zs, kph[0], kpl[0]);
-                tile_frag(Kp, 1, inv_zs, kph[1], kpl[1]);
-                static_for<0, 2>([&](auto ac) {
-                    MPG_CI(a, ac);
-                    constexpr int hd = 2 * t + a;
-                    VF kh, kl;
-                    tile_frag(Kn, a, inv_zs * sa, kh, kl);
-                    VB vbh, vbl;
-                    tile_frag(Vn, a, inv_zs, vbh, vbl);
-                    f32x16 sx = mfma3(kh, kl, qh[hd], ql[hd], zero16());
-                    const f32x16 dP = mfma3(vbh, vbl, dobh[hd], dobl[hd], zero16());
-                    f32x16 dS;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float pr = __builtin_amdgcn_exp2f(sx[i] * sc2 + kneg[i] - cq[hd]) * iden[hd];
-                        dS[i] = pr * (dP[i] - Dq[hd]) * 0.25f;
-                    }
-                    VB dsh[2], dsl[2];
-                    tile_frag(dS, 0, 1.f, dsh[0], dsl[0]);
-                    tile_frag(dS, 1, 1.f, dsh[1], dsl[1]);
-                    dqa[hd] = mfma3(kph[0], kpl[0], dsh[0], dsl[0], dqa[hd]);
-                    dqa[hd] = mfma3(kph[1], kpl[1], dsh[1], dsl[1], dqa[hd]);
-                });
-            });
-        }
-        static_for<0, NT>([&](auto tc) {
-            MPG_CI(t, tc);
-            f32x16 dQt;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { dQt[j] = dqa[2 * t][j]; dQt[8 + j] = dqa[2 * t + 1][8 + j]; }
-            if (p.dq != nullptr && xvalid) tile_to_rows(p.dq, p.lddq, xrow, t, h, dQt, 1.f);
-            VB fh[2], fl[2];
-            tile_frag(dQt, 0, 1.f, fh[0], fl[0]); tile_frag(dQt, 1, 1.f, fh[1], fl[1]);
-            acc_wt<NT>(rInT, nfInT, 3 * KS, 2 * t, fh, fl, dxa, lane16);
-        });
-    }
-    __syncthreads();      // every query's c and D are in LDS, every row of dza in memory (workgroup scope)
-
-    if (isk) {
-        // ---- the wave's own keys against every query tile: dK', dV'
-        const float ign_r = (p.ignore != nullptr ? p.ignore + jet * p.S : p.x)[p.ignore != nullptr ? min(tok, p.S - 1) : 0];
-        const bool key_off = !yvalid || (p.ignore != nullptr && ign_r != 0.f);
-        f32x16* const dkv_acc = dya;
-        VF yh[KS], yl[KS];
-        rows_to_frags<KS>(p.y, p.ldy, yrow, sa, h, yh, yl);
-        static_for<0, NT>([&](auto tc) {
-            MPG_CI(t, tc);
-            VF kh[2], kl[2];
-            VB vbh[2], vbl[2];
-            {
-                const f32x16 Kn = proj_n<KS>(rIn, nfIn, NT + t, yh, yl, bias_regs(sBin, NT + t, h), lane16);
-                const f32x16 Vn = proj_n<KS>(rIn, nfIn, 2 * NT + t, yh, yl, bias_regs(sBin, 2 * NT + t, h), lane16);
-                static_for<0, 2>([&](auto ac) {
-                    MPG_CI(a, ac);
-                    tile_frag(Kn, a, inv_zs * sa, kh[a], kl[a]);
-                    tile_frag(Vn, a, inv_zs, vbh[a], vbl[a]);
-                });
-            }
-            f32x16 dka[2] = {zero16(), zero16()}, dva[2] = {zero16(), zero16()};
-            for (int qt = 0; qt < nqt; ++qt) {
-                const int qtok = 32 * qt + r;
-                const long qrow = jet * p.L + min(qtok, p.L - 1);
-                VF qh[2], ql[2];
-                VB qph[2], qpl[2], dobh[2], dobl[2], doph[2], dopl[2];
-                {
-                    VF xh[KS], xl[KS];
-                    rows_to_frags<KS>(p.x, p.ldx, qrow, sa, h, xh, xl);
-                    const f32x16 Qn = proj_n<KS>(rIn, nfIn, t, xh, xl, bias_regs(sBin, t, h), lane16);
-                    const f32x16 Qp = proj_t<KS>(rIn, nfIn, t, xh, xl, bias_lanes(sBin, t, r), lane16);
-                    static_for<0, 2>([&](auto sc) {
-                        MPG_CI(s2, sc);
-                        tile_frag(Qn, s2, inv_zs * sa * 0.25f, qh[s2], ql[s2]);
-                        tile_frag(Qp, s2, inv_zs, qph[s2], qpl[s2]);
-                    });
-                }
-                {
-                    VB dzh[KS], dzl[KS];
-                    rows_to_frags<KS>(p.dza, p.E, qrow, qtok < p.L ? 1.f : 0.f, h, dzh, dzl);
-                    const f32x16 dOn = proj_n<KS>(rOT, nfE, t, dzh, dzl, zero16(), lane16);
-                    const f32x16 dOp = proj_t<KS>(rOT, nfE, t, dzh, dzl, zero16(), lane16);
-                    static_for<0, 2>([&](auto sc) {
-                        MPG_CI(s2, sc);
-                        tile_frag(dOn, s2, 1.f, dobh[s2], dobl[s2]);
-                        tile_frag(dOp, s2, 1.f, doph[s2], dopl[s2]);
-                    });
-                }
-                static_for<0, 2>([&](auto ac) {
-                    MPG_CI(a, ac);
-                    constexpr int hd = 2 * t + a;
-                    const f32x16 sT = mfma3(qh[a], ql[a], kh[a], kl[a], zero16());      // queries in registers, keys on lanes
-                    const f32x16 dPT = mfma3(dobh[a], dobl[a], vbh[a], vbl[a], zero16());
-                    f32x16 pT, dST;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int i = 4 * g + e, qi = 32 * qt + 8 * g + 4 * h + e;   // the query this register belongs to
-                            const float c_q = sCQ[hd * TOKMAX + qi], id_q = sID[hd * TOKMAX + qi], D_q = sDD[hd * TOKMAX + qi];
-                            const float pr = key_off ? 0.f : __builtin_amdgcn_exp2f(sT[i] * sc2 - c_q) * id_q;
-                            pT[i] = pr;
-                            dST[i] = pr * (dPT[i] - D_q) * 0.25f;
-                        }
-                    VB pth[2], ptl[2], dsth[2], dstl[2];
-                    static_for<0, 2>([&](auto sc) {
-                        MPG_CI(s2, sc);
-                        tile_frag(pT, s2, 1.f, pth[s2], ptl[s2]);
-                        tile_frag(dST, s2, 1.f, dsth[s2], dstl[s2]);
-                    });
-                    dka[a] = mfma3(qph[0], qpl[0], dsth[0], dstl[0], dka[a]);
-                    dka[a] = mfma3(qph[1], qpl[1], dsth[1], dstl[1], dka[a]);
-                    dva[a] = mfma3(doph[0], dopl[0], pth[0], ptl[0], dva[a]);
-                    dva[a] = mfma3(doph[1], dopl[1], pth[1], ptl[1], dva[a]);
-                });
-            }
-            f32x16 dKt, dVt;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { dKt[j] = dka[0][j]; dKt[8 + j] = dka[1][8 + j]; dVt[j] = dva[0][j]; dVt[8 + j] = dva[1][8 + j]; }
-            if (p.dk != nullptr && yvalid) {
-                tile_to_rows(p.dk, p.lddkv, yrow, t, h, dKt, 1.f);
-                tile_to_rows(p.dv, p.lddkv, yrow, t, h, dVt, 1.f);
-            }
-            VB fh[2], fl[2];
-            tile_frag(dKt, 0, 1.f, fh[0], fl[0]); tile_frag(dKt, 1, 1.f, fh[1], fl[1]);
-            acc_wt<NT>(rInT, nfInT, 3 * KS, 2 * (NT + t), fh, fl, dkv_acc, lane16);
-            tile_frag(dVt, 0, 1.f, fh[0], fl[0]); tile_frag(dVt, 1, 1.f, fh[1], fl[1]);
-            acc_wt<NT>(rInT, nfInT, 3 * KS, 2 * (2 * NT + t), fh, fl, dkv_acc, lane16);
-        });
-    }
-    static_for<0, NT>([&](auto tc) {
-        MPG_CI(t, tc);
-        if constexpr (CROSS) {
-            if (p.dx != nullptr && xvalid) tile_to_rows(p.dx, p.lddx, xrow, t, h, dxa[t], 1.f);
-            if (p.dy != nullptr && yvalid) tile_to_rows(p.dy, p.lddy, yrow, t, h, dya[t], 1.f);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) dxa[t][i] += dya[t][i];
-            if (p.dx != nullptr && xvalid) tile_to_rows(p.dx, p.lddx, xrow, t, h, dxa[t], 1.f);
-        }
-    });
-}
-
-// ---- LARGE SETS, backward, the form that SHARES the projections (default; mab_bwdN_kernel above recomputes them and stays as the
-// A/B: MPG_MAB_BWDN=recompute).  Same ownership -- wave w: query tile w and key tile w --, but every projection is made ONCE, by its
+// ---- LARGE SETS, backward, the form that SHARES the projections (the recomputing form of round 5 -- every wave projecting the other
+// tiles' rows itself -- is tools/ubench/mab_bwdN_recompute.inc).  Same ownership -- wave w: query tile w and key tile w --, but every projection is made ONCE, by its
 // tile's owner, and handed round through LDS as the fragments the products take.  The room comes from the weight images: Wf / WfT
 // are dead behind the feed-forward half and WinT is not loaded until its turn, which leaves 80 KiB beside Win and WoT -- the key
 // side of ONE feature tile for all five tiles (12 KiB each) or the query side (16 KiB each).  Per feature tile t:
@@ -2213,21 +1916,16 @@ extern "C" int mpg_mab_bwd(const MpgMab* p, void* stream) {
     const bool cross = p->y != p->x;
     const int NT = p->E / 32;
     const int lds = 2 * 1024 * (2 * 3 * NT * 2 * NT + 3 * NT * 2 * NT) + 4 * 128 * NT;   // Win, WinT (3E x E) + Wf, WoT, WfT (E x E) + biases
-    if (p->L > 32 || p->S > 32 || getenv("MPG_MAB_BIG") != nullptr) {   // large sets: a workgroup per jet, a wave per tile of 32 tokens (mab_bwdN_kernel)
-        if (p->dza == nullptr && getenv("MPG_MAB_BWDN") != nullptr) return -5;   // (the recomputing form's key owners read the rows of dza back)
+    if (p->L > 32 || p->S > 32 || getenv("MPG_MAB_BIG") != nullptr) {   // large sets: a workgroup per jet, a wave per tile of 32 tokens (mab_bwdS_kernel)
         const bool ln = p->ln1_w != nullptr;
         if (ln && (p->ln2_w == nullptr || p->save_za == nullptr || !(p->ln_eps > 0.f) || (p->dn1 == nullptr) != (p->gn1 == nullptr) ||
                    (p->dn1 == nullptr) != (p->dn2 == nullptr) || (p->dn1 == nullptr) != (p->gn2 == nullptr))) return -6;
-        const int nw = (std::max(p->L, p->S) + 31) / 32, ldsN = lds + 4 * 3 * (2 * NT) * 160;
-        // (the sharing form: Win + WoT + the 80 KiB exchange area + biases + statistics)
+        const int nw = (std::max(p->L, p->S) + 31) / 32;
+        // Win + WoT + the 80 KiB exchange area + biases + statistics
         const int ldsS = 2 * 1024 * (3 * NT * 2 * NT + NT * 2 * NT) + 80 * 1024 + 4 * 128 * NT + 4 * 3 * (2 * NT) * 160;
-        const char* const form = getenv("MPG_MAB_BWDN");   // (read at every launch: a test holds the two forms against each other)
-        const bool recompute = form != nullptr && strcmp(form, "recompute") == 0;
         const dim3 grid(p->B), block(64 * nw);
-#define MPG_BWDN(NTv, CR, LNv) do { if (recompute) { MPG_ENSURE_LDS((mab_bwdN_kernel<NTv, CR, LNv>), ldsN); \
-        hipLaunchKernelGGL((mab_bwdN_kernel<NTv, CR, LNv>), grid, block, ldsN, st, *p); } else { \
-        MPG_ENSURE_LDS((mab_bwdS_kernel<NTv, CR, LNv>), ldsS); \
-        hipLaunchKernelGGL((mab_bwdS_kernel<NTv, CR, LNv>), grid, block, ldsS, st, *p); } } while (0)
+#define MPG_BWDN(NTv, CR, LNv) do { MPG_ENSURE_LDS((mab_bwdS_kernel<NTv, CR, LNv>), ldsS); \
+        hipLaunchKernelGGL((mab_bwdS_kernel<NTv, CR, LNv>), grid, block, ldsS, st, *p); } while (0)
         if (NT == 2) { if (cross) { if (ln) MPG_BWDN(2, true, true); else MPG_BWDN(2, true, false); }
                        else { if (ln) MPG_BWDN(2, false, true); else MPG_BWDN(2, false, false); } }
         else { if (cross) { if (ln) MPG_BWDN(1, true, true); else MPG_BWDN(1, true, false); }

@@ -45,6 +45,10 @@ OPTIONS = {
     "fn_chunks": os.environ.get("MPG_FN_CHUNKS", "1") != "0",
     # the per-workgroup reduction of mpg_edge_dw inside the layer's grouped split-K reduction launch (mpg_splitk_reduce_group_dw)
     "dw_reduce_grouped": os.environ.get("MPG_DW_REDUCE_GROUPED", "1") != "0",
+    # product form of the fused edge forward (MpgEdgeFwd.two_term): 0 = three 16-bit terms in every product; 1 = fe.net.2 on two terms
+    # (its input E2 as the one fp16 value that is parked for the backward anyway): -15 % per launch, pre-activations of fe.net.2 to
+    # ~1e-4 of their scale instead of ~5e-7.  MPG_FWD_TWO_TERM.
+    "fwd_two_term": int(os.environ.get("MPG_FWD_TWO_TERM", "0")),
 }
 NUM_CUS = 256
 # Forward products (they decide LeakyReLU signs) are split as fp16 hi/lo with the operand scales below (~2^-21 per
@@ -235,15 +239,6 @@ def drop_params(p: float):
     return thr, 256.0 / (256.0 - thr)
 
 
-def edge_waves(fwd: int = 0, bwd: int = 0):
-    """Launch form of the plain fused edge kernels from now on (``mpg_edge_waves``): 8 = eight waves per workgroup, 4 = four,
-    0 = the environment's choice (MPG_FWD_WAVES / MPG_BWD_WAVES, default 8).  Returns the previous (fwd, bwd) pair."""
-    L = _lib.lib()
-    prev = (L.mpg_edge_waves_get(0), L.mpg_edge_waves_get(1))
-    check(L.mpg_edge_waves(int(fwd), int(bwd)), "mpg_edge_waves")
-    return prev
-
-
 TICKET_SLOTS = 32
 
 
@@ -253,22 +248,30 @@ def _tickets(device, n: int) -> torch.Tensor:
     streams (the generator-ahead branch beside the D step's own generator call) must not count on the same words, and a
     captured launch keeps the region it was given.  A buffer that has been handed out is NEVER freed (a replayed hipGraph keeps
     raw pointers into it: a larger request gets a new buffer, the old one stays on ``DeviceState``), and a new buffer is zeroed
-    and the device synchronised before its first region goes out, whichever stream asks first -- inside a capture that cannot be
-    done, so a capture must find its buffer ready (``TrainStep.capture`` warms up eagerly)."""
+    and the device synchronised before its first region goes out, whichever stream asks first (``TrainStep`` reserves it for its
+    largest launch when it is built)."""
+    buf = reserve_tickets(device, n)
+    st = dev_state(device)
+    st._ticket_i = (st._ticket_i + 1) % TICKET_SLOTS
+    return buf[st._ticket_i]
+
+
+def reserve_tickets(device, n: int) -> torch.Tensor:
+    """Make sure the device's ticket buffer has regions of at least ``n`` words (``TrainStep`` calls this when it is built, for its
+    largest launch: a capture with ``warmup=0`` then finds the buffer ready)."""
     st = dev_state(device)
     buf = getattr(st, "_tickets", None)
     per = max(4096, n)
     if buf is None or buf.shape[1] < per:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("mpgan_amd: a capture needs a larger ticket buffer than any eager launch before it (warm the "
-                               "iteration up eagerly first: TrainStep.capture(warmup >= 1))")
         if buf is not None:
             st._tickets_retired = getattr(st, "_tickets_retired", []) + [buf]
         buf = torch.zeros((TICKET_SLOTS, per), dtype=torch.int32, device=device)
-        torch.cuda.synchronize(device)   # the zeros are there for every stream (the launches that use them run on several)
+        # the zeros are there for every stream (the launches that use them run on several).  Inside a capture -- a module captured
+        # without a TrainStep in front of it -- the fill is a node of that graph, ordered before the captured launches.
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize(device)
         st._tickets, st._ticket_i = buf, 0
-    st._ticket_i = (st._ticket_i + 1) % TICKET_SLOTS
-    return buf[st._ticket_i]
+    return buf
 
 
 def _stream():
@@ -743,6 +746,8 @@ class FusedMPLayerFn(torch.autograd.Function):
         e.seed, e.tag_base, e.thr, e.dscale = _p(seed_t), tag, thr, dscale
         e.skip_masked = int(OPTIONS["skip_masked"])
         e.f16 = int(f16)
+        # product form of the edge layers (MpgEdgeFwd.two_term; edge scalars ride on the three-term kernels only)
+        e.two_term = int(OPTIONS["fwd_two_term"]) if es is None else 0
         wq = None
         if es is not None:
             assert 0 < nq <= EDGE_SCALARS and tuple(es.shape) == (B, N, EDGE_SCALARS, N) and W1.shape[1] == 2 * F + nq

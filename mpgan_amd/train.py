@@ -373,6 +373,9 @@ class TrainStep:
                 self.state.auto_seed_key = key
             self.fG.seed_device = dev
             self.fG.seed_rank = rank
+            # arrival counters of the sender-chunked launches (ops._tickets): allocated and zeroed HERE, on the default stream, for
+            # the step's largest launch (the D step's 2B jets) -- never inside a capture, never first on a side stream
+            ops.reserve_tickets(dev, 2 * batch_size * ((num_particles + 31) // 32))
         self.data = torch.zeros(batch_size, num_particles, 4, device=dev)
         self.labels = torch.zeros(batch_size, 1, device=dev)
         self._real = torch.cat([torch.ones(batch_size, device=dev), torch.zeros(batch_size, device=dev)])
