@@ -383,6 +383,51 @@ def test_train_step_other_losses_vs_oracle(loss, B, head):
     assert abs(float(ts.D_loss) - dl) < 1e-4 * max(abs(dl), 1e-3) and abs(float(ts.G_loss) - gl) < 1e-4 * max(abs(gl), 1e-3)
 
 
+def test_train_step_top_jet_settings_vs_oracle():
+    """BASELINE config 3's settings on one rank's shard shapes (``--jets t``: lr_disc 6e-5, lr_gen 2e-5, setup_training.py:852-866;
+    top jets nearly fill the 30 slots -- ``data.synthetic_jets(dist="top")``), B = 32: one whole iteration with BOTH optimizers
+    stepping at those rates -- losses, D's and G's first-iteration gradients against the oracle (G's behind D's real update), and the
+    size of the steps themselves (RMSprop's first step is 10 lr per entry whatever the gradient)."""
+    from oracle import train_ref as T
+    from mpgan_amd import train
+    from mpgan_amd.data import synthetic_jets
+    B, N = 32, 30
+    lr_d, lr_g = train.LR["t"]
+    assert (lr_d, lr_g) == (6e-5, 2e-5)
+    G, D = train.default_mpgan(N, disc_dropout=0.0)
+    sdG = T.init_state_dict(T.mpgan_param_shapes(True), 41, torch.float64)
+    sdD = T.init_state_dict(T.mpgan_param_shapes(False), 42, torch.float64)
+    G.load_state_dict({k: v.float() for k, v in sdG.items()})
+    D.load_state_dict({k: v.float() for k, v in sdD.items()})
+    w0 = {"D": D.state_dict()["mp_layers.1.fe.net.2.weight"].clone(), "G": G.state_dict()["mp_layers.1.fe.net.2.weight"].clone()}
+    data, labels = synthetic_jets(B, N, seed=31, dist="top")
+    assert float((data[..., 3] > 0).float().mean()) > 0.9          # (top jets: nearly every slot holds a particle)
+    gen = torch.Generator().manual_seed(17)
+    nD, nG = torch.randn(B, N, 32, generator=gen) * 0.2, torch.randn(B, N, 32, generator=gen) * 0.2
+    ts = train.TrainStep(G, D, B, N, use_graphs=False, lr_disc=lr_d, lr_gen=lr_g)
+    ts.set_batch(data.cuda(), labels.cuda())
+    ts.fixed_noise = (nD.cuda(), nG.cuda())
+    ts._seg_D()
+    gradD = {k: p.grad.detach().double().cpu().numpy().copy() for k, p in D.named_parameters()}
+    ts._seg_G()
+    gradG = {k: p.grad.detach().double().cpu().numpy().copy() for k, p in G.named_parameters()}
+    ts._seg_end()
+    torch.cuda.synchronize()
+    c32 = lambda sd: {k: v.float() for k, v in sd.items()}
+    c64 = lambda sd: {k: v.clone() for k, v in sd.items()}
+    _, _, cD, cG = T.train_iteration("mpgan", c32(sdD), c32(sdG), {}, {}, data.float(), labels.float(), nD.float(), nG.float(),
+                                     lr_d, lr_g, return_grads=True)
+    dl, gl, gD, gG = T.train_iteration("mpgan", c64(sdD), c64(sdG), {}, {}, data.double(), labels.double(), nD.double(), nG.double(),
+                                       lr_d, lr_g, return_grads=True)
+    num = lambda d: {k: v.detach().double().numpy() for k, v in d.items()}
+    assert abs(float(ts.D_loss) - dl) < 1e-4 * abs(dl) and abs(float(ts.G_loss) - gl) < 1e-4 * abs(gl)
+    assert_grads(gradD, num(gD), 1e-3, control=num(cD), what=("top", B, "D"))
+    assert_grads(gradG, num(gG), 1e-3, control=num(cG), what=("top", B, "G"))
+    for net, mod, lr in (("D", D, lr_d), ("G", G, lr_g)):
+        step = (mod.state_dict()["mp_layers.1.fe.net.2.weight"] - w0[net]).abs()
+        assert abs(float(step.max()) - 10.0 * lr) < 1e-2 * 10.0 * lr, (net, float(step.max()), lr)
+
+
 @pytest.mark.parametrize("opt", ["rmsprop", "adam", "adadelta"])
 def test_fused_optimizers_vs_torch(opt):
     """mpg_rmsprop / mpg_adam / mpg_adadelta against torch.optim on the same gradients, five steps, incl. gscale."""

@@ -222,3 +222,22 @@ def test_spectral_norm_two_forwards_before_one_backward():
     v = torch.mv(w.t(), u); v = v / (v.norm() + 1e-12)
     u = torch.mv(w, v); u = u / (u.norm() + 1e-12)
     assert torch.allclose(sn2.weight(), w / (u.dot(w.mv(v)) + 1e-12), atol=1e-7)
+
+
+def test_synthetic_jet_laws_and_learning_rates_per_jet_type():
+    """``bench.py --jets {g,t,q}``: the learning rates of setup_training.py:848-872 and the synthetic multiplicity laws standing in for
+    the three JetNet jet types (top jets nearly fill their 30 slots, quark jets are lighter than gluon jets)."""
+    import bench
+    from mpgan_amd import train
+    from mpgan_amd.data import synthetic_jets
+    assert train.LR == {"g": (3e-5, 1e-5), "t": (6e-5, 2e-5), "q": (1.5e-5, 0.5e-5)}
+    assert bench.JET_LAW == {"g": "gluon", "t": "top", "q": "quark"}
+    mean = {}
+    for law in ("gluon", "top", "quark", "uniform"):
+        data, labels = synthetic_jets(512, 30, seed=3, dist=law)
+        n = (data[..., 3] > 0).sum(1)
+        assert int(n.min()) >= 1 and int(n.max()) <= 30
+        assert torch.equal((labels[:, 0] * 30).round().long(), n)          # labels = multiplicity / N
+        assert bool(((data[..., 3] > 0)[:, :-1] >= (data[..., 3] > 0)[:, 1:]).all())   # real particles first
+        mean[law] = float(n.float().mean())
+    assert mean["top"] > 27 > mean["gluon"] > mean["quark"] > mean["uniform"]
