@@ -425,7 +425,8 @@ def test_train_step_top_jet_settings_vs_oracle():
     assert_grads(gradG, num(gG), 1e-3, control=num(cG), what=("top", B, "G"))
     for net, mod, lr in (("D", D, lr_d), ("G", G, lr_g)):
         step = (mod.state_dict()["mp_layers.1.fe.net.2.weight"] - w0[net]).abs()
-        assert abs(float(step.max()) - 10.0 * lr) < 1e-2 * 10.0 * lr, (net, float(step.max()), lr)
+        # (lr g / (sqrt(0.01 g^2) + 1e-8): 10 lr from below, by the few per cent the epsilon takes where the gradients are ~1e-6)
+        assert 0.9 * 10.0 * lr < float(step.max()) <= 10.0 * lr * (1 + 1e-3), (net, float(step.max()), lr)
 
 
 @pytest.mark.parametrize("opt", ["rmsprop", "adam", "adadelta"])
