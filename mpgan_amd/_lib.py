@@ -257,9 +257,21 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+DIGEST_FILE = os.path.join(LIBDIR, "libmpgan_amd.source_digest")
+
+
 def _stale():
+    """Is the library older than what it is compiled from?  By CONTENT where the build left its sources' digest beside the library
+    (a checkout or a copy that resets modification times must not make a fresh library look stale inside a multi-rank job, where
+    nothing may be compiled); by modification time otherwise."""
     if not os.path.isfile(LIBPATH):
         return True
+    if os.path.isfile(DIGEST_FILE):
+        try:
+            with open(DIGEST_FILE) as f:
+                return f.read().strip() != source_digest()
+        except OSError:
+            pass
     t = os.path.getmtime(LIBPATH)
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
     return any(os.path.getmtime(d) > t for d in deps)
@@ -341,12 +353,26 @@ def _under_profiler() -> bool:
     return any(t in pre for t in ("rocprof", "roctracer", "rocp_")) or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
 
 
+def _note_digest():
+    """Leave the sources' digest beside a library that is fresh by modification time and has none yet (a library built before
+    the digest existed): from then on staleness is judged by content."""
+    if not os.path.isfile(DIGEST_FILE):
+        try:
+            tmp = DIGEST_FILE + ".%d.tmp" % os.getpid()
+            with open(tmp, "w") as f:
+                f.write(source_digest() + "\n")
+            os.replace(tmp, DIGEST_FILE)
+        except OSError:   # (a read-only tree: the modification-time rule stays)
+            pass
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into mpgan_amd/lib/libmpgan_amd.so (in-tree).
 
     Safe against concurrent callers (ranks of one torchrun job, parallel test workers): an exclusive file lock is
     held for the whole build, objects and the library are written under temporary names and moved into place."""
     if not force and not _stale():
+        _note_digest()
         return LIBPATH
     import fcntl
     import tempfile
@@ -390,6 +416,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
             tmplib = os.path.join(tmpdir, "libmpgan_amd.so")
             subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmplib] + objs, check=True, env=env)
             os.replace(tmplib, LIBPATH)
+            with open(os.path.join(tmpdir, "digest"), "w") as f:
+                f.write(source_digest() + "\n")
+            os.replace(os.path.join(tmpdir, "digest"), DIGEST_FILE)
         finally:
             import shutil
             shutil.rmtree(tmpdir, ignore_errors=True)
