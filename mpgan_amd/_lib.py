@@ -13,7 +13,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIBDIR = os.path.join(_HERE, "lib")
+# (MPG_LIBDIR: another directory for the built library and its object cache -- two builds of the kernels, e.g. under different
+# MPG_HIPCC_FLAGS, side by side for same-box A/B runs; the product loads mpgan_amd/lib)
+LIBDIR = os.environ.get("MPG_LIBDIR") or os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libmpgan_amd.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 

@@ -103,7 +103,10 @@ MPG_DEV void c2_body(const MpgChain& p, const int m0, const int nrows, char* fb0
     // whole sequence of k-steps -- item g = (layer, k-step) sits in slot g % 8; the ring starts with items 0..7 and item g + 8 is
     // requested into the slot item g has just left (a whole 16-k-step tile, 128 registers, did not fit beside the epilogue state:
     // 72 registers spilled, and every scratch access drained the weight prefetch)
-    constexpr int RING = NSL == 1 ? 8 : 16;
+#ifndef MPG_C2_RING
+#define MPG_C2_RING 8   // (experiments: -DMPG_C2_RING=n; beyond 8 the eight-wave edge kernels that carry the chain as their epilogue spill)
+#endif
+    constexpr int RING = NSL == 1 ? MPG_C2_RING : 16;
     V wb[NSL][RING][2];
     constexpr int KSA[3] = {KS0, KS1, KS2};
     constexpr int OFF1 = KS0, OFF2 = KS0 + KS1, NITEM = KS0 + KS1 + KS2;
