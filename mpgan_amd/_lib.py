@@ -436,7 +436,8 @@ def lib():
     here -- run ``python __graft_entry__.py`` (build only) first."""
     global _lib
     if _lib is None:
-        if _stale():
+        # (MPG_LIB_STALE_OK=1 beside MPG_LIBDIR: load that directory's library as it is -- an A/B against a build of OLDER sources)
+        if _stale() and not (os.environ.get("MPG_LIB_STALE_OK") == "1" and os.environ.get("MPG_LIBDIR") and os.path.isfile(LIBPATH)):
             can_build = os.path.isfile(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) and os.path.isdir(CSRC)
             guarded = int(os.environ.get("WORLD_SIZE", "1")) > 1 or _under_profiler()
             if can_build and not guarded:

@@ -129,11 +129,13 @@ def test_pack_many_equals_pack_weights():
 
 
 def test_wgrad_group_and_accumulate():
-    """Six dW = dY^T X (+ bias sums) as one grouped launch; a second flush with accumulate doubles the result."""
+    """Eleven dW = dY^T X (+ bias sums: every even job) as one grouped launch; a second flush with accumulate doubles the result."""
     from mpgan_amd import ops
     rs = np.random.RandomState(21)
     M = 7680
-    shapes = [(32, 256), (256, 256), (256, 192), (256, 32), (96, 32), (96, 3)]
+    # (the node network's own shapes with and without the bias column -- folded into tile column 0 at 256 inputs, inside the last
+    # tile at 224 / 192 --, ragged tiles (160 x 130), a single column (96 x 3))
+    shapes = [(32, 256), (256, 256), (256, 192), (256, 32), (96, 32), (96, 3), (256, 224), (160, 130), (256, 256), (128, 128), (160, 130)]
     dys = [_t(rs, M, n) for n, _ in shapes]
     xs = [_t(rs, M, k) for _, k in shapes]
     outs = [torch.zeros(n, k + 5, device=_dev()) for n, k in shapes]
