@@ -271,8 +271,9 @@ int mpg_edge_bwd_fn(const MpgEdgeBwd* p, const MpgChain* cdx, const MpgChain* cn
 /* mpg_edge_dw: weight gradients of fe.net.1 / fe.net.2 (and their biases) from the fragments parked by
  * mpg_edge_bwd:  dW3 = dscale * sum_e dZ3 E2^T [192,160], dW2 = dscale * sum_e dZ2 E1^T [160,96],
  * db3 = sum_e dZ3 [192], db2 = sum_e dZ2 [160]; E1 and dZ3 are rebuilt from a, c, dagg and the sign words.
- * Two fp16 terms per product: the rebuilt operand as hi + lo, the parked one as the fp16 value it was parked as,
- * everything in ONE gradient unit 2^-min(gexp) for the launch (the parked dZ2 is rescaled exactly).
+ * ONE fp16 term per product: every operand a single fp16 value -- the parked ones as they were parked, the rebuilt ones rounded
+ * once, in per-block dithered units so that the roundings are independent from edge to edge and average out over the ~1e5 edges a
+ * weight gradient sums (csrc/edge_dw.hip) --, everything in ONE gradient unit 2^-min(gexp) for the launch.
  * `part` is scratch of nwg * 46,432 floats (per-workgroup partial sums); the nwg workgroups share the B*RB*N blocks
  * in runs of R consecutive senders (R = the largest divisor of N up to 6), and each may take at most 64 blocks, i.e.
  * R * ceil(B*RB*N / R / nwg) <= 64 (error -5 otherwise). */
