@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the HIP runtime says why it aborts (a faulting kernel's queue error, an invalid launch) only at this log level; errors only
+os.environ.setdefault("AMD_LOG_LEVEL", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
