@@ -300,14 +300,17 @@ def run_workload(torch, dist, model, B, N, steps, warmup, dev, rank, world, pg, 
     log(f"timed {steps} steps in {dt:.3f} s -> {jets_per_s:.0f} jets/s")
     d_loss, g_loss = float(ts.D_loss), float(ts.G_loss)
 
-    headline = model == "mpgan" and N == 30 and B == 256 and jets == "g" and not gp and loss == "ls"
-    variant = ("" if jets == "g" else f" {JET_NAME[jets]} jets") + (f" loss={loss}" if loss != "ls" else "") + (f" gp={gp:g}" if gp else "")
+    two_term = bool(ops.OPTIONS["fwd_two_term"]) and model == "mpgan"   # (MPG_FWD_TWO_TERM=1: never the headline's arithmetic)
+    headline = model == "mpgan" and N == 30 and B == 256 and jets == "g" and not gp and loss == "ls" and not two_term
+    variant = (("" if jets == "g" else f" {JET_NAME[jets]} jets") + (f" loss={loss}" if loss != "ls" else "") + (f" gp={gp:g}" if gp else "")
+               + (" fe.net.2 on two 16-bit terms" if two_term else ""))
     out = {
         "metric": "jets/sec (G+D step) MPGAN gluon N=30 bs=256 @1/2/4/8 MI355X" if headline
                   else f"jets/sec (G+D step) {model} N={N} bs={B}{variant}",
         "value": jets_per_s, "unit": "jets/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "split-16-bit MFMA, fp32 accumulate, fp32 in/out: f16 hi/lo x3 terms (forward), f16 x2 / x1 "
+        "dtype": ("split-16-bit MFMA, fp32 accumulate, fp32 in/out: f16 hi/lo x3 terms (forward; fe.net.2 x2: MPG_FWD_TWO_TERM), f16 x2 / x1 "
+                  if two_term else "split-16-bit MFMA, fp32 accumulate, fp32 in/out: f16 hi/lo x3 terms (forward), f16 x2 / x1 ") +
                  "terms in per-sender dithered units (edge backward: data / weight gradients), bf16 hi/lo x3 (node network "
                  "gradients)" if model == "mpgan" else
                  "split-16-bit MFMA, fp32 accumulate, fp32 in/out: f16 hi/lo x3 terms (forward), bf16 hi/lo x3 (gradients)",
@@ -315,7 +318,7 @@ def run_workload(torch, dist, model, B, N, steps, warmup, dev, rank, world, pg, 
         "config": {"workload": f"{model.upper()} {JET_NAME[jets]}-like jets (--jets {jets}: lr_disc {lr_d:g}, lr_gen {lr_g:g}), N={N} particles, "
                                f"B={B} per GPU, one train_D+train_G iteration ({LOSS_NAME[loss]}"
                                + (f" + gradient penalty {gp:g} on the double-backward route" if gp else "") + ", RMSprop, D dropout 0.5)",
-                   "jets": jets, "lr_disc": lr_d, "lr_gen": lr_g, "loss": loss, "gp_lambda": gp,
+                   "jets": jets, "lr_disc": lr_d, "lr_gen": lr_g, "loss": loss, "gp_lambda": gp, "fwd_two_term": two_term,
                    "global_batch": world * B, "particles": N, "multiplicity": mult,
                    "mean_multiplicity": valid_frac * N, "parallelism": f"dp{world}", "hip_graphs": graphs,
                    **({"rehearsal": "all ranks share cuda:0, gloo exchange (MPGAN_BENCH_SHARE_GPU)"} if share else {})},
